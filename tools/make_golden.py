@@ -1,0 +1,297 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (CPU, fp32).
+
+Runs only in the build container (it imports /root/reference, which does not
+exist on the GPU box and must never travel).  Only data -- seeded inputs and
+the reference's outputs -- is written; no reference source is copied.
+
+    cd /root/reference && python3 /root/repo/tools/make_golden.py [--only NAME]
+
+Import recipe: SURVEY.md Appendix C (stub the seven missing third-party
+imports, neutralise the hard-coded .cuda() calls).
+"""
+import argparse
+import math
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("KD_REFERENCE", "/root/reference")
+os.chdir(REF)
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+import numpy as np
+import torch
+from torch import nn
+
+
+class _Any:
+    def __init__(s, *a, **k): pass
+    def __call__(s, *a, **k): return s
+    def __getattr__(s, n): return _Any()
+    def __setitem__(s, k, v): pass
+    def __getitem__(s, k): return _Any()
+    def __str__(s): return "<stub>"
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    m.__path__ = []
+    sys.modules[name] = m
+    return m
+
+
+_stub("beautifultable", BeautifulTable=_Any)
+tv = _stub("torchvision")
+tv.transforms = _stub("torchvision.transforms", ToPILImage=_Any, Compose=_Any, ToTensor=_Any, Normalize=_Any, Lambda=_Any)
+tv.utils = _stub("torchvision.utils", make_grid=_Any())
+tv.datasets = _stub("torchvision.datasets", CIFAR10=_Any, CIFAR100=_Any)
+_stub("torchvision.datasets.utils", extract_archive=_Any(), verify_str_arg=_Any(), iterable_to_str=_Any())
+_stub("cv2"); _stub("tensorboardX", SummaryWriter=_Any); _stub("torchsummary", summary=_Any())
+_stub("skimage"); _stub("skimage.filters", gaussian=_Any()); _stub("skimage.restoration", denoise_bilateral=_Any())
+_stub("torch._six", inf=math.inf, string_classes=(str,))
+nn.Module.cuda = lambda self, *a, **k: self
+torch.cuda.empty_cache = lambda: None
+
+import warnings
+warnings.filterwarnings("ignore")
+
+import losses as ref_losses                                            # noqa: E402
+import models as ref_models                                            # noqa: E402
+from models.students import DepthwiseStudent                           # noqa: E402
+from models.students.transform_blocks import DepthwiseSeparableBlock   # noqa: E402
+from models.encoders.wider_resnet import IdentityResidualBlock, bnrelu  # noqa: E402
+from models.deeplabv3.deeplabv3 import _AtrousSpatialPyramidPoolingModule, DeepWV3Plus  # noqa: E402
+from utils.optim.radam import RAdam                                    # noqa: E402
+
+from _seeded import seeded_fill_, seeded_input, summarize              # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+torch.set_num_threads(8)
+
+
+def save(name, **arrs):
+    flat = {}
+    for k, v in arrs.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                flat[f"{k}.{kk}"] = np.asarray(vv)
+        elif torch.is_tensor(v):
+            flat[k] = v.detach().cpu().numpy()
+        else:
+            flat[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **flat)
+    print(f"wrote {path}  ({os.path.getsize(path)/1024:.1f} KiB)")
+
+
+# ----------------------------------------------------------------------------
+def g_losses():
+    """losses/KLDiv.py, MSELoss.py, WeightedHintMSELoss.py, CrossEntropy.py: (inputs, targets) -> (loss, grad)."""
+    out = {}
+
+    def run(tag, crit, s, t, *extra):
+        s = s.clone().requires_grad_(True)
+        loss = crit(s, t, *extra)
+        loss.backward()
+        out[f"{tag}.s"] = s.detach().numpy()
+        out[f"{tag}.t"] = t.numpy()
+        out[f"{tag}.loss"] = np.float64(loss.item())
+        out[f"{tag}.grad"] = s.grad.numpy()
+
+    s4, t4 = seeded_input("loss.s4", (2, 19, 8, 16)), seeded_input("loss.t4", (2, 19, 8, 16))
+    run("kld_T1", ref_losses.KLDivergenceLoss(1), s4, t4)
+    run("kld_T5", ref_losses.KLDivergenceLoss(5), s4 * 3, t4 * 3)
+    s2, t2 = seeded_input("loss.s2", (32, 10), 2.0), seeded_input("loss.t2", (32, 10), 2.0)
+    run("kld2d_T5", ref_losses.KLDivergenceLoss(5), s2, t2)
+    h, g = seeded_input("loss.h", (2, 24, 8, 16)), seeded_input("loss.g", (2, 24, 8, 16))
+    run("mse_1000", ref_losses.MSELoss(num_classes=1000), h, g)
+    run("mse_1", ref_losses.MSELoss(num_classes=1), h, g)
+    wc = torch.rand(24, generator=torch.Generator().manual_seed(7))
+    wnc = torch.rand(2, 24, generator=torch.Generator().manual_seed(8))
+    run("whmse_c", ref_losses.WeightedHintMSELoss(), h, g, wc)
+    out["whmse_c.w"] = wc.numpy()
+    run("whmse_nc", ref_losses.WeightedHintMSELoss(), h, g, wnc)
+    out["whmse_nc.w"] = wnc.numpy()
+    # CrossEntropyLoss2d (logged metric), with an ignore band
+    tgt = torch.randint(0, 19, (2, 8, 16), generator=torch.Generator().manual_seed(9))
+    tgt[:, :2] = 255
+    ce = ref_losses.CrossEntropyLoss2d(ignore_index=255)(s4, tgt)
+    out["ce.x"] = s4.numpy(); out["ce.target"] = tgt.numpy(); out["ce.loss"] = np.float64(ce.item())
+    # the SURVEY 8c anchors (torch.manual_seed(0); randn twice)
+    torch.manual_seed(0)
+    x, t = torch.randn(2, 19, 8, 16), torch.randn(2, 19, 8, 16)
+    out["anchor.kld_T1"] = np.float64(ref_losses.KLDivergenceLoss(1)(x, t).item())
+    out["anchor.kld_T5"] = np.float64(ref_losses.KLDivergenceLoss(5)(x, t).item())
+    out["anchor.mse_1000"] = np.float64(ref_losses.MSELoss(num_classes=1000)(x, t).item())
+    out["anchor.x"] = x.numpy(); out["anchor.t"] = t.numpy()
+    save("losses", **out)
+
+
+def g_dwsep():
+    """models/students/transform_blocks/depthwise_separable_conv.py: fwd + all grads."""
+    out = {}
+    for tag, (C, Co, k, p, d, H, W) in {
+        "k9d5": (16, 24, 9, 20, 5, 24, 32),
+        "k3d1": (16, 16, 3, 1, 1, 8, 8),
+    }.items():
+        blk = DepthwiseSeparableBlock(C, Co, k, p, d, groups=C, bias=False)
+        seeded_fill_(blk, f"dwsep.{tag}.")
+        x = seeded_input(f"dwsep.{tag}.x", (2, C, H, W)).requires_grad_(True)
+        y = blk(x)
+        gy = seeded_input(f"dwsep.{tag}.gy", tuple(y.shape))
+        y.backward(gy)
+        out[f"{tag}.cfg"] = np.array([C, Co, k, p, d, H, W])
+        out[f"{tag}.x"] = x.detach().numpy()
+        out[f"{tag}.w_dw"] = blk.separable_conv.weight.detach().numpy()
+        out[f"{tag}.w_pw"] = blk.pointwise_conv.weight.detach().numpy()
+        out[f"{tag}.y"] = y.detach().numpy()
+        out[f"{tag}.gy"] = gy.numpy()
+        out[f"{tag}.gx"] = x.grad.numpy()
+        out[f"{tag}.gw_dw"] = blk.separable_conv.weight.grad.numpy()
+        out[f"{tag}.gw_pw"] = blk.pointwise_conv.weight.grad.numpy()
+    save("dwsep", **out)
+
+
+def g_resblock():
+    """models/encoders/wider_resnet.py:119-182 IdentityResidualBlock in eval mode: fwd + input grad."""
+    out = {}
+    cases = {
+        "id2_d1": dict(cin=16, ch=(16, 16), stride=1, dil=1),           # identity shortcut, 2-conv
+        "proj2_s2": dict(cin=8, ch=(16, 16), stride=2, dil=1),          # proj + stride 2 (mod4.block1 shape class)
+        "proj2_d2": dict(cin=16, ch=(8, 32), stride=1, dil=2),          # mod5 shape class
+        "bott_d4": dict(cin=16, ch=(8, 16, 32), stride=1, dil=4),       # mod6/mod7 bottleneck
+    }
+    for tag, c in cases.items():
+        blk = IdentityResidualBlock(c["cin"], c["ch"], stride=c["stride"], dilation=c["dil"], norm_act=bnrelu)
+        seeded_fill_(blk, f"resblock.{tag}.")
+        blk.eval()
+        x = seeded_input(f"resblock.{tag}.x", (2, c["cin"], 12, 16)).requires_grad_(True)
+        y = blk(x)
+        gy = seeded_input(f"resblock.{tag}.gy", tuple(y.shape))
+        y.backward(gy)
+        out[f"{tag}.cfg"] = np.array([c["cin"], c["stride"], c["dil"], len(c["ch"])] + list(c["ch"]))
+        out[f"{tag}.x"] = x.detach().numpy(); out[f"{tag}.y"] = y.detach().numpy()
+        out[f"{tag}.gy"] = gy.numpy(); out[f"{tag}.gx"] = x.grad.numpy()
+    save("resblock", **out)
+
+
+def g_aspp():
+    """models/deeplabv3/deeplabv3.py:21-75 ASPP (output_stride 8 -> rates 12/24/36), eval mode."""
+    aspp = _AtrousSpatialPyramidPoolingModule(32, 16, output_stride=8)
+    seeded_fill_(aspp, "aspp.")
+    aspp.eval()
+    x = seeded_input("aspp.x", (2, 32, 16, 24))
+    with torch.no_grad():
+        y = aspp(x)
+    save("aspp", x=x.numpy(), y=y.numpy())
+
+
+def g_ops():
+    """Functional ops the trunk uses: max-pool 3x3/s2/p1, bilinear align_corners upsample, global avg-pool."""
+    x = seeded_input("ops.x", (2, 6, 11, 14))
+    mp = nn.MaxPool2d(3, stride=2, padding=1)(x)
+    up = nn.functional.interpolate(x, size=(29, 40), mode="bilinear", align_corners=True)
+    up2 = nn.functional.interpolate(x, size=(22, 28), mode="bilinear", align_corners=True)
+    gp = nn.AdaptiveAvgPool2d(1)(x)
+    # conv variants incl. stride 2 and dilation, plus grads
+    w = seeded_input("ops.w", (8, 6, 3, 3)) * 0.2
+    outs = {}
+    for tag, (s, p, d) in {"s1d1": (1, 1, 1), "s2d1": (2, 1, 1), "s1d4": (1, 4, 4)}.items():
+        xi = x.clone().requires_grad_(True); wi = w.clone().requires_grad_(True)
+        y = nn.functional.conv2d(xi, wi, None, s, p, d)
+        gy = seeded_input(f"ops.gy.{tag}", tuple(y.shape))
+        y.backward(gy)
+        outs[f"conv_{tag}.y"] = y.detach().numpy(); outs[f"conv_{tag}.gy"] = gy.numpy()
+        outs[f"conv_{tag}.gx"] = xi.grad.numpy(); outs[f"conv_{tag}.gw"] = wi.grad.numpy()
+    # train-mode BN (+ReLU) fwd/bwd: the ClassificationTrainer path (bn.training == True)
+    bn = nn.BatchNorm2d(6); seeded_fill_(bn, "ops.bn."); bn.train()
+    xb = x.clone().requires_grad_(True)
+    yb = torch.relu(bn(xb))
+    gyb = seeded_input("ops.gyb", tuple(yb.shape))
+    yb.backward(gyb)
+    save("ops", x=x.numpy(), w=w.numpy(), maxpool=mp.numpy(), up=up.numpy(), up2=up2.numpy(), gap=gp.numpy(),
+         bn_gamma=bn.weight.detach().numpy(), bn_beta=bn.bias.detach().numpy(), bn_y=yb.detach().numpy(),
+         bn_gy=gyb.numpy(), bn_gx=xb.grad.numpy(), bn_ggamma=bn.weight.grad.numpy(), bn_gbeta=bn.bias.grad.numpy(),
+         **outs)
+
+
+def g_radam():
+    """utils/optim/radam.py:30-98: 8 steps (crosses the N_sma>=5 switch at step 6) on one tensor."""
+    p = seeded_input("radam.p", (64,)).requires_grad_(True)
+    opt = RAdam([p], lr=0.005)
+    ps, gs = [p.detach().clone().numpy()], []
+    for i in range(8):
+        g = seeded_input(f"radam.g{i}", (64,))
+        p.grad = g.clone()
+        opt.step()
+        gs.append(g.numpy()); ps.append(p.detach().clone().numpy())
+    save("radam", p=np.stack(ps), g=np.stack(gs), lr=0.005)
+
+
+PLANS = {
+    # 4 replaced blocks covering every hint class: aliased conv2 (F7), raw conv1, bottleneck conv2, ASPP branch
+    "g4": ["mod4.block2.convs.conv2", "mod4.block3.convs.conv1", "mod7.block1.convs.conv2", "aspp.features.1.0"],
+}
+
+
+def build_student(plan, kernel=(9, 20, 5)):
+    teacher = DeepWV3Plus(num_classes=19)
+    seeded_fill_(teacher, "teacher.")
+    teacher.eval()
+    model = DepthwiseStudent(teacher, config=None)
+    k, p, d = kernel
+    model.replace([{"name": n, "epoch": 1} for n in plan], kernel_size=k, padding=p, dilation=d)
+    model.register_hint_layers(plan)
+    model.unfreeze(plan)
+    for n in plan:  # new blocks: seeded by checkpoint key name
+        seeded_fill_(model.get_block(n, model.student), f"student.{n}.")
+    return model
+
+
+def g_student_step(plan_name="g4", hw=(64, 128), batch=2):
+    """DepthwiseStudent.forward + the four criteria + loss.backward() of
+    trainer/layerwise_trainer.py:223-235 on seeded weights / inputs."""
+    plan = PLANS[plan_name]
+    model = build_student(plan)
+    x = seeded_input(f"step.{plan_name}.x", (batch, 3) + hw)
+    tgt = torch.randint(0, 19, (batch,) + hw, generator=torch.Generator().manual_seed(11))
+    tgt[:, :4] = 255
+    out_st, out_tc = model(x)
+    crit = [ref_losses.CrossEntropyLoss2d(ignore_index=255), ref_losses.KLDivergenceLoss(1),
+            ref_losses.MSELoss(num_classes=1000), ref_losses.MSELoss(num_classes=1)]
+    sup = crit[0](out_st, tgt); kd = crit[1](out_st, out_tc); tl = crit[0](out_tc, tgt); kd_mse = crit[3](out_st, out_tc)
+    hint = 0
+    per_hint = []
+    for s, t in zip(model.student_hidden_outputs, model.teacher_hidden_outputs):
+        l = crit[2](s, t); per_hint.append(l.item()); hint = hint + l
+    hint.backward()
+    out = dict(plan=np.array(plan), x_key=f"step.{plan_name}.x", target=tgt.numpy().astype(np.uint8),
+               hint_loss=np.float64(hint.item()), per_hint=np.array(per_hint), kd_loss=np.float64(kd.item()),
+               kd_mse=np.float64(kd_mse.item()), supervised_loss=np.float64(sup.item()), teacher_loss=np.float64(tl.item()),
+               student_logits=summarize(out_st), teacher_logits=summarize(out_tc))
+    for i, (s, t) in enumerate(zip(model.student_hidden_outputs, model.teacher_hidden_outputs)):
+        out[f"hint_s{i}"] = summarize(s); out[f"hint_t{i}"] = summarize(t)
+    names = []
+    for n, p in model.student.named_parameters():
+        if p.requires_grad:
+            names.append(n); out[f"grad:{n}"] = summarize(p.grad)
+    out["trainable"] = np.array(names)
+    save(f"student_step_{plan_name}", **out)
+
+
+ALL = dict(losses=g_losses, dwsep=g_dwsep, resblock=g_resblock, aspp=g_aspp, ops=g_ops, radam=g_radam,
+           student_step=g_student_step)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    for k, fn in ALL.items():
+        if a.only in (None, k):
+            fn()
