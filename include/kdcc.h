@@ -1,0 +1,233 @@
+/*
+ * kdcc.h -- C-ABI of libkdcc_hip.so: the MI355X (gfx950) kernels behind the
+ * KD train step of lehduong/Knowledge-Distillation-by-Replacing-Cheap-Conv.
+ *
+ * The reference has no FFI / operator ABI: its hot path is Python classes
+ * resolved by name (parse_config.py:80-93 `init_obj`; train.py:38-71) that
+ * bottom out in torch.nn.functional calls.  Each entry point below replaces
+ * the torch call(s) cited next to it; the Python host mirror
+ * (knowledge-distillation-by-replacing-cheap-conv_amd/) keeps the reference's
+ * class names and binds these symbols with ctypes.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; the caller owns every buffer (device memory);
+ *    the library allocates nothing persistent and keeps no state;
+ *  - all work is enqueued on the hipStream_t passed as `stream` (never the
+ *    default stream implicitly, never a synchronisation);
+ *  - return 0 on success, a negative KD_ERR_* otherwise; never throws;
+ *    kd_last_error() returns a thread-local message for the last failure;
+ *  - activations are NHWC ("channels last"): element (n,h,w,c) of a view with
+ *    pixel stride `ld` lives at base[((n*H + h)*W + w)*ld + c]; ld >= C lets a
+ *    kernel read / write a channel slice of a wider buffer (concat-free ASPP
+ *    and decoder, deeplabv3.py:74,157);
+ *  - dtype KD_BF16: bf16 storage, fp32 accumulate (the measured path);
+ *    dtype KD_F32: fp32 storage, exact-fp32 MFMA (the parity path, 1e-3 gate).
+ */
+#ifndef KDCC_H
+#define KDCC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *kd_stream_t; /* hipStream_t */
+
+enum { KD_F32 = 0, KD_BF16 = 1 };
+enum {
+    KD_OK = 0,
+    KD_ERR_INVALID = -1,     /* bad descriptor / null pointer / misalignment */
+    KD_ERR_UNSUPPORTED = -2, /* shape outside what the kernels implement */
+    KD_ERR_WORKSPACE = -3,   /* workspace too small */
+    KD_ERR_HIP = -4          /* launch failed (hipGetLastError) */
+};
+
+int kd_version(void);
+const char *kd_last_error(void);
+
+/* ---------------------------------------------------------------- dense conv
+ * Implicit-GEMM convolution on MFMA (im2col tile gathered straight into LDS).
+ * Replaces nn.Conv2d forward at models/encoders/wider_resnet.py:124-167,
+ * models/deeplabv3/deeplabv3.py:46-55,127-137 and the 1x1 `pointwise_conv` of
+ * models/students/transform_blocks/depthwise_separable_conv.py:9, together
+ * with the BN(eval)+ReLU (wider_resnet.py:43-48) and in-place residual add
+ * (wider_resnet.py:181) that surround them, which are fused into the epilogue.
+ * The same entry point computes the input gradient (autograd of those calls,
+ * reached from loss.backward(), trainer/layerwise_trainer.py:235) when given
+ * weights packed by kd_pack_conv_weight(..., KD_PACK_DGRAD) and the gradient as
+ * `x`: for stride 1 the dgrad of a conv is a conv with flipped taps.
+ *
+ * Requirements: kh*kw in {1, 9}; Cin % 64 == 0 (bf16) or % 32 == 0 (f32);
+ * x and w 16-byte aligned, ldx*sizeof(elem) % 16 == 0.
+ * w: packed [Cout][kh][kw][Cin] in `dtype`.
+ */
+typedef struct kd_conv_desc {
+    int32_t dtype;
+    int32_t N, H, W, Cin; /* input view */
+    int32_t Ho, Wo, Cout; /* output view */
+    int32_t kh, kw, stride, pad, dil;
+    int32_t ldx;          /* input pixel stride, elements */
+} kd_conv_desc;
+
+/* Epilogue, applied per output element (m = pixel, c = output channel):
+ *   v = acc
+ *   if res_pre   v += res_pre[m*ld_res_pre + c]
+ *   if mask      v = mask[m*ld_mask + c] > 0 ? v * (mask_scale ? mask_scale[c] : 1) : 0
+ *   if res_post  v += res_post[m*ld_res_post + c]
+ *   if out_raw   out_raw[m*ld_raw + c] = v            (as float when raw_f32 != 0)
+ *   if out_act   a = v * (act_scale ? act_scale[c] : 1) + (act_shift ? act_shift[c] : 0);
+ *                out_act[m*ld_act + c] = act_relu ? max(a, 0) : a
+ * forward:  res_pre = shortcut, out_raw = block output / hint, out_act = input of the next conv
+ *           (next layer's eval-mode BN folded to scale/shift, + ReLU);
+ * backward: mask = the saved activated tensor, mask_scale = that BN's scale
+ *           (d relu(bn(x)) / dx), res_post = gradient arriving over the identity shortcut.
+ */
+typedef struct kd_conv_epilogue {
+    const void *res_pre;  int32_t ld_res_pre;
+    const void *mask;     int32_t ld_mask;     const float *mask_scale;
+    const void *res_post; int32_t ld_res_post;
+    void *out_raw;        int32_t ld_raw;      int32_t raw_f32;
+    void *out_act;        int32_t ld_act;      const float *act_scale; const float *act_shift; int32_t act_relu;
+} kd_conv_epilogue;
+
+int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w_packed,
+                  const kd_conv_epilogue *ep, kd_stream_t stream);
+
+/* Weight packing (runs on device, on `stream`).  src: the reference's
+ * nn.Conv2d.weight, fp32 (Cout, Cin, kh, kw) contiguous.
+ *   KD_PACK_FWD   dst[co][ky][kx][ci]            = src[co][ci][ky][kx]
+ *   KD_PACK_DGRAD dst[ci][kh-1-ky][kw-1-kx][co]  = src[co][ci][ky][kx]
+ * cin_pad >= Cin (fwd) zero-fills channels [Cin, cin_pad) (decoder 304 -> 320). */
+enum { KD_PACK_FWD = 0, KD_PACK_DGRAD = 1 };
+int kd_pack_conv_weight(const float *src, void *dst, int32_t dtype, int32_t mode,
+                        int32_t Cout, int32_t Cin, int32_t kh, int32_t kw, int32_t cin_pad,
+                        kd_stream_t stream);
+
+/* Weight gradient of a 1x1 convolution (the trainable `pointwise_conv`,
+ * depthwise_separable_conv.py:9):  dw[co][ci] = sum_m dy[m][co] * a[m][ci],
+ * fp32 (Cout, Cin, 1, 1) like the reference's .grad.  accumulate != 0 adds into dw
+ * (gradient accumulation, layerwise_trainer.py:237-239).
+ * workspace: kd_pw_wgrad_workspace() bytes. */
+size_t kd_pw_wgrad_workspace(int32_t M, int32_t Cin, int32_t Cout);
+int kd_pw_wgrad(int32_t dtype, int32_t M, int32_t Cin, int32_t Cout,
+                const void *a, int32_t lda, const void *dy, int32_t ldy,
+                float *dw, int32_t accumulate, void *workspace, size_t workspace_bytes,
+                kd_stream_t stream);
+
+/* ------------------------------------------------------------ depthwise conv
+ * `separable_conv` of depthwise_separable_conv.py:7-8: Conv2d(C, C, k,
+ * padding, dilation, groups=C), stride 1 (9x9 / dilation 5 / padding 20 in
+ * cfg/cityscapes/58M_deeplab_all.json:117-122; 3x3 in the CIFAR configs).
+ * w_taps: [k*k][C] float (tap-major), from kd_pack_dw_weight.
+ *   flip != 0 in the pack gives the dgrad operand (dx = dwconv(dy, flipped w)
+ *   with pad' = dil*(k-1) - pad).
+ * bias: (C) float or NULL (always NULL for the WRN-38 / ASPP targets). */
+typedef struct kd_dw_desc {
+    int32_t dtype;
+    int32_t N, H, W, C;
+    int32_t k, pad, dil;
+    int32_t ldx, ldy;
+} kd_dw_desc;
+int kd_pack_dw_weight(const float *src /* (C,1,k,k) */, float *dst /* [k*k][C] */,
+                      int32_t C, int32_t k, int32_t flip, kd_stream_t stream);
+int kd_dwconv_fwd(const kd_dw_desc *d, const void *x, const float *w_taps, const float *bias,
+                  void *y, kd_stream_t stream);
+/* dw[c][ky][kx] = sum_{n,h,w} dy[n,h,w,c] * x[n,h-pad+ky*dil,w-pad+kx*dil,c]; fp32 (C,1,k,k). */
+size_t kd_dwconv_wgrad_workspace(const kd_dw_desc *d);
+int kd_dwconv_wgrad(const kd_dw_desc *d, const void *x, const void *dy, int32_t ld_dy,
+                    float *dw, int32_t accumulate, void *workspace, size_t workspace_bytes,
+                    kd_stream_t stream);
+
+/* ----------------------------------------------------------- trunk plumbing
+ * Stem conv mod1.conv1 (wider_resnet.py:307-309): 3x3, 3 -> 64, stride 1, pad 1,
+ * reading the trainer's NCHW fp32 batch directly (layerwise_trainer.py:221).
+ * w: fp32 (64,3,3,3) as in the reference.  y: NHWC `dtype`, 64 channels. */
+int kd_stem_conv(int32_t dtype, const float *x_nchw, const float *w, void *y,
+                 int32_t N, int32_t H, int32_t W, kd_stream_t stream);
+
+/* MaxPool2d(3, stride=2, padding=1) (wider_resnet.py:353-356), optionally followed
+ * by the next block's BN(eval)+ReLU: y_raw (may be NULL) = pool, y_act (may be NULL) =
+ * relu(pool*scale+shift). */
+int kd_maxpool3x3s2(int32_t dtype, const void *x, int32_t ldx, void *y_raw, int32_t ld_raw,
+                    void *y_act, int32_t ld_act, const float *scale, const float *shift,
+                    int32_t N, int32_t H, int32_t W, int32_t C, kd_stream_t stream);
+
+/* F.interpolate(bilinear, align_corners=True) (deeplabv3.py:16-18,69,155,160).
+ * Input and output element types are given separately (the final logits are
+ * produced in fp32 from an fp32 decoder output whatever the compute dtype). */
+int kd_upsample_bilinear_ac(const void *x, int32_t x_dtype, int32_t ldx, void *y, int32_t y_dtype, int32_t ldy,
+                            int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
+                            kd_stream_t stream);
+
+/* ASPP image-pooling branch (deeplabv3.py:59-62,67-70): AdaptiveAvgPool2d(1) ->
+ * 1x1 conv (w fp32 (Cout,Cin)) -> BN(eval) scale/shift -> ReLU -> broadcast
+ * ("upsample" of a 1x1 map) into y[.., 0:Cout] of an NHWC view with stride ldy.
+ * workspace: kd_aspp_image_pool_workspace() bytes (pixel-chunk partial sums, reduced in fixed order). */
+size_t kd_aspp_image_pool_workspace(int32_t N, int32_t Cin, int32_t Cout);
+int kd_aspp_image_pool(int32_t dtype, const void *x, int32_t ldx, const float *w, const float *scale,
+                       const float *shift, void *y, int32_t ldy, int32_t N, int32_t H, int32_t W,
+                       int32_t Cin, int32_t Cout, void *workspace, size_t workspace_bytes, kd_stream_t stream);
+
+/* BN(eval) scale/shift from running statistics (nn.BatchNorm2d in eval mode):
+ *   scale = gamma / sqrt(var + eps),  shift = beta - mean * scale. */
+int kd_bn_fold(const float *gamma, const float *beta, const float *mean, const float *var, float eps,
+               float *scale, float *shift, int32_t C, kd_stream_t stream);
+
+/* generic strided copy / cast between NCHW-or-NHWC fp32/bf16 views:
+ * dst(n,c,p) = src(n,c,p), element (n,c,p) at n*sN + c*sC + p*sP (elements). */
+int kd_copy_cast(const void *src, int32_t src_dtype, int64_t s_sN, int64_t s_sC, int64_t s_sP,
+                 void *dst, int32_t dst_dtype, int64_t d_sN, int64_t d_sC, int64_t d_sP,
+                 int32_t N, int32_t C, int64_t P, kd_stream_t stream);
+
+/* -------------------------------------------------------------------- losses
+ * Each writes the scalar loss (fp32, device) and, when grad != NULL, the
+ * gradient w.r.t. `s` in one pass.  Views are (N, C, P) with element strides
+ * (sN, sC, sP) so NCHW (reference layout) and NHWC (engine layout) are both
+ * accepted; dtype per operand.  partial: workspace of kd_loss_workspace() bytes.
+ *
+ * kd_kldiv: KLDivergenceLoss.forward, losses/KLDiv.py:19-23
+ *   loss = kl_div(log_softmax(s/T,1), softmax(t/T,1), 'mean') * T^2 * C
+ *   grad = T/(N*P) * (softmax(s/T) - softmax(t/T))
+ * kd_hint_mse: MSELoss.forward, losses/MSELoss.py:14-16
+ *   loss = mean((s-t)^2) * num_classes ; grad = 2*num_classes*(s-t)/numel
+ * kd_weighted_hint_mse: WeightedHintMSELoss.forward, losses/WeightedHintMSELoss.py:12-16
+ *   w: (C) if w_per_sample == 0 else (N,C), fp32.
+ * kd_ce2d: CrossEntropyLoss2d.forward, losses/CrossEntropy.py:10-14 (logged metric);
+ *   target int64 (N,P), ignore_index excluded from the mean.
+ */
+typedef struct kd_view3 {
+    const void *ptr;
+    int32_t dtype;
+    int64_t sN, sC, sP;
+} kd_view3;
+typedef struct kd_mview3 {
+    void *ptr;
+    int32_t dtype;
+    int64_t sN, sC, sP;
+} kd_mview3;
+
+size_t kd_loss_workspace(int32_t N, int32_t C, int64_t P);
+int kd_kldiv(const kd_view3 *s, const kd_view3 *t, float temperature, int32_t N, int32_t C, int64_t P,
+             float *loss, const kd_mview3 *grad, float grad_scale, void *workspace, size_t workspace_bytes,
+             kd_stream_t stream);
+int kd_hint_mse(const kd_view3 *s, const kd_view3 *t, float num_classes, int32_t N, int32_t C, int64_t P,
+                float *loss, const kd_mview3 *grad, float grad_scale, void *workspace, size_t workspace_bytes,
+                kd_stream_t stream);
+int kd_weighted_hint_mse(const kd_view3 *s, const kd_view3 *t, const float *w, int32_t w_per_sample,
+                         int32_t N, int32_t C, int64_t P, float *loss, const kd_mview3 *grad, float grad_scale,
+                         void *workspace, size_t workspace_bytes, kd_stream_t stream);
+int kd_ce2d(const kd_view3 *x, const int64_t *target, int32_t ignore_index, int32_t N, int32_t C, int64_t P,
+            float *loss, void *workspace, size_t workspace_bytes, kd_stream_t stream);
+
+/* ----------------------------------------------------------------- optimizer
+ * RAdam.step for one tensor, utils/optim/radam.py:30-98 (fp32 params/state).
+ * `step` is the per-tensor step count after the increment (radam.py:62). */
+int kd_radam_step(float *p, const float *g, float *exp_avg, float *exp_avg_sq, int64_t n, int32_t step,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, kd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KDCC_H */

@@ -1,0 +1,98 @@
+"""ctypes binding of libkdcc_hip.so (include/kdcc.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a call
+fails this module raises.  Build with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C knowledge-distillation-by-replacing-cheap-conv_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkdcc_hip.so")
+
+KD_F32, KD_BF16 = 0, 1
+KD_PACK_FWD, KD_PACK_DGRAD = 0, 1
+
+c_int, c_i64, c_f, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, c_int) for n in ("dtype", "N", "H", "W", "Cin", "Ho", "Wo", "Cout", "kh", "kw", "stride", "pad",
+                                     "dil", "ldx")]
+
+
+class ConvEpilogue(C.Structure):
+    _fields_ = [("res_pre", c_vp), ("ld_res_pre", c_int),
+                ("mask", c_vp), ("ld_mask", c_int), ("mask_scale", c_vp),
+                ("res_post", c_vp), ("ld_res_post", c_int),
+                ("out_raw", c_vp), ("ld_raw", c_int), ("raw_f32", c_int),
+                ("out_act", c_vp), ("ld_act", c_int), ("act_scale", c_vp), ("act_shift", c_vp), ("act_relu", c_int)]
+
+
+class DwDesc(C.Structure):
+    _fields_ = [(n, c_int) for n in ("dtype", "N", "H", "W", "C", "k", "pad", "dil", "ldx", "ldy")]
+
+
+class View3(C.Structure):
+    _fields_ = [("ptr", c_vp), ("dtype", c_int), ("sN", c_i64), ("sC", c_i64), ("sP", c_i64)]
+
+
+_P = C.POINTER
+_SIGS = {
+    "kd_version": (c_int, []),
+    "kd_last_error": (C.c_char_p, []),
+    "kd_conv2d_fwd": (c_int, [_P(ConvDesc), c_vp, c_vp, _P(ConvEpilogue), c_vp]),
+    "kd_pack_conv_weight": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "kd_pw_wgrad_workspace": (c_sz, [c_int, c_int, c_int]),
+    "kd_pw_wgrad": (c_int, [c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_sz, c_vp]),
+    "kd_pack_dw_weight": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "kd_dwconv_fwd": (c_int, [_P(DwDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "kd_dwconv_wgrad_workspace": (c_sz, [_P(DwDesc)]),
+    "kd_dwconv_wgrad": (c_int, [_P(DwDesc), c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_sz, c_vp]),
+    "kd_stem_conv": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "kd_maxpool3x3s2": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "kd_upsample_bilinear_ac": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "kd_aspp_image_pool_workspace": (c_sz, [c_int, c_int, c_int]),
+    "kd_aspp_image_pool": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_vp, c_sz, c_vp]),
+    "kd_bn_fold": (c_int, [c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_int, c_vp]),
+    "kd_copy_cast": (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_i64, c_vp]),
+    "kd_loss_workspace": (c_sz, [c_int, c_int, c_i64]),
+    "kd_kldiv": (c_int, [_P(View3), _P(View3), c_f, c_int, c_int, c_i64, c_vp, _P(View3), c_f, c_vp, c_sz, c_vp]),
+    "kd_hint_mse": (c_int, [_P(View3), _P(View3), c_f, c_int, c_int, c_i64, c_vp, _P(View3), c_f, c_vp, c_sz, c_vp]),
+    "kd_weighted_hint_mse": (c_int, [_P(View3), _P(View3), c_vp, c_int, c_int, c_int, c_i64, c_vp, _P(View3), c_f, c_vp,
+                                     c_sz, c_vp]),
+    "kd_ce2d": (c_int, [_P(View3), c_vp, c_int, c_int, c_int, c_i64, c_vp, c_vp, c_sz, c_vp]),
+    "kd_radam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f, c_f, c_f, c_f, c_f, c_vp]),
+}
+
+_lib = None
+
+
+class KdccError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise KdccError(f"{LIB_PATH} not built: the HIP extension is required (no CPU fallback). "
+                            "Run __graft_entry__.build().")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().kd_last_error()
+        raise KdccError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

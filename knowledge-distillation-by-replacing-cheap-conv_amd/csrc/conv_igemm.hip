@@ -1,0 +1,346 @@
+// Implicit-GEMM NHWC convolution on gfx950 MFMA (kd_conv2d_fwd; also the dgrad
+// engine when fed KD_PACK_DGRAD weights).  See include/kdcc.h for semantics.
+//
+// GEMM view:  Y[m][co] = sum_{tap,ci} X[pixel(m) + tap][ci] * Wp[co][tap][ci]
+//   M = N*Ho*Wo pixels, N = Cout, K = kh*kw*Cin.
+// Block tile 128(M) x 128(N), 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16 tiles.
+// One K stage = 128 bytes of K per row (64 bf16 / 32 f32): the A tile is gathered
+// (im2col) and the B tile streamed straight into LDS with global_load_lds (16 B per
+// lane), rows XOR-swizzled on the SOURCE side so that the ds_read_b128 fragment
+// reads are bank-conflict free.  Out-of-image taps and tile tails read a zero page.
+// Epilogue: accumulators -> per-wave LDS patch -> 8-channel (16/32 B) vector rows:
+// residual add, BN(eval)+ReLU of the next layer, ReLU-mask backward, dual outputs.
+#include "igemm_core.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int ROWB = IG_ROWB;               // bytes of K per LDS row per stage
+constexpr int STAGE_A = BM * ROWB;          // 16 KiB
+constexpr int STAGE_B = BN * ROWB;          // 16 KiB
+constexpr int STAGE = STAGE_A + STAGE_B;    // 32 KiB
+constexpr int EP_LD = 68;                   // floats per epilogue row (64 + pad)
+static_assert(32 * EP_LD * 4 <= STAGE_A, "a wave's half-tile epilogue patch must fit one stage array");
+
+__device__ __attribute__((aligned(256))) uint32_t kd_zero_page[64];  // zero-initialised
+
+struct ConvParams {
+    const void *x;
+    const void *w;
+    int M, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil, ldx;
+    int HoWo, nkc, nk, Ktot, tiles_n;
+    int vec_ok;  // every epilogue pointer/stride is 16-B friendly
+    kd_conv_epilogue ep;
+};
+
+__device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
+}
+
+// load/store 8 channels with tail + alignment handling
+template <typename U>
+__device__ __forceinline__ void ld8_guard(const U *p, int valid, bool vec, float (&v)[8])
+{
+    if (vec && valid == 8) {
+        ld8(p, v);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = e < valid ? Elem<U>::ld(p + e) : 0.f;
+    }
+}
+template <typename U>
+__device__ __forceinline__ void st8_guard(U *p, int valid, bool vec, const float (&v)[8])
+{
+    if (vec && valid == 8) {
+        st8(p, v);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (e < valid) Elem<U>::st(p + e, v[e]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p)
+{
+    // Four separate LDS objects (not one array): hipcc tags accesses per LDS variable, so the
+    // ds_reads of stage `cur` do not wait (vmcnt) for the LDS-DMA still filling stage `cur^1`.
+    __shared__ __attribute__((aligned(16))) char sA0[STAGE_A];
+    __shared__ __attribute__((aligned(16))) char sB0[STAGE_B];
+    __shared__ __attribute__((aligned(16))) char sA1[STAGE_A];
+    __shared__ __attribute__((aligned(16))) char sB1[STAGE_B];
+    constexpr int ES = sizeof(T);
+    constexpr int BK = ROWB / ES;   // K elements per stage
+    constexpr int EPC = 16 / ES;    // elements per 16-B chunk
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const T *__restrict__ xg = (const T *)p.x;
+    const T *__restrict__ wg = (const T *)p.w;
+    const T *zero = (const T *)kd_zero_page;
+
+    // ---- per-lane staging state: 4 A rows + 4 B rows, fixed over the K loop -------------
+    const int srow = lane >> 3;
+    const int chunk = (lane & 7) ^ srow;  // source-side swizzle: LDS slot (lane&7) of row r holds chunk slot^(r&7)
+    int a_off[4];
+    uint32_t a_mask[4];
+    int b_off[4];
+    const int ntaps = p.kh * p.kw;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wv * 4 + j) * 8 + srow;
+        const int m = m0 + r;
+        a_off[j] = 0;
+        a_mask[j] = 0;
+        if (m < p.M) {
+            const int n = m / p.HoWo, rem = m - n * p.HoWo;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+            a_off[j] = ((n * p.H + hi0) * p.W + wi0) * p.ldx + chunk * EPC;
+            uint32_t mk = 0;
+            for (int t = 0; t < ntaps; ++t) {
+                const int ky = t / p.kw, kx = t - ky * p.kw;
+                const int hi = hi0 + ky * p.dil, wi = wi0 + kx * p.dil;
+                if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) mk |= 1u << t;
+            }
+            a_mask[j] = mk;
+        }
+        const int nn = n0 + r;
+        b_off[j] = nn < p.Cout ? nn * p.Ktot + chunk * EPC : -1;
+    }
+
+    auto stage = [&](int kt, int tap, int cb, char *sA, char *sB) {
+        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+        const int tap_off = (ky * p.dil * p.W + kx * p.dil) * p.ldx + cb * BK;
+        char *la = sA + wv * 4096;
+        char *lb = sB + wv * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const T *src = ((a_mask[j] >> tap) & 1u) ? xg + (a_off[j] + tap_off) : zero;
+            glds16(src, la + j * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const T *src = b_off[j] >= 0 ? wg + ((size_t)b_off[j] + (size_t)kt * BK) : zero;
+            glds16(src, lb + j * 1024);
+        }
+        // keep the DMA issue ahead of the MFMA block it is meant to overlap with
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    auto compute = [&](const char *sA, const char *sB) { ig_compute_stage<T>(sA, sB, wm, wn, lane, acc); };
+
+    // ---- K loop: double-buffered, one barrier per stage --------------------------------
+    int tap = 0, cb = 0, kt = 0;
+    stage(0, 0, 0, sA0, sB0);
+    __syncthreads();
+    // buffers are named statically (loop unrolled by two) so the compiler can tell them apart
+    for (; kt + 2 < p.nk; kt += 2) {
+        if (++cb == p.nkc) { cb = 0; ++tap; }
+        stage(kt + 1, tap, cb, sA1, sB1);
+        compute(sA0, sB0);
+        __syncthreads();
+        if (++cb == p.nkc) { cb = 0; ++tap; }
+        stage(kt + 2, tap, cb, sA0, sB0);
+        compute(sA1, sB1);
+        __syncthreads();
+    }
+    if (kt + 1 < p.nk) {  // two stages left: kt (in buffer 0) and kt+1
+        if (++cb == p.nkc) { cb = 0; ++tap; }
+        stage(kt + 1, tap, cb, sA1, sB1);
+        compute(sA0, sB0);
+        __syncthreads();
+        compute(sA1, sB1);
+    } else {
+        compute(sA0, sB0);
+    }
+    __syncthreads();  // every wave is done reading the stage buffers
+
+    // ---- epilogue ---------------------------------------------------------------------
+    const kd_conv_epilogue &e = p.ep;
+    const int cg = (lane & 7) * 8;
+    const int c0 = n0 + wn * 64 + cg;
+    const int valid = p.Cout - c0 >= 8 ? 8 : (p.Cout - c0 > 0 ? p.Cout - c0 : 0);
+    const bool vec = p.vec_ok != 0;
+
+    float mscale[8], ascale[8], ashift[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const bool ok = q < valid;
+        mscale[q] = (e.mask_scale && ok) ? e.mask_scale[c0 + q] : 1.f;
+        ascale[q] = (e.act_scale && ok) ? e.act_scale[c0 + q] : 1.f;
+        ashift[q] = (e.act_shift && ok) ? e.act_shift[c0 + q] : 0.f;
+    }
+
+    // each wave owns one stage array as its private 32 x 64 fp32 patch (two half-tiles in turn)
+    float *ep = (float *)(wv == 0 ? sA0 : wv == 1 ? sB0 : wv == 2 ? sA1 : sB1);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ep[(i * 16 + fq * 4 + r) * EP_LD + j * 16 + frow] = acc[half * 2 + i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+#pragma unroll 1
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 8 + (lane >> 3);
+            const int m = m0 + wm * 64 + half * 32 + row;
+            if (m >= p.M || valid == 0) continue;
+            float v[8];
+            {
+                const float4 lo = *(const float4 *)(ep + row * EP_LD + cg);
+                const float4 hi = *(const float4 *)(ep + row * EP_LD + cg + 4);
+                v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            }
+            float t[8];
+            if (e.res_pre) {
+                ld8_guard((const T *)e.res_pre + (size_t)m * e.ld_res_pre + c0, valid, vec, t);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += t[q];
+            }
+            if (e.mask) {
+                ld8_guard((const T *)e.mask + (size_t)m * e.ld_mask + c0, valid, vec, t);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = t[q] > 0.f ? v[q] * mscale[q] : 0.f;
+            }
+            if (e.res_post) {
+                ld8_guard((const T *)e.res_post + (size_t)m * e.ld_res_post + c0, valid, vec, t);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += t[q];
+            }
+            if (e.out_raw) {
+                if (e.raw_f32) st8_guard((float *)e.out_raw + (size_t)m * e.ld_raw + c0, valid, vec, v);
+                else st8_guard((T *)e.out_raw + (size_t)m * e.ld_raw + c0, valid, vec, v);
+            }
+            if (e.out_act) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float a = v[q] * ascale[q] + ashift[q];
+                    t[q] = e.act_relu ? fmaxf(a, 0.f) : a;
+                }
+                st8_guard((T *)e.out_act + (size_t)m * e.ld_act + c0, valid, vec, t);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// ---- weight packing ------------------------------------------------------------------
+template <typename T>
+__global__ void pack_conv_weight_kernel(const float *__restrict__ src, T *__restrict__ dst, int mode, int Cout,
+                                        int Cin, int kh, int kw, int cin_pad)
+{
+    // one thread per destination element
+    const int taps = kh * kw;
+    const size_t total = mode == KD_PACK_FWD ? (size_t)Cout * taps * cin_pad : (size_t)Cin * taps * Cout;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (mode == KD_PACK_FWD) {
+            const int ci = (int)(i % cin_pad);
+            const size_t r = i / cin_pad;
+            const int t = (int)(r % taps), co = (int)(r / taps);
+            if (ci < Cin) v = src[((size_t)co * Cin + ci) * taps + t];
+        } else {
+            const int co = (int)(i % Cout);
+            const size_t r = i / Cout;
+            const int tf = (int)(r % taps), ci = (int)(r / taps);
+            const int t = taps - 1 - tf;  // flip both spatial axes
+            v = src[((size_t)co * Cin + ci) * taps + t];
+        }
+        Elem<T>::st(dst + i, v);
+    }
+}
+
+}  // namespace
+
+extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w_packed, const kd_conv_epilogue *ep,
+                             kd_stream_t stream)
+{
+    KD_REQUIRE(d && x && w_packed && ep, KD_ERR_INVALID, "kd_conv2d_fwd: null argument");
+    KD_REQUIRE(d->dtype == KD_F32 || d->dtype == KD_BF16, KD_ERR_INVALID, "kd_conv2d_fwd: bad dtype %d", d->dtype);
+    const int es = kd_elem_size(d->dtype);
+    const int bk = ROWB / es;
+    KD_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 && d->Wo > 0,
+               KD_ERR_INVALID, "kd_conv2d_fwd: non-positive dimension");
+    KD_REQUIRE((d->kh == 1 && d->kw == 1) || (d->kh == 3 && d->kw == 3), KD_ERR_UNSUPPORTED,
+               "kd_conv2d_fwd: kernel %dx%d not supported (1x1, 3x3)", d->kh, d->kw);
+    KD_REQUIRE(d->stride >= 1 && d->dil >= 1 && d->pad >= 0, KD_ERR_INVALID, "kd_conv2d_fwd: bad stride/dil/pad");
+    KD_REQUIRE(d->Cin % bk == 0, KD_ERR_UNSUPPORTED, "kd_conv2d_fwd: Cin=%d must be a multiple of %d", d->Cin, bk);
+    KD_REQUIRE(d->ldx >= d->Cin && (d->ldx * es) % 16 == 0, KD_ERR_INVALID, "kd_conv2d_fwd: bad ldx=%d", d->ldx);
+    KD_REQUIRE(kd_aligned16(x) && kd_aligned16(w_packed), KD_ERR_INVALID, "kd_conv2d_fwd: x/w must be 16-B aligned");
+    const int ho = (d->H + 2 * d->pad - d->dil * (d->kh - 1) - 1) / d->stride + 1;
+    const int wo = (d->W + 2 * d->pad - d->dil * (d->kw - 1) - 1) / d->stride + 1;
+    KD_REQUIRE(ho == d->Ho && wo == d->Wo, KD_ERR_INVALID, "kd_conv2d_fwd: Ho/Wo (%d,%d) inconsistent, expect (%d,%d)",
+               d->Ho, d->Wo, ho, wo);
+    const long long in_elems = (long long)d->N * d->H * d->W * d->ldx;
+    const long long w_elems = (long long)d->Cout * d->kh * d->kw * d->Cin;
+    KD_REQUIRE(in_elems < (1ll << 31) && w_elems < (1ll << 31), KD_ERR_UNSUPPORTED,
+               "kd_conv2d_fwd: tensor exceeds 2^31 elements");
+    KD_REQUIRE(ep->out_raw || ep->out_act, KD_ERR_INVALID, "kd_conv2d_fwd: no output requested");
+
+    ConvParams p;
+    p.x = x; p.w = w_packed;
+    p.M = d->N * d->Ho * d->Wo;
+    p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+    p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.ldx = d->ldx;
+    p.HoWo = d->Ho * d->Wo;
+    p.nkc = d->Cin / bk;
+    p.nk = d->kh * d->kw * p.nkc;
+    p.Ktot = d->kh * d->kw * d->Cin;
+    p.tiles_n = (d->Cout + BN - 1) / BN;
+    p.ep = *ep;
+    auto ok = [&](const void *ptr, int ld, int esz) { return !ptr || (kd_aligned16(ptr) && (ld * esz) % 16 == 0); };
+    p.vec_ok = ok(ep->res_pre, ep->ld_res_pre, es) && ok(ep->mask, ep->ld_mask, es) &&
+               ok(ep->res_post, ep->ld_res_post, es) && ok(ep->out_raw, ep->ld_raw, ep->raw_f32 ? 4 : es) &&
+               ok(ep->out_act, ep->ld_act, es);
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const dim3 grid((unsigned)(tiles_m * p.tiles_n));
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == KD_BF16) hipLaunchKernelGGL(conv_igemm_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(conv_igemm_kernel<float>, grid, dim3(256), 0, s, p);
+    KD_CHECK_LAUNCH("kd_conv2d_fwd");
+    return KD_OK;
+}
+
+extern "C" int kd_pack_conv_weight(const float *src, void *dst, int32_t dtype, int32_t mode, int32_t Cout, int32_t Cin,
+                                   int32_t kh, int32_t kw, int32_t cin_pad, kd_stream_t stream)
+{
+    KD_REQUIRE(src && dst, KD_ERR_INVALID, "kd_pack_conv_weight: null argument");
+    KD_REQUIRE(dtype == KD_F32 || dtype == KD_BF16, KD_ERR_INVALID, "kd_pack_conv_weight: bad dtype");
+    KD_REQUIRE(mode == KD_PACK_FWD || mode == KD_PACK_DGRAD, KD_ERR_INVALID, "kd_pack_conv_weight: bad mode");
+    KD_REQUIRE(Cout > 0 && Cin > 0 && kh > 0 && kw > 0, KD_ERR_INVALID, "kd_pack_conv_weight: bad shape");
+    if (mode == KD_PACK_FWD) KD_REQUIRE(cin_pad >= Cin, KD_ERR_INVALID, "kd_pack_conv_weight: cin_pad < Cin");
+    else KD_REQUIRE(cin_pad == Cin, KD_ERR_INVALID, "kd_pack_conv_weight: dgrad pack takes cin_pad == Cin");
+    const size_t total = mode == KD_PACK_FWD ? (size_t)Cout * kh * kw * cin_pad : (size_t)Cin * kh * kw * Cout;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == KD_BF16)
+        hipLaunchKernelGGL(pack_conv_weight_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, src, (bf16_t *)dst, mode, Cout,
+                           Cin, kh, kw, cin_pad);
+    else
+        hipLaunchKernelGGL(pack_conv_weight_kernel<float>, dim3(blocks), dim3(256), 0, s, src, (float *)dst, mode, Cout,
+                           Cin, kh, kw, cin_pad);
+    KD_CHECK_LAUNCH("kd_pack_conv_weight");
+    return KD_OK;
+}

@@ -1,0 +1,336 @@
+// Depthwise k x k dilated convolution, NHWC (kd_dwconv_fwd / kd_dwconv_wgrad).
+// The shipped cheap conv is 9x9, dilation 5, padding 20 (effective 41x41 field): the
+// image splits into dil*dil residue classes, each an independent dense k x k stencil on
+// the lattice {r + dil*l}.  A thread owns 4 channels and an S x R patch of lattice
+// outputs, so each input vector (4 channels, 8/16 B) it loads feeds up to k*S FMAs and
+// every weight quad k*R of them; 16 consecutive lanes cover 64 contiguous channels
+// (128/256 B per pixel per load instruction).  Weights sit in LDS tap-major.
+// VALU/L1-bound by design (81 FMA per output element); no MFMA reshaping.
+#include "kd_common.h"
+
+namespace {
+
+constexpr int CB = 64;    // channels per block
+constexpr int CQ = 16;    // channel quads per block (threads along channels)
+constexpr int TS = 2;     // lattice rows per thread
+constexpr int TR = 8;     // lattice cols per thread
+
+struct DwParams {
+    const void *x;
+    const float *w;      // [k*k][C]
+    const float *bias;   // (C) or null
+    void *y;
+    int N, H, W, C, pad, dil, ldx, ldy;
+    int LH, LW;          // lattice extent upper bounds: ceil(H/dil), ceil(W/dil)
+    int tiles_h, tiles_w;
+};
+
+template <typename T> __device__ __forceinline__ void ld4(const T *p, float (&v)[4]);
+template <> __device__ __forceinline__ void ld4<float>(const float *p, float (&v)[4])
+{
+    const float4 a = *(const float4 *)p;
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t *p, float (&v)[4])
+{
+    const uint2 u = *(const uint2 *)p;
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+}
+__device__ __forceinline__ void st4(float *p, const float (&v)[4]) { *(float4 *)p = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void st4(bf16_t *p, const float (&v)[4])
+{
+    *(uint2 *)p = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+}
+
+// grid: x = ceil(tiles_h*tiles_w / 16), y = ceil(C / 64), z = N * dil * dil
+template <typename T, int K>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwParams p)
+{
+    __shared__ __attribute__((aligned(16))) float wl[K * K * CB];
+    const int tid = threadIdx.x;
+    const int cq = tid & (CQ - 1), tt = tid >> 4;
+    const int c0 = blockIdx.y * CB;
+    for (int i = tid; i < K * K * CB; i += 256) {
+        const int t = i / CB, c = c0 + (i - t * CB);
+        wl[i] = c < p.C ? p.w[(size_t)t * p.C + c] : 0.f;
+    }
+    __syncthreads();
+
+    const int dd = p.dil * p.dil;
+    const int n = blockIdx.z / dd, rc = blockIdx.z - n * dd;
+    const int rh = rc / p.dil, rw = rc - rh * p.dil;
+    const int tile = blockIdx.x * 16 + tt;
+    const int c = c0 + cq * 4;
+    if (tile >= p.tiles_h * p.tiles_w || c >= p.C) return;
+    const int th = tile / p.tiles_w, tw = tile - th * p.tiles_w;
+    const int h0 = rh + p.dil * (th * TS), w0 = rw + p.dil * (tw * TR);
+    if (h0 >= p.H || w0 >= p.W) return;
+
+    float acc[TS][TR][4];
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) { b4[0] = p.bias[c]; b4[1] = p.bias[c + 1]; b4[2] = p.bias[c + 2]; b4[3] = p.bias[c + 3]; }
+#pragma unroll
+    for (int s = 0; s < TS; ++s)
+#pragma unroll
+        for (int r = 0; r < TR; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[s][r][q] = b4[q];
+
+    const T *xb = (const T *)p.x + (size_t)n * p.H * p.W * p.ldx + c;
+#pragma unroll 1
+    for (int rho = 0; rho < TS + K - 1; ++rho) {
+        const int hin = h0 - p.pad + rho * p.dil;
+        if (hin < 0 || hin >= p.H) continue;  // block-divergent only at image borders
+        float xv[TR + K - 1][4];
+        const T *xr = xb + (size_t)hin * p.W * p.ldx;
+#pragma unroll
+        for (int idx = 0; idx < TR + K - 1; ++idx) {
+            const int win = w0 - p.pad + idx * p.dil;
+            if (win >= 0 && win < p.W) ld4<T>(xr + (size_t)win * p.ldx, xv[idx]);
+            else { xv[idx][0] = xv[idx][1] = xv[idx][2] = xv[idx][3] = 0.f; }
+        }
+#pragma unroll
+        for (int s = 0; s < TS; ++s) {
+            const int i = rho - s;  // tap row feeding output row s from input row rho
+            if (i < 0 || i >= K) continue;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const float4 w4 = *(const float4 *)&wl[(i * K + j) * CB + cq * 4];
+#pragma unroll
+                for (int r = 0; r < TR; ++r) {
+                    acc[s][r][0] = fmaf(xv[r + j][0], w4.x, acc[s][r][0]);
+                    acc[s][r][1] = fmaf(xv[r + j][1], w4.y, acc[s][r][1]);
+                    acc[s][r][2] = fmaf(xv[r + j][2], w4.z, acc[s][r][2]);
+                    acc[s][r][3] = fmaf(xv[r + j][3], w4.w, acc[s][r][3]);
+                }
+            }
+        }
+    }
+
+    T *yb = (T *)p.y + (size_t)n * p.H * p.W * p.ldy + c;
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+        const int h = h0 + s * p.dil;
+        if (h >= p.H) continue;
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            const int w = w0 + r * p.dil;
+            if (w < p.W) st4(yb + ((size_t)h * p.W + w) * p.ldy, acc[s][r]);
+        }
+    }
+}
+
+// ---- weight gradient ---------------------------------------------------------------
+// thread = (channel quad, lattice row strip); block = 16 quads x 16 strips, blockIdx.z = tap row i.
+// Each thread keeps K taps x 4 channels of partial sums over its strip, the block reduces the 16
+// strips through LDS and writes one partial [K][64] slab; a second kernel sums slabs in order.
+struct DwWgradParams {
+    const void *x;
+    const void *dy;
+    float *part;  // [gridDim.x][K*K][C]
+    int N, H, W, C, pad, dil, ldx, ld_dy;
+    int LH, LW, nstrips;
+};
+
+template <typename T, int K>
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwWgradParams p)
+{
+    __shared__ float red[16][K][CB + 4];
+    const int tid = threadIdx.x;
+    const int cq = tid & (CQ - 1), tt = tid >> 4;
+    const int c = blockIdx.y * CB + cq * 4;
+    const int i = blockIdx.z;  // tap row
+    const int strip = blockIdx.x * 16 + tt;
+
+    float acc[K][4];
+#pragma unroll
+    for (int j = 0; j < K; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.f;
+
+    if (strip < p.nstrips && c < p.C) {
+        // strip -> (n, rh, rw, lh)
+        const int dd = p.dil * p.dil;
+        int t = strip;
+        const int lh = t % p.LH; t /= p.LH;
+        const int rc = t % dd;
+        const int n = t / dd;
+        const int rh = rc / p.dil, rw = rc - rh * p.dil;
+        const int h = rh + p.dil * lh;
+        const int hin = h - p.pad + i * p.dil;
+        if (h < p.H && hin >= 0 && hin < p.H) {
+            const T *dyr = (const T *)p.dy + ((size_t)n * p.H + h) * p.W * p.ld_dy + c;
+            const T *xr = (const T *)p.x + ((size_t)n * p.H + hin) * p.W * p.ldx + c;
+#pragma unroll 1
+            for (int lw0 = 0; lw0 < p.LW; lw0 += TR) {
+                const int w0 = rw + p.dil * lw0;
+                if (w0 >= p.W) break;
+                float g[TR][4], xv[TR + K - 1][4];
+#pragma unroll
+                for (int r = 0; r < TR; ++r) {
+                    const int w = w0 + r * p.dil;
+                    if (w < p.W) ld4<T>(dyr + (size_t)w * p.ld_dy, g[r]);
+                    else { g[r][0] = g[r][1] = g[r][2] = g[r][3] = 0.f; }
+                }
+#pragma unroll
+                for (int idx = 0; idx < TR + K - 1; ++idx) {
+                    const int win = w0 - p.pad + idx * p.dil;
+                    if (win >= 0 && win < p.W) ld4<T>(xr + (size_t)win * p.ldx, xv[idx]);
+                    else { xv[idx][0] = xv[idx][1] = xv[idx][2] = xv[idx][3] = 0.f; }
+                }
+#pragma unroll
+                for (int j = 0; j < K; ++j)
+#pragma unroll
+                    for (int r = 0; r < TR; ++r) {
+                        acc[j][0] = fmaf(g[r][0], xv[r + j][0], acc[j][0]);
+                        acc[j][1] = fmaf(g[r][1], xv[r + j][1], acc[j][1]);
+                        acc[j][2] = fmaf(g[r][2], xv[r + j][2], acc[j][2]);
+                        acc[j][3] = fmaf(g[r][3], xv[r + j][3], acc[j][3]);
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[tt][j][cq * 4 + q] = acc[j][q];
+    __syncthreads();
+    // 16 strips -> 1, fixed order
+    for (int o = tid; o < K * CB; o += 256) {
+        const int j = o / CB, cc = o - j * CB;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][j][cc];
+        const int cg = blockIdx.y * CB + cc;
+        if (cg < p.C) p.part[((size_t)blockIdx.x * K * K + (i * K + j)) * p.C + cg] = s;
+    }
+}
+
+// dw (C,1,K,K) = sum over slabs of part[slab][tap][c]
+__global__ void dw_slab_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, int nslabs, int taps,
+                                      int C, int accumulate)
+{
+    const int total = taps * C;
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gridDim.x * blockDim.x) {
+        const int t = o / C, c = o - t * C;
+        float s = 0.f;
+        for (int k = 0; k < nslabs; ++k) s += part[((size_t)k * taps + t) * C + c];
+        float *d = dw + (size_t)c * taps + t;
+        *d = accumulate ? *d + s : s;
+    }
+}
+
+__global__ void pack_dw_weight_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int taps, int flip)
+{
+    const int total = C * taps;
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gridDim.x * blockDim.x) {
+        const int t = o / C, c = o - t * C;
+        dst[o] = src[(size_t)c * taps + (flip ? taps - 1 - t : t)];
+    }
+}
+
+int check_desc(const kd_dw_desc *d, const char *who)
+{
+    KD_REQUIRE(d, KD_ERR_INVALID, "%s: null descriptor", who);
+    KD_REQUIRE(d->dtype == KD_F32 || d->dtype == KD_BF16, KD_ERR_INVALID, "%s: bad dtype", who);
+    KD_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->dil >= 1 && d->pad >= 0, KD_ERR_INVALID,
+               "%s: bad shape", who);
+    KD_REQUIRE(d->k == 3 || d->k == 9, KD_ERR_UNSUPPORTED, "%s: kernel size %d not supported (3, 9)", who, d->k);
+    KD_REQUIRE(2 * d->pad == d->dil * (d->k - 1), KD_ERR_UNSUPPORTED,
+               "%s: only 'same' geometry (2*pad == dil*(k-1)) is supported, got pad=%d dil=%d k=%d", who, d->pad,
+               d->dil, d->k);
+    KD_REQUIRE(d->C % 4 == 0, KD_ERR_UNSUPPORTED, "%s: C=%d must be a multiple of 4", who, d->C);
+    const int es = kd_elem_size(d->dtype);
+    KD_REQUIRE(d->ldx >= d->C && (d->ldx * es) % (4 * es) == 0, KD_ERR_INVALID, "%s: bad ldx", who);
+    return KD_OK;
+}
+
+}  // namespace
+
+extern "C" int kd_pack_dw_weight(const float *src, float *dst, int32_t C, int32_t k, int32_t flip, kd_stream_t stream)
+{
+    KD_REQUIRE(src && dst && C > 0 && k > 0, KD_ERR_INVALID, "kd_pack_dw_weight: bad argument");
+    const int total = C * k * k;
+    hipLaunchKernelGGL(pack_dw_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, dst, C,
+                       k * k, flip);
+    KD_CHECK_LAUNCH("kd_pack_dw_weight");
+    return KD_OK;
+}
+
+extern "C" int kd_dwconv_fwd(const kd_dw_desc *d, const void *x, const float *w_taps, const float *bias, void *y,
+                             kd_stream_t stream)
+{
+    int rc = check_desc(d, "kd_dwconv_fwd");
+    if (rc) return rc;
+    KD_REQUIRE(x && w_taps && y, KD_ERR_INVALID, "kd_dwconv_fwd: null argument");
+    const int es = kd_elem_size(d->dtype);
+    KD_REQUIRE(d->ldy >= d->C && d->ldy % 4 == 0 && d->ldx % 4 == 0, KD_ERR_INVALID, "kd_dwconv_fwd: ld must be a multiple of 4");
+    KD_REQUIRE(((uintptr_t)x % (4 * es)) == 0 && ((uintptr_t)y % (4 * es)) == 0, KD_ERR_INVALID,
+               "kd_dwconv_fwd: x/y must be aligned to 4 elements");
+    DwParams p;
+    p.x = x; p.w = w_taps; p.bias = bias; p.y = y;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.pad = d->pad; p.dil = d->dil; p.ldx = d->ldx; p.ldy = d->ldy;
+    p.LH = (d->H + d->dil - 1) / d->dil;
+    p.LW = (d->W + d->dil - 1) / d->dil;
+    p.tiles_h = (p.LH + TS - 1) / TS;
+    p.tiles_w = (p.LW + TR - 1) / TR;
+    const dim3 grid((unsigned)((p.tiles_h * p.tiles_w + 15) / 16), (unsigned)((d->C + CB - 1) / CB),
+                    (unsigned)(d->N * d->dil * d->dil));
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == KD_BF16) {
+        if (d->k == 9) hipLaunchKernelGGL((dwconv_fwd_kernel<bf16_t, 9>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((dwconv_fwd_kernel<bf16_t, 3>), grid, dim3(256), 0, s, p);
+    } else {
+        if (d->k == 9) hipLaunchKernelGGL((dwconv_fwd_kernel<float, 9>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((dwconv_fwd_kernel<float, 3>), grid, dim3(256), 0, s, p);
+    }
+    KD_CHECK_LAUNCH("kd_dwconv_fwd");
+    return KD_OK;
+}
+
+static int wgrad_slabs(const kd_dw_desc *d)
+{
+    const int LH = (d->H + d->dil - 1) / d->dil;
+    const int nstrips = d->N * d->dil * d->dil * LH;
+    return (nstrips + 15) / 16;
+}
+
+extern "C" size_t kd_dwconv_wgrad_workspace(const kd_dw_desc *d)
+{
+    if (!d || d->dil < 1) return 0;
+    return (size_t)wgrad_slabs(d) * d->k * d->k * d->C * sizeof(float);
+}
+
+extern "C" int kd_dwconv_wgrad(const kd_dw_desc *d, const void *x, const void *dy, int32_t ld_dy, float *dw,
+                               int32_t accumulate, void *workspace, size_t workspace_bytes, kd_stream_t stream)
+{
+    int rc = check_desc(d, "kd_dwconv_wgrad");
+    if (rc) return rc;
+    KD_REQUIRE(x && dy && dw && workspace, KD_ERR_INVALID, "kd_dwconv_wgrad: null argument");
+    const int es = kd_elem_size(d->dtype);
+    KD_REQUIRE(ld_dy >= d->C && ld_dy % 4 == 0 && d->ldx % 4 == 0, KD_ERR_INVALID, "kd_dwconv_wgrad: ld must be a multiple of 4");
+    KD_REQUIRE(((uintptr_t)x % (4 * es)) == 0 && ((uintptr_t)dy % (4 * es)) == 0, KD_ERR_INVALID,
+               "kd_dwconv_wgrad: x/dy must be aligned to 4 elements");
+    KD_REQUIRE(workspace_bytes >= kd_dwconv_wgrad_workspace(d), KD_ERR_WORKSPACE, "kd_dwconv_wgrad: workspace too small");
+    DwWgradParams p;
+    p.x = x; p.dy = dy; p.part = (float *)workspace;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.pad = d->pad; p.dil = d->dil; p.ldx = d->ldx; p.ld_dy = ld_dy;
+    p.LH = (d->H + d->dil - 1) / d->dil;
+    p.LW = (d->W + d->dil - 1) / d->dil;
+    p.nstrips = d->N * d->dil * d->dil * p.LH;
+    const int slabs = wgrad_slabs(d);
+    const dim3 grid((unsigned)slabs, (unsigned)((d->C + CB - 1) / CB), (unsigned)d->k);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == KD_BF16) {
+        if (d->k == 9) hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16_t, 9>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16_t, 3>), grid, dim3(256), 0, s, p);
+    } else {
+        if (d->k == 9) hipLaunchKernelGGL((dwconv_wgrad_kernel<float, 9>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((dwconv_wgrad_kernel<float, 3>), grid, dim3(256), 0, s, p);
+    }
+    KD_CHECK_LAUNCH("kd_dwconv_wgrad");
+    const int total = d->k * d->k * d->C;
+    hipLaunchKernelGGL(dw_slab_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, (const float *)workspace, dw,
+                       slabs, d->k * d->k, d->C, accumulate);
+    KD_CHECK_LAUNCH("kd_dwconv_wgrad(reduce)");
+    return KD_OK;
+}

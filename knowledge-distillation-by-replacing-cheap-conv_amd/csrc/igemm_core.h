@@ -1,0 +1,53 @@
+// MFMA fragment math shared by the implicit-GEMM conv and the 1x1 weight-gradient kernels.
+// LDS tile format (both operands): 128 rows x 128 bytes of K, 16-B chunk c of row r stored at
+// slot c ^ (r & 7) -- conflict-free for the ds_read_b128 fragment reads below.
+#pragma once
+#include "kd_common.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+constexpr int IG_ROWB = 128;  // bytes of K per LDS row per stage
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    __device__ static __forceinline__ void run(const uint4 &a, const uint4 &b, f32x4_t &acc)
+    {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
+                                                      acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // the 16-B chunk holds 4 consecutive k; MFMA e consumes element e of every lane's chunk:
+    // lane (row r, quad q) supplies k = 4*chunk(q) + e on both operands, so the sum over q is consistent.
+    __device__ static __forceinline__ void run(const uint4 &a, const uint4 &b, f32x4_t &acc)
+    {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    }
+};
+
+// One K stage (128 B per row) of a wave's 64x64 sub-tile: acc[i][j] += A(rows wm*64+16i..)·B(rows wn*64+16j..)^T
+template <typename T>
+__device__ __forceinline__ void ig_compute_stage(const char *sA, const char *sB, int wm, int wn, int lane,
+                                                 f32x4_t (&acc)[4][4])
+{
+    const int frow = lane & 15, fq = lane >> 4;
+    const char *A = sA + (wm * 64 + frow) * IG_ROWB;
+    const char *B = sB + (wn * 64 + frow) * IG_ROWB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int sw = ((fq + 4 * ks) ^ (lane & 7)) << 4;
+        uint4 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *(const uint4 *)(A + i * 16 * IG_ROWB + sw);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *(const uint4 *)(B + j * 16 * IG_ROWB + sw);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
+    }
+}

@@ -1,0 +1,351 @@
+// KD losses, forward + gradient fused in one pass (kd_kldiv, kd_hint_mse,
+// kd_weighted_hint_mse, kd_ce2d) and the RAdam update (kd_radam_step).
+// All are HBM-bound streaming kernels.  Loss scalars are reduced in two fixed-order
+// stages (per-block partials in fp64 -> one finishing block), so results are
+// bit-reproducible run to run.
+#include "kd_common.h"
+
+namespace {
+
+constexpr int MAX_BLOCKS = 2048;
+
+__device__ __forceinline__ void block_partial(double v, double *partial)
+{
+    __shared__ double wsum[4];
+    v = wave_sum_d(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wsum[wv] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// loss = scale * sum(partial[0..n)) / (denom_ptr ? sum(partial2) : 1)
+__global__ __launch_bounds__(256) void finish_kernel(const double *partial, int n, double scale, const double *count,
+                                                     float *loss)
+{
+    __shared__ double sh[256], sc[256];
+    double s = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) { s += partial[i]; if (count) c += count[i]; }
+    sh[threadIdx.x] = s; sc[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { sh[threadIdx.x] += sh[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double v = sh[0] * scale;
+        if (count) v = sc[0] > 0.0 ? v / sc[0] : 0.0;
+        *loss = (float)v;
+    }
+}
+
+struct V3 { const void *p; int dt; long long sN, sC, sP; };
+struct M3 { void *p; int dt; long long sN, sC, sP; };
+
+// ---- KLDiv: one thread per pixel ----------------------------------------------------------
+__global__ __launch_bounds__(256) void kldiv_kernel(V3 s, V3 t, M3 g, float invT, float gscale, int N, int C, long long P,
+                                                    double *partial)
+{
+    double acc = 0.0;
+    const long long total = (long long)N * P;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long n = i / P, p = i - n * P;
+        const long long bs = n * s.sN + p * s.sP, bt = n * t.sN + p * t.sP;
+        float ms = -INFINITY, mt = -INFINITY;
+        for (int c = 0; c < C; ++c) {
+            ms = fmaxf(ms, kd_ld(s.p, s.dt, bs + c * s.sC) * invT);
+            mt = fmaxf(mt, kd_ld(t.p, t.dt, bt + c * t.sC) * invT);
+        }
+        float zs = 0.f, zt = 0.f;
+        for (int c = 0; c < C; ++c) {
+            zs += __expf(kd_ld(s.p, s.dt, bs + c * s.sC) * invT - ms);
+            zt += __expf(kd_ld(t.p, t.dt, bt + c * t.sC) * invT - mt);
+        }
+        const float lzs = __logf(zs) + ms, lzt = __logf(zt) + mt;
+        float kl = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float lps = kd_ld(s.p, s.dt, bs + c * s.sC) * invT - lzs;
+            const float lpt = kd_ld(t.p, t.dt, bt + c * t.sC) * invT - lzt;
+            const float pt = __expf(lpt);
+            kl += pt > 0.f ? pt * (lpt - lps) : 0.f;
+            if (g.p) kd_st(g.p, g.dt, n * g.sN + p * g.sP + c * g.sC, gscale * (__expf(lps) - pt));
+        }
+        acc += (double)kl;
+    }
+    block_partial(acc, partial);
+}
+
+// ---- hint MSE -----------------------------------------------------------------------------
+// contiguous fast path: s, t, g share one dense layout -> 8 elements per thread per step
+template <typename T>
+__global__ __launch_bounds__(256) void mse_vec_kernel(const T *__restrict__ s, const T *__restrict__ t, T *__restrict__ g,
+                                                      float gscale, long long n8, double *partial)
+{
+    float acc = 0.f;
+    double dacc = 0.0;
+    int cnt = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        float a[8], b[8], d[8];
+        ld8(s + i * 8, a);
+        ld8(t + i * 8, b);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { d[q] = a[q] - b[q]; acc = fmaf(d[q], d[q], acc); }
+        if (g) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) d[q] *= gscale;
+            st8(g + i * 8, d);
+        }
+        if (++cnt == 16) { dacc += (double)acc; acc = 0.f; cnt = 0; }  // bound fp32 accumulation length
+    }
+    dacc += (double)acc;
+    block_partial(dacc, partial);
+}
+__global__ __launch_bounds__(256) void mse_strided_kernel(V3 s, V3 t, M3 g, float gscale, int N, int C, long long P,
+                                                          int c_fast, double *partial)
+{
+    double acc = 0.0;
+    const long long total = (long long)N * C * P;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        long long n, c, p;
+        if (c_fast) { c = i % C; const long long r = i / C; p = r % P; n = r / P; }
+        else { p = i % P; const long long r = i / P; c = r % C; n = r / C; }
+        const float d = kd_ld(s.p, s.dt, n * s.sN + c * s.sC + p * s.sP) - kd_ld(t.p, t.dt, n * t.sN + c * t.sC + p * t.sP);
+        acc += (double)d * d;
+        if (g.p) kd_st(g.p, g.dt, n * g.sN + c * g.sC + p * g.sP, gscale * d);
+    }
+    block_partial(acc, partial);
+}
+
+// ---- weighted hint MSE ---------------------------------------------------------------------
+__global__ void wsum_kernel(const float *w, int per_sample, int N, int C, float *wsum)
+{
+    // one wave per sample
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const float *wn = w + (per_sample ? (size_t)n * C : 0);
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += wn[c];
+    s = wave_sum(s);
+    if (lane == 0) wsum[n] = s;
+}
+// grid: x = P chunks, y = ceil(C/256), z = N ; thread = one channel, loops over its pixel chunk
+__global__ __launch_bounds__(256) void whmse_kernel(V3 s, V3 t, M3 g, const float *w, int per_sample, const float *wsum,
+                                                    float gscale, int N, int C, long long P, long long per_chunk,
+                                                    double *partial)
+{
+    const int c = blockIdx.y * 256 + threadIdx.x, n = blockIdx.z;
+    double contrib = 0.0;
+    if (c < C) {
+        const float wc = w[(per_sample ? (size_t)n * C : 0) + c], ws = wsum[n];
+        const float gs = gscale * wc / (ws * (float)N * (float)P) * 2.f;
+        const long long p0 = blockIdx.x * per_chunk, p1 = min(P, p0 + per_chunk);
+        float acc = 0.f;
+        for (long long p = p0; p < p1; ++p) {
+            const float d = kd_ld(s.p, s.dt, n * s.sN + c * s.sC + p * s.sP) - kd_ld(t.p, t.dt, n * t.sN + c * t.sC + p * t.sP);
+            acc = fmaf(d, d, acc);
+            if (g.p) kd_st(g.p, g.dt, n * g.sN + c * g.sC + p * g.sP, gs * d);
+        }
+        contrib = (double)acc * (double)wc / ((double)ws * (double)P);
+    }
+    // block partial, flattened block index
+    __shared__ double wsm[4];
+    contrib = wave_sum_d(contrib);
+    if ((threadIdx.x & 63) == 0) wsm[threadIdx.x >> 6] = contrib;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        partial[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = wsm[0] + wsm[1] + wsm[2] + wsm[3];
+}
+
+// ---- cross entropy (logged metric) ----------------------------------------------------------
+__global__ __launch_bounds__(256) void ce2d_kernel(V3 x, const int64_t *target, int ignore_index, int N, int C, long long P,
+                                                   double *partial, double *count)
+{
+    double acc = 0.0, cnt = 0.0;
+    const long long total = (long long)N * P;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int64_t y = target[i];
+        if (y == ignore_index || y < 0 || y >= C) continue;
+        const long long n = i / P, p = i - n * P;
+        const long long b = n * x.sN + p * x.sP;
+        float m = -INFINITY;
+        for (int c = 0; c < C; ++c) m = fmaxf(m, kd_ld(x.p, x.dt, b + c * x.sC));
+        float z = 0.f;
+        for (int c = 0; c < C; ++c) z += __expf(kd_ld(x.p, x.dt, b + c * x.sC) - m);
+        acc += (double)(-(kd_ld(x.p, x.dt, b + y * x.sC) - m - __logf(z)));
+        cnt += 1.0;
+    }
+    __shared__ double w1[4], w2[4];
+    acc = wave_sum_d(acc); cnt = wave_sum_d(cnt);
+    if ((threadIdx.x & 63) == 0) { w1[threadIdx.x >> 6] = acc; w2[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) { partial[blockIdx.x] = w1[0] + w1[1] + w1[2] + w1[3]; count[blockIdx.x] = w2[0] + w2[1] + w2[2] + w2[3]; }
+}
+
+// ---- RAdam ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void radam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                    float *__restrict__ v, long long n, float beta1, float beta2, float eps,
+                                                    float wd_lr, float step_lr, int rectified)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gi = g[i];
+        const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+        const float mi = m[i] * beta1 + (1.f - beta1) * gi;
+        v[i] = vi; m[i] = mi;
+        float pi = p[i];
+        if (wd_lr != 0.f) pi += -wd_lr * pi;
+        pi += rectified ? -step_lr * mi / (sqrtf(vi) + eps) : -step_lr * mi;
+        p[i] = pi;
+    }
+}
+
+inline V3 v3(const kd_view3 *v) { return V3{v->ptr, v->dtype, (long long)v->sN, (long long)v->sC, (long long)v->sP}; }
+inline M3 m3(const kd_mview3 *v)
+{
+    if (!v) return M3{nullptr, 0, 0, 0, 0};
+    return M3{v->ptr, v->dtype, (long long)v->sN, (long long)v->sC, (long long)v->sP};
+}
+inline bool ok_dt(int d) { return d == KD_F32 || d == KD_BF16; }
+inline int blocks_for(long long total)
+{
+    long long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > MAX_BLOCKS ? MAX_BLOCKS : b));
+}
+inline bool dense_same(const kd_view3 *a, const kd_view3 *b, const kd_mview3 *g, int N, int C, long long P)
+{
+    // every operand covers exactly N*C*P elements with the same (dense) strides
+    auto dense = [&](long long sN, long long sC, long long sP) {
+        return (sC == 1 && sP == C && sN == (long long)C * P) || (sP == 1 && sC == P && sN == (long long)C * P);
+    };
+    if (!dense(a->sN, a->sC, a->sP)) return false;
+    if (a->sN != b->sN || a->sC != b->sC || a->sP != b->sP || a->dtype != b->dtype) return false;
+    if (g && (g->sN != a->sN || g->sC != a->sC || g->sP != a->sP || g->dtype != a->dtype)) return false;
+    if (!kd_aligned16(a->ptr) || !kd_aligned16(b->ptr) || (g && !kd_aligned16(g->ptr))) return false;
+    return ((long long)N * C * P) % 8 == 0;
+}
+
+}  // namespace
+
+extern "C" size_t kd_loss_workspace(int32_t N, int32_t C, int64_t P)
+{
+    // partial sums (+ counts) for up to MAX_BLOCKS blocks, the weighted loss' per-sample weight sums,
+    // and its (P chunks x channel blocks x N) partials
+    const size_t wh_blocks = (size_t)64 * ((C + 255) / 256) * (size_t)N;
+    const size_t nb = wh_blocks > (size_t)MAX_BLOCKS ? wh_blocks : (size_t)MAX_BLOCKS;
+    (void)P;
+    return 2 * nb * sizeof(double) + (size_t)N * sizeof(float) + 64;
+}
+
+#define KD_LOSS_COMMON(who)                                                                                          \
+    KD_REQUIRE(s && t && s->ptr && t->ptr && loss && workspace, KD_ERR_INVALID, who ": null argument");              \
+    KD_REQUIRE(ok_dt(s->dtype) && ok_dt(t->dtype) && (!grad || ok_dt(grad->dtype)), KD_ERR_INVALID, who ": bad dtype"); \
+    KD_REQUIRE(N > 0 && C > 0 && P > 0, KD_ERR_INVALID, who ": bad shape");                                          \
+    KD_REQUIRE(workspace_bytes >= kd_loss_workspace(N, C, P), KD_ERR_WORKSPACE, who ": workspace too small");        \
+    KD_REQUIRE(((uintptr_t)workspace & 7) == 0, KD_ERR_INVALID, who ": workspace must be 8-B aligned")
+
+extern "C" int kd_kldiv(const kd_view3 *s, const kd_view3 *t, float temperature, int32_t N, int32_t C, int64_t P, float *loss,
+                        const kd_mview3 *grad, float grad_scale, void *workspace, size_t workspace_bytes, kd_stream_t stream)
+{
+    KD_LOSS_COMMON("kd_kldiv");
+    KD_REQUIRE(temperature > 0.f, KD_ERR_INVALID, "kd_kldiv: temperature must be positive");
+    double *partial = (double *)workspace;
+    const int nb = blocks_for((long long)N * P);
+    hipStream_t st = (hipStream_t)stream;
+    const float gscale = grad_scale * temperature / ((float)N * (float)P);
+    hipLaunchKernelGGL(kldiv_kernel, dim3(nb), dim3(256), 0, st, v3(s), v3(t), m3(grad), 1.f / temperature, gscale, N, C,
+                       (long long)P, partial);
+    KD_CHECK_LAUNCH("kd_kldiv");
+    // 'mean' over N*C*P elements, then * T^2 * C  ==  T^2 / (N*P) * sum
+    const double scale = (double)temperature * temperature / ((double)N * (double)P);
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, (const double *)partial, nb, scale, (const double *)nullptr, loss);
+    KD_CHECK_LAUNCH("kd_kldiv(finish)");
+    return KD_OK;
+}
+
+extern "C" int kd_hint_mse(const kd_view3 *s, const kd_view3 *t, float num_classes, int32_t N, int32_t C, int64_t P,
+                           float *loss, const kd_mview3 *grad, float grad_scale, void *workspace, size_t workspace_bytes,
+                           kd_stream_t stream)
+{
+    KD_LOSS_COMMON("kd_hint_mse");
+    double *partial = (double *)workspace;
+    const long long numel = (long long)N * C * P;
+    const float gscale = grad_scale * 2.f * num_classes / (float)numel;
+    hipStream_t st = (hipStream_t)stream;
+    int nb;
+    if (dense_same(s, t, grad, N, C, P)) {
+        nb = blocks_for(numel / 8);
+        if (s->dtype == KD_BF16)
+            hipLaunchKernelGGL(mse_vec_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t *)s->ptr, (const bf16_t *)t->ptr,
+                               (bf16_t *)(grad ? grad->ptr : nullptr), gscale, numel / 8, partial);
+        else
+            hipLaunchKernelGGL(mse_vec_kernel<float>, dim3(nb), dim3(256), 0, st, (const float *)s->ptr, (const float *)t->ptr,
+                               (float *)(grad ? grad->ptr : nullptr), gscale, numel / 8, partial);
+    } else {
+        nb = blocks_for(numel);
+        hipLaunchKernelGGL(mse_strided_kernel, dim3(nb), dim3(256), 0, st, v3(s), v3(t), m3(grad), gscale, N, C, (long long)P,
+                           s->sC == 1 ? 1 : 0, partial);
+    }
+    KD_CHECK_LAUNCH("kd_hint_mse");
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, (const double *)partial, nb, (double)num_classes / (double)numel,
+                       (const double *)nullptr, loss);
+    KD_CHECK_LAUNCH("kd_hint_mse(finish)");
+    return KD_OK;
+}
+
+extern "C" int kd_weighted_hint_mse(const kd_view3 *s, const kd_view3 *t, const float *w, int32_t w_per_sample, int32_t N,
+                                    int32_t C, int64_t P, float *loss, const kd_mview3 *grad, float grad_scale, void *workspace,
+                                    size_t workspace_bytes, kd_stream_t stream)
+{
+    KD_LOSS_COMMON("kd_weighted_hint_mse");
+    KD_REQUIRE(w, KD_ERR_INVALID, "kd_weighted_hint_mse: null weight");
+    hipStream_t st = (hipStream_t)stream;
+    const int chunks = (int)(P < 64 ? P : 64);
+    const long long per_chunk = (P + chunks - 1) / chunks;
+    const dim3 grid((unsigned)chunks, (unsigned)((C + 255) / 256), (unsigned)N);
+    const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+    double *partial = (double *)workspace;
+    float *wsum = (float *)((char *)workspace + 2 * (nblocks > (size_t)MAX_BLOCKS ? nblocks : (size_t)MAX_BLOCKS) * sizeof(double));
+    hipLaunchKernelGGL(wsum_kernel, dim3(N), dim3(64), 0, st, w, w_per_sample, N, C, wsum);
+    hipLaunchKernelGGL(whmse_kernel, grid, dim3(256), 0, st, v3(s), v3(t), m3(grad), w, w_per_sample, (const float *)wsum,
+                       grad_scale, N, C, (long long)P, per_chunk, partial);
+    KD_CHECK_LAUNCH("kd_weighted_hint_mse");
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, (const double *)partial, (int)nblocks, 1.0 / (double)N,
+                       (const double *)nullptr, loss);
+    KD_CHECK_LAUNCH("kd_weighted_hint_mse(finish)");
+    return KD_OK;
+}
+
+extern "C" int kd_ce2d(const kd_view3 *x, const int64_t *target, int32_t ignore_index, int32_t N, int32_t C, int64_t P,
+                       float *loss, void *workspace, size_t workspace_bytes, kd_stream_t stream)
+{
+    KD_REQUIRE(x && x->ptr && target && loss && workspace, KD_ERR_INVALID, "kd_ce2d: null argument");
+    KD_REQUIRE(ok_dt(x->dtype) && N > 0 && C > 0 && P > 0, KD_ERR_INVALID, "kd_ce2d: bad argument");
+    KD_REQUIRE(workspace_bytes >= kd_loss_workspace(N, C, P), KD_ERR_WORKSPACE, "kd_ce2d: workspace too small");
+    double *partial = (double *)workspace, *count = partial + MAX_BLOCKS;
+    const int nb = blocks_for((long long)N * P);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ce2d_kernel, dim3(nb), dim3(256), 0, st, v3(x), target, ignore_index, N, C, (long long)P, partial, count);
+    KD_CHECK_LAUNCH("kd_ce2d");
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, (const double *)partial, nb, 1.0, (const double *)count, loss);
+    KD_CHECK_LAUNCH("kd_ce2d(finish)");
+    return KD_OK;
+}
+
+extern "C" int kd_radam_step(float *p, const float *g, float *exp_avg, float *exp_avg_sq, int64_t n, int32_t step, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, kd_stream_t stream)
+{
+    KD_REQUIRE(p && g && exp_avg && exp_avg_sq && n > 0 && step >= 1, KD_ERR_INVALID, "kd_radam_step: bad argument");
+    // (N_sma, step_size) exactly as utils/optim/radam.py:64-83 computes (and caches) them
+    const double beta2_t = pow((double)beta2, step);
+    const double nmax = 2.0 / (1.0 - (double)beta2) - 1.0;
+    const double nsma = nmax - 2.0 * step * beta2_t / (1.0 - beta2_t);
+    double step_size;
+    const int rect = nsma >= 5.0;
+    if (rect)
+        step_size = sqrt((1 - beta2_t) * (nsma - 4) / (nmax - 4) * (nsma - 2) / nsma * nmax / (nmax - 2)) /
+                    (1 - pow((double)beta1, step));
+    else
+        step_size = 1.0 / (1 - pow((double)beta1, step));
+    hipLaunchKernelGGL(radam_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg, exp_avg_sq,
+                       (long long)n, beta1, beta2, eps, (float)((double)weight_decay * lr), (float)(step_size * lr), rect);
+    KD_CHECK_LAUNCH("kd_radam_step");
+    return KD_OK;
+}

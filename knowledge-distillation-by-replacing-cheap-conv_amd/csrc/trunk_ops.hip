@@ -1,0 +1,386 @@
+// HBM-bound trunk plumbing around the convolutions: stem conv, max-pool (+BN/ReLU),
+// bilinear align_corners upsample, ASPP image pooling, BN folding, strided copy/cast.
+// Also hosts the error plumbing of the C-ABI.
+#include <stdarg.h>
+#include <string.h>
+
+#include "kd_common.h"
+
+static thread_local char g_err[512] = "";
+
+void kd_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int kd_version(void) { return 100; }
+extern "C" const char *kd_last_error(void) { return g_err; }
+
+namespace {
+
+// ---- stem conv 3 -> 64, 3x3, pad 1, NCHW fp32 in, NHWC out ---------------------------
+// block = 64 pixels x 4 channel groups of 16; weights (27 x 64) in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                        T *__restrict__ y, int N, int H, int W)
+{
+    __shared__ __attribute__((aligned(16))) float wl[27 * 64];  // [ci*9 + ky*3 + kx][co]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 27 * 64; i += 256) {
+        const int t = i >> 6, co = i & 63;
+        wl[i] = w[co * 27 + t];
+    }
+    __syncthreads();
+    const int cg = tid >> 6;  // 16-channel group (wave-uniform)
+    const long long pix = (long long)blockIdx.x * 64 + (tid & 63);
+    const long long HW = (long long)H * W;
+    if (pix >= (long long)N * HW) return;
+    const int n = (int)(pix / HW);
+    const int rem = (int)(pix - (long long)n * HW);
+    const int h = rem / W, ww = rem - h * W;
+    float acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int hi = h - 1 + ky;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int wi = ww - 1 + kx;
+                float v = 0.f;
+                if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = x[((size_t)(n * 3 + ci) * H + hi) * W + wi];
+                const float *wr = &wl[(ci * 9 + ky * 3 + kx) * 64 + cg * 16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[q] = fmaf(v, wr[q], acc[q]);
+            }
+        }
+    T *o = y + (size_t)pix * 64 + cg * 16;
+    float lo[8], hi8[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { lo[q] = acc[q]; hi8[q] = acc[8 + q]; }
+    st8(o, lo);
+    st8(o + 8, hi8);
+}
+
+// ---- max-pool 3x3 / stride 2 / pad 1 (+ optional BN-eval + ReLU second output) ---------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T *__restrict__ x, int ldx, T *__restrict__ y_raw, int ld_raw,
+                                                      T *__restrict__ y_act, int ld_act, const float *__restrict__ scale,
+                                                      const float *__restrict__ shift, int N, int H, int W, int C, int Ho,
+                                                      int Wo)
+{
+    const int c8 = C >> 3;
+    const long long total = (long long)N * Ho * Wo * c8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cq = (int)(i % c8);
+        long long r = i / c8;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        float m[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m[q] = -INFINITY;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int hi = ho * 2 - 1 + ky;
+            if (hi < 0 || hi >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int wi = wo * 2 - 1 + kx;
+                if (wi < 0 || wi >= W) continue;
+                float v[8];
+                ld8(x + (((size_t)n * H + hi) * W + wi) * ldx + cq * 8, v);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], v[q]);
+            }
+        }
+        const size_t op = ((size_t)n * Ho + ho) * Wo + wo;
+        if (y_raw) st8(y_raw + op * ld_raw + cq * 8, m);
+        if (y_act) {
+            float a[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = fmaxf(fmaf(m[q], scale[cq * 8 + q], shift[cq * 8 + q]), 0.f);
+            st8(y_act + op * ld_act + cq * 8, a);
+        }
+    }
+}
+
+// ---- bilinear upsample, align_corners=True ---------------------------------------------
+template <typename TI, typename TO, int VEC>
+__global__ __launch_bounds__(256) void upsample_kernel(const TI *__restrict__ x, int ldx, TO *__restrict__ y, int ldy, int N,
+                                                       int H, int W, int C, int Ho, int Wo, float sh, float sw)
+{
+    const int cv = C / VEC;
+    const long long total = (long long)N * Ho * Wo * cv;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cq = (int)(i % cv);
+        long long r = i / cv;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        const float fh = ho * sh, fw = wo * sw;
+        int h0 = (int)fh; h0 = h0 > H - 1 ? H - 1 : h0;
+        int w0 = (int)fw; w0 = w0 > W - 1 ? W - 1 : w0;
+        const int h1 = h0 + 1 < H ? h0 + 1 : H - 1, w1 = w0 + 1 < W ? w0 + 1 : W - 1;
+        const float ah = fh - h0, aw = fw - w0;
+        const TI *b = x + (size_t)n * H * W * ldx + cq * VEC;
+        const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * ldy + cq * VEC;
+        if constexpr (VEC == 8) {
+            float a00[8], a01[8], a10[8], a11[8], v[8];
+            ld8(b + ((size_t)h0 * W + w0) * ldx, a00);
+            ld8(b + ((size_t)h0 * W + w1) * ldx, a01);
+            ld8(b + ((size_t)h1 * W + w0) * ldx, a10);
+            ld8(b + ((size_t)h1 * W + w1) * ldx, a11);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                v[q] = (1.f - ah) * ((1.f - aw) * a00[q] + aw * a01[q]) + ah * ((1.f - aw) * a10[q] + aw * a11[q]);
+            st8(y + o, v);
+        } else {
+            const float a00 = Elem<TI>::ld(b + ((size_t)h0 * W + w0) * ldx), a01 = Elem<TI>::ld(b + ((size_t)h0 * W + w1) * ldx);
+            const float a10 = Elem<TI>::ld(b + ((size_t)h1 * W + w0) * ldx), a11 = Elem<TI>::ld(b + ((size_t)h1 * W + w1) * ldx);
+            Elem<TO>::st(y + o, (1.f - ah) * ((1.f - aw) * a00 + aw * a01) + ah * ((1.f - aw) * a10 + aw * a11));
+        }
+    }
+}
+
+// ---- ASPP image pooling ------------------------------------------------------------------
+constexpr int GAP_CHUNKS = 64;
+// partial[chunk][n][c] = sum over the chunk's pixels; block = 32 channel octets x 8 pixel lanes
+template <typename T>
+__global__ __launch_bounds__(256) void gap_partial_kernel(const T *__restrict__ x, int ldx, float *__restrict__ partial,
+                                                          int N, int HW, int C)
+{
+    __shared__ float red[8][256 + 8];
+    const int co = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int c = blockIdx.y * 256 + co * 8;
+    const int n = blockIdx.z, chunk = blockIdx.x;
+    const int per = (HW + GAP_CHUNKS - 1) / GAP_CHUNKS;
+    const int p0 = chunk * per, p1 = min(HW, p0 + per);
+    float s[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s[q] = 0.f;
+    if (c < C)
+        for (int p = p0 + pl; p < p1; p += 8) {
+            float v[8];
+            ld8(x + ((size_t)n * HW + p) * ldx + c, v);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s[q] += v[q];
+        }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) red[pl][co * 8 + q] = s[q];
+    __syncthreads();
+    const int cc = threadIdx.x;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cc];
+    if (blockIdx.y * 256 + cc < C) partial[((size_t)chunk * N + n) * C + blockIdx.y * 256 + cc] = t;
+}
+// mean[n][c], then out[n][co] = relu(scale*dot(w[co], mean[n]) + shift); one block per (co-block of 4 waves, n)
+__global__ __launch_bounds__(256) void gap_finish_kernel(const float *__restrict__ partial, float *__restrict__ mean,
+                                                         int N, int HW, int C)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C) return;
+    float s = 0.f;
+    for (int k = 0; k < GAP_CHUNKS; ++k) s += partial[(size_t)k * N * C + i];
+    mean[i] = s / (float)HW;
+}
+__global__ __launch_bounds__(256) void img_conv_kernel(const float *__restrict__ mean, const float *__restrict__ w,
+                                                       const float *__restrict__ scale, const float *__restrict__ shift,
+                                                       float *__restrict__ out, int Cin, int Cout)
+{
+    // one wave per output channel
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int co = blockIdx.x * 4 + wv, n = blockIdx.y;
+    if (co >= Cout) return;
+    float s = 0.f;
+    for (int ci = lane; ci < Cin; ci += 64) s = fmaf(w[(size_t)co * Cin + ci], mean[(size_t)n * Cin + ci], s);
+    s = wave_sum(s);
+    if (lane == 0) out[(size_t)n * Cout + co] = fmaxf(s * scale[co] + shift[co], 0.f);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void broadcast_kernel(const float *__restrict__ v, T *__restrict__ y, int ldy, int N,
+                                                        int HW, int C)
+{
+    const int c8 = C >> 3;
+    const long long total = (long long)N * HW * c8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cq = (int)(i % c8);
+        const long long pix = i / c8;
+        const int n = (int)(pix / HW);
+        float t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = v[(size_t)n * C + cq * 8 + q];
+        st8(y + (size_t)pix * ldy + cq * 8, t);
+    }
+}
+
+__global__ void bn_fold_kernel(const float *g, const float *b, const float *m, const float *v, float eps, float *scale,
+                               float *shift, int C)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = g[c] / sqrtf(v[c] + eps);
+    scale[c] = sc;
+    shift[c] = b[c] - m[c] * sc;
+}
+
+__global__ __launch_bounds__(256) void copy_cast_kernel(const void *src, int sdt, long long s_sN, long long s_sC,
+                                                        long long s_sP, void *dst, int ddt, long long d_sN, long long d_sC,
+                                                        long long d_sP, int N, int C, long long P, int c_fast)
+{
+    const long long total = (long long)N * C * P;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        long long n, c, p;
+        if (c_fast) { c = i % C; const long long r = i / C; p = r % P; n = r / P; }
+        else { p = i % P; const long long r = i / P; c = r % C; n = r / C; }
+        kd_st(dst, ddt, n * d_sN + c * d_sC + p * d_sP, kd_ld(src, sdt, n * s_sN + c * s_sC + p * s_sP));
+    }
+}
+
+inline int grid_for(long long total, int cap = 8192)
+{
+    long long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+extern "C" int kd_stem_conv(int32_t dtype, const float *x_nchw, const float *w, void *y, int32_t N, int32_t H, int32_t W,
+                            kd_stream_t stream)
+{
+    KD_REQUIRE(x_nchw && w && y && N > 0 && H > 0 && W > 0, KD_ERR_INVALID, "kd_stem_conv: bad argument");
+    KD_REQUIRE(dtype == KD_F32 || dtype == KD_BF16, KD_ERR_INVALID, "kd_stem_conv: bad dtype");
+    KD_REQUIRE(kd_aligned16(y), KD_ERR_INVALID, "kd_stem_conv: y must be 16-B aligned");
+    const long long pix = (long long)N * H * W;
+    const dim3 grid((unsigned)((pix + 63) / 64));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == KD_BF16) hipLaunchKernelGGL(stem_conv_kernel<bf16_t>, grid, dim3(256), 0, s, x_nchw, w, (bf16_t *)y, N, H, W);
+    else hipLaunchKernelGGL(stem_conv_kernel<float>, grid, dim3(256), 0, s, x_nchw, w, (float *)y, N, H, W);
+    KD_CHECK_LAUNCH("kd_stem_conv");
+    return KD_OK;
+}
+
+extern "C" int kd_maxpool3x3s2(int32_t dtype, const void *x, int32_t ldx, void *y_raw, int32_t ld_raw, void *y_act,
+                               int32_t ld_act, const float *scale, const float *shift, int32_t N, int32_t H, int32_t W,
+                               int32_t C, kd_stream_t stream)
+{
+    KD_REQUIRE(x && (y_raw || y_act), KD_ERR_INVALID, "kd_maxpool3x3s2: null argument");
+    KD_REQUIRE(dtype == KD_F32 || dtype == KD_BF16, KD_ERR_INVALID, "kd_maxpool3x3s2: bad dtype");
+    KD_REQUIRE(!y_act || (scale && shift), KD_ERR_INVALID, "kd_maxpool3x3s2: y_act needs scale/shift");
+    const int es = kd_elem_size(dtype);
+    KD_REQUIRE(C % 8 == 0 && kd_aligned16(x) && (ldx * es) % 16 == 0 && (!y_raw || (kd_aligned16(y_raw) && (ld_raw * es) % 16 == 0)) &&
+                   (!y_act || (kd_aligned16(y_act) && (ld_act * es) % 16 == 0)),
+               KD_ERR_INVALID, "kd_maxpool3x3s2: C %% 8 and 16-B alignment required");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long total = (long long)N * Ho * Wo * (C / 8);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == KD_BF16)
+        hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3(grid_for(total, 1 << 20)), dim3(256), 0, s, (const bf16_t *)x, ldx,
+                           (bf16_t *)y_raw, ld_raw, (bf16_t *)y_act, ld_act, scale, shift, N, H, W, C, Ho, Wo);
+    else
+        hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid_for(total, 1 << 20)), dim3(256), 0, s, (const float *)x, ldx,
+                           (float *)y_raw, ld_raw, (float *)y_act, ld_act, scale, shift, N, H, W, C, Ho, Wo);
+    KD_CHECK_LAUNCH("kd_maxpool3x3s2");
+    return KD_OK;
+}
+
+template <typename TI, typename TO>
+static void launch_up(const void *x, int ldx, void *y, int ldy, int N, int H, int W, int C, int Ho, int Wo, bool vec,
+                      hipStream_t s)
+{
+    const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+    const float sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    if (vec) {
+        const long long total = (long long)N * Ho * Wo * (C / 8);
+        hipLaunchKernelGGL((upsample_kernel<TI, TO, 8>), dim3(grid_for(total, 1 << 20)), dim3(256), 0, s, (const TI *)x, ldx,
+                           (TO *)y, ldy, N, H, W, C, Ho, Wo, sh, sw);
+    } else {
+        const long long total = (long long)N * Ho * Wo * C;
+        hipLaunchKernelGGL((upsample_kernel<TI, TO, 1>), dim3(grid_for(total, 1 << 20)), dim3(256), 0, s, (const TI *)x, ldx,
+                           (TO *)y, ldy, N, H, W, C, Ho, Wo, sh, sw);
+    }
+}
+
+extern "C" int kd_upsample_bilinear_ac(const void *x, int32_t x_dtype, int32_t ldx, void *y, int32_t y_dtype, int32_t ldy,
+                                       int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
+                                       kd_stream_t stream)
+{
+    KD_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0, KD_ERR_INVALID,
+               "kd_upsample_bilinear_ac: bad argument");
+    KD_REQUIRE((x_dtype == KD_F32 || x_dtype == KD_BF16) && (y_dtype == KD_F32 || y_dtype == KD_BF16), KD_ERR_INVALID,
+               "kd_upsample_bilinear_ac: bad dtype");
+    const bool vec = C % 8 == 0 && kd_aligned16(x) && kd_aligned16(y) && (ldx * kd_elem_size(x_dtype)) % 16 == 0 &&
+                     (ldy * kd_elem_size(y_dtype)) % 16 == 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (x_dtype == KD_BF16 && y_dtype == KD_BF16) launch_up<bf16_t, bf16_t>(x, ldx, y, ldy, N, H, W, C, Ho, Wo, vec, s);
+    else if (x_dtype == KD_BF16) launch_up<bf16_t, float>(x, ldx, y, ldy, N, H, W, C, Ho, Wo, vec, s);
+    else if (y_dtype == KD_BF16) launch_up<float, bf16_t>(x, ldx, y, ldy, N, H, W, C, Ho, Wo, vec, s);
+    else launch_up<float, float>(x, ldx, y, ldy, N, H, W, C, Ho, Wo, vec, s);
+    KD_CHECK_LAUNCH("kd_upsample_bilinear_ac");
+    return KD_OK;
+}
+
+extern "C" size_t kd_aspp_image_pool_workspace(int32_t N, int32_t Cin, int32_t Cout)
+{
+    return ((size_t)GAP_CHUNKS * N * Cin + (size_t)N * Cin + (size_t)N * Cout) * sizeof(float);
+}
+
+extern "C" int kd_aspp_image_pool(int32_t dtype, const void *x, int32_t ldx, const float *w, const float *scale,
+                                  const float *shift, void *y, int32_t ldy, int32_t N, int32_t H, int32_t W, int32_t Cin,
+                                  int32_t Cout, void *workspace, size_t workspace_bytes, kd_stream_t stream)
+{
+    KD_REQUIRE(x && w && scale && shift && y && workspace, KD_ERR_INVALID, "kd_aspp_image_pool: null argument");
+    KD_REQUIRE(dtype == KD_F32 || dtype == KD_BF16, KD_ERR_INVALID, "kd_aspp_image_pool: bad dtype");
+    const int es = kd_elem_size(dtype);
+    KD_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && kd_aligned16(x) && kd_aligned16(y) && (ldx * es) % 16 == 0 && (ldy * es) % 16 == 0,
+               KD_ERR_INVALID, "kd_aspp_image_pool: channels %% 8 and 16-B alignment required");
+    KD_REQUIRE(workspace_bytes >= kd_aspp_image_pool_workspace(N, Cin, Cout), KD_ERR_WORKSPACE,
+               "kd_aspp_image_pool: workspace too small");
+    float *partial = (float *)workspace;
+    float *mean = partial + (size_t)GAP_CHUNKS * N * Cin;
+    float *vec = mean + (size_t)N * Cin;
+    const int HW = H * W;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g1(GAP_CHUNKS, (Cin + 255) / 256, N);
+    if (dtype == KD_BF16) hipLaunchKernelGGL(gap_partial_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t *)x, ldx, partial, N, HW, Cin);
+    else hipLaunchKernelGGL(gap_partial_kernel<float>, g1, dim3(256), 0, s, (const float *)x, ldx, partial, N, HW, Cin);
+    KD_CHECK_LAUNCH("kd_aspp_image_pool(partial)");
+    hipLaunchKernelGGL(gap_finish_kernel, dim3((N * Cin + 255) / 256), dim3(256), 0, s, partial, mean, N, HW, Cin);
+    hipLaunchKernelGGL(img_conv_kernel, dim3((Cout + 3) / 4, N), dim3(256), 0, s, mean, w, scale, shift, vec, Cin, Cout);
+    const long long total = (long long)N * HW * (Cout / 8);
+    if (dtype == KD_BF16) hipLaunchKernelGGL(broadcast_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, vec, (bf16_t *)y, ldy, N, HW, Cout);
+    else hipLaunchKernelGGL(broadcast_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, vec, (float *)y, ldy, N, HW, Cout);
+    KD_CHECK_LAUNCH("kd_aspp_image_pool");
+    return KD_OK;
+}
+
+extern "C" int kd_bn_fold(const float *gamma, const float *beta, const float *mean, const float *var, float eps,
+                          float *scale, float *shift, int32_t C, kd_stream_t stream)
+{
+    KD_REQUIRE(gamma && beta && mean && var && scale && shift && C > 0, KD_ERR_INVALID, "kd_bn_fold: bad argument");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, mean, var, eps,
+                       scale, shift, C);
+    KD_CHECK_LAUNCH("kd_bn_fold");
+    return KD_OK;
+}
+
+extern "C" int kd_copy_cast(const void *src, int32_t src_dtype, int64_t s_sN, int64_t s_sC, int64_t s_sP, void *dst,
+                            int32_t dst_dtype, int64_t d_sN, int64_t d_sC, int64_t d_sP, int32_t N, int32_t C, int64_t P,
+                            kd_stream_t stream)
+{
+    KD_REQUIRE(src && dst && N > 0 && C > 0 && P > 0, KD_ERR_INVALID, "kd_copy_cast: bad argument");
+    KD_REQUIRE((src_dtype == KD_F32 || src_dtype == KD_BF16) && (dst_dtype == KD_F32 || dst_dtype == KD_BF16),
+               KD_ERR_INVALID, "kd_copy_cast: bad dtype");
+    const long long total = (long long)N * C * P;
+    hipLaunchKernelGGL(copy_cast_kernel, dim3(grid_for(total, 1 << 20)), dim3(256), 0, (hipStream_t)stream, src, src_dtype,
+                       (long long)s_sN, (long long)s_sC, (long long)s_sP, dst, dst_dtype, (long long)d_sN, (long long)d_sC,
+                       (long long)d_sP, N, C, (long long)P, d_sC == 1 ? 1 : 0);
+    KD_CHECK_LAUNCH("kd_copy_cast");
+    return KD_OK;
+}

@@ -1,0 +1,346 @@
+"""Tensor-level wrappers over the C-ABI (include/kdcc.h).
+
+Activations are torch tensors of logical shape (N, H, W, C) whose last
+dimension is dense and whose pixel stride `ld` may exceed C (a channel slice of
+a wider NHWC buffer).  Every function validates shapes on the host before a
+kernel is launched and enqueues on torch's current HIP stream.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import KD_BF16, KD_F32, KD_PACK_DGRAD, KD_PACK_FWD, ConvDesc, ConvEpilogue, DwDesc, View3, check
+
+
+def dt_of(t):
+    if t.dtype == torch.bfloat16:
+        return KD_BF16
+    if t.dtype == torch.float32:
+        return KD_F32
+    raise TypeError(f"unsupported dtype {t.dtype} (float32 / bfloat16 only)")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.KdccError("kdcc kernels need device tensors (there is no CPU fallback)")
+
+
+def nhwc_ld(t):
+    """Pixel stride of an (N,H,W,C) activation view; validates the layout."""
+    if t.dim() != 4 or t.stride(3) != 1:
+        raise ValueError(f"expected an (N,H,W,C) tensor with dense channels, got shape {tuple(t.shape)} stride {t.stride()}")
+    N, H, W, _ = t.shape
+    ld = t.stride(2)
+    if (W > 1 and ld < t.shape[3]) or (H > 1 and t.stride(1) != W * ld) or (N > 1 and t.stride(0) != H * W * ld):
+        raise ValueError(f"not a pixel-strided NHWC view: shape {tuple(t.shape)} stride {t.stride()}")
+    return ld
+
+
+def new_nhwc(N, H, W, Cc, dtype, device, zero=False):
+    f = torch.zeros if zero else torch.empty
+    return f((N, H, W, Cc), dtype=dtype, device=device)
+
+
+def as_nchw(t):
+    """(N,H,W,C) activation -> logical NCHW view (channels_last memory), no copy."""
+    return t.permute(0, 3, 1, 2)
+
+
+def conv_out_size(h, k, stride, pad, dil):
+    return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+# ------------------------------------------------------------------------------ dense conv
+def pack_conv_weight(w, dtype, mode=KD_PACK_FWD, cin_pad=None):
+    """nn.Conv2d.weight (Cout,Cin,kh,kw) fp32 -> packed operand for conv2d()."""
+    _need_cuda(w)
+    w = w.detach().contiguous().float()
+    Cout, Cin, kh, kw = w.shape
+    cin_pad = Cin if cin_pad is None else cin_pad
+    if mode == KD_PACK_FWD:
+        out = torch.empty((Cout, kh, kw, cin_pad), dtype=dtype, device=w.device)
+    else:
+        out = torch.empty((Cin, kh, kw, Cout), dtype=dtype, device=w.device)
+    check(_lib.lib().kd_pack_conv_weight(_ptr(w), _ptr(out), dt_of(out), mode, Cout, Cin, kh, kw, cin_pad, stream_ptr()),
+          "kd_pack_conv_weight")
+    return out
+
+
+def conv2d(x, w_packed, stride=1, pad=0, dil=1, *, res_pre=None, mask=None, mask_scale=None, res_post=None,
+           out_raw=None, out_act=None, act_scale=None, act_shift=None, act_relu=False):
+    """Implicit-GEMM conv; w_packed is (Cout,kh,kw,Cin). Outputs are caller-provided NHWC views."""
+    _need_cuda(x, w_packed)
+    N, H, W, Cin = x.shape
+    Cout, kh, kw, Cin_w = w_packed.shape
+    if Cin_w != Cin:
+        raise ValueError(f"conv2d: input has {Cin} channels, packed weight expects {Cin_w}")
+    if w_packed.dtype != x.dtype or not w_packed.is_contiguous():
+        raise ValueError("conv2d: packed weight must be contiguous and of the activation dtype")
+    Ho, Wo = conv_out_size(H, kh, stride, pad, dil), conv_out_size(W, kw, stride, pad, dil)
+    d = ConvDesc(dt_of(x), N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil, nhwc_ld(x))
+    ep = ConvEpilogue()
+
+    def chk(t, name, f32_ok=False):
+        if t is None:
+            return 0
+        if tuple(t.shape) != (N, Ho, Wo, Cout):
+            raise ValueError(f"conv2d: {name} has shape {tuple(t.shape)}, expected {(N, Ho, Wo, Cout)}")
+        if t.dtype != x.dtype and not (f32_ok and t.dtype == torch.float32):
+            raise ValueError(f"conv2d: {name} dtype {t.dtype} != {x.dtype}")
+        _need_cuda(t)
+        return nhwc_ld(t)
+
+    def chk_vec(v, name):
+        if v is not None and (v.dtype != torch.float32 or v.numel() != Cout or not v.is_contiguous()):
+            raise ValueError(f"conv2d: {name} must be a contiguous fp32 vector of {Cout}")
+        _need_cuda(v)
+
+    ep.res_pre, ep.ld_res_pre = _ptr(res_pre), chk(res_pre, "res_pre")
+    ep.mask, ep.ld_mask = _ptr(mask), chk(mask, "mask")
+    chk_vec(mask_scale, "mask_scale"); ep.mask_scale = _ptr(mask_scale)
+    ep.res_post, ep.ld_res_post = _ptr(res_post), chk(res_post, "res_post")
+    ep.out_raw, ep.ld_raw = _ptr(out_raw), chk(out_raw, "out_raw", f32_ok=True)
+    ep.raw_f32 = int(out_raw is not None and out_raw.dtype == torch.float32 and x.dtype != torch.float32)
+    ep.out_act, ep.ld_act = _ptr(out_act), chk(out_act, "out_act")
+    chk_vec(act_scale, "act_scale"); chk_vec(act_shift, "act_shift")
+    ep.act_scale, ep.act_shift, ep.act_relu = _ptr(act_scale), _ptr(act_shift), int(act_relu)
+    check(_lib.lib().kd_conv2d_fwd(C.byref(d), _ptr(x), _ptr(w_packed), C.byref(ep), stream_ptr()), "kd_conv2d_fwd")
+    return out_raw, out_act
+
+
+def pw_wgrad(a, dy, dw, accumulate=False, workspace=None):
+    """dw (Cout,Cin,1,1) fp32 = sum_pixels dy (N,H,W,Cout) x a (N,H,W,Cin)."""
+    _need_cuda(a, dy, dw)
+    N, H, W, Cin = a.shape
+    Cout = dy.shape[3]
+    if tuple(dy.shape[:3]) != (N, H, W) or a.dtype != dy.dtype:
+        raise ValueError("pw_wgrad: a / dy mismatch")
+    if dw.dtype != torch.float32 or dw.numel() != Cout * Cin or not dw.is_contiguous():
+        raise ValueError("pw_wgrad: dw must be contiguous fp32 (Cout,Cin,1,1)")
+    M = N * H * W
+    need = _lib.lib().kd_pw_wgrad_workspace(M, Cin, Cout)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=a.device)
+    check(_lib.lib().kd_pw_wgrad(dt_of(a), M, Cin, Cout, _ptr(a), nhwc_ld(a), _ptr(dy), nhwc_ld(dy), _ptr(dw),
+                                 int(accumulate), _ptr(workspace), workspace.numel() * workspace.element_size(),
+                                 stream_ptr()), "kd_pw_wgrad")
+    return dw
+
+
+# --------------------------------------------------------------------------- depthwise conv
+def pack_dw_weight(w, flip=False):
+    """(C,1,k,k) fp32 -> tap-major [k*k][C] fp32 (flip=True: the dgrad operand)."""
+    _need_cuda(w)
+    w = w.detach().contiguous().float()
+    Cc, one, k, k2 = w.shape
+    if one != 1 or k != k2:
+        raise ValueError("pack_dw_weight: expected (C,1,k,k)")
+    out = torch.empty((k * k, Cc), dtype=torch.float32, device=w.device)
+    check(_lib.lib().kd_pack_dw_weight(_ptr(w), _ptr(out), Cc, k, int(flip), stream_ptr()), "kd_pack_dw_weight")
+    return out
+
+
+def _dw_desc(x, k, pad, dil, y=None):
+    N, H, W, Cc = x.shape
+    return DwDesc(dt_of(x), N, H, W, Cc, k, pad, dil, nhwc_ld(x), nhwc_ld(y) if y is not None else Cc)
+
+
+def dwconv(x, w_taps, k, pad, dil, bias=None, out=None):
+    _need_cuda(x, w_taps, bias, out)
+    N, H, W, Cc = x.shape
+    if tuple(w_taps.shape) != (k * k, Cc) or w_taps.dtype != torch.float32 or not w_taps.is_contiguous():
+        raise ValueError("dwconv: w_taps must be contiguous fp32 [k*k][C]")
+    if out is None:
+        out = torch.empty((N, H, W, Cc), dtype=x.dtype, device=x.device)
+    if tuple(out.shape) != (N, H, W, Cc) or out.dtype != x.dtype:
+        raise ValueError("dwconv: bad output view")
+    d = _dw_desc(x, k, pad, dil, out)
+    check(_lib.lib().kd_dwconv_fwd(C.byref(d), _ptr(x), _ptr(w_taps), _ptr(bias), _ptr(out), stream_ptr()), "kd_dwconv_fwd")
+    return out
+
+
+def dwconv_wgrad(x, dy, dw, k, pad, dil, accumulate=False, workspace=None):
+    _need_cuda(x, dy, dw)
+    N, H, W, Cc = x.shape
+    if tuple(dy.shape) != (N, H, W, Cc) or dy.dtype != x.dtype:
+        raise ValueError("dwconv_wgrad: x / dy mismatch")
+    if dw.dtype != torch.float32 or dw.numel() != Cc * k * k or not dw.is_contiguous():
+        raise ValueError("dwconv_wgrad: dw must be contiguous fp32 (C,1,k,k)")
+    d = _dw_desc(x, k, pad, dil)
+    need = _lib.lib().kd_dwconv_wgrad_workspace(C.byref(d))
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+    check(_lib.lib().kd_dwconv_wgrad(C.byref(d), _ptr(x), _ptr(dy), nhwc_ld(dy), _ptr(dw), int(accumulate), _ptr(workspace),
+                                     workspace.numel() * workspace.element_size(), stream_ptr()), "kd_dwconv_wgrad")
+    return dw
+
+
+# ------------------------------------------------------------------------------ trunk plumbing
+def stem_conv(x_nchw, w, dtype):
+    """(N,3,H,W) fp32 NCHW batch + (64,3,3,3) fp32 weight -> (N,H,W,64) NHWC."""
+    _need_cuda(x_nchw, w)
+    if x_nchw.dtype != torch.float32 or not x_nchw.is_contiguous() or x_nchw.shape[1] != 3:
+        raise ValueError("stem_conv: expects a contiguous fp32 (N,3,H,W) batch")
+    if tuple(w.shape) != (64, 3, 3, 3) or w.dtype != torch.float32 or not w.is_contiguous():
+        raise ValueError("stem_conv: expects a contiguous fp32 (64,3,3,3) weight")
+    N, _, H, W = x_nchw.shape
+    y = torch.empty((N, H, W, 64), dtype=dtype, device=x_nchw.device)
+    check(_lib.lib().kd_stem_conv(dt_of(y), _ptr(x_nchw), _ptr(w), _ptr(y), N, H, W, stream_ptr()), "kd_stem_conv")
+    return y
+
+
+def maxpool3x3s2(x, scale=None, shift=None, want_raw=True):
+    _need_cuda(x, scale, shift)
+    N, H, W, Cc = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y_raw = torch.empty((N, Ho, Wo, Cc), dtype=x.dtype, device=x.device) if want_raw else None
+    y_act = torch.empty((N, Ho, Wo, Cc), dtype=x.dtype, device=x.device) if scale is not None else None
+    check(_lib.lib().kd_maxpool3x3s2(dt_of(x), _ptr(x), nhwc_ld(x), _ptr(y_raw), Cc, _ptr(y_act), Cc, _ptr(scale), _ptr(shift),
+                                     N, H, W, Cc, stream_ptr()), "kd_maxpool3x3s2")
+    return y_raw, y_act
+
+
+def upsample_bilinear_ac(x, size, out=None, out_dtype=None):
+    _need_cuda(x, out)
+    N, H, W, Cc = x.shape
+    Ho, Wo = size
+    if out is None:
+        out = torch.empty((N, Ho, Wo, Cc), dtype=out_dtype or x.dtype, device=x.device)
+    if tuple(out.shape) != (N, Ho, Wo, Cc):
+        raise ValueError("upsample: bad output view")
+    check(_lib.lib().kd_upsample_bilinear_ac(_ptr(x), dt_of(x), nhwc_ld(x), _ptr(out), dt_of(out), nhwc_ld(out), N, H, W, Cc,
+                                             Ho, Wo, stream_ptr()), "kd_upsample_bilinear_ac")
+    return out
+
+
+def aspp_image_pool(x, w, scale, shift, out):
+    """x (N,H,W,Cin); w (Cout,Cin[,1,1]) fp32; writes the broadcast branch into `out` (N,H,W,Cout) view."""
+    _need_cuda(x, w, scale, shift, out)
+    N, H, W, Cin = x.shape
+    Cout = out.shape[3]
+    w = w.reshape(Cout, Cin)
+    if w.dtype != torch.float32 or not w.is_contiguous() or tuple(out.shape[:3]) != (N, H, W) or out.dtype != x.dtype:
+        raise ValueError("aspp_image_pool: bad operands")
+    need = _lib.lib().kd_aspp_image_pool_workspace(N, Cin, Cout)
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    check(_lib.lib().kd_aspp_image_pool(dt_of(x), _ptr(x), nhwc_ld(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(out),
+                                        nhwc_ld(out), N, H, W, Cin, Cout, _ptr(ws), need, stream_ptr()), "kd_aspp_image_pool")
+    return out
+
+
+def bn_fold(bn):
+    """Eval-mode nn.BatchNorm2d -> (scale, shift) fp32 device vectors."""
+    g, b, m, v = bn.weight.detach().float(), bn.bias.detach().float(), bn.running_mean.float(), bn.running_var.float()
+    _need_cuda(g, b, m, v)
+    scale, shift = torch.empty_like(g), torch.empty_like(g)
+    check(_lib.lib().kd_bn_fold(_ptr(g.contiguous()), _ptr(b.contiguous()), _ptr(m.contiguous()), _ptr(v.contiguous()),
+                                C.c_float(bn.eps), _ptr(scale), _ptr(shift), g.numel(), stream_ptr()), "kd_bn_fold")
+    return scale, shift
+
+
+# ------------------------------------------------------------------------------------- losses
+def view3(t):
+    """(N,C,*spatial) logical tensor (any of NCHW / channels_last / (N,C)) -> kd_view3 + (N,C,P)."""
+    if t.dim() == 2:
+        N, Cc = t.shape
+        return View3(t.data_ptr(), dt_of(t), t.stride(0), t.stride(1), 0), (N, Cc, 1)
+    if t.dim() != 4:
+        raise ValueError("loss operands must be (N,C) or (N,C,H,W)")
+    N, Cc, H, W = t.shape
+    sN, sC, sH, sW = t.stride()
+    if H > 1 and sH != W * sW:
+        raise ValueError(f"loss operand rows are not uniformly strided: stride {t.stride()}")
+    return View3(t.data_ptr(), dt_of(t), sN, sC, sW), (N, Cc, H * W)
+
+
+_ws_cache = {}
+
+
+def loss_workspace(N, Cc, P, device):
+    need = _lib.lib().kd_loss_workspace(N, Cc, P)
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws, need
+
+
+def _loss_common(s, t):
+    _need_cuda(s, t)
+    if s.shape != t.shape:
+        raise ValueError(f"loss: inputs {tuple(s.shape)} vs targets {tuple(t.shape)}")
+    vs, dims = view3(s)
+    vt, _ = view3(t)
+    return vs, vt, dims
+
+
+def kldiv(s, t, temperature=1.0, want_grad=True, grad_scale=1.0):
+    vs, vt, (N, Cc, P) = _loss_common(s, t)
+    loss = torch.empty((), dtype=torch.float32, device=s.device)
+    grad = torch.empty_like(s) if want_grad else None
+    vg = view3(grad)[0] if want_grad else None
+    ws, need = loss_workspace(N, Cc, P, s.device)
+    check(_lib.lib().kd_kldiv(C.byref(vs), C.byref(vt), C.c_float(temperature), N, Cc, P, _ptr(loss),
+                              C.byref(vg) if vg is not None else None, C.c_float(grad_scale), _ptr(ws), need, stream_ptr()),
+          "kd_kldiv")
+    return loss, grad
+
+
+def hint_mse(s, t, num_classes=19, want_grad=True, grad_scale=1.0):
+    vs, vt, (N, Cc, P) = _loss_common(s, t)
+    loss = torch.empty((), dtype=torch.float32, device=s.device)
+    grad = torch.empty_like(s) if want_grad else None
+    vg = view3(grad)[0] if want_grad else None
+    ws, need = loss_workspace(N, Cc, P, s.device)
+    check(_lib.lib().kd_hint_mse(C.byref(vs), C.byref(vt), C.c_float(num_classes), N, Cc, P, _ptr(loss),
+                                 C.byref(vg) if vg is not None else None, C.c_float(grad_scale), _ptr(ws), need, stream_ptr()),
+          "kd_hint_mse")
+    return loss, grad
+
+
+def weighted_hint_mse(s, t, w, want_grad=True, grad_scale=1.0):
+    vs, vt, (N, Cc, P) = _loss_common(s, t)
+    _need_cuda(w)
+    w = w.detach().float().contiguous()
+    if tuple(w.shape) not in ((Cc,), (N, Cc)):
+        raise ValueError(f"weighted_hint_mse: filter_weight must be (C,) or (N,C), got {tuple(w.shape)}")
+    loss = torch.empty((), dtype=torch.float32, device=s.device)
+    grad = torch.empty_like(s) if want_grad else None
+    vg = view3(grad)[0] if want_grad else None
+    ws, need = loss_workspace(N, Cc, P, s.device)
+    check(_lib.lib().kd_weighted_hint_mse(C.byref(vs), C.byref(vt), _ptr(w), int(w.dim() == 2), N, Cc, P, _ptr(loss),
+                                          C.byref(vg) if vg is not None else None, C.c_float(grad_scale), _ptr(ws), need,
+                                          stream_ptr()), "kd_weighted_hint_mse")
+    return loss, grad
+
+
+def ce2d(x, target, ignore_index=255):
+    _need_cuda(x, target)
+    vx, (N, Cc, P) = view3(x)
+    tgt = target.contiguous()
+    if tgt.dtype != torch.int64 or tgt.numel() != N * P:
+        raise ValueError("ce2d: target must be int64 (N,H,W)")
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    ws, need = loss_workspace(N, Cc, P, x.device)
+    check(_lib.lib().kd_ce2d(C.byref(vx), _ptr(tgt), ignore_index, N, Cc, P, _ptr(loss), _ptr(ws), need, stream_ptr()), "kd_ce2d")
+    return loss
+
+
+def radam_step(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay):
+    _need_cuda(p, g, m, v)
+    for t in (p, g, m, v):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != p.numel():
+            raise ValueError("radam_step: fp32 contiguous tensors of equal size required")
+    check(_lib.lib().kd_radam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(step), C.c_float(lr), C.c_float(beta1),
+                                   C.c_float(beta2), C.c_float(eps), C.c_float(weight_decay), stream_ptr()), "kd_radam_step")

@@ -1,0 +1,294 @@
+"""Per-kernel parity: HIP path (through the C-ABI) vs the CPU oracle, seeded inputs.
+
+fp32 tolerance 1e-3 relative (north_star's bar; most kernels hold 1e-5);
+bf16 kernels are compared against the oracle evaluated on the bf16-rounded
+inputs with a 1.5e-2 relative-to-range tolerance (bf16 has 8 significant bits).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def K():
+    import kdcc_amd
+    from kdcc_amd import ops
+    assert torch.cuda.is_available()
+    return ops
+
+
+DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+RNG = np.random.default_rng(1234)
+
+
+def rnd(*shape, scale=1.0):
+    return (RNG.standard_normal(shape) * scale).astype(np.float32)
+
+
+def q(a, dt):
+    """Round a numpy array to the kernel's storage dtype (so the oracle sees identical inputs)."""
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DT[dt]).float().numpy()
+
+
+def dev_nhwc(a_nchw, dt, ld=None):
+    t = torch.from_numpy(np.ascontiguousarray(a_nchw.transpose(0, 2, 3, 1))).to(DT[dt]).cuda()
+    if ld is None:
+        return t
+    N, H, W, C = t.shape
+    buf = torch.zeros((N, H, W, ld), dtype=t.dtype, device="cuda")
+    buf[..., 8:8 + C] = t
+    return buf[..., 8:8 + C]
+
+
+def host_nchw(t):
+    return t.float().cpu().numpy().transpose(0, 3, 1, 2)
+
+
+def assert_close(got, ref, dt, what=""):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    scale = max(np.abs(ref).max(), 1e-6)
+    tol = 1e-3 if dt == "f32" else 1.5e-2
+    err = np.abs(got - ref).max() / scale
+    assert err < tol, f"{what}: max err {err:.3e} of range (tol {tol})"
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, dil
+    (2, 8, 16, 64, 128, 1, 1, 0, 1),
+    (1, 12, 16, 64, 64, 3, 1, 1, 1),
+    (2, 9, 11, 128, 64, 3, 1, 2, 2),     # ragged M, dilation 2
+    (1, 16, 16, 64, 128, 3, 2, 1, 1),    # stride 2 (mod4.block1)
+    (1, 10, 12, 128, 19, 3, 1, 4, 4),    # odd Cout (classifier-like), dilation 4
+    (1, 6, 8, 320, 48, 1, 1, 0, 1),      # Cout 48 (bot_fine-like), Cin 320
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd(K, dt, case):
+    N, H, W, Cin, Cout, k, s, p, d = case
+    x = q(rnd(N, Cin, H, W), dt)
+    w = q(rnd(Cout, Cin, k, k, scale=(2.0 / (Cin * k * k)) ** 0.5), dt)
+    ref = orc.conv2d_fwd(x, w, stride=s, pad=p, dil=d)
+    xd = dev_nhwc(x, dt)
+    wp = K.pack_conv_weight(torch.from_numpy(w).cuda(), DT[dt])
+    Ho, Wo = ref.shape[2:]
+    out = torch.empty((N, Ho, Wo, Cout), dtype=DT[dt], device="cuda")
+    K.conv2d(xd, wp, s, p, d, out_raw=out)
+    assert_close(host_nchw(out), ref, dt, f"conv {case}")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv_epilogue_forward(K, dt):
+    """shortcut add + raw/act dual output with folded BN + ReLU, reading/writing channel slices."""
+    N, H, W, Cin, Cout = 2, 8, 8, 64, 64
+    x, w = q(rnd(N, Cin, H, W), dt), q(rnd(Cout, Cin, 3, 3, scale=0.06), dt)
+    res = q(rnd(N, Cout, H, W), dt)
+    scale, shift = rnd(Cout) * 0.2 + 1.0, rnd(Cout) * 0.3
+    conv = orc.conv2d_fwd(x, w, pad=1)
+    raw_ref = conv + res
+    act_ref = np.maximum(raw_ref * scale[None, :, None, None] + shift[None, :, None, None], 0)
+    xd = dev_nhwc(x, dt, ld=Cin + 16)           # input is a slice of a wider buffer
+    wide = torch.zeros((N, H, W, 3 * Cout), dtype=DT[dt], device="cuda")
+    out_act = wide[..., Cout:2 * Cout]           # concat-free write into a slice
+    out_raw = torch.empty((N, H, W, Cout), dtype=DT[dt], device="cuda")
+    wp = K.pack_conv_weight(torch.from_numpy(w).cuda(), DT[dt])
+    K.conv2d(xd, wp, 1, 1, 1, res_pre=dev_nhwc(res, dt), out_raw=out_raw, out_act=out_act,
+             act_scale=torch.from_numpy(scale).cuda(), act_shift=torch.from_numpy(shift).cuda(), act_relu=True)
+    assert_close(host_nchw(out_raw), raw_ref, dt, "raw")
+    assert_close(host_nchw(out_act), act_ref, dt, "act")
+    assert float(wide[..., :Cout].abs().max()) == 0 and float(wide[..., 2 * Cout:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("k,p,d", [(3, 1, 1), (3, 4, 4), (1, 0, 1)])
+def test_conv_dgrad_with_bn_relu_mask(K, dt, k, p, d):
+    """dgrad = conv with KD_PACK_DGRAD weights; epilogue applies d(relu(bn(x)))/dx and adds the shortcut gradient."""
+    from kdcc_amd._lib import KD_PACK_DGRAD
+    N, H, W, Cin, Cout = 2, 8, 12, 64, 128
+    w = q(rnd(Cout, Cin, k, k, scale=0.05), dt)
+    gy = q(rnd(N, Cout, H, W), dt)
+    act = q(np.maximum(rnd(N, Cin, H, W), 0), dt)      # saved activated input (mask)
+    bn_scale = rnd(Cin) * 0.2 + 1.0
+    short = q(rnd(N, Cin, H, W), dt)
+    ref = orc.conv2d_dgrad(gy, w, (N, Cin, H, W), pad=p, dil=d)
+    ref = np.where(act > 0, ref * bn_scale[None, :, None, None], 0) + short
+    wp = K.pack_conv_weight(torch.from_numpy(w).cuda(), DT[dt], KD_PACK_DGRAD)
+    out = torch.empty((N, H, W, Cin), dtype=DT[dt], device="cuda")
+    K.conv2d(dev_nhwc(gy, dt), wp, 1, d * (k - 1) - p, d, mask=dev_nhwc(act, dt),
+             mask_scale=torch.from_numpy(bn_scale).cuda(), res_post=dev_nhwc(short, dt), out_raw=out)
+    assert_close(host_nchw(out), ref, dt, "dgrad")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 8, 16, 64, 128), (1, 13, 9, 128, 64), (1, 40, 64, 256, 64)])
+def test_pw_wgrad(K, dt, shape):
+    N, H, W, Cin, Cout = shape
+    a, gy = q(rnd(N, Cin, H, W), dt), q(rnd(N, Cout, H, W), dt)
+    ref = orc.conv2d_wgrad(a, gy, (Cout, Cin, 1, 1))
+    dw = torch.full((Cout, Cin, 1, 1), 7.0, device="cuda")
+    K.pw_wgrad(dev_nhwc(a, dt), dev_nhwc(gy, dt), dw)
+    assert_close(dw.cpu().numpy(), ref, dt, "pw_wgrad")
+    K.pw_wgrad(dev_nhwc(a, dt), dev_nhwc(gy, dt), dw, accumulate=True)
+    assert_close(dw.cpu().numpy(), 2 * ref, dt, "pw_wgrad accumulate")
+
+
+DW_CASES = [(2, 24, 32, 16, 9, 20, 5), (1, 8, 8, 16, 3, 1, 1), (1, 23, 37, 72, 9, 20, 5), (2, 6, 50, 8, 9, 20, 5)]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", DW_CASES)
+def test_dwconv_fwd_dgrad_wgrad(K, dt, case):
+    N, H, W, Cc, k, p, d = case
+    x, w = q(rnd(N, Cc, H, W), dt), rnd(Cc, 1, k, k, scale=1.0 / k)
+    gy = q(rnd(N, Cc, H, W), dt)
+    wd = torch.from_numpy(w).cuda()
+    y = K.dwconv(dev_nhwc(x, dt), K.pack_dw_weight(wd), k, p, d)
+    assert_close(host_nchw(y), orc.conv2d_fwd(x, w, pad=p, dil=d, groups=Cc), dt, "dw fwd")
+    gx = K.dwconv(dev_nhwc(gy, dt), K.pack_dw_weight(wd, flip=True), k, p, d)
+    assert_close(host_nchw(gx), orc.conv2d_dgrad(gy, w, x.shape, pad=p, dil=d, groups=Cc), dt, "dw dgrad")
+    dw = torch.zeros((Cc, 1, k, k), device="cuda")
+    K.dwconv_wgrad(dev_nhwc(x, dt), dev_nhwc(gy, dt), dw, k, p, d)
+    assert_close(dw.cpu().numpy(), orc.conv2d_wgrad(x, gy, w.shape, pad=p, dil=d, groups=Cc), dt, "dw wgrad")
+
+
+def test_dwsep_block_golden(K, golden):
+    """DepthwiseSeparableBlock fwd + all grads against the reference's own outputs (fp32 path)."""
+    g = golden("dwsep")
+    for tag in ("k9d5", "k3d1"):
+        Cc, Co, k, p, d, H, W = [int(v) for v in g[f"{tag}.cfg"]]
+        # pad channels to the GEMM granule (32 for f32) with zeros: result is unchanged
+        Cp = 32
+        x = np.zeros((2, Cp, H, W), np.float32); x[:, :Cc] = g[f"{tag}.x"]
+        wdw = np.zeros((Cp, 1, k, k), np.float32); wdw[:Cc] = g[f"{tag}.w_dw"]
+        wpw = np.zeros((Co, Cp, 1, 1), np.float32); wpw[:, :Cc] = g[f"{tag}.w_pw"]
+        xd = dev_nhwc(x, "f32")
+        mid = K.dwconv(xd, K.pack_dw_weight(torch.from_numpy(wdw).cuda()), k, p, d)
+        out = torch.empty((2, H, W, Co), device="cuda")
+        K.conv2d(mid, K.pack_conv_weight(torch.from_numpy(wpw).cuda(), torch.float32), out_raw=out)
+        assert_close(host_nchw(out), g[f"{tag}.y"], "f32", f"{tag} y")
+        gy = dev_nhwc(g[f"{tag}.gy"], "f32")
+        gw_pw = torch.empty((Co, Cp, 1, 1), device="cuda")
+        K.pw_wgrad(mid, gy, gw_pw)
+        assert_close(gw_pw.cpu().numpy()[:, :Cc], g[f"{tag}.gw_pw"], "f32", f"{tag} gw_pw")
+        # dgrad of the 1x1: Cout (=K dim) must be a multiple of 32 -> pad gy / weight rows with zeros
+        Kp = ((Co + 31) // 32) * 32
+        gyp = np.zeros((2, Kp, H, W), np.float32); gyp[:, :Co] = g[f"{tag}.gy"]
+        wpp = np.zeros((Kp, Cp, 1, 1), np.float32); wpp[:Co] = wpw
+        from kdcc_amd._lib import KD_PACK_DGRAD
+        gmid = torch.empty((2, H, W, Cp), device="cuda")
+        K.conv2d(dev_nhwc(gyp, "f32"), K.pack_conv_weight(torch.from_numpy(wpp).cuda(), torch.float32, KD_PACK_DGRAD), out_raw=gmid)
+        gw_dw = torch.empty((Cp, 1, k, k), device="cuda")
+        K.dwconv_wgrad(xd, gmid, gw_dw, k, p, d)
+        assert_close(gw_dw.cpu().numpy()[:Cc], g[f"{tag}.gw_dw"], "f32", f"{tag} gw_dw")
+        gx = K.dwconv(gmid, K.pack_dw_weight(torch.from_numpy(wdw).cuda(), flip=True), k, p, d)
+        assert_close(host_nchw(gx)[:, :Cc], g[f"{tag}.gx"], "f32", f"{tag} gx")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_stem_pool_upsample_imagepool(K, dt):
+    x = rnd(2, 3, 20, 28)
+    w = rnd(64, 3, 3, 3, scale=0.2)
+    y = K.stem_conv(torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda(), DT[dt])
+    ref = orc.conv2d_fwd(x, w, pad=1)
+    assert_close(host_nchw(y), ref, dt, "stem")
+    # max-pool (+ BN/ReLU second output) on the stem output as stored
+    yq = host_nchw(y)
+    scale, shift = rnd(64) * 0.2 + 1.0, rnd(64) * 0.2
+    raw, act = K.maxpool3x3s2(y, torch.from_numpy(scale).cuda(), torch.from_numpy(shift).cuda())
+    pref = orc.maxpool3x3s2(yq)
+    assert_close(host_nchw(raw), pref, dt, "pool raw")
+    assert_close(host_nchw(act), np.maximum(pref * scale[None, :, None, None] + shift[None, :, None, None], 0), dt, "pool act")
+    # upsample x4 into a channel slice, and an odd-channel fp32-out case (the logits path)
+    up = torch.zeros((2, 40, 56, 80), dtype=DT[dt], device="cuda")
+    K.upsample_bilinear_ac(raw, (40, 56), out=up[..., 16:80])
+    assert_close(host_nchw(up[..., 16:80]), orc.upsample_bilinear_ac(host_nchw(raw), (40, 56)), dt, "upsample")
+    lg = rnd(2, 19, 7, 9)
+    lgd = torch.from_numpy(np.ascontiguousarray(lg.transpose(0, 2, 3, 1))).cuda()  # fp32 decoder output
+    o = K.upsample_bilinear_ac(lgd, (14, 18), out_dtype=torch.float32)
+    assert_close(host_nchw(o), orc.upsample_bilinear_ac(lg, (14, 18)), "f32", "logit upsample")
+    # ASPP image pooling branch
+    Cin, Cout = 64, 16
+    xi = q(rnd(2, Cin, 6, 10), dt)
+    wi, sc, sh = rnd(Cout, Cin, scale=0.2), rnd(Cout) * 0.2 + 1, rnd(Cout) * 0.2
+    cat = torch.zeros((2, 6, 10, 48), dtype=DT[dt], device="cuda")
+    K.aspp_image_pool(dev_nhwc(xi, dt), torch.from_numpy(wi).cuda(), torch.from_numpy(sc).cuda(), torch.from_numpy(sh).cuda(),
+                      cat[..., :Cout])
+    v = np.maximum((orc.gap(xi) @ wi.T) * sc + sh, 0)
+    assert_close(host_nchw(cat[..., :Cout]), np.broadcast_to(v[:, :, None, None], (2, Cout, 6, 10)), dt, "image pool")
+
+
+def test_losses_vs_golden_and_oracle(K, golden):
+    g = golden("losses")
+    for tag, T in (("kld_T1", 1.0), ("kld_T5", 5.0), ("kld2d_T5", 5.0)):
+        s, t = torch.from_numpy(g[f"{tag}.s"]).cuda(), torch.from_numpy(g[f"{tag}.t"]).cuda()
+        loss, grad = K.kldiv(s, t, T)
+        np.testing.assert_allclose(loss.item(), g[f"{tag}.loss"], rtol=1e-4)
+        np.testing.assert_allclose(grad.cpu().numpy(), g[f"{tag}.grad"], rtol=1e-3, atol=1e-7)
+    # same values through a channels_last (NHWC memory) view: the engine's layout
+    s = torch.from_numpy(g["kld_T1.s"]).cuda().contiguous(memory_format=torch.channels_last)
+    t = torch.from_numpy(g["kld_T1.t"]).cuda().contiguous(memory_format=torch.channels_last)
+    loss, grad = K.kldiv(s, t, 1.0)
+    np.testing.assert_allclose(loss.item(), g["kld_T1.loss"], rtol=1e-4)
+    np.testing.assert_allclose(grad.cpu().numpy(), g["kld_T1.grad"], rtol=1e-3, atol=1e-7)
+    for tag, nc in (("mse_1000", 1000), ("mse_1", 1)):
+        for fmt in (torch.contiguous_format, torch.channels_last):
+            s = torch.from_numpy(g[f"{tag}.s"]).cuda().contiguous(memory_format=fmt)
+            t = torch.from_numpy(g[f"{tag}.t"]).cuda().contiguous(memory_format=fmt)
+            loss, grad = K.hint_mse(s, t, nc)
+            np.testing.assert_allclose(loss.item(), g[f"{tag}.loss"], rtol=1e-5)
+            np.testing.assert_allclose(grad.cpu().numpy(), g[f"{tag}.grad"], rtol=1e-4, atol=1e-9)
+    # mixed layouts -> strided kernel
+    s = torch.from_numpy(g["mse_1000.s"]).cuda()
+    t = torch.from_numpy(g["mse_1000.t"]).cuda().contiguous(memory_format=torch.channels_last)
+    loss, grad = K.hint_mse(s, t, 1000)
+    np.testing.assert_allclose(loss.item(), g["mse_1000.loss"], rtol=1e-5)
+    np.testing.assert_allclose(grad.cpu().numpy(), g["mse_1000.grad"], rtol=1e-4, atol=1e-9)
+    for tag in ("whmse_c", "whmse_nc"):
+        for fmt in (torch.contiguous_format, torch.channels_last):
+            s = torch.from_numpy(g[f"{tag}.s"]).cuda().contiguous(memory_format=fmt)
+            t = torch.from_numpy(g[f"{tag}.t"]).cuda().contiguous(memory_format=fmt)
+            loss, grad = K.weighted_hint_mse(s, t, torch.from_numpy(g[f"{tag}.w"]).cuda())
+            np.testing.assert_allclose(loss.item(), g[f"{tag}.loss"], rtol=1e-5)
+            np.testing.assert_allclose(grad.cpu().numpy(), g[f"{tag}.grad"], rtol=1e-4, atol=1e-9)
+    ce = K.ce2d(torch.from_numpy(g["ce.x"]).cuda(), torch.from_numpy(g["ce.target"]).cuda())
+    np.testing.assert_allclose(ce.item(), g["ce.loss"], rtol=1e-5)
+
+
+def test_losses_bf16_large_vs_oracle(K):
+    """bf16 NHWC operands at a hint-like size: vector path, compared with the oracle on the rounded inputs."""
+    N, Cc, H, W = 2, 64, 24, 40
+    s, t = q(rnd(N, Cc, H, W), "bf16"), q(rnd(N, Cc, H, W), "bf16")
+    sd = dev_nhwc(s, "bf16").permute(0, 3, 1, 2)
+    td = dev_nhwc(t, "bf16").permute(0, 3, 1, 2)
+    loss, grad = K.hint_mse(sd, td, 1000)
+    rl, rg = orc.mse(s, t, 1000)
+    np.testing.assert_allclose(loss.item(), rl, rtol=1e-5)
+    assert_close(grad.float().cpu().numpy(), rg, "bf16", "mse grad")
+    loss, grad = K.kldiv(sd[:, :19], td[:, :19], 1.0)
+    rl, rg = orc.kldiv(s[:, :19], t[:, :19], 1.0)
+    np.testing.assert_allclose(loss.item(), rl, rtol=1e-4)
+    assert_close(grad.float().cpu().numpy(), rg, "bf16", "kld grad")
+
+
+def test_radam_golden(K, golden):
+    g = golden("radam")
+    p = torch.from_numpy(g["p"][0].copy()).cuda()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for i in range(8):
+        K.radam_step(p, torch.from_numpy(g["g"][i]).cuda(), m, v, i + 1, float(g["lr"]), 0.9, 0.999, 1e-8, 0.0)
+        np.testing.assert_allclose(p.cpu().numpy(), g["p"][i + 1], rtol=2e-6, atol=1e-7)
+
+
+def test_errors_are_loud(K):
+    from kdcc_amd._lib import KdccError
+    x = torch.zeros((1, 4, 4, 48), device="cuda")  # Cin not a multiple of 32
+    w = torch.zeros((32, 1, 1, 48), device="cuda")
+    with pytest.raises(KdccError):
+        K.conv2d(x, w, out_raw=torch.empty((1, 4, 4, 32), device="cuda"))
+    with pytest.raises(KdccError):
+        K.conv2d(torch.zeros((1, 4, 4, 64)), torch.zeros((32, 1, 1, 64)), out_raw=torch.empty((1, 4, 4, 32)))  # CPU tensors
