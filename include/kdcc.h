@@ -130,10 +130,19 @@ typedef struct kd_dw_desc {
     int32_t k, pad, dil;
     int32_t ldx, ldy;
 } kd_dw_desc;
+/* Optional epilogue (NULL = none), same meaning and order as kd_conv_epilogue's first three
+ * steps; used when the kernel computes an input gradient that continues through the
+ * BN(eval)+ReLU in front of the replaced conv, or accumulates into an existing gradient:
+ *   v = acc; v += res_pre; v = mask > 0 ? v*mask_scale[c] : 0; v += res_post; y = v */
+typedef struct kd_dw_epilogue {
+    const void *res_pre;  int32_t ld_res_pre;
+    const void *mask;     int32_t ld_mask;     const float *mask_scale;
+    const void *res_post; int32_t ld_res_post;
+} kd_dw_epilogue;
 int kd_pack_dw_weight(const float *src /* (C,1,k,k) */, float *dst /* [k*k][C] */,
                       int32_t C, int32_t k, int32_t flip, kd_stream_t stream);
 int kd_dwconv_fwd(const kd_dw_desc *d, const void *x, const float *w_taps, const float *bias,
-                  void *y, kd_stream_t stream);
+                  const kd_dw_epilogue *ep, void *y, kd_stream_t stream);
 /* dw[c][ky][kx] = sum_{n,h,w} dy[n,h,w,c] * x[n,h-pad+ky*dil,w-pad+kx*dil,c]; fp32 (C,1,k,k). */
 size_t kd_dwconv_wgrad_workspace(const kd_dw_desc *d);
 int kd_dwconv_wgrad(const kd_dw_desc *d, const void *x, const void *dy, int32_t ld_dy,

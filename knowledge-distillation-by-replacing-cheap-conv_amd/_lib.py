@@ -33,6 +33,11 @@ class DwDesc(C.Structure):
     _fields_ = [(n, c_int) for n in ("dtype", "N", "H", "W", "C", "k", "pad", "dil", "ldx", "ldy")]
 
 
+class DwEpilogue(C.Structure):
+    _fields_ = [("res_pre", c_vp), ("ld_res_pre", c_int), ("mask", c_vp), ("ld_mask", c_int), ("mask_scale", c_vp),
+                ("res_post", c_vp), ("ld_res_post", c_int)]
+
+
 class View3(C.Structure):
     _fields_ = [("ptr", c_vp), ("dtype", c_int), ("sN", c_i64), ("sC", c_i64), ("sP", c_i64)]
 
@@ -46,7 +51,7 @@ _SIGS = {
     "kd_pw_wgrad_workspace": (c_sz, [c_int, c_int, c_int]),
     "kd_pw_wgrad": (c_int, [c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_sz, c_vp]),
     "kd_pack_dw_weight": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
-    "kd_dwconv_fwd": (c_int, [_P(DwDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "kd_dwconv_fwd": (c_int, [_P(DwDesc), c_vp, c_vp, c_vp, _P(DwEpilogue), c_vp, c_vp]),
     "kd_dwconv_wgrad_workspace": (c_sz, [_P(DwDesc)]),
     "kd_dwconv_wgrad": (c_int, [_P(DwDesc), c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_sz, c_vp]),
     "kd_stem_conv": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),

@@ -6,6 +6,8 @@
 // every weight quad k*R of them; 16 consecutive lanes cover 64 contiguous channels
 // (128/256 B per pixel per load instruction).  Weights sit in LDS tap-major.
 // VALU/L1-bound by design (81 FMA per output element); no MFMA reshaping.
+#include <string.h>
+
 #include "kd_common.h"
 
 namespace {
@@ -23,6 +25,7 @@ struct DwParams {
     int N, H, W, C, pad, dil, ldx, ldy;
     int LH, LW;          // lattice extent upper bounds: ceil(H/dil), ceil(W/dil)
     int tiles_h, tiles_w;
+    kd_dw_epilogue ep;
 };
 
 template <typename T> __device__ __forceinline__ void ld4(const T *p, float (&v)[4]);
@@ -109,6 +112,9 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwParams p)
     }
 
     T *yb = (T *)p.y + (size_t)n * p.H * p.W * p.ldy + c;
+    const kd_dw_epilogue &e = p.ep;
+    float ms[4] = {1.f, 1.f, 1.f, 1.f};
+    if (e.mask && e.mask_scale) { ms[0] = e.mask_scale[c]; ms[1] = e.mask_scale[c + 1]; ms[2] = e.mask_scale[c + 2]; ms[3] = e.mask_scale[c + 3]; }
 #pragma unroll
     for (int s = 0; s < TS; ++s) {
         const int h = h0 + s * p.dil;
@@ -116,7 +122,25 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwParams p)
 #pragma unroll
         for (int r = 0; r < TR; ++r) {
             const int w = w0 + r * p.dil;
-            if (w < p.W) st4(yb + ((size_t)h * p.W + w) * p.ldy, acc[s][r]);
+            if (w >= p.W) continue;
+            const size_t pix = ((size_t)n * p.H + h) * p.W + w;
+            float t4[4];
+            if (e.res_pre) {
+                ld4<T>((const T *)e.res_pre + pix * e.ld_res_pre + c, t4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[s][r][q] += t4[q];
+            }
+            if (e.mask) {
+                ld4<T>((const T *)e.mask + pix * e.ld_mask + c, t4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[s][r][q] = t4[q] > 0.f ? acc[s][r][q] * ms[q] : 0.f;
+            }
+            if (e.res_post) {
+                ld4<T>((const T *)e.res_post + pix * e.ld_res_post + c, t4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[s][r][q] += t4[q];
+            }
+            st4(yb + ((size_t)h * p.W + w) * p.ldy, acc[s][r]);
         }
     }
 }
@@ -256,8 +280,8 @@ extern "C" int kd_pack_dw_weight(const float *src, float *dst, int32_t C, int32_
     return KD_OK;
 }
 
-extern "C" int kd_dwconv_fwd(const kd_dw_desc *d, const void *x, const float *w_taps, const float *bias, void *y,
-                             kd_stream_t stream)
+extern "C" int kd_dwconv_fwd(const kd_dw_desc *d, const void *x, const float *w_taps, const float *bias,
+                             const kd_dw_epilogue *ep, void *y, kd_stream_t stream)
 {
     int rc = check_desc(d, "kd_dwconv_fwd");
     if (rc) return rc;
@@ -267,6 +291,13 @@ extern "C" int kd_dwconv_fwd(const kd_dw_desc *d, const void *x, const float *w_
     KD_REQUIRE(((uintptr_t)x % (4 * es)) == 0 && ((uintptr_t)y % (4 * es)) == 0, KD_ERR_INVALID,
                "kd_dwconv_fwd: x/y must be aligned to 4 elements");
     DwParams p;
+    memset(&p.ep, 0, sizeof(p.ep));
+    if (ep) {
+        p.ep = *ep;
+        auto okp = [&](const void *q, int ld) { return !q || (((uintptr_t)q % (4 * es)) == 0 && ld >= d->C && ld % 4 == 0); };
+        KD_REQUIRE(okp(ep->res_pre, ep->ld_res_pre) && okp(ep->mask, ep->ld_mask) && okp(ep->res_post, ep->ld_res_post),
+                   KD_ERR_INVALID, "kd_dwconv_fwd: epilogue operands must be aligned to 4 elements");
+    }
     p.x = x; p.w = w_taps; p.bias = bias; p.y = y;
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.pad = d->pad; p.dil = d->dil; p.ldx = d->ldx; p.ldy = d->ldy;
     p.LH = (d->H + d->dil - 1) / d->dil;

@@ -1,0 +1,90 @@
+"""KD criteria with the reference's class names and constructor arguments (losses/__init__.py:1-7 of the
+reference), so `config.init_obj('kd_loss' | 'hint_loss' | 'supervised_loss', losses)` resolves unchanged.
+Each forward is one fused HIP pass producing the loss and its gradient (include/kdcc.h, losses section)."""
+import torch
+from torch import nn
+
+from .. import ops
+
+
+class _FusedLoss(torch.autograd.Function):
+    """loss, d loss / d inputs computed together in forward; backward only scales by the upstream gradient."""
+
+    @staticmethod
+    def forward(ctx, kind, inputs, targets, arg, weight):
+        want = inputs.requires_grad
+        s, t = inputs.detach(), targets.detach()
+        if kind == "kld":
+            loss, grad = ops.kldiv(s, t, arg, want_grad=want)
+        elif kind == "mse":
+            loss, grad = ops.hint_mse(s, t, arg, want_grad=want)
+        else:
+            loss, grad = ops.weighted_hint_mse(s, t, weight, want_grad=want)
+        ctx.grad = grad
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        grad = ctx.grad
+        ctx.grad = None
+        if grad is None:
+            return None, None, None, None, None
+        return None, grad * g.to(grad.dtype), None, None, None
+
+
+def _same_device_dtype(inputs, targets):
+    if targets.dtype != inputs.dtype and not (targets.dtype in (torch.float32, torch.bfloat16)):
+        targets = targets.to(inputs.dtype)
+    return targets
+
+
+class KLDivergenceLoss(nn.Module):
+    """kl_div(log_softmax(inputs/T, 1), softmax(targets/T, 1), 'mean') * T^2 * C  (losses/KLDiv.py:15-23)."""
+
+    def __init__(self, temperature=1):
+        super().__init__()
+        self.temperature = temperature
+
+    def forward(self, inputs, targets):
+        return _FusedLoss.apply("kld", inputs, _same_device_dtype(inputs, targets), float(self.temperature), None)
+
+
+class MSELoss(nn.Module):
+    """nn.MSELoss('mean')(inputs, targets) * num_classes  (losses/MSELoss.py:9-16)."""
+
+    def __init__(self, reduction='mean', num_classes=19):
+        super().__init__()
+        if reduction != 'mean':
+            raise NotImplementedError("only reduction='mean' (every shipped config) is implemented")
+        self.num_classes = num_classes
+
+    def forward(self, inputs, targets):
+        return _FusedLoss.apply("mse", inputs, _same_device_dtype(inputs, targets), float(self.num_classes), None)
+
+
+class WeightedHintMSELoss(nn.Module):
+    """mean_n( sum_c w * mean_hw (s-t)^2 / sum_c w )  (losses/WeightedHintMSELoss.py:5-16); w is (C,) or (N,C)."""
+
+    def __init__(self, reduction='mean', num_classes=19):
+        super().__init__()
+        self.reduction = reduction
+        self.num_classes = num_classes
+
+    def forward(self, inputs, targets, filter_weight):
+        return _FusedLoss.apply("whmse", inputs, _same_device_dtype(inputs, targets), None, filter_weight)
+
+
+class CrossEntropyLoss2d(nn.Module):
+    """NLLLoss(ignore_index)(log_softmax(inputs, 1), targets)  (losses/CrossEntropy.py:5-14).  Logged metric in the
+    KD trainers (never back-propagated there), so forward-only."""
+
+    def __init__(self, weight=None, size_average=True, ignore_index=255):
+        super().__init__()
+        if weight is not None or not size_average:
+            raise NotImplementedError("class weights / sum reduction are not used by any KD config")
+        self.ignore_index = ignore_index
+
+    def forward(self, inputs, targets):
+        if inputs.requires_grad and torch.is_grad_enabled():
+            inputs = inputs.detach()
+        return ops.ce2d(inputs, targets, self.ignore_index)

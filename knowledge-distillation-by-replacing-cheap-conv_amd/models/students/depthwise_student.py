@@ -1,0 +1,228 @@
+"""`DepthwiseStudent`: frozen teacher + student copy whose named blocks are swapped for cheap convs.
+
+API mirror of the reference's models/students/depthwise_student.py (replace :86-124, register_hint_layers
+:46-78, unfreeze :80-84, get_block :151-166, _set_block :134-149, forward :168-177, inference :179-185,
+reset :261-273, train :275-283).  What differs is how forward executes:
+  * a DeepWV3Plus student runs through engine.StudentEngine (hand-written HIP kernels, hints captured by name);
+  * the teacher stays a PyTorch-ROCm module under no_grad, in channels_last at the engine's dtype, on a side
+    HIP stream so its kernels overlap the student's (its logits / hints are only needed by the losses);
+  * any other architecture (e.g. the CIFAR ResNet-20 plumbing config) falls back to the reference's own
+    mechanism -- module forward + hooks -- with the replaced blocks still HIP-backed.
+"""
+import copy
+import gc
+from functools import reduce
+
+import torch
+from torch import nn
+
+from ..deeplabv3 import DeepWV3Plus
+from .transform_blocks import DepthwiseSeparableBlock
+
+BLOCKS_LEVEL_SPLIT_CHAR = '.'
+
+
+class DepthwiseStudent(nn.Module):
+    def __init__(self, teacher_model, config=None, dtype=None):
+        super().__init__()
+        self.config = config
+        self.teacher = copy.deepcopy(teacher_model)
+        if self.teacher.training:
+            self.teacher.eval()
+        for param in self.teacher.parameters():
+            param.requires_grad = False
+        self.student = copy.deepcopy(self.teacher)  # eval mode and frozen, like its source
+
+        self.replaced_block_names = []
+        self.student_hidden_outputs = list()
+        self.teacher_hidden_outputs = list()
+        self._student_hook_handlers = list()
+        self._teacher_hook_handlers = list()
+        self.aux_block_names = list()
+        self.hint_block_names = list()
+        self.save_hidden = True
+
+        # compute dtype of the fused path: bf16 (measured path) unless the config / caller asks for fp32 parity mode
+        if dtype is None:
+            dtype = torch.bfloat16
+            try:
+                if config is not None and str(config['trainer'].get('dtype', 'bf16')) in ('fp32', 'float32', 'f32'):
+                    dtype = torch.float32
+            except (KeyError, TypeError, AttributeError):
+                pass
+        self.dtype = dtype
+        self._engine = None
+        self._teacher_ready = None
+        self._side_stream = None
+        self.overlap_teacher = True
+
+    # ------------------------------------------------------------------ model surgery (host side)
+    def register_hint_layers(self, block_names):
+        if len(block_names) > 0:
+            self._remove_hooks()
+            self.hint_block_names = []
+        for block_name in block_names:
+            self.aux_block_names.append(block_name)
+            self.hint_block_names.append(block_name)
+            teacher_block = self.get_block(block_name, self.teacher)
+            student_block = self.get_block(block_name, self.student)
+
+            def teacher_handle(m, inp, out):
+                if self.save_hidden:
+                    self.teacher_hidden_outputs.append(out)
+
+            self._teacher_hook_handlers.append(teacher_block.register_forward_hook(teacher_handle))
+
+            def student_handle(m, inp, out):
+                if self.save_hidden:
+                    self.student_hidden_outputs.append(out)
+
+            # only reached on the non-fused path; the engine captures student hints by name
+            self._student_hook_handlers.append(student_block.register_forward_hook(student_handle))
+        gc.collect()
+
+    def unfreeze(self, block_names):
+        for block_name in block_names:
+            block = self.get_block(block_name, self.student)
+            for param in block.parameters():
+                param.requires_grad = True
+
+    def replace(self, blocks, **kwargs):
+        """blocks: [{"name": 'mod4.block2.convs.conv2', "epoch": 1, "args"(optional): {kernel_size, padding, dilation}}]"""
+        for block in blocks:
+            block_name = block['name']
+            self.replaced_block_names.append(block_name)
+            teacher_block = self.get_block(block_name, self.teacher)
+            args = block['args'] if "args" in block else kwargs
+            replace_block = DepthwiseSeparableBlock(in_channels=teacher_block.in_channels,
+                                                    out_channels=teacher_block.out_channels,
+                                                    kernel_size=args['kernel_size'],
+                                                    padding=args['padding'],
+                                                    dilation=args['dilation'],
+                                                    groups=teacher_block.in_channels,
+                                                    bias=teacher_block.bias)
+            ref = next(self.student.parameters())
+            replace_block.to(ref.device)
+            self._set_block(block_name, replace_block, self.student)
+        gc.collect()
+
+    def _remove_hooks(self):
+        while self._student_hook_handlers:
+            self._student_hook_handlers.pop().remove()
+        while self._teacher_hook_handlers:
+            self._teacher_hook_handlers.pop().remove()
+
+    def _set_block(self, block_name, block, model):
+        parts = block_name.split(BLOCKS_LEVEL_SPLIT_CHAR)
+        if len(parts) == 1:
+            setattr(model, block_name, block)
+        else:
+            obj = self.get_block(BLOCKS_LEVEL_SPLIT_CHAR.join(parts[:-1]), model)
+            if parts[-1].isdigit():
+                obj[int(parts[-1])] = block
+            else:
+                setattr(obj, parts[-1], block)
+
+    def get_block(self, block_name, model):
+        def step(acc, elem):
+            return acc[int(elem)] if elem.isdigit() else getattr(acc, elem)
+        return reduce(step, block_name.split(BLOCKS_LEVEL_SPLIT_CHAR), model)
+
+    # ------------------------------------------------------------------ execution
+    @property
+    def fused(self):
+        return isinstance(self.student, DeepWV3Plus)
+
+    def _student_engine(self):
+        from ...engine import StudentEngine
+        if self._engine is None or self._engine.net is not self.student or self._engine.dtype != self.dtype:
+            self._engine = StudentEngine(self.student, self.dtype)
+        self._engine.hint_names = list(self.hint_block_names) if self.save_hidden else []
+        return self._engine
+
+    def _prepare_teacher(self, device):
+        """Teacher in channels_last at the engine dtype (weights converted once per device/dtype)."""
+        key = (device, self.dtype)
+        if self._teacher_ready != key:
+            self.teacher.to(device=device, dtype=self.dtype, memory_format=torch.channels_last)
+            self._teacher_ready = key
+
+    def _teacher_forward(self, x):
+        self._prepare_teacher(x.device)
+        xt = x.to(dtype=self.dtype, memory_format=torch.channels_last)
+        with torch.no_grad():
+            return self.teacher(xt)
+
+    def forward(self, x):
+        self.student_hidden_outputs = []
+        self.teacher_hidden_outputs = []
+        if not self.fused:
+            with torch.no_grad():
+                teacher_pred = self.teacher(x)
+            return self.student(x), teacher_pred
+        if not x.is_cuda:
+            raise RuntimeError("the fused DeepWV3Plus student runs on the GPU only (no CPU fallback)")
+        from ...engine import run_student
+        engine = self._student_engine()
+        if self.overlap_teacher:
+            # frozen teacher on a side stream: its logits/hints are consumed only by the losses, so it overlaps the
+            # student's forward on the main stream
+            if self._side_stream is None or self._side_stream.device != x.device:
+                self._side_stream = torch.cuda.Stream(device=x.device)
+            main = torch.cuda.current_stream()
+            self._side_stream.wait_stream(main)
+            with torch.cuda.stream(self._side_stream):
+                teacher_pred = self._teacher_forward(x)
+            student_pred, hints = run_student(engine, x)
+            main.wait_stream(self._side_stream)
+            for t in [teacher_pred] + list(self.teacher_hidden_outputs):
+                t.record_stream(main)
+        else:
+            teacher_pred = self._teacher_forward(x)
+            student_pred, hints = run_student(engine, x)
+        if self.save_hidden:
+            self.student_hidden_outputs = hints
+        return student_pred, teacher_pred
+
+    def inference(self, x):
+        self.student_hidden_outputs = []
+        self.teacher_hidden_outputs = []
+        if not self.fused:
+            return self.student(x)
+        from ...engine import run_student
+        engine = self._student_engine()
+        engine.hint_names = []
+        with torch.no_grad():
+            pred, _ = run_student(engine, x)
+        return pred
+
+    # ------------------------------------------------------------------ bookkeeping
+    def dump_trainable_params(self):
+        params = sum(p.numel() for p in self.parameters() if p.requires_grad)
+        return '\nTrainable parameters: {}'.format(params)
+
+    def dump_student_teacher_blocks_info(self):
+        rows = ["Block name | old block params | new block params"]
+        for name in self.replaced_block_names:
+            t = sum(p.numel() for p in self.get_block(name, self.teacher).parameters())
+            s = sum(p.numel() for p in self.get_block(name, self.student).parameters())
+            rows.append(f"{name} | {t} | {s}")
+        return "\n".join(rows)
+
+    def __str__(self):
+        return super().__str__() + '\n' + self.dump_student_teacher_blocks_info()
+
+    def reset(self):
+        self._remove_hooks()
+        self.hint_block_names = []
+        while self.replaced_block_names:
+            block_name = self.replaced_block_names.pop()
+            teacher_block = self.get_block(block_name, self.teacher)
+            self._set_block(block_name, copy.deepcopy(teacher_block).float(), self.student)
+        self._engine = None
+
+    def train(self, mode=True):
+        self.save_hidden = bool(mode)
+        super().train(mode)
+        self.teacher.eval()  # teacher will always be in eval mode
+        return self

@@ -10,7 +10,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import KD_BF16, KD_F32, KD_PACK_DGRAD, KD_PACK_FWD, ConvDesc, ConvEpilogue, DwDesc, View3, check
+from ._lib import (KD_BF16, KD_F32, KD_PACK_DGRAD, KD_PACK_FWD, ConvDesc, ConvEpilogue, DwDesc, DwEpilogue, View3,
+                   check)
 
 
 def dt_of(t):
@@ -155,8 +156,8 @@ def _dw_desc(x, k, pad, dil, y=None):
     return DwDesc(dt_of(x), N, H, W, Cc, k, pad, dil, nhwc_ld(x), nhwc_ld(y) if y is not None else Cc)
 
 
-def dwconv(x, w_taps, k, pad, dil, bias=None, out=None):
-    _need_cuda(x, w_taps, bias, out)
+def dwconv(x, w_taps, k, pad, dil, bias=None, out=None, res_pre=None, mask=None, mask_scale=None, res_post=None):
+    _need_cuda(x, w_taps, bias, out, res_pre, mask, mask_scale, res_post)
     N, H, W, Cc = x.shape
     if tuple(w_taps.shape) != (k * k, Cc) or w_taps.dtype != torch.float32 or not w_taps.is_contiguous():
         raise ValueError("dwconv: w_taps must be contiguous fp32 [k*k][C]")
@@ -165,7 +166,19 @@ def dwconv(x, w_taps, k, pad, dil, bias=None, out=None):
     if tuple(out.shape) != (N, H, W, Cc) or out.dtype != x.dtype:
         raise ValueError("dwconv: bad output view")
     d = _dw_desc(x, k, pad, dil, out)
-    check(_lib.lib().kd_dwconv_fwd(C.byref(d), _ptr(x), _ptr(w_taps), _ptr(bias), _ptr(out), stream_ptr()), "kd_dwconv_fwd")
+    ep = None
+    if res_pre is not None or mask is not None or res_post is not None:
+        ep = DwEpilogue()
+        for name, t in (("res_pre", res_pre), ("mask", mask), ("res_post", res_post)):
+            if t is not None and (tuple(t.shape) != (N, H, W, Cc) or t.dtype != x.dtype):
+                raise ValueError(f"dwconv: {name} must match the output shape/dtype")
+            setattr(ep, name, _ptr(t))
+            setattr(ep, "ld_" + name, nhwc_ld(t) if t is not None else 0)
+        if mask_scale is not None and (mask_scale.dtype != torch.float32 or mask_scale.numel() != Cc):
+            raise ValueError("dwconv: mask_scale must be fp32 (C,)")
+        ep.mask_scale = _ptr(mask_scale)
+    check(_lib.lib().kd_dwconv_fwd(C.byref(d), _ptr(x), _ptr(w_taps), _ptr(bias), C.byref(ep) if ep is not None else None,
+                                   _ptr(out), stream_ptr()), "kd_dwconv_fwd")
     return out
 
 

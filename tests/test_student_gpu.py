@@ -1,0 +1,117 @@
+"""Network-level parity: DepthwiseStudent (HIP engine) vs golden vectors captured from the reference itself
+(tools/make_golden.py: g_student_step) on identical seeded weights and inputs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from _seeded import sample_idx, seeded_fill_, seeded_input  # noqa: E402
+
+
+def build_model(plan, dtype):
+    import kdcc_amd
+    from kdcc_amd.models import DeepWV3Plus
+    from kdcc_amd.models.students import DepthwiseStudent
+    teacher = DeepWV3Plus(num_classes=19)
+    seeded_fill_(teacher, "teacher.")
+    teacher.eval()
+    model = DepthwiseStudent(teacher, None, dtype=dtype)
+    model.replace([{"name": n, "epoch": 1} for n in plan], kernel_size=9, padding=20, dilation=5)
+    model.register_hint_layers(plan)
+    model.unfreeze(plan)
+    for n in plan:
+        seeded_fill_(model.get_block(n, model.student), f"student.{n}.")
+    return model.cuda()
+
+
+def check_summary(t, g, key, tol, what):
+    """t: NCHW-logical tensor; g[key.*]: the reference's fixed subsample + moments."""
+    f = t.detach().float().contiguous().reshape(-1).cpu()
+    assert list(t.shape) == [int(v) for v in g[f"{key}.shape"]], what
+    ref = g[f"{key}.sample"].astype(np.float64)
+    got = f[sample_idx(f.numel())].numpy().astype(np.float64)
+    scale = max(np.abs(ref).max(), 1e-12)
+    err = np.abs(got - ref).max() / scale
+    assert err < tol, f"{what}: sample err {err:.3e} (tol {tol})"
+    ssq = float((f.double() ** 2).sum())
+    assert abs(ssq - float(g[f"{key}.sumsq"][0])) <= 4 * tol * float(g[f"{key}.sumsq"][0]) + 1e-12, f"{what}: sumsq"
+
+
+@pytest.fixture(scope="module")
+def step_f32(golden):
+    from kdcc_amd import losses
+    g = golden("student_step_g4")
+    plan = [str(s) for s in g["plan"]]
+    model = build_model(plan, torch.float32)
+    x = seeded_input(str(g["x_key"]), (2, 3, 64, 128)).cuda()
+    tgt = torch.from_numpy(g["target"].astype(np.int64)).cuda()
+    out_st, out_tc = model(x)
+    crit = [losses.CrossEntropyLoss2d(ignore_index=255), losses.KLDivergenceLoss(1), losses.MSELoss(num_classes=1000),
+            losses.MSELoss(num_classes=1)]
+    res = dict(sup=crit[0](out_st, tgt), kd=crit[1](out_st, out_tc), tl=crit[0](out_tc, tgt), kd_mse=crit[3](out_st, out_tc))
+    hint, per = 0, []
+    for s, t in zip(model.student_hidden_outputs, model.teacher_hidden_outputs):
+        l = crit[2](s, t)
+        per.append(l)
+        hint = hint + l
+    hint.backward()
+    torch.cuda.synchronize()
+    res.update(hint=hint, per=per, model=model, out_st=out_st, out_tc=out_tc, g=g, plan=plan)
+    return res
+
+
+def test_forward_parity_fp32(step_f32):
+    r, g = step_f32, step_f32["g"]
+    check_summary(r["out_tc"], g, "teacher_logits", 1e-3, "teacher logits (PyTorch-ROCm)")
+    check_summary(r["out_st"], g, "student_logits", 1e-3, "student logits (HIP engine)")
+    m = r["model"]
+    assert len(m.student_hidden_outputs) == len(r["plan"]) == len(m.teacher_hidden_outputs)
+    for i, (s, t) in enumerate(zip(m.student_hidden_outputs, m.teacher_hidden_outputs)):
+        check_summary(t, g, f"hint_t{i}", 1e-3, f"teacher hint {i}")
+        check_summary(s, g, f"hint_s{i}", 1e-3, f"student hint {i}")
+
+
+def test_losses_parity_fp32(step_f32):
+    r, g = step_f32, step_f32["g"]
+    np.testing.assert_allclose(r["hint"].item(), float(g["hint_loss"]), rtol=1e-3)
+    np.testing.assert_allclose([p.item() for p in r["per"]], g["per_hint"], rtol=1e-3)
+    np.testing.assert_allclose(r["kd"].item(), float(g["kd_loss"]), rtol=1e-3)
+    np.testing.assert_allclose(r["kd_mse"].item(), float(g["kd_mse"]), rtol=1e-3)
+    np.testing.assert_allclose(r["sup"].item(), float(g["supervised_loss"]), rtol=1e-3)
+    np.testing.assert_allclose(r["tl"].item(), float(g["teacher_loss"]), rtol=1e-3)
+
+
+def test_gradients_parity_fp32(step_f32):
+    r, g = step_f32, step_f32["g"]
+    names = [str(s) for s in g["trainable"]]
+    got = {n: p for n, p in r["model"].student.named_parameters() if p.requires_grad}
+    assert sorted(got) == sorted(names)
+    for n in names:
+        assert got[n].grad is not None, n
+        check_summary(got[n].grad, g, f"grad:{n}", 2e-3, f"grad {n}")
+
+
+def test_bf16_step_tracks_fp32(golden):
+    """The measured (bf16) path on the same inputs: loose agreement with the reference, finite gradients."""
+    from kdcc_amd import losses
+    g = golden("student_step_g4")
+    plan = [str(s) for s in g["plan"]]
+    model = build_model(plan, torch.bfloat16)
+    x = seeded_input(str(g["x_key"]), (2, 3, 64, 128)).cuda()
+    out_st, out_tc = model(x)
+    crit = losses.MSELoss(num_classes=1000)
+    hint = 0
+    for s, t in zip(model.student_hidden_outputs, model.teacher_hidden_outputs):
+        hint = hint + crit(s, t)
+    hint.backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(hint.item(), float(g["hint_loss"]), rtol=5e-2)
+    ref = g["student_logits.sample"]
+    got = out_st.float().contiguous().reshape(-1).cpu()[sample_idx(out_st.numel())].numpy()
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 8e-2
+    for n, p in model.student.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), n
+            rs = g[f"grad:{n}.sumsq"][0]
+            assert abs(float((p.grad.double() ** 2).sum()) - rs) < 0.15 * rs, n

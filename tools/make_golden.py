@@ -284,7 +284,19 @@ def g_student_step(plan_name="g4", hw=(64, 128), batch=2):
     save(f"student_step_{plan_name}", **out)
 
 
-ALL = dict(losses=g_losses, dwsep=g_dwsep, resblock=g_resblock, aspp=g_aspp, ops=g_ops, radam=g_radam,
+def g_keys():
+    """State-dict key / shape inventory of the reference's DeepWV3Plus(19) (the checkpoint contract)."""
+    import json
+    with torch.device("meta"):
+        m = DeepWV3Plus(num_classes=19)
+    inv = {k: list(v.shape) for k, v in m.state_dict().items()}
+    path = os.path.join(OUT, "deepwv3plus_keys.json")
+    with open(path, "w") as f:
+        json.dump(inv, f)
+    print("wrote", path, len(inv), "entries", sum(int(np.prod(v)) for k, v in inv.items() if "num_batches" not in k and "running" not in k), "params")
+
+
+ALL = dict(keys=g_keys, losses=g_losses, dwsep=g_dwsep, resblock=g_resblock, aspp=g_aspp, ops=g_ops, radam=g_radam,
            student_step=g_student_step)
 
 if __name__ == "__main__":
