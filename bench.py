@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the KD train step, DeepLabV3+(WRN-38) student, 1024x2048 synthetic
+Cityscapes-shaped tensors (BASELINE.json).  One process per GPU:
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A step = what trainer/layerwise_trainer.py:220-239 of the reference does per batch: teacher forward (frozen, PyTorch-
+ROCm), student forward (HIP engine), the four criteria (CE x2, KD, hint), loss = hint loss, backward, (N>1: bucketed
+RCCL all-reduce of the trainable gradients, overlapped with backward), RAdam step, zero_grad.  Inputs are resident in
+HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PLANS = {
+    # P92 = 92.13 M-parameter student (BASELINE's "92M"); P79 = cfg/cityscapes/58M_deeplab_all.json verbatim
+    "P92": ["mod4.block2.convs.conv2", "mod4.block3.convs.conv1", "mod7.block1.convs.conv2",
+            "aspp.features.1.0", "aspp.features.2.0", "aspp.features.3.0"],
+    "P79": ["mod4.block2.convs.conv2", "mod4.block3.convs.conv1", "mod4.block3.convs.conv2", "mod4.block4.convs.conv2",
+            "mod4.block5.convs.conv2", "mod4.block6.convs.conv2", "mod5.block2.convs.conv2", "mod7.block1.convs.conv2",
+            "aspp.features.1.0", "aspp.features.2.0", "aspp.features.3.0"],
+}
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md chip-level table
+PEAK_F32_TFLOPS = 157.3
+
+
+def build(plan, dtype, device, seed=123):
+    import kdcc_amd
+    from kdcc_amd import losses
+    from kdcc_amd.models import DeepWV3Plus
+    from kdcc_amd.models.students import DepthwiseStudent
+    from kdcc_amd.utils.optim import RAdam
+    torch.manual_seed(seed)                       # train.py:17-21 of the reference
+    teacher = DeepWV3Plus(num_classes=19).eval()  # random init: the Cityscapes checkpoint is not shipped
+    cpu_sd = {k: v.detach().clone() for k, v in teacher.state_dict().items() if not k.endswith("num_batches_tracked")}
+    model = DepthwiseStudent(teacher, None, dtype=dtype).to(device)
+    model.replace([{"name": n, "epoch": 1} for n in plan], kernel_size=9, padding=20, dilation=5)
+    model.register_hint_layers(plan)
+    model.unfreeze(plan)
+    crit = [losses.CrossEntropyLoss2d(ignore_index=255), losses.KLDivergenceLoss(1), losses.MSELoss(num_classes=1000)]
+    opt = RAdam([p for p in model.student.parameters() if p.requires_grad], lr=0.005)
+    return model, crit, opt, cpu_sd
+
+
+def kd_step(model, crit, opt, data, target):
+    out_st, out_tc = model(data)
+    sup = crit[0](out_st, target)
+    kd = crit[1](out_st, out_tc)
+    tl = crit[0](out_tc, target)
+    hint = 0
+    for s, t in zip(model.student_hidden_outputs, model.teacher_hidden_outputs):
+        hint = hint + crit[2](s, t)
+    loss = hint                      # "Only use hint loss", layerwise_trainer.py:233-235
+    loss.backward()
+    opt.step()
+    opt.zero_grad()
+    return loss, sup, kd, tl
+
+
+def cpu_baseline(cpu_sd, model, plan, hw=(256, 512)):
+    """The network-level oracle (stock torch CPU ops, fp32) timed on this box's host cores on a bounded sample."""
+    from oracle import net_ref
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    new = {}
+    for n in plan:
+        blk = model.get_block(n, model.student)
+        new[f"{n}.separable_conv.weight"] = blk.separable_conv.weight.detach().float().cpu()
+        new[f"{n}.pointwise_conv.weight"] = blk.pointwise_conv.weight.detach().float().cpu()
+    ssd = net_ref.make_student_sd(cpu_sd, plan, new)
+    g = torch.Generator().manual_seed(1000)
+    x = torch.randn((1, 3) + hw, generator=g)
+    tgt = torch.randint(0, 19, (1,) + hw, generator=g)
+    net_ref.kd_step(cpu_sd, ssd, x[:, :, :64, :128].contiguous(), tgt[:, :64, :128].contiguous(), plan)  # warm-up
+    t0 = time.perf_counter()
+    net_ref.kd_step(cpu_sd, ssd, x, tgt, plan)
+    dt = time.perf_counter() - t0
+    frac = (hw[0] * hw[1]) / (1024.0 * 2048.0)
+    return {"value": frac / dt, "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"1 KD step (teacher fwd + student fwd + hint bwd, fp32 torch CPU ops = oracle/net_ref.py) at "
+                      f"{hw[0]}x{hw[1]} = {frac:.4f} of a 1024x2048 image, {dt:.2f} s; value = that fraction / time"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--plan", default="P92", choices=sorted(PLANS))
+    ap.add_argument("--batch", type=int, default=1, help="images per GPU")
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="run the teacher on the main stream")
+    a = ap.parse_args()
+
+    import kdcc_amd
+    from kdcc_amd import ops, parallel
+    rank, local, world = parallel.init_distributed()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    device = torch.device("cuda", local)
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    plan = PLANS[a.plan]
+    model, crit, opt, cpu_sd = build(plan, dtype, device)
+    model.overlap_teacher = not a.no_overlap
+    if world > 1:
+        eng = model._student_engine()
+        eng.reducer = parallel.GradReducer(eng.grad_production_order())
+
+    g = torch.Generator().manual_seed(1000 + rank)
+    data = torch.randn((a.batch, 3, a.height, a.width), generator=g).to(device)
+    target = torch.randint(0, 19, (a.batch, a.height, a.width), generator=g)
+    target[:, :32] = 255
+    target = target.to(device)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        kd_step(model, crit, opt, data, target)
+    sync()
+    prof = []
+    ops.PROFILER = prof
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss, sup, kd, tl = kd_step(model, crit, opt, data, target)
+    sync()
+    dt = time.perf_counter() - t0
+    ops.PROFILER = None
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        # dominant kernel: the implicit-GEMM conv (student forward + dgrad); live HIP-event timing of every launch
+        flops = sum(p[1] for p in prof)
+        ms = sum(p[2].elapsed_time(p[3]) for p in prof)
+        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        res = {
+            "metric": "images/sec KD train step, DeepLabV3+(WRN38) student 1024x2048",
+            "value": world * a.batch * a.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"KD train step (frozen teacher fwd + student fwd + CE/KD/hint criteria + hint-loss bwd + "
+                                   f"RAdam), DeepLabV3+(WRN-38) student plan {a.plan} ({len(plan)} cheap-conv blocks, 9x9 d5), "
+                                   f"{a.height}x{a.width}, {a.batch} image/GPU, random-init weights",
+                       "plan": a.plan, "per_gpu_batch": a.batch, "global_batch": world * a.batch,
+                       "parallelism": f"dp{world}", "teacher_overlap": bool(model.overlap_teacher)},
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (student dense conv fwd + dgrad)", "achieved": ach,
+                         "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                         "launches_per_step": len(prof) / max(a.steps, 1), "ms_per_step_in_kernel": ms / max(a.steps, 1),
+                         "algorithmic_tflop_per_step": flops / max(a.steps, 1) / 1e12},
+            "losses": {"hint": float(loss), "supervised": float(sup), "kd": float(kd), "teacher": float(tl)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cpu_sd, model, plan)
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

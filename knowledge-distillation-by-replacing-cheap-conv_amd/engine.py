@@ -73,6 +73,16 @@ class StudentEngine:
         self._pack = {}   # (id(param), version, tag) -> packed tensor
         self._bn = {}     # id(bn) -> (scale, shift)
         self._tape = None
+        self.reducer = None   # optional parallel.GradReducer: gradients are written into its buckets and announced
+
+    def _grad_like(self, p):
+        if self.reducer is not None:
+            return self.reducer.grad_buffer(p)
+        return torch.empty_like(p, dtype=torch.float32)
+
+    def _grad_done(self, p):
+        if self.reducer is not None:
+            self.reducer.grad_ready(p)
 
     # ------------------------------------------------------------------ parameter operands
     def _packed(self, p, tag, fn):
@@ -205,7 +215,8 @@ class StudentEngine:
         f = net.final
         sc, sh = self._bn_fold(f[1])
         d1 = self._new(N, h2, w2, 256)
-        ops.conv2d(dec0, self._w_fwd(f[0], cin_pad=320), 1, 1, 1, out_act=d1, act_scale=sc, act_shift=sh, act_relu=True)
+        ops.conv2d(dec0, self._w_fwd(f[0], cin_pad=320), 1, 1, 1, out_act=d1, act_scale=sc, act_shift=sh, act_relu=True,
+                   algo_cin=304)
         sc, sh = self._bn_fold(f[4])
         d2 = self._new(N, h2, w2, 256)
         ops.conv2d(d1, self._w_fwd(f[3]), 1, 1, 1, out_act=d2, act_scale=sc, act_shift=sh, act_relu=True)
@@ -294,6 +305,24 @@ class StudentEngine:
         return x_out, a_next, rg, rec
 
     # ------------------------------------------------------------------ backward
+    def grad_production_order(self):
+        """Trainable parameters in the order backward produces their gradients (ASPP branches first, then the trunk
+        blocks from mod7 back to the first trainable block; within a block last conv first, pointwise before depthwise)."""
+        net, order = self.net, []
+
+        def add(mod):
+            if isinstance(mod, DepthwiseSeparableBlock):
+                for p in (mod.pointwise_conv.weight, mod.separable_conv.weight):
+                    if p.requires_grad:
+                        order.append(p)
+        for br in net.aspp.features:
+            add(br[0])
+        blocks = [blk for i in range(2, 8) for _, blk in getattr(net, f"mod{i}").named_children()]
+        for blk in reversed(blocks):
+            for _, m in reversed([(n, m) for n, m in blk.convs.named_children() if n.startswith("conv")]):
+                add(m)
+        return order
+
     def backward(self, hint_grads):
         """hint_grads: list aligned with forward()'s hints; entries are (N,h,w,C) NHWC tensors or None.
         Returns {parameter: fp32 gradient} for every trainable parameter reached."""
@@ -351,6 +380,8 @@ class StudentEngine:
                     raise EngineError("gradient through pool3 is not supported")
                 g_block_out[bi - 1] = g_xin if (bi - 1) not in g_block_out else g_block_out[bi - 1].add_(g_xin)
         self._tape = None
+        if self.reducer is not None:
+            self.reducer.finish()   # current stream waits for the (already overlapped) bucket all-reduces
         return grads
 
     def _as_nhwc(self, g):
@@ -380,18 +411,20 @@ class StudentEngine:
         """Backward of dw -> pw: both weight gradients, and (optionally) the input gradient with epilogue `ep`."""
         dw, pw = site.mod.separable_conv, site.mod.pointwise_conv
         if pw.weight.requires_grad:
-            gw = torch.empty_like(pw.weight, dtype=torch.float32)
+            gw = self._grad_like(pw.weight)
             ops.pw_wgrad(mid, g, gw)
             grads[pw.weight] = gw
+            self._grad_done(pw.weight)
         if not (dw.weight.requires_grad or need_in):
             return None
         N, H, W, _ = g.shape
         g_mid = self._new(N, H, W, pw.in_channels)
         ops.conv2d(g, self._w_dgrad(pw), out_raw=g_mid)
         if dw.weight.requires_grad:
-            gw = torch.empty_like(dw.weight, dtype=torch.float32)
+            gw = self._grad_like(dw.weight)
             ops.dwconv_wgrad(a_in, g_mid, gw, site.k, site.pad, site.dil)
             grads[dw.weight] = gw
+            self._grad_done(dw.weight)
         if not need_in:
             return None
         return ops.dwconv(g_mid, self._w_dw(dw, True), site.k, site.dil * (site.k - 1) - site.pad, site.dil, **ep)

@@ -14,6 +14,11 @@ from ._lib import (KD_BF16, KD_F32, KD_PACK_DGRAD, KD_PACK_FWD, ConvDesc, ConvEp
                    check)
 
 
+# Optional live profiler (bench.py): a list that receives (kernel family, algorithmic flops, start event, end event)
+# for every dense-conv launch, recorded on the stream the kernel is launched on.
+PROFILER = None
+
+
 def dt_of(t):
     if t.dtype == torch.bfloat16:
         return KD_BF16
@@ -78,7 +83,7 @@ def pack_conv_weight(w, dtype, mode=KD_PACK_FWD, cin_pad=None):
 
 
 def conv2d(x, w_packed, stride=1, pad=0, dil=1, *, res_pre=None, mask=None, mask_scale=None, res_post=None,
-           out_raw=None, out_act=None, act_scale=None, act_shift=None, act_relu=False):
+           out_raw=None, out_act=None, act_scale=None, act_shift=None, act_relu=False, algo_cin=None):
     """Implicit-GEMM conv; w_packed is (Cout,kh,kw,Cin). Outputs are caller-provided NHWC views."""
     _need_cuda(x, w_packed)
     N, H, W, Cin = x.shape
@@ -115,7 +120,15 @@ def conv2d(x, w_packed, stride=1, pad=0, dil=1, *, res_pre=None, mask=None, mask
     ep.out_act, ep.ld_act = _ptr(out_act), chk(out_act, "out_act")
     chk_vec(act_scale, "act_scale"); chk_vec(act_shift, "act_shift")
     ep.act_scale, ep.act_shift, ep.act_relu = _ptr(act_scale), _ptr(act_shift), int(act_relu)
+    prof = PROFILER
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(_lib.lib().kd_conv2d_fwd(C.byref(d), _ptr(x), _ptr(w_packed), C.byref(ep), stream_ptr()), "kd_conv2d_fwd")
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        prof.append(("conv_igemm", 2.0 * N * Ho * Wo * Cout * kh * kw * (algo_cin or Cin), e0, e1))
     return out_raw, out_act
 
 

@@ -1,0 +1,152 @@
+"""Network-level CPU oracle: the reference's KD train step restated with stock torch CPU ops.
+
+TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg) -- never imported by the
+product package and independent of it: the graph is written here functionally over a flat {checkpoint key: tensor}
+dict, following the reference line by line:
+  DeepWV3Plus.forward                      models/deeplabv3/deeplabv3.py:141-162
+  _AtrousSpatialPyramidPoolingModule       models/deeplabv3/deeplabv3.py:64-75
+  IdentityResidualBlock.forward            models/encoders/wider_resnet.py:169-182  (incl. the in-place add that
+                                           aliases a hook on the block's last conv with the block output)
+  WiderResNetA2 layout                     models/encoders/wider_resnet.py:304-356
+  DepthwiseSeparableBlock                  models/students/transform_blocks/depthwise_separable_conv.py:4-13
+  DepthwiseStudent.forward / hooks         models/students/depthwise_student.py:46-78,168-177
+  the four criteria + loss = hint_loss     trainer/layerwise_trainer.py:223-235, losses/*.py
+Pinned by tests/golden/student_step_g4.npz (outputs of the reference itself), see tests/test_oracle_net.py.
+"""
+import torch
+import torch.nn.functional as F
+
+CHANNELS = [(128, 128), (256, 256), (512, 512), (512, 1024), (512, 1024, 2048), (1024, 2048, 4096)]
+STRUCTURE = [3, 3, 6, 3, 1, 1]
+EPS = 1e-5
+
+
+def _bnrelu(sd, p, x, relu=True):
+    y = F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.0, EPS)
+    return F.relu(y) if relu else y
+
+
+def _conv(sd, name, x, stride, pad, dil, cheap_geom):
+    """Dense conv `name`, or -- when the student's dict holds a replaced block there -- depthwise k x k then 1x1."""
+    if name + ".weight" in sd:
+        return F.conv2d(x, sd[name + ".weight"], None, stride, pad, dil)
+    k, p, d = cheap_geom
+    wd = sd[name + ".separable_conv.weight"]
+    y = F.conv2d(x, wd, sd.get(name + ".separable_conv.bias"), 1, p, d, groups=wd.shape[0])
+    return F.conv2d(y, sd[name + ".pointwise_conv.weight"], sd.get(name + ".pointwise_conv.bias"))
+
+
+def _upsample(x, size):
+    return F.interpolate(x, size=size, mode="bilinear", align_corners=True)
+
+
+def forward(sd, x, hint_names=(), cheap_geom=(9, 20, 5)):
+    """Returns (logits, [hint tensors in forward-execution order], [their names])."""
+    want = set(hint_names)
+    hints, names = [], []
+
+    def note(name, t):
+        if name in want:
+            hints.append(t)
+            names.append(name)
+
+    x = F.conv2d(x, sd["mod1.conv1.weight"], None, 1, 1)
+    m2 = None
+    for mod_id, nblocks in enumerate(STRUCTURE):
+        mname = f"mod{mod_id + 2}"
+        if mod_id < 2:
+            x = F.max_pool2d(x, 3, stride=2, padding=1)
+        for b in range(nblocks):
+            p = f"{mname}.block{b + 1}"
+            ch = CHANNELS[mod_id]
+            dil = 2 if mod_id == 3 else (4 if mod_id > 3 else 1)
+            stride = 2 if (b == 0 and mod_id == 2) else 1
+            a = _bnrelu(sd, p + ".bn1.0", x)
+            shortcut = F.conv2d(a, sd[p + ".proj_conv.weight"], None, stride) if (p + ".proj_conv.weight") in sd else x
+            if len(ch) == 2:
+                c1 = _conv(sd, p + ".convs.conv1", a, stride, dil, dil, cheap_geom)
+                note(p + ".convs.conv1", c1)
+                out = _conv(sd, p + ".convs.conv2", _bnrelu(sd, p + ".convs.bn2.0", c1), 1, dil, dil, cheap_geom)
+                last = "conv2"
+            else:
+                c1 = _conv(sd, p + ".convs.conv1", a, stride, 0, 1, cheap_geom)
+                note(p + ".convs.conv1", c1)
+                c2 = _conv(sd, p + ".convs.conv2", _bnrelu(sd, p + ".convs.bn2.0", c1), 1, dil, dil, cheap_geom)
+                note(p + ".convs.conv2", c2)
+                out = _conv(sd, p + ".convs.conv3", _bnrelu(sd, p + ".convs.bn3.0", c2), 1, 0, 1, cheap_geom)  # dropout: eval
+                last = "conv3"
+            out = out + shortcut           # reference: out.add_(shortcut) -> hooked tensor == block output
+            note(p + ".convs." + last, out)
+            note(p + ".convs", out)
+            x = out
+        if mod_id == 0:
+            m2 = x
+    # ASPP
+    size = x.shape[2:]
+    img = F.adaptive_avg_pool2d(x, 1)
+    img = _bnrelu(sd, "aspp.img_conv.1", F.conv2d(img, sd["aspp.img_conv.0.weight"]))
+    outs = [_upsample(img, size)]
+    for i, r in enumerate([None, 12, 24, 36]):
+        n = f"aspp.features.{i}.0"
+        y = _conv(sd, n, x, 1, 0 if r is None else r, 1 if r is None else r, cheap_geom)
+        note(n, y)
+        outs.append(_bnrelu(sd, f"aspp.features.{i}.1", y))
+    x = torch.cat(outs, 1)
+    dec0_up = F.conv2d(x, sd["bot_aspp.weight"])
+    dec0 = torch.cat([F.conv2d(m2, sd["bot_fine.weight"]), _upsample(dec0_up, m2.shape[2:])], 1)
+    y = _bnrelu(sd, "final.1", F.conv2d(dec0, sd["final.0.weight"], None, 1, 1))
+    y = _bnrelu(sd, "final.4", F.conv2d(y, sd["final.3.weight"], None, 1, 1))
+    y = F.conv2d(y, sd["final.6.weight"])
+    return _upsample(y, (y.shape[2] * 2, y.shape[3] * 2)), hints, names
+
+
+def kl_div_loss(s, t, T=1.0):  # losses/KLDiv.py:19-23
+    return F.kl_div(F.log_softmax(s / T, dim=1), F.softmax(t / T, dim=1), reduction="mean") * (T ** 2) * t.shape[1]
+
+
+def mse_loss(s, t, num_classes):  # losses/MSELoss.py:14-16
+    return F.mse_loss(s, t) * num_classes
+
+
+def weighted_hint_loss(s, t, w):  # losses/WeightedHintMSELoss.py:12-16
+    m = ((s - t) ** 2).mean(dim=(-1, -2))
+    return ((w * m).sum(dim=-1) / w.sum(dim=-1)).mean()
+
+
+def kd_step(teacher_sd, student_sd, x, target, plan, hint_num_classes=1000, temperature=1.0, cheap_geom=(9, 20, 5),
+            hint_weights=None):
+    """One reference-faithful step (loss = hint loss only).  student_sd tensors with requires_grad=True are the
+    trainable set; returns a dict of losses / outputs / gradients."""
+    with torch.no_grad():
+        t_logits, t_hints, _ = forward(teacher_sd, x, plan, cheap_geom)
+    s_logits, s_hints, names = forward(student_sd, x, plan, cheap_geom)
+    hint = 0
+    per = []
+    for i, (s, t) in enumerate(zip(s_hints, t_hints)):
+        l = mse_loss(s, t, hint_num_classes) if hint_weights is None else weighted_hint_loss(s, t, hint_weights[i])
+        per.append(l)
+        hint = hint + l
+    train = {k: v for k, v in student_sd.items() if v.requires_grad}
+    grads = torch.autograd.grad(hint, list(train.values())) if train else []
+    out = dict(hint_loss=hint.detach(), per_hint=[p.detach() for p in per], student_logits=s_logits.detach(),
+               teacher_logits=t_logits, student_hints=[h.detach() for h in s_hints], teacher_hints=t_hints,
+               hint_names=names, grads=dict(zip(train.keys(), grads)),
+               kd_loss=kl_div_loss(s_logits.detach(), t_logits, temperature),
+               kd_mse=mse_loss(s_logits.detach(), t_logits, 1))
+    if target is not None:
+        out["supervised_loss"] = F.cross_entropy(s_logits.detach(), target, ignore_index=255)
+        out["teacher_loss"] = F.cross_entropy(t_logits, target, ignore_index=255)
+    return out
+
+
+def make_student_sd(teacher_sd, plan, new_weights, trainable=None):
+    """Student dict = teacher dict with each plan entry's dense weight replaced by the cheap-conv pair."""
+    sd = {k: v.detach().clone() for k, v in teacher_sd.items()}
+    for name in plan:
+        del sd[name + ".weight"]
+        for suffix in ("separable_conv.weight", "pointwise_conv.weight"):
+            sd[f"{name}.{suffix}"] = new_weights[f"{name}.{suffix}"].detach().clone()
+    for name in (plan if trainable is None else trainable):
+        for suffix in ("separable_conv.weight", "pointwise_conv.weight"):
+            sd[f"{name}.{suffix}"].requires_grad_(True)
+    return sd

@@ -1,0 +1,41 @@
+"""Pins the network-level oracle (oracle/net_ref.py) against the reference's own student-step outputs. CPU only."""
+import numpy as np
+import torch
+
+from _netutil import seeded_cheap_weights, seeded_teacher_sd
+from _seeded import sample_idx, seeded_input
+from oracle import net_ref
+
+
+def _cmp(t, g, key, tol=2e-5):
+    f = t.detach().float().contiguous().reshape(-1)
+    assert list(t.shape) == [int(v) for v in g[f"{key}.shape"]]
+    ref = g[f"{key}.sample"].astype(np.float64)
+    got = f[sample_idx(f.numel())].numpy().astype(np.float64)
+    assert np.abs(got - ref).max() <= tol * max(np.abs(ref).max(), 1e-12), key
+
+
+def test_net_oracle_matches_reference_step(golden):
+    g = golden("student_step_g4")
+    plan = [str(s) for s in g["plan"]]
+    torch.set_num_threads(8)
+    tsd = seeded_teacher_sd()
+    ssd = net_ref.make_student_sd(tsd, plan, seeded_cheap_weights(tsd, plan))
+    x = seeded_input(str(g["x_key"]), (2, 3, 64, 128))
+    tgt = torch.from_numpy(g["target"].astype(np.int64))
+    r = net_ref.kd_step(tsd, ssd, x, tgt, plan)
+    np.testing.assert_allclose(r["hint_loss"].item(), float(g["hint_loss"]), rtol=1e-5)
+    np.testing.assert_allclose([p.item() for p in r["per_hint"]], g["per_hint"], rtol=1e-5)
+    np.testing.assert_allclose(r["kd_loss"].item(), float(g["kd_loss"]), rtol=1e-4)
+    np.testing.assert_allclose(r["kd_mse"].item(), float(g["kd_mse"]), rtol=1e-4)
+    np.testing.assert_allclose(r["supervised_loss"].item(), float(g["supervised_loss"]), rtol=1e-5)
+    np.testing.assert_allclose(r["teacher_loss"].item(), float(g["teacher_loss"]), rtol=1e-5)
+    _cmp(r["student_logits"], g, "student_logits")
+    _cmp(r["teacher_logits"], g, "teacher_logits")
+    assert r["hint_names"] == plan  # forward-execution order == plan order for this plan
+    for i in range(len(plan)):
+        _cmp(r["student_hints"][i], g, f"hint_s{i}")
+        _cmp(r["teacher_hints"][i], g, f"hint_t{i}")
+    assert sorted(r["grads"]) == sorted(str(s) for s in g["trainable"])
+    for n, gr in r["grads"].items():
+        _cmp(gr, g, f"grad:{n}", tol=1e-4)

