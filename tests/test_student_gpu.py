@@ -114,7 +114,7 @@ def test_bf16_step_tracks_fp32(golden):
     torch.cuda.synchronize()
     np.testing.assert_allclose(hint.item(), float(g["hint_loss"]), rtol=5e-2)
     ref = g["student_logits.sample"]
-    got = out_st.float().contiguous().reshape(-1).cpu()[sample_idx(out_st.numel())].numpy()
+    got = out_st.detach().float().contiguous().reshape(-1).cpu()[sample_idx(out_st.numel())].numpy()
     assert np.abs(got - ref).max() / np.abs(ref).max() < 8e-2
     for n, p in model.student.named_parameters():
         if p.requires_grad:
