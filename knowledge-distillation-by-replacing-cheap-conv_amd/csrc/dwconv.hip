@@ -89,9 +89,13 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwParams p)
         const T *xr = xb + (size_t)hin * p.W * p.ldx;
 #pragma unroll
         for (int idx = 0; idx < TR + K - 1; ++idx) {
+            // unconditional load from a clamped address, zeroed by a select afterwards: a branch per load would make
+            // hipcc wait vmcnt(0) at every join, i.e. TR+K-1 dependent memory round trips per row
             const int win = w0 - p.pad + idx * p.dil;
-            if (win >= 0 && win < p.W) ld4<T>(xr + (size_t)win * p.ldx, xv[idx]);
-            else { xv[idx][0] = xv[idx][1] = xv[idx][2] = xv[idx][3] = 0.f; }
+            const bool ok = win >= 0 && win < p.W;
+            const int wc = win < 0 ? 0 : (win >= p.W ? p.W - 1 : win);
+            ld4<T>(xr + (size_t)wc * p.ldx, xv[idx]);
+            if (!ok) { xv[idx][0] = xv[idx][1] = xv[idx][2] = xv[idx][3] = 0.f; }
         }
 #pragma unroll
         for (int s = 0; s < TS; ++s) {
@@ -192,14 +196,17 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwWgradParams p
 #pragma unroll
                 for (int r = 0; r < TR; ++r) {
                     const int w = w0 + r * p.dil;
-                    if (w < p.W) ld4<T>(dyr + (size_t)w * p.ld_dy, g[r]);
-                    else { g[r][0] = g[r][1] = g[r][2] = g[r][3] = 0.f; }
+                    const int wc = w >= p.W ? p.W - 1 : w;
+                    ld4<T>(dyr + (size_t)wc * p.ld_dy, g[r]);
+                    if (w >= p.W) { g[r][0] = g[r][1] = g[r][2] = g[r][3] = 0.f; }
                 }
 #pragma unroll
                 for (int idx = 0; idx < TR + K - 1; ++idx) {
                     const int win = w0 - p.pad + idx * p.dil;
-                    if (win >= 0 && win < p.W) ld4<T>(xr + (size_t)win * p.ldx, xv[idx]);
-                    else { xv[idx][0] = xv[idx][1] = xv[idx][2] = xv[idx][3] = 0.f; }
+                    const bool ok = win >= 0 && win < p.W;
+                    const int wc = win < 0 ? 0 : (win >= p.W ? p.W - 1 : win);
+                    ld4<T>(xr + (size_t)wc * p.ldx, xv[idx]);
+                    if (!ok) { xv[idx][0] = xv[idx][1] = xv[idx][2] = xv[idx][3] = 0.f; }
                 }
 #pragma unroll
                 for (int j = 0; j < K; ++j)

@@ -52,8 +52,10 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float *__restrict_
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int wi = ww - 1 + kx;
-                float v = 0.f;
-                if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = x[((size_t)(n * 3 + ci) * H + hi) * W + wi];
+                const bool ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
+                const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi), wc = wi < 0 ? 0 : (wi >= W ? W - 1 : wi);
+                float v = x[((size_t)(n * 3 + ci) * H + hc) * W + wc];  // unconditional load, select after (no branch per tap)
+                v = ok ? v : 0.f;
                 const float *wr = &wl[(ci * 9 + ky * 3 + kx) * 64 + cg * 16];
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[q] = fmaf(v, wr[q], acc[q]);

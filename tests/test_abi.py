@@ -1,0 +1,57 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/kdcc.h declares; no compute calls."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    import kdcc_amd
+    return kdcc_amd
+
+
+def test_exports_every_declared_symbol(built):
+    from kdcc_amd import _lib
+    header = open(os.path.join(ROOT, "include", "kdcc.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(kd_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in kdcc.h but not exported"
+    assert sorted(_lib.exported_symbols()) == declared, "ctypes binding table and kdcc.h disagree"
+    assert _lib.lib().kd_version() >= 100
+
+
+def test_no_cpu_fallback(built):
+    """The product path refuses CPU tensors instead of silently computing somewhere else."""
+    from kdcc_amd import losses, ops
+    from kdcc_amd._lib import KdccError
+    with pytest.raises(KdccError):
+        ops.hint_mse(torch.zeros(1, 4, 2, 2), torch.zeros(1, 4, 2, 2), 1000)
+    with pytest.raises(KdccError):
+        losses.MSELoss(num_classes=1000)(torch.zeros(1, 4, 2, 2, requires_grad=True), torch.zeros(1, 4, 2, 2))
+
+
+def test_missing_library_is_loud(built, monkeypatch):
+    from kdcc_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libkdcc_hip.so")
+    with pytest.raises(_lib.KdccError):
+        _lib.lib()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "knowledge-distillation-by-replacing-cheap-conv_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"

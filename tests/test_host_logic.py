@@ -1,0 +1,129 @@
+"""CPU-only host logic: model surgery API, checkpoint-key contract, parameter counts, optimizer, reducer ordering."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+import kdcc_amd  # noqa: F401
+from kdcc_amd.models import DeepWV3Plus, forgiving_state_restore
+from kdcc_amd.models.students import DepthwiseSeparableBlock, DepthwiseStudent
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+P79 = ["mod4.block2.convs.conv2", "mod4.block3.convs.conv1", "mod4.block3.convs.conv2", "mod4.block4.convs.conv2",
+       "mod4.block5.convs.conv2", "mod4.block6.convs.conv2", "mod5.block2.convs.conv2", "mod7.block1.convs.conv2",
+       "aspp.features.1.0", "aspp.features.2.0", "aspp.features.3.0"]
+P92 = ["mod4.block2.convs.conv2", "mod4.block3.convs.conv1", "mod7.block1.convs.conv2", "aspp.features.1.0",
+       "aspp.features.2.0", "aspp.features.3.0"]
+
+
+@pytest.fixture(scope="module")
+def teacher():
+    with torch.device("meta"):
+        return DeepWV3Plus(num_classes=19)
+
+
+def nparams(m):
+    return sum(p.numel() for p in m.parameters())
+
+
+def test_checkpoint_key_contract(teacher):
+    """Names and shapes equal the reference's DeepWV3Plus(19).state_dict() (captured by tools/make_golden.py)."""
+    ref = json.load(open(os.path.join(HERE, "golden", "deepwv3plus_keys.json")))
+    mine = {k: list(v.shape) for k, v in teacher.state_dict().items()}
+    assert list(mine) == list(ref) and mine == ref
+    assert nparams(teacher) == 137103936  # README "137M"; SURVEY F10
+
+
+@pytest.mark.parametrize("plan,total,trainable", [(P79, 79752256, 8708608), (P92, 92127808, 6928384)])
+def test_replace_unfreeze_counts(teacher, plan, total, trainable):
+    """Parameter counts of the shipped 58M plan and of the 92M plan."""
+    with torch.device("meta"):
+        m = DepthwiseStudent(teacher, None)
+        m.replace([{"name": n, "epoch": 1} for n in plan], kernel_size=9, padding=20, dilation=5)
+    m.register_hint_layers(plan)
+    m.unfreeze(plan)
+    assert nparams(m.student) == total
+    assert sum(p.numel() for p in m.student.parameters() if p.requires_grad) == trainable
+    assert all(not p.requires_grad for p in m.teacher.parameters())
+    assert not m.student.training and not m.teacher.training          # student stays in eval mode
+    blk = m.get_block(plan[0], m.student)
+    assert isinstance(blk, DepthwiseSeparableBlock) and blk.geometry == (9, 20, 5)
+    keys = m.state_dict().keys()
+    assert f"student.{plan[0]}.separable_conv.weight" in keys and f"student.{plan[0]}.pointwise_conv.weight" in keys
+    assert f"teacher.{plan[0]}.weight" in keys                          # checkpoints hold both copies (App. B item 11)
+    assert m.replaced_block_names == plan and m.hint_block_names == plan
+    # per-entry args override the defaults
+    with torch.device("meta"):
+        m2 = DepthwiseStudent(teacher, None)
+        m2.replace([{"name": plan[0], "epoch": 1, "args": {"kernel_size": 3, "padding": 1, "dilation": 1}}],
+                   kernel_size=9, padding=20, dilation=5)
+    assert m2.get_block(plan[0], m2.student).geometry == (3, 1, 1)
+    # a new hint list replaces the old hooks (App. B 6a); reset restores the teacher's blocks
+    m.register_hint_layers(plan[:2])
+    assert m.hint_block_names == plan[:2] and len(m._teacher_hook_handlers) == 2
+    m.train()
+    assert m.save_hidden and not m.teacher.training
+    m.train(False)
+    assert not m.save_hidden
+    with torch.device("meta"):
+        m.reset()
+    assert nparams(m.student) == 137103936 and m.replaced_block_names == []
+
+
+def test_engine_rejects_unsupported_graphs(teacher):
+    from kdcc_amd.engine import EngineError, StudentEngine, _Site
+    with torch.device("meta"):
+        m = DepthwiseStudent(teacher, None)
+        m.replace([{"name": n, "epoch": 1} for n in P92], kernel_size=9, padding=20, dilation=5)
+    m.unfreeze(P92)
+    eng = StudentEngine(m.student)
+    order = eng.grad_production_order()
+    names = {id(p): n for n, p in m.student.named_parameters()}
+    got = [names[id(p)] for p in order]
+    assert got[0] == "aspp.features.1.0.pointwise_conv.weight" and got[-1] == "mod4.block2.convs.conv2.separable_conv.weight"
+    assert len(got) == 12
+    # dense trainable convs are refused loudly rather than silently skipped
+    m.student.mod5.block1.convs.conv1.weight.requires_grad = True
+    with pytest.raises(EngineError):
+        _Site("mod5.block1.convs.conv1", m.student.mod5.block1.convs.conv1)
+
+
+def test_forgiving_state_restore():
+    a, b = nn.Linear(4, 3), nn.Linear(4, 3)
+    sd = {"module." + k: v.clone() + 1 for k, v in a.state_dict().items()}   # DataParallel-style checkpoint
+    sd["module.extra"] = torch.zeros(1)
+    forgiving_state_restore(b, sd)
+    assert torch.equal(b.weight, a.weight + 1)
+    c = nn.Linear(4, 5)
+    forgiving_state_restore(c, a.state_dict())   # shape mismatch -> silently skipped (App. B item 10)
+    assert c.weight.shape == (5, 4)
+
+
+def test_radam_cpu_path_matches_reference(golden):
+    from kdcc_amd.utils.optim import RAdam
+    g = golden("radam")
+    p = torch.from_numpy(g["p"][0].copy()).requires_grad_(True)
+    opt = RAdam([p], lr=float(g["lr"]))
+    for i in range(8):
+        p.grad = torch.from_numpy(g["g"][i].copy())
+        opt.step()
+        np.testing.assert_allclose(p.detach().numpy(), g["p"][i + 1], rtol=2e-6, atol=1e-7)
+
+
+def test_weight_scheduler_and_lr_scheduler_names():
+    from kdcc_amd.utils import WeightScheduler, optim
+    w = WeightScheduler({"alpha": {"value": 0.0001, "anneal_rate": 2, "max": 0}, "beta": {"value": 0.99, "anneal_rate": 0.95, "min": 0.99},
+                         "gamma": {"value": 1, "anneal_rate": 1}})
+    w.step()
+    assert (w.alpha, w.beta, w.gamma) == (0, 0.99, 1)
+    w.reset()
+    assert w.alpha == 0.0001
+    p = torch.zeros(1, requires_grad=True)
+    sch = optim.lr_scheduler.MyReduceLROnPlateau(optim.RAdam([p], lr=0.005), mode="min", threshold=0.01, factor=0.5, patience=0,
+                                                 verbose=True, min_lr=1e-05, threshold_mode="rel")
+    sch.step(1.0); sch.step(1.0)
+    assert sch.optimizer.param_groups[0]["lr"] == 0.0025
+    sch.reset()
