@@ -7,3 +7,6 @@ Import as `kdcc_amd` (see kdcc_amd.py at the repo root).
 __version__ = "0.1.0"
 
 from . import _lib  # noqa: F401
+
+from . import losses, models, trainer, utils  # noqa: E402,F401
+from .parse_config import ConfigParser  # noqa: E402,F401

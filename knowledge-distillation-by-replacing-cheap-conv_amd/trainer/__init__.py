@@ -1,0 +1,2 @@
+from .classification_trainer import ClassificationTrainer  # noqa: F401
+from .layerwise_trainer import LayerwiseTrainer  # noqa: F401

@@ -1,0 +1,274 @@
+"""`LayerwiseTrainer`: the KD training loop with the reference's constructor, epoch semantics and logged keys
+(trainer/layerwise_trainer.py:18-427).  Reference behaviour that is kept on purpose: loss = hint loss only (:233-235);
+the student is left in eval mode (:211-215); the optimizer is rebuilt at epoch 1 from requires_grad parameters (:175-186);
+`len_epoch + 1` iterations per epoch (:277-278); the plateau scheduler steps on the running mean of `loss` (:293-296).
+
+Re-designed for the GPU: no per-step host synchronisation (the reference does five `.item()` and two full-logit D2H
+copies per step, :244-250): losses are accumulated as device scalars, the confusion matrices are built on the device and
+only read at log points; with torch.distributed initialised each rank runs its own shard and gradients are averaged by
+parallel.GradReducer from inside backward.
+"""
+import gc
+from functools import reduce
+
+import torch
+from torch import nn
+
+from ..base import BaseTrainer
+from ..models import forgiving_state_restore
+from ..utils import CityscapesMetricTracker, EarlyStopTracker, MetricTracker, inf_loop
+from ..utils import optim as optim_module
+from ..utils.optim.lr_scheduler import MyOneCycleLR, MyReduceLROnPlateau
+
+_LOSS_KEYS = ('loss', 'supervised_loss', 'kd_loss', 'hint_loss', 'teacher_loss')
+
+
+class LayerwiseTrainer(BaseTrainer):
+    def __init__(self, model, criterions, metric_ftns, optimizer, config, train_data_loader, valid_data_loader=None,
+                 lr_scheduler=None, weight_scheduler=None):
+        super().__init__(model, None, metric_ftns, optimizer, config)
+        self.config = config
+        self.train_data_loader = train_data_loader
+        self.valid_data_loader = valid_data_loader
+        self.do_validation = self.valid_data_loader is not None
+        self.do_validation_interval = self.config['trainer']['do_validation_interval']
+        self.lr_scheduler = lr_scheduler
+        self.weight_scheduler = weight_scheduler
+        self.log_step = config['trainer']['log_step']
+        if "len_epoch" in self.config['trainer']:
+            self.train_data_loader = inf_loop(train_data_loader)   # iteration-based training
+            self.len_epoch = self.config['trainer']['len_epoch']
+        else:
+            self.len_epoch = len(self.train_data_loader)            # epoch-based training
+
+        names = [m.__name__ for m in self.metric_ftns]
+        self.train_metrics = MetricTracker(*_LOSS_KEYS, *names, writer=self.writer)
+        self.train_iou_metrics = CityscapesMetricTracker(writer=self.writer)
+        self.train_teacher_iou_metrics = CityscapesMetricTracker(writer=self.writer)
+        self.valid_metrics = MetricTracker(*_LOSS_KEYS, *names, writer=self.writer)
+        self.valid_iou_metrics = CityscapesMetricTracker(writer=self.writer)
+        self.test_metrics = MetricTracker(*_LOSS_KEYS, *names, *['teacher_' + n for n in names], writer=self.writer)
+        self.test_iou_metrics = CityscapesMetricTracker(writer=self.writer)
+        self.val_iou_tracker = EarlyStopTracker('best', 'max', 0.01, 'rel')
+
+        self.criterions = nn.ModuleList(criterions).to(self.device)
+        del self.criterion
+        self.track_miou = bool(self.config['trainer'].get('track_train_miou', True))
+        self._reducer = None
+        if 'resume_path' in self.config['trainer']:
+            self.resume(self.config['trainer']['resume_path'])
+
+    # ------------------------------------------------------------------ epoch preparation (host side)
+    def prepare_train_epoch(self, epoch, config=None):
+        """Apply the plan entries scheduled for `epoch`: replace layers, (re)register hints, unfreeze, fix the optimizer."""
+        if config is None:
+            config = self.config
+        self.reset_scheduler()
+        pruning = config['pruning']
+        if (epoch == 1) and (len(pruning['pruning_plan']) + len(pruning['hint']) + len(pruning['unfreeze'])) == 0:
+            self.logger.debug('Train a student with identical architecture with teacher')
+            for param in self.model.student.parameters():
+                param.requires_grad = True
+            self.logger.info(self.model.dump_trainable_params())
+            self.create_new_optimizer()
+            return
+        epochs = [x['epoch'] for x in pruning['pruning_plan'] + pruning['hint'] + pruning['unfreeze']]
+        if epoch not in epochs:
+            self.logger.info('EPOCH: ' + str(epoch))
+            self.logger.info('There is no update ...')
+            return
+        replaced_layers = [x for x in pruning['pruning_plan'] if x['epoch'] == epoch]
+        hint_layers = [x['name'] for x in pruning['hint'] if x['epoch'] == epoch]
+        unfreeze_cfg = [x for x in pruning['unfreeze'] if x['epoch'] == epoch]
+        unfreeze_layers = [x['name'] for x in unfreeze_cfg]
+        self.logger.info('EPOCH: ' + str(epoch))
+        self.logger.info('Replaced layers: ' + str(replaced_layers))
+        self.logger.info('Hint layers: ' + str(hint_layers))
+        self.logger.info('Unfreeze layers: ' + str(unfreeze_layers))
+        if 'args' in pruning:
+            kwargs = pruning['args']
+        else:
+            self.logger.warning('Using deprecate checkpoint...')
+            kwargs = pruning['pruner']
+        self.model.replace(replaced_layers, **kwargs)
+        self.model.register_hint_layers(hint_layers)
+        self.model.unfreeze(unfreeze_layers)
+        if epoch == 1:
+            self.create_new_optimizer()   # fresh optimizer: no stale momentum (the one passed to __init__ is discarded)
+        else:
+            self.update_optimizer(unfreeze_cfg)
+        self._reducer = None              # trainable set changed: rebuild the gradient buckets lazily
+        self.logger.info(self.model.dump_trainable_params())
+        self.logger.info(self.model.dump_student_teacher_blocks_info())
+
+    def update_optimizer(self, unfreeze_config):
+        """Add the newly unfrozen layers as param groups ({'name':..., 'epoch':..., 'lr'(optional): ...})."""
+        if len(unfreeze_config) > 0:
+            self.logger.debug('Updating optimizer for new layer')
+        for cfg in unfreeze_config:
+            self.logger.debug('Add parameters of layer: {} to optimizer'.format(cfg['name']))
+            layer = self.model.get_block(cfg['name'], self.model.student)
+            optimizer_arg = self.config['optimizer']['args']
+            if "lr" in cfg:
+                optimizer_arg['lr'] = cfg['lr']
+            self.optimizer.add_param_group({'params': layer.parameters(), **optimizer_arg})
+
+    def create_new_optimizer(self):
+        self.logger.debug('Creating new optimizer ...')
+        self.optimizer = self.config.init_obj('optimizer', optim_module,
+                                              [p for p in self.model.student.parameters() if p.requires_grad])
+        self.lr_scheduler = self.config.init_obj('lr_scheduler', optim_module.lr_scheduler, self.optimizer)
+
+    def reset_scheduler(self):
+        """Reset schedulers, metrics and trackers when new layers are unfrozen."""
+        self.weight_scheduler.reset()
+        self.val_iou_tracker.reset()
+        self.train_metrics.reset()
+        self.valid_metrics.reset()
+        self.train_iou_metrics.reset()
+        self.valid_iou_metrics.reset()
+        self.train_teacher_iou_metrics.reset()
+        if isinstance(self.lr_scheduler, MyReduceLROnPlateau):
+            self.lr_scheduler.reset()
+
+    # ------------------------------------------------------------------ data-parallel plumbing
+    def _attach_reducer(self):
+        if self.world_size == 1 or self._reducer is not None:
+            return
+        from ..parallel import GradReducer
+        if getattr(self.model, "fused", False):
+            eng = self.model._student_engine()
+            self._reducer = GradReducer(eng.grad_production_order())
+            eng.reducer = self._reducer
+        else:
+            params = [p for p in reversed(list(self.model.student.parameters())) if p.requires_grad]
+            self._reducer = GradReducer(params)
+
+    def _reduce_unfused_grads(self):
+        """Non-fused students (plain module graphs): all-reduce after backward."""
+        if self.world_size == 1 or getattr(self.model, "fused", False):
+            return
+        for p in self._reducer.params:
+            self._reducer.grad_buffer(p).copy_(p.grad)
+            self._reducer.grad_ready(p)
+        self._reducer.finish()
+        for p in self._reducer.params:
+            p.grad.copy_(self._reducer.grad_buffer(p))
+
+    # ------------------------------------------------------------------ the hot loop
+    def _hint_loss(self):
+        pairs = zip(self.model.student_hidden_outputs, self.model.teacher_hidden_outputs)
+        return reduce(lambda acc, st: acc + self.criterions[2](st[0], st[1]), pairs, 0)
+
+    def _train_epoch(self, epoch):
+        self.prepare_train_epoch(epoch)
+        # the student deliberately stays in eval mode (reference :211-215); hints must be collected even after a
+        # validation pass switched them off (reference latent bug)
+        self.model.save_hidden = True
+        self.train_iou_metrics.reset()
+        self.train_teacher_iou_metrics.reset()
+        self._clean_cache()
+        self._attach_reducer()
+
+        for batch_idx, (data, target) in enumerate(self.train_data_loader):
+            data, target = data.to(self.device, non_blocking=True), target.to(self.device, non_blocking=True)
+            output_st, output_tc = self.model(data)
+
+            supervised_loss = self.criterions[0](output_st, target) / self.accumulation_steps
+            kd_loss = self.criterions[1](output_st, output_tc) / self.accumulation_steps
+            teacher_loss = self.criterions[0](output_tc, target)   # for comparison
+            hint_loss = self._hint_loss() / self.accumulation_steps
+
+            loss = hint_loss                                        # only use hint loss
+            loss.backward()
+            self._reduce_unfused_grads()
+            if batch_idx % self.accumulation_steps == 0:
+                self.optimizer.step()
+                self.optimizer.zero_grad()
+            self.writer.set_step((epoch - 1) * self.len_epoch + batch_idx)
+
+            acc = self.accumulation_steps
+            self.train_metrics.update('loss', loss.detach() * acc)
+            self.train_metrics.update('supervised_loss', supervised_loss.detach() * acc)
+            self.train_metrics.update('kd_loss', kd_loss.detach() * acc)
+            self.train_metrics.update('hint_loss', hint_loss.detach() * acc)
+            self.train_metrics.update('teacher_loss', teacher_loss.detach())
+            if self.track_miou:
+                self.train_iou_metrics.update(output_st, target)
+                self.train_teacher_iou_metrics.update(output_tc, target)
+            for met in self.metric_ftns:
+                self.train_metrics.update(met.__name__, met(output_st, target))
+
+            if batch_idx % self.log_step == 0 and self.rank == 0:
+                self.logger.info(
+                    'Train Epoch: {} [{}]/[{}] Loss: {:.6f} mIoU: {:.6f} Teacher mIoU: {:.6f} Supervised Loss: {:.6f} '
+                    'Knowledge Distillation loss: {:.6f} Hint Loss: {:.6f} Teacher Loss: {:.6f}'.format(
+                        epoch, batch_idx, self.len_epoch, self.train_metrics.avg('loss'), self.train_iou_metrics.get_iou(),
+                        self.train_teacher_iou_metrics.get_iou(), self.train_metrics.avg('supervised_loss'),
+                        self.train_metrics.avg('kd_loss'), self.train_metrics.avg('hint_loss'),
+                        self.train_metrics.avg('teacher_loss')))
+            if batch_idx == self.len_epoch:
+                break
+
+        log = self.train_metrics.result()
+        log.update({'train_teacher_mIoU': self.train_teacher_iou_metrics.get_iou()})
+        log.update({'train_student_mIoU': self.train_iou_metrics.get_iou()})
+        if self.do_validation and ((epoch % self.config["trainer"]["do_validation_interval"]) == 0):
+            val_log = self._valid_epoch(epoch)
+            log.update(**{'val_' + k: v for k, v in val_log.items()})
+            log.update(**{'val_mIoU': self.valid_iou_metrics.get_iou()})
+            self.val_iou_tracker.update(self.valid_iou_metrics.get_iou())
+        self._teacher_student_iou_gap = self.train_teacher_iou_metrics.get_iou() - self.train_iou_metrics.get_iou()
+
+        if (self.lr_scheduler is not None) and (not isinstance(self.lr_scheduler, MyOneCycleLR)):
+            if isinstance(self.lr_scheduler, MyReduceLROnPlateau):
+                self.lr_scheduler.step(self.train_metrics.avg('loss'))
+            else:
+                self.lr_scheduler.step()
+        self.weight_scheduler.step()
+        return log
+
+    def _valid_epoch(self, epoch):
+        self._clean_cache()
+        self.model.save_hidden = False
+        self.valid_metrics.reset()
+        self.valid_iou_metrics.reset()
+        with torch.no_grad():
+            for batch_idx, (data, target) in enumerate(self.valid_data_loader):
+                data, target = data.to(self.device), target.to(self.device)
+                output = self.model.inference(data)
+                supervised_loss = self.criterions[0](output, target)
+                self.writer.set_step((epoch - 1) * len(self.valid_data_loader) + batch_idx, 'valid')
+                self.valid_metrics.update('supervised_loss', supervised_loss)
+                self.valid_iou_metrics.update(output, target)
+                for met in self.metric_ftns:
+                    self.valid_metrics.update(met.__name__, met(output, target))
+        result = self.valid_metrics.result()
+        result['mIoU'] = self.valid_iou_metrics.get_iou()
+        return result
+
+    def _test_epoch(self, epoch):
+        raise NotImplementedError("sliding-window test-time inference / submission export is outside the KD hot path "
+                                  "(SURVEY section 2, 'TTA / submission': out of scope)")
+
+    def _clean_cache(self):
+        self.model.student_hidden_outputs, self.model.teacher_hidden_outputs = list(), list()
+        gc.collect()
+
+    def resume(self, checkpoint_path):
+        """Rebuild the replaced-block topology by replaying prepare_train_epoch for every saved epoch, then load weights."""
+        self.logger.info("Loading checkpoint: {} ...".format(checkpoint_path))
+        checkpoint = torch.load(checkpoint_path, map_location=torch.device('cpu'), weights_only=False)
+        self.start_epoch = checkpoint['epoch'] + 1
+        self.mnt_best = checkpoint['monitor_best']
+        config = checkpoint['config']
+        for i in range(1, checkpoint['epoch'] + 1):
+            self.prepare_train_epoch(i, config)
+        forgiving_state_restore(self.model, checkpoint['state_dict'])
+        self.logger.info("Loaded model's state dict")
+        if checkpoint['config']['optimizer']['type'] != self.config['optimizer']['type']:
+            self.logger.warning("Warning: Optimizer type given in config file is different from that of checkpoint. "
+                                "Optimizer parameters not being resumed.")
+        else:
+            self.optimizer.load_state_dict(checkpoint['optimizer'])
+        self.logger.info("Checkpoint loaded. Resume training from epoch {}".format(self.start_epoch))

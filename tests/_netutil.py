@@ -30,3 +30,26 @@ def seeded_cheap_weights(teacher_sd, plan, k=9, dtype=torch.float32):
         out[f"{n}.separable_conv.weight"] = seeded_value(f"student.{n}.separable_conv.weight", torch.empty(cin, 1, k, k)).to(dtype)
         out[f"{n}.pointwise_conv.weight"] = seeded_value(f"student.{n}.pointwise_conv.weight", torch.empty(cout, cin, 1, 1)).to(dtype)
     return out
+
+
+def trainer_config(plan, lr, len_epoch, save_dir, n_gpu=1, dtype="fp32"):
+    """A config dict in the reference's JSON schema (cfg/cityscapes/*.json) for a tiny synthetic run
+    (the same dict tools/make_golden.py feeds the reference's ConfigParser / LayerwiseTrainer)."""
+    ent = [{"name": n, "epoch": 1} for n in plan]
+    return {
+        "name": "golden_trainer", "n_gpu": n_gpu,
+        "teacher": {"type": "DeepWV3Plus", "args": {"num_classes": 19}},
+        "optimizer": {"type": "RAdam", "args": {"lr": lr}},
+        "supervised_loss": {"type": "CrossEntropyLoss2d", "args": {"ignore_index": 255}},
+        "kd_loss": {"type": "MSELoss", "args": {"reduction": "mean", "num_classes": 1}},
+        "hint_loss": {"type": "MSELoss", "args": {"reduction": "mean", "num_classes": 1000}},
+        "metrics": [],
+        "lr_scheduler": {"type": "MyReduceLROnPlateau", "args": {"mode": "min", "threshold": 0.01, "factor": 0.5, "patience": 0,
+                                                               "verbose": True, "min_lr": 1e-05, "threshold_mode": "rel"}},
+        "trainer": {"name": "LayerwiseTrainer", "epochs": 1, "save_dir": save_dir, "save_period": 100, "verbosity": 0,
+                    "monitor": "off", "accumulation_steps": 1, "log_step": 100, "do_validation_interval": 100,
+                    "len_epoch": len_epoch, "tensorboard": False, "dtype": dtype},
+        "pruning": {"args": {"dilation": 5, "padding": 20, "kernel_size": 9}, "pruning_plan": ent, "hint": ent, "unfreeze": ent},
+        "weight_scheduler": {"alpha": {"value": 0.0001, "anneal_rate": 2, "max": 0}, "beta": {"value": 0.99, "anneal_rate": 0.95, "min": 0.99},
+                             "gamma": {"value": 1, "anneal_rate": 1}},
+    }

@@ -26,13 +26,13 @@ def seeded_value(key, t):
     if key.endswith("running_mean"):
         return torch.randn(shape, generator=g) * 0.1
     if t.dim() == 1 and key.endswith(".weight"):  # BN gamma
-        return torch.rand(shape, generator=g) + 0.5
+        return torch.rand(shape, generator=g) * 0.5 + 0.5
     if t.dim() == 1:  # biases (BN beta, conv bias)
         return torch.randn(shape, generator=g) * 0.1
     fan_in = 1
     for d in shape[1:]:
         fan_in *= d
-    return torch.randn(shape, generator=g) * (2.0 / fan_in) ** 0.5
+    return torch.randn(shape, generator=g) * (1.0 / fan_in) ** 0.5
 
 
 def seeded_fill_(module, prefix=""):

@@ -284,6 +284,68 @@ def g_student_step(plan_name="g4", hw=(64, 128), batch=2):
     save(f"student_step_{plan_name}", **out)
 
 
+def trainer_config(plan, lr, len_epoch, save_dir):
+    """A config dict in the reference's JSON schema (cfg/cityscapes/*.json) for a tiny synthetic run."""
+    ent = [{"name": n, "epoch": 1} for n in plan]
+    return {
+        "name": "golden_trainer", "n_gpu": 0,
+        "teacher": {"type": "DeepWV3Plus", "args": {"num_classes": 19}},
+        "optimizer": {"type": "RAdam", "args": {"lr": lr}},
+        "supervised_loss": {"type": "CrossEntropyLoss2d", "args": {"ignore_index": 255}},
+        "kd_loss": {"type": "MSELoss", "args": {"reduction": "mean", "num_classes": 1}},
+        "hint_loss": {"type": "MSELoss", "args": {"reduction": "mean", "num_classes": 1000}},
+        "metrics": [],
+        "lr_scheduler": {"type": "MyReduceLROnPlateau", "args": {"mode": "min", "threshold": 0.01, "factor": 0.5, "patience": 0,
+                                                               "verbose": True, "min_lr": 1e-05, "threshold_mode": "rel"}},
+        "trainer": {"name": "LayerwiseTrainer", "epochs": 1, "save_dir": save_dir, "save_period": 100, "verbosity": 0,
+                    "monitor": "off", "accumulation_steps": 1, "log_step": 100, "do_validation_interval": 100,
+                    "len_epoch": len_epoch, "tensorboard": False},
+        "pruning": {"args": {"dilation": 5, "padding": 20, "kernel_size": 9}, "pruning_plan": ent, "hint": ent, "unfreeze": ent},
+        "weight_scheduler": {"alpha": {"value": 0.0001, "anneal_rate": 2, "max": 0}, "beta": {"value": 0.99, "anneal_rate": 0.95, "min": 0.99},
+                             "gamma": {"value": 1, "anneal_rate": 1}},
+    }
+
+
+def g_trainer_epoch():
+    """LayerwiseTrainer._train_epoch(1) of the reference on seeded synthetic batches: the log dict after
+    len_epoch+1 = 3 iterations and the trainable tensors after 3 RAdam steps (trainer/layerwise_trainer.py:203-305)."""
+    import tempfile
+    from parse_config import ConfigParser
+    from trainer import LayerwiseTrainer
+    from utils import WeightScheduler
+    from utils import optim as ref_optim
+    plan = PLANS["g4"]
+    cfgd = trainer_config(plan, lr=1e-3, len_epoch=2, save_dir=tempfile.mkdtemp(prefix="kdgold_"))
+    config = ConfigParser(cfgd, run_id="g")
+    teacher = DeepWV3Plus(num_classes=19); seeded_fill_(teacher, "teacher."); teacher.eval()
+    model = DepthwiseStudent(teacher, config)
+    # new blocks must be seeded AFTER replace(): wrap it (replace runs inside prepare_train_epoch)
+    orig_replace = model.replace
+    def replace_and_seed(blocks, **kw):
+        orig_replace(blocks, **kw)
+        for b in blocks:
+            seeded_fill_(model.get_block(b["name"], model.student), f"student.{b['name']}.")
+    model.replace = replace_and_seed
+    crit = [config.init_obj(k, ref_losses) for k in ("supervised_loss", "kd_loss", "hint_loss")]
+    opt = config.init_obj("optimizer", ref_optim, model.student.parameters())
+    sched = config.init_obj("lr_scheduler", ref_optim.lr_scheduler, opt)
+    batches = []
+    for i in range(3):
+        x = seeded_input(f"trainer.x{i}", (2, 3, 64, 128))
+        t = torch.randint(0, 19, (2, 64, 128), generator=torch.Generator().manual_seed(100 + i)); t[:, :4] = 255
+        batches.append((x, t))
+    tr = LayerwiseTrainer(model, crit, [], opt, config, [(x, t.clone()) for x, t in batches], None, sched,
+                          WeightScheduler(config["weight_scheduler"]))
+    log = tr._train_epoch(1)
+    out = {"plan": np.array(plan), "lr": 1e-3, "targets": np.stack([t.numpy() for _, t in batches]).astype(np.uint8)}
+    for k, v in log.items():
+        out["log:" + k] = np.float64(v)
+    for n, p in model.student.named_parameters():
+        if p.requires_grad:
+            out["param:" + n] = summarize(p.data)
+    save("trainer_epoch_g4", **out)
+
+
 def g_keys():
     """State-dict key / shape inventory of the reference's DeepWV3Plus(19) (the checkpoint contract)."""
     import json
@@ -296,7 +358,7 @@ def g_keys():
     print("wrote", path, len(inv), "entries", sum(int(np.prod(v)) for k, v in inv.items() if "num_batches" not in k and "running" not in k), "params")
 
 
-ALL = dict(keys=g_keys, losses=g_losses, dwsep=g_dwsep, resblock=g_resblock, aspp=g_aspp, ops=g_ops, radam=g_radam,
+ALL = dict(keys=g_keys, trainer_epoch=g_trainer_epoch, losses=g_losses, dwsep=g_dwsep, resblock=g_resblock, aspp=g_aspp, ops=g_ops, radam=g_radam,
            student_step=g_student_step)
 
 if __name__ == "__main__":
