@@ -370,3 +370,6 @@ def radam_step(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay):
             raise ValueError("radam_step: fp32 contiguous tensors of equal size required")
     check(_lib.lib().kd_radam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(step), C.c_float(lr), C.c_float(beta1),
                                    C.c_float(beta2), C.c_float(eps), C.c_float(weight_decay), stream_ptr()), "kd_radam_step")
+    # the kernel wrote through raw pointers: tell autograd / version-keyed caches (engine weight packs) about it
+    for t in (p, m, v):
+        torch.autograd.graph.increment_version(t)
