@@ -6,6 +6,7 @@
 // every weight quad k*R of them; 16 consecutive lanes cover 64 contiguous channels
 // (128/256 B per pixel per load instruction).  Weights sit in LDS tap-major.
 // VALU/L1-bound by design (81 FMA per output element); no MFMA reshaping.
+#include <stdlib.h>
 #include <string.h>
 
 #include "kd_common.h"
@@ -14,8 +15,7 @@ namespace {
 
 constexpr int CB = 64;    // channels per block
 constexpr int CQ = 16;    // channel quads per block (threads along channels)
-constexpr int TS = 2;     // lattice rows per thread
-constexpr int TR = 8;     // lattice cols per thread
+constexpr int WTR = 8;    // lattice cols per thread in the weight-gradient kernel
 
 struct DwParams {
     const void *x;
@@ -47,7 +47,7 @@ __device__ __forceinline__ void st4(bf16_t *p, const float (&v)[4])
 }
 
 // grid: x = ceil(tiles_h*tiles_w / 16), y = ceil(C / 64), z = N * dil * dil
-template <typename T, int K>
+template <typename T, int K, int TS, int TR>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwParams p)
 {
     __shared__ __attribute__((aligned(16))) float wl[K * K * CB];
@@ -123,28 +123,42 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwParams p)
     for (int s = 0; s < TS; ++s) {
         const int h = h0 + s * p.dil;
         if (h >= p.H) continue;
+        // epilogue operands for the whole output row are loaded first (independent loads in flight together)
+        float e_pre[TR][4], e_msk[TR][4], e_post[TR][4];
+        size_t pix[TR];
 #pragma unroll
         for (int r = 0; r < TR; ++r) {
             const int w = w0 + r * p.dil;
-            if (w >= p.W) continue;
-            const size_t pix = ((size_t)n * p.H + h) * p.W + w;
-            float t4[4];
-            if (e.res_pre) {
-                ld4<T>((const T *)e.res_pre + pix * e.ld_res_pre + c, t4);
+            pix[r] = ((size_t)n * p.H + h) * p.W + (w < p.W ? w : p.W - 1);
+        }
+        if (e.res_pre) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[s][r][q] += t4[q];
+            for (int r = 0; r < TR; ++r) ld4<T>((const T *)e.res_pre + pix[r] * e.ld_res_pre + c, e_pre[r]);
+        }
+        if (e.mask) {
+#pragma unroll
+            for (int r = 0; r < TR; ++r) ld4<T>((const T *)e.mask + pix[r] * e.ld_mask + c, e_msk[r]);
+        }
+        if (e.res_post) {
+#pragma unroll
+            for (int r = 0; r < TR; ++r) ld4<T>((const T *)e.res_post + pix[r] * e.ld_res_post + c, e_post[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            const int w = w0 + r * p.dil;
+            if (e.res_pre) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[s][r][q] += e_pre[r][q];
             }
             if (e.mask) {
-                ld4<T>((const T *)e.mask + pix * e.ld_mask + c, t4);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[s][r][q] = t4[q] > 0.f ? acc[s][r][q] * ms[q] : 0.f;
+                for (int q = 0; q < 4; ++q) acc[s][r][q] = e_msk[r][q] > 0.f ? acc[s][r][q] * ms[q] : 0.f;
             }
             if (e.res_post) {
-                ld4<T>((const T *)e.res_post + pix * e.ld_res_post + c, t4);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[s][r][q] += t4[q];
+                for (int q = 0; q < 4; ++q) acc[s][r][q] += e_post[r][q];
             }
-            st4(yb + ((size_t)h * p.W + w) * p.ldy, acc[s][r]);
+            if (w < p.W) st4(yb + ((size_t)h * p.W + w) * p.ldy, acc[s][r]);
         }
     }
 }
@@ -189,19 +203,19 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwWgradParams p
             const T *dyr = (const T *)p.dy + ((size_t)n * p.H + h) * p.W * p.ld_dy + c;
             const T *xr = (const T *)p.x + ((size_t)n * p.H + hin) * p.W * p.ldx + c;
 #pragma unroll 1
-            for (int lw0 = 0; lw0 < p.LW; lw0 += TR) {
+            for (int lw0 = 0; lw0 < p.LW; lw0 += WTR) {
                 const int w0 = rw + p.dil * lw0;
                 if (w0 >= p.W) break;
-                float g[TR][4], xv[TR + K - 1][4];
+                float g[WTR][4], xv[WTR + K - 1][4];
 #pragma unroll
-                for (int r = 0; r < TR; ++r) {
+                for (int r = 0; r < WTR; ++r) {
                     const int w = w0 + r * p.dil;
                     const int wc = w >= p.W ? p.W - 1 : w;
                     ld4<T>(dyr + (size_t)wc * p.ld_dy, g[r]);
                     if (w >= p.W) { g[r][0] = g[r][1] = g[r][2] = g[r][3] = 0.f; }
                 }
 #pragma unroll
-                for (int idx = 0; idx < TR + K - 1; ++idx) {
+                for (int idx = 0; idx < WTR + K - 1; ++idx) {
                     const int win = w0 - p.pad + idx * p.dil;
                     const bool ok = win >= 0 && win < p.W;
                     const int wc = win < 0 ? 0 : (win >= p.W ? p.W - 1 : win);
@@ -211,7 +225,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwWgradParams p
 #pragma unroll
                 for (int j = 0; j < K; ++j)
 #pragma unroll
-                    for (int r = 0; r < TR; ++r) {
+                    for (int r = 0; r < WTR; ++r) {
                         acc[j][0] = fmaf(g[r][0], xv[r + j][0], acc[j][0]);
                         acc[j][1] = fmaf(g[r][1], xv[r + j][1], acc[j][1]);
                         acc[j][2] = fmaf(g[r][2], xv[r + j][2], acc[j][2]);
@@ -309,17 +323,27 @@ extern "C" int kd_dwconv_fwd(const kd_dw_desc *d, const void *x, const float *w_
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.pad = d->pad; p.dil = d->dil; p.ldx = d->ldx; p.ldy = d->ldy;
     p.LH = (d->H + d->dil - 1) / d->dil;
     p.LW = (d->W + d->dil - 1) / d->dil;
-    p.tiles_h = (p.LH + TS - 1) / TS;
-    p.tiles_w = (p.LW + TR - 1) / TR;
+    // thread tile (lattice rows x cols per thread): 2x8 measured fastest at the student's shapes
+    int ts = 2, tr = 8;
+    if (const char *e = getenv("KDCC_DW_TILE")) sscanf(e, "%dx%d", &ts, &tr);   // tuning hook (2x8 | 2x4 | 4x4)
+    p.tiles_h = (p.LH + ts - 1) / ts;
+    p.tiles_w = (p.LW + tr - 1) / tr;
     const dim3 grid((unsigned)((p.tiles_h * p.tiles_w + 15) / 16), (unsigned)((d->C + CB - 1) / CB),
                     (unsigned)(d->N * d->dil * d->dil));
     hipStream_t s = (hipStream_t)stream;
+#define KD_DW_LAUNCH(TT, KK, A, B) hipLaunchKernelGGL((dwconv_fwd_kernel<TT, KK, A, B>), grid, dim3(256), 0, s, p)
+#define KD_DW_TILES(TT, KK)                                   \
+    do {                                                      \
+        if (ts == 2 && tr == 4) KD_DW_LAUNCH(TT, KK, 2, 4);   \
+        else if (ts == 4 && tr == 4) KD_DW_LAUNCH(TT, KK, 4, 4); \
+        else KD_DW_LAUNCH(TT, KK, 2, 8);                      \
+    } while (0)
     if (d->dtype == KD_BF16) {
-        if (d->k == 9) hipLaunchKernelGGL((dwconv_fwd_kernel<bf16_t, 9>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((dwconv_fwd_kernel<bf16_t, 3>), grid, dim3(256), 0, s, p);
+        if (d->k == 9) KD_DW_TILES(bf16_t, 9);
+        else KD_DW_TILES(bf16_t, 3);
     } else {
-        if (d->k == 9) hipLaunchKernelGGL((dwconv_fwd_kernel<float, 9>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((dwconv_fwd_kernel<float, 3>), grid, dim3(256), 0, s, p);
+        if (d->k == 9) KD_DW_TILES(float, 9);
+        else KD_DW_TILES(float, 3);
     }
     KD_CHECK_LAUNCH("kd_dwconv_fwd");
     return KD_OK;

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Standalone microbenchmark of the depthwise kernels at the student's shapes (GPU box only)."""
+import sys, os
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import kdcc_amd
+from kdcc_amd import ops
+
+def t(fn, it=10):
+    for _ in range(2): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(it): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / it
+
+for C in (512, 1024, 4096):
+    H, W, k, p, d = 128, 256, 9, 20, 5
+    x = torch.randn(1, H, W, C, device="cuda").bfloat16()
+    g = torch.randn(1, H, W, C, device="cuda").bfloat16()
+    w = torch.randn(C, 1, k, k, device="cuda") / k
+    wt = ops.pack_dw_weight(w)
+    y = torch.empty_like(x)
+    dw = torch.empty_like(w)
+    ws = torch.empty(ops._lib.lib().kd_dwconv_wgrad_workspace(__import__("ctypes").byref(ops._dw_desc(x, k, p, d))), dtype=torch.uint8, device="cuda")
+    fl = 2.0 * k * k * C * H * W
+    by = 2.0 * 2 * C * H * W
+    ms = t(lambda: ops.dwconv(x, wt, k, p, d, out=y))
+    print(f"dw fwd   C={C:5d}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TFLOP/s  {by/ms/1e6:7.1f} GB/s (algorithmic in+out)")
+    ms = t(lambda: ops.dwconv(x, wt, k, p, d, out=y, mask=g, mask_scale=torch.ones(C, device='cuda'), res_post=g))
+    print(f"dw dgrad(mask+res) C={C:5d}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TFLOP/s")
+    ms = t(lambda: ops.dwconv_wgrad(x, g, dw, k, p, d, workspace=ws))
+    print(f"dw wgrad C={C:5d}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TFLOP/s")
