@@ -67,11 +67,17 @@ def kd_step(model, crit, opt, data, target):
     return loss, sup, kd, tl
 
 
-def cpu_baseline(cpu_sd, model, plan, hw=(256, 512)):
+def cpu_baseline(cpu_sd, model, plan, hw=(512, 1024)):
     """The network-level oracle (stock torch CPU ops, fp32) timed on this box's host cores on a bounded sample."""
     from oracle import net_ref
-    threads = os.cpu_count() or 1
+    # the box's CPU share, not the host's core count (oversubscribed OpenMP threads spin for minutes)
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        threads = os.cpu_count() or 1
+    threads = max(1, min(threads, 16))
     torch.set_num_threads(threads)
+    print(f"[bench] cpu_baseline: oracle/net_ref.py on {threads} host threads, one {hw[0]}x{hw[1]} step ...", file=sys.stderr, flush=True)
     new = {}
     for n in plan:
         blk = model.get_block(n, model.student)
@@ -85,6 +91,7 @@ def cpu_baseline(cpu_sd, model, plan, hw=(256, 512)):
     t0 = time.perf_counter()
     net_ref.kd_step(cpu_sd, ssd, x, tgt, plan)
     dt = time.perf_counter() - t0
+    print(f"[bench] cpu_baseline: {dt:.2f} s", file=sys.stderr, flush=True)
     frac = (hw[0] * hw[1]) / (1024.0 * 2048.0)
     return {"value": frac / dt, "unit": "images/sec", "cores": threads, "kind": "port",
             "sample": f"1 KD step (teacher fwd + student fwd + hint bwd, fp32 torch CPU ops = oracle/net_ref.py) at "
@@ -103,6 +110,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the teacher on the main stream")
+    ap.add_argument("--teacher", default="hip", choices=["torch", "hip"],
+                    help="hip: frozen teacher graph through the engine's HIP kernels (default); torch: teacher as a PyTorch-ROCm "
+                         "module (MIOpen) on a side stream, the split north_star describes")
     a = ap.parse_args()
 
     import kdcc_amd
@@ -117,6 +127,7 @@ def main():
     plan = PLANS[a.plan]
     model, crit, opt, cpu_sd = build(plan, dtype, device)
     model.overlap_teacher = not a.no_overlap
+    model.teacher_backend = a.teacher
     if world > 1:
         eng = model._student_engine()
         eng.reducer = parallel.GradReducer(eng.grad_production_order())
@@ -149,7 +160,7 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        # dominant kernel: the implicit-GEMM conv (student forward + dgrad); live HIP-event timing of every launch
+        # dominant kernel: the implicit-GEMM conv; live HIP-event timing of every launch on its launching stream
         flops = sum(p[1] for p in prof)
         ms = sum(p[2].elapsed_time(p[3]) for p in prof)
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -163,12 +174,13 @@ def main():
                                    f"RAdam), DeepLabV3+(WRN-38) student plan {a.plan} ({len(plan)} cheap-conv blocks, 9x9 d5), "
                                    f"{a.height}x{a.width}, {a.batch} image/GPU, random-init weights",
                        "plan": a.plan, "per_gpu_batch": a.batch, "global_batch": world * a.batch,
-                       "parallelism": f"dp{world}", "teacher_overlap": bool(model.overlap_teacher)},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (student dense conv fwd + dgrad)", "achieved": ach,
+                       "parallelism": f"dp{world}", "teacher_overlap": bool(model.overlap_teacher),
+                       "teacher_backend": a.teacher},
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (dense conv fwd + dgrad, student" + (" + teacher)" if a.teacher == "hip" else ")"), "achieved": ach,
                          "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                          "launches_per_step": len(prof) / max(a.steps, 1), "ms_per_step_in_kernel": ms / max(a.steps, 1),
                          "algorithmic_tflop_per_step": flops / max(a.steps, 1) / 1e12},
-            "losses": {"hint": float(loss), "supervised": float(sup), "kd": float(kd), "teacher": float(tl)},
+            "losses": {"hint": float(loss.detach()), "supervised": float(sup), "kd": float(kd), "teacher": float(tl)},
         }
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cpu_sd, model, plan)

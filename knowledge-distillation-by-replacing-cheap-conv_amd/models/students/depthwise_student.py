@@ -55,6 +55,11 @@ class DepthwiseStudent(nn.Module):
         self._teacher_ready = None
         self._side_stream = None
         self.overlap_teacher = True
+        # "hip":   the frozen teacher graph runs through the engine's kernels (fused BN/ReLU/add/concat); default for
+        #          DeepWV3Plus: 45 % of the step's FLOPs are the teacher's, and it avoids MIOpen's first-run solver search.
+        # "torch": the teacher runs as a PyTorch-ROCm module (MIOpen convs) on a side stream (north_star's split).
+        self.teacher_backend = "hip"
+        self._teacher_engine = None
 
     # ------------------------------------------------------------------ model surgery (host side)
     def register_hint_layers(self, block_names):
@@ -148,6 +153,19 @@ class DepthwiseStudent(nn.Module):
             self._teacher_ready = key
 
     def _teacher_forward(self, x):
+        if self.teacher_backend == "hip" and isinstance(self.teacher, DeepWV3Plus):
+            from ...engine import StudentEngine
+            if self._teacher_engine is None or self._teacher_engine.net is not self.teacher or \
+                    self._teacher_engine.dtype != self.dtype:
+                self._teacher_engine = StudentEngine(self.teacher, self.dtype)
+            eng = self._teacher_engine
+            eng.hint_names = list(self.hint_block_names) if self.save_hidden else []
+            with torch.no_grad():
+                logits, hints = eng.forward(x)
+            eng._tape = None
+            if self.save_hidden:
+                self.teacher_hidden_outputs = [h.permute(0, 3, 1, 2) for h in hints]
+            return logits.permute(0, 3, 1, 2)
         self._prepare_teacher(x.device)
         xt = x.to(dtype=self.dtype, memory_format=torch.channels_last)
         with torch.no_grad():
@@ -164,8 +182,8 @@ class DepthwiseStudent(nn.Module):
             raise RuntimeError("the fused DeepWV3Plus student runs on the GPU only (no CPU fallback)")
         from ...engine import run_student
         engine = self._student_engine()
-        if self.overlap_teacher:
-            # frozen teacher on a side stream: its logits/hints are consumed only by the losses, so it overlaps the
+        if self.overlap_teacher and not (self.teacher_backend == "hip" and isinstance(self.teacher, DeepWV3Plus)):
+            # frozen PyTorch teacher on a side stream: its logits/hints are consumed only by the losses, so it overlaps the
             # student's forward on the main stream
             if self._side_stream is None or self._side_stream.device != x.device:
                 self._side_stream = torch.cuda.Stream(device=x.device)
