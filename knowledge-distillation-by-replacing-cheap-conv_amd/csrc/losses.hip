@@ -75,6 +75,82 @@ __global__ __launch_bounds__(256) void kldiv_kernel(V3 s, V3 t, M3 g, float invT
     block_partial(acc, partial);
 }
 
+// NHWC-dense fast path (the engine's logits layout): a block stages 256 pixels x C channels of both operands in LDS
+// with fully coalesced loads, each thread then owns one pixel (row stride C words: conflict-free for odd C), and
+// the gradient goes back out through the same LDS rows, coalesced.
+template <typename TS, typename TT, typename TG>
+__global__ __launch_bounds__(256) void kldiv_nhwc_kernel(const TS *__restrict__ s, const TT *__restrict__ t, TG *__restrict__ g,
+                                                         int C, long long npix, float invT, float gscale, double *partial)
+{
+    extern __shared__ float sm[];
+    float *ss = sm, *st = sm + 256 * C;
+    double acc = 0.0;
+    for (long long base = (long long)blockIdx.x * 256; base < npix; base += (long long)gridDim.x * 256) {
+        const int np = (int)min((long long)256, npix - base);
+        const int nel = np * C;
+        const TS *sp = s + base * C;
+        const TT *tp = t + base * C;
+        for (int i = threadIdx.x; i < nel; i += 256) { ss[i] = Elem<TS>::ld(sp + i) * invT; st[i] = Elem<TT>::ld(tp + i) * invT; }
+        __syncthreads();
+        if ((int)threadIdx.x < np) {
+            float *a = ss + threadIdx.x * C, *b = st + threadIdx.x * C;
+            float ms = -INFINITY, mt = -INFINITY;
+            for (int c = 0; c < C; ++c) { ms = fmaxf(ms, a[c]); mt = fmaxf(mt, b[c]); }
+            float zs = 0.f, zt = 0.f;
+            for (int c = 0; c < C; ++c) { zs += __expf(a[c] - ms); zt += __expf(b[c] - mt); }
+            const float lzs = __logf(zs) + ms, lzt = __logf(zt) + mt;
+            float kl = 0.f;
+            for (int c = 0; c < C; ++c) {
+                const float lps = a[c] - lzs, lpt = b[c] - lzt;
+                const float pt = __expf(lpt);
+                kl += pt > 0.f ? pt * (lpt - lps) : 0.f;
+                a[c] = gscale * (__expf(lps) - pt);
+            }
+            acc += (double)kl;
+        }
+        __syncthreads();
+        if (g) {
+            TG *gp = g + base * C;
+            for (int i = threadIdx.x; i < nel; i += 256) Elem<TG>::st(gp + i, ss[i]);
+        }
+        __syncthreads();
+    }
+    block_partial(acc, partial);
+}
+
+template <typename TX>
+__global__ __launch_bounds__(256) void ce2d_nhwc_kernel(const TX *__restrict__ x, const int64_t *__restrict__ target, int ignore_index,
+                                                        int C, long long npix, double *partial, double *count)
+{
+    extern __shared__ float sm[];
+    double acc = 0.0, cnt = 0.0;
+    for (long long base = (long long)blockIdx.x * 256; base < npix; base += (long long)gridDim.x * 256) {
+        const int np = (int)min((long long)256, npix - base);
+        const int nel = np * C;
+        const TX *xp = x + base * C;
+        for (int i = threadIdx.x; i < nel; i += 256) sm[i] = Elem<TX>::ld(xp + i);
+        __syncthreads();
+        if ((int)threadIdx.x < np) {
+            const int64_t y = target[base + threadIdx.x];
+            if (!(y == ignore_index || y < 0 || y >= C)) {
+                const float *a = sm + threadIdx.x * C;
+                float m = -INFINITY;
+                for (int c = 0; c < C; ++c) m = fmaxf(m, a[c]);
+                float z = 0.f;
+                for (int c = 0; c < C; ++c) z += __expf(a[c] - m);
+                acc += (double)(-(a[y] - m - __logf(z)));
+                cnt += 1.0;
+            }
+        }
+        __syncthreads();
+    }
+    __shared__ double w1[4], w2[4];
+    acc = wave_sum_d(acc); cnt = wave_sum_d(cnt);
+    if ((threadIdx.x & 63) == 0) { w1[threadIdx.x >> 6] = acc; w2[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) { partial[blockIdx.x] = w1[0] + w1[1] + w1[2] + w1[3]; count[blockIdx.x] = w2[0] + w2[1] + w2[2] + w2[3]; }
+}
+
 // ---- hint MSE -----------------------------------------------------------------------------
 // contiguous fast path: s, t, g share one dense layout -> 8 elements per thread per step
 template <typename T>
@@ -250,8 +326,30 @@ extern "C" int kd_kldiv(const kd_view3 *s, const kd_view3 *t, float temperature,
     const int nb = blocks_for((long long)N * P);
     hipStream_t st = (hipStream_t)stream;
     const float gscale = grad_scale * temperature / ((float)N * (float)P);
-    hipLaunchKernelGGL(kldiv_kernel, dim3(nb), dim3(256), 0, st, v3(s), v3(t), m3(grad), 1.f / temperature, gscale, N, C,
-                       (long long)P, partial);
+    auto nhwc = [&](long long sN, long long sC, long long sP) { return sC == 1 && sP == C && (sN == (long long)C * P || N == 1); };
+    const bool fast = C <= 64 && nhwc(s->sN, s->sC, s->sP) && nhwc(t->sN, t->sC, t->sP) &&
+                      (!grad || nhwc(grad->sN, grad->sC, grad->sP));
+    if (fast) {
+        const long long npix = (long long)N * P;
+        const size_t lds = (size_t)2 * 256 * C * sizeof(float);
+        const float invT = 1.f / temperature;
+        void *gp = grad ? grad->ptr : nullptr;
+        const int gdt = grad ? grad->dtype : s->dtype;
+#define KD_KLD(TS, TT, TG) hipLaunchKernelGGL((kldiv_nhwc_kernel<TS, TT, TG>), dim3(nb), dim3(256), lds, st, (const TS *)s->ptr, \
+                                              (const TT *)t->ptr, (TG *)gp, C, npix, invT, gscale, partial)
+        if (s->dtype == KD_F32 && t->dtype == KD_F32 && gdt == KD_F32) KD_KLD(float, float, float);
+        else if (s->dtype == KD_F32 && t->dtype == KD_BF16 && gdt == KD_F32) KD_KLD(float, bf16_t, float);
+        else if (s->dtype == KD_BF16 && t->dtype == KD_BF16 && gdt == KD_BF16) KD_KLD(bf16_t, bf16_t, bf16_t);
+        else if (s->dtype == KD_BF16 && t->dtype == KD_F32 && gdt == KD_BF16) KD_KLD(bf16_t, float, bf16_t);
+        else if (s->dtype == KD_F32 && t->dtype == KD_F32) KD_KLD(float, float, bf16_t);
+        else if (s->dtype == KD_F32 && t->dtype == KD_BF16) KD_KLD(float, bf16_t, bf16_t);
+        else if (s->dtype == KD_BF16 && t->dtype == KD_BF16) KD_KLD(bf16_t, bf16_t, float);
+        else KD_KLD(bf16_t, float, float);
+#undef KD_KLD
+    } else {
+        hipLaunchKernelGGL(kldiv_kernel, dim3(nb), dim3(256), 0, st, v3(s), v3(t), m3(grad), 1.f / temperature, gscale, N, C,
+                           (long long)P, partial);
+    }
     KD_CHECK_LAUNCH("kd_kldiv");
     // 'mean' over N*C*P elements, then * T^2 * C  ==  T^2 / (N*P) * sum
     const double scale = (double)temperature * temperature / ((double)N * (double)P);
@@ -322,7 +420,17 @@ extern "C" int kd_ce2d(const kd_view3 *x, const int64_t *target, int32_t ignore_
     double *partial = (double *)workspace, *count = partial + MAX_BLOCKS;
     const int nb = blocks_for((long long)N * P);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(ce2d_kernel, dim3(nb), dim3(256), 0, st, v3(x), target, ignore_index, N, C, (long long)P, partial, count);
+    if (C <= 128 && x->sC == 1 && x->sP == C && (x->sN == (long long)C * P || N == 1)) {
+        const size_t lds = (size_t)256 * C * sizeof(float);
+        if (x->dtype == KD_F32)
+            hipLaunchKernelGGL(ce2d_nhwc_kernel<float>, dim3(nb), dim3(256), lds, st, (const float *)x->ptr, target, ignore_index, C,
+                               (long long)N * P, partial, count);
+        else
+            hipLaunchKernelGGL(ce2d_nhwc_kernel<bf16_t>, dim3(nb), dim3(256), lds, st, (const bf16_t *)x->ptr, target, ignore_index,
+                               C, (long long)N * P, partial, count);
+    } else {
+        hipLaunchKernelGGL(ce2d_kernel, dim3(nb), dim3(256), 0, st, v3(x), target, ignore_index, N, C, (long long)P, partial, count);
+    }
     KD_CHECK_LAUNCH("kd_ce2d");
     hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, (const double *)partial, nb, 1.0, (const double *)count, loss);
     KD_CHECK_LAUNCH("kd_ce2d(finish)");
