@@ -3,7 +3,8 @@
 //
 // GEMM view:  Y[m][co] = sum_{tap,ci} X[pixel(m) + tap][ci] * Wp[co][tap][ci]
 //   M = N*Ho*Wo pixels, N = Cout, K = kh*kw*Cin.
-// Block tile 128(M) x 128(N), 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16 tiles.
+// Block tile 256(M) x 256(N) (waves 2x4 of 128x64, two K stages) or 256 x 128 (waves 4x2 of 64x64, three K
+// stages, counted vmcnt + raw s_barrier so the LDS-DMA of stage k+2 spans the barrier of stage k); MFMA 16x16 tiles.
 // One K stage = 128 bytes of K per row (64 bf16 / 32 f32): the A tile is gathered
 // (im2col) and the B tile streamed straight into LDS with global_load_lds (16 B per
 // lane), rows XOR-swizzled on the SOURCE side so that the ds_read_b128 fragment
@@ -14,13 +15,26 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128;
 constexpr int ROWB = IG_ROWB;               // bytes of K per LDS row per stage
-constexpr int STAGE_A = BM * ROWB;          // 16 KiB
-constexpr int STAGE_B = BN * ROWB;          // 16 KiB
-constexpr int STAGE = STAGE_A + STAGE_B;    // 32 KiB
 constexpr int EP_LD = 68;                   // floats per epilogue row (64 + pad)
-static_assert(32 * EP_LD * 4 <= STAGE_A, "a wave's half-tile epilogue patch must fit one stage array");
+
+// Tile configurations (8 waves = 512 threads, one workgroup per CU, two waves per SIMD):
+//   Cfg<4, 4, 2, 3>: 256(M) x 128(N), waves 4x2 of 64x64,  three K stages in flight (144 KiB LDS)  -- Cout <= 128
+//   Cfg<8, 2, 4, 2>: 256(M) x 256(N), waves 2x4 of 128x64, two K stages (128 KiB LDS)              -- Cout  > 128
+// The kernel is bound by L2 -> LDS staging requests (measured: ~86-94 G 128-B requests/s whatever the shape), so the
+// wide tile's 1.5x lower bytes-per-flop is what buys throughput; the narrow one avoids wasting half the MFMAs when the
+// layer has only 128 (or 48, 19) output channels.
+template <int MI_, int WM_, int WN_, int NST_> struct Cfg {
+    static constexpr int MI = MI_, WM = WM_, WN = WN_, NST = NST_;
+    static constexpr int BM = WM * MI * 16, BN = WN * 64;
+    static constexpr int STAGE_A = BM * ROWB, STAGE_B = BN * ROWB, STAGE = STAGE_A + STAGE_B;
+    static constexpr int GA = BM / 64, GB = BN / 64;   // LDS-DMA pieces per wave per stage (A, B): 8 rows per piece
+    static constexpr int LDS_BYTES = NST * STAGE;
+    static_assert(WM * WN == 8, "8 waves");
+    static_assert(8 * 32 * EP_LD * 4 <= LDS_BYTES, "epilogue patches must fit the stage buffers");
+};
+typedef Cfg<4, 4, 2, 3> CfgNarrow;
+typedef Cfg<8, 2, 4, 2> CfgWide;
 
 __device__ __attribute__((aligned(256))) uint32_t kd_zero_page[64];  // zero-initialised
 
@@ -33,10 +47,20 @@ struct ConvParams {
     kd_conv_epilogue ep;
 };
 
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS at (wave-uniform base + lane*16).
+// Issued through inline asm on purpose: hipcc then does not track the DMA, so it inserts no vmcnt waits of its own
+// in front of the fragment reads (at a loop header it falls back to vmcnt(0), which would drain the prefetch); every
+// wait for these pieces is the hand-counted KD_WAIT_VM_BARRIER below.  M0 carries the LDS base and is restored
+// (cdna_hip_programming.md 5.7).
 __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
 {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                     (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
+    const uint32_t lds_addr =
+        __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)lds_dst);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
 }
 
 // load/store 8 channels with tail + alignment handling
@@ -62,40 +86,46 @@ __device__ __forceinline__ void st8_guard(U *p, int valid, bool vec, const float
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p)
+// Wait until at most N of this wave's vector-memory operations (here: LDS-DMA pieces) are outstanding, and all LDS
+// reads have returned; then a bare barrier.  Unlike __syncthreads() this does not drain the DMA of the stages still
+// in flight, which is what lets the prefetch run two K stages ahead.
+#define KD_WAIT_VM_BARRIER(N)                                                   \
+    do {                                                                        \
+        asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory");        \
+        __builtin_amdgcn_s_barrier();                                           \
+    } while (0)
+
+template <typename T, typename CF>
+__global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvParams p)
 {
-    // Four separate LDS objects (not one array): hipcc tags accesses per LDS variable, so the
-    // ds_reads of stage `cur` do not wait (vmcnt) for the LDS-DMA still filling stage `cur^1`.
-    __shared__ __attribute__((aligned(16))) char sA0[STAGE_A];
-    __shared__ __attribute__((aligned(16))) char sB0[STAGE_B];
-    __shared__ __attribute__((aligned(16))) char sA1[STAGE_A];
-    __shared__ __attribute__((aligned(16))) char sB1[STAGE_B];
+    // One LDS array: the DMA is issued through inline asm, so hipcc sees only the fragment reads and inserts no waits.
+    __shared__ __attribute__((aligned(16))) char lds[CF::LDS_BYTES];
     constexpr int ES = sizeof(T);
     constexpr int BK = ROWB / ES;   // K elements per stage
     constexpr int EPC = 16 / ES;    // elements per 16-B chunk
+    constexpr int MI = CF::MI, GA = CF::GA, GB = CF::GB, NST = CF::NST;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wv >> 1, wn = wv & 1;
+    const int wm = wv / CF::WN, wn = wv % CF::WN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * CF::BM, n0 = tn * CF::BN;
 
     const T *__restrict__ xg = (const T *)p.x;
     const T *__restrict__ wg = (const T *)p.w;
     const T *zero = (const T *)kd_zero_page;
 
-    // ---- per-lane staging state: 4 A rows + 4 B rows, fixed over the K loop -------------
+    // ---- per-lane staging state: GA A rows + GB B rows, fixed over the K loop -------------
     const int srow = lane >> 3;
     const int chunk = (lane & 7) ^ srow;  // source-side swizzle: LDS slot (lane&7) of row r holds chunk slot^(r&7)
-    int a_off[4];
-    uint32_t a_mask[4];
-    int b_off[4];
+    int a_off[GA];
+    uint32_t a_mask[GA];
+    int b_off[GB];
     const int ntaps = p.kh * p.kw;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = (wv * 4 + j) * 8 + srow;
+    for (int j = 0; j < GA; ++j) {
+        const int r = (wv * GA + j) * 8 + srow;
         const int m = m0 + r;
         a_off[j] = 0;
         a_mask[j] = 0;
@@ -112,62 +142,64 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p)
             }
             a_mask[j] = mk;
         }
-        const int nn = n0 + r;
+    }
+#pragma unroll
+    for (int j = 0; j < GB; ++j) {
+        const int nn = n0 + (wv * GB + j) * 8 + srow;
         b_off[j] = nn < p.Cout ? nn * p.Ktot + chunk * EPC : -1;
     }
 
-    auto stage = [&](int kt, int tap, int cb, char *sA, char *sB) {
-        const int ky = tap / p.kw, kx = tap - ky * p.kw;
-        const int tap_off = (ky * p.dil * p.W + kx * p.dil) * p.ldx + cb * BK;
-        char *la = sA + wv * 4096;
-        char *lb = sB + wv * 4096;
+    // next stage to issue: (kt, tap, channel block)
+    int s_kt = 0, s_tap = 0, s_cb = 0;
+    auto stage = [&]() {
+        const int ky = s_tap / p.kw, kx = s_tap - ky * p.kw;
+        const int tap_off = (ky * p.dil * p.W + kx * p.dil) * p.ldx + s_cb * BK;
+        char *la = lds + (s_kt % NST) * CF::STAGE + wv * (GA * 1024);
+        char *lb = lds + (s_kt % NST) * CF::STAGE + CF::STAGE_A + wv * (GB * 1024);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const T *src = ((a_mask[j] >> tap) & 1u) ? xg + (a_off[j] + tap_off) : zero;
+        for (int j = 0; j < GA; ++j) {
+            const T *src = ((a_mask[j] >> s_tap) & 1u) ? xg + (a_off[j] + tap_off) : zero;
             glds16(src, la + j * 1024);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const T *src = b_off[j] >= 0 ? wg + ((size_t)b_off[j] + (size_t)kt * BK) : zero;
+        for (int j = 0; j < GB; ++j) {
+            const T *src = b_off[j] >= 0 ? wg + ((size_t)b_off[j] + (size_t)s_kt * BK) : zero;
             glds16(src, lb + j * 1024);
         }
+        ++s_kt;
+        if (++s_cb == p.nkc) { s_cb = 0; ++s_tap; }
         // keep the DMA issue ahead of the MFMA block it is meant to overlap with
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fq = lane >> 4;
-    auto compute = [&](const char *sA, const char *sB) { ig_compute_stage<T>(sA, sB, wm, wn, lane, acc); };
 
-    // ---- K loop: double-buffered, one barrier per stage --------------------------------
-    int tap = 0, cb = 0, kt = 0;
-    stage(0, 0, 0, sA0, sB0);
-    __syncthreads();
-    // buffers are named statically (loop unrolled by two) so the compiler can tell them apart
-    for (; kt + 2 < p.nk; kt += 2) {
-        if (++cb == p.nkc) { cb = 0; ++tap; }
-        stage(kt + 1, tap, cb, sA1, sB1);
-        compute(sA0, sB0);
-        __syncthreads();
-        if (++cb == p.nkc) { cb = 0; ++tap; }
-        stage(kt + 2, tap, cb, sA0, sB0);
-        compute(sA1, sB1);
-        __syncthreads();
+    // ---- K loop: NST stages resident, NST-1 in flight ahead of the one being consumed; one barrier per stage ----
+    // A wave's vmcnt counts its own DMA pieces in issue order: to know stage k+1 has landed while stage k+2 is still
+    // in flight, wait until at most (GA+GB) pieces are outstanding (three-stage config), else drain to zero.
+    const int nk = p.nk;
+    constexpr int D = NST - 1;
+    for (int i = 0; i < D && i < nk; ++i) stage();
+    if (D == 2 && nk > 1) KD_WAIT_VM_BARRIER(6); else KD_WAIT_VM_BARRIER(0);
+    static_assert(D == 1 || (D == 2 && GA + GB == 6), "vmcnt immediates below are written for these two configs");
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool pf = kt + D < nk;
+        if (pf) stage();
+        const char *sA = lds + (kt % NST) * CF::STAGE;
+        ig_compute_stage<T, MI>(sA, sA + CF::STAGE_A, wm, wn, lane, acc);
+        if (kt + 1 < nk) {
+            if (D == 2 && pf) KD_WAIT_VM_BARRIER(6);
+            else KD_WAIT_VM_BARRIER(0);
+        }
     }
-    if (kt + 1 < p.nk) {  // two stages left: kt (in buffer 0) and kt+1
-        if (++cb == p.nkc) { cb = 0; ++tap; }
-        stage(kt + 1, tap, cb, sA1, sB1);
-        compute(sA0, sB0);
-        __syncthreads();
-        compute(sA1, sB1);
-    } else {
-        compute(sA0, sB0);
-    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();  // every wave is done reading the stage buffers
 
     // ---- epilogue ---------------------------------------------------------------------
@@ -186,10 +218,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p)
         ashift[q] = (e.act_shift && ok) ? e.act_shift[c0 + q] : 0.f;
     }
 
-    // each wave owns one stage array as its private 32 x 64 fp32 patch (two half-tiles in turn)
-    float *ep = (float *)(wv == 0 ? sA0 : wv == 1 ? sB0 : wv == 2 ? sA1 : sB1);
+    // each wave owns a private 32 x 64 fp32 patch inside the (now idle) stage buffers, 32 rows of its sub-tile in turn
+    constexpr int PATCH = 32 * EP_LD * 4;
+    float *ep = (float *)(lds + wv * PATCH);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < MI / 2; ++half) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -203,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p)
 #pragma unroll 1
         for (int pass = 0; pass < 4; ++pass) {
             const int row = pass * 8 + (lane >> 3);
-            const int m = m0 + wm * 64 + half * 32 + row;
+            const int m = m0 + wm * (16 * MI) + half * 32 + row;
             if (m >= p.M || valid == 0) continue;
             float v[8];
             {
@@ -308,17 +341,27 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
     p.nkc = d->Cin / bk;
     p.nk = d->kh * d->kw * p.nkc;
     p.Ktot = d->kh * d->kw * d->Cin;
-    p.tiles_n = (d->Cout + BN - 1) / BN;
+    // wide tiles only when they still fill the chip (one workgroup per CU, 256 CUs); e.g. the ASPP 4096->256 1x1 at
+    // 128x256 pixels would give 128 wide tiles, so it runs on the narrow config (256 tiles)
+    const long long wide_tiles = (long long)((p.M + CfgWide::BM - 1) / CfgWide::BM) * ((d->Cout + CfgWide::BN - 1) / CfgWide::BN);
+    const bool wide = d->Cout > 128 && wide_tiles >= 224;
+    const int bm = wide ? CfgWide::BM : CfgNarrow::BM, bn = wide ? CfgWide::BN : CfgNarrow::BN;
+    p.tiles_n = (d->Cout + bn - 1) / bn;
     p.ep = *ep;
     auto ok = [&](const void *ptr, int ld, int esz) { return !ptr || (kd_aligned16(ptr) && (ld * esz) % 16 == 0); };
     p.vec_ok = ok(ep->res_pre, ep->ld_res_pre, es) && ok(ep->mask, ep->ld_mask, es) &&
                ok(ep->res_post, ep->ld_res_post, es) && ok(ep->out_raw, ep->ld_raw, ep->raw_f32 ? 4 : es) &&
                ok(ep->out_act, ep->ld_act, es);
-    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_m = (p.M + bm - 1) / bm;
     const dim3 grid((unsigned)(tiles_m * p.tiles_n));
     hipStream_t s = (hipStream_t)stream;
-    if (d->dtype == KD_BF16) hipLaunchKernelGGL(conv_igemm_kernel<bf16_t>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(conv_igemm_kernel<float>, grid, dim3(256), 0, s, p);
+    if (d->dtype == KD_BF16) {
+        if (wide) hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, CfgWide>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, CfgNarrow>), grid, dim3(512), 0, s, p);
+    } else {
+        if (wide) hipLaunchKernelGGL((conv_igemm_kernel<float, CfgWide>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_kernel<float, CfgNarrow>), grid, dim3(512), 0, s, p);
+    }
     KD_CHECK_LAUNCH("kd_conv2d_fwd");
     return KD_OK;
 }

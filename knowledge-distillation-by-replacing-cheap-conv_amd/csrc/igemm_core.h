@@ -29,24 +29,25 @@ template <> struct Mma<float> {
     }
 };
 
-// One K stage (128 B per row) of a wave's 64x64 sub-tile: acc[i][j] += A(rows wm*64+16i..)·B(rows wn*64+16j..)^T
-template <typename T>
+// One K stage (128 B per row) of a wave's (16*MI) x 64 sub-tile:
+//   acc[i][j] += A(rows wm*16*MI + 16i ..) . B(rows wn*64 + 16j ..)^T
+template <typename T, int MI = 4>
 __device__ __forceinline__ void ig_compute_stage(const char *sA, const char *sB, int wm, int wn, int lane,
-                                                 f32x4_t (&acc)[4][4])
+                                                 f32x4_t (&acc)[MI][4])
 {
     const int frow = lane & 15, fq = lane >> 4;
-    const char *A = sA + (wm * 64 + frow) * IG_ROWB;
+    const char *A = sA + (wm * 16 * MI + frow) * IG_ROWB;
     const char *B = sB + (wn * 64 + frow) * IG_ROWB;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         const int sw = ((fq + 4 * ks) ^ (lane & 7)) << 4;
-        uint4 a[4], b[4];
+        uint4 a[MI], b[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = *(const uint4 *)(A + i * 16 * IG_ROWB + sw);
+        for (int i = 0; i < MI; ++i) a[i] = *(const uint4 *)(A + i * 16 * IG_ROWB + sw);
 #pragma unroll
         for (int j = 0; j < 4; ++j) b[j] = *(const uint4 *)(B + j * 16 * IG_ROWB + sw);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
     }
