@@ -149,11 +149,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvParams p)
         b_off[j] = nn < p.Cout ? nn * p.Ktot + chunk * EPC : -1;
     }
 
-    // next stage to issue: (kt, tap, channel block)
+    // next stage to issue.  K order is channel-block outer, tap inner: the nine taps of one 64-channel block re-read
+    // (shifted) the same few image rows and one thin weight slab back to back, so they stay L2-resident; with taps outer
+    // the XCD's working set (every channel of ~18 image rows + all weights) overflowed its 4 MiB L2 between re-uses.
     int s_kt = 0, s_tap = 0, s_cb = 0;
     auto stage = [&]() {
         const int ky = s_tap / p.kw, kx = s_tap - ky * p.kw;
         const int tap_off = (ky * p.dil * p.W + kx * p.dil) * p.ldx + s_cb * BK;
+        const int w_off = s_tap * p.Cin + s_cb * BK;
         char *la = lds + (s_kt % NST) * CF::STAGE + wv * (GA * 1024);
         char *lb = lds + (s_kt % NST) * CF::STAGE + CF::STAGE_A + wv * (GB * 1024);
 #pragma unroll
@@ -163,11 +166,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvParams p)
         }
 #pragma unroll
         for (int j = 0; j < GB; ++j) {
-            const T *src = b_off[j] >= 0 ? wg + ((size_t)b_off[j] + (size_t)s_kt * BK) : zero;
+            const T *src = b_off[j] >= 0 ? wg + (b_off[j] + w_off) : zero;
             glds16(src, lb + j * 1024);
         }
         ++s_kt;
-        if (++s_cb == p.nkc) { s_cb = 0; ++s_tap; }
+        if (++s_tap == ntaps) { s_tap = 0; ++s_cb; }
         // keep the DMA issue ahead of the MFMA block it is meant to overlap with
         __builtin_amdgcn_sched_barrier(0);
     };

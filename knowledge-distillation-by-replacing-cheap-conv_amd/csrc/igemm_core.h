@@ -50,5 +50,9 @@ __device__ __forceinline__ void ig_compute_stage(const char *sA, const char *sB,
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
+        // issue the k-step's fragment reads back to back, then its MFMAs: one exposed LDS latency per k-step instead
+        // of one per pair of reads (hipcc otherwise interleaves read-wait-4 MFMAs to save registers)
+        __builtin_amdgcn_sched_group_barrier(0x100, MI + 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MI * 4 * (sizeof(T) == 4 ? 4 : 1), 0);
     }
 }
