@@ -6,6 +6,7 @@ from functools import reduce
 import torch
 from torch import nn
 
+from . import cifar_models, metric  # noqa: F401
 from .deeplabv3 import DeepWV3Plus  # noqa: F401
 
 

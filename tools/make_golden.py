@@ -346,6 +346,43 @@ def g_trainer_epoch():
     save("trainer_epoch_g4", **out)
 
 
+def g_classification_epoch():
+    """ClassificationTrainer._train_epoch(1) of the reference (BASELINE config 0 shape: ResNet-20 teacher, identical
+    student fully unfrozen, loss = KLDiv(T=5), Adam) on seeded weights / batches: log dict after 3 iterations."""
+    import tempfile
+    from parse_config import ConfigParser
+    from trainer import ClassificationTrainer
+    from utils import WeightScheduler
+    from utils import optim as ref_optim
+    import models.cifar_models as ref_cifar
+    import models.metric as ref_metric
+    cfgd = trainer_config([], lr=0.01, len_epoch=2, save_dir=tempfile.mkdtemp(prefix="kdgold_"))
+    cfgd.update(name="golden_cls", teacher={"type": "resnet20", "args": {}}, optimizer={"type": "Adam", "args": {"lr": 0.01}},
+                kd_loss={"type": "KLDivergenceLoss", "args": {"temperature": 5}},
+                hint_loss={"type": "MSELoss", "args": {"reduction": "mean", "num_classes": 1}},
+                metrics=["accuracy", "top_k_acc"],
+                lr_scheduler={"type": "MultiStepLR", "args": {"milestones": [15, 25], "gamma": 0.2}})
+    cfgd["trainer"]["name"] = "ClassificationTrainer"
+    config = ConfigParser(cfgd, run_id="c")
+    teacher = ref_cifar.resnet20(); seeded_fill_(teacher, "cifar.teacher."); teacher.eval()
+    model = DepthwiseStudent(teacher, config)
+    crit = [config.init_obj(k, ref_losses) for k in ("supervised_loss", "kd_loss", "hint_loss")]
+    metrics = [getattr(ref_metric, m) for m in config["metrics"]]
+    opt = config.init_obj("optimizer", ref_optim, model.student.parameters())
+    sched = config.init_obj("lr_scheduler", ref_optim.lr_scheduler, opt)
+    batches = [(seeded_input(f"cls.x{i}", (32, 3, 32, 32)),
+                torch.randint(0, 10, (32,), generator=torch.Generator().manual_seed(200 + i))) for i in range(3)]
+    tr = ClassificationTrainer(model, crit, metrics, opt, config, batches, None, sched, WeightScheduler(config["weight_scheduler"]))
+    log = tr._train_epoch(1)
+    out = {"targets": np.stack([t.numpy() for _, t in batches])}
+    for k, v in log.items():
+        out["log:" + k] = np.float64(v)
+    out["param:linear.weight"] = model.student.linear.weight.detach().numpy()
+    out["param:conv1.weight"] = model.student.conv1.weight.detach().numpy()
+    out["buf:bn1.running_mean"] = model.student.bn1.running_mean.numpy()
+    save("classification_epoch", **out)
+
+
 def g_keys():
     """State-dict key / shape inventory of the reference's DeepWV3Plus(19) (the checkpoint contract)."""
     import json
@@ -358,7 +395,7 @@ def g_keys():
     print("wrote", path, len(inv), "entries", sum(int(np.prod(v)) for k, v in inv.items() if "num_batches" not in k and "running" not in k), "params")
 
 
-ALL = dict(keys=g_keys, trainer_epoch=g_trainer_epoch, losses=g_losses, dwsep=g_dwsep, resblock=g_resblock, aspp=g_aspp, ops=g_ops, radam=g_radam,
+ALL = dict(keys=g_keys, trainer_epoch=g_trainer_epoch, classification_epoch=g_classification_epoch, losses=g_losses, dwsep=g_dwsep, resblock=g_resblock, aspp=g_aspp, ops=g_ops, radam=g_radam,
            student_step=g_student_step)
 
 if __name__ == "__main__":
