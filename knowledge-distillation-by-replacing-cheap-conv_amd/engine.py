@@ -73,6 +73,7 @@ class StudentEngine:
         self._pack = {}   # (id(param), version, tag) -> packed tensor
         self._bn = {}     # id(bn) -> (scale, shift)
         self._tape = None
+        self.last_hint_names = []
         self.reducer = None   # optional parallel.GradReducer: gradients are written into its buckets and announced
 
     def _grad_like(self, p):
@@ -229,6 +230,7 @@ class StudentEngine:
         if missing:
             raise EngineError(f"hint layers not found in the student graph: {sorted(missing)}")
         self._tape = tape
+        self.last_hint_names = list(seen)   # forward-execution order (what hooks would have produced)
         return logits, hints
 
     def _block_fwd(self, name, blk, x_raw, a1, rg_in, next_bn, need_raw, want, note_hint, bi):

@@ -40,6 +40,7 @@ class DepthwiseStudent(nn.Module):
         self._teacher_hook_handlers = list()
         self.aux_block_names = list()
         self.hint_block_names = list()
+        self.student_hint_names = list()   # names of student_hidden_outputs, forward-execution order (fused path)
         self.save_hidden = True
 
         # compute dtype of the fused path: bf16 (measured path) unless the config / caller asks for fp32 parity mode
@@ -200,6 +201,7 @@ class DepthwiseStudent(nn.Module):
             student_pred, hints = run_student(engine, x)
         if self.save_hidden:
             self.student_hidden_outputs = hints
+            self.student_hint_names = list(engine.last_hint_names)
         return student_pred, teacher_pred
 
     def inference(self, x):

@@ -156,8 +156,34 @@ class LayerwiseTrainer(BaseTrainer):
             p.grad.copy_(self._reducer.grad_buffer(p))
 
     # ------------------------------------------------------------------ the hot loop
+    def _filter_weight(self, index, channels, device):
+        """Per-filter weights for WeightedHintMSELoss.  The reference never supplies them (its trainers call the criterion
+        with two arguments), so the source is build-defined: config['trainer']['hint_filter_weight'] =
+        'uniform' (default) | 'rand:<seed>' (rand(C) with generator seed+index, BASELINE config 4) | path to a torch-saved
+        {hint name: (C,) tensor} dict, e.g. averaged Taylor importances."""
+        key = (index, channels)
+        cache = self.__dict__.setdefault('_fw_cache', {})
+        if key not in cache:
+            spec = str(self.config['trainer'].get('hint_filter_weight', 'uniform'))
+            if spec == 'uniform':
+                w = torch.ones(channels)
+            elif spec.startswith('rand:'):
+                w = torch.rand(channels, generator=torch.Generator().manual_seed(int(spec[5:]) + index))
+            else:
+                table = self.__dict__.setdefault('_fw_table', None) or torch.load(spec, map_location='cpu')
+                self._fw_table = table
+                names = getattr(self.model, 'student_hint_names', None) or self.model.hint_block_names
+                w = table[names[index]].float()
+            cache[key] = w.to(device)
+        return cache[key]
+
     def _hint_loss(self):
-        pairs = zip(self.model.student_hidden_outputs, self.model.teacher_hidden_outputs)
+        from ..losses import WeightedHintMSELoss
+        pairs = list(zip(self.model.student_hidden_outputs, self.model.teacher_hidden_outputs))
+        if isinstance(self.criterions[2], WeightedHintMSELoss):
+            return reduce(lambda acc, ist: acc + self.criterions[2](ist[1][0], ist[1][1],
+                                                                    self._filter_weight(ist[0], ist[1][0].shape[1], ist[1][0].device)),
+                          enumerate(pairs), 0)
         return reduce(lambda acc, st: acc + self.criterions[2](st[0], st[1]), pairs, 0)
 
     def _train_epoch(self, epoch):

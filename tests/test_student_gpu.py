@@ -121,3 +121,35 @@ def test_bf16_step_tracks_fp32(golden):
             assert p.grad is not None and torch.isfinite(p.grad).all(), n
             rs = g[f"grad:{n}.sumsq"][0]
             assert abs(float((p.grad.double() ** 2).sum()) - rs) < 0.15 * rs, n
+
+
+def test_weighted_hint_step_vs_network_oracle():
+    """BASELINE config 4 shape: WeightedHintMSELoss feature-hint KD (filter_weight = rand(C) per hint) on a plan / size
+    other than the golden's, checked against the network-level CPU oracle (oracle/net_ref.py) in fp32."""
+    from kdcc_amd import losses
+    from oracle import net_ref
+    from _netutil import seeded_cheap_weights, seeded_teacher_sd
+    plan = ["mod4.block3.convs.conv2", "mod5.block2.convs.conv2", "aspp.features.3.0"]
+    model = build_model(plan, torch.float32)
+    x = seeded_input("whint.x", (1, 3, 48, 96))
+    ws = [torch.rand(c, generator=torch.Generator().manual_seed(7 + i)) for i, c in enumerate((512, 1024, 256))]
+    out_st, out_tc = model(x.cuda())
+    crit = losses.WeightedHintMSELoss()
+    hint = 0
+    for i, (s, t) in enumerate(zip(model.student_hidden_outputs, model.teacher_hidden_outputs)):
+        hint = hint + crit(s, t, ws[i].cuda())
+    hint.backward()
+    torch.cuda.synchronize()
+    assert model.student_hint_names == plan
+    tsd = seeded_teacher_sd()
+    ssd = net_ref.make_student_sd(tsd, plan, seeded_cheap_weights(tsd, plan))
+    torch.set_num_threads(8)
+    r = net_ref.kd_step(tsd, ssd, x, None, plan, hint_weights=ws)
+    np.testing.assert_allclose(hint.item(), r["hint_loss"].item(), rtol=1e-3)
+    ref_l, got_l = r["student_logits"].numpy(), out_st.detach().float().cpu().numpy()
+    assert np.abs(ref_l - got_l).max() / np.abs(ref_l).max() < 1e-3
+    for n, p in model.student.named_parameters():
+        if p.requires_grad:
+            ref = r["grads"][n].numpy().astype(np.float64)
+            got = p.grad.cpu().numpy().astype(np.float64)
+            assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-3, n
