@@ -25,6 +25,7 @@ struct DwParams {
     int N, H, W, C, pad, dil, ldx, ldy;
     int LH, LW;          // lattice extent upper bounds: ceil(H/dil), ceil(W/dil)
     int tiles_h, tiles_w;
+    int gx, gz;          // logical grid extents: tile groups, N*dil*dil (channel blocks are the slowest index)
     kd_dw_epilogue ep;
 };
 
@@ -53,7 +54,13 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwParams p)
     __shared__ __attribute__((aligned(16))) float wl[K * K * CB];
     const int tid = threadIdx.x;
     const int cq = tid & (CQ - 1), tt = tid >> 4;
-    const int c0 = blockIdx.y * CB;
+    // 1-D grid, XCD-aware: each XCD gets a contiguous range of (tile group fastest, then residue class, then channel
+    // block), so blocks sharing halo rows / the same 64-channel slab run on one L2
+    int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = lin % p.gx; lin /= p.gx;
+    const int bz = lin % p.gz;
+    const int by = lin / p.gz;
+    const int c0 = by * CB;
     for (int i = tid; i < K * K * CB; i += 256) {
         const int t = i / CB, c = c0 + (i - t * CB);
         wl[i] = c < p.C ? p.w[(size_t)t * p.C + c] : 0.f;
@@ -61,9 +68,9 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwParams p)
     __syncthreads();
 
     const int dd = p.dil * p.dil;
-    const int n = blockIdx.z / dd, rc = blockIdx.z - n * dd;
+    const int n = bz / dd, rc = bz - n * dd;
     const int rh = rc / p.dil, rw = rc - rh * p.dil;
-    const int tile = blockIdx.x * 16 + tt;
+    const int tile = bx * 16 + tt;
     const int c = c0 + cq * 4;
     if (tile >= p.tiles_h * p.tiles_w || c >= p.C) return;
     const int th = tile / p.tiles_w, tw = tile - th * p.tiles_w;
@@ -172,7 +179,7 @@ struct DwWgradParams {
     const void *dy;
     float *part;  // [gridDim.x][K*K][C]
     int N, H, W, C, pad, dil, ldx, ld_dy;
-    int LH, LW, nstrips;
+    int LH, LW, nstrips, nslabs;
 };
 
 template <typename T, int K>
@@ -181,9 +188,14 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwWgradParams p
     __shared__ float red[16][K][CB + 4];
     const int tid = threadIdx.x;
     const int cq = tid & (CQ - 1), tt = tid >> 4;
-    const int c = blockIdx.y * CB + cq * 4;
-    const int i = blockIdx.z;  // tap row
-    const int strip = blockIdx.x * 16 + tt;
+    // 1-D grid, XCD-aware, tap row fastest: the K blocks that read the same dy rows (and x rows one lattice row apart)
+    // are neighbours on one XCD instead of K far-apart sweeps over both tensors (measured 9x HBM over-fetch before)
+    int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int i = lin % K; lin /= K;       // tap row
+    const int bx = lin % p.nslabs;
+    const int by = lin / p.nslabs;
+    const int c = by * CB + cq * 4;
+    const int strip = bx * 16 + tt;
 
     float acc[K][4];
 #pragma unroll
@@ -245,8 +257,8 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwWgradParams p
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) s += red[k][j][cc];
-        const int cg = blockIdx.y * CB + cc;
-        if (cg < p.C) p.part[((size_t)blockIdx.x * K * K + (i * K + j)) * p.C + cg] = s;
+        const int cg = by * CB + cc;
+        if (cg < p.C) p.part[((size_t)bx * K * K + (i * K + j)) * p.C + cg] = s;
     }
 }
 
@@ -328,8 +340,9 @@ extern "C" int kd_dwconv_fwd(const kd_dw_desc *d, const void *x, const float *w_
     if (const char *e = getenv("KDCC_DW_TILE")) sscanf(e, "%dx%d", &ts, &tr);   // tuning hook (2x8 | 2x4 | 4x4)
     p.tiles_h = (p.LH + ts - 1) / ts;
     p.tiles_w = (p.LW + tr - 1) / tr;
-    const dim3 grid((unsigned)((p.tiles_h * p.tiles_w + 15) / 16), (unsigned)((d->C + CB - 1) / CB),
-                    (unsigned)(d->N * d->dil * d->dil));
+    p.gx = (p.tiles_h * p.tiles_w + 15) / 16;
+    p.gz = d->N * d->dil * d->dil;
+    const dim3 grid((unsigned)(p.gx * p.gz * ((d->C + CB - 1) / CB)));
     hipStream_t s = (hipStream_t)stream;
 #define KD_DW_LAUNCH(TT, KK, A, B) hipLaunchKernelGGL((dwconv_fwd_kernel<TT, KK, A, B>), grid, dim3(256), 0, s, p)
 #define KD_DW_TILES(TT, KK)                                   \
@@ -380,7 +393,8 @@ extern "C" int kd_dwconv_wgrad(const kd_dw_desc *d, const void *x, const void *d
     p.LW = (d->W + d->dil - 1) / d->dil;
     p.nstrips = d->N * d->dil * d->dil * p.LH;
     const int slabs = wgrad_slabs(d);
-    const dim3 grid((unsigned)slabs, (unsigned)((d->C + CB - 1) / CB), (unsigned)d->k);
+    p.nslabs = slabs;
+    const dim3 grid((unsigned)(slabs * ((d->C + CB - 1) / CB) * d->k));
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == KD_BF16) {
         if (d->k == 9) hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16_t, 9>), grid, dim3(256), 0, s, p);
