@@ -11,30 +11,37 @@
 // reads are bank-conflict free.  Out-of-image taps and tile tails read a zero page.
 // Epilogue: accumulators -> per-wave LDS patch -> 8-channel (16/32 B) vector rows:
 // residual add, BN(eval)+ReLU of the next layer, ReLU-mask backward, dual outputs.
+#include <stdlib.h>
+#include <string.h>
+
 #include "igemm_core.h"
 
 namespace {
 
-constexpr int ROWB = IG_ROWB;               // bytes of K per LDS row per stage
 constexpr int EP_LD = 68;                   // floats per epilogue row (64 + pad)
 
 // Tile configurations (8 waves = 512 threads, one workgroup per CU, two waves per SIMD):
-//   Cfg<4, 4, 2, 3>: 256(M) x 128(N), waves 4x2 of 64x64,  three K stages in flight (144 KiB LDS)  -- Cout <= 128
-//   Cfg<8, 2, 4, 2>: 256(M) x 256(N), waves 2x4 of 128x64, two K stages (128 KiB LDS)              -- Cout  > 128
-// The kernel is bound by L2 -> LDS staging requests (measured: ~86-94 G 128-B requests/s whatever the shape), so the
-// wide tile's 1.5x lower bytes-per-flop is what buys throughput; the narrow one avoids wasting half the MFMAs when the
-// layer has only 128 (or 48, 19) output channels.
-template <int MI_, int WM_, int WN_, int NST_> struct Cfg {
-    static constexpr int MI = MI_, WM = WM_, WN = WN_, NST = NST_;
+//   CfgWide   256(M) x 256(N), waves 2x4 of 128x64, K stage = 128 B per row, two stages (128 KiB LDS)  -- Cout > 128
+//   CfgNarrow 256(M) x 128(N), waves 4x2 of 64x64,  K stage = 128 B per row, three stages (144 KiB)    -- Cout <= 128
+//   CfgDeep   256 x 256 with 64-B K stages, four resident (three in flight): measured SLOWER than CfgWide (878 vs 944
+//             TFLOP/s over the student's shapes) -- prefetch depth is not the limiter; kept for A/B runs only.
+// Measured anatomy of CfgWide on the 512/1024-channel 3x3 layers (tools/bench_conv.py ablations): MFMA + LDS fragment
+// reads alone 1.5-1.7 PFLOP/s; + the LDS-DMA instruction stream hitting one cached page 1.4; + real L2 traffic 1.1.
+// So the staging traffic (both operands) costs ~22 %, its issue ~9 %; wide tiles cut that traffic 1.5x vs 128-wide.
+template <int MI_, int WM_, int WN_, int NST_, int RB_> struct Cfg {
+    static constexpr int MI = MI_, WM = WM_, WN = WN_, NST = NST_, RB = RB_;
     static constexpr int BM = WM * MI * 16, BN = WN * 64;
-    static constexpr int STAGE_A = BM * ROWB, STAGE_B = BN * ROWB, STAGE = STAGE_A + STAGE_B;
-    static constexpr int GA = BM / 64, GB = BN / 64;   // LDS-DMA pieces per wave per stage (A, B): 8 rows per piece
+    static constexpr int STAGE_A = BM * RB, STAGE_B = BN * RB, STAGE = STAGE_A + STAGE_B;
+    static constexpr int PR = 1024 / RB;                        // rows per 1-KiB LDS-DMA piece
+    static constexpr int GA = BM / PR / 8, GB = BN / PR / 8;    // pieces per wave per stage (A, B)
     static constexpr int LDS_BYTES = NST * STAGE;
     static_assert(WM * WN == 8, "8 waves");
     static_assert(8 * 32 * EP_LD * 4 <= LDS_BYTES, "epilogue patches must fit the stage buffers");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
-typedef Cfg<4, 4, 2, 3> CfgNarrow;
-typedef Cfg<8, 2, 4, 2> CfgWide;
+typedef Cfg<4, 4, 2, 3, 128> CfgNarrow;
+typedef Cfg<8, 2, 4, 2, 128> CfgWide;
+typedef Cfg<8, 2, 4, 4, 64> CfgDeep;     // A/B runs only: KDCC_CONV_CFG=deep
 
 __device__ __attribute__((aligned(256))) uint32_t kd_zero_page[64];  // zero-initialised
 
@@ -50,7 +57,7 @@ struct ConvParams {
 // One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS at (wave-uniform base + lane*16).
 // Issued through inline asm on purpose: hipcc then does not track the DMA, so it inserts no vmcnt waits of its own
 // in front of the fragment reads (at a loop header it falls back to vmcnt(0), which would drain the prefetch); every
-// wait for these pieces is the hand-counted KD_WAIT_VM_BARRIER below.  M0 carries the LDS base and is restored
+// wait for these pieces is the hand-counted wait_stage_barrier below.  M0 carries the LDS base and is restored
 // (cdna_hip_programming.md 5.7).
 __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
 {
@@ -86,14 +93,21 @@ __device__ __forceinline__ void st8_guard(U *p, int valid, bool vec, const float
     }
 }
 
-// Wait until at most N of this wave's vector-memory operations (here: LDS-DMA pieces) are outstanding, and all LDS
+// Wait until at most N of this wave's vector-memory operations (here: LDS-DMA pieces) are outstanding and all LDS
 // reads have returned; then a bare barrier.  Unlike __syncthreads() this does not drain the DMA of the stages still
-// in flight, which is what lets the prefetch run two K stages ahead.
-#define KD_WAIT_VM_BARRIER(N)                                                   \
-    do {                                                                        \
-        asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory");        \
-        __builtin_amdgcn_s_barrier();                                           \
-    } while (0)
+// in flight, which is what lets the prefetch run NST-1 K stages ahead.
+template <int N> __device__ __forceinline__ void wait_vm_barrier()
+{
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_s_barrier();
+}
+// r = number of stages issued after the one that must have landed (0 .. NST-2); G = pieces per wave per stage
+template <int G> __device__ __forceinline__ void wait_stage_barrier(int r)
+{
+    if (r <= 0) wait_vm_barrier<0>();
+    else if (r == 1) wait_vm_barrier<G>();
+    else wait_vm_barrier<2 * G>();
+}
 
 template <typename T, typename CF>
 __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvParams p)
@@ -101,9 +115,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvParams p)
     // One LDS array: the DMA is issued through inline asm, so hipcc sees only the fragment reads and inserts no waits.
     __shared__ __attribute__((aligned(16))) char lds[CF::LDS_BYTES];
     constexpr int ES = sizeof(T);
-    constexpr int BK = ROWB / ES;   // K elements per stage
+    constexpr int RB = CF::RB;
+    constexpr int BK = RB / ES;     // K elements per stage
     constexpr int EPC = 16 / ES;    // elements per 16-B chunk
-    constexpr int MI = CF::MI, GA = CF::GA, GB = CF::GB, NST = CF::NST;
+    constexpr int MI = CF::MI, GA = CF::GA, GB = CF::GB, NST = CF::NST, PR = CF::PR;
+    constexpr int CPR = RB / 16;    // 16-B chunks per row
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -117,15 +133,17 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvParams p)
     const T *zero = (const T *)kd_zero_page;
 
     // ---- per-lane staging state: GA A rows + GB B rows, fixed over the K loop -------------
-    const int srow = lane >> 3;
-    const int chunk = (lane & 7) ^ srow;  // source-side swizzle: LDS slot (lane&7) of row r holds chunk slot^(r&7)
+    // a piece (64 lanes x 16 B, LDS-linear) covers PR rows; lane -> (row in piece, slot); the swizzle is applied on the
+    // SOURCE side: LDS slot s of row r holds chunk s ^ (r & 7) (128-B rows) / s ^ ((r >> 1) & 3) (64-B rows)
+    const int srow = lane / CPR;
+    const int chunk = RB == 128 ? ((lane & 7) ^ srow) : ((lane & 3) ^ ((srow >> 1) & 3));
     int a_off[GA];
     uint32_t a_mask[GA];
     int b_off[GB];
     const int ntaps = p.kh * p.kw;
 #pragma unroll
     for (int j = 0; j < GA; ++j) {
-        const int r = (wv * GA + j) * 8 + srow;
+        const int r = (wv * GA + j) * PR + srow;
         const int m = m0 + r;
         a_off[j] = 0;
         a_mask[j] = 0;
@@ -145,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvParams p)
     }
 #pragma unroll
     for (int j = 0; j < GB; ++j) {
-        const int nn = n0 + (wv * GB + j) * 8 + srow;
+        const int nn = n0 + (wv * GB + j) * PR + srow;
         b_off[j] = nn < p.Cout ? nn * p.Ktot + chunk * EPC : -1;
     }
 
@@ -187,20 +205,17 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvParams p)
     // A wave's vmcnt counts its own DMA pieces in issue order: to know stage k+1 has landed while stage k+2 is still
     // in flight, wait until at most (GA+GB) pieces are outstanding (three-stage config), else drain to zero.
     const int nk = p.nk;
-    constexpr int D = NST - 1;
-    for (int i = 0; i < D && i < nk; ++i) stage();
-    if (D == 2 && nk > 1) KD_WAIT_VM_BARRIER(6); else KD_WAIT_VM_BARRIER(0);
-    static_assert(D == 1 || (D == 2 && GA + GB == 6), "vmcnt immediates below are written for these two configs");
+    constexpr int D = NST - 1, G = GA + GB;
+    static_assert(D <= 3, "wait_stage_barrier handles up to two stages in flight behind the awaited one");
+    int issued = 0;
+    for (; issued < D && issued < nk; ++issued) stage();
+    wait_stage_barrier<G>(issued - 1);   // stage 0 has landed (for every wave, after the barrier)
 #pragma unroll 1
     for (int kt = 0; kt < nk; ++kt) {
-        const bool pf = kt + D < nk;
-        if (pf) stage();
+        if (issued < nk) { stage(); ++issued; }
         const char *sA = lds + (kt % NST) * CF::STAGE;
-        ig_compute_stage<T, MI>(sA, sA + CF::STAGE_A, wm, wn, lane, acc);
-        if (kt + 1 < nk) {
-            if (D == 2 && pf) KD_WAIT_VM_BARRIER(6);
-            else KD_WAIT_VM_BARRIER(0);
-        }
+        ig_compute_stage<T, MI, RB>(sA, sA + CF::STAGE_A, wm, wn, lane, acc);
+        if (kt + 1 < nk) wait_stage_barrier<G>(issued - (kt + 2));   // stage kt+1 landed; later ones may still fly
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();  // every wave is done reading the stage buffers
@@ -316,7 +331,7 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
     KD_REQUIRE(d && x && w_packed && ep, KD_ERR_INVALID, "kd_conv2d_fwd: null argument");
     KD_REQUIRE(d->dtype == KD_F32 || d->dtype == KD_BF16, KD_ERR_INVALID, "kd_conv2d_fwd: bad dtype %d", d->dtype);
     const int es = kd_elem_size(d->dtype);
-    const int bk = ROWB / es;
+    const int bk = 128 / es;   // channel granule (both K-stage widths divide it)
     KD_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 && d->Wo > 0,
                KD_ERR_INVALID, "kd_conv2d_fwd: non-positive dimension");
     KD_REQUIRE((d->kh == 1 && d->kw == 1) || (d->kh == 3 && d->kw == 3), KD_ERR_UNSUPPORTED,
@@ -341,29 +356,39 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
     p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
     p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.ldx = d->ldx;
     p.HoWo = d->Ho * d->Wo;
-    p.nkc = d->Cin / bk;
-    p.nk = d->kh * d->kw * p.nkc;
     p.Ktot = d->kh * d->kw * d->Cin;
-    // wide tiles only when they still fill the chip (one workgroup per CU, 256 CUs); e.g. the ASPP 4096->256 1x1 at
-    // 128x256 pixels would give 128 wide tiles, so it runs on the narrow config (256 tiles)
-    const long long wide_tiles = (long long)((p.M + CfgWide::BM - 1) / CfgWide::BM) * ((d->Cout + CfgWide::BN - 1) / CfgWide::BN);
-    const bool wide = d->Cout > 128 && wide_tiles >= 224;
-    const int bm = wide ? CfgWide::BM : CfgNarrow::BM, bn = wide ? CfgWide::BN : CfgNarrow::BN;
-    p.tiles_n = (d->Cout + bn - 1) / bn;
     p.ep = *ep;
     auto ok = [&](const void *ptr, int ld, int esz) { return !ptr || (kd_aligned16(ptr) && (ld * esz) % 16 == 0); };
     p.vec_ok = ok(ep->res_pre, ep->ld_res_pre, es) && ok(ep->mask, ep->ld_mask, es) &&
                ok(ep->res_post, ep->ld_res_post, es) && ok(ep->out_raw, ep->ld_raw, ep->raw_f32 ? 4 : es) &&
                ok(ep->out_act, ep->ld_act, es);
-    const int tiles_m = (p.M + bm - 1) / bm;
-    const dim3 grid((unsigned)(tiles_m * p.tiles_n));
+    // wide tiles only when they still fill the chip (one workgroup per CU, 256 CUs); e.g. the ASPP 4096->256 1x1 at
+    // 128x256 pixels would give 128 wide tiles, so it runs on the narrow config (256 tiles)
+    const long long wide_tiles = (long long)((p.M + CfgWide::BM - 1) / CfgWide::BM) * ((d->Cout + CfgWide::BN - 1) / CfgWide::BN);
+    int cfg = (d->Cout > 128 && wide_tiles >= 224) ? 1 : 0;   // 0 narrow, 1 wide, 2 deep
+    if (const char *e = getenv("KDCC_CONV_CFG")) {              // tuning hook
+        if (!strcmp(e, "narrow")) cfg = 0;
+        else if (!strcmp(e, "deep") && cfg == 1) cfg = 2;
+    }
     hipStream_t s = (hipStream_t)stream;
+    auto launch = [&](auto cf, auto tag) {
+        using CF = decltype(cf);
+        using T = decltype(tag);
+        const int bkk = CF::RB / (int)sizeof(T);
+        p.nkc = d->Cin / bkk;
+        p.nk = d->kh * d->kw * p.nkc;
+        p.tiles_n = (d->Cout + CF::BN - 1) / CF::BN;
+        const int tiles_m = (p.M + CF::BM - 1) / CF::BM;
+        hipLaunchKernelGGL((conv_igemm_kernel<T, CF>), dim3((unsigned)(tiles_m * p.tiles_n)), dim3(512), 0, s, p);
+    };
     if (d->dtype == KD_BF16) {
-        if (wide) hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, CfgWide>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, CfgNarrow>), grid, dim3(512), 0, s, p);
+        if (cfg == 1) launch(CfgWide{}, bf16_t{});
+        else if (cfg == 2) launch(CfgDeep{}, bf16_t{});
+        else launch(CfgNarrow{}, bf16_t{});
     } else {
-        if (wide) hipLaunchKernelGGL((conv_igemm_kernel<float, CfgWide>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((conv_igemm_kernel<float, CfgNarrow>), grid, dim3(512), 0, s, p);
+        if (cfg == 1) launch(CfgWide{}, float{});
+        else if (cfg == 2) launch(CfgDeep{}, float{});
+        else launch(CfgNarrow{}, float{});
     }
     KD_CHECK_LAUNCH("kd_conv2d_fwd");
     return KD_OK;

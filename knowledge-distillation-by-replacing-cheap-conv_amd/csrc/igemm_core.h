@@ -29,23 +29,24 @@ template <> struct Mma<float> {
     }
 };
 
-// One K stage (128 B per row) of a wave's (16*MI) x 64 sub-tile:
-//   acc[i][j] += A(rows wm*16*MI + 16i ..) . B(rows wn*64 + 16j ..)^T
-template <typename T, int MI = 4>
+// One K stage of a wave's (16*MI) x 64 sub-tile:  acc[i][j] += A(rows wm*16*MI + 16i ..) . B(rows wn*64 + 16j ..)^T
+// RB = bytes of K per LDS row per stage: 128 (two MFMA k-steps; 16-B chunk c of row r at slot c ^ (r & 7)) or
+//      64 (one k-step; chunk c of row r at slot c ^ ((r >> 1) & 3)).  Both are conflict-free for ds_read_b128.
+template <typename T, int MI = 4, int RB = 128>
 __device__ __forceinline__ void ig_compute_stage(const char *sA, const char *sB, int wm, int wn, int lane,
                                                  f32x4_t (&acc)[MI][4])
 {
     const int frow = lane & 15, fq = lane >> 4;
-    const char *A = sA + (wm * 16 * MI + frow) * IG_ROWB;
-    const char *B = sB + (wn * 64 + frow) * IG_ROWB;
+    const char *A = sA + (wm * 16 * MI + frow) * RB;
+    const char *B = sB + (wn * 64 + frow) * RB;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const int sw = ((fq + 4 * ks) ^ (lane & 7)) << 4;
+    for (int ks = 0; ks < RB / 64; ++ks) {
+        const int sw = RB == 128 ? (((fq + 4 * ks) ^ (lane & 7)) << 4) : ((fq ^ ((frow >> 1) & 3)) << 4);
         uint4 a[MI], b[4];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) a[i] = *(const uint4 *)(A + i * 16 * IG_ROWB + sw);
+        for (int i = 0; i < MI; ++i) a[i] = *(const uint4 *)(A + i * 16 * RB + sw);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = *(const uint4 *)(B + j * 16 * IG_ROWB + sw);
+        for (int j = 0; j < 4; ++j) b[j] = *(const uint4 *)(B + j * 16 * RB + sw);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
