@@ -54,22 +54,6 @@ struct ConvParams {
     kd_conv_epilogue ep;
 };
 
-// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS at (wave-uniform base + lane*16).
-// Issued through inline asm on purpose: hipcc then does not track the DMA, so it inserts no vmcnt waits of its own
-// in front of the fragment reads (at a loop header it falls back to vmcnt(0), which would drain the prefetch); every
-// wait for these pieces is the hand-counted wait_stage_barrier below.  M0 carries the LDS base and is restored
-// (cdna_hip_programming.md 5.7).
-__device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
-{
-    const uint32_t lds_addr =
-        __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)lds_dst);
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_addr)
-                 : "memory");
-}
-
 // load/store 8 channels with tail + alignment handling
 template <typename U>
 __device__ __forceinline__ void ld8_guard(const U *p, int valid, bool vec, float (&v)[8])
@@ -91,22 +75,6 @@ __device__ __forceinline__ void st8_guard(U *p, int valid, bool vec, const float
         for (int e = 0; e < 8; ++e)
             if (e < valid) Elem<U>::st(p + e, v[e]);
     }
-}
-
-// Wait until at most N of this wave's vector-memory operations (here: LDS-DMA pieces) are outstanding and all LDS
-// reads have returned; then a bare barrier.  Unlike __syncthreads() this does not drain the DMA of the stages still
-// in flight, which is what lets the prefetch run NST-1 K stages ahead.
-template <int N> __device__ __forceinline__ void wait_vm_barrier()
-{
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
-    __builtin_amdgcn_s_barrier();
-}
-// r = number of stages issued after the one that must have landed (0 .. NST-2); G = pieces per wave per stage
-template <int G> __device__ __forceinline__ void wait_stage_barrier(int r)
-{
-    if (r <= 0) wait_vm_barrier<0>();
-    else if (r == 1) wait_vm_barrier<G>();
-    else wait_vm_barrier<2 * G>();
 }
 
 template <typename T, typename CF>

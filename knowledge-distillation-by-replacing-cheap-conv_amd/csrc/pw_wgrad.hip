@@ -11,6 +11,7 @@
 namespace {
 
 constexpr int TM = 128, TN = 128;
+__device__ __attribute__((aligned(256))) uint32_t kd_zero_page_w[64];  // zero-initialised: source of out-of-range DMA lanes
 constexpr int STAGE_BYTES = (TM + TN) * IG_ROWB;  // 32 KiB
 
 struct WgradParams {
@@ -131,6 +132,104 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const WgradParams p)
             }
 }
 
+// ---- bf16 fast path: LDS-DMA staging in the natural [pixel][channel] layout + hardware-transposed fragment reads ----
+// Stage = 64 pixels x 128 channels per operand (16 KiB each), double-buffered.  The MFMA operands need 8 consecutive
+// k (= pixels) per lane for one channel: ds_read_b64_tr_b16 delivers a 4-pixel x 16-channel block column-major, so two
+// of them per 16x32 fragment replace the per-element transposing LDS writes of the generic kernel.  LDS rows are
+// 256 B; the 32-B channel block b of row m is stored at block b ^ f(m), f(m) = (m & 3) | ((m >> 3) & 1) << 2, which
+// makes the eight rows a 32-lane half touches (m, m+1, m+2, m+3, m+8 ...) hit distinct bank groups.
+typedef short v4i16_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int tr_f(int m) { return (m & 3) | (((m >> 3) & 1) << 2); }
+
+__global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(const WgradParams p)
+{
+    __shared__ __attribute__((aligned(16))) char lds[2 * 32768];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const int tile = blockIdx.x, split = blockIdx.y;
+    const int t_ci = tile % p.tiles_ci, t_co = tile / p.tiles_ci;
+    const int co0 = t_co * TM, ci0 = t_ci * TN;
+    const int m_begin = split * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+    const int nst = (m_end - m_begin + 63) / 64;
+    const bf16_t *dy = (const bf16_t *)p.dy;
+    const bf16_t *a = (const bf16_t *)p.a;
+    const bf16_t *zero = (const bf16_t *)kd_zero_page_w;
+
+    // staging: a piece = 4 pixel rows x 256 B; lane -> (row l>>4, slot l&15); 4 pieces per operand per wave per stage
+    const int prow = lane >> 4, slot = lane & 15;
+    auto stage = [&](int st, int buf) {
+        char *base = lds + buf * 32768;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (wv * 4 + j) * 4 + prow;          // row within the stage (0..63)
+            const int m = m_begin + st * 64 + r;
+            const int c = (slot ^ (tr_f(r) << 1)) * 8;      // source-side swizzle (8 channels per 16-B chunk)
+            const bool mok = m < m_end;
+            const bf16_t *s0 = (mok && co0 + c < p.Cout) ? dy + (size_t)m * p.ldy + co0 + c : zero;
+            const bf16_t *s1 = (mok && ci0 + c < p.Cin) ? a + (size_t)m * p.lda + ci0 + c : zero;
+            glds16(s0, base + (wv * 4 + j) * 1024);
+            glds16(s1, base + 16384 + (wv * 4 + j) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int q = lane >> 4, li = lane & 15;
+    auto frag = [&](const char *img, int ks, int t) {
+        // 16 channels (block t) x 32 pixels (k-step ks): this lane's 8 k values for channel 16t + li
+        const int m0 = ks * 32 + 8 * q + (li >> 2);
+        const int m1 = m0 + 4;
+        const v4i16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4i16_t *)(img + m0 * 256 + ((t ^ tr_f(m0)) << 5) + (li & 3) * 8));
+        const v4i16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4i16_t *)(img + m1 * 256 + ((t ^ tr_f(m1)) << 5) + (li & 3) * 8));
+        return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+
+    if (nst > 0) stage(0, 0);
+    wait_vm_barrier<0>();
+    for (int st = 0; st < nst; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nst) stage(st + 1, cur ^ 1);
+        const char *imgY = lds + cur * 32768, *imgA = imgY + 16384;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = frag(imgY, ks, wm * 4 + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = frag(imgA, ks, wn * 4 + j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        wait_vm_barrier<0>();   // next stage landed everywhere; everybody is done reading this one
+    }
+
+    float *out = p.part + (size_t)split * p.Cout * p.Cin;
+    const int frow = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wm * 64 + i * 16 + fq * 4 + r;
+                const int ci = ci0 + wn * 64 + j * 16 + frow;
+                if (co < p.Cout && ci < p.Cin) out[(size_t)co * p.Cin + ci] = acc[i][j][r];
+            }
+}
+
 __global__ void slab_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, size_t n, int splits,
                                    int accumulate)
 {
@@ -189,7 +288,8 @@ extern "C" int kd_pw_wgrad(int32_t dtype, int32_t M, int32_t Cin, int32_t Cout, 
     p.tiles_ci = tiles_ci; p.rows_per_split = rps; p.splits = splits;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)tiles, (unsigned)splits);
-    if (dtype == KD_BF16) hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+    if (dtype == KD_BF16 && Cin % 8 == 0 && Cout % 8 == 0) hipLaunchKernelGGL(pw_wgrad_tr_kernel, grid, dim3(256), 0, s, p);
+    else if (dtype == KD_BF16) hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(pw_wgrad_kernel<float>, grid, dim3(256), 0, s, p);
     KD_CHECK_LAUNCH("kd_pw_wgrad");
     const size_t n = (size_t)Cout * Cin;

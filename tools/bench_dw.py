@@ -32,3 +32,13 @@ for C in (512, 1024, 4096):
     print(f"dw dgrad(mask+res) C={C:5d}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TFLOP/s")
     ms = t(lambda: ops.dwconv_wgrad(x, g, dw, k, p, d, workspace=ws))
     print(f"dw wgrad C={C:5d}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TFLOP/s")
+
+# pointwise weight gradient at the student's trainable 1x1 shapes
+for (Cin, Cout) in ((512, 512), (1024, 2048), (4096, 256)):
+    H, W = 128, 256
+    a = torch.randn(1, H, W, Cin, device="cuda").bfloat16()
+    g = torch.randn(1, H, W, Cout, device="cuda").bfloat16()
+    dw = torch.empty(Cout, Cin, 1, 1, device="cuda")
+    ws = torch.empty(ops._lib.lib().kd_pw_wgrad_workspace(H * W, Cin, Cout), dtype=torch.uint8, device="cuda")
+    ms = t(lambda: ops.pw_wgrad(a, g, dw, workspace=ws))
+    print(f"pw wgrad {Cin}->{Cout}: {ms:7.3f} ms  {2.0 * H * W * Cin * Cout / ms / 1e9:7.1f} TFLOP/s")
