@@ -98,13 +98,26 @@ def cpu_baseline(cpu_sd, model, plan, hw=(512, 1024)):
                       f"{hw[0]}x{hw[1]} = {frac:.4f} of a 1024x2048 image, {dt:.2f} s; value = that fraction / time"}
 
 
+def conv_traffic(plan, batch, height, width, dtype):
+    """HBM bytes per conv_igemm launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate
+    passes, same command); None when the profiled configuration is not the one being run."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")
+    if not (plan == "P92" and batch == 2 and (height, width) == (1024, 2048) and dtype == "bf16" and os.path.exists(path)):
+        return None
+    try:
+        with open(path) as f:
+            return float(json.load(f)["kernels"]["conv_igemm"]["hbm_bytes_per_launch"])
+    except (KeyError, ValueError, OSError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--plan", default="P92", choices=sorted(PLANS))
-    ap.add_argument("--batch", type=int, default=1, help="images per GPU")
+    ap.add_argument("--batch", type=int, default=2, help="images per GPU (2 by default: +4 %% img/s over 1 from fuller grids)")
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -177,7 +190,11 @@ def main():
                        "parallelism": f"dp{world}", "teacher_overlap": bool(model.overlap_teacher),
                        "teacher_backend": a.teacher},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (dense conv fwd + dgrad, student" + (" + teacher)" if a.teacher == "hip" else ")"), "achieved": ach,
-                         "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                         "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                         "traffic": conv_traffic(a.plan, a.batch, a.height, a.width, a.dtype),
+                         "traffic_note": "mean HBM bytes per conv_igemm launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + "
+                                         "WRITE_SIZE, separate passes (profiles/r01_traffic_pmc.json); mean algorithmic "
+                                         "FLOP per launch = algorithmic_tflop_per_step / launches_per_step",
                          "launches_per_step": len(prof) / max(a.steps, 1), "ms_per_step_in_kernel": ms / max(a.steps, 1),
                          "algorithmic_tflop_per_step": flops / max(a.steps, 1) / 1e12},
             "losses": {"hint": float(loss.detach()), "supervised": float(sup), "kd": float(kd), "teacher": float(tl)},

@@ -6,6 +6,10 @@
 // every weight quad k*R of them; 16 consecutive lanes cover 64 contiguous channels
 // (128/256 B per pixel per load instruction).  Weights sit in LDS tap-major.
 // VALU/L1-bound by design (81 FMA per output element); no MFMA reshaping.
+// Measured (MI355X, 4096 ch @128x256, bf16): 42 TFLOP/s; sustained v_pk_fma_f32 rate of the chip is 127-138 TFLOP/s
+// (tools/ubench/valu_rate.hip), the kernel's own VALU mix (62 % pk_fma) bounds it at ~75.  An LDS-DMA row-ring variant
+// (3x instead of 10x input over-fetch, no masks) was built and measured slower (31-39 TFLOP/s: idle lanes at the
+// lattice/tile edges outweigh the cleaner load path), so the register-only form stays.
 #include <stdlib.h>
 #include <string.h>
 
@@ -41,6 +45,31 @@ template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t *p, float (
     v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
     v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
 }
+// Explicit 2-wide float vectors: the FMAs are written on register PAIRS from the start, so hipcc emits v_pk_fma_f32
+// on values that already sit in adjacent VGPRs (the scalar formulation was SLP-packed after the fact, at the price of
+// ~0.7 v_mov per v_pk_fma to shuffle operands into pairs).  A loaded 4-channel vector becomes two pairs; out-of-image
+// samples are zeroed by AND-ing the still-packed words with an all-ones / zero mask (2 ops instead of 4 selects).
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct Quad { v2f lo, hi; };   // channels (0,1) and (2,3)
+__device__ __forceinline__ Quad ldq(const float *p, uint32_t m)
+{
+    const float4 a = *(const float4 *)p;
+    Quad q;
+    q.lo = (v2f){__uint_as_float(__float_as_uint(a.x) & m), __uint_as_float(__float_as_uint(a.y) & m)};
+    q.hi = (v2f){__uint_as_float(__float_as_uint(a.z) & m), __uint_as_float(__float_as_uint(a.w) & m)};
+    return q;
+}
+__device__ __forceinline__ Quad ldq(const bf16_t *p, uint32_t m)
+{
+    uint2 u = *(const uint2 *)p;
+    u.x &= m; u.y &= m;
+    Quad q;
+    q.lo = (v2f){__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u)};
+    q.hi = (v2f){__uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+    return q;
+}
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
 __device__ __forceinline__ void st4(float *p, const float (&v)[4]) { *(float4 *)p = make_float4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ void st4(bf16_t *p, const float (&v)[4])
 {
@@ -77,33 +106,37 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwParams p)
     const int h0 = rh + p.dil * (th * TS), w0 = rw + p.dil * (tw * TR);
     if (h0 >= p.H || w0 >= p.W) return;
 
-    float acc[TS][TR][4];
-    float b4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) { b4[0] = p.bias[c]; b4[1] = p.bias[c + 1]; b4[2] = p.bias[c + 2]; b4[3] = p.bias[c + 3]; }
+    Quad acc2[TS][TR];
+    {
+        Quad b0;
+        b0.lo = (v2f){0.f, 0.f}; b0.hi = (v2f){0.f, 0.f};
+        if (p.bias) { b0.lo = (v2f){p.bias[c], p.bias[c + 1]}; b0.hi = (v2f){p.bias[c + 2], p.bias[c + 3]}; }
 #pragma unroll
-    for (int s = 0; s < TS; ++s)
+        for (int s = 0; s < TS; ++s)
 #pragma unroll
-        for (int r = 0; r < TR; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[s][r][q] = b4[q];
+            for (int r = 0; r < TR; ++r) acc2[s][r] = b0;
+    }
 
+    // per-thread column table (same for every input row): clamped pixel offset and all-ones / zero validity mask
+    constexpr int NX = TR + K - 1;
+    int coff[NX];
+    uint32_t cmask = 0;
+#pragma unroll
+    for (int idx = 0; idx < NX; ++idx) {
+        const int win = w0 - p.pad + idx * p.dil;
+        coff[idx] = (win < 0 ? 0 : (win >= p.W ? p.W - 1 : win)) * p.ldx;
+        cmask |= (win >= 0 && win < p.W) ? (1u << idx) : 0u;
+    }
     const T *xb = (const T *)p.x + (size_t)n * p.H * p.W * p.ldx + c;
 #pragma unroll 1
     for (int rho = 0; rho < TS + K - 1; ++rho) {
         const int hin = h0 - p.pad + rho * p.dil;
         if (hin < 0 || hin >= p.H) continue;  // block-divergent only at image borders
-        float xv[TR + K - 1][4];
+        Quad xv[NX];
         const T *xr = xb + (size_t)hin * p.W * p.ldx;
+        // unconditional loads from clamped addresses (a branch per load would serialise them behind vmcnt(0) waits)
 #pragma unroll
-        for (int idx = 0; idx < TR + K - 1; ++idx) {
-            // unconditional load from a clamped address, zeroed by a select afterwards: a branch per load would make
-            // hipcc wait vmcnt(0) at every join, i.e. TR+K-1 dependent memory round trips per row
-            const int win = w0 - p.pad + idx * p.dil;
-            const bool ok = win >= 0 && win < p.W;
-            const int wc = win < 0 ? 0 : (win >= p.W ? p.W - 1 : win);
-            ld4<T>(xr + (size_t)wc * p.ldx, xv[idx]);
-            if (!ok) { xv[idx][0] = xv[idx][1] = xv[idx][2] = xv[idx][3] = 0.f; }
-        }
+        for (int idx = 0; idx < NX; ++idx) xv[idx] = ldq(xr + coff[idx], (uint32_t)(-(int)((cmask >> idx) & 1u)));
 #pragma unroll
         for (int s = 0; s < TS; ++s) {
             const int i = rho - s;  // tap row feeding output row s from input row rho
@@ -111,16 +144,23 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwParams p)
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const float4 w4 = *(const float4 *)&wl[(i * K + j) * CB + cq * 4];
+                const v2f wlo = (v2f){w4.x, w4.y}, whi = (v2f){w4.z, w4.w};
 #pragma unroll
                 for (int r = 0; r < TR; ++r) {
-                    acc[s][r][0] = fmaf(xv[r + j][0], w4.x, acc[s][r][0]);
-                    acc[s][r][1] = fmaf(xv[r + j][1], w4.y, acc[s][r][1]);
-                    acc[s][r][2] = fmaf(xv[r + j][2], w4.z, acc[s][r][2]);
-                    acc[s][r][3] = fmaf(xv[r + j][3], w4.w, acc[s][r][3]);
+                    acc2[s][r].lo = fma2(xv[r + j].lo, wlo, acc2[s][r].lo);
+                    acc2[s][r].hi = fma2(xv[r + j].hi, whi, acc2[s][r].hi);
                 }
             }
         }
     }
+    float acc[TS][TR][4];
+#pragma unroll
+    for (int s = 0; s < TS; ++s)
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            acc[s][r][0] = acc2[s][r].lo[0]; acc[s][r][1] = acc2[s][r].lo[1];
+            acc[s][r][2] = acc2[s][r].hi[0]; acc[s][r][3] = acc2[s][r].hi[1];
+        }
 
     T *yb = (T *)p.y + (size_t)n * p.H * p.W * p.ldy + c;
     const kd_dw_epilogue &e = p.ep;
