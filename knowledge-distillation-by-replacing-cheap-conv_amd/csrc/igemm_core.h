@@ -80,13 +80,30 @@ __device__ __forceinline__ void ig_compute_stage(const char *sA, const char *sB,
         for (int i = 0; i < MI; ++i) a[i] = *(const uint4 *)(A + i * 16 * RB + sw);
 #pragma unroll
         for (int j = 0; j < 4; ++j) b[j] = *(const uint4 *)(B + j * 16 * RB + sw);
+        if constexpr (sizeof(T) == 4) {
+            // fp32 parity path: the f32 MFMA is an exact k-ordered fmaf chain with no wider internal accumulation, so a
+            // single chain over K = 4608..9216 products drifts ~2e-5 relative per conv on zero-mean (backward) operands.
+            // Accumulate each k-step (16 products) in a fresh register tile and add it to the running sum: short chains +
+            // ~K/16 fp32 adds, i.e. blocked summation like the CPU reference's GEMM.
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i) {
+                f32x4_t part[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < 4; ++j) {
+                    part[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                    Mma<T>::run(a[i], b[j], part[j]);
+                    acc[i][j] += part[j];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
+        }
         // issue the k-step's fragment reads back to back, then its MFMAs: one exposed LDS latency per k-step instead
         // of one per pair of reads (hipcc otherwise interleaves read-wait-4 MFMAs to save registers)
         __builtin_amdgcn_sched_group_barrier(0x100, MI + 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, MI * 4 * (sizeof(T) == 4 ? 4 : 1), 0);
+        if constexpr (sizeof(T) != 4) __builtin_amdgcn_sched_group_barrier(0x008, MI * 4, 0);
     }
 }
