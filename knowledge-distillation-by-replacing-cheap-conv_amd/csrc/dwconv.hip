@@ -68,6 +68,24 @@ __device__ __forceinline__ Quad ldq(const bf16_t *p, uint32_t m)
     q.hi = (v2f){__uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
     return q;
 }
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { typedef float4 type; };
+template <> struct Raw4<bf16_t> { typedef uint2 type; };
+__device__ __forceinline__ Quad unpackq(const float4 &a, uint32_t m)
+{
+    Quad q;
+    q.lo = (v2f){__uint_as_float(__float_as_uint(a.x) & m), __uint_as_float(__float_as_uint(a.y) & m)};
+    q.hi = (v2f){__uint_as_float(__float_as_uint(a.z) & m), __uint_as_float(__float_as_uint(a.w) & m)};
+    return q;
+}
+__device__ __forceinline__ Quad unpackq(uint2 u, uint32_t m)
+{
+    u.x &= m; u.y &= m;
+    Quad q;
+    q.lo = (v2f){__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u)};
+    q.hi = (v2f){__uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+    return q;
+}
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
 __device__ __forceinline__ void st4(float *p, const float (&v)[4]) { *(float4 *)p = make_float4(v[0], v[1], v[2], v[3]); }
@@ -128,15 +146,30 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwParams p)
         cmask |= (win >= 0 && win < p.W) ? (1u << idx) : 0u;
     }
     const T *xb = (const T *)p.x + (size_t)n * p.H * p.W * p.ldx + c;
+    // Software prefetch: the next input row's (still packed) loads are issued as soon as the current row has been
+    // unpacked, so they fly under this row's 2*K*TR packed FMAs.  Row addresses are clamped into the image (a branch
+    // per load would serialise them behind vmcnt(0) waits); rows outside the image are skipped wave-uniformly or zeroed
+    // through the mask.
+    typedef typename Raw4<T>::type raw_t;
+    auto issue = [&](int rho, raw_t (&dst)[NX]) {
+        const int hin = h0 - p.pad + rho * p.dil;
+        const int hc = hin < 0 ? 0 : (hin >= p.H ? p.H - 1 : hin);
+        const T *xr = xb + (size_t)hc * p.W * p.ldx;
+#pragma unroll
+        for (int idx = 0; idx < NX; ++idx) dst[idx] = *(const raw_t *)(xr + coff[idx]);
+    };
+    raw_t raw[NX];
+    issue(0, raw);
 #pragma unroll 1
     for (int rho = 0; rho < TS + K - 1; ++rho) {
         const int hin = h0 - p.pad + rho * p.dil;
-        if (hin < 0 || hin >= p.H) continue;  // block-divergent only at image borders
+        const bool rok = hin >= 0 && hin < p.H;
+        const uint32_t rmask = rok ? 0xffffffffu : 0u;
         Quad xv[NX];
-        const T *xr = xb + (size_t)hin * p.W * p.ldx;
-        // unconditional loads from clamped addresses (a branch per load would serialise them behind vmcnt(0) waits)
 #pragma unroll
-        for (int idx = 0; idx < NX; ++idx) xv[idx] = ldq(xr + coff[idx], (uint32_t)(-(int)((cmask >> idx) & 1u)));
+        for (int idx = 0; idx < NX; ++idx) xv[idx] = unpackq(raw[idx], rmask & (uint32_t)(-(int)((cmask >> idx) & 1u)));
+        if (rho + 1 < TS + K - 1) issue(rho + 1, raw);
+        if (__ballot(rok) == 0ull) continue;   // the whole wave's row is outside the image
 #pragma unroll
         for (int s = 0; s < TS; ++s) {
             const int i = rho - s;  // tap row feeding output row s from input row rho
@@ -237,9 +270,9 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwWgradParams p
     const int c = by * CB + cq * 4;
     const int strip = bx * 16 + tt;
 
-    float acc[K][4];
+    Quad acc2[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.f;
+    for (int j = 0; j < K; ++j) { acc2[j].lo = (v2f){0.f, 0.f}; acc2[j].hi = (v2f){0.f, 0.f}; }
 
     if (strip < p.nstrips && c < p.C) {
         // strip -> (n, rh, rw, lh)
@@ -254,37 +287,52 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwWgradParams p
         if (h < p.H && hin >= 0 && hin < p.H) {
             const T *dyr = (const T *)p.dy + ((size_t)n * p.H + h) * p.W * p.ld_dy + c;
             const T *xr = (const T *)p.x + ((size_t)n * p.H + hin) * p.W * p.ldx + c;
-#pragma unroll 1
-            for (int lw0 = 0; lw0 < p.LW; lw0 += WTR) {
+            typedef typename Raw4<T>::type raw_t;
+            constexpr int NX = WTR + K - 1;
+            // chunks of WTR lattice columns; the next chunk's (packed) loads are issued as soon as this chunk is unpacked
+            auto issue = [&](int lw0, raw_t (&gd)[WTR], raw_t (&xd)[NX]) {
                 const int w0 = rw + p.dil * lw0;
-                if (w0 >= p.W) break;
-                float g[WTR][4], xv[WTR + K - 1][4];
 #pragma unroll
                 for (int r = 0; r < WTR; ++r) {
                     const int w = w0 + r * p.dil;
-                    const int wc = w >= p.W ? p.W - 1 : w;
-                    ld4<T>(dyr + (size_t)wc * p.ld_dy, g[r]);
-                    if (w >= p.W) { g[r][0] = g[r][1] = g[r][2] = g[r][3] = 0.f; }
+                    gd[r] = *(const raw_t *)(dyr + (size_t)(w >= p.W ? p.W - 1 : w) * p.ld_dy);
                 }
 #pragma unroll
-                for (int idx = 0; idx < WTR + K - 1; ++idx) {
+                for (int idx = 0; idx < NX; ++idx) {
                     const int win = w0 - p.pad + idx * p.dil;
-                    const bool ok = win >= 0 && win < p.W;
-                    const int wc = win < 0 ? 0 : (win >= p.W ? p.W - 1 : win);
-                    ld4<T>(xr + (size_t)wc * p.ldx, xv[idx]);
-                    if (!ok) { xv[idx][0] = xv[idx][1] = xv[idx][2] = xv[idx][3] = 0.f; }
+                    xd[idx] = *(const raw_t *)(xr + (size_t)(win < 0 ? 0 : (win >= p.W ? p.W - 1 : win)) * p.ldx);
                 }
+            };
+            int nchunks = 0;
+            for (int lw0 = 0; lw0 < p.LW && rw + p.dil * lw0 < p.W; lw0 += WTR) ++nchunks;
+            raw_t gr[WTR], xr4[NX];
+            if (nchunks > 0) issue(0, gr, xr4);
+#pragma unroll 1
+            for (int ch = 0; ch < nchunks; ++ch) {
+                const int w0 = rw + p.dil * ch * WTR;
+                Quad g[WTR], xv[NX];
+#pragma unroll
+                for (int r = 0; r < WTR; ++r) g[r] = unpackq(gr[r], (w0 + r * p.dil < p.W) ? 0xffffffffu : 0u);
+#pragma unroll
+                for (int idx = 0; idx < NX; ++idx) {
+                    const int win = w0 - p.pad + idx * p.dil;
+                    xv[idx] = unpackq(xr4[idx], (win >= 0 && win < p.W) ? 0xffffffffu : 0u);
+                }
+                if (ch + 1 < nchunks) issue((ch + 1) * WTR, gr, xr4);
 #pragma unroll
                 for (int j = 0; j < K; ++j)
 #pragma unroll
                     for (int r = 0; r < WTR; ++r) {
-                        acc[j][0] = fmaf(g[r][0], xv[r + j][0], acc[j][0]);
-                        acc[j][1] = fmaf(g[r][1], xv[r + j][1], acc[j][1]);
-                        acc[j][2] = fmaf(g[r][2], xv[r + j][2], acc[j][2]);
-                        acc[j][3] = fmaf(g[r][3], xv[r + j][3], acc[j][3]);
+                        acc2[j].lo = fma2(g[r].lo, xv[r + j].lo, acc2[j].lo);
+                        acc2[j].hi = fma2(g[r].hi, xv[r + j].hi, acc2[j].hi);
                     }
             }
         }
+    }
+    float acc[K][4];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        acc[j][0] = acc2[j].lo[0]; acc[j][1] = acc2[j].lo[1]; acc[j][2] = acc2[j].hi[0]; acc[j][3] = acc2[j].hi[1];
     }
 #pragma unroll
     for (int j = 0; j < K; ++j)
