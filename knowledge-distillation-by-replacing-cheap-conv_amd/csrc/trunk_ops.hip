@@ -76,27 +76,26 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T *__restrict__ x, i
                                                       const float *__restrict__ shift, int N, int H, int W, int C, int Ho,
                                                       int Wo)
 {
-    const int c8 = C >> 3;
-    const long long total = (long long)N * Ho * Wo * c8;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cq = (int)(i % c8);
-        long long r = i / c8;
-        const int wo = (int)(r % Wo); r /= Wo;
-        const int ho = (int)(r % Ho);
-        const int n = (int)(r / Ho);
+    // grid: x = chunks of one output row's (Wo * C/8) vectors, y = output row, z = image
+    const unsigned c8 = (unsigned)C >> 3;
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= (unsigned)Wo * c8) return;
+    const unsigned wo = e / c8, cq = e - wo * c8;
+    const int ho = blockIdx.y, n = blockIdx.z;
+    {
         float m[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) m[q] = -INFINITY;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int hi = ho * 2 - 1 + ky;
-            if (hi < 0 || hi >= H) continue;
+            if (hi < 0 || hi >= H) continue;   // block-uniform
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int wi = wo * 2 - 1 + kx;
-                if (wi < 0 || wi >= W) continue;
+                const int wi = (int)wo * 2 - 1 + kx;
+                const int wc = wi < 0 ? 0 : (wi >= W ? W - 1 : wi);   // clamped tap duplicates a valid one: max unchanged
                 float v[8];
-                ld8(x + (((size_t)n * H + hi) * W + wi) * ldx + cq * 8, v);
+                ld8(x + (((size_t)n * H + hi) * W + wc) * ldx + cq * 8, v);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], v[q]);
             }
@@ -113,40 +112,38 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T *__restrict__ x, i
 }
 
 // ---- bilinear upsample, align_corners=True ---------------------------------------------
+// grid: x = chunks of one output row's (Wo * C/VEC) elements, y = output row, z = image: the row interpolation
+// weights are block-uniform and the only per-thread division is a 32-bit one by C/VEC.
 template <typename TI, typename TO, int VEC>
 __global__ __launch_bounds__(256) void upsample_kernel(const TI *__restrict__ x, int ldx, TO *__restrict__ y, int ldy, int N,
                                                        int H, int W, int C, int Ho, int Wo, float sh, float sw)
 {
-    const int cv = C / VEC;
-    const long long total = (long long)N * Ho * Wo * cv;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cq = (int)(i % cv);
-        long long r = i / cv;
-        const int wo = (int)(r % Wo); r /= Wo;
-        const int ho = (int)(r % Ho);
-        const int n = (int)(r / Ho);
-        const float fh = ho * sh, fw = wo * sw;
-        int h0 = (int)fh; h0 = h0 > H - 1 ? H - 1 : h0;
-        int w0 = (int)fw; w0 = w0 > W - 1 ? W - 1 : w0;
-        const int h1 = h0 + 1 < H ? h0 + 1 : H - 1, w1 = w0 + 1 < W ? w0 + 1 : W - 1;
-        const float ah = fh - h0, aw = fw - w0;
-        const TI *b = x + (size_t)n * H * W * ldx + cq * VEC;
-        const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * ldy + cq * VEC;
-        if constexpr (VEC == 8) {
-            float a00[8], a01[8], a10[8], a11[8], v[8];
-            ld8(b + ((size_t)h0 * W + w0) * ldx, a00);
-            ld8(b + ((size_t)h0 * W + w1) * ldx, a01);
-            ld8(b + ((size_t)h1 * W + w0) * ldx, a10);
-            ld8(b + ((size_t)h1 * W + w1) * ldx, a11);
+    const unsigned cv = (unsigned)C / VEC;
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= (unsigned)Wo * cv) return;
+    const unsigned wo = e / cv, cq = e - wo * cv;
+    const int ho = blockIdx.y, n = blockIdx.z;
+    const float fh = ho * sh, fw = wo * sw;
+    int h0 = (int)fh; h0 = h0 > H - 1 ? H - 1 : h0;
+    int w0 = (int)fw; w0 = w0 > W - 1 ? W - 1 : w0;
+    const int h1 = h0 + 1 < H ? h0 + 1 : H - 1, w1 = w0 + 1 < W ? w0 + 1 : W - 1;
+    const float ah = fh - h0, aw = fw - w0;
+    const TI *b = x + (size_t)n * H * W * ldx + cq * VEC;
+    const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * ldy + cq * VEC;
+    if constexpr (VEC == 8) {
+        float a00[8], a01[8], a10[8], a11[8], v[8];
+        ld8(b + ((size_t)h0 * W + w0) * ldx, a00);
+        ld8(b + ((size_t)h0 * W + w1) * ldx, a01);
+        ld8(b + ((size_t)h1 * W + w0) * ldx, a10);
+        ld8(b + ((size_t)h1 * W + w1) * ldx, a11);
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                v[q] = (1.f - ah) * ((1.f - aw) * a00[q] + aw * a01[q]) + ah * ((1.f - aw) * a10[q] + aw * a11[q]);
-            st8(y + o, v);
-        } else {
-            const float a00 = Elem<TI>::ld(b + ((size_t)h0 * W + w0) * ldx), a01 = Elem<TI>::ld(b + ((size_t)h0 * W + w1) * ldx);
-            const float a10 = Elem<TI>::ld(b + ((size_t)h1 * W + w0) * ldx), a11 = Elem<TI>::ld(b + ((size_t)h1 * W + w1) * ldx);
-            Elem<TO>::st(y + o, (1.f - ah) * ((1.f - aw) * a00 + aw * a01) + ah * ((1.f - aw) * a10 + aw * a11));
-        }
+        for (int q = 0; q < 8; ++q)
+            v[q] = (1.f - ah) * ((1.f - aw) * a00[q] + aw * a01[q]) + ah * ((1.f - aw) * a10[q] + aw * a11[q]);
+        st8(y + o, v);
+    } else {
+        const float a00 = Elem<TI>::ld(b + ((size_t)h0 * W + w0) * ldx), a01 = Elem<TI>::ld(b + ((size_t)h0 * W + w1) * ldx);
+        const float a10 = Elem<TI>::ld(b + ((size_t)h1 * W + w0) * ldx), a11 = Elem<TI>::ld(b + ((size_t)h1 * W + w1) * ldx);
+        Elem<TO>::st(y + o, (1.f - ah) * ((1.f - aw) * a00 + aw * a01) + ah * ((1.f - aw) * a10 + aw * a11));
     }
 }
 
@@ -280,14 +277,14 @@ extern "C" int kd_maxpool3x3s2(int32_t dtype, const void *x, int32_t ldx, void *
                    (!y_act || (kd_aligned16(y_act) && (ld_act * es) % 16 == 0)),
                KD_ERR_INVALID, "kd_maxpool3x3s2: C %% 8 and 16-B alignment required");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const long long total = (long long)N * Ho * Wo * (C / 8);
+    const dim3 g((unsigned)((Wo * (C / 8) + 255) / 256), (unsigned)Ho, (unsigned)N);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == KD_BF16)
-        hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3(grid_for(total, 1 << 20)), dim3(256), 0, s, (const bf16_t *)x, ldx,
-                           (bf16_t *)y_raw, ld_raw, (bf16_t *)y_act, ld_act, scale, shift, N, H, W, C, Ho, Wo);
+        hipLaunchKernelGGL(maxpool_kernel<bf16_t>, g, dim3(256), 0, s, (const bf16_t *)x, ldx, (bf16_t *)y_raw, ld_raw,
+                           (bf16_t *)y_act, ld_act, scale, shift, N, H, W, C, Ho, Wo);
     else
-        hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid_for(total, 1 << 20)), dim3(256), 0, s, (const float *)x, ldx,
-                           (float *)y_raw, ld_raw, (float *)y_act, ld_act, scale, shift, N, H, W, C, Ho, Wo);
+        hipLaunchKernelGGL(maxpool_kernel<float>, g, dim3(256), 0, s, (const float *)x, ldx, (float *)y_raw, ld_raw,
+                           (float *)y_act, ld_act, scale, shift, N, H, W, C, Ho, Wo);
     KD_CHECK_LAUNCH("kd_maxpool3x3s2");
     return KD_OK;
 }
@@ -299,13 +296,13 @@ static void launch_up(const void *x, int ldx, void *y, int ldy, int N, int H, in
     const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
     const float sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
     if (vec) {
-        const long long total = (long long)N * Ho * Wo * (C / 8);
-        hipLaunchKernelGGL((upsample_kernel<TI, TO, 8>), dim3(grid_for(total, 1 << 20)), dim3(256), 0, s, (const TI *)x, ldx,
-                           (TO *)y, ldy, N, H, W, C, Ho, Wo, sh, sw);
+        const dim3 g((unsigned)((Wo * (C / 8) + 255) / 256), (unsigned)Ho, (unsigned)N);
+        hipLaunchKernelGGL((upsample_kernel<TI, TO, 8>), g, dim3(256), 0, s, (const TI *)x, ldx, (TO *)y, ldy, N, H, W, C, Ho, Wo,
+                           sh, sw);
     } else {
-        const long long total = (long long)N * Ho * Wo * C;
-        hipLaunchKernelGGL((upsample_kernel<TI, TO, 1>), dim3(grid_for(total, 1 << 20)), dim3(256), 0, s, (const TI *)x, ldx,
-                           (TO *)y, ldy, N, H, W, C, Ho, Wo, sh, sw);
+        const dim3 g((unsigned)((Wo * C + 255) / 256), (unsigned)Ho, (unsigned)N);
+        hipLaunchKernelGGL((upsample_kernel<TI, TO, 1>), g, dim3(256), 0, s, (const TI *)x, ldx, (TO *)y, ldy, N, H, W, C, Ho, Wo,
+                           sh, sw);
     }
 }
 
