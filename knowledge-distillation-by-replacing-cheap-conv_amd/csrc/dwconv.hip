@@ -391,6 +391,10 @@ int check_desc(const kd_dw_desc *d, const char *who)
 
 }  // namespace
 
+// dwconv_mfma.hip: matrix-core path for bf16 / 9x9 (1 = launched, 0 = not eligible, < 0 = error)
+int kd_internal_dw_mfma_fwd(const kd_dw_desc *d, const void *x, const float *w_taps, const float *bias,
+                            const kd_dw_epilogue *ep, void *y, hipStream_t s);
+
 extern "C" int kd_pack_dw_weight(const float *src, float *dst, int32_t C, int32_t k, int32_t flip, kd_stream_t stream)
 {
     KD_REQUIRE(src && dst && C > 0 && k > 0, KD_ERR_INVALID, "kd_pack_dw_weight: bad argument");
@@ -411,6 +415,11 @@ extern "C" int kd_dwconv_fwd(const kd_dw_desc *d, const void *x, const float *w_
     KD_REQUIRE(d->ldy >= d->C && d->ldy % 4 == 0 && d->ldx % 4 == 0, KD_ERR_INVALID, "kd_dwconv_fwd: ld must be a multiple of 4");
     KD_REQUIRE(((uintptr_t)x % (4 * es)) == 0 && ((uintptr_t)y % (4 * es)) == 0, KD_ERR_INVALID,
                "kd_dwconv_fwd: x/y must be aligned to 4 elements");
+    {
+        const int took = kd_internal_dw_mfma_fwd(d, x, w_taps, bias, ep, y, (hipStream_t)stream);
+        if (took < 0) return took;
+        if (took) return KD_OK;
+    }
     DwParams p;
     memset(&p.ep, 0, sizeof(p.ep));
     if (ep) {

@@ -1,0 +1,352 @@
+// Depthwise 9x9 dilated convolution on the matrix cores (bf16 activations; kd_dwconv_fwd's fast path, also used for
+// the input gradient with flipped taps).
+//
+// A depthwise conv has no channel contraction, so it is not a GEMM -- but along one image axis it is a banded
+// (Toeplitz) matrix product.  On the lattice {r + dil*l} of one residue class (ry, rx) the 9x9 stencil is dense, and
+//   out[ly][lx] = sum_ky  sum_k  X[ly + ky][lx0 + k] * T_ky[k][lx - lx0],   T_ky[k][j] = w[ky][k - j] (0 <= k-j < 9)
+// i.e. per channel and tap row one v_mfma_f32_16x16x32_bf16: A = 16 lattice rows x 32 lattice columns of the input
+// (rows shifted by ky), B = the 32 x 16 Toeplitz band of tap row ky, D = 16 x 16 outputs, accumulated over the 9 tap
+// rows.  9 of the 32 products per output are non-zero (28 % of the MFMA's MACs are useful), which at MFMA rates still
+// beats the 81-FMA VALU stencil several times over and leaves the op bound by its HBM traffic.
+//
+// Block (8 waves, one per CU) = (image, 16 channels, a segment of the list of work items); a work item is a residue
+// class x lattice tile of <= 26 x 52 outputs.  Wave w owns channels 2w, 2w+1; their Toeplitz operands (2 x 9 x 16 B
+// per lane) are built once per block and stay in registers.  Per item:
+//   1. the next item's tile + 4-cell halo is fetched to registers (NHWC, 16 channels = 32 B per pixel), a few loads at
+//      a time between the MFMA tiles, while
+//   2. this item's MFMAs run from the LDS copy X[row][channel][64 cols] (zero outside the image; row stride 2080 B
+//      keeps the 16-row ds_read_b128 fragment reads bank-conflict-free): 2 x 4 output tiles x 9 MFMAs per channel;
+//   3. accumulators -> LDS as [pixel][16 channels] bf16 (over the X buffer just consumed), then 16-B NHWC stores;
+//   4. the prefetched registers are transposed into the other X buffer.
+// Edge tiles overlap their neighbours instead of running past the staged rows/columns (identical values are written
+// twice), so no LDS read leaves the buffer and every operand is finite.
+#include <stdlib.h>
+#include <string.h>
+
+#include "igemm_core.h"
+
+namespace {
+
+constexpr int CG = 16;                      // channels per block
+constexpr int NT = 512;                     // threads per block
+constexpr int TLY = 26, TLX = 52;           // lattice outputs per work item (rows, cols)
+constexpr int RY = TLY + 8;                 // staged lattice rows (4-cell halo each side)
+constexpr int NCOL = 64;                    // staged lattice cols per (row, channel): 60 used
+constexpr int CSTR = NCOL * 2;              // bytes per (row, channel)
+constexpr int RSTR = CG * CSTR + 32;        // row stride: == 32 (mod 256) -> conflict-free fragment reads
+constexpr int XBYTES = (RY * RSTR + 64 + 15) & ~15;   // one X buffer (+ tail: K padding of the last column tile)
+constexpr int WT_OFF = 2 * XBYTES;
+constexpr int WTBYTES = CG * 9 * 16 * 2;    // bf16 taps [channel][ky][16] (kx 9..15 zero)
+constexpr int LDS_BYTES = WT_OFF + WTBYTES;
+constexpr int OSTR = CG * 2;                // output staging: bytes per pixel
+constexpr int ITEMS = RY * 32 * 2;          // stage-in units per work item: (row, column pair, 8-channel half)
+constexpr int NIT = (ITEMS + NT - 1) / NT;
+constexpr int OPX = 56;                     // output staging: pixels per row (last column tile starts at <= 40)
+static_assert(TLY * OPX * OSTR <= RY * RSTR, "output staging must fit in the input buffer it aliases");
+static_assert(TLY <= 28 && TLX <= 64 && NT == 512, "store phase: thread = (half, 64 columns, row mod 4), 7 rows each");
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+
+struct DwMfmaParams {
+    const bf16_t *x;
+    const float *w;      // [81][C]
+    bf16_t *y;
+    int N, H, W, C, dil, ldx, ldy;
+    int nty, ntx, ncg;
+    int nitems, nseg;    // work items per (image, channel group); segments they are split into
+};
+
+struct Item {
+    int ry, rx, ty, tx, RV, CV;
+};
+
+__device__ __forceinline__ Item decode_item(const DwMfmaParams &p, int e)
+{
+    Item it;
+    const int d = p.dil;
+    it.rx = e % d; e /= d;
+    it.ry = e % d; e /= d;
+    it.tx = e % p.ntx;
+    it.ty = e / p.ntx;
+    const int Ly = (p.H - it.ry + d - 1) / d, Lx = (p.W - it.rx + d - 1) / d;   // lattice extent of this residue class
+    it.RV = min(TLY, Ly - it.ty * TLY);
+    it.CV = min(TLX, Lx - it.tx * TLX);
+    return it;
+}
+
+struct Staged {
+    uint4 a[NIT], b[NIT];
+    uint32_t ok[NIT];
+};
+
+// global -> registers: unit (row r, column pair lp, half h) = two pixels of the residue lattice, 8 channels each
+__device__ __forceinline__ void fetch_unit(int it, const DwMfmaParams &p, const bf16_t *xb, const Item &w, int tid, Staged &s)
+{
+    const int d = p.dil;
+    {
+        const int unit = min(tid + it * NT, ITEMS - 1);
+        const int h = unit & 1, lp = (unit >> 1) & 31, r = unit >> 6;
+        const int ly = w.ty * TLY + r - 4, lx = w.tx * TLX + 2 * lp - 4;
+        const int yy = w.ry + d * ly, xa = w.rx + d * lx, xb2 = xa + d;
+        const bool rok = ly >= 0 && yy < p.H && lp < 30;
+        const bool aok = rok && lx >= 0 && xa < p.W, bok = rok && lx + 1 >= 0 && xb2 < p.W;
+        const int yc = min(max(yy, 0), p.H - 1);
+        const bf16_t *row = xb + (size_t)yc * p.W * p.ldx + h * 8;
+        s.a[it] = *(const uint4 *)(row + (size_t)min(max(xa, 0), p.W - 1) * p.ldx);
+        s.b[it] = *(const uint4 *)(row + (size_t)min(max(xb2, 0), p.W - 1) * p.ldx);
+        s.ok[it] = (aok ? 0x0000ffffu : 0u) | (bok ? 0xffff0000u : 0u);
+    }
+}
+__device__ __forceinline__ void fetch_item(const DwMfmaParams &p, const bf16_t *xb, const Item &w, int tid, Staged &s)
+{
+    fetch_unit(0, p, xb, w, tid, s); fetch_unit(1, p, xb, w, tid, s); fetch_unit(2, p, xb, w, tid, s);
+    fetch_unit(3, p, xb, w, tid, s); fetch_unit(4, p, xb, w, tid, s);
+}
+static_assert(NIT == 5, "fetch_item / the interleaved fetch below are written for 5 units per thread");
+
+// registers -> X buffer, transposed to per-channel lattice rows (two neighbouring lattice columns per dword)
+__device__ __forceinline__ void write_item(char *X, int tid, const Staged &s)
+{
+    for (int e = tid; e < RY * 8 + 16; e += NT) {   // row pads + tail: K padding, must be finite
+        const int r = e >> 3;
+        if (r < RY) *(uint32_t *)(X + r * RSTR + CG * CSTR + (e & 7) * 4) = 0u;
+        else *(uint32_t *)(X + RY * RSTR + (e - RY * 8) * 4) = 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int unit = tid + it * NT;
+        if (unit < ITEMS) {
+            const int h = unit & 1, lp = (unit >> 1) & 31, r = unit >> 6;
+            char *dst = X + r * RSTR + (h * 8) * CSTR + lp * 4;
+            const uint32_t a[4] = {s.a[it].x, s.a[it].y, s.a[it].z, s.a[it].w};
+            const uint32_t b[4] = {s.b[it].x, s.b[it].y, s.b[it].z, s.b[it].w};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                *(uint32_t *)(dst + (2 * m) * CSTR) = ((a[m] & 0xffffu) | (b[m] << 16)) & s.ok[it];
+                *(uint32_t *)(dst + (2 * m + 1) * CSTR) = ((a[m] >> 16) | (b[m] & 0xffff0000u)) & s.ok[it];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int cgi = lin % p.ncg; lin /= p.ncg;
+    const int seg = lin % p.nseg;
+    const int n = lin / p.nseg;
+    const int c0 = cgi * CG;
+    const int ibeg = (int)((long long)p.nitems * seg / p.nseg), iend = (int)((long long)p.nitems * (seg + 1) / p.nseg);
+    const bf16_t *xb = p.x + (size_t)n * p.H * p.W * p.ldx + c0;
+    const int d = p.dil;
+
+    // first valid item's loads go out before anything else
+    int cur = ibeg;
+    Item wi = decode_item(p, cur);
+    while (cur < iend && (wi.RV <= 0 || wi.CV <= 0)) { ++cur; if (cur < iend) wi = decode_item(p, cur); }
+    if (cur >= iend) return;   // block-uniform
+    Staged st;
+    fetch_item(p, xb, wi, tid, st);
+
+    // taps -> bf16 table (loads issued together, then converted)
+    {
+        bf16_t *wt = (bf16_t *)(smem + WT_OFF);
+        constexpr int NW = (CG * 81 + NT - 1) / NT;
+        float wv[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int e = min(tid + i * NT, CG * 81 - 1);
+            wv[i] = p.w[(size_t)(e >> 4) * p.C + c0 + (e & 15)];
+        }
+        for (int e = tid; e < CG * 9 * 16; e += NT) wt[e] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int e = tid + i * NT;
+            if (e < CG * 81) {
+                const int c = e & 15, tap = e >> 4, ky = tap / 9, kx = tap - ky * 9;
+                wt[(c * 9 + ky) * 16 + kx] = f32_to_bf16(wv[i]);
+            }
+        }
+    }
+    write_item(smem, tid, st);
+    __syncthreads();
+
+    // Toeplitz operands of this wave's two channels
+    const int fi = lane & 15, kg = lane >> 4;
+    uint4 B[2][9];
+    {
+        int widx[8];   // byte offset of tap kx = kg*8 + q - fi in a table row (slot 15 holds zero)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int kx = kg * 8 + q - fi;
+            widx[q] = (kx >= 0 && kx < 9 ? kx : 15) * 2;
+        }
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int ky = 0; ky < 9; ++ky) {
+                const char *wr = smem + WT_OFF + ((wave * 2 + cc) * 9 + ky) * 32;
+                uint32_t v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = *(const bf16_t *)(wr + widx[q]);
+                B[cc][ky] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+            }
+    }
+
+    int buf = 0;
+    while (true) {
+        // ---- 1. next item's loads ------------------------------------------------------------------------------------------
+        int nxt = cur + 1;
+        Item wn = wi;
+        if (nxt < iend) wn = decode_item(p, nxt);
+        while (nxt < iend && (wn.RV <= 0 || wn.CV <= 0)) { ++nxt; if (nxt < iend) wn = decode_item(p, nxt); }
+        const bool more = nxt < iend;
+
+        // ---- 2. MFMA ---------------------------------------------------------------------------------------------------------
+        char *X = smem + buf * XBYTES;
+        const int RV = wi.RV, CV = wi.CV;
+        const int nmt = RV > 16 ? 2 : 1, njt = (CV + 15) >> 4;
+        const int m1 = RV - 16;                                  // second row tile overlaps the first
+        const int jlast = max(((CV + 7) & ~7) - 16, 0);          // last column tile start (multiple of 8: 16-B reads)
+        f32x4_t acc[2][2][4];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const char *xc = X + (wave * 2 + cc) * CSTR + kg * 16;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+                    acc[cc][mt][jt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                    // the next item's loads go out a unit at a time between the tiles, so they trickle through the
+                    // memory pipeline under the MFMAs instead of stalling the wave's issue in one burst
+                    const int step = cc * 8 + mt * 4 + jt;
+                    if (more) {
+                        if (step == 0) fetch_unit(0, p, xb, wn, tid, st);
+                        if (step == 3) fetch_unit(1, p, xb, wn, tid, st);
+                        if (step == 6) fetch_unit(2, p, xb, wn, tid, st);
+                        if (step == 9) fetch_unit(3, p, xb, wn, tid, st);
+                        if (step == 12) fetch_unit(4, p, xb, wn, tid, st);
+                    }
+                    if (mt < nmt && jt < njt) {
+                        const char *xa = xc + ((mt ? m1 : 0) + fi) * RSTR + min(jt * 16, jlast) * 2;
+#pragma unroll
+                        for (int ky = 0; ky < 9; ++ky) {
+                            const uint4 a = *(const uint4 *)(xa + ky * RSTR);
+                            Mma<bf16_t>::run(a, B[cc][ky], acc[cc][mt][jt]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);   // one tile's 9 fragments in flight at a time (register budget)
+                    }
+                }
+            }
+        }
+        __syncthreads();   // every wave is done reading X: the output staging may overwrite it
+
+        // ---- 3. accumulators -> [pixel][16 ch] bf16 -> NHWC ------------------------------------------------------------------
+        // staging rows are OPX pixels wide so the last (overlapping) column tile can be written whole; the 4-B channel
+        // pair of wave w goes to slot w ^ (col & 7) of the pixel's 32 B (spreads the 16 lanes of a tile row over banks)
+        {
+            char *ob = X + ((kg * 4) * OPX + fi) * OSTR;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+                    if (mt < nmt && jt < njt) {
+                        const int cb = min(jt * 16, jlast);
+                        char *o = ob + ((mt ? m1 : 0) * OPX + cb) * OSTR + ((wave ^ ((cb + fi) & 7)) << 2);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            *(uint32_t *)(o + r * OPX * OSTR) = pack_bf16x2(acc[0][mt][jt][r], acc[1][mt][jt][r]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        {
+            // thread = (8-channel half, column, row mod 4): no divisions, 16-B loads/stores
+            const int h = tid & 1, col = (tid >> 1) & 63, rq = tid >> 7;
+            if (col < CV) {
+                const int xx = wi.rx + d * (wi.tx * TLX + col);
+                const char *osrc = X + col * OSTR + ((h ^ ((col >> 2) & 1)) << 4);
+                const bool s1 = col & 1, s2 = col & 2;
+                bf16_t *ycol = p.y + ((size_t)n * p.H * p.W + xx) * p.ldy + c0 + h * 8;
+#pragma unroll
+                for (int k = 0; k < (TLY + 3) / 4; ++k) {
+                    const int row = rq + 4 * k;
+                    if (row < RV) {
+                        // un-swizzle: this half's four channel pairs sit in half h ^ bit2(col), permuted by col & 3
+                        const uint4 o = *(const uint4 *)(osrc + row * OPX * OSTR);
+                        const uint32_t a0 = s1 ? o.y : o.x, a1 = s1 ? o.x : o.y, a2 = s1 ? o.w : o.z, a3 = s1 ? o.z : o.w;
+                        const int yy = wi.ry + d * (wi.ty * TLY + row);
+                        *(uint4 *)(ycol + (size_t)yy * p.W * p.ldy) = make_uint4(s2 ? a2 : a0, s2 ? a3 : a1, s2 ? a0 : a2, s2 ? a1 : a3);
+                    }
+                }
+            }
+        }
+        if (!more) break;
+
+        // ---- 4. prefetched registers -> the other X buffer -----------------------------------------------------------------
+        buf ^= 1;
+        write_item(smem + buf * XBYTES, tid, st);
+        __syncthreads();
+        cur = nxt;
+        wi = wn;
+    }
+}
+
+}  // namespace
+
+// Returns 1 if the MFMA path took the call, 0 if the shape is not eligible (caller falls back to the register kernel),
+// < 0 on a launch error.
+int kd_internal_dw_mfma_fwd(const kd_dw_desc *d, const void *x, const float *w_taps, const float *bias,
+                            const kd_dw_epilogue *ep, void *y, hipStream_t s)
+{
+    if (d->dtype != KD_BF16 || d->k != 9 || d->C % CG != 0 || d->ldx % 8 != 0 || d->ldy % 8 != 0) return 0;
+    if (!kd_aligned16(x) || !kd_aligned16(y)) return 0;
+    // Calls with a bias or an epilogue stay on the register kernel: their extra operands are read per pixel in 32-B
+    // (16-channel) pieces here, which the memory system serves at about a third of the rate of the register kernel's
+    // 128-B-per-pixel rows (measured: 1.22 vs 0.99 ms at 4096 channels, mask + residual, 2 images).
+    if (bias || (ep && (ep->res_pre || ep->mask || ep->res_post))) return 0;
+    DwMfmaParams p;
+    static int enabled = -1;
+    if (enabled < 0) {
+        const char *e = getenv("KDCC_DW_MFMA");   // A/B hook: 0 = always use the register kernel
+        enabled = !(e && e[0] == '0');
+    }
+    if (!enabled) return 0;
+    p.x = (const bf16_t *)x; p.w = w_taps; p.y = (bf16_t *)y;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.dil = d->dil; p.ldx = d->ldx; p.ldy = d->ldy;
+    const int LH = (d->H + d->dil - 1) / d->dil, LW = (d->W + d->dil - 1) / d->dil;
+    p.nty = (LH + TLY - 1) / TLY;
+    p.ntx = (LW + TLX - 1) / TLX;
+    p.ncg = d->C / CG;
+    const long long nitems = (long long)p.nty * p.ntx * d->dil * d->dil;
+    if (nitems <= 0 || nitems > (1 << 24)) return 0;
+    p.nitems = (int)nitems;
+    // one block per CU at a time (LDS): aim at two rounds of blocks over the 256 CUs, but keep >= 3 items per block so
+    // the prefetch has something to overlap with and the per-block set-up (tap table, Toeplitz operands) is amortised
+    const long long groups = (long long)d->N * p.ncg;
+    long long nseg = (512 + groups - 1) / groups;
+    if (nseg > nitems / 3) nseg = nitems / 3;
+    if (nseg < 1) nseg = 1;
+    p.nseg = (int)nseg;
+    const long long blocks = groups * nseg;
+    if (blocks > 0x7fffffffLL || (long long)d->N * d->H * d->W > 0x7fffffffLL) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)dw_mfma_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+            hipSuccess) {
+            kd_set_error("kd_dwconv_fwd: cannot reserve %d B of LDS", LDS_BYTES);
+            return KD_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(dw_mfma_fwd_kernel, dim3((unsigned)blocks), dim3(NT), LDS_BYTES, s, p);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        kd_set_error("kd_dwconv_fwd(mfma): launch failed: %s", hipGetErrorString(err));
+        return KD_ERR_HIP;
+    }
+    return 1;
+}

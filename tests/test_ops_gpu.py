@@ -137,7 +137,9 @@ def test_pw_wgrad(K, dt, shape):
     assert_close(dw.cpu().numpy(), 2 * ref, dt, "pw_wgrad accumulate")
 
 
-DW_CASES = [(2, 24, 32, 16, 9, 20, 5), (1, 8, 8, 16, 3, 1, 1), (1, 23, 37, 72, 9, 20, 5), (2, 6, 50, 8, 9, 20, 5)]
+DW_CASES = [(2, 24, 32, 16, 9, 20, 5), (1, 8, 8, 16, 3, 1, 1), (1, 23, 37, 72, 9, 20, 5), (2, 6, 50, 8, 9, 20, 5),
+            # matrix-core path (bf16, C % 16 == 0): several lattice tiles with real halos, dil 1, ragged last tiles
+            (1, 140, 270, 32, 9, 20, 5), (1, 40, 70, 16, 9, 4, 1), (2, 64, 128, 48, 9, 20, 5)]
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
@@ -154,6 +156,23 @@ def test_dwconv_fwd_dgrad_wgrad(K, dt, case):
     dw = torch.zeros((Cc, 1, k, k), device="cuda")
     K.dwconv_wgrad(dev_nhwc(x, dt), dev_nhwc(gy, dt), dw, k, p, d)
     assert_close(dw.cpu().numpy(), orc.conv2d_wgrad(x, gy, w.shape, pad=p, dil=d, groups=Cc), dt, "dw wgrad")
+
+
+@pytest.mark.parametrize("case", [(2, 24, 32, 16, 5), (1, 131, 261, 32, 5), (1, 30, 60, 16, 2)])
+def test_dwconv_epilogue_bf16(K, case):
+    """bias + res_pre + BN/ReLU mask + res_post through the depthwise epilogue, multi-tile shapes included."""
+    N, H, W, Cc, d = case
+    k, p, dt = 9, 4 * d, "bf16"
+    x, w = q(rnd(N, Cc, H, W), dt), rnd(Cc, 1, k, k, scale=1.0 / k)
+    bias, scale = rnd(Cc), np.abs(rnd(Cc)) + 0.5
+    pre, post = q(rnd(N, Cc, H, W), dt), q(rnd(N, Cc, H, W), dt)
+    act = q(np.maximum(rnd(N, Cc, H, W), 0), dt)
+    y = K.dwconv(dev_nhwc(x, dt, ld=Cc + 16), K.pack_dw_weight(torch.from_numpy(w).cuda()), k, p, d,
+                 bias=torch.from_numpy(bias).cuda(), res_pre=dev_nhwc(pre, dt), mask=dev_nhwc(act, dt),
+                 mask_scale=torch.from_numpy(scale).cuda(), res_post=dev_nhwc(post, dt))
+    ref = orc.conv2d_fwd(x, w, pad=p, dil=d, groups=Cc) + bias[None, :, None, None] + pre
+    ref = np.where(act > 0, ref * scale[None, :, None, None], 0.0) + post
+    assert_close(host_nchw(y), ref, dt, "dw epilogue")
 
 
 def test_dwsep_block_golden(K, golden):

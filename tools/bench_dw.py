@@ -15,17 +15,18 @@ def t(fn, it=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / it
 
-for C in (512, 1024, 4096):
+NB = int(os.environ.get("KDCC_BENCH_BATCH", "2"))
+for C in (512, 1024, 2048, 4096):
     H, W, k, p, d = 128, 256, 9, 20, 5
-    x = torch.randn(1, H, W, C, device="cuda").bfloat16()
-    g = torch.randn(1, H, W, C, device="cuda").bfloat16()
+    x = torch.randn(NB, H, W, C, device="cuda").bfloat16()
+    g = torch.randn(NB, H, W, C, device="cuda").bfloat16()
     w = torch.randn(C, 1, k, k, device="cuda") / k
     wt = ops.pack_dw_weight(w)
     y = torch.empty_like(x)
     dw = torch.empty_like(w)
     ws = torch.empty(ops._lib.lib().kd_dwconv_wgrad_workspace(__import__("ctypes").byref(ops._dw_desc(x, k, p, d))), dtype=torch.uint8, device="cuda")
-    fl = 2.0 * k * k * C * H * W
-    by = 2.0 * 2 * C * H * W
+    fl = 2.0 * k * k * C * H * W * NB
+    by = 2.0 * 2 * C * H * W * NB
     ms = t(lambda: ops.dwconv(x, wt, k, p, d, out=y))
     print(f"dw fwd   C={C:5d}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TFLOP/s  {by/ms/1e6:7.1f} GB/s (algorithmic in+out)")
     ms = t(lambda: ops.dwconv(x, wt, k, p, d, out=y, mask=g, mask_scale=torch.ones(C, device='cuda'), res_post=g))
