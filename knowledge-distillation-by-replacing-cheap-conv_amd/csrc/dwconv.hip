@@ -395,6 +395,9 @@ int check_desc(const kd_dw_desc *d, const char *who)
 int kd_internal_dw_mfma_fwd(const kd_dw_desc *d, const void *x, const float *w_taps, const float *bias,
                             const kd_dw_epilogue *ep, void *y, hipStream_t s);
 
+int kd_internal_dw_mfma_wgrad_slabs(const kd_dw_desc *d);
+int kd_internal_dw_mfma_wgrad(const kd_dw_desc *d, const void *x, const void *dy, int ld_dy, float *part, hipStream_t s);
+
 extern "C" int kd_pack_dw_weight(const float *src, float *dst, int32_t C, int32_t k, int32_t flip, kd_stream_t stream)
 {
     KD_REQUIRE(src && dst && C > 0 && k > 0, KD_ERR_INVALID, "kd_pack_dw_weight: bad argument");
@@ -469,7 +472,8 @@ static int wgrad_slabs(const kd_dw_desc *d)
 extern "C" size_t kd_dwconv_wgrad_workspace(const kd_dw_desc *d)
 {
     if (!d || d->dil < 1) return 0;
-    return (size_t)wgrad_slabs(d) * d->k * d->k * d->C * sizeof(float);
+    const int slabs = wgrad_slabs(d), mslabs = kd_internal_dw_mfma_wgrad_slabs(d);
+    return (size_t)(slabs > mslabs ? slabs : mslabs) * d->k * d->k * d->C * sizeof(float);
 }
 
 extern "C" int kd_dwconv_wgrad(const kd_dw_desc *d, const void *x, const void *dy, int32_t ld_dy, float *dw,
@@ -483,6 +487,18 @@ extern "C" int kd_dwconv_wgrad(const kd_dw_desc *d, const void *x, const void *d
     KD_REQUIRE(((uintptr_t)x % (4 * es)) == 0 && ((uintptr_t)dy % (4 * es)) == 0, KD_ERR_INVALID,
                "kd_dwconv_wgrad: x/dy must be aligned to 4 elements");
     KD_REQUIRE(workspace_bytes >= kd_dwconv_wgrad_workspace(d), KD_ERR_WORKSPACE, "kd_dwconv_wgrad: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    {
+        const int took = kd_internal_dw_mfma_wgrad(d, x, dy, ld_dy, (float *)workspace, s);
+        if (took < 0) return took;
+        if (took) {
+            const int total = d->k * d->k * d->C;
+            hipLaunchKernelGGL(dw_slab_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, (const float *)workspace, dw,
+                               kd_internal_dw_mfma_wgrad_slabs(d), d->k * d->k, d->C, accumulate);
+            KD_CHECK_LAUNCH("kd_dwconv_wgrad(reduce)");
+            return KD_OK;
+        }
+    }
     DwWgradParams p;
     p.x = x; p.dy = dy; p.part = (float *)workspace;
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.pad = d->pad; p.dil = d->dil; p.ldx = d->ldx; p.ld_dy = ld_dy;
@@ -492,7 +508,6 @@ extern "C" int kd_dwconv_wgrad(const kd_dw_desc *d, const void *x, const void *d
     const int slabs = wgrad_slabs(d);
     p.nslabs = slabs;
     const dim3 grid((unsigned)(slabs * ((d->C + CB - 1) / CB) * d->k));
-    hipStream_t s = (hipStream_t)stream;
     if (d->dtype == KD_BF16) {
         if (d->k == 9) hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16_t, 9>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16_t, 3>), grid, dim3(256), 0, s, p);

@@ -295,6 +295,197 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
     }
 }
 
+// ---- weight gradient -----------------------------------------------------------------------------------------------------
+// dW[ky][kx] = sum_{ly,lx} g[ly][lx] * x[ly + ky - 4][lx + kx - 4] on every residue lattice.  One MFMA per (staged x
+// row R, block of 32 lattice columns, channel):
+//   A[i = kx][k] = x[R][cb + k + kx]      (a Hankel band of the x row: 8 consecutive elements from a 2-B-granular start,
+//                                          fetched as 5 aligned dwords and funnel-shifted by 0 or 16 bits per lane)
+//   B[k][j]      = g[R - 8 + j][cb + k]   (16 lattice rows of g, plain 16-B fragment reads; rows outside the tile -> 0)
+//   D[kx][j]    += ...                    = dW[ky = 8 - j][kx] for j = 0..8, summed over every R, column block, tile,
+// residue class and image the block sees: one 16x16 accumulator per channel for the whole block (31 % of its MACs are
+// useful).  x and g tiles are staged like the forward kernel's X (same transposed layout, g without halo); the next
+// item's loads are spread over the row loop and land in the same LDS buffers after the MFMAs.
+constexpr int GBYTES = (TLY * RSTR + 64 + 15) & ~15;
+constexpr int WG_LDS = XBYTES + GBYTES;
+constexpr int GUNITS = TLY * 32 * 2, NIG = (GUNITS + NT - 1) / NT;
+static_assert(NIG == 4, "interleaved fetch below is written for 4 g units per thread");
+
+struct DwWgMfmaParams {
+    const bf16_t *x, *g;
+    float *part;         // [slab][81][C]
+    int N, H, W, C, dil, ldx, ldg;
+    int nty, ntx, ncg;
+    int nitems, nseg;
+};
+
+struct StagedG {
+    uint4 a[NIG], b[NIG];
+    uint32_t ok[NIG];
+};
+
+__device__ __forceinline__ void fetch_unit_g(int it, const DwWgMfmaParams &p, const bf16_t *gb, const Item &w, int tid,
+                                             StagedG &s)
+{
+    const int d = p.dil;
+    const int unit = min(tid + it * NT, GUNITS - 1);
+    const int h = unit & 1, lp = (unit >> 1) & 31, r = unit >> 6;
+    const int ly = w.ty * TLY + r, lx = w.tx * TLX + 2 * lp;
+    const int yy = w.ry + d * ly, xa = w.rx + d * lx, xb2 = xa + d;
+    // cells past this tile's valid outputs belong to another tile (or to no pixel): zero
+    const bool rok = r < w.RV && yy < p.H;
+    const bool aok = rok && 2 * lp < w.CV && xa < p.W, bok = rok && 2 * lp + 1 < w.CV && xb2 < p.W;
+    const bf16_t *row = gb + (size_t)min(yy, p.H - 1) * p.W * p.ldg + h * 8;
+    s.a[it] = *(const uint4 *)(row + (size_t)min(xa, p.W - 1) * p.ldg);
+    s.b[it] = *(const uint4 *)(row + (size_t)min(xb2, p.W - 1) * p.ldg);
+    s.ok[it] = (aok ? 0x0000ffffu : 0u) | (bok ? 0xffff0000u : 0u);
+}
+
+__device__ __forceinline__ void write_item_g(char *G, int tid, const StagedG &s)
+{
+    for (int e = tid; e < TLY * 8 + 16; e += NT) {
+        const int r = e >> 3;
+        if (r < TLY) *(uint32_t *)(G + r * RSTR + CG * CSTR + (e & 7) * 4) = 0u;
+        else *(uint32_t *)(G + TLY * RSTR + (e - TLY * 8) * 4) = 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < NIG; ++it) {
+        const int unit = tid + it * NT;
+        if (unit < GUNITS) {
+            const int h = unit & 1, lp = (unit >> 1) & 31, r = unit >> 6;
+            char *dst = G + r * RSTR + (h * 8) * CSTR + lp * 4;
+            const uint32_t a[4] = {s.a[it].x, s.a[it].y, s.a[it].z, s.a[it].w};
+            const uint32_t b[4] = {s.b[it].x, s.b[it].y, s.b[it].z, s.b[it].w};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                *(uint32_t *)(dst + (2 * m) * CSTR) = ((a[m] & 0xffffu) | (b[m] << 16)) & s.ok[it];
+                *(uint32_t *)(dst + (2 * m + 1) * CSTR) = ((a[m] >> 16) | (b[m] & 0xffff0000u)) & s.ok[it];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT, 1) void dw_mfma_wgrad_kernel(DwWgMfmaParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *const Xx = smem, *const Xg = smem + XBYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int cgi = lin % p.ncg; lin /= p.ncg;
+    const int seg = lin % p.nseg;
+    const int n = lin / p.nseg;
+    const int c0 = cgi * CG;
+    const int ibeg = (int)((long long)p.nitems * seg / p.nseg), iend = (int)((long long)p.nitems * (seg + 1) / p.nseg);
+    const bf16_t *xb = p.x + (size_t)n * p.H * p.W * p.ldx + c0;
+    const bf16_t *gb = p.g + (size_t)n * p.H * p.W * p.ldg + c0;
+    // the forward kernel's fetch helpers take its parameter block: only the geometry and ldx are read
+    DwMfmaParams px;
+    px.H = p.H; px.W = p.W; px.dil = p.dil; px.ldx = p.ldx; px.ntx = p.ntx;
+
+    const int fi = lane & 15, kg = lane >> 4;
+    f32x4_t acc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+
+    int cur = ibeg;
+    Item wi = decode_item(px, cur < iend ? cur : 0);
+    while (cur < iend && (wi.RV <= 0 || wi.CV <= 0)) { ++cur; if (cur < iend) wi = decode_item(px, cur); }
+    if (cur < iend) {
+        Staged sx;
+        StagedG sg;
+        fetch_item(px, xb, wi, tid, sx);
+#pragma unroll
+        for (int it = 0; it < NIG; ++it) fetch_unit_g(it, p, gb, wi, tid, sg);
+        write_item(Xx, tid, sx);
+        write_item_g(Xg, tid, sg);
+        __syncthreads();
+
+        const int kxl = min(fi, 8);                       // A row i = kx (rows 9..15 duplicate row 8, discarded)
+        const uint32_t sh = (kxl & 1) ? 16u : 0u;
+        const int aoff = (kg * 8 + (kxl & ~1)) * 2;       // dword-aligned start of this lane's Hankel window
+        while (true) {
+            int nxt = cur + 1;
+            Item wn = wi;
+            if (nxt < iend) wn = decode_item(px, nxt);
+            while (nxt < iend && (wn.RV <= 0 || wn.CV <= 0)) { ++nxt; if (nxt < iend) wn = decode_item(px, nxt); }
+            const bool more = nxt < iend;
+
+            const int RV = wi.RV, ncb = wi.CV > 32 ? 2 : 1;
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const char *xc = Xx + (wave * 2 + cc) * CSTR + aoff;
+                const char *gc = Xg + (wave * 2 + cc) * CSTR + kg * 16;
+#pragma unroll 2
+                for (int R = 0; R < RV + 8; ++R) {
+                    if (cc == 0 && more && (R & 3) == 0) {   // next item's loads, one unit every four rows
+                        switch (R >> 2) {
+                        case 0: fetch_unit(0, px, xb, wn, tid, sx); break;
+                        case 1: fetch_unit(1, px, xb, wn, tid, sx); break;
+                        case 2: fetch_unit(2, px, xb, wn, tid, sx); break;
+                        case 3: fetch_unit(3, px, xb, wn, tid, sx); break;
+                        case 4: fetch_unit(4, px, xb, wn, tid, sx); break;
+                        case 5: fetch_unit_g(0, p, gb, wn, tid, sg); break;
+                        case 6: fetch_unit_g(1, p, gb, wn, tid, sg); break;
+                        case 7: fetch_unit_g(2, p, gb, wn, tid, sg); break;
+                        default: fetch_unit_g(3, p, gb, wn, tid, sg); break;
+                        }
+                    }
+                    const int ly = R - 8 + fi;
+                    const bool gok = ly >= 0 && ly < RV;
+                    const char *gr = gc + min(max(ly, 0), TLY - 1) * RSTR;
+                    const char *xr = xc + R * RSTR;
+                    for (int cb = 0; cb < ncb; ++cb) {
+                        const uint32_t *xw = (const uint32_t *)(xr + cb * 64);
+                        const uint32_t d0 = xw[0], d1 = xw[1], d2 = xw[2], d3 = xw[3], d4 = xw[4];
+                        uint4 b = *(const uint4 *)(gr + cb * 64);
+                        if (!gok) b = make_uint4(0u, 0u, 0u, 0u);
+                        const uint4 a = make_uint4(__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh),
+                                                   __builtin_amdgcn_alignbit(d3, d2, sh), __builtin_amdgcn_alignbit(d4, d3, sh));
+                        Mma<bf16_t>::run(a, b, acc[cc]);
+                    }
+                }
+            }
+            if (!more) break;
+            if (wi.RV + 8 <= 32) {   // short tiles: the row loop did not reach every fetch slot
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+                    if (it * 4 >= wi.RV + 8) fetch_unit(it, px, xb, wn, tid, sx);
+#pragma unroll
+                for (int it = 0; it < NIG; ++it)
+                    if ((NIT + it) * 4 >= wi.RV + 8) fetch_unit_g(it, p, gb, wn, tid, sg);
+            }
+            __syncthreads();   // every wave is done reading the tiles
+            write_item(Xx, tid, sx);
+            write_item_g(Xg, tid, sg);
+            __syncthreads();
+            cur = nxt;
+            wi = wn;
+        }
+    }
+    // D[kx = 4*kg + r][j = fi] -> part[slab][ky = 8 - fi][kx][channel]
+    float *part = p.part + (size_t)(n * p.nseg + seg) * 81 * p.C + c0 + wave * 2;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kx = kg * 4 + r;
+            if (kx < 9 && fi < 9) part[(size_t)((8 - fi) * 9 + kx) * p.C + cc] = acc[cc][r];
+        }
+}
+
+static void dw_mfma_split(int N, int C, int H, int W, int dil, int *nty, int *ntx, int *nitems, int *nseg)
+{
+    const int LH = (H + dil - 1) / dil, LW = (W + dil - 1) / dil;
+    *nty = (LH + TLY - 1) / TLY;
+    *ntx = (LW + TLX - 1) / TLX;
+    const long long ni = (long long)*nty * *ntx * dil * dil;
+    *nitems = ni > (1 << 24) ? 0 : (int)ni;
+    // one block per CU at a time (LDS): aim at two rounds of blocks over the 256 CUs, but keep >= 3 items per block so
+    // the prefetch has something to overlap with and the per-block set-up is amortised
+    const long long groups = (long long)N * (C / CG);
+    long long s = (512 + groups - 1) / groups;
+    if (s > ni / 3) s = ni / 3;
+    if (s < 1) s = 1;
+    *nseg = (int)s;
+}
+
 }  // namespace
 
 // Returns 1 if the MFMA path took the call, 0 if the shape is not eligible (caller falls back to the register kernel),
@@ -317,21 +508,10 @@ int kd_internal_dw_mfma_fwd(const kd_dw_desc *d, const void *x, const float *w_t
     if (!enabled) return 0;
     p.x = (const bf16_t *)x; p.w = w_taps; p.y = (bf16_t *)y;
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.dil = d->dil; p.ldx = d->ldx; p.ldy = d->ldy;
-    const int LH = (d->H + d->dil - 1) / d->dil, LW = (d->W + d->dil - 1) / d->dil;
-    p.nty = (LH + TLY - 1) / TLY;
-    p.ntx = (LW + TLX - 1) / TLX;
+    dw_mfma_split(d->N, d->C, d->H, d->W, d->dil, &p.nty, &p.ntx, &p.nitems, &p.nseg);
     p.ncg = d->C / CG;
-    const long long nitems = (long long)p.nty * p.ntx * d->dil * d->dil;
-    if (nitems <= 0 || nitems > (1 << 24)) return 0;
-    p.nitems = (int)nitems;
-    // one block per CU at a time (LDS): aim at two rounds of blocks over the 256 CUs, but keep >= 3 items per block so
-    // the prefetch has something to overlap with and the per-block set-up (tap table, Toeplitz operands) is amortised
-    const long long groups = (long long)d->N * p.ncg;
-    long long nseg = (512 + groups - 1) / groups;
-    if (nseg > nitems / 3) nseg = nitems / 3;
-    if (nseg < 1) nseg = 1;
-    p.nseg = (int)nseg;
-    const long long blocks = groups * nseg;
+    if (p.nitems <= 0) return 0;
+    const long long blocks = (long long)d->N * p.ncg * p.nseg;
     if (blocks > 0x7fffffffLL || (long long)d->N * d->H * d->W > 0x7fffffffLL) return 0;
     static bool attr_set = false;
     if (!attr_set) {
@@ -346,6 +526,58 @@ int kd_internal_dw_mfma_fwd(const kd_dw_desc *d, const void *x, const float *w_t
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
         kd_set_error("kd_dwconv_fwd(mfma): launch failed: %s", hipGetErrorString(err));
+        return KD_ERR_HIP;
+    }
+    return 1;
+}
+
+static bool dw_mfma_wgrad_eligible(const kd_dw_desc *d, const void *x, const void *dy, int ld_dy)
+{
+    if (d->dtype != KD_BF16 || d->k != 9 || d->C % CG != 0 || d->ldx % 8 != 0 || ld_dy % 8 != 0) return false;
+    if ((x && !kd_aligned16(x)) || (dy && !kd_aligned16(dy))) return false;
+    if ((long long)d->N * d->H * d->W > 0x7fffffffLL) return false;
+    static int enabled = -1;
+    if (enabled < 0) {
+        const char *e = getenv("KDCC_DW_MFMA");
+        enabled = !(e && e[0] == '0');
+    }
+    return enabled != 0;
+}
+
+// Slabs of [81][C] fp32 partial sums the MFMA weight-gradient path writes (0 = path not eligible).
+int kd_internal_dw_mfma_wgrad_slabs(const kd_dw_desc *d)
+{
+    if (!dw_mfma_wgrad_eligible(d, nullptr, nullptr, 8)) return 0;
+    int nty, ntx, nitems, nseg;
+    dw_mfma_split(d->N, d->C, d->H, d->W, d->dil, &nty, &ntx, &nitems, &nseg);
+    return nitems > 0 ? d->N * nseg : 0;
+}
+
+// 1 = partial sums written to `part` (caller reduces the slabs), 0 = not eligible, < 0 = error.
+int kd_internal_dw_mfma_wgrad(const kd_dw_desc *d, const void *x, const void *dy, int ld_dy, float *part, hipStream_t s)
+{
+    if (!dw_mfma_wgrad_eligible(d, x, dy, ld_dy)) return 0;
+    DwWgMfmaParams p;
+    p.x = (const bf16_t *)x; p.g = (const bf16_t *)dy; p.part = part;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.dil = d->dil; p.ldx = d->ldx; p.ldg = ld_dy;
+    dw_mfma_split(d->N, d->C, d->H, d->W, d->dil, &p.nty, &p.ntx, &p.nitems, &p.nseg);
+    p.ncg = d->C / CG;
+    if (p.nitems <= 0) return 0;
+    const long long blocks = (long long)d->N * p.ncg * p.nseg;
+    if (blocks > 0x7fffffffLL) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)dw_mfma_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS) !=
+            hipSuccess) {
+            kd_set_error("kd_dwconv_wgrad: cannot reserve %d B of LDS", WG_LDS);
+            return KD_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(dw_mfma_wgrad_kernel, dim3((unsigned)blocks), dim3(NT), WG_LDS, s, p);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        kd_set_error("kd_dwconv_wgrad(mfma): launch failed: %s", hipGetErrorString(err));
         return KD_ERR_HIP;
     }
     return 1;
