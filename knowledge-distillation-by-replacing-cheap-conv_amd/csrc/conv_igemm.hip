@@ -22,14 +22,17 @@ constexpr int EP_LD = 68;                   // floats per epilogue row (64 + pad
 
 // Tile configurations (8 waves = 512 threads, one workgroup per CU, two waves per SIMD):
 //   CfgWide   256(M) x 256(N), waves 2x4 of 128x64, K stage = 128 B per row, two stages (128 KiB LDS)  -- Cout > 128
-//   CfgNarrow 256(M) x 128(N), waves 4x2 of 64x64,  K stage = 128 B per row, three stages (144 KiB)    -- Cout <= 128
+//   CfgNarrow2 256(M) x 128(N), waves 4x2 of 64x64, K stage = 64 B per row, three stages (72 KiB), two workgroups per
+//             CU so one tile's epilogue / pipeline fill overlaps the other's main loop                  -- Cout <= 128
+//             (short-K layers: mod2 3x3 128->128 625 -> 739 TFLOP/s, bot_fine / classifier 1x1 +36..44 % over CfgNarrow)
+//   CfgNarrow 256 x 128, K stage = 128 B, three stages (144 KiB), one workgroup per CU: A/B only (KDCC_CONV_CFG=narrow1)
 //   CfgDeep   256 x 256 with 64-B K stages, four resident (three in flight): measured SLOWER than CfgWide (878 vs 944
 //             TFLOP/s over the student's shapes) -- prefetch depth is not the limiter; kept for A/B runs only.
 // Measured anatomy of CfgWide on the 512/1024-channel 3x3 layers (tools/bench_conv.py ablations): MFMA + LDS fragment
 // reads alone 1.5-1.7 PFLOP/s; + the LDS-DMA instruction stream hitting one cached page 1.4; + real L2 traffic 1.1.
 // So the staging traffic (both operands) costs ~22 %, its issue ~9 %; wide tiles cut that traffic 1.5x vs 128-wide.
-template <int MI_, int WM_, int WN_, int NST_, int RB_> struct Cfg {
-    static constexpr int MI = MI_, WM = WM_, WN = WN_, NST = NST_, RB = RB_;
+template <int MI_, int WM_, int WN_, int NST_, int RB_, int WPE_ = 2> struct Cfg {
+    static constexpr int MI = MI_, WM = WM_, WN = WN_, NST = NST_, RB = RB_, WPE = WPE_;   // WPE: waves per SIMD to compile for
     static constexpr int BM = WM * MI * 16, BN = WN * 64;
     static constexpr int STAGE_A = BM * RB, STAGE_B = BN * RB, STAGE = STAGE_A + STAGE_B;
     static constexpr int PR = 1024 / RB;                        // rows per 1-KiB LDS-DMA piece
@@ -42,6 +45,7 @@ template <int MI_, int WM_, int WN_, int NST_, int RB_> struct Cfg {
 typedef Cfg<4, 4, 2, 3, 128> CfgNarrow;
 typedef Cfg<8, 2, 4, 2, 128> CfgWide;
 typedef Cfg<8, 2, 4, 4, 64> CfgDeep;     // A/B runs only: KDCC_CONV_CFG=deep
+typedef Cfg<4, 4, 2, 3, 64, 4> CfgNarrow2;   // 256 x 128 with 64-B K stages, 72 KiB, <= 128 VGPRs: two workgroups per CU
 
 __device__ __attribute__((aligned(256))) uint32_t kd_zero_page[64];  // zero-initialised
 
@@ -78,7 +82,7 @@ __device__ __forceinline__ void st8_guard(U *p, int valid, bool vec, const float
 }
 
 template <typename T, typename CF>
-__global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvParams p)
+__global__ __launch_bounds__(512, CF::WPE) void conv_igemm_kernel(const ConvParams p)
 {
     // One LDS array: the DMA is issued through inline asm, so hipcc sees only the fragment reads and inserts no waits.
     __shared__ __attribute__((aligned(16))) char lds[CF::LDS_BYTES];
@@ -333,10 +337,11 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
     // wide tiles only when they still fill the chip (one workgroup per CU, 256 CUs); e.g. the ASPP 4096->256 1x1 at
     // 128x256 pixels would give 128 wide tiles, so it runs on the narrow config (256 tiles)
     const long long wide_tiles = (long long)((p.M + CfgWide::BM - 1) / CfgWide::BM) * ((d->Cout + CfgWide::BN - 1) / CfgWide::BN);
-    int cfg = (d->Cout > 128 && wide_tiles >= 224) ? 1 : 0;   // 0 narrow, 1 wide, 2 deep
+    int cfg = (d->Cout > 128 && wide_tiles >= 224) ? 1 : 0;   // 0 narrow2, 1 wide, 2 deep, 3 narrow (one workgroup per CU)
     if (const char *e = getenv("KDCC_CONV_CFG")) {              // tuning hook
         if (!strcmp(e, "narrow")) cfg = 0;
         else if (!strcmp(e, "deep") && cfg == 1) cfg = 2;
+        else if (!strcmp(e, "narrow1") && cfg == 0) cfg = 3;
     }
     hipStream_t s = (hipStream_t)stream;
     auto launch = [&](auto cf, auto tag) {
@@ -352,11 +357,12 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
     if (d->dtype == KD_BF16) {
         if (cfg == 1) launch(CfgWide{}, bf16_t{});
         else if (cfg == 2) launch(CfgDeep{}, bf16_t{});
-        else launch(CfgNarrow{}, bf16_t{});
+        else if (cfg == 3) launch(CfgNarrow{}, bf16_t{});
+        else launch(CfgNarrow2{}, bf16_t{});
     } else {
         if (cfg == 1) launch(CfgWide{}, float{});
         else if (cfg == 2) launch(CfgDeep{}, float{});
-        else launch(CfgNarrow{}, float{});
+        else launch(CfgNarrow{}, float{});   // fp32 parity path: its blocked accumulation does not fit 128 VGPRs
     }
     KD_CHECK_LAUNCH("kd_conv2d_fwd");
     return KD_OK;

@@ -35,11 +35,11 @@ def main():
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     tot_f, tot_t = 0.0, 0.0
     for name, H, W, Cin, Cout, k, s, d, cnt in SHAPES:
-        x = torch.randn(1, H, W, Cin, device="cuda").to(dt)
+        NB = int(os.environ.get("KDCC_BENCH_BATCH", "2")); x = torch.randn(NB, H, W, Cin, device="cuda").to(dt)
         w = (torch.randn(Cout, k, k, Cin, device="cuda") * 0.05).to(dt)
         pad = d * (k - 1) // 2
         Ho, Wo = ops.conv_out_size(H, k, s, pad, d), ops.conv_out_size(W, k, s, pad, d)
-        out = torch.empty(1, Ho, Wo, Cout, device="cuda", dtype=dt)
+        out = torch.empty(NB, Ho, Wo, Cout, device="cuda", dtype=dt)
         sc = torch.ones(Cout, device="cuda"); sh = torch.zeros(Cout, device="cuda")
         for _ in range(2): ops.conv2d(x, w, s, pad, d, out_act=out, act_scale=sc, act_shift=sh, act_relu=True)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -47,7 +47,7 @@ def main():
         for _ in range(a.iters): ops.conv2d(x, w, s, pad, d, out_act=out, act_scale=sc, act_shift=sh, act_relu=True)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
-        fl = 2.0 * Ho * Wo * Cout * k * k * Cin
+        fl = 2.0 * NB * Ho * Wo * Cout * k * k * Cin
         tot_f += fl * cnt; tot_t += ms * cnt
         print(f"{name:26s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s   x{cnt}")
     print(f"weighted total {tot_t:.2f} ms for {tot_f / 1e12:.2f} TFLOP -> {tot_f / tot_t / 1e9:.1f} TFLOP/s")
