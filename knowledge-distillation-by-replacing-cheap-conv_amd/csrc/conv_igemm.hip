@@ -81,6 +81,88 @@ __device__ __forceinline__ void st8_guard(U *p, int valid, bool vec, const float
     }
 }
 
+// ---- epilogue: accumulators -> per-wave LDS patch -> 8-channel vector rows (shared by both main loops) -----------------
+template <typename T, int MI>
+__device__ __forceinline__ void ig_epilogue(const ConvParams &p, char *lds, f32x4_t (&acc)[MI][4], int m0, int n0, int wm,
+                                            int wn, int wv, int lane)
+{
+    const int frow = lane & 15, fq = lane >> 4;
+    const kd_conv_epilogue &e = p.ep;
+    const int cg = (lane & 7) * 8;
+    const int c0 = n0 + wn * 64 + cg;
+    const int valid = p.Cout - c0 >= 8 ? 8 : (p.Cout - c0 > 0 ? p.Cout - c0 : 0);
+    const bool vec = p.vec_ok != 0;
+
+    float mscale[8], ascale[8], ashift[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const bool ok = q < valid;
+        mscale[q] = (e.mask_scale && ok) ? e.mask_scale[c0 + q] : 1.f;
+        ascale[q] = (e.act_scale && ok) ? e.act_scale[c0 + q] : 1.f;
+        ashift[q] = (e.act_shift && ok) ? e.act_shift[c0 + q] : 0.f;
+    }
+
+    // each wave owns a private 32 x 64 fp32 patch inside the (now idle) stage buffers, 32 rows of its sub-tile in turn
+    constexpr int PATCH = 32 * EP_LD * 4;
+    float *ep = (float *)(lds + wv * PATCH);
+#pragma unroll
+    for (int half = 0; half < MI / 2; ++half) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ep[(i * 16 + fq * 4 + r) * EP_LD + j * 16 + frow] = acc[half * 2 + i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+#pragma unroll 1
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 8 + (lane >> 3);
+            const int m = m0 + wm * (16 * MI) + half * 32 + row;
+            if (m >= p.M || valid == 0) continue;
+            float v[8];
+            {
+                const float4 lo = *(const float4 *)(ep + row * EP_LD + cg);
+                const float4 hi = *(const float4 *)(ep + row * EP_LD + cg + 4);
+                v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            }
+            float t[8];
+            if (e.res_pre) {
+                ld8_guard((const T *)e.res_pre + (size_t)m * e.ld_res_pre + c0, valid, vec, t);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += t[q];
+            }
+            if (e.mask) {
+                ld8_guard((const T *)e.mask + (size_t)m * e.ld_mask + c0, valid, vec, t);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = t[q] > 0.f ? v[q] * mscale[q] : 0.f;
+            }
+            if (e.res_post) {
+                ld8_guard((const T *)e.res_post + (size_t)m * e.ld_res_post + c0, valid, vec, t);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += t[q];
+            }
+            if (e.out_raw) {
+                if (e.raw_f32) st8_guard((float *)e.out_raw + (size_t)m * e.ld_raw + c0, valid, vec, v);
+                else st8_guard((T *)e.out_raw + (size_t)m * e.ld_raw + c0, valid, vec, v);
+            }
+            if (e.out_act) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float a = v[q] * ascale[q] + ashift[q];
+                    t[q] = e.act_relu ? fmaxf(a, 0.f) : a;
+                }
+                st8_guard((T *)e.out_act + (size_t)m * e.ld_act + c0, valid, vec, t);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 template <typename T, typename CF>
 __global__ __launch_bounds__(512, CF::WPE) void conv_igemm_kernel(const ConvParams p)
 {
@@ -192,81 +274,164 @@ __global__ __launch_bounds__(512, CF::WPE) void conv_igemm_kernel(const ConvPara
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();  // every wave is done reading the stage buffers
 
-    // ---- epilogue ---------------------------------------------------------------------
-    const kd_conv_epilogue &e = p.ep;
-    const int cg = (lane & 7) * 8;
-    const int c0 = n0 + wn * 64 + cg;
-    const int valid = p.Cout - c0 >= 8 ? 8 : (p.Cout - c0 > 0 ? p.Cout - c0 : 0);
-    const bool vec = p.vec_ok != 0;
+    ig_epilogue<T, MI>(p, lds, acc, m0, n0, wm, wn, wv, lane);
+}
 
-    float mscale[8], ascale[8], ashift[8];
+// ---- 3x3 / stride 1 / 'same' convolutions whose 256-pixel tiles are segments of one image row -----------------------------
+// The im2col gather stages the A tile once per tap: the three kx taps of a kernel row re-read the same image row shifted by
+// +-dil pixels, so two thirds of the A traffic (L2 -> LDS bytes, DMA instructions, LDS writes) is redundant.  Here the A
+// operand is a ROW BUFFER: per (channel block, ky) one segment of 256 + 2*dil pixels (halo included, zero outside the
+// image) is staged once, and the three kx stages read their fragments from it at row offsets kx*dil; the XOR swizzle is
+// keyed on the buffer row, so the shifted reads stay bank-conflict free.  The B tile is staged per tap as before.
+// Kernel rows that fall outside the image contribute nothing and are skipped for the whole tile.
+// LDS: 2 x 40 KiB row buffers (320 rows: dil <= 32) + 2 x 32 KiB B stages = 144 KiB.
+struct CfgRow {
+    static constexpr int MI = 8, WM = 2, WN = 4, RB = 128;
+    static constexpr int BM = 256, BN = 256;
+    static constexpr int AROWS = 320, ABUF = AROWS * RB, BSTAGE = BN * RB;
+    static constexpr int GAR = AROWS / 8 / 8;      // 1-KiB pieces per wave per row buffer
+    static constexpr int GB = BN / 8 / 8;          // ... per B stage
+    static constexpr int LDS_BYTES = 2 * ABUF + 2 * BSTAGE;
+    static_assert(8 * 32 * EP_LD * 4 <= LDS_BYTES, "epilogue patches must fit");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv_igemm_row_kernel(const ConvParams p)
+{
+    typedef CfgRow CF;
+    __shared__ __attribute__((aligned(16))) char lds[CF::LDS_BYTES];
+    constexpr int ES = sizeof(T), RB = CF::RB, BK = RB / ES, EPC = 16 / ES;
+    constexpr int MI = CF::MI, GAR = CF::GAR, GB = CF::GB;
+    char *const ldsB = lds + 2 * CF::ABUF;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv / CF::WN, wn = wv % CF::WN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+    const int m0 = tm * CF::BM, n0 = tn * CF::BN;
+    const T *__restrict__ xg = (const T *)p.x;
+    const T *__restrict__ wg = (const T *)p.w;
+    const T *zero = (const T *)kd_zero_page;
+    const int d = p.dil;
+
+    // the tile: image n, output row ho, columns x0 .. x0 + 255 (W % 256 == 0, Ho == H, Wo == W)
+    const int n = m0 / p.HoWo, rem = m0 - n * p.HoWo;
+    const int ho = rem / p.W, x0 = rem - ho * p.W;
+    // kernel rows inside the image (block-uniform)
+    const int ky_lo = ho - d < 0 ? 1 : 0, ky_hi = ho + d >= p.H ? 1 : 2;
+    const int nky = ky_hi - ky_lo + 1;
+
+    // ---- per-lane staging state -------------------------------------------------------------------------------------
+    const int srow = lane >> 3;
+    const int chunk = (lane & 7) ^ srow;             // source-side swizzle: LDS slot s of buffer row r holds chunk s ^ (r & 7)
+    int a_off[GAR];                                  // element offset of (n, ho, x) + chunk for the lane's row of piece j
+    uint32_t a_ok = 0;                               // bit j: that pixel is inside the image row and the buffer
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const bool ok = q < valid;
-        mscale[q] = (e.mask_scale && ok) ? e.mask_scale[c0 + q] : 1.f;
-        ascale[q] = (e.act_scale && ok) ? e.act_scale[c0 + q] : 1.f;
-        ashift[q] = (e.act_shift && ok) ? e.act_shift[c0 + q] : 0.f;
+    for (int j = 0; j < GAR; ++j) {
+        const int r = (wv * GAR + j) * 8 + srow;     // buffer row: pixel x0 - d + r
+        const int x = x0 - d + r;
+        const bool ok = r < CF::BM + 2 * d && x >= 0 && x < p.W;
+        a_off[j] = ((n * p.H + ho) * p.W + (ok ? x : 0)) * p.ldx + chunk * EPC;
+        a_ok |= ok ? (1u << j) : 0u;
+    }
+    int b_off[GB];
+#pragma unroll
+    for (int j = 0; j < GB; ++j) {
+        const int nn = n0 + (wv * GB + j) * 8 + srow;
+        b_off[j] = nn < p.Cout ? nn * p.Ktot + chunk * EPC : -1;
     }
 
-    // each wave owns a private 32 x 64 fp32 patch inside the (now idle) stage buffers, 32 rows of its sub-tile in turn
-    constexpr int PATCH = 32 * EP_LD * 4;
-    float *ep = (float *)(lds + wv * PATCH);
+    // stage order: channel block outer, ky, kx inner (taps of one channel block back to back: L2-resident)
+    int u_cb = 0, u_ky = ky_lo, u_idx = 0;           // next row buffer to issue
+    auto stage_a = [&]() {
+        const int row_off = ((u_ky - 1) * d * p.W) * p.ldx + u_cb * BK;
+        char *la = lds + (u_idx & 1) * CF::ABUF + wv * (GAR * 1024);
 #pragma unroll
-    for (int half = 0; half < MI / 2; ++half) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ep[(i * 16 + fq * 4 + r) * EP_LD + j * 16 + frow] = acc[half * 2 + i][j][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-#pragma unroll 1
-        for (int pass = 0; pass < 4; ++pass) {
-            const int row = pass * 8 + (lane >> 3);
-            const int m = m0 + wm * (16 * MI) + half * 32 + row;
-            if (m >= p.M || valid == 0) continue;
-            float v[8];
-            {
-                const float4 lo = *(const float4 *)(ep + row * EP_LD + cg);
-                const float4 hi = *(const float4 *)(ep + row * EP_LD + cg + 4);
-                v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-            }
-            float t[8];
-            if (e.res_pre) {
-                ld8_guard((const T *)e.res_pre + (size_t)m * e.ld_res_pre + c0, valid, vec, t);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] += t[q];
-            }
-            if (e.mask) {
-                ld8_guard((const T *)e.mask + (size_t)m * e.ld_mask + c0, valid, vec, t);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = t[q] > 0.f ? v[q] * mscale[q] : 0.f;
-            }
-            if (e.res_post) {
-                ld8_guard((const T *)e.res_post + (size_t)m * e.ld_res_post + c0, valid, vec, t);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] += t[q];
-            }
-            if (e.out_raw) {
-                if (e.raw_f32) st8_guard((float *)e.out_raw + (size_t)m * e.ld_raw + c0, valid, vec, v);
-                else st8_guard((T *)e.out_raw + (size_t)m * e.ld_raw + c0, valid, vec, v);
-            }
-            if (e.out_act) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float a = v[q] * ascale[q] + ashift[q];
-                    t[q] = e.act_relu ? fmaxf(a, 0.f) : a;
-                }
-                st8_guard((T *)e.out_act + (size_t)m * e.ld_act + c0, valid, vec, t);
-            }
+        for (int j = 0; j < GAR; ++j) {
+            const T *src = ((a_ok >> j) & 1u) ? xg + (a_off[j] + row_off) : zero;
+            glds16(src, la + j * 1024);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        ++u_idx;
+        if (++u_ky > ky_hi) { u_ky = ky_lo; ++u_cb; }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int s_cb = 0, s_ky = ky_lo, s_kx = 0, s_idx = 0; // next B stage to issue
+    auto stage_b = [&]() {
+        const int w_off = (s_ky * 3 + s_kx) * p.Cin + s_cb * BK;
+        char *lb = ldsB + (s_idx & 1) * CF::BSTAGE + wv * (GB * 1024);
+#pragma unroll
+        for (int j = 0; j < GB; ++j) {
+            const T *src = b_off[j] >= 0 ? wg + (b_off[j] + w_off) : zero;
+            glds16(src, lb + j * 1024);
+        }
+        ++s_idx;
+        if (++s_kx == 3) {
+            s_kx = 0;
+            if (++s_ky > ky_hi) { s_ky = ky_lo; ++s_cb; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    f32x4_t acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    const int nu = p.nkc * nky, ns = nu * 3;
+    stage_a();
+    stage_b();
+    wait_vm_barrier<0>();
+#pragma unroll 1
+    for (int u = 0; u < nu; ++u) {
+        const char *Au = lds + (u & 1) * CF::ABUF;
+#pragma unroll 1
+        for (int kx = 0; kx < 3; ++kx) {
+            const int s = u * 3 + kx;
+            // the other row buffer was last read in the previous super-stage, which every wave left at a barrier
+            if (kx == 0 && u + 1 < nu) stage_a();
+            if (s + 1 < ns) stage_b();
+            // fragments: A rows shifted by kx*dil inside the row buffer, B from the per-tap stage
+            const int rsh = frow + kx * d;
+            const char *A = Au + (wm * 128 + rsh) * RB;
+            const char *B = ldsB + (s & 1) * CF::BSTAGE + (wn * 64 + frow) * RB;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int swa = ((fq + 4 * ks) ^ (rsh & 7)) << 4, swb = ((fq + 4 * ks) ^ (lane & 7)) << 4;
+                uint4 a[MI], b[4];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i] = *(const uint4 *)(A + i * 16 * RB + swa);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = *(const uint4 *)(B + j * 16 * RB + swb);
+                if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        f32x4_t part[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            part[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                            Mma<T>::run(a[i], b[j], part[j]);
+                            acc[i][j] += part[j];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, MI + 4, 0);
+                if constexpr (sizeof(T) != 4) __builtin_amdgcn_sched_group_barrier(0x008, MI * 4, 0);
+            }
+            if (s + 1 < ns) wait_vm_barrier<0>();
+        }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();  // every wave is done reading the buffers
+    ig_epilogue<T, MI>(p, lds, acc, m0, n0, wm, wn, wv, lane);
 }
 
 // ---- weight packing ------------------------------------------------------------------
@@ -337,9 +502,11 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
     // wide tiles only when they still fill the chip (one workgroup per CU, 256 CUs); e.g. the ASPP 4096->256 1x1 at
     // 128x256 pixels would give 128 wide tiles, so it runs on the narrow config (256 tiles)
     const long long wide_tiles = (long long)((p.M + CfgWide::BM - 1) / CfgWide::BM) * ((d->Cout + CfgWide::BN - 1) / CfgWide::BN);
+    bool norow = false;
     int cfg = (d->Cout > 128 && wide_tiles >= 224) ? 1 : 0;   // 0 narrow2, 1 wide, 2 deep, 3 narrow (one workgroup per CU)
     if (const char *e = getenv("KDCC_CONV_CFG")) {              // tuning hook
         if (!strcmp(e, "narrow")) cfg = 0;
+        else if (!strcmp(e, "norow")) norow = true;
         else if (!strcmp(e, "deep") && cfg == 1) cfg = 2;
         else if (!strcmp(e, "narrow1") && cfg == 0) cfg = 3;
     }
@@ -354,7 +521,19 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         const int tiles_m = (p.M + CF::BM - 1) / CF::BM;
         hipLaunchKernelGGL((conv_igemm_kernel<T, CF>), dim3((unsigned)(tiles_m * p.tiles_n)), dim3(512), 0, s, p);
     };
-    if (d->dtype == KD_BF16) {
+    // wide tiles that are segments of one image row, 3x3 / stride 1 / 'same': row-buffer kernel
+    const bool row_ok = cfg == 1 && !norow && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == d->dil && d->dil <= 32 &&
+                        d->W % CfgRow::BM == 0;
+    if (row_ok) {
+        p.nkc = d->Cin / (128 / es);
+        p.nk = 9 * p.nkc;
+        p.tiles_n = (d->Cout + CfgRow::BN - 1) / CfgRow::BN;
+        const int tiles_m = p.M / CfgRow::BM;
+        if (d->dtype == KD_BF16)
+            hipLaunchKernelGGL(conv_igemm_row_kernel<bf16_t>, dim3((unsigned)(tiles_m * p.tiles_n)), dim3(512), 0, s, p);
+        else
+            hipLaunchKernelGGL(conv_igemm_row_kernel<float>, dim3((unsigned)(tiles_m * p.tiles_n)), dim3(512), 0, s, p);
+    } else if (d->dtype == KD_BF16) {
         if (cfg == 1) launch(CfgWide{}, bf16_t{});
         else if (cfg == 2) launch(CfgDeep{}, bf16_t{});
         else if (cfg == 3) launch(CfgNarrow{}, bf16_t{});

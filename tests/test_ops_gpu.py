@@ -64,6 +64,10 @@ CONV_CASES = [
     (1, 16, 16, 64, 128, 3, 2, 1, 1),    # stride 2 (mod4.block1)
     (1, 10, 12, 128, 19, 3, 1, 4, 4),    # odd Cout (classifier-like), dilation 4
     (1, 6, 8, 320, 48, 1, 1, 0, 1),      # Cout 48 (bot_fine-like), Cin 320
+    # >= 224 wide tiles whose 256-pixel M tiles are image-row segments: the row-buffer kernel (3x3, stride 1, 'same')
+    (2, 112, 256, 64, 256, 3, 1, 1, 1),
+    (1, 112, 512, 64, 256, 3, 1, 2, 2),  # two tiles per image row: real column halos
+    (1, 224, 256, 128, 256, 3, 1, 12, 12),   # ASPP-like dilation, kernel rows leaving the image at top and bottom
 ]
 
 
