@@ -284,25 +284,31 @@ __global__ __launch_bounds__(512, CF::WPE) void conv_igemm_kernel(const ConvPara
 // image) is staged once, and the three kx stages read their fragments from it at row offsets kx*dil; the XOR swizzle is
 // keyed on the buffer row, so the shifted reads stay bank-conflict free.  The B tile is staged per tap as before.
 // Kernel rows that fall outside the image contribute nothing and are skipped for the whole tile.
-// LDS: 2 x 40 KiB row buffers (320 rows: dil <= 32) + 2 x 32 KiB B stages = 144 KiB.
-struct CfgRow {
-    static constexpr int MI = 8, WM = 2, WN = 4, RB = 128;
-    static constexpr int BM = 256, BN = 256;
-    static constexpr int AROWS = 320, ABUF = AROWS * RB, BSTAGE = BN * RB;
-    static constexpr int GAR = AROWS / 8 / 8;      // 1-KiB pieces per wave per row buffer
-    static constexpr int GB = BN / 8 / 8;          // ... per B stage
-    static constexpr int LDS_BYTES = 2 * ABUF + 2 * BSTAGE;
-    static_assert(8 * 32 * EP_LD * 4 <= LDS_BYTES, "epilogue patches must fit");
+// Wide: 2 x 40 KiB row buffers (320 rows: dil <= 32) + 2 x 32 KiB B stages = 144 KiB.  Narrow (Cout <= 128, bf16): 64-B rows,
+// 2 x 24 KiB + 2 x 8 KiB, two workgroups per CU.
+template <int MI_, int WM_, int WN_, int RB_, int AROWS_, int WPE_> struct CfgRowT {
+    static constexpr int MI = MI_, WM = WM_, WN = WN_, RB = RB_, WPE = WPE_;
+    static constexpr int BM = WM * MI * 16, BN = WN * 64;
+    static constexpr int PR = 1024 / RB;           // rows per 1-KiB LDS-DMA piece
+    static constexpr int AROWS = AROWS_, ABUF = AROWS * RB, BSTAGE = BN * RB;
+    static constexpr int GAR = AROWS / PR / 8;     // pieces per wave per row buffer
+    static constexpr int GB = BN / PR / 8;         // ... per B stage
+    static constexpr int MAXDIL = (AROWS - BM) / 2;
+    static constexpr int NEED = 2 * ABUF + 2 * BSTAGE, EPI = 8 * 32 * EP_LD * 4;
+    static constexpr int LDS_BYTES = NEED > EPI ? NEED : EPI;   // the epilogue patches reuse the buffers
+    static_assert(BM == 256 && WM * WN == 8, "256-pixel tiles, 8 waves");
+    static_assert(AROWS % (PR * 8) == 0 && BN % (PR * 8) == 0, "whole pieces per wave");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
+typedef CfgRowT<8, 2, 4, 128, 320, 2> CfgRow;      // 256 x 256, 144 KiB: dil <= 32
+typedef CfgRowT<4, 4, 2, 64, 384, 4> CfgRowN;      // 256 x 128 with 64-B K stages, 68 KiB, <= 128 VGPRs: two workgroups per CU
 
-template <typename T>
-__global__ __launch_bounds__(512, 2) void conv_igemm_row_kernel(const ConvParams p)
+template <typename T, typename CF>
+__global__ __launch_bounds__(512, CF::WPE) void conv_igemm_row_kernel(const ConvParams p)
 {
-    typedef CfgRow CF;
     __shared__ __attribute__((aligned(16))) char lds[CF::LDS_BYTES];
     constexpr int ES = sizeof(T), RB = CF::RB, BK = RB / ES, EPC = 16 / ES;
-    constexpr int MI = CF::MI, GAR = CF::GAR, GB = CF::GB;
+    constexpr int MI = CF::MI, GAR = CF::GAR, GB = CF::GB, PR = CF::PR, CPR = RB / 16;
     char *const ldsB = lds + 2 * CF::ABUF;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -324,13 +330,15 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_row_kernel(const ConvParams
     const int nky = ky_hi - ky_lo + 1;
 
     // ---- per-lane staging state -------------------------------------------------------------------------------------
-    const int srow = lane >> 3;
-    const int chunk = (lane & 7) ^ srow;             // source-side swizzle: LDS slot s of buffer row r holds chunk s ^ (r & 7)
+    // source-side swizzle: LDS slot s of buffer row r holds chunk s ^ (r & 7) (128-B rows) / s ^ ((r >> 1) & 3) (64-B rows);
+    // pieces start at multiples of PR rows, so the key is a function of the lane's row inside the piece
+    const int srow = lane / CPR;
+    const int chunk = RB == 128 ? ((lane & 7) ^ srow) : ((lane & 3) ^ ((srow >> 1) & 3));
     int a_off[GAR];                                  // element offset of (n, ho, x) + chunk for the lane's row of piece j
     uint32_t a_ok = 0;                               // bit j: that pixel is inside the image row and the buffer
 #pragma unroll
     for (int j = 0; j < GAR; ++j) {
-        const int r = (wv * GAR + j) * 8 + srow;     // buffer row: pixel x0 - d + r
+        const int r = (wv * GAR + j) * PR + srow;    // buffer row: pixel x0 - d + r
         const int x = x0 - d + r;
         const bool ok = r < CF::BM + 2 * d && x >= 0 && x < p.W;
         a_off[j] = ((n * p.H + ho) * p.W + (ok ? x : 0)) * p.ldx + chunk * EPC;
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_row_kernel(const ConvParams
     int b_off[GB];
 #pragma unroll
     for (int j = 0; j < GB; ++j) {
-        const int nn = n0 + (wv * GB + j) * 8 + srow;
+        const int nn = n0 + (wv * GB + j) * PR + srow;
         b_off[j] = nn < p.Cout ? nn * p.Ktot + chunk * EPC : -1;
     }
 
@@ -396,11 +404,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_row_kernel(const ConvParams
             if (s + 1 < ns) stage_b();
             // fragments: A rows shifted by kx*dil inside the row buffer, B from the per-tap stage
             const int rsh = frow + kx * d;
-            const char *A = Au + (wm * 128 + rsh) * RB;
+            const char *A = Au + (wm * (16 * MI) + rsh) * RB;
             const char *B = ldsB + (s & 1) * CF::BSTAGE + (wn * 64 + frow) * RB;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int swa = ((fq + 4 * ks) ^ (rsh & 7)) << 4, swb = ((fq + 4 * ks) ^ (lane & 7)) << 4;
+            for (int ks = 0; ks < RB / 64; ++ks) {
+                const int swa = RB == 128 ? (((fq + 4 * ks) ^ (rsh & 7)) << 4) : ((fq ^ ((rsh >> 1) & 3)) << 4);
+                const int swb = RB == 128 ? (((fq + 4 * ks) ^ (lane & 7)) << 4) : ((fq ^ ((frow >> 1) & 3)) << 4);
                 uint4 a[MI], b[4];
 #pragma unroll
                 for (int i = 0; i < MI; ++i) a[i] = *(const uint4 *)(A + i * 16 * RB + swa);
@@ -521,18 +530,19 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         const int tiles_m = (p.M + CF::BM - 1) / CF::BM;
         hipLaunchKernelGGL((conv_igemm_kernel<T, CF>), dim3((unsigned)(tiles_m * p.tiles_n)), dim3(512), 0, s, p);
     };
-    // wide tiles that are segments of one image row, 3x3 / stride 1 / 'same': row-buffer kernel
-    const bool row_ok = cfg == 1 && !norow && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == d->dil && d->dil <= 32 &&
-                        d->W % CfgRow::BM == 0;
-    if (row_ok) {
-        p.nkc = d->Cin / (128 / es);
+    // 256-pixel tiles that are segments of one image row, 3x3 / stride 1 / 'same': row-buffer kernels (the narrow one is
+    // compiled for <= 128 VGPRs, which the fp32 parity path's blocked accumulation does not fit)
+    const bool row_geom = !norow && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == d->dil && d->W % 256 == 0;
+    const bool row_wide = row_geom && cfg == 1 && d->dil <= CfgRow::MAXDIL;
+    const bool row_narrow = row_geom && cfg == 0 && d->dtype == KD_BF16 && d->dil <= CfgRowN::MAXDIL;
+    if (row_wide || row_narrow) {
+        p.nkc = d->Cin / ((row_wide ? CfgRow::RB : CfgRowN::RB) / es);
         p.nk = 9 * p.nkc;
-        p.tiles_n = (d->Cout + CfgRow::BN - 1) / CfgRow::BN;
-        const int tiles_m = p.M / CfgRow::BM;
-        if (d->dtype == KD_BF16)
-            hipLaunchKernelGGL(conv_igemm_row_kernel<bf16_t>, dim3((unsigned)(tiles_m * p.tiles_n)), dim3(512), 0, s, p);
-        else
-            hipLaunchKernelGGL(conv_igemm_row_kernel<float>, dim3((unsigned)(tiles_m * p.tiles_n)), dim3(512), 0, s, p);
+        p.tiles_n = (d->Cout + (row_wide ? CfgRow::BN : CfgRowN::BN) - 1) / (row_wide ? CfgRow::BN : CfgRowN::BN);
+        const dim3 grid((unsigned)((p.M / 256) * p.tiles_n));
+        if (row_narrow) hipLaunchKernelGGL((conv_igemm_row_kernel<bf16_t, CfgRowN>), grid, dim3(512), 0, s, p);
+        else if (d->dtype == KD_BF16) hipLaunchKernelGGL((conv_igemm_row_kernel<bf16_t, CfgRow>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_row_kernel<float, CfgRow>), grid, dim3(512), 0, s, p);
     } else if (d->dtype == KD_BF16) {
         if (cfg == 1) launch(CfgWide{}, bf16_t{});
         else if (cfg == 2) launch(CfgDeep{}, bf16_t{});
