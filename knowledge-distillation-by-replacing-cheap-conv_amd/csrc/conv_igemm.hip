@@ -286,22 +286,23 @@ __global__ __launch_bounds__(512, CF::WPE) void conv_igemm_kernel(const ConvPara
 // Kernel rows that fall outside the image contribute nothing and are skipped for the whole tile.
 // Wide: 2 x 40 KiB row buffers (320 rows: dil <= 32) + 2 x 32 KiB B stages = 144 KiB.  Narrow (Cout <= 128, bf16): 64-B rows,
 // 2 x 24 KiB + 2 x 8 KiB, two workgroups per CU.
-template <int MI_, int WM_, int WN_, int RB_, int AROWS_, int WPE_> struct CfgRowT {
-    static constexpr int MI = MI_, WM = WM_, WN = WN_, RB = RB_, WPE = WPE_;
+template <int MI_, int WM_, int WN_, int RB_, int AROWS_, int NBS_, int WPE_> struct CfgRowT {
+    static constexpr int MI = MI_, WM = WM_, WN = WN_, RB = RB_, NBS = NBS_, WPE = WPE_;   // NBS: B stages resident
     static constexpr int BM = WM * MI * 16, BN = WN * 64;
     static constexpr int PR = 1024 / RB;           // rows per 1-KiB LDS-DMA piece
     static constexpr int AROWS = AROWS_, ABUF = AROWS * RB, BSTAGE = BN * RB;
     static constexpr int GAR = AROWS / PR / 8;     // pieces per wave per row buffer
     static constexpr int GB = BN / PR / 8;         // ... per B stage
     static constexpr int MAXDIL = (AROWS - BM) / 2;
-    static constexpr int NEED = 2 * ABUF + 2 * BSTAGE, EPI = 8 * 32 * EP_LD * 4;
+    static constexpr int NEED = 2 * ABUF + NBS * BSTAGE, EPI = 8 * 32 * EP_LD * 4;
     static constexpr int LDS_BYTES = NEED > EPI ? NEED : EPI;   // the epilogue patches reuse the buffers
     static_assert(BM == 256 && WM * WN == 8, "256-pixel tiles, 8 waves");
     static_assert(AROWS % (PR * 8) == 0 && BN % (PR * 8) == 0, "whole pieces per wave");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
-typedef CfgRowT<8, 2, 4, 128, 320, 2> CfgRow;      // 256 x 256, 144 KiB: dil <= 32
-typedef CfgRowT<4, 4, 2, 64, 384, 4> CfgRowN;      // 256 x 128 with 64-B K stages, 68 KiB, <= 128 VGPRs: two workgroups per CU
+typedef CfgRowT<8, 2, 4, 128, 320, 2, 2> CfgRow;    // 256 x 256, 144 KiB: dil <= 32
+typedef CfgRowT<8, 2, 4, 128, 384, 2, 2> CfgRowX;   // 256 x 256, 160 KiB: dil <= 64 (ASPP rate 36)
+typedef CfgRowT<4, 4, 2, 64, 384, 3, 4> CfgRowN;    // 256 x 128 with 64-B K stages, 72 KiB, <= 128 VGPRs: two workgroups per CU
 
 template <typename T, typename CF>
 __global__ __launch_bounds__(512, CF::WPE) void conv_igemm_row_kernel(const ConvParams p)
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(512, CF::WPE) void conv_igemm_row_kernel(const Conv
     int s_cb = 0, s_ky = ky_lo, s_kx = 0, s_idx = 0; // next B stage to issue
     auto stage_b = [&]() {
         const int w_off = (s_ky * 3 + s_kx) * p.Cin + s_cb * BK;
-        char *lb = ldsB + (s_idx & 1) * CF::BSTAGE + wv * (GB * 1024);
+        char *lb = ldsB + (s_idx % CF::NBS) * CF::BSTAGE + wv * (GB * 1024);
 #pragma unroll
         for (int j = 0; j < GB; ++j) {
             const T *src = b_off[j] >= 0 ? wg + (b_off[j] + w_off) : zero;
@@ -389,9 +390,14 @@ __global__ __launch_bounds__(512, CF::WPE) void conv_igemm_row_kernel(const Conv
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fq = lane >> 4;
+    // B stages run NBS - 1 ahead of the one being consumed.  vmcnt completes in issue order; with three B stages the
+    // operations younger than B(s+1) at the end of stage s are the ones issued in stage s itself (the next row buffer on
+    // kx == 0, then B(s+2)), so "all but those" == B(s+1) -- and every older row buffer -- has landed.
     const int nu = p.nkc * nky, ns = nu * 3;
+    constexpr int NBS = CF::NBS;
     stage_a();
     stage_b();
+    if (NBS == 3 && ns > 1) stage_b();
     wait_vm_barrier<0>();
 #pragma unroll 1
     for (int u = 0; u < nu; ++u) {
@@ -400,12 +406,13 @@ __global__ __launch_bounds__(512, CF::WPE) void conv_igemm_row_kernel(const Conv
         for (int kx = 0; kx < 3; ++kx) {
             const int s = u * 3 + kx;
             // the other row buffer was last read in the previous super-stage, which every wave left at a barrier
-            if (kx == 0 && u + 1 < nu) stage_a();
-            if (s + 1 < ns) stage_b();
+            const bool new_a = kx == 0 && u + 1 < nu, new_b = s + NBS - 1 < ns;
+            if (new_a) stage_a();
+            if (new_b) stage_b();
             // fragments: A rows shifted by kx*dil inside the row buffer, B from the per-tap stage
             const int rsh = frow + kx * d;
             const char *A = Au + (wm * (16 * MI) + rsh) * RB;
-            const char *B = ldsB + (s & 1) * CF::BSTAGE + (wn * 64 + frow) * RB;
+            const char *B = ldsB + (s % NBS) * CF::BSTAGE + (wn * 64 + frow) * RB;
 #pragma unroll
             for (int ks = 0; ks < RB / 64; ++ks) {
                 const int swa = RB == 128 ? (((fq + 4 * ks) ^ (rsh & 7)) << 4) : ((fq ^ ((rsh >> 1) & 3)) << 4);
@@ -435,7 +442,14 @@ __global__ __launch_bounds__(512, CF::WPE) void conv_igemm_row_kernel(const Conv
                 __builtin_amdgcn_sched_group_barrier(0x100, MI + 4, 0);
                 if constexpr (sizeof(T) != 4) __builtin_amdgcn_sched_group_barrier(0x008, MI * 4, 0);
             }
-            if (s + 1 < ns) wait_vm_barrier<0>();
+            if (s + 1 < ns) {
+                if (NBS == 3 && new_b) {
+                    if (new_a) wait_vm_barrier<GAR + GB>();
+                    else wait_vm_barrier<GB>();
+                } else {
+                    wait_vm_barrier<0>();
+                }
+            }
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -533,7 +547,8 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
     // 256-pixel tiles that are segments of one image row, 3x3 / stride 1 / 'same': row-buffer kernels (the narrow one is
     // compiled for <= 128 VGPRs, which the fp32 parity path's blocked accumulation does not fit)
     const bool row_geom = !norow && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == d->dil && d->W % 256 == 0;
-    const bool row_wide = row_geom && cfg == 1 && d->dil <= CfgRow::MAXDIL;
+    const bool row_wide = row_geom && cfg == 1 && d->dil <= CfgRowX::MAXDIL;
+    const bool row_x = row_wide && d->dil > CfgRow::MAXDIL;
     const bool row_narrow = row_geom && cfg == 0 && d->dtype == KD_BF16 && d->dil <= CfgRowN::MAXDIL;
     if (row_wide || row_narrow) {
         p.nkc = d->Cin / ((row_wide ? CfgRow::RB : CfgRowN::RB) / es);
@@ -541,7 +556,9 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         p.tiles_n = (d->Cout + (row_wide ? CfgRow::BN : CfgRowN::BN) - 1) / (row_wide ? CfgRow::BN : CfgRowN::BN);
         const dim3 grid((unsigned)((p.M / 256) * p.tiles_n));
         if (row_narrow) hipLaunchKernelGGL((conv_igemm_row_kernel<bf16_t, CfgRowN>), grid, dim3(512), 0, s, p);
+        else if (d->dtype == KD_BF16 && row_x) hipLaunchKernelGGL((conv_igemm_row_kernel<bf16_t, CfgRowX>), grid, dim3(512), 0, s, p);
         else if (d->dtype == KD_BF16) hipLaunchKernelGGL((conv_igemm_row_kernel<bf16_t, CfgRow>), grid, dim3(512), 0, s, p);
+        else if (row_x) hipLaunchKernelGGL((conv_igemm_row_kernel<float, CfgRowX>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv_igemm_row_kernel<float, CfgRow>), grid, dim3(512), 0, s, p);
     } else if (d->dtype == KD_BF16) {
         if (cfg == 1) launch(CfgWide{}, bf16_t{});

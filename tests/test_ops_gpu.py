@@ -68,6 +68,7 @@ CONV_CASES = [
     (2, 112, 256, 64, 256, 3, 1, 1, 1),
     (1, 112, 512, 64, 256, 3, 1, 2, 2),  # two tiles per image row: real column halos
     (1, 224, 256, 128, 256, 3, 1, 12, 12),   # ASPP-like dilation, kernel rows leaving the image at top and bottom
+    (1, 224, 256, 64, 256, 3, 1, 36, 36),    # ASPP rate 36: the 384-row buffer (all 160 KiB of LDS)
     (1, 12, 256, 64, 128, 3, 1, 1, 1),       # narrow row-buffer kernel (bf16; fp32 takes the gather kernel)
     (1, 10, 512, 128, 64, 3, 1, 2, 2),
 ]
