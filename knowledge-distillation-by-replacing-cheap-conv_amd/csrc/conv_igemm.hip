@@ -291,13 +291,14 @@ template <int MI_, int WM_, int WN_, int RB_, int AROWS_, int NBS_, int WPE_> st
     static constexpr int BM = WM * MI * 16, BN = WN * 64;
     static constexpr int PR = 1024 / RB;           // rows per 1-KiB LDS-DMA piece
     static constexpr int AROWS = AROWS_, ABUF = AROWS * RB, BSTAGE = BN * RB;
-    static constexpr int GAR = AROWS / PR / 8;     // pieces per wave per row buffer
-    static constexpr int GB = BN / PR / 8;         // ... per B stage
+    static constexpr int NW = WM * WN;             // waves per workgroup
+    static constexpr int GAR = AROWS / PR / NW;    // pieces per wave per row buffer
+    static constexpr int GB = BN / PR / NW;        // ... per B stage
     static constexpr int MAXDIL = (AROWS - BM) / 2;
-    static constexpr int NEED = 2 * ABUF + NBS * BSTAGE, EPI = 8 * 32 * EP_LD * 4;
+    static constexpr int NEED = 2 * ABUF + NBS * BSTAGE, EPI = NW * 32 * EP_LD * 4;
     static constexpr int LDS_BYTES = NEED > EPI ? NEED : EPI;   // the epilogue patches reuse the buffers
-    static_assert(BM == 256 && WM * WN == 8, "256-pixel tiles, 8 waves");
-    static_assert(AROWS % (PR * 8) == 0 && BN % (PR * 8) == 0, "whole pieces per wave");
+    static_assert(BM == 256, "256-pixel tiles");
+    static_assert(AROWS % (PR * NW) == 0 && BN % (PR * NW) == 0, "whole pieces per wave");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 typedef CfgRowT<8, 2, 4, 128, 320, 2, 2> CfgRow;    // 256 x 256, 144 KiB: dil <= 32
@@ -305,7 +306,7 @@ typedef CfgRowT<8, 2, 4, 128, 384, 2, 2> CfgRowX;   // 256 x 256, 160 KiB: dil <
 typedef CfgRowT<4, 4, 2, 64, 384, 3, 4> CfgRowN;    // 256 x 128 with 64-B K stages, 72 KiB, <= 128 VGPRs: two workgroups per CU
 
 template <typename T, typename CF>
-__global__ __launch_bounds__(512, CF::WPE) void conv_igemm_row_kernel(const ConvParams p)
+__global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_row_kernel(const ConvParams p)
 {
     __shared__ __attribute__((aligned(16))) char lds[CF::LDS_BYTES];
     constexpr int ES = sizeof(T), RB = CF::RB, BK = RB / ES, EPC = 16 / ES;
