@@ -55,6 +55,7 @@ struct ConvParams {
     int M, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil, ldx;
     int HoWo, nkc, nk, Ktot, tiles_n;
     int vec_ok;  // every epilogue pointer/stride is 16-B friendly
+    int epi_batch;  // A/B hook: 0 = one pass at a time (KDCC_EPI_BATCH=0)
     kd_conv_epilogue ep;
 };
 
@@ -82,7 +83,7 @@ __device__ __forceinline__ void st8_guard(U *p, int valid, bool vec, const float
 }
 
 // ---- epilogue: accumulators -> per-wave LDS patch -> 8-channel vector rows (shared by both main loops) -----------------
-template <typename T, int MI>
+template <typename T, int MI, int EB>   // EB: passes (8 rows each) whose epilogue operands are loaded together
 __device__ __forceinline__ void ig_epilogue(const ConvParams &p, char *lds, f32x4_t (&acc)[MI][4], int m0, int n0, int wm,
                                             int wn, int wv, int lane)
 {
@@ -117,6 +118,66 @@ __device__ __forceinline__ void ig_epilogue(const ConvParams &p, char *lds, f32x
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        bool done = false;
+        if constexpr (sizeof(T) == 2) {
+            // fast path (whole 8-channel vectors, 16-B aligned operands): the residual / mask operands of the four passes
+            // are loaded together, ahead of the stores they could alias, so their latency is paid once per 32 rows
+            if (p.epi_batch && __all(vec && valid == 8)) {
+                const int mb = m0 + wm * (16 * MI) + half * 32 + (lane >> 3);
+#pragma unroll
+                for (int pb = 0; pb < 4; pb += EB) {
+                uint4 rp[EB], rm[EB], rq[EB];
+#pragma unroll
+                for (int pass = pb; pass < pb + EB; ++pass) {
+                    const size_t m = (size_t)min(mb + pass * 8, p.M - 1);
+                    if (e.res_pre) rp[pass - pb] = *(const uint4 *)((const T *)e.res_pre + m * e.ld_res_pre + c0);
+                    if (e.mask) rm[pass - pb] = *(const uint4 *)((const T *)e.mask + m * e.ld_mask + c0);
+                    if (e.res_post) rq[pass - pb] = *(const uint4 *)((const T *)e.res_post + m * e.ld_res_post + c0);
+                }
+#pragma unroll
+                for (int pass = pb; pass < pb + EB; ++pass) {
+                    const int row = pass * 8 + (lane >> 3);
+                    const int m = mb + pass * 8;
+                    if (m >= p.M) continue;
+                    float v[8], t[8];
+                    {
+                        const float4 lo = *(const float4 *)(ep + row * EP_LD + cg);
+                        const float4 hi = *(const float4 *)(ep + row * EP_LD + cg + 4);
+                        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+                    }
+                    if (e.res_pre) {
+                        ld8((const T *)&rp[pass - pb], t);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] += t[q];
+                    }
+                    if (e.mask) {
+                        ld8((const T *)&rm[pass - pb], t);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = t[q] > 0.f ? v[q] * mscale[q] : 0.f;
+                    }
+                    if (e.res_post) {
+                        ld8((const T *)&rq[pass - pb], t);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] += t[q];
+                    }
+                    if (e.out_raw) {
+                        if (e.raw_f32) st8((float *)e.out_raw + (size_t)m * e.ld_raw + c0, v);
+                        else st8((T *)e.out_raw + (size_t)m * e.ld_raw + c0, v);
+                    }
+                    if (e.out_act) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const float a = v[q] * ascale[q] + ashift[q];
+                            t[q] = e.act_relu ? fmaxf(a, 0.f) : a;
+                        }
+                        st8((T *)e.out_act + (size_t)m * e.ld_act + c0, t);
+                    }
+                }
+                }
+                done = true;
+            }
+        }
+        if (!done) {
 #pragma unroll 1
         for (int pass = 0; pass < 4; ++pass) {
             const int row = pass * 8 + (lane >> 3);
@@ -156,6 +217,7 @@ __device__ __forceinline__ void ig_epilogue(const ConvParams &p, char *lds, f32x
                 }
                 st8_guard((T *)e.out_act + (size_t)m * e.ld_act + c0, valid, vec, t);
             }
+        }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -201,7 +263,11 @@ __global__ __launch_bounds__(512, CF::WPE) void conv_igemm_kernel(const ConvPara
         const int m = m0 + r;
         a_off[j] = 0;
         a_mask[j] = 0;
-        if (m < p.M) {
+        if (m < p.M && ntaps == 1 && p.stride == 1 && p.pad == 0) {
+            // 1x1 / stride 1: output pixel m is input pixel m (no divisions, no border)
+            a_off[j] = m * p.ldx + chunk * EPC;
+            a_mask[j] = 1u;
+        } else if (m < p.M) {
             const int n = m / p.HoWo, rem = m - n * p.HoWo;
             const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
             const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
@@ -274,7 +340,7 @@ __global__ __launch_bounds__(512, CF::WPE) void conv_igemm_kernel(const ConvPara
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();  // every wave is done reading the stage buffers
 
-    ig_epilogue<T, MI>(p, lds, acc, m0, n0, wm, wn, wv, lane);
+    ig_epilogue<T, MI, (CF::WPE > 2 ? 1 : 4)>(p, lds, acc, m0, n0, wm, wn, wv, lane);
 }
 
 // ---- 3x3 / stride 1 / 'same' convolutions whose 256-pixel tiles are segments of one image row -----------------------------
@@ -455,7 +521,7 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_row_kernel(co
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();  // every wave is done reading the buffers
-    ig_epilogue<T, MI>(p, lds, acc, m0, n0, wm, wn, wv, lane);
+    ig_epilogue<T, MI, (CF::WPE > 2 ? 1 : 4)>(p, lds, acc, m0, n0, wm, wn, wv, lane);
 }
 
 // ---- weight packing ------------------------------------------------------------------
@@ -523,6 +589,11 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
     p.vec_ok = ok(ep->res_pre, ep->ld_res_pre, es) && ok(ep->mask, ep->ld_mask, es) &&
                ok(ep->res_post, ep->ld_res_post, es) && ok(ep->out_raw, ep->ld_raw, ep->raw_f32 ? 4 : es) &&
                ok(ep->out_act, ep->ld_act, es);
+    {
+        static int eb = -1;
+        if (eb < 0) { const char *v = getenv("KDCC_EPI_BATCH"); eb = !(v && v[0] == '0'); }
+        p.epi_batch = eb;
+    }
     // wide tiles only when they still fill the chip (one workgroup per CU, 256 CUs); e.g. the ASPP 4096->256 1x1 at
     // 128x256 pixels would give 128 wide tiles, so it runs on the narrow config (256 tiles)
     const long long wide_tiles = (long long)((p.M + CfgWide::BM - 1) / CfgWide::BM) * ((d->Cout + CfgWide::BN - 1) / CfgWide::BN);
