@@ -22,6 +22,7 @@
 // twice), so no LDS read leaves the buffer and every operand is finite.
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #include "igemm_core.h"
 
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
 // residue class and image the block sees: one 16x16 accumulator per channel for the whole block (31 % of its MACs are
 // useful).  x and g tiles are staged like the forward kernel's X (same transposed layout, g without halo); the next
 // item's loads are spread over the row loop and land in the same LDS buffers after the MFMAs.
-constexpr int GBYTES = (TLY * RSTR + 64 + 15) & ~15;
+constexpr int GBYTES = ((TLY + 1) * RSTR + 64 + 15) & ~15;   // + one all-zero row: what out-of-tile g rows read
 constexpr int WG_LDS = XBYTES + GBYTES;
 constexpr int GUNITS = TLY * 32 * 2, NIG = (GUNITS + NT - 1) / NT;
 static_assert(NIG == 4, "interleaved fetch below is written for 4 g units per thread");
@@ -342,11 +343,8 @@ __device__ __forceinline__ void fetch_unit_g(int it, const DwWgMfmaParams &p, co
 
 __device__ __forceinline__ void write_item_g(char *G, int tid, const StagedG &s)
 {
-    for (int e = tid; e < TLY * 8 + 16; e += NT) {
-        const int r = e >> 3;
-        if (r < TLY) *(uint32_t *)(G + r * RSTR + CG * CSTR + (e & 7) * 4) = 0u;
-        else *(uint32_t *)(G + TLY * RSTR + (e - TLY * 8) * 4) = 0u;
-    }
+    for (int e = tid; e < TLY * 8; e += NT) *(uint32_t *)(G + (e >> 3) * RSTR + CG * CSTR + (e & 7) * 4) = 0u;   // row pads
+    for (int e = tid; e < (RSTR + 64) / 4; e += NT) *(uint32_t *)(G + TLY * RSTR + e * 4) = 0u;                   // zero row + tail
 #pragma unroll
     for (int it = 0; it < NIG; ++it) {
         const int unit = tid + it * NT;
@@ -407,15 +405,45 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_wgrad_kernel(DwWgMfmaParams p)
             while (nxt < iend && (wn.RV <= 0 || wn.CV <= 0)) { ++nxt; if (nxt < iend) wn = decode_item(px, nxt); }
             const bool more = nxt < iend;
 
-            const int RV = wi.RV, ncb = wi.CV > 32 ? 2 : 1;
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
+            const int RV = wi.RV;
+            // rows in groups of four: the group's 8 x (5 + 4) fragment dwords are read first, then shifted / masked, then
+            // the 8 MFMAs issue back to back -- one exposed LDS latency per group instead of one per MFMA
+            auto rows = [&](auto ncb_tag, int cc, int R0) __attribute__((always_inline)) {
+                constexpr int NCB = decltype(ncb_tag)::value;
                 const char *xc = Xx + (wave * 2 + cc) * CSTR + aoff;
                 const char *gc = Xg + (wave * 2 + cc) * CSTR + kg * 16;
-#pragma unroll 2
-                for (int R = 0; R < RV + 8; ++R) {
-                    if (cc == 0 && more && (R & 3) == 0) {   // next item's loads, one unit every four rows
-                        switch (R >> 2) {
+                uint32_t dd[4][NCB][5];
+                uint4 bv[4][NCB];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int R = R0 + rr, ly = R - 8 + fi;
+                    const bool ok = ly >= 0 && ly < RV && R < RV + 8;
+                    const char *gr = gc + (ok ? ly : TLY) * RSTR;
+                    const char *xr = xc + min(R, RY - 1) * RSTR;
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) {
+                        const uint32_t *xw = (const uint32_t *)(xr + cb * 64);
+#pragma unroll
+                        for (int q = 0; q < 5; ++q) dd[rr][cb][q] = xw[q];
+                        bv[rr][cb] = *(const uint4 *)(gr + cb * 64);
+                    }
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) {
+                        const uint32_t *d5 = dd[rr][cb];
+                        const uint4 av = make_uint4(__builtin_amdgcn_alignbit(d5[1], d5[0], sh), __builtin_amdgcn_alignbit(d5[2], d5[1], sh),
+                                                    __builtin_amdgcn_alignbit(d5[3], d5[2], sh), __builtin_amdgcn_alignbit(d5[4], d5[3], sh));
+                        Mma<bf16_t>::run(av, bv[rr][cb], acc[cc]);
+                    }
+            };
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+#pragma unroll 1
+                for (int R0 = 0; R0 < RV + 8; R0 += 4) {
+                    if (cc == 0 && more) {   // next item's loads, one unit per group of rows
+                        switch (R0 >> 2) {
                         case 0: fetch_unit(0, px, xb, wn, tid, sx); break;
                         case 1: fetch_unit(1, px, xb, wn, tid, sx); break;
                         case 2: fetch_unit(2, px, xb, wn, tid, sx); break;
@@ -427,19 +455,8 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_wgrad_kernel(DwWgMfmaParams p)
                         default: fetch_unit_g(3, p, gb, wn, tid, sg); break;
                         }
                     }
-                    const int ly = R - 8 + fi;
-                    const bool gok = ly >= 0 && ly < RV;
-                    const char *gr = gc + min(max(ly, 0), TLY - 1) * RSTR;
-                    const char *xr = xc + R * RSTR;
-                    for (int cb = 0; cb < ncb; ++cb) {
-                        const uint32_t *xw = (const uint32_t *)(xr + cb * 64);
-                        const uint32_t d0 = xw[0], d1 = xw[1], d2 = xw[2], d3 = xw[3], d4 = xw[4];
-                        uint4 b = *(const uint4 *)(gr + cb * 64);
-                        if (!gok) b = make_uint4(0u, 0u, 0u, 0u);
-                        const uint4 a = make_uint4(__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh),
-                                                   __builtin_amdgcn_alignbit(d3, d2, sh), __builtin_amdgcn_alignbit(d4, d3, sh));
-                        Mma<bf16_t>::run(a, b, acc[cc]);
-                    }
+                    if (wi.CV > 32) rows(std::integral_constant<int, 2>{}, cc, R0);
+                    else rows(std::integral_constant<int, 1>{}, cc, R0);
                 }
             }
             if (!more) break;
