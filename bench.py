@@ -189,10 +189,10 @@ def main():
                        "plan": a.plan, "per_gpu_batch": a.batch, "global_batch": world * a.batch,
                        "parallelism": f"dp{world}", "teacher_overlap": bool(model.overlap_teacher),
                        "teacher_backend": a.teacher},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (dense conv fwd + dgrad, student" + (" + teacher)" if a.teacher == "hip" else ")"), "achieved": ach,
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_row_kernel + conv_igemm_kernel (dense conv fwd + dgrad, student" + (" + teacher)" if a.teacher == "hip" else ")"), "achieved": ach,
                          "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": conv_traffic(a.plan, a.batch, a.height, a.width, a.dtype),
-                         "traffic_note": "mean HBM bytes per conv_igemm launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + "
+                         "traffic_note": "mean HBM bytes per conv_igemm* launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + "
                                          "WRITE_SIZE, separate passes (profiles/r01_traffic_pmc.json); mean algorithmic "
                                          "FLOP per launch = algorithmic_tflop_per_step / launches_per_step",
                          "launches_per_step": len(prof) / max(a.steps, 1), "ms_per_step_in_kernel": ms / max(a.steps, 1),
