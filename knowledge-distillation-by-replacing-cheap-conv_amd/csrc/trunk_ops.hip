@@ -69,6 +69,88 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float *__restrict_
     st8(o + 8, hi8);
 }
 
+// bf16 variant on the matrix cores: K = 27 taps x channels (padded to 32), one v_mfma_f32_16x16x32_bf16 per 16 pixels x 16
+// output channels.  A wave walks 16-pixel row segments: lane (pixel i, k-group q) gathers its 8 taps from the NCHW fp32
+// image (16 consecutive pixels per tap: 64-B runs), the four weight fragments stay in registers, and the 16 x 64 result
+// goes through a 2-KiB LDS patch so that every pixel's 128 B of channels leave as whole 32-B vectors.
+typedef __attribute__((ext_vector_type(8))) short stem_bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float stem_f32x4_t;
+__global__ __launch_bounds__(256) void stem_conv_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                             bf16_t *__restrict__ y, int N, int H, int W, int groups_per_row)
+{
+    constexpr int PSTR = 64 * 2 + 16;   // patch row stride (bytes): 16 pixels x 64 channels bf16, padded
+    __shared__ __attribute__((aligned(16))) char patch[4][16 * PSTR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, kg = lane >> 4;
+    // this lane's 8 taps: k = kg*8 + q = ci*9 + ky*3 + kx (k >= 27: zero)
+    int toff[8], tdy[8], tdx[8];
+    uint32_t tvalid = 0;
+    const size_t HW = (size_t)H * W;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k = kg * 8 + q, kc = k < 27 ? k : 0;
+        const int ci = kc / 9, ky = (kc % 9) / 3, kx = kc % 3;
+        tdy[q] = ky - 1; tdx[q] = kx - 1;
+        toff[q] = ci;
+        tvalid |= k < 27 ? (1u << q) : 0u;
+    }
+    // weight fragments: lane (channel j = fi of tile t, k-group kg)
+    uint4 bw[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = kg * 8 + q;
+            v[q] = k < 27 ? w[(t * 16 + fi) * 27 + k] : 0.f;
+        }
+        bw[t] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    }
+    char *pw = patch[wave];
+    const long long ngroups = (long long)N * H * groups_per_row;
+    for (long long g = (long long)blockIdx.x * 4 + wave; g < ngroups; g += (long long)gridDim.x * 4) {
+        const int gx = (int)(g % groups_per_row);
+        const long long rowid = g / groups_per_row;
+        const int h = (int)(rowid % H), n = (int)(rowid / H);
+        const int px = gx * 16 + fi;   // this lane's pixel column (may run past W in the last group)
+        const float *xn = x + (size_t)n * 3 * HW;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int hi = h + tdy[q], wi = px + tdx[q];
+            const bool ok = ((tvalid >> q) & 1u) && hi >= 0 && hi < H && wi >= 0 && wi < W;
+            const int hc = min(max(hi, 0), H - 1), wc = min(max(wi, 0), W - 1);
+            const float t = xn[(size_t)toff[q] * HW + (size_t)hc * W + wc];   // unconditional load, select after
+            v[q] = ok ? t : 0.f;
+        }
+        const uint4 a = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            stem_f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(stem_bf16x8_t, a), __builtin_bit_cast(stem_bf16x8_t, bw[t]),
+                                                          acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *(bf16_t *)(pw + (kg * 4 + r) * PSTR + (t * 16 + fi) * 2) = f32_to_bf16(acc[r]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            const int p = lane >> 2, c = lane & 3;   // pixel of the group, 16-channel quarter
+            const uint4 lo = *(const uint4 *)(pw + p * PSTR + c * 32), hi = *(const uint4 *)(pw + p * PSTR + c * 32 + 16);
+            const int col = gx * 16 + p;
+            if (col < W) {
+                bf16_t *o = y + (((size_t)n * H + h) * W + col) * 64 + c * 16;
+                *(uint4 *)o = lo;
+                *(uint4 *)(o + 8) = hi;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // ---- max-pool 3x3 / stride 2 / pad 1 (+ optional BN-eval + ReLU second output) ---------
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_kernel(const T *__restrict__ x, int ldx, T *__restrict__ y_raw, int ld_raw,
@@ -259,8 +341,15 @@ extern "C" int kd_stem_conv(int32_t dtype, const float *x_nchw, const float *w, 
     const long long pix = (long long)N * H * W;
     const dim3 grid((unsigned)((pix + 63) / 64));
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == KD_BF16) hipLaunchKernelGGL(stem_conv_kernel<bf16_t>, grid, dim3(256), 0, s, x_nchw, w, (bf16_t *)y, N, H, W);
-    else hipLaunchKernelGGL(stem_conv_kernel<float>, grid, dim3(256), 0, s, x_nchw, w, (float *)y, N, H, W);
+    if (dtype == KD_BF16) {
+        const int gpr = (W + 15) / 16;
+        const long long ngroups = (long long)N * H * gpr;
+        const long long want = (ngroups + 3) / 4;
+        const unsigned blocks = (unsigned)(want < 256 * 16 ? want : 256 * 16);   // persistent-ish: 16 workgroups per CU
+        hipLaunchKernelGGL(stem_conv_mfma_kernel, dim3(blocks), dim3(256), 0, s, x_nchw, w, (bf16_t *)y, N, H, W, gpr);
+    } else {
+        hipLaunchKernelGGL(stem_conv_kernel<float>, grid, dim3(256), 0, s, x_nchw, w, (float *)y, N, H, W);
+    }
     KD_CHECK_LAUNCH("kd_stem_conv");
     return KD_OK;
 }
