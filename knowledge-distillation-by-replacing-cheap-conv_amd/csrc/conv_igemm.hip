@@ -56,6 +56,7 @@ struct ConvParams {
     int HoWo, nkc, nk, Ktot, tiles_n;
     int vec_ok;  // every epilogue pointer/stride is 16-B friendly
     int epi_batch;  // A/B hook: 0 = one pass at a time (KDCC_EPI_BATCH=0)
+    int tune;       // A/B hook (KDCC_CONV_TUNE)
     kd_conv_epilogue ep;
 };
 
@@ -474,8 +475,15 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_row_kernel(co
             const int s = u * 3 + kx;
             // the other row buffer was last read in the previous super-stage, which every wave left at a barrier
             const bool new_a = kx == 0 && u + 1 < nu, new_b = s + NBS - 1 < ns;
-            if (new_a) stage_a();
-            if (new_b) stage_b();
+            if (NBS == 2 && !(p.tune & 1)) {
+                // two B stages: B(s+1) first, then the next row buffer, which may then stay in flight across this stage's
+                // wait (it is first read two stages later; the wait of stage s+1 covers it)
+                if (new_b) stage_b();
+                if (new_a) stage_a();
+            } else {
+                if (new_a) stage_a();
+                if (new_b) stage_b();
+            }
             // fragments: A rows shifted by kx*dil inside the row buffer, B from the per-tap stage
             const int rsh = frow + kx * d;
             const char *A = Au + (wm * (16 * MI) + rsh) * RB;
@@ -513,6 +521,8 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_row_kernel(co
                 if (NBS == 3 && new_b) {
                     if (new_a) wait_vm_barrier<GAR + GB>();
                     else wait_vm_barrier<GB>();
+                } else if (NBS == 2 && new_a && new_b && !(p.tune & 1)) {
+                    wait_vm_barrier<GAR>();
                 } else {
                     wait_vm_barrier<0>();
                 }
@@ -593,6 +603,9 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         static int eb = -1;
         if (eb < 0) { const char *v = getenv("KDCC_EPI_BATCH"); eb = !(v && v[0] == '0'); }
         p.epi_batch = eb;
+        static int tn = -1;
+        if (tn < 0) { const char *v = getenv("KDCC_CONV_TUNE"); tn = v ? atoi(v) : 0; }
+        p.tune = tn;
     }
     // wide tiles only when they still fill the chip (one workgroup per CU, 256 CUs); e.g. the ASPP 4096->256 1x1 at
     // 128x256 pixels would give 128 wide tiles, so it runs on the narrow config (256 tiles)
