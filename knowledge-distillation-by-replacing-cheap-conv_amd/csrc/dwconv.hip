@@ -5,10 +5,13 @@
 // outputs, so each input vector (4 channels, 8/16 B) it loads feeds up to k*S FMAs and
 // every weight quad k*R of them; 16 consecutive lanes cover 64 contiguous channels
 // (128/256 B per pixel per load instruction).  Weights sit in LDS tap-major.
-// VALU/L1-bound by design (81 FMA per output element); no MFMA reshaping.
-// Measured (MI355X, 4096 ch @128x256, bf16): 42 TFLOP/s; sustained v_pk_fma_f32 rate of the chip is 127-138 TFLOP/s
-// (tools/ubench/valu_rate.hip), the kernel's own VALU mix (62 % pk_fma) bounds it at ~75.  An LDS-DMA row-ring variant
-// (3x instead of 10x input over-fetch, no masks) was built and measured slower (31-39 TFLOP/s: idle lanes at the
+// VALU/L1-bound (81 FMA per output element).  These register kernels are the fp32 parity path, the 3x3 / odd-channel
+// path and the input gradient that carries a BN/ReLU-mask + residual epilogue; bf16 9x9 forward, plain input gradient
+// and weight gradient go to the matrix-core kernels of dwconv_mfma.hip (1.6-1.8x faster), which kd_dwconv_fwd /
+// kd_dwconv_wgrad try first.
+// Measured (MI355X, 4096 ch @128x256, bf16): 46 TFLOP/s fwd, 30 wgrad; sustained v_pk_fma_f32 rate of the chip is 127-138
+// TFLOP/s (tools/ubench/valu_rate.hip), the kernel's own VALU mix (62 % pk_fma) bounds it at ~75.  An LDS-DMA row-ring
+// variant (3x instead of 10x input over-fetch, no masks) was built and measured slower (31-39 TFLOP/s: idle lanes at the
 // lattice/tile edges outweigh the cleaner load path), so the register-only form stays.
 #include <stdlib.h>
 #include <string.h>
