@@ -210,7 +210,8 @@ class StudentEngine:
         up_small = self._new(N, h8, w8, 256)
         ops.conv2d(cat, self._w_fwd(net.bot_aspp), out_raw=up_small)
         h2, w2 = m2.shape[1], m2.shape[2]
-        dec0 = self._new(N, h2, w2, 320, zero=True)  # 48 + 256 = 304 channels, zero-padded to the GEMM K granule
+        dec0 = self._new(N, h2, w2, 320)  # 48 + 256 = 304 channels, zero-padded to the GEMM K granule
+        dec0[..., 304:320].zero_()       # (only the 16 pad channels: the slices below fill the rest)
         ops.conv2d(m2, self._w_fwd(net.bot_fine), out_raw=dec0[..., 0:48])
         ops.upsample_bilinear_ac(up_small, (h2, w2), out=dec0[..., 48:304])
         f = net.final
