@@ -84,14 +84,17 @@ __device__ __forceinline__ void st8_guard(U *p, int valid, bool vec, const float
 }
 
 // ---- epilogue: accumulators -> per-wave LDS patch -> 8-channel vector rows (shared by both main loops) -----------------
-template <typename T, int MI, int EB>   // EB: passes (8 rows each) whose epilogue operands are loaded together
-__device__ __forceinline__ void ig_epilogue(const ConvParams &p, char *lds, f32x4_t (&acc)[MI][4], int m0, int n0, int wm,
+template <typename T, int MI, int EB, int NJ = 4>   // EB: passes (8 rows each) whose epilogue operands are loaded together
+__device__ __forceinline__ void ig_epilogue(const ConvParams &p, char *lds, f32x4_t (&acc)[MI][NJ], int m0, int n0, int wm,
                                             int wn, int wv, int lane)
 {
+    static_assert(NJ % 4 == 0, "64-column groups");
+#pragma unroll
+    for (int jg = 0; jg < NJ / 4; ++jg) {   // the wave's columns in groups of 64
     const int frow = lane & 15, fq = lane >> 4;
     const kd_conv_epilogue &e = p.ep;
     const int cg = (lane & 7) * 8;
-    const int c0 = n0 + wn * 64 + cg;
+    const int c0 = n0 + wn * (16 * NJ) + jg * 64 + cg;
     const int valid = p.Cout - c0 >= 8 ? 8 : (p.Cout - c0 > 0 ? p.Cout - c0 : 0);
     const bool vec = p.vec_ok != 0;
 
@@ -114,7 +117,7 @@ __device__ __forceinline__ void ig_epilogue(const ConvParams &p, char *lds, f32x
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ep[(i * 16 + fq * 4 + r) * EP_LD + j * 16 + frow] = acc[half * 2 + i][j][r];
+                for (int r = 0; r < 4; ++r) ep[(i * 16 + fq * 4 + r) * EP_LD + j * 16 + frow] = acc[half * 2 + i][jg * 4 + j][r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -223,6 +226,7 @@ __device__ __forceinline__ void ig_epilogue(const ConvParams &p, char *lds, f32x
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     }
 }
 
@@ -353,9 +357,9 @@ __global__ __launch_bounds__(512, CF::WPE) void conv_igemm_kernel(const ConvPara
 // Kernel rows that fall outside the image contribute nothing and are skipped for the whole tile.
 // Wide: 2 x 40 KiB row buffers (320 rows: dil <= 32) + 2 x 32 KiB B stages = 144 KiB.  Narrow (Cout <= 128, bf16): 64-B rows,
 // 2 x 24 KiB + 2 x 8 KiB, two workgroups per CU.
-template <int MI_, int WM_, int WN_, int RB_, int AROWS_, int NBS_, int WPE_> struct CfgRowT {
-    static constexpr int MI = MI_, WM = WM_, WN = WN_, RB = RB_, NBS = NBS_, WPE = WPE_;   // NBS: B stages resident
-    static constexpr int BM = WM * MI * 16, BN = WN * 64;
+template <int MI_, int WM_, int WN_, int RB_, int AROWS_, int NBS_, int WPE_, int NJ_ = 4, int PIPE_ = 0> struct CfgRowT {
+    static constexpr int MI = MI_, WM = WM_, WN = WN_, RB = RB_, NBS = NBS_, WPE = WPE_, NJ = NJ_, PIPE = PIPE_;   // NBS: B stages resident; NJ: 16-column MFMA tiles per wave
+    static constexpr int BM = WM * MI * 16, BN = WN * NJ * 16;
     static constexpr int PR = 1024 / RB;           // rows per 1-KiB LDS-DMA piece
     static constexpr int AROWS = AROWS_, ABUF = AROWS * RB, BSTAGE = BN * RB;
     static constexpr int NW = WM * WN;             // waves per workgroup
@@ -368,8 +372,10 @@ template <int MI_, int WM_, int WN_, int RB_, int AROWS_, int NBS_, int WPE_> st
     static_assert(AROWS % (PR * NW) == 0 && BN % (PR * NW) == 0, "whole pieces per wave");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
-typedef CfgRowT<8, 2, 4, 128, 320, 2, 2> CfgRow;    // 256 x 256, 144 KiB: dil <= 32
-typedef CfgRowT<8, 2, 4, 128, 384, 2, 2> CfgRowX;   // 256 x 256, 160 KiB: dil <= 64 (ASPP rate 36)
+typedef CfgRowT<8, 2, 4, 128, 320, 2, 2, 4, 1> CfgRow;    // 256 x 256, 144 KiB: dil <= 32; software-pipelined main loop (bf16)
+typedef CfgRowT<8, 2, 4, 128, 384, 2, 2, 4, 1> CfgRowX;   // 256 x 256, 160 KiB: dil <= 64 (ASPP rate 36)
+typedef CfgRowT<8, 2, 4, 128, 320, 2, 2> CfgRowF;         // fp32 parity path: plain loop (blocked accumulation)
+typedef CfgRowT<8, 2, 4, 128, 384, 2, 2> CfgRowXF;
 typedef CfgRowT<4, 4, 2, 64, 384, 3, 4> CfgRowN;    // 256 x 128 with 64-B K stages, 72 KiB, <= 128 VGPRs: two workgroups per CU
 
 template <typename T, typename CF>
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_row_kernel(co
 {
     __shared__ __attribute__((aligned(16))) char lds[CF::LDS_BYTES];
     constexpr int ES = sizeof(T), RB = CF::RB, BK = RB / ES, EPC = 16 / ES;
-    constexpr int MI = CF::MI, GAR = CF::GAR, GB = CF::GB, PR = CF::PR, CPR = RB / 16;
+    constexpr int MI = CF::MI, NJ = CF::NJ, GAR = CF::GAR, GB = CF::GB, PR = CF::PR, CPR = RB / 16;
     char *const ldsB = lds + 2 * CF::ABUF;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -451,11 +457,11 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_row_kernel(co
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    f32x4_t acc[MI][4];
+    f32x4_t acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fq = lane >> 4;
     // B stages run NBS - 1 ahead of the one being consumed.  vmcnt completes in issue order; with three B stages the
@@ -467,6 +473,47 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_row_kernel(co
     stage_b();
     if (NBS == 3 && ns > 1) stage_b();
     wait_vm_barrier<0>();
+    if constexpr (CF::PIPE) {
+        // Software-pipelined main loop (128-B stages = two k-steps, two B stages): the fragments of a k-step are read
+        // one k-step ahead into a second register set, and the stage hand-over (wait + barrier + the DMA of stage s+2 +
+        // the first fragment reads of stage s+1) sits between the two k-steps' MFMA blocks -- the second block's operands
+        // are already in registers, so its 16*MI*NJ/16 MFMAs cover the barrier and the LDS latency of the next reads.
+        static_assert(RB == 128 && NBS == 2 && sizeof(T) == 2, "pipelined loop: bf16, 128-B stages, two B stages");
+        uint4 a0[MI], b0[NJ], a1[MI], b1[NJ];
+        auto read_frags = [&](int s, int ks, uint4 (&a)[MI], uint4 (&b)[NJ]) __attribute__((always_inline)) {
+            const int u = s / 3, kx = s - u * 3;
+            const int rsh = frow + kx * d;
+            const char *A = lds + (u & 1) * CF::ABUF + (wm * (16 * MI) + rsh) * RB + (((fq + 4 * ks) ^ (rsh & 7)) << 4);
+            const char *B = ldsB + (s & 1) * CF::BSTAGE + (wn * (16 * NJ) + frow) * RB + (((fq + 4 * ks) ^ (lane & 7)) << 4);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = *(const uint4 *)(A + i * 16 * RB);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) b[j] = *(const uint4 *)(B + j * 16 * RB);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto mfmas = [&](const uint4 (&a)[MI], const uint4 (&b)[NJ]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (ns > 1) stage_b();   // B(1)
+        if (nu > 1) stage_a();   // row buffer 1
+        read_frags(0, 0, a0, b0);
+#pragma unroll 1
+        for (int s = 0; s < ns; ++s) {
+            read_frags(s, 1, a1, b1);
+            mfmas(a0, b0);
+            if (s + 1 < ns) {
+                wait_vm_barrier<0>();   // this stage's reads are in registers, stage s+1 (and its row buffer) has landed
+                if (s + 2 < ns) stage_b();   // into the B stage just released
+                if ((s + 1) % 3 == 0 && (s + 1) / 3 + 1 < nu) stage_a();   // into the row buffer just released
+                read_frags(s + 1, 0, a0, b0);
+            }
+            mfmas(a1, b1);
+        }
+    } else {
 #pragma unroll 1
     for (int u = 0; u < nu; ++u) {
         const char *Au = lds + (u & 1) * CF::ABUF;
@@ -487,22 +534,22 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_row_kernel(co
             // fragments: A rows shifted by kx*dil inside the row buffer, B from the per-tap stage
             const int rsh = frow + kx * d;
             const char *A = Au + (wm * (16 * MI) + rsh) * RB;
-            const char *B = ldsB + (s % NBS) * CF::BSTAGE + (wn * 64 + frow) * RB;
+            const char *B = ldsB + (s % NBS) * CF::BSTAGE + (wn * (16 * NJ) + frow) * RB;
 #pragma unroll
             for (int ks = 0; ks < RB / 64; ++ks) {
                 const int swa = RB == 128 ? (((fq + 4 * ks) ^ (rsh & 7)) << 4) : ((fq ^ ((rsh >> 1) & 3)) << 4);
                 const int swb = RB == 128 ? (((fq + 4 * ks) ^ (lane & 7)) << 4) : ((fq ^ ((frow >> 1) & 3)) << 4);
-                uint4 a[MI], b[4];
+                uint4 a[MI], b[NJ];
 #pragma unroll
                 for (int i = 0; i < MI; ++i) a[i] = *(const uint4 *)(A + i * 16 * RB + swa);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) b[j] = *(const uint4 *)(B + j * 16 * RB + swb);
+                for (int j = 0; j < NJ; ++j) b[j] = *(const uint4 *)(B + j * 16 * RB + swb);
                 if constexpr (sizeof(T) == 4) {
 #pragma unroll
                     for (int i = 0; i < MI; ++i) {
-                        f32x4_t part[4];
+                        f32x4_t part[NJ];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
+                        for (int j = 0; j < NJ; ++j) {
                             part[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
                             Mma<T>::run(a[i], b[j], part[j]);
                             acc[i][j] += part[j];
@@ -512,10 +559,10 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_row_kernel(co
 #pragma unroll
                     for (int i = 0; i < MI; ++i)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
+                        for (int j = 0; j < NJ; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x100, MI + 4, 0);
-                if constexpr (sizeof(T) != 4) __builtin_amdgcn_sched_group_barrier(0x008, MI * 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, MI + NJ, 0);
+                if constexpr (sizeof(T) != 4) __builtin_amdgcn_sched_group_barrier(0x008, MI * NJ, 0);
             }
             if (s + 1 < ns) {
                 if (NBS == 3 && new_b) {
@@ -529,9 +576,10 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_row_kernel(co
             }
         }
     }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();  // every wave is done reading the buffers
-    ig_epilogue<T, MI, (CF::WPE > 2 ? 1 : 4)>(p, lds, acc, m0, n0, wm, wn, wv, lane);
+    ig_epilogue<T, MI, (CF::WPE > 2 ? 1 : 4), NJ>(p, lds, acc, m0, n0, wm, wn, wv, lane);
 }
 
 // ---- weight packing ------------------------------------------------------------------
@@ -643,8 +691,8 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         if (row_narrow) hipLaunchKernelGGL((conv_igemm_row_kernel<bf16_t, CfgRowN>), grid, dim3(512), 0, s, p);
         else if (d->dtype == KD_BF16 && row_x) hipLaunchKernelGGL((conv_igemm_row_kernel<bf16_t, CfgRowX>), grid, dim3(512), 0, s, p);
         else if (d->dtype == KD_BF16) hipLaunchKernelGGL((conv_igemm_row_kernel<bf16_t, CfgRow>), grid, dim3(512), 0, s, p);
-        else if (row_x) hipLaunchKernelGGL((conv_igemm_row_kernel<float, CfgRowX>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((conv_igemm_row_kernel<float, CfgRow>), grid, dim3(512), 0, s, p);
+        else if (row_x) hipLaunchKernelGGL((conv_igemm_row_kernel<float, CfgRowXF>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_row_kernel<float, CfgRowF>), grid, dim3(512), 0, s, p);
     } else if (d->dtype == KD_BF16) {
         if (cfg == 1) launch(CfgWide{}, bf16_t{});
         else if (cfg == 2) launch(CfgDeep{}, bf16_t{});
