@@ -31,8 +31,8 @@ constexpr int EP_LD = 68;                   // floats per epilogue row (64 + pad
 // Measured anatomy of CfgWide on the 512/1024-channel 3x3 layers (tools/bench_conv.py ablations): MFMA + LDS fragment
 // reads alone 1.5-1.7 PFLOP/s; + the LDS-DMA instruction stream hitting one cached page 1.4; + real L2 traffic 1.1.
 // So the staging traffic (both operands) costs ~22 %, its issue ~9 %; wide tiles cut that traffic 1.5x vs 128-wide.
-template <int MI_, int WM_, int WN_, int NST_, int RB_, int WPE_ = 2> struct Cfg {
-    static constexpr int MI = MI_, WM = WM_, WN = WN_, NST = NST_, RB = RB_, WPE = WPE_;   // WPE: waves per SIMD to compile for
+template <int MI_, int WM_, int WN_, int NST_, int RB_, int WPE_ = 2, int PIPE_ = 0> struct Cfg {
+    static constexpr int MI = MI_, WM = WM_, WN = WN_, NST = NST_, RB = RB_, WPE = WPE_, PIPE = PIPE_;   // WPE: waves per SIMD to compile for
     static constexpr int BM = WM * MI * 16, BN = WN * 64;
     static constexpr int STAGE_A = BM * RB, STAGE_B = BN * RB, STAGE = STAGE_A + STAGE_B;
     static constexpr int PR = 1024 / RB;                        // rows per 1-KiB LDS-DMA piece
@@ -43,7 +43,8 @@ template <int MI_, int WM_, int WN_, int NST_, int RB_, int WPE_ = 2> struct Cfg
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 typedef Cfg<4, 4, 2, 3, 128> CfgNarrow;
-typedef Cfg<8, 2, 4, 2, 128> CfgWide;
+typedef Cfg<8, 2, 4, 2, 128, 2, 1> CfgWide;   // bf16: software-pipelined main loop (see conv_igemm_row_kernel)
+typedef Cfg<8, 2, 4, 2, 128> CfgWideF;        // fp32 parity path
 typedef Cfg<8, 2, 4, 4, 64> CfgDeep;     // A/B runs only: KDCC_CONV_CFG=deep
 typedef Cfg<4, 4, 2, 3, 64, 4> CfgNarrow2;   // 256 x 128 with 64-B K stages, 72 KiB, <= 128 VGPRs: two workgroups per CU
 
@@ -332,6 +333,43 @@ __global__ __launch_bounds__(512, CF::WPE) void conv_igemm_kernel(const ConvPara
     const int nk = p.nk;
     constexpr int D = NST - 1, G = GA + GB;
     static_assert(D <= 3, "wait_stage_barrier handles up to two stages in flight behind the awaited one");
+    if constexpr (CF::PIPE) {
+        // two 128-B stages, fragments read one k-step ahead; the stage hand-over sits between the two MFMA blocks
+        static_assert(RB == 128 && NST == 2 && sizeof(T) == 2, "pipelined loop: bf16, two 128-B stages");
+        uint4 a0[MI], b0[4], a1[MI], b1[4];
+        auto read_frags = [&](int kt, int ks, uint4 (&a)[MI], uint4 (&b)[4]) __attribute__((always_inline)) {
+            const char *sA = lds + (kt & 1) * CF::STAGE;
+            const int sw = ((fq + 4 * ks) ^ (lane & 7)) << 4;
+            const char *A = sA + (wm * 16 * MI + frow) * RB + sw, *B = sA + CF::STAGE_A + (wn * 64 + frow) * RB + sw;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = *(const uint4 *)(A + i * 16 * RB);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *(const uint4 *)(B + j * 16 * RB);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto mfmas = [&](const uint4 (&a)[MI], const uint4 (&b)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        stage();
+        wait_vm_barrier<0>();
+        if (nk > 1) stage();
+        read_frags(0, 0, a0, b0);
+#pragma unroll 1
+        for (int kt = 0; kt < nk; ++kt) {
+            read_frags(kt, 1, a1, b1);
+            mfmas(a0, b0);
+            if (kt + 1 < nk) {
+                wait_vm_barrier<0>();        // this stage's fragments are in registers, stage kt+1 has landed
+                if (kt + 2 < nk) stage();    // into the stage just released
+                read_frags(kt + 1, 0, a0, b0);
+            }
+            mfmas(a1, b1);
+        }
+    } else {
     int issued = 0;
     for (; issued < D && issued < nk; ++issued) stage();
     wait_stage_barrier<G>(issued - 1);   // stage 0 has landed (for every wave, after the barrier)
@@ -341,6 +379,7 @@ __global__ __launch_bounds__(512, CF::WPE) void conv_igemm_kernel(const ConvPara
         const char *sA = lds + (kt % NST) * CF::STAGE;
         ig_compute_stage<T, MI, RB>(sA, sA + CF::STAGE_A, wm, wn, lane, acc);
         if (kt + 1 < nk) wait_stage_barrier<G>(issued - (kt + 2));   // stage kt+1 landed; later ones may still fly
+    }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();  // every wave is done reading the stage buffers
@@ -694,12 +733,13 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         else if (row_x) hipLaunchKernelGGL((conv_igemm_row_kernel<float, CfgRowXF>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv_igemm_row_kernel<float, CfgRowF>), grid, dim3(512), 0, s, p);
     } else if (d->dtype == KD_BF16) {
-        if (cfg == 1) launch(CfgWide{}, bf16_t{});
+        if (cfg == 1 && (p.tune & 8)) launch(CfgWideF{}, bf16_t{});   // A/B: plain main loop
+        else if (cfg == 1) launch(CfgWide{}, bf16_t{});
         else if (cfg == 2) launch(CfgDeep{}, bf16_t{});
         else if (cfg == 3) launch(CfgNarrow{}, bf16_t{});
         else launch(CfgNarrow2{}, bf16_t{});
     } else {
-        if (cfg == 1) launch(CfgWide{}, float{});
+        if (cfg == 1) launch(CfgWideF{}, float{});
         else if (cfg == 2) launch(CfgDeep{}, float{});
         else launch(CfgNarrow{}, float{});   // fp32 parity path: its blocked accumulation does not fit 128 VGPRs
     }
