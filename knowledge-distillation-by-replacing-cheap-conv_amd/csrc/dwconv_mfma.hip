@@ -308,8 +308,10 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
 // item's loads are spread over the row loop and land in the same LDS buffers after the MFMAs.
 constexpr int GBYTES = ((TLY + 1) * RSTR + 64 + 15) & ~15;   // + one all-zero row: what out-of-tile g rows read
 constexpr int WG_LDS = XBYTES + GBYTES;
-constexpr int GUNITS = TLY * 32 * 2, NIG = (GUNITS + NT - 1) / NT;
-static_assert(NIG == 4, "interleaved fetch below is written for 4 g units per thread");
+constexpr int NTW = 1024;                   // 16 waves, one channel each: four waves per SIMD hide the LDS / VALU chain
+constexpr int GUNITS = TLY * 32 * 2;
+constexpr int NIXW = (ITEMS + NTW - 1) / NTW, NIGW = (GUNITS + NTW - 1) / NTW;
+static_assert(NIXW == 3 && NIGW == 2, "interleaved fetch below is written for 3 x units + 2 g units per thread");
 
 struct DwWgMfmaParams {
     const bf16_t *x, *g;
@@ -319,38 +321,51 @@ struct DwWgMfmaParams {
     int nitems, nseg;
 };
 
-struct StagedG {
-    uint4 a[NIG], b[NIG];
-    uint32_t ok[NIG];
+template <int NU> struct StagedW {
+    uint4 a[NU], b[NU];
+    uint32_t ok[NU];
 };
 
-__device__ __forceinline__ void fetch_unit_g(int it, const DwWgMfmaParams &p, const bf16_t *gb, const Item &w, int tid,
-                                             StagedG &s)
+// stage-in unit (row r, column pair lp, 8-channel half h) of the x tile (HALO = 4) or the g tile (HALO = 0: cells past
+// this tile's valid outputs belong to another tile or to no pixel and are zeroed)
+template <int HALO, int NU>
+__device__ __forceinline__ void fetch_unit_w(int it, const bf16_t *base, int ld, int H, int W, int d, const Item &w, int tid,
+                                             StagedW<NU> &s)
 {
-    const int d = p.dil;
-    const int unit = min(tid + it * NT, GUNITS - 1);
+    constexpr int UNITS = HALO ? ITEMS : GUNITS;
+    const int unit = min(tid + it * NTW, UNITS - 1);
     const int h = unit & 1, lp = (unit >> 1) & 31, r = unit >> 6;
-    const int ly = w.ty * TLY + r, lx = w.tx * TLX + 2 * lp;
+    const int ly = w.ty * TLY + r - HALO, lx = w.tx * TLX + 2 * lp - HALO;
     const int yy = w.ry + d * ly, xa = w.rx + d * lx, xb2 = xa + d;
-    // cells past this tile's valid outputs belong to another tile (or to no pixel): zero
-    const bool rok = r < w.RV && yy < p.H;
-    const bool aok = rok && 2 * lp < w.CV && xa < p.W, bok = rok && 2 * lp + 1 < w.CV && xb2 < p.W;
-    const bf16_t *row = gb + (size_t)min(yy, p.H - 1) * p.W * p.ldg + h * 8;
-    s.a[it] = *(const uint4 *)(row + (size_t)min(xa, p.W - 1) * p.ldg);
-    s.b[it] = *(const uint4 *)(row + (size_t)min(xb2, p.W - 1) * p.ldg);
-    s.ok[it] = (aok ? 0x0000ffffu : 0u) | (bok ? 0xffff0000u : 0u);
+    bool rok = ly >= 0 && yy < H, aok = lx >= 0 && xa < W, bok = lx + 1 >= 0 && xb2 < W;
+    if (HALO) {
+        rok = rok && lp < 30;
+    } else {
+        rok = rok && r < w.RV;
+        aok = aok && 2 * lp < w.CV;
+        bok = bok && 2 * lp + 1 < w.CV;
+    }
+    const bf16_t *row = base + (size_t)min(max(yy, 0), H - 1) * W * ld + h * 8;
+    s.a[it] = *(const uint4 *)(row + (size_t)min(max(xa, 0), W - 1) * ld);
+    s.b[it] = *(const uint4 *)(row + (size_t)min(max(xb2, 0), W - 1) * ld);
+    s.ok[it] = (rok && aok ? 0x0000ffffu : 0u) | (rok && bok ? 0xffff0000u : 0u);
 }
 
-__device__ __forceinline__ void write_item_g(char *G, int tid, const StagedG &s)
+template <int HALO, int NU> __device__ __forceinline__ void write_item_w(char *X, int tid, const StagedW<NU> &s)
 {
-    for (int e = tid; e < TLY * 8; e += NT) *(uint32_t *)(G + (e >> 3) * RSTR + CG * CSTR + (e & 7) * 4) = 0u;   // row pads
-    for (int e = tid; e < (RSTR + 64) / 4; e += NT) *(uint32_t *)(G + TLY * RSTR + e * 4) = 0u;                   // zero row + tail
+    constexpr int UNITS = HALO ? ITEMS : GUNITS, NR = HALO ? RY : TLY;
+    for (int e = tid; e < NR * 8; e += NTW) *(uint32_t *)(X + (e >> 3) * RSTR + CG * CSTR + (e & 7) * 4) = 0u;   // row pads
+    if (HALO) {
+        for (int e = tid; e < 16; e += NTW) *(uint32_t *)(X + RY * RSTR + e * 4) = 0u;                            // tail
+    } else {
+        for (int e = tid; e < (RSTR + 64) / 4; e += NTW) *(uint32_t *)(X + TLY * RSTR + e * 4) = 0u;              // zero row + tail
+    }
 #pragma unroll
-    for (int it = 0; it < NIG; ++it) {
-        const int unit = tid + it * NT;
-        if (unit < GUNITS) {
+    for (int it = 0; it < NU; ++it) {
+        const int unit = tid + it * NTW;
+        if (unit < UNITS) {
             const int h = unit & 1, lp = (unit >> 1) & 31, r = unit >> 6;
-            char *dst = G + r * RSTR + (h * 8) * CSTR + lp * 4;
+            char *dst = X + r * RSTR + (h * 8) * CSTR + lp * 4;
             const uint32_t a[4] = {s.a[it].x, s.a[it].y, s.a[it].z, s.a[it].w};
             const uint32_t b[4] = {s.b[it].x, s.b[it].y, s.b[it].z, s.b[it].w};
 #pragma unroll
@@ -362,11 +377,11 @@ __device__ __forceinline__ void write_item_g(char *G, int tid, const StagedG &s)
     }
 }
 
-__global__ __launch_bounds__(NT, 1) void dw_mfma_wgrad_kernel(DwWgMfmaParams p)
+__global__ __launch_bounds__(NTW, 1) void dw_mfma_wgrad_kernel(DwWgMfmaParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *const Xx = smem, *const Xg = smem + XBYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // wave = channel of the group
     int lin = xcd_remap(blockIdx.x, gridDim.x);
     const int cgi = lin % p.ncg; lin /= p.ncg;
     const int seg = lin % p.nseg;
@@ -375,29 +390,31 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_wgrad_kernel(DwWgMfmaParams p)
     const int ibeg = (int)((long long)p.nitems * seg / p.nseg), iend = (int)((long long)p.nitems * (seg + 1) / p.nseg);
     const bf16_t *xb = p.x + (size_t)n * p.H * p.W * p.ldx + c0;
     const bf16_t *gb = p.g + (size_t)n * p.H * p.W * p.ldg + c0;
-    // the forward kernel's fetch helpers take its parameter block: only the geometry and ldx are read
-    DwMfmaParams px;
+    DwMfmaParams px;   // decode_item reads only the geometry
     px.H = p.H; px.W = p.W; px.dil = p.dil; px.ldx = p.ldx; px.ntx = p.ntx;
 
     const int fi = lane & 15, kg = lane >> 4;
-    f32x4_t acc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 
     int cur = ibeg;
     Item wi = decode_item(px, cur < iend ? cur : 0);
     while (cur < iend && (wi.RV <= 0 || wi.CV <= 0)) { ++cur; if (cur < iend) wi = decode_item(px, cur); }
     if (cur < iend) {
-        Staged sx;
-        StagedG sg;
-        fetch_item(px, xb, wi, tid, sx);
+        StagedW<NIXW> sx;
+        StagedW<NIGW> sg;
 #pragma unroll
-        for (int it = 0; it < NIG; ++it) fetch_unit_g(it, p, gb, wi, tid, sg);
-        write_item(Xx, tid, sx);
-        write_item_g(Xg, tid, sg);
+        for (int it = 0; it < NIXW; ++it) fetch_unit_w<4>(it, xb, p.ldx, p.H, p.W, p.dil, wi, tid, sx);
+#pragma unroll
+        for (int it = 0; it < NIGW; ++it) fetch_unit_w<0>(it, gb, p.ldg, p.H, p.W, p.dil, wi, tid, sg);
+        write_item_w<4>(Xx, tid, sx);
+        write_item_w<0>(Xg, tid, sg);
         __syncthreads();
 
         const int kxl = min(fi, 8);                       // A row i = kx (rows 9..15 duplicate row 8, discarded)
         const uint32_t sh = (kxl & 1) ? 16u : 0u;
         const int aoff = (kg * 8 + (kxl & ~1)) * 2;       // dword-aligned start of this lane's Hankel window
+        const char *xc = Xx + wave * CSTR + aoff;
+        const char *gc = Xg + wave * CSTR + kg * 16;
         while (true) {
             int nxt = cur + 1;
             Item wn = wi;
@@ -406,16 +423,13 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_wgrad_kernel(DwWgMfmaParams p)
             const bool more = nxt < iend;
 
             const int RV = wi.RV;
-            // rows in groups of four: the group's 8 x (5 + 4) fragment dwords are read first, then shifted / masked, then
-            // the 8 MFMAs issue back to back -- one exposed LDS latency per group instead of one per MFMA
-            auto rows = [&](auto ncb_tag, int cc, int R0) __attribute__((always_inline)) {
+            // rows in pairs: the pair's 4 x (5 + 4) fragment dwords are read first, then shifted, then the 4 MFMAs issue
+            auto rows = [&](auto ncb_tag, int R0) __attribute__((always_inline)) {
                 constexpr int NCB = decltype(ncb_tag)::value;
-                const char *xc = Xx + (wave * 2 + cc) * CSTR + aoff;
-                const char *gc = Xg + (wave * 2 + cc) * CSTR + kg * 16;
-                uint32_t dd[4][NCB][5];
-                uint4 bv[4][NCB];
+                uint32_t dd[2][NCB][5];
+                uint4 bv[2][NCB];
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
+                for (int rr = 0; rr < 2; ++rr) {
                     const int R = R0 + rr, ly = R - 8 + fi;
                     const bool ok = ly >= 0 && ly < RV && R < RV + 8;
                     const char *gr = gc + (ok ? ly : TLY) * RSTR;
@@ -429,62 +443,52 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_wgrad_kernel(DwWgMfmaParams p)
                     }
                 }
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
+                for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
                     for (int cb = 0; cb < NCB; ++cb) {
                         const uint32_t *d5 = dd[rr][cb];
                         const uint4 av = make_uint4(__builtin_amdgcn_alignbit(d5[1], d5[0], sh), __builtin_amdgcn_alignbit(d5[2], d5[1], sh),
                                                     __builtin_amdgcn_alignbit(d5[3], d5[2], sh), __builtin_amdgcn_alignbit(d5[4], d5[3], sh));
-                        Mma<bf16_t>::run(av, bv[rr][cb], acc[cc]);
+                        Mma<bf16_t>::run(av, bv[rr][cb], acc);
                     }
             };
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
 #pragma unroll 1
-                for (int R0 = 0; R0 < RV + 8; R0 += 4) {
-                    if (cc == 0 && more) {   // next item's loads, one unit per group of rows
-                        switch (R0 >> 2) {
-                        case 0: fetch_unit(0, px, xb, wn, tid, sx); break;
-                        case 1: fetch_unit(1, px, xb, wn, tid, sx); break;
-                        case 2: fetch_unit(2, px, xb, wn, tid, sx); break;
-                        case 3: fetch_unit(3, px, xb, wn, tid, sx); break;
-                        case 4: fetch_unit(4, px, xb, wn, tid, sx); break;
-                        case 5: fetch_unit_g(0, p, gb, wn, tid, sg); break;
-                        case 6: fetch_unit_g(1, p, gb, wn, tid, sg); break;
-                        case 7: fetch_unit_g(2, p, gb, wn, tid, sg); break;
-                        default: fetch_unit_g(3, p, gb, wn, tid, sg); break;
-                        }
+            for (int R0 = 0; R0 < RV + 8; R0 += 2) {
+                if (more && (R0 & 7) == 0) {   // next item's loads, one unit per eight rows
+                    switch (R0 >> 3) {
+                    case 0: fetch_unit_w<4>(0, xb, p.ldx, p.H, p.W, p.dil, wn, tid, sx); break;
+                    case 1: fetch_unit_w<4>(1, xb, p.ldx, p.H, p.W, p.dil, wn, tid, sx); break;
+                    case 2: fetch_unit_w<4>(2, xb, p.ldx, p.H, p.W, p.dil, wn, tid, sx); break;
+                    case 3: fetch_unit_w<0>(0, gb, p.ldg, p.H, p.W, p.dil, wn, tid, sg); break;
+                    default: fetch_unit_w<0>(1, gb, p.ldg, p.H, p.W, p.dil, wn, tid, sg); break;
                     }
-                    if (wi.CV > 32) rows(std::integral_constant<int, 2>{}, cc, R0);
-                    else rows(std::integral_constant<int, 1>{}, cc, R0);
                 }
+                if (wi.CV > 32) rows(std::integral_constant<int, 2>{}, R0);
+                else rows(std::integral_constant<int, 1>{}, R0);
             }
             if (!more) break;
-            if (wi.RV + 8 <= 32) {   // short tiles: the row loop did not reach every fetch slot
+            // short tiles: the row loop did not reach every fetch slot (slot k sits at row 8k)
 #pragma unroll
-                for (int it = 0; it < NIT; ++it)
-                    if (it * 4 >= wi.RV + 8) fetch_unit(it, px, xb, wn, tid, sx);
+            for (int it = 0; it < NIXW; ++it)
+                if (it * 8 >= wi.RV + 8) fetch_unit_w<4>(it, xb, p.ldx, p.H, p.W, p.dil, wn, tid, sx);
 #pragma unroll
-                for (int it = 0; it < NIG; ++it)
-                    if ((NIT + it) * 4 >= wi.RV + 8) fetch_unit_g(it, p, gb, wn, tid, sg);
-            }
+            for (int it = 0; it < NIGW; ++it)
+                if ((NIXW + it) * 8 >= wi.RV + 8) fetch_unit_w<0>(it, gb, p.ldg, p.H, p.W, p.dil, wn, tid, sg);
             __syncthreads();   // every wave is done reading the tiles
-            write_item(Xx, tid, sx);
-            write_item_g(Xg, tid, sg);
+            write_item_w<4>(Xx, tid, sx);
+            write_item_w<0>(Xg, tid, sg);
             __syncthreads();
             cur = nxt;
             wi = wn;
         }
     }
     // D[kx = 4*kg + r][j = fi] -> part[slab][ky = 8 - fi][kx][channel]
-    float *part = p.part + (size_t)(n * p.nseg + seg) * 81 * p.C + c0 + wave * 2;
+    float *part = p.part + (size_t)(n * p.nseg + seg) * 81 * p.C + c0 + wave;
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int kx = kg * 4 + r;
-            if (kx < 9 && fi < 9) part[(size_t)((8 - fi) * 9 + kx) * p.C + cc] = acc[cc][r];
-        }
+    for (int r = 0; r < 4; ++r) {
+        const int kx = kg * 4 + r;
+        if (kx < 9 && fi < 9) part[(size_t)((8 - fi) * 9 + kx) * p.C] = acc[r];
+    }
 }
 
 static void dw_mfma_split(int N, int C, int H, int W, int dil, int *nty, int *ntx, int *nitems, int *nseg)
@@ -591,7 +595,7 @@ int kd_internal_dw_mfma_wgrad(const kd_dw_desc *d, const void *x, const void *dy
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(dw_mfma_wgrad_kernel, dim3((unsigned)blocks), dim3(NT), WG_LDS, s, p);
+    hipLaunchKernelGGL(dw_mfma_wgrad_kernel, dim3((unsigned)blocks), dim3(NTW), WG_LDS, s, p);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
         kd_set_error("kd_dwconv_wgrad(mfma): launch failed: %s", hipGetErrorString(err));
