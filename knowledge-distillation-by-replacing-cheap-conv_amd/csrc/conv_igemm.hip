@@ -39,7 +39,7 @@ template <int MI_, int WM_, int WN_, int NST_, int RB_, int WPE_ = 2, int PIPE_ 
     static constexpr int GA = BM / PR / 8, GB = BN / PR / 8;    // pieces per wave per stage (A, B)
     static constexpr int LDS_BYTES = NST * STAGE;
     static_assert(WM * WN == 8, "8 waves");
-    static_assert(8 * 32 * EP_LD * 4 <= LDS_BYTES, "epilogue patches must fit the stage buffers");
+    static_assert(8 * 32 * EP_LD * 4 <= LDS_BYTES && 8 * 16 * MI * 128 <= LDS_BYTES, "epilogue patches must fit the stage buffers");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 typedef Cfg<4, 4, 2, 3, 128> CfgNarrow;
@@ -99,29 +99,69 @@ __device__ __forceinline__ void ig_epilogue(const ConvParams &p, char *lds, f32x
     const int valid = p.Cout - c0 >= 8 ? 8 : (p.Cout - c0 > 0 ? p.Cout - c0 : 0);
     const bool vec = p.vec_ok != 0;
 
+    // per-channel epilogue parameters: whole 32-B vectors, all in flight together (a guarded scalar load per element costs
+    // one exposed memory latency each -- 24 of them per tile -- before the first output row can leave)
     float mscale[8], ascale[8], ashift[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const bool ok = q < valid;
-        mscale[q] = (e.mask_scale && ok) ? e.mask_scale[c0 + q] : 1.f;
-        ascale[q] = (e.act_scale && ok) ? e.act_scale[c0 + q] : 1.f;
-        ashift[q] = (e.act_shift && ok) ? e.act_shift[c0 + q] : 0.f;
+    for (int q = 0; q < 8; ++q) { mscale[q] = 1.f; ascale[q] = 1.f; ashift[q] = 0.f; }
+    if (!(p.tune & 32) && __all(valid == 8)) {
+        if (e.mask_scale) ld8(e.mask_scale + c0, mscale);
+        if (e.act_scale) ld8(e.act_scale + c0, ascale);
+        if (e.act_shift) ld8(e.act_shift + c0, ashift);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool ok = q < valid;
+            if (e.mask_scale && ok) mscale[q] = e.mask_scale[c0 + q];
+            if (e.act_scale && ok) ascale[q] = e.act_scale[c0 + q];
+            if (e.act_shift && ok) ashift[q] = e.act_shift[c0 + q];
+        }
     }
 
-    // each wave owns a private 32 x 64 fp32 patch inside the (now idle) stage buffers, 32 rows of its sub-tile in turn
+    // Accumulator layout (the main loops issue the MFMAs with swapped operands, i.e. they compute the transposed tile):
+    // acc[i][j][r] = output(pixel 16*i + (lane & 15), channel 16*j + 4*(lane >> 4) + r) -- four consecutive channels of
+    // one pixel per lane, so the patch is written with one vector store per MFMA tile instead of four scalar ones.
+    // Each wave owns a private 32-pixel x 64-channel patch inside the (now idle) stage buffers, 32 rows of its sub-tile
+    // in turn: fp32 (272-B rows) when T is fp32 or the raw output is fp32; else bf16, the wave's whole sub-tile at once
+    // (swizzled 128-B rows; the raw output is exactly the patch contents).
     constexpr int PATCH = 32 * EP_LD * 4;
-    float *ep = (float *)(lds + wv * PATCH);
+    constexpr int ROWB16 = 128;                      // bf16 patch row: 64 channels, 8-B chunk c of row r stored at c ^ (r & 15)
+    const bool p16 = sizeof(T) == 2 && !e.raw_f32;   // block-uniform
+    char *epb = lds + wv * (p16 ? 16 * MI * ROWB16 : PATCH);
+    float *ep = (float *)epb;
+    if (p16) {
+        // the bf16 patch holds the wave's whole 16*MI x 64 sub-tile: one write phase, one wave barrier, then every
+        // 8-row pass reads independently (no write -> barrier -> read round trip per 32 rows)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // (a previous 64-column group's reads are done)
 #pragma unroll
-    for (int half = 0; half < MI / 2; ++half) {
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ep[(i * 16 + fq * 4 + r) * EP_LD + j * 16 + frow] = acc[half * 2 + i][jg * 4 + j][r];
+            for (int j = 0; j < 4; ++j) {
+                const f32x4_t v = acc[i][jg * 4 + j];
+                *(uint2 *)(epb + (i * 16 + frow) * ROWB16 + (((j * 4 + fq) ^ frow) << 3)) =
+                    make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll
+    for (int half = 0; half < MI / 2; ++half) {
+        if (!p16) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4_t v = acc[half * 2 + i][jg * 4 + j];
+                    *(float4 *)(ep + (i * 16 + frow) * EP_LD + j * 16 + fq * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+        }
+        if (!p16) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
 
         bool done = false;
         if constexpr (sizeof(T) == 2) {
@@ -145,7 +185,14 @@ __device__ __forceinline__ void ig_epilogue(const ConvParams &p, char *lds, f32x
                     const int m = mb + pass * 8;
                     if (m >= p.M) continue;
                     float v[8], t[8];
-                    {
+                    uint4 rawv = make_uint4(0u, 0u, 0u, 0u);   // the row's 8 channels as stored bf16 (p16 only)
+                    if (p16) {
+                        const int prow = half * 32 + row, c2 = (lane & 7) * 2;
+                        const uint2 lo = *(const uint2 *)(epb + prow * ROWB16 + ((c2 ^ (prow & 15)) << 3));
+                        const uint2 hi = *(const uint2 *)(epb + prow * ROWB16 + (((c2 + 1) ^ (prow & 15)) << 3));
+                        rawv = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                        ld8((const bf16_t *)&rawv, v);
+                    } else {
                         const float4 lo = *(const float4 *)(ep + row * EP_LD + cg);
                         const float4 hi = *(const float4 *)(ep + row * EP_LD + cg + 4);
                         v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
@@ -167,6 +214,7 @@ __device__ __forceinline__ void ig_epilogue(const ConvParams &p, char *lds, f32x
                     }
                     if (e.out_raw) {
                         if (e.raw_f32) st8((float *)e.out_raw + (size_t)m * e.ld_raw + c0, v);
+                        else if (p16 && !e.res_pre && !e.mask && !e.res_post) *(uint4 *)((T *)e.out_raw + (size_t)m * e.ld_raw + c0) = rawv;
                         else st8((T *)e.out_raw + (size_t)m * e.ld_raw + c0, v);
                     }
                     if (e.out_act) {
@@ -189,7 +237,13 @@ __device__ __forceinline__ void ig_epilogue(const ConvParams &p, char *lds, f32x
             const int m = m0 + wm * (16 * MI) + half * 32 + row;
             if (m >= p.M || valid == 0) continue;
             float v[8];
-            {
+            if (p16) {
+                const int prow = half * 32 + row, c2 = (lane & 7) * 2;
+                const uint2 lo = *(const uint2 *)(epb + prow * ROWB16 + ((c2 ^ (prow & 15)) << 3));
+                const uint2 hi = *(const uint2 *)(epb + prow * ROWB16 + (((c2 + 1) ^ (prow & 15)) << 3));
+                const uint4 rawv = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                ld8((const bf16_t *)&rawv, v);
+            } else {
                 const float4 lo = *(const float4 *)(ep + row * EP_LD + cg);
                 const float4 hi = *(const float4 *)(ep + row * EP_LD + cg + 4);
                 v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
@@ -224,9 +278,11 @@ __device__ __forceinline__ void ig_epilogue(const ConvParams &p, char *lds, f32x
             }
         }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (!p16) {   // the next half overwrites the fp32 patch
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
     }
     }
 }
@@ -351,7 +407,7 @@ __global__ __launch_bounds__(512, CF::WPE) void conv_igemm_kernel(const ConvPara
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < 4; ++j) Mma<T>::run(b[j], a[i], acc[i][j]);   // transposed tile: see ig_epilogue
             __builtin_amdgcn_sched_barrier(0);
         };
         stage();
@@ -377,7 +433,7 @@ __global__ __launch_bounds__(512, CF::WPE) void conv_igemm_kernel(const ConvPara
     for (int kt = 0; kt < nk; ++kt) {
         if (issued < nk) { stage(); ++issued; }
         const char *sA = lds + (kt % NST) * CF::STAGE;
-        ig_compute_stage<T, MI, RB>(sA, sA + CF::STAGE_A, wm, wn, lane, acc);
+        ig_compute_stage<T, MI, RB, true>(sA, sA + CF::STAGE_A, wm, wn, lane, acc);
         if (kt + 1 < nk) wait_stage_barrier<G>(issued - (kt + 2));   // stage kt+1 landed; later ones may still fly
     }
     }
@@ -406,6 +462,7 @@ template <int MI_, int WM_, int WN_, int RB_, int AROWS_, int NBS_, int WPE_, in
     static constexpr int GB = BN / PR / NW;        // ... per B stage
     static constexpr int MAXDIL = (AROWS - BM) / 2;
     static constexpr int NEED = 2 * ABUF + NBS * BSTAGE, EPI = NW * 32 * EP_LD * 4;
+    static_assert(NW * 16 * MI * 128 <= NEED || NW * 16 * MI * 128 <= EPI, "bf16 epilogue patches must fit");
     static constexpr int LDS_BYTES = NEED > EPI ? NEED : EPI;   // the epilogue patches reuse the buffers
     static_assert(BM == 256, "256-pixel tiles");
     static_assert(AROWS % (PR * NW) == 0 && BN % (PR * NW) == 0, "whole pieces per wave");
@@ -534,7 +591,7 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_row_kernel(co
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < NJ; ++j) Mma<T>::run(b[j], a[i], acc[i][j]);   // transposed tile: see ig_epilogue
             __builtin_amdgcn_sched_barrier(0);
         };
         if (ns > 1) stage_b();   // B(1)
@@ -590,7 +647,7 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_row_kernel(co
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) {
                             part[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                            Mma<T>::run(a[i], b[j], part[j]);
+                            Mma<T>::run(b[j], a[i], part[j]);
                             acc[i][j] += part[j];
                         }
                     }
@@ -598,7 +655,7 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_row_kernel(co
 #pragma unroll
                     for (int i = 0; i < MI; ++i)
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
+                        for (int j = 0; j < NJ; ++j) Mma<T>::run(b[j], a[i], acc[i][j]);   // transposed tile: see ig_epilogue
                 }
                 __builtin_amdgcn_sched_group_barrier(0x100, MI + NJ, 0);
                 if constexpr (sizeof(T) != 4) __builtin_amdgcn_sched_group_barrier(0x008, MI * NJ, 0);

@@ -65,7 +65,9 @@ template <> struct Mma<float> {
 // One K stage of a wave's (16*MI) x 64 sub-tile:  acc[i][j] += A(rows wm*16*MI + 16i ..) . B(rows wn*64 + 16j ..)^T
 // RB = bytes of K per LDS row per stage: 128 (two MFMA k-steps; 16-B chunk c of row r at slot c ^ (r & 7)) or
 //      64 (one k-step; chunk c of row r at slot c ^ ((r >> 1) & 3)).  Both are conflict-free for ds_read_b128.
-template <typename T, int MI = 4, int RB = 128>
+// SWAP: issue the MFMAs with the operands exchanged, i.e. accumulate the transposed 16x16 tiles (lane = pixel, registers =
+// four consecutive output channels), the layout conv_igemm.hip's epilogue consumes.
+template <typename T, int MI = 4, int RB = 128, bool SWAP = false>
 __device__ __forceinline__ void ig_compute_stage(const char *sA, const char *sB, int wm, int wn, int lane,
                                                  f32x4_t (&acc)[MI][4])
 {
@@ -91,7 +93,8 @@ __device__ __forceinline__ void ig_compute_stage(const char *sA, const char *sB,
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     part[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                    Mma<T>::run(a[i], b[j], part[j]);
+                    if (SWAP) Mma<T>::run(b[j], a[i], part[j]);
+                    else Mma<T>::run(a[i], b[j], part[j]);
                     acc[i][j] += part[j];
                 }
             }
@@ -99,7 +102,10 @@ __device__ __forceinline__ void ig_compute_stage(const char *sA, const char *sB,
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < 4; ++j) {
+                    if (SWAP) Mma<T>::run(b[j], a[i], acc[i][j]);
+                    else Mma<T>::run(a[i], b[j], acc[i][j]);
+                }
         }
         // issue the k-step's fragment reads back to back, then its MFMAs: one exposed LDS latency per k-step instead
         // of one per pair of reads (hipcc otherwise interleaves read-wait-4 MFMAs to save registers)
