@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the teacher on the main stream")
+    ap.add_argument("--ref-logging", action="store_true",
+                    help="also do the reference's per-step host syncs (five .item() calls, layerwise_trainer.py:244-250); the "
+                         "default measures the step without them, as this trainer runs it (metrics stay on the device)")
     ap.add_argument("--teacher", default="hip", choices=["torch", "hip"],
                     help="hip: frozen teacher graph through the engine's HIP kernels (default); torch: teacher as a PyTorch-ROCm "
                          "module (MIOpen) on a side stream, the split north_star describes")
@@ -164,6 +167,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss, sup, kd, tl = kd_step(model, crit, opt, data, target)
+        if a.ref_logging:
+            _ = (loss.item(), sup.item(), kd.item(), loss.item(), tl.item())
     sync()
     dt = time.perf_counter() - t0
     ops.PROFILER = None
@@ -188,7 +193,7 @@ def main():
                                    f"{a.height}x{a.width}, {a.batch} image/GPU, random-init weights",
                        "plan": a.plan, "per_gpu_batch": a.batch, "global_batch": world * a.batch,
                        "parallelism": f"dp{world}", "teacher_overlap": bool(model.overlap_teacher),
-                       "teacher_backend": a.teacher},
+                       "teacher_backend": a.teacher, "per_step_host_syncs": bool(a.ref_logging)},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_row_kernel + conv_igemm_kernel (dense conv fwd + dgrad, student" + (" + teacher)" if a.teacher == "hip" else ")"), "achieved": ach,
                          "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": conv_traffic(a.plan, a.batch, a.height, a.width, a.dtype),
