@@ -237,6 +237,10 @@ def test_stem_pool_upsample_imagepool(K, dt):
     lgd = torch.from_numpy(np.ascontiguousarray(lg.transpose(0, 2, 3, 1))).cuda()  # fp32 decoder output
     o = K.upsample_bilinear_ac(lgd, (14, 18), out_dtype=torch.float32)
     assert_close(host_nchw(o), orc.upsample_bilinear_ac(lg, (14, 18)), "f32", "logit upsample")
+    lg2 = rnd(1, 19, 21, 333)                      # several 256-pixel output segments per row, ragged last one
+    lgd2 = torch.from_numpy(np.ascontiguousarray(lg2.transpose(0, 2, 3, 1))).cuda()
+    o2 = K.upsample_bilinear_ac(lgd2, (42, 666), out_dtype=torch.float32)
+    assert_close(host_nchw(o2), orc.upsample_bilinear_ac(lg2, (42, 666)), "f32", "logit upsample (segments)")
     # ASPP image pooling branch
     Cin, Cout = 64, 16
     xi = q(rnd(2, Cin, 6, 10), dt)
