@@ -230,6 +230,15 @@ int kd_weighted_hint_mse(const kd_view3 *s, const kd_view3 *t, const float *w, i
 int kd_ce2d(const kd_view3 *x, const int64_t *target, int32_t ignore_index, int32_t N, int32_t C, int64_t P,
             float *loss, void *workspace, size_t workspace_bytes, kd_stream_t stream);
 
+/* CityscapesMetricTracker.update / confusion_for_batch (utils/util.py:108-128), the logged train mIoU, without the
+ * reference's two full-logit D2H copies per step (trainer/layerwise_trainer.py:249-250):
+ *   for every pixel with 0 <= target < C:  conf[target][argmax_c x(n,c,p)] += 1
+ * (labels == ignore_index, which the reference rewrites to C before masking, fall outside the range; argmax = first
+ * index of the maximum like torch.argmax).  conf: int64 (C, C) on the device, row = label, column = prediction;
+ * accumulate == 0 zeroes it first.  Integer result, exact and order-independent.  C <= 64. */
+int kd_confusion(const kd_view3 *x, const int64_t *target, int32_t N, int32_t C, int64_t P,
+                 int64_t *conf, int32_t accumulate, kd_stream_t stream);
+
 /* ----------------------------------------------------------------- optimizer
  * RAdam.step for one tensor, utils/optim/radam.py:30-98 (fp32 params/state).
  * `step` is the per-tensor step count after the increment (radam.py:62). */

@@ -42,6 +42,68 @@ __global__ __launch_bounds__(256) void finish_kernel(const double *partial, int 
 struct V3 { const void *p; int dt; long long sN, sC, sP; };
 struct M3 { void *p; int dt; long long sN, sC, sP; };
 
+// ---- confusion matrix (logged mIoU): argmax over channels + C x C histogram ------------------------------------------
+// Integer work, so the result is exact whatever the order: per-block histogram in LDS (integer atomics), flushed with
+// 64-bit integer atomics.  argmax = first index of the maximum (torch.argmax), a NaN counts as the maximum.
+__device__ __forceinline__ bool arg_better(float a, float m) { return a > m || (a != a && m == m); }
+
+template <typename TX>
+__global__ __launch_bounds__(256) void confusion_nhwc_kernel(const TX *__restrict__ x, const int64_t *__restrict__ target, int C,
+                                                             long long npix, unsigned long long *conf)
+{
+    extern __shared__ float sm[];              // 256 pixels x C logits, then C*C counters
+    unsigned int *hist = (unsigned int *)(sm + 256 * C);
+    for (int i = threadIdx.x; i < C * C; i += 256) hist[i] = 0u;
+    __syncthreads();
+    for (long long base = (long long)blockIdx.x * 256; base < npix; base += (long long)gridDim.x * 256) {
+        const int np = (int)min((long long)256, npix - base);
+        const int nel = np * C;
+        const TX *xp = x + base * C;
+        for (int i = threadIdx.x; i < nel; i += 256) sm[i] = Elem<TX>::ld(xp + i);
+        __syncthreads();
+        if ((int)threadIdx.x < np) {
+            const int64_t y = target[base + threadIdx.x];
+            if (y >= 0 && y < C) {
+                const float *a = sm + threadIdx.x * C;
+                float m = a[0];
+                int am = 0;
+                for (int c = 1; c < C; ++c)
+                    if (arg_better(a[c], m)) { m = a[c]; am = c; }
+                atomicAdd(&hist[(int)y * C + am], 1u);
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < C * C; i += 256)
+        if (hist[i]) atomicAdd(&conf[i], (unsigned long long)hist[i]);
+}
+
+__global__ __launch_bounds__(256) void confusion_kernel(V3 x, const int64_t *__restrict__ target, int N, int C, long long P,
+                                                        unsigned long long *conf)
+{
+    extern __shared__ float sm[];
+    unsigned int *hist = (unsigned int *)sm;
+    for (int i = threadIdx.x; i < C * C; i += 256) hist[i] = 0u;
+    __syncthreads();
+    const long long total = (long long)N * P;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int64_t y = target[i];
+        if (y < 0 || y >= C) continue;
+        const long long n = i / P, p = i - n * P;
+        const long long b = n * x.sN + p * x.sP;
+        float m = kd_ld(x.p, x.dt, b);
+        int am = 0;
+        for (int c = 1; c < C; ++c) {
+            const float a = kd_ld(x.p, x.dt, b + c * x.sC);
+            if (arg_better(a, m)) { m = a; am = c; }
+        }
+        atomicAdd(&hist[(int)y * C + am], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += 256)
+        if (hist[i]) atomicAdd(&conf[i], (unsigned long long)hist[i]);
+}
+
 // ---- KLDiv: one thread per pixel ----------------------------------------------------------
 __global__ __launch_bounds__(256) void kldiv_kernel(V3 s, V3 t, M3 g, float invT, float gscale, int N, int C, long long P,
                                                     double *partial)
@@ -434,6 +496,37 @@ extern "C" int kd_ce2d(const kd_view3 *x, const int64_t *target, int32_t ignore_
     KD_CHECK_LAUNCH("kd_ce2d");
     hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, (const double *)partial, nb, 1.0, (const double *)count, loss);
     KD_CHECK_LAUNCH("kd_ce2d(finish)");
+    return KD_OK;
+}
+
+extern "C" int kd_confusion(const kd_view3 *x, const int64_t *target, int32_t N, int32_t C, int64_t P, int64_t *conf,
+                            int32_t accumulate, kd_stream_t stream)
+{
+    KD_REQUIRE(x && x->ptr && target && conf, KD_ERR_INVALID, "kd_confusion: null argument");
+    KD_REQUIRE(ok_dt(x->dtype) && N > 0 && P > 0, KD_ERR_INVALID, "kd_confusion: bad argument");
+    KD_REQUIRE(C >= 1 && C <= 64, KD_ERR_UNSUPPORTED, "kd_confusion: 1 <= C <= 64 classes (got %d)", C);
+    KD_REQUIRE(((uintptr_t)conf & 7) == 0, KD_ERR_INVALID, "kd_confusion: conf must be 8-B aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate) {
+        if (hipMemsetAsync(conf, 0, (size_t)C * C * sizeof(int64_t), st) != hipSuccess) {
+            kd_set_error("kd_confusion: hipMemsetAsync failed");
+            return KD_ERR_HIP;
+        }
+    }
+    const int nb = blocks_for((long long)N * P);
+    if (x->sC == 1 && x->sP == C && (x->sN == (long long)C * P || N == 1)) {
+        const size_t lds = (size_t)256 * C * sizeof(float) + (size_t)C * C * sizeof(unsigned int);
+        if (x->dtype == KD_F32)
+            hipLaunchKernelGGL(confusion_nhwc_kernel<float>, dim3(nb), dim3(256), lds, st, (const float *)x->ptr, target, C,
+                               (long long)N * P, (unsigned long long *)conf);
+        else
+            hipLaunchKernelGGL(confusion_nhwc_kernel<bf16_t>, dim3(nb), dim3(256), lds, st, (const bf16_t *)x->ptr, target, C,
+                               (long long)N * P, (unsigned long long *)conf);
+    } else {
+        hipLaunchKernelGGL(confusion_kernel, dim3(nb), dim3(256), (size_t)C * C * sizeof(unsigned int), st, v3(x), target, N, C,
+                           (long long)P, (unsigned long long *)conf);
+    }
+    KD_CHECK_LAUNCH("kd_confusion");
     return KD_OK;
 }
 

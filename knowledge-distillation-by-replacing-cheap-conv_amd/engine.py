@@ -87,12 +87,19 @@ class StudentEngine:
 
     # ------------------------------------------------------------------ parameter operands
     def _packed(self, p, tag, fn):
+        # keyed by id(p), but the entry holds p itself: a Parameter freed by a later replace() cannot hand its id (and a
+        # matching small _version) to a new one while the entry is alive, and `ent[2] is p` catches any other aliasing
         key = (id(p), tag)
         ent = self._pack.get(key)
-        if ent is None or ent[0] != p._version or ent[1].device != p.device:
-            ent = (p._version, fn())
+        if ent is None or ent[2] is not p or ent[0] != p._version or ent[1].device != p.device:
+            ent = (p._version, fn(), p)
             self._pack[key] = ent
         return ent[1]
+
+    def drop_caches(self):
+        """Forget packed weights / folded BN vectors (called when the module tree is edited: replace(), reset())."""
+        self._pack.clear()
+        self._bn.clear()
 
     def _w_fwd(self, conv, cin_pad=None):
         return self._packed(conv.weight, ("fwd", self.dtype, cin_pad),
@@ -115,8 +122,8 @@ class StudentEngine:
         key = id(bn)
         ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, bn.weight.device)
         ent = self._bn.get(key)
-        if ent is None or ent[0] != ver:
-            ent = (ver, ops.bn_fold(bn))
+        if ent is None or ent[2] is not bn or ent[0] != ver:
+            ent = (ver, ops.bn_fold(bn), bn)
             self._bn[key] = ent
         return ent[1]
 
@@ -266,8 +273,10 @@ class StudentEngine:
             rec["rg_a"].append(rg)
             ho = ops.conv_out_size(a.shape[1], site.k, site.stride, site.pad, site.dil)
             wo = ops.conv_out_size(a.shape[2], site.k, site.stride, site.pad, site.dil)
-            # hint names: the conv itself, or (for the last conv) the whole `convs` Sequential
-            hinted = site.name in want or (last and f"{name}.convs" in want)
+            # hint names: the conv itself, or -- for the last conv -- the `convs` Sequential or the whole block (a forward
+            # hook on either observes the tensor the in-place add turns into the block output; cfg/cityscapes/
+            # 51M_deeplab_incremental.json uses 'mod4.block2.convs' and 'mod7.block1')
+            hinted = site.name in want or (last and (f"{name}.convs" in want or name in want))
             kw = {}
             if last:
                 want_raw = need_raw or hinted
@@ -296,7 +305,7 @@ class StudentEngine:
                 # forward hooks fire in execution order; the last conv's hooked tensor is mutated by the in-place
                 # residual add, so the hint IS the block output
                 if last:
-                    for nm in (site.name, f"{name}.convs"):
+                    for nm in (site.name, f"{name}.convs", name):
                         if nm in want:
                             note_hint(nm, raw, ("block", bi, "out"))
                 else:

@@ -110,6 +110,8 @@ class DepthwiseStudent(nn.Module):
             ref = next(self.student.parameters())
             replace_block.to(ref.device)
             self._set_block(block_name, replace_block, self.student)
+        if self._engine is not None:
+            self._engine.drop_caches()   # the freed dense weights' cache entries must not outlive them
         gc.collect()
 
     def _remove_hooks(self):

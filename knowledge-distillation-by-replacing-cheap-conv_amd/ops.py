@@ -363,6 +363,21 @@ def ce2d(x, target, ignore_index=255):
     return loss
 
 
+def confusion(x, target, conf=None, accumulate=False):
+    """conf (C,C) int64 [label][prediction] of argmax_c x vs target; pixels whose label is outside [0, C) are skipped."""
+    _need_cuda(x, target, conf)
+    vx, (N, Cc, P) = view3(x)
+    tgt = target.contiguous()
+    if tgt.dtype != torch.int64 or tgt.numel() != N * P:
+        raise ValueError("confusion: target must be int64 with one label per pixel")
+    if conf is None:
+        conf, accumulate = torch.empty((Cc, Cc), dtype=torch.int64, device=x.device), False
+    if conf.dtype != torch.int64 or tuple(conf.shape) != (Cc, Cc) or not conf.is_contiguous():
+        raise ValueError("confusion: conf must be a contiguous int64 (C, C) tensor")
+    check(_lib.lib().kd_confusion(C.byref(vx), _ptr(tgt), N, Cc, P, _ptr(conf), int(accumulate), stream_ptr()), "kd_confusion")
+    return conf
+
+
 def radam_step(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay):
     _need_cuda(p, g, m, v)
     for t in (p, g, m, v):

@@ -90,17 +90,56 @@ class GradReducer:
             torch.cuda.current_stream().wait_stream(self._stream)
 
 
-def init_distributed():
-    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run); returns (rank, local_rank, world)."""
+def init_distributed(use_cuda=None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run) and, when WORLD_SIZE > 1, creates the
+    process group once: backend "nccl" (= RCCL over xGMI) when the run uses the GPUs, "gloo" otherwise.  Idempotent --
+    ConfigParser, BaseTrainer and bench.py all call it.  Returns (rank, local_rank, world)."""
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if torch.cuda.is_available():
-            torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    elif torch.cuda.is_available():
+    cuda = torch.cuda.is_available() if use_cuda is None else (bool(use_cuda) and torch.cuda.is_available())
+    if cuda:
         torch.cuda.set_device(local)
+    if dist.is_initialized():
+        return dist.get_rank(), local, dist.get_world_size()
+    if world > 1:
+        dist.init_process_group(backend="nccl" if cuda else "gloo", rank=rank, world_size=world)
     return rank, local, world
+
+
+def _comm_device():
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def mean_scalar(value):
+    """Rank mean of a python number / 0-dim tensor (identity without a process group).  The trainers feed the result to
+    everything that steers control flow -- plateau LR scheduler, best-metric monitor, early stop -- so that all ranks
+    take the same decision from their different data shards."""
+    value = float(value)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=_comm_device())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item()) / dist.get_world_size()
+
+
+def broadcast_object(obj, src=0):
+    """Rank `src`'s picklable object on every rank (e.g. the run id that names the checkpoint directory)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src, device=_comm_device())
+    return box[0]
+
+
+def broadcast_module(module, src=0):
+    """Make every replica start from rank `src`'s parameters and buffers (freshly created cheap-conv blocks are drawn
+    from each process's own RNG)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            if dist.get_backend() == "nccl" and not t.is_cuda:
+                continue
+            dist.broadcast(t.data, src=src)

@@ -5,6 +5,7 @@ from functools import reduce
 
 import torch
 
+from ..parallel import mean_scalar
 from ..utils import MetricTracker
 from ..utils.optim.lr_scheduler import MyOneCycleLR, MyReduceLROnPlateau
 from .layerwise_trainer import _LOSS_KEYS, LayerwiseTrainer
@@ -51,6 +52,8 @@ class ClassificationTrainer(LayerwiseTrainer):
             for met in self.metric_ftns:
                 self.train_metrics.update(met.__name__, met(output_st, target), data.shape[0])
                 self.train_teacher_metrics.update(met.__name__, met(output_tc, target), data.shape[0])
+            if batch_idx % self.log_step == 0:
+                self.train_metrics.flush()
             if batch_idx % self.log_step == 0 and self.rank == 0:
                 self.logger.info('Train Epoch: {} [{}]/[{}] Loss: {:.6f} Supervised Loss: {:.6f} Knowledge Distillation '
                                  'loss: {:.6f} Hint Loss: {:.6f} Teacher Loss: {:.6f}'.format(
@@ -59,13 +62,14 @@ class ClassificationTrainer(LayerwiseTrainer):
                                      self.train_metrics.avg('hint_loss'), self.train_metrics.avg('teacher_loss')))
             if batch_idx == self.len_epoch:
                 break
+        self.train_metrics.flush()
         log = self.train_metrics.result()
         if self.do_validation and ((epoch % self.config["trainer"]["do_validation_interval"]) == 0):
             val_log = self._valid_epoch(epoch)
             log.update(**{'val_' + k: v for k, v in val_log.items()})
         if (self.lr_scheduler is not None) and (not isinstance(self.lr_scheduler, MyOneCycleLR)):
             if isinstance(self.lr_scheduler, MyReduceLROnPlateau):
-                self.lr_scheduler.step(self.train_metrics.avg('loss'))
+                self.lr_scheduler.step(mean_scalar(self.train_metrics.avg('loss')))
             else:
                 self.lr_scheduler.step()
         self.weight_scheduler.step()

@@ -16,6 +16,7 @@ from torch import nn
 
 from ..base import BaseTrainer
 from ..models import forgiving_state_restore
+from ..parallel import mean_scalar
 from ..utils import CityscapesMetricTracker, EarlyStopTracker, MetricTracker, inf_loop
 from ..utils import optim as optim_module
 from ..utils.optim.lr_scheduler import MyOneCycleLR, MyReduceLROnPlateau
@@ -135,7 +136,8 @@ class LayerwiseTrainer(BaseTrainer):
     def _attach_reducer(self):
         if self.world_size == 1 or self._reducer is not None:
             return
-        from ..parallel import GradReducer
+        from ..parallel import GradReducer, broadcast_module
+        broadcast_module(self.model.student)   # replicas start from rank 0's weights (new blocks come from each rank's RNG)
         if getattr(self.model, "fused", False):
             eng = self.model._student_engine()
             self._reducer = GradReducer(eng.grad_production_order())
@@ -225,6 +227,8 @@ class LayerwiseTrainer(BaseTrainer):
             for met in self.metric_ftns:
                 self.train_metrics.update(met.__name__, met(output_st, target))
 
+            if batch_idx % self.log_step == 0:
+                self.train_metrics.flush()   # buffered device scalars -> TensorBoard, one host sync per log point
             if batch_idx % self.log_step == 0 and self.rank == 0:
                 self.logger.info(
                     'Train Epoch: {} [{}]/[{}] Loss: {:.6f} mIoU: {:.6f} Teacher mIoU: {:.6f} Supervised Loss: {:.6f} '
@@ -236,6 +240,7 @@ class LayerwiseTrainer(BaseTrainer):
             if batch_idx == self.len_epoch:
                 break
 
+        self.train_metrics.flush()
         log = self.train_metrics.result()
         log.update({'train_teacher_mIoU': self.train_teacher_iou_metrics.get_iou()})
         log.update({'train_student_mIoU': self.train_iou_metrics.get_iou()})
@@ -248,7 +253,8 @@ class LayerwiseTrainer(BaseTrainer):
 
         if (self.lr_scheduler is not None) and (not isinstance(self.lr_scheduler, MyOneCycleLR)):
             if isinstance(self.lr_scheduler, MyReduceLROnPlateau):
-                self.lr_scheduler.step(self.train_metrics.avg('loss'))
+                # every rank sees its own shard's loss: decide on the rank mean so the replicas cut the LR together
+                self.lr_scheduler.step(mean_scalar(self.train_metrics.avg('loss')))
             else:
                 self.lr_scheduler.step()
         self.weight_scheduler.step()

@@ -41,14 +41,33 @@ class MetricTracker:
     def reset(self):
         self._total = {k: 0.0 for k in self._keys}
         self._count = {k: 0 for k in self._keys}
+        self._pending = []   # (key, writer mode, writer step, 0-dim device tensor) not yet sent to the writer
 
     def update(self, key, value, n=1):
+        """The reference pushes every update to TensorBoard immediately (utils/util.py:60-63), which for a device scalar
+        is a host sync per logged key per step.  Device scalars are buffered with the writer's current step instead and
+        flush() sends them all with ONE stacked device->host copy (at log points / epoch end)."""
         if torch.is_tensor(value):
             value = value.detach().float()
-        if self.writer is not None and not torch.is_tensor(value):
+            if self.writer is not None:
+                self._pending.append((key, getattr(self.writer, 'mode', ''), getattr(self.writer, 'step', 0), value))
+        elif self.writer is not None:
             self.writer.add_scalar(key, value)
         self._total[key] = self._total[key] + value * n
         self._count[key] += n
+
+    def flush(self):
+        if not self._pending:
+            return
+        pend, self._pending = self._pending, []
+        vals = torch.stack([p[3].reshape(()) for p in pend]).cpu().tolist()
+        keep = (getattr(self.writer, 'mode', ''), getattr(self.writer, 'step', 0))
+        for (key, mode, step, _), v in zip(pend, vals):
+            if hasattr(self.writer, 'mode'):
+                self.writer.mode, self.writer.step = mode, step
+            self.writer.add_scalar(key, v)
+        if hasattr(self.writer, 'mode'):
+            self.writer.mode, self.writer.step = keep
 
     def avg(self, key):
         c = self._count[key]
@@ -78,8 +97,20 @@ class CityscapesMetricTracker:
     def update(self, outputs, labels):
         """outputs (N,C,H,W) logits on any device, labels (N,H,W); stays on the outputs' device. Does NOT modify labels
         (the reference rewrites 255 -> 19 in the caller's tensor)."""
-        pred = torch.argmax(outputs.detach(), dim=1).reshape(-1)
-        tgt = labels.to(pred.device).reshape(-1)
+        outputs = outputs.detach()
+        if outputs.is_cuda:
+            # one fused HIP pass (argmax + int64 histogram, kd_confusion): exact, no temporaries, no host transfer
+            from .. import ops
+            if outputs.shape[1] != self.num_classes:
+                raise ValueError(f"expected {self.num_classes}-class logits, got {outputs.shape[1]} channels")
+            tgt = labels.to(device=outputs.device, dtype=torch.int64)
+            if self.conf is None:
+                self.conf = torch.zeros((self.num_classes, self.num_classes), dtype=torch.int64, device=outputs.device)
+            ops.confusion(outputs, tgt, self.conf, accumulate=True)
+            return
+        # host tensors (n_gpu = 0 runs): the reference's own numpy recipe, in torch
+        pred = torch.argmax(outputs, dim=1).reshape(-1)
+        tgt = labels.reshape(-1)
         mask = (tgt >= 0) & (tgt < self.num_classes)
         idx = self.num_classes * tgt[mask].long() + pred[mask]
         hist = torch.bincount(idx, minlength=self.num_classes ** 2).reshape(self.num_classes, self.num_classes)

@@ -175,6 +175,28 @@ def ce2d(x, target, ignore_index=255):
     return lib().orc_ce2d(_p(x), tgt.ctypes.data_as(_i64), ignore_index, N, C, HW)
 
 
+def confusion(x, target, ignore_index=255, conf=None):
+    """(C, C) int64 confusion matrix [label][argmax prediction]; accumulates into `conf` when given."""
+    x = _c(x)
+    N, C = x.shape[:2]
+    t = np.ascontiguousarray(target, dtype=np.int64)
+    if conf is None:
+        conf = np.zeros((C, C), np.int64)
+    lib().orc_confusion(_p(x), t.ctypes.data_as(_i64), ctypes.c_int64(ignore_index), N, C, int(np.prod(x.shape[2:])),
+                        conf.ctypes.data_as(_i64))
+    return conf
+
+
+def miou(conf):
+    """CityscapesMetricTracker.get_iou (utils/util.py:113-118)."""
+    conf = np.asarray(conf, np.float64)
+    if not conf.any():
+        return 1.0
+    tp = np.diag(conf)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return float(np.nanmean(tp / (conf.sum(0) + conf.sum(1) - tp)))
+
+
 def radam_step(p, g, m, v, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
     """In-place on p, m, v (float32 contiguous)."""
     lib().orc_radam_step(_p(p), _p(_c(g)), _p(m), _p(v), ctypes.c_size_t(p.size), int(step),

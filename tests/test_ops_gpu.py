@@ -71,6 +71,11 @@ CONV_CASES = [
     (1, 224, 256, 64, 256, 3, 1, 36, 36),    # ASPP rate 36: the 384-row buffer (all 160 KiB of LDS)
     (1, 12, 256, 64, 128, 3, 1, 1, 1),       # narrow row-buffer kernel (bf16; fp32 takes the gather kernel)
     (1, 10, 512, 128, 64, 3, 1, 2, 2),
+    # gathered-A 256x256 tiles (CfgWide / CfgWideF): Cout > 128 and >= 224 wide tiles, 1x1 / stride-2 / W % 256 != 0
+    (1, 112, 512, 64, 256, 1, 1, 0, 1),      # 1x1: 224 x 1 tiles, K = one 128-B stage (bf16) / two (f32)
+    (2, 57, 509, 128, 512, 1, 1, 0, 1),      # 1x1: ragged last M tile, two N tiles, several K stages
+    (1, 224, 1024, 64, 256, 3, 2, 1, 1),     # stride-2 3x3 (the mod4.block1 class) on wide tiles
+    (1, 120, 480, 64, 320, 3, 1, 2, 2),      # 3x3 whose rows are not tile segments: gathered im2col with border taps, ragged Cout
 ]
 
 
@@ -109,6 +114,64 @@ def test_conv_epilogue_forward(K, dt):
     assert_close(host_nchw(out_raw), raw_ref, dt, "raw")
     assert_close(host_nchw(out_act), act_ref, dt, "act")
     assert float(wide[..., :Cout].abs().max()) == 0 and float(wide[..., 2 * Cout:].abs().max()) == 0
+
+
+WIDE_EPI_CASES = [
+    # N, H, W, Cin, Cout, k, pad, dil -- every one selects a 256 x 256 tile config (>= 224 wide tiles, Cout > 128)
+    (1, 112, 512, 64, 256, 1, 0, 1),      # gathered 1x1 (CfgWide, pipelined loop in bf16)
+    (1, 112, 512, 64, 256, 3, 1, 1),      # row-buffer 3x3 (CfgRow)
+    (1, 120, 480, 64, 256, 3, 2, 2),      # gathered 3x3 (CfgWide), ragged last M tile
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("raw_f32", [False, True])
+@pytest.mark.parametrize("case", WIDE_EPI_CASES)
+def test_conv_wide_tile_full_epilogue(K, dt, raw_f32, case):
+    """The wide-tile epilogue (bf16: the batched EB=4 operand loads) with every operand set at once:
+    v = acc + res_pre; v = mask > 0 ? v * mask_scale : 0; v += res_post; out_raw = v (bf16 or fp32);
+    out_act = relu(v * act_scale + act_shift) -- operands and outputs are channel slices of wider buffers."""
+    N, H, W, Cin, Cout, k, p, d = case
+    if raw_f32 and dt == "f32":
+        pytest.skip("raw_f32 only differs from the plain output on the bf16 path")
+    x = q(rnd(N, Cin, H, W), dt)
+    w = q(rnd(Cout, Cin, k, k, scale=(2.0 / (Cin * k * k)) ** 0.5), dt)
+    pre, post = q(rnd(N, Cout, H, W), dt), q(rnd(N, Cout, H, W), dt)
+    mask = q(np.maximum(rnd(N, Cout, H, W), 0), dt)
+    mscale, ascale, ashift = rnd(Cout) * 0.2 + 1.0, rnd(Cout) * 0.2 + 1.0, rnd(Cout) * 0.3
+    bc = lambda v: v[None, :, None, None]
+    raw_ref = np.where(mask > 0, (orc.conv2d_fwd(x, w, pad=p, dil=d) + pre) * bc(mscale), 0.0) + post
+    act_ref = np.maximum(raw_ref * bc(ascale) + bc(ashift), 0)
+    wp = K.pack_conv_weight(torch.from_numpy(w).cuda(), DT[dt])
+    out_raw = torch.zeros((N, H, W, Cout + 32), dtype=torch.float32 if raw_f32 else DT[dt], device="cuda")[..., 16:16 + Cout]
+    out_act = torch.zeros((N, H, W, 2 * Cout), dtype=DT[dt], device="cuda")[..., Cout:]
+    cu = lambda v: torch.from_numpy(v).cuda()
+    K.conv2d(dev_nhwc(x, dt), wp, 1, p, d, res_pre=dev_nhwc(pre, dt, ld=Cout + 16), mask=dev_nhwc(mask, dt),
+             mask_scale=cu(mscale), res_post=dev_nhwc(post, dt, ld=Cout + 24), out_raw=out_raw, out_act=out_act,
+             act_scale=cu(ascale), act_shift=cu(ashift), act_relu=True)
+    assert_close(host_nchw(out_raw), raw_ref, dt, f"raw {case}")
+    # the activated output is derived from the unrounded value; compare against the oracle chain directly
+    assert_close(host_nchw(out_act), act_ref, dt, f"act {case}")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv_wide_tile_dgrad_epilogue(K, dt):
+    """Backward use of the wide tiles: dgrad (KD_PACK_DGRAD weights) of a 3x3 dil-2 conv on row-buffer tiles and of a 1x1 on
+    gathered tiles, with the ReLU/BN mask and the shortcut gradient (res_post), plus res_pre (projection-path gradient)."""
+    from kdcc_amd._lib import KD_PACK_DGRAD
+    for (N, H, W, Cin, Cout, k, p, d) in [(1, 112, 512, 256, 64, 3, 2, 2), (1, 112, 512, 256, 128, 1, 0, 1)]:
+        w = q(rnd(Cout, Cin, k, k, scale=0.05), dt)
+        gy = q(rnd(N, Cout, H, W), dt)
+        act = q(np.maximum(rnd(N, Cin, H, W), 0), dt)
+        bn_scale = rnd(Cin) * 0.2 + 1.0
+        short, proj = q(rnd(N, Cin, H, W), dt), q(rnd(N, Cin, H, W), dt)
+        ref = orc.conv2d_dgrad(gy, w, (N, Cin, H, W), pad=p, dil=d) + proj
+        ref = np.where(act > 0, ref * bn_scale[None, :, None, None], 0) + short
+        wp = K.pack_conv_weight(torch.from_numpy(w).cuda(), DT[dt], KD_PACK_DGRAD)
+        out = torch.empty((N, H, W, Cin), dtype=DT[dt], device="cuda")
+        K.conv2d(dev_nhwc(gy, dt), wp, 1, d * (k - 1) - p, d, res_pre=dev_nhwc(proj, dt), mask=dev_nhwc(act, dt),
+                 mask_scale=torch.from_numpy(bn_scale).cuda(), res_post=dev_nhwc(short, dt), out_raw=out)
+        assert_close(host_nchw(out), ref, dt, f"wide dgrad k={k}")
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
@@ -322,3 +385,25 @@ def test_errors_are_loud(K):
         K.conv2d(x, w, out_raw=torch.empty((1, 4, 4, 32), device="cuda"))
     with pytest.raises(KdccError):
         K.conv2d(torch.zeros((1, 4, 4, 64)), torch.zeros((32, 1, 1, 64)), out_raw=torch.empty((1, 4, 4, 32)))  # CPU tensors
+
+
+def test_confusion_exact(K, golden):
+    """kd_confusion == the reference's accumulated confusion matrix, bit for bit (int64), for NCHW fp32 logits, the
+    engine's NHWC layout, bf16 logits (vs the integer oracle on the rounded values) and a ragged large case."""
+    g = golden("confusion")
+    conf = None
+    for x, t in zip(g["x"], g["target"]):
+        xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(t.astype(np.int64)).cuda()
+        conf = K.confusion(xd, td, conf, accumulate=conf is not None)
+    assert conf.dtype == torch.int64 and np.array_equal(conf.cpu().numpy(), g["conf"])
+    conf2 = torch.zeros((19, 19), dtype=torch.int64, device="cuda")
+    for x, t in zip(g["x"], g["target"]):
+        xd = torch.from_numpy(x).cuda().contiguous(memory_format=torch.channels_last)
+        K.confusion(xd, torch.from_numpy(t.astype(np.int64)).cuda(), conf2, accumulate=True)
+    assert np.array_equal(conf2.cpu().numpy(), g["conf"])
+    # bf16 NHWC logits, pixel count not a multiple of the block, labels outside [0, C) other than 255
+    x = q(rnd(3, 19, 37, 53), "bf16")
+    t = RNG.integers(-1, 21, (3, 37, 53)).astype(np.int64)
+    t[:, :2] = 255
+    got = K.confusion(dev_nhwc(x, "bf16").permute(0, 3, 1, 2), torch.from_numpy(t).cuda())
+    assert np.array_equal(got.cpu().numpy(), orc.confusion(x, t))

@@ -101,3 +101,35 @@ def test_radam(golden):
     for i in range(8):
         orc.radam_step(p, g["g"][i], m, v, step=i + 1, lr=float(g["lr"]))
         close(p, g["p"][i + 1], rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["id2_d1", "proj2_s2", "proj2_d2", "bott_d4"])
+def test_resblock_golden(golden, tag):
+    """IdentityResidualBlock (eval BN, identity / projection shortcut, stride 2, dilation 2 / 4, bottleneck): the block
+    restated from oracle.c ops (tests/_blockref.py) reproduces the reference's output and input gradient."""
+    from _blockref import RESBLOCK_CASES, resblock_fwd_bwd
+    g = golden("resblock")
+    cin, ch, stride, dil = RESBLOCK_CASES[tag]
+    assert [int(v) for v in g[f"{tag}.cfg"]] == [cin, stride, dil, len(ch)] + list(ch)
+    y, gx = resblock_fwd_bwd(tag, g[f"{tag}.x"], g[f"{tag}.gy"])
+    close(y, g[f"{tag}.y"], rtol=1e-4, atol=1e-5)
+    close(gx, g[f"{tag}.gx"], rtol=1e-4, atol=1e-5)
+
+
+def test_aspp_golden(golden):
+    """ASPP module (image pooling + 1x1 + rates 12/24/36, BN-eval + ReLU, concat) vs the reference's output."""
+    from _blockref import aspp_fwd
+    g = golden("aspp")
+    close(aspp_fwd(g["x"]), g["y"], rtol=1e-4, atol=1e-5)
+
+
+def test_confusion_golden(golden):
+    """Integer work: the 19x19 confusion matrix accumulated over two CityscapesMetricTracker.update() calls, bit-exact
+    (ignore band, exact logit ties -> first maximum, a never-predicted and a never-labelled class), and get_iou()."""
+    g = golden("confusion")
+    conf = None
+    for x, t in zip(g["x"], g["target"]):
+        conf = orc.confusion(x, t.astype(np.int64), 255, conf)
+    assert conf.dtype == np.int64 and np.array_equal(conf, g["conf"])
+    assert conf[:, 17].sum() == 0 and conf[16].sum() == 0
+    close(orc.miou(conf), g["miou"], rtol=1e-12)

@@ -153,3 +153,75 @@ def test_weighted_hint_step_vs_network_oracle():
             ref = r["grads"][n].numpy().astype(np.float64)
             got = p.grad.cpu().numpy().astype(np.float64)
             assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-3, n
+
+
+def test_torch_teacher_backend_step_matches_reference(golden):
+    """The split north_star describes: frozen teacher as a PyTorch-ROCm module (MIOpen) on a side HIP stream with
+    record_stream hand-over, student on the HIP engine; same golden as the default (engine-teacher) path."""
+    import os
+    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+    from kdcc_amd import losses
+    g = golden("student_step_g4")
+    plan = [str(s) for s in g["plan"]]
+    model = build_model(plan, torch.float32)
+    model.teacher_backend = "torch"
+    model.overlap_teacher = True
+    x = seeded_input(str(g["x_key"]), (2, 3, 64, 128)).cuda()
+    out_st, out_tc = model(x)
+    assert model._side_stream is not None            # the teacher really ran on the side stream
+    crit = losses.MSELoss(num_classes=1000)
+    hint = 0
+    for s, t in zip(model.student_hidden_outputs, model.teacher_hidden_outputs):
+        hint = hint + crit(s, t)
+    hint.backward()
+    torch.cuda.synchronize()
+    check_summary(out_tc, g, "teacher_logits", 1e-3, "teacher logits (PyTorch-ROCm, side stream)")
+    check_summary(out_st, g, "student_logits", 1e-3, "student logits")
+    assert len(model.teacher_hidden_outputs) == len(plan)
+    for i, t in enumerate(model.teacher_hidden_outputs):
+        check_summary(t, g, f"hint_t{i}", 1e-3, f"teacher hint {i} (hooked PyTorch module)")
+    np.testing.assert_allclose(hint.item(), float(g["hint_loss"]), rtol=1e-3)
+    for n, p in model.student.named_parameters():
+        if p.requires_grad:
+            check_summary(p.grad, g, f"grad:{n}", 1e-3, f"grad {n}", allow_kinks=True)
+
+
+def test_p92_step_midsize_vs_network_oracle():
+    """BASELINE config 2's plan (P92, six cheap-conv blocks incl. all three ASPP branches) forward + hint-loss backward at
+    256x512, fp32, against the network-level CPU oracle (oracle/net_ref.py): logits, every hint, loss, every gradient."""
+    from kdcc_amd import losses
+    from oracle import net_ref
+    from _netutil import seeded_cheap_weights, seeded_teacher_sd
+    plan = ["mod4.block2.convs.conv2", "mod4.block3.convs.conv1", "mod7.block1.convs.conv2",
+            "aspp.features.1.0", "aspp.features.2.0", "aspp.features.3.0"]
+    model = build_model(plan, torch.float32)
+    x = seeded_input("p92mid.x", (1, 3, 256, 512))
+    out_st, out_tc = model(x.cuda())
+    crit = losses.MSELoss(num_classes=1000)
+    hint = 0
+    for s, t in zip(model.student_hidden_outputs, model.teacher_hidden_outputs):
+        hint = hint + crit(s, t)
+    hint.backward()
+    torch.cuda.synchronize()
+    tsd = seeded_teacher_sd()
+    ssd = net_ref.make_student_sd(tsd, plan, seeded_cheap_weights(tsd, plan))
+    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    r = net_ref.kd_step(tsd, ssd, x, None, plan)
+    assert model.student_hint_names == r["hint_names"]
+    np.testing.assert_allclose(hint.item(), r["hint_loss"].item(), rtol=1e-3)
+
+    def relerr(got, ref):
+        got, ref = got.detach().float().cpu().numpy().astype(np.float64), ref.numpy().astype(np.float64)
+        return np.abs(got - ref).max() / np.abs(ref).max(), np.linalg.norm(got - ref) / np.linalg.norm(ref)
+    for name, got, ref in [("student logits", out_st, r["student_logits"]), ("teacher logits", out_tc, r["teacher_logits"])]:
+        mx, l2 = relerr(got, ref)
+        assert mx < 1e-3 and l2 < 1e-3, (name, mx, l2)
+    for i, (s, t) in enumerate(zip(model.student_hidden_outputs, model.teacher_hidden_outputs)):
+        assert relerr(s, r["student_hints"][i])[0] < 1e-3, f"student hint {i}"
+        assert relerr(t, r["teacher_hints"][i])[0] < 1e-3, f"teacher hint {i}"
+    n_grads = 0
+    for n, p in model.student.named_parameters():
+        if p.requires_grad:
+            n_grads += 1
+            assert relerr(p.grad, r["grads"][n])[1] < 1e-3, n
+    assert n_grads == 12

@@ -383,6 +383,25 @@ def g_classification_epoch():
     save("classification_epoch", **out)
 
 
+def g_confusion():
+    """utils/util.py:73-128 CityscapesMetricTracker: two update() calls on seeded logits / labels (ignore band, exact ties,
+    a class that never occurs) -> the accumulated 19x19 confusion matrix and get_iou()."""
+    from utils.util import CityscapesMetricTracker
+    tr = CityscapesMetricTracker()
+    xs, ts = [], []
+    for i in range(2):
+        x = seeded_input(f"conf.x{i}", (2, 19, 24, 40))
+        x[:, 17] = -100.0                       # class 17 is never predicted
+        x[0, 3, :4] = x[0, 5, :4]               # exact ties: argmax must take the first maximum
+        x[0, 3, :4] += 50.0; x[0, 5, :4] += 50.0
+        t = torch.randint(0, 19, (2, 24, 40), generator=torch.Generator().manual_seed(40 + i))
+        t[t == 16] = 3                          # class 16 never occurs as a label
+        t[:, :3] = 255
+        xs.append(x.numpy().copy()); ts.append(t.numpy().astype(np.uint8))
+        tr.update(x.clone(), t.clone())         # (update rewrites 255 -> 19 in the tensor it is given)
+    save("confusion", x=np.stack(xs), target=np.stack(ts), conf=tr.conf.astype(np.int64), miou=np.float64(tr.get_iou()))
+
+
 def g_keys():
     """State-dict key / shape inventory of the reference's DeepWV3Plus(19) (the checkpoint contract)."""
     import json
@@ -395,7 +414,7 @@ def g_keys():
     print("wrote", path, len(inv), "entries", sum(int(np.prod(v)) for k, v in inv.items() if "num_batches" not in k and "running" not in k), "params")
 
 
-ALL = dict(keys=g_keys, trainer_epoch=g_trainer_epoch, classification_epoch=g_classification_epoch, losses=g_losses, dwsep=g_dwsep, resblock=g_resblock, aspp=g_aspp, ops=g_ops, radam=g_radam,
+ALL = dict(keys=g_keys, confusion=g_confusion, trainer_epoch=g_trainer_epoch, classification_epoch=g_classification_epoch, losses=g_losses, dwsep=g_dwsep, resblock=g_resblock, aspp=g_aspp, ops=g_ops, radam=g_radam,
            student_step=g_student_step)
 
 if __name__ == "__main__":
