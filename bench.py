@@ -67,17 +67,46 @@ def kd_step(model, crit, opt, data, target):
     return loss, sup, kd, tl
 
 
-def cpu_baseline(cpu_sd, model, plan, hw=(512, 1024)):
-    """The network-level oracle (stock torch CPU ops, fp32) timed on this box's host cores on a bounded sample."""
-    from oracle import net_ref
-    # the box's CPU share, not the host's core count (oversubscribed OpenMP threads spin for minutes)
+def cpu_share():
+    """Host cores this process can actually use: the affinity mask, cut to the cgroup CPU quota when there is one.  A GPU
+    box exposes all 256 host cores in the mask but schedules a one-GPU job on a 16-core share; OpenMP threads beyond the
+    share only spin (a 256-thread run of the CPU step did not finish in 7 minutes), so without a readable quota a mask
+    wider than 32 cores is taken to be that case and 16 is used."""
     try:
-        threads = len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        threads = os.cpu_count() or 1
-    threads = max(1, min(threads, 16))
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2: "<quota|max> <period>"
+            q, per = f.read().split()
+            if q != "max":
+                quota = max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = int(f.read()), int(g.read())
+                if q > 0:
+                    quota = max(1, q // per)
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        return max(1, min(n, quota))
+    return n if n <= 32 else 16
+
+
+def cpu_baseline(cpu_sd, model, plan, full=False):
+    """The network-level oracle (stock torch CPU ops, fp32) timed on this box's host cores.
+
+    Default: a BOUNDED sample -- one 512x1024 step (a quarter of the pixels, ~15-30 s), scaled by pixel count -- so that the
+    default bench run finishes in minutes.  full=True (--cpu-baseline full) is BASELINE.md section 3's recipe: 1 warm-up +
+    2 timed steps at 1024x2048 (~1-2 min each) plus 5 timed steps at 256x512 for the linear-in-pixels check."""
+    from oracle import net_ref
+    threads = cpu_share()
     torch.set_num_threads(threads)
-    print(f"[bench] cpu_baseline: oracle/net_ref.py on {threads} host threads, one {hw[0]}x{hw[1]} step ...", file=sys.stderr, flush=True)
+    hw = (1024, 2048) if full else (512, 1024)
+    print(f"[bench] cpu_baseline: oracle/net_ref.py on {threads} host threads (os.cpu_count() = {os.cpu_count()}), "
+          f"{'1 warm-up + 2 timed' if full else 'one'} {hw[0]}x{hw[1]} step(s) ...", file=sys.stderr, flush=True)
     new = {}
     for n in plan:
         blk = model.get_block(n, model.student)
@@ -87,15 +116,33 @@ def cpu_baseline(cpu_sd, model, plan, hw=(512, 1024)):
     g = torch.Generator().manual_seed(1000)
     x = torch.randn((1, 3) + hw, generator=g)
     tgt = torch.randint(0, 19, (1,) + hw, generator=g)
+    def timed(xx, tt, reps):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            net_ref.kd_step(cpu_sd, ssd, xx, tt, plan)
+            ts.append(time.perf_counter() - t0)
+            print(f"[bench] cpu_baseline: {tuple(xx.shape[2:])} step {ts[-1]:.2f} s", file=sys.stderr, flush=True)
+        return ts
+
+    if full:
+        timed(x, tgt, 1)                                   # warm-up at full size
+        ts = timed(x, tgt, 2)
+        small = timed(x[:, :, :256, :512].contiguous(), tgt[:, :256, :512].contiguous(), 5)
+        dt = sum(ts) / len(ts)
+        return {"value": 1.0 / dt, "unit": "images/sec", "cores": threads, "host_cpu_count": os.cpu_count(), "kind": "port",
+                "sample": f"BASELINE.md section 3: 1 warm-up + 2 timed KD steps (teacher fwd + student fwd + hint bwd, fp32 torch "
+                          f"CPU ops = oracle/net_ref.py) at 1024x2048, {ts[0]:.1f} / {ts[1]:.1f} s; 5 steps at 256x512: "
+                          f"{sum(small) / len(small):.2f} s mean = {16 * sum(small) / len(small):.1f} s per full-size image equivalent",
+                "steps_s": ts, "steps_256x512_s": small}
     net_ref.kd_step(cpu_sd, ssd, x[:, :, :64, :128].contiguous(), tgt[:, :64, :128].contiguous(), plan)  # warm-up
-    t0 = time.perf_counter()
-    net_ref.kd_step(cpu_sd, ssd, x, tgt, plan)
-    dt = time.perf_counter() - t0
-    print(f"[bench] cpu_baseline: {dt:.2f} s", file=sys.stderr, flush=True)
+    dt = timed(x, tgt, 1)[0]
     frac = (hw[0] * hw[1]) / (1024.0 * 2048.0)
-    return {"value": frac / dt, "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"1 KD step (teacher fwd + student fwd + hint bwd, fp32 torch CPU ops = oracle/net_ref.py) at "
-                      f"{hw[0]}x{hw[1]} = {frac:.4f} of a 1024x2048 image, {dt:.2f} s; value = that fraction / time"}
+    return {"value": frac / dt, "unit": "images/sec", "cores": threads, "host_cpu_count": os.cpu_count(), "kind": "port",
+            "sample": f"bounded sample (the bench must finish in minutes; --cpu-baseline full runs BASELINE.md section 3's 1+2 "
+                      f"full-size steps): 1 KD step (teacher fwd + student fwd + hint bwd, fp32 torch CPU ops = "
+                      f"oracle/net_ref.py) at {hw[0]}x{hw[1]} = {frac:.4f} of a 1024x2048 image, {dt:.2f} s; value = that "
+                      f"fraction / time (the CPU step is linear in pixels: DESIGN.md section 5)"}
 
 
 def conv_traffic(plan, batch, height, width, dtype):
@@ -122,7 +169,11 @@ def main():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="run the teacher on the main stream")
+    ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full"],
+                    help="sample: one 512x1024 CPU step scaled by pixels (default, bounded); full: BASELINE.md section 3 "
+                         "(1 warm-up + 2 steps at 1024x2048 + 5 steps at 256x512; several minutes)")
+    ap.add_argument("--no-batch-sweep", action="store_true", help="skip the 1 and 2 images/GPU side measurements")
+    ap.add_argument("--no-overlap", action="store_true", help="with --teacher torch: run the teacher on the main stream")
     ap.add_argument("--ref-logging", action="store_true",
                     help="also do the reference's per-step host syncs (five .item() calls, layerwise_trainer.py:244-250); the "
                          "default measures the step without them, as this trainer runs it (metrics stay on the device)")
@@ -177,6 +228,29 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
+    # SURVEY 8(d) defines the metric at 1 and 2 images per GPU; the headline uses --batch (fuller grids).  Measure both
+    # side by side (short: 2 warm-up + 8 timed steps each) so one record carries all three.
+    sweep = {}
+    if not a.no_batch_sweep:
+        for nb in (1, 2):
+            if nb >= a.batch:
+                continue
+            d_, t_ = data[:nb].contiguous(), target[:nb].contiguous()
+            for _ in range(2):
+                kd_step(model, crit, opt, d_, t_)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(8):
+                kd_step(model, crit, opt, d_, t_)
+            sync()
+            d1 = time.perf_counter() - t1
+            if world > 1:
+                tt = torch.tensor([d1], device=device, dtype=torch.float64)
+                torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+                d1 = float(tt.item())
+            sweep[str(nb)] = {"images_per_sec": world * nb * 8 / d1, "ms_per_step": d1 / 8 * 1e3, "steps": 8}
+
+    overlapped = bool(model.overlap_teacher) and a.teacher == "torch"   # the engine teacher runs in stream order
     if rank == 0:
         # dominant kernel: the implicit-GEMM conv; live HIP-event timing of every launch on its launching stream
         flops = sum(p[1] for p in prof)
@@ -192,8 +266,9 @@ def main():
                                    f"RAdam), DeepLabV3+(WRN-38) student plan {a.plan} ({len(plan)} cheap-conv blocks, 9x9 d5), "
                                    f"{a.height}x{a.width}, {a.batch} image/GPU, random-init weights",
                        "plan": a.plan, "per_gpu_batch": a.batch, "global_batch": world * a.batch,
-                       "parallelism": f"dp{world}", "teacher_overlap": bool(model.overlap_teacher),
-                       "teacher_backend": a.teacher, "per_step_host_syncs": bool(a.ref_logging)},
+                       "parallelism": f"dp{world}", "teacher_overlap": overlapped,
+                       "teacher_backend": a.teacher, "per_step_host_syncs": bool(a.ref_logging),
+                       "per_gpu_batch_sweep": sweep},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_row_kernel + conv_igemm_kernel (dense conv fwd + dgrad, student" + (" + teacher)" if a.teacher == "hip" else ")"), "achieved": ach,
                          "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": conv_traffic(a.plan, a.batch, a.height, a.width, a.dtype),
@@ -205,7 +280,7 @@ def main():
             "losses": {"hint": float(loss.detach()), "supervised": float(sup), "kd": float(kd), "teacher": float(tl)},
         }
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(cpu_sd, model, plan)
+            res["cpu_baseline"] = cpu_baseline(cpu_sd, model, plan, full=a.cpu_baseline == "full")
         print(json.dumps(res))
     if world > 1:
         torch.distributed.destroy_process_group()

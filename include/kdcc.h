@@ -116,6 +116,18 @@ int kd_pw_wgrad(int32_t dtype, int32_t M, int32_t Cin, int32_t Cout,
                 float *dw, int32_t accumulate, void *workspace, size_t workspace_bytes,
                 kd_stream_t stream);
 
+/* Weight gradient of a general convolution (autograd of nn.Conv2d w.r.t. its weight, reached from loss.backward(),
+ * trainer/layerwise_trainer.py:235 / trainer/classification_trainer.py:39, whenever a dense conv of the student is
+ * trainable: `pruning.unfreeze` naming a dense block, models/students/depthwise_student.py:80-84, or the "identical
+ * architecture" branch that unfreezes everything, layerwise_trainer.py:88-100):
+ *   dw[co][ci][ky][kx] = sum_{n,ho,wo} dy[n,ho,wo,co] * x[n, ho*stride - pad + ky*dil, wo*stride - pad + kx*dil, ci]
+ * fp32 (Cout, Cin, kh, kw) like the reference's .grad; d describes the forward conv (x view N,H,W,Cin with stride ldx;
+ * dy view N,Ho,Wo,Cout with stride ld_dy).  One TN GEMM per tap over pixel splits, partial slabs in the workspace,
+ * fixed-order reduction (deterministic).  Cin, Cout: any (multiples of 8 take the LDS-DMA path in bf16). */
+size_t kd_conv2d_wgrad_workspace(const kd_conv_desc *d);
+int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void *dy, int32_t ld_dy, float *dw,
+                    int32_t accumulate, void *workspace, size_t workspace_bytes, kd_stream_t stream);
+
 /* ------------------------------------------------------------ depthwise conv
  * `separable_conv` of depthwise_separable_conv.py:7-8: Conv2d(C, C, k,
  * padding, dilation, groups=C), stride 1 (9x9 / dilation 5 / padding 20 in
@@ -178,6 +190,48 @@ size_t kd_aspp_image_pool_workspace(int32_t N, int32_t Cin, int32_t Cout);
 int kd_aspp_image_pool(int32_t dtype, const void *x, int32_t ldx, const float *w, const float *scale,
                        const float *shift, void *y, int32_t ldy, int32_t N, int32_t H, int32_t W,
                        int32_t Cin, int32_t Cout, void *workspace, size_t workspace_bytes, kd_stream_t stream);
+
+/* ------------------------------------------------- backward of the trunk plumbing
+ * (autograd of the calls above; needed once gradients flow through the whole student: loss = kd + hint with every
+ * parameter trainable, or hints taken behind a BN+ReLU such as the `aspp` module output).
+ *
+ * kd_stem_wgrad: weight gradient of mod1.conv1 (wider_resnet.py:307-309) from the trainer's NCHW fp32 batch:
+ *   dw (64,3,3,3) fp32 = sum_pixels dy[n,h,w,:] (x) x[n,:,h-1+ky,w-1+kx].
+ * kd_maxpool3x3s2_bwd: gx[n,h,w,c] = sum of gy over the (<= 4) windows whose first maximum is (h,w)
+ *   (nn.MaxPool2d(3,2,1) backward, wider_resnet.py:353-356); x is the pool's input.
+ * kd_upsample_bilinear_ac_bwd: transpose of kd_upsample_bilinear_ac (deeplabv3.py:16-18,155,160): gy (N,Ho,Wo,C) ->
+ *   gx (N,H,W,C); separable gather, workspace = one (N,Ho,W,C) float plane.
+ * kd_zero_insert: y[n, h*stride, w*stride, :] = x[n,h,w,:], zeros elsewhere (Hy x Wy output): turns the input gradient
+ *   of a stride-s conv (mod4.block1, wider_resnet.py:322-332) into a stride-1 kd_conv2d_fwd with KD_PACK_DGRAD weights.
+ * kd_relu_bn_bwd: y = (mask > 0 ? g * scale[c] : 0) + res -- d relu(bn_eval(x))/dx applied to a gradient that arrives
+ *   behind the activation (wider_resnet.py:43-48); res may be NULL.
+ * kd_channel_sums: s1[b][c] = sum_m (g - sub)[m][c], s2[b][c] = sum_m (g - sub)[m][c] * a[m][c] over `groups` groups of
+ *   rows_per_group consecutive rows (sub, a, s2 optional); float (groups, C); two fixed-order stages.
+ * kd_bn_eval_param_grads: eval-mode BatchNorm2d weight / bias gradients from those sums of the gradient w.r.t. the BN
+ *   input: dbeta = s1/scale, dgamma = (s2 - beta*s1)/(scale*gamma)   (scale = gamma/sqrt(var+eps), s2 taken against
+ *   relu(bn(x)); masked elements carry zero gradient).
+ * kd_broadcast_add: y[n,p,c] = (accumulate ? y : 0) + alpha * v[n,c] (backward of the ASPP image-pooling broadcast). */
+size_t kd_stem_wgrad_workspace(int32_t N, int32_t H, int32_t W);
+int kd_stem_wgrad(int32_t dtype, const float *x_nchw, const void *dy, int32_t ld_dy, float *dw, int32_t N, int32_t H,
+                  int32_t W, int32_t accumulate, void *workspace, size_t workspace_bytes, kd_stream_t stream);
+int kd_maxpool3x3s2_bwd(int32_t dtype, const void *x, int32_t ldx, const void *gy, int32_t ldgy, void *gx, int32_t ldgx,
+                        int32_t N, int32_t H, int32_t W, int32_t C, kd_stream_t stream);
+size_t kd_upsample_bilinear_ac_bwd_workspace(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo);
+int kd_upsample_bilinear_ac_bwd(const void *gy, int32_t gy_dtype, int32_t ldgy, void *gx, int32_t gx_dtype, int32_t ldgx,
+                                int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
+                                void *workspace, size_t workspace_bytes, kd_stream_t stream);
+int kd_zero_insert(int32_t dtype, const void *x, int32_t ldx, void *y, int32_t ldy, int32_t N, int32_t H, int32_t W,
+                   int32_t C, int32_t stride, int32_t Hy, int32_t Wy, kd_stream_t stream);
+int kd_relu_bn_bwd(int32_t dtype, const void *g, int32_t ldg, const void *mask, int32_t ldm, const float *scale,
+                   const void *res, int32_t ldres, void *y, int32_t ldy, int64_t M, int32_t C, kd_stream_t stream);
+size_t kd_channel_sums_workspace(int32_t groups, int64_t rows_per_group, int32_t C);
+int kd_channel_sums(int32_t dtype, const void *g, int32_t ldg, const void *sub, int32_t ldsub, const void *a, int32_t lda,
+                    int32_t groups, int64_t rows_per_group, int32_t C, float *s1, float *s2,
+                    void *workspace, size_t workspace_bytes, kd_stream_t stream);
+int kd_bn_eval_param_grads(const float *s1, const float *s2, const float *scale, const float *gamma, const float *beta,
+                           float *dgamma, float *dbeta, int32_t C, int32_t accumulate, kd_stream_t stream);
+int kd_broadcast_add(int32_t dtype, const float *v, void *y, int32_t ldy, int32_t N, int64_t HW, int32_t C, float alpha,
+                     int32_t accumulate, kd_stream_t stream);
 
 /* BN(eval) scale/shift from running statistics (nn.BatchNorm2d in eval mode):
  *   scale = gamma / sqrt(var + eps),  shift = beta - mean * scale. */

@@ -50,6 +50,20 @@ _SIGS = {
     "kd_pack_conv_weight": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "kd_pw_wgrad_workspace": (c_sz, [c_int, c_int, c_int]),
     "kd_pw_wgrad": (c_int, [c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_sz, c_vp]),
+    "kd_conv2d_wgrad_workspace": (c_sz, [_P(ConvDesc)]),
+    "kd_conv2d_wgrad": (c_int, [_P(ConvDesc), c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_sz, c_vp]),
+    "kd_stem_wgrad_workspace": (c_sz, [c_int, c_int, c_int]),
+    "kd_stem_wgrad": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
+    "kd_maxpool3x3s2_bwd": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "kd_upsample_bilinear_ac_bwd_workspace": (c_sz, [c_int] * 6),
+    "kd_upsample_bilinear_ac_bwd": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp,
+                                            c_sz, c_vp]),
+    "kd_zero_insert": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "kd_relu_bn_bwd": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_i64, c_int, c_vp]),
+    "kd_channel_sums_workspace": (c_sz, [c_int, c_i64, c_int]),
+    "kd_channel_sums": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_i64, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "kd_bn_eval_param_grads": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
+    "kd_broadcast_add": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_i64, c_int, c_f, c_int, c_vp]),
     "kd_pack_dw_weight": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "kd_dwconv_fwd": (c_int, [_P(DwDesc), c_vp, c_vp, c_vp, _P(DwEpilogue), c_vp, c_vp]),
     "kd_dwconv_wgrad_workspace": (c_sz, [_P(DwDesc)]),

@@ -1,0 +1,508 @@
+// Backward plumbing of the student graph (everything autograd would run between the conv dgrad / wgrad kernels when
+// gradients flow through the whole network: loss = kd + hint with every student parameter trainable, SURVEY 8(d) mode B,
+// and hints taken after a BN+ReLU such as the `aspp` module output of cfg/cityscapes/51M_deeplab_incremental.json).
+// All kernels are HBM-bound streams over NHWC tensors; every reduction has a fixed order (two stages, no float atomics),
+// so results are bit-reproducible run to run.
+#include "kd_common.h"
+
+namespace {
+
+inline int grid_for(long long total, int cap = 16384)
+{
+    long long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+inline bool ok_dt(int d) { return d == KD_F32 || d == KD_BF16; }
+inline bool vec_ok(const void *p, int ld, int es) { return !p || (kd_aligned16(p) && (ld * es) % 16 == 0); }
+
+// ---- d relu(bn(x)) / dx on a gradient ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bn_bwd_kernel(const T *__restrict__ g, int ldg, const T *__restrict__ mask, int ldm,
+                                                          const float *__restrict__ scale, const T *__restrict__ res, int ldres,
+                                                          T *__restrict__ y, int ldy, long long M, int C8)
+{
+    const long long total = M * C8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long m = i / C8;
+        const int c = (int)(i - m * C8) * 8;
+        float v[8], k[8], s[8];
+        ld8(g + m * ldg + c, v);
+        ld8(mask + m * ldm + c, k);
+        ld8(scale + c, s);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = k[q] > 0.f ? v[q] * s[q] : 0.f;
+        if (res) {
+            ld8(res + m * ldres + c, k);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += k[q];
+        }
+        st8(y + m * ldy + c, v);
+    }
+}
+
+// ---- per-group channel sums ------------------------------------------------------------------------------------------------
+// stage 1: block (chunk, channel block of 256, group) sums its rows in fp32 per thread (<= CS_ROWS rows);
+// stage 2: one thread per (group, channel) adds the chunk partials in order, in fp64.
+constexpr int CS_ROWS = 512;
+
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sums_partial_kernel(const T *__restrict__ g, int ldg, const T *__restrict__ sub,
+                                                                   int ldsub, const T *__restrict__ a, int lda, long long rows,
+                                                                   int C, int chunks, float *__restrict__ part)
+{
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    const int chunk = blockIdx.x, grp = blockIdx.z;
+    if (c >= C) return;
+    const long long per = (rows + chunks - 1) / chunks;
+    const long long r0 = (long long)chunk * per, r1 = min(rows, r0 + per);
+    const long long base = (long long)grp * rows;
+    float s1 = 0.f, s2 = 0.f;
+    double d1 = 0.0, d2 = 0.0;
+    int cnt = 0;
+    for (long long r = r0; r < r1; ++r) {
+        const long long m = base + r;
+        float v = Elem<T>::ld(g + m * ldg + c);
+        if (sub) v -= Elem<T>::ld(sub + m * ldsub + c);
+        s1 += v;
+        if (a) s2 += v * Elem<T>::ld(a + m * lda + c);
+        if (++cnt == CS_ROWS) { d1 += s1; d2 += s2; s1 = s2 = 0.f; cnt = 0; }
+    }
+    d1 += s1; d2 += s2;
+    float *o = part + (((size_t)grp * chunks + chunk) * 2) * C;
+    o[c] = (float)d1;
+    o[C + c] = (float)d2;
+}
+
+__global__ __launch_bounds__(256) void channel_sums_finish_kernel(const float *__restrict__ part, int groups, int chunks, int C,
+                                                                  float *__restrict__ s1, float *__restrict__ s2)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= groups * C) return;
+    const int grp = i / C, c = i - grp * C;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        const float *o = part + (((size_t)grp * chunks + k) * 2) * C;
+        a += o[c];
+        b += o[C + c];
+    }
+    s1[i] = (float)a;
+    if (s2) s2[i] = (float)b;
+}
+
+// eval-mode BN parameter gradients from the two channel sums of the gradient w.r.t. the BN INPUT (post ReLU mask):
+//   g_y = g_x / scale;  dbeta = sum g_y = s1 / scale;  dgamma = sum g_y * xhat = (s2 - beta * s1) / (scale * gamma)
+// with s2 = sum g_x * relu(bn(x)) (masked elements carry g_x = 0).  A channel whose gamma (hence scale) is 0 gets 0.
+__global__ void bn_eval_param_grads_kernel(const float *s1, const float *s2, const float *scale, const float *gamma,
+                                           const float *beta, float *dgamma, float *dbeta, int C, int accumulate)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = scale[c], gm = gamma[c];
+    const float db = sc != 0.f ? s1[c] / sc : 0.f;
+    const float dg = (sc != 0.f && gm != 0.f) ? (s2[c] - beta[c] * s1[c]) / (sc * gm) : 0.f;
+    dbeta[c] = accumulate ? dbeta[c] + db : db;
+    dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+}
+
+// ---- max-pool 3x3 / stride 2 / pad 1 backward ------------------------------------------------------------------------------
+// gather form: input pixel (h, w) belongs to at most 2 x 2 windows; it receives a window's gradient when it is that window's
+// arg-max -- the FIRST maximum in (ky, kx) scan order, as nn.MaxPool2d's backward (a NaN counts as the maximum).
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T *__restrict__ x, int ldx, const T *__restrict__ gy, int ldgy,
+                                                          T *__restrict__ gx, int ldgx, int N, int H, int W, int C, int Ho, int Wo)
+{
+    const int CV = C / VEC;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= W * CV) return;
+    const int w = i / CV, c = (i - w * CV) * VEC;
+    const int h = blockIdx.y, n = blockIdx.z;
+    const T *xn = x + (size_t)n * H * W * ldx;
+    float acc[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
+    float mine[VEC];
+    if constexpr (VEC == 8) ld8(xn + ((size_t)h * W + w) * ldx + c, mine);
+    else mine[0] = Elem<T>::ld(xn + ((size_t)h * W + w) * ldx + c);
+    // windows (ho, wo) with 2*ho - 1 <= h <= 2*ho + 1
+    const int ho_lo = max(0, h / 2), ho_hi = min(Ho - 1, (h + 1) / 2);
+    const int wo_lo = max(0, w / 2), wo_hi = min(Wo - 1, (w + 1) / 2);
+    for (int ho = ho_lo; ho <= ho_hi; ++ho)
+        for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+            // is (h, w) the first maximum of window (ho, wo)?  An element earlier in scan order wins on >=, a later one on >.
+            bool win[VEC];
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) win[q] = true;
+            for (int ky = 0; ky < 3; ++ky) {
+                const int hh = 2 * ho - 1 + ky;
+                if (hh < 0 || hh >= H) continue;
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ww = 2 * wo - 1 + kx;
+                    if (ww < 0 || ww >= W || (hh == h && ww == w)) continue;
+                    const bool earlier = hh < h || (hh == h && ww < w);
+                    float o[VEC];
+                    if constexpr (VEC == 8) ld8(xn + ((size_t)hh * W + ww) * ldx + c, o);
+                    else o[0] = Elem<T>::ld(xn + ((size_t)hh * W + ww) * ldx + c);
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        const bool onan = o[q] != o[q], mnan = mine[q] != mine[q];
+                        const bool beats = earlier ? (onan || (!mnan && o[q] >= mine[q])) : (!mnan && (onan || o[q] > mine[q]));
+                        if (beats) win[q] = false;
+                    }
+                }
+            }
+            float gv[VEC];
+            const T *gp = gy + (((size_t)n * Ho + ho) * Wo + wo) * ldgy + c;
+            if constexpr (VEC == 8) ld8(gp, gv);
+            else gv[0] = Elem<T>::ld(gp);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q)
+                if (win[q]) acc[q] += gv[q];
+        }
+    T *op = gx + (((size_t)n * H + h) * W + w) * ldgx + c;
+    if constexpr (VEC == 8) st8(op, acc);
+    else Elem<T>::st(op, acc[0]);
+}
+
+// ---- bilinear (align_corners=True) upsample backward, separable gather ---------------------------------------------------------
+// forward: src = o * (I - 1) / (O - 1); i0 = floor(src), i1 = min(i0 + 1, I - 1), f = src - i0; y[o] = (1-f) x[i0] + f x[i1].
+// backward along one axis: gx[i] = sum_o [i0(o) == i] (1 - f(o)) gy[o] + [i1(o) == i] f(o) gy[o]; the candidate range of o is
+// bracketed generously and every candidate re-evaluates the forward's own (i0, i1, f), so the two sides cannot disagree.
+__device__ __forceinline__ void up_src(int o, float sc, int I, int &i0, int &i1, float &f)
+{
+    const float src = o * sc;
+    i0 = min((int)src, I - 1);
+    i1 = min(i0 + 1, I - 1);
+    f = src - (float)i0;
+}
+
+// pass 1: along W.  gy (N, Ho, Wo, C) -> tmp (N, Ho, W, C) float
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_w_kernel(const T *__restrict__ gy, int ldgy, float *__restrict__ tmp, int N,
+                                                             int Ho, int Wo, int W, int C, float sw)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= W * C) return;
+    const int w = i / C, c = i - w * C;
+    const int ho = blockIdx.y, n = blockIdx.z;
+    const float inv = sw > 0.f ? 1.f / sw : 0.f;
+    int lo = sw > 0.f ? (int)((w - 1) * inv) - 1 : 0, hi = sw > 0.f ? (int)((w + 1) * inv) + 2 : Wo - 1;
+    lo = max(lo, 0); hi = min(hi, Wo - 1);
+    const T *row = gy + (((size_t)n * Ho + ho) * Wo) * ldgy + c;
+    float acc = 0.f;
+    for (int o = lo; o <= hi; ++o) {
+        int i0, i1; float f;
+        up_src(o, sw, W, i0, i1, f);
+        float wgt = 0.f;
+        if (i0 == w) wgt += 1.f - f;
+        if (i1 == w) wgt += f;
+        if (wgt != 0.f) acc += wgt * Elem<T>::ld(row + (size_t)o * ldgy);
+    }
+    tmp[(((size_t)n * Ho + ho) * W + w) * C + c] = acc;
+}
+
+// pass 2: along H.  tmp (N, Ho, W, C) float -> gx (N, H, W, C)
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_h_kernel(const float *__restrict__ tmp, T *__restrict__ gx, int ldgx, int N, int Ho,
+                                                             int H, int W, int C, float sh)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= W * C) return;
+    const int w = i / C, c = i - w * C;
+    const int h = blockIdx.y, n = blockIdx.z;
+    const float inv = sh > 0.f ? 1.f / sh : 0.f;
+    int lo = sh > 0.f ? (int)((h - 1) * inv) - 1 : 0, hi = sh > 0.f ? (int)((h + 1) * inv) + 2 : Ho - 1;
+    lo = max(lo, 0); hi = min(hi, Ho - 1);
+    float acc = 0.f;
+    for (int o = lo; o <= hi; ++o) {
+        int i0, i1; float f;
+        up_src(o, sh, H, i0, i1, f);
+        float wgt = 0.f;
+        if (i0 == h) wgt += 1.f - f;
+        if (i1 == h) wgt += f;
+        if (wgt != 0.f) acc += wgt * tmp[(((size_t)n * Ho + o) * W + w) * C + c];
+    }
+    Elem<T>::st(gx + (((size_t)n * H + h) * W + w) * ldgx + c, acc);
+}
+
+// ---- zero insertion (the transposed view of a strided conv's output gradient) -----------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void zero_insert_kernel(const T *__restrict__ x, int ldx, T *__restrict__ y, int ldy, int H, int W,
+                                                          int C8, int stride, int Hy, int Wy)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Wy * C8) return;
+    const int w = i / C8, c = (i - w * C8) * 8;
+    const int h = blockIdx.y, n = blockIdx.z;
+    uint4 z[sizeof(T) / 2];
+#pragma unroll
+    for (unsigned q = 0; q < sizeof(T) / 2; ++q) z[q] = make_uint4(0u, 0u, 0u, 0u);
+    const bool src = h % stride == 0 && w % stride == 0 && h / stride < H && w / stride < W;
+    T *op = y + (((size_t)n * Hy + h) * Wy + w) * ldy + c;
+    if (src) {
+        const T *ip = x + (((size_t)n * H + h / stride) * W + w / stride) * ldx + c;
+#pragma unroll
+        for (unsigned q = 0; q < sizeof(T) / 2; ++q) z[q] = ((const uint4 *)ip)[q];
+    }
+#pragma unroll
+    for (unsigned q = 0; q < sizeof(T) / 2; ++q) ((uint4 *)op)[q] = z[q];
+}
+
+// ---- y[n, p, c] (+)= v[n, c] * alpha  (broadcast of a per-image vector over the pixels) --------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void broadcast_add_kernel(const float *__restrict__ v, T *__restrict__ y, int ldy, int N,
+                                                            long long HW, int C8, float alpha, int accumulate)
+{
+    const long long total = (long long)N * HW * C8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cq = (int)(i % C8);
+        const long long pix = i / C8;
+        const int n = (int)(pix / HW);
+        float t[8], a[8];
+        ld8(v + (size_t)n * C8 * 8 + cq * 8, t);
+        T *op = y + (size_t)pix * ldy + cq * 8;
+        if (accumulate) {
+            ld8(op, a);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = a[q] + alpha * t[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] *= alpha;
+        }
+        st8(op, t);
+    }
+}
+
+// ---- stem conv weight gradient: dW[64][3][3][3] = sum_pixels dy[p][64] x x_nchw[p + tap][3] -------------------------------
+// persistent blocks over (image row, 256-column segment) work items; the 3 x 258 x 3 input patch goes to LDS, thread =
+// (output channel, pixel phase): 27 running sums each; block partials -> fixed-order reduce.
+constexpr int SW_SEG = 256;
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float *__restrict__ x, const T *__restrict__ dy, int lddy, int N, int H,
+                                                         int W, float *__restrict__ part)
+{
+    __shared__ float patch[3][3][SW_SEG + 2];   // [ci][ky][col]
+    __shared__ float red[4][64 * 27];
+    const int co = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int nseg = (W + SW_SEG - 1) / SW_SEG;
+    const long long nitems = (long long)N * H * nseg;
+    float acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = 0.f;
+    for (long long it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const int seg = (int)(it % nseg);
+        const long long r = it / nseg;
+        const int h = (int)(r % H), n = (int)(r / H);
+        const int w0 = seg * SW_SEG, cols = min(SW_SEG, W - w0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < 9 * (SW_SEG + 2); e += 256) {
+            const int col = e % (SW_SEG + 2), rk = e / (SW_SEG + 2);
+            const int ci = rk / 3, ky = rk - ci * 3;
+            const int hh = h - 1 + ky, ww = w0 - 1 + col;
+            patch[ci][ky][col] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? x[(((size_t)n * 3 + ci) * H + hh) * W + ww] : 0.f;
+        }
+        __syncthreads();
+        const T *dyr = dy + (((size_t)n * H + h) * W + w0) * lddy + co;
+        for (int c = ph; c < cols; c += 4) {
+            const float g = Elem<T>::ld(dyr + (size_t)c * lddy);
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) acc[(ci * 3 + ky) * 3 + kx] += g * patch[ci][ky][c + kx];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 27; ++t) red[ph][co * 27 + t] = acc[t];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 27; e += 256)
+        part[(size_t)blockIdx.x * 64 * 27 + e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+}
+
+__global__ void stem_wgrad_finish_kernel(const float *__restrict__ part, int nblocks, float *__restrict__ dw, int accumulate)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 64 * 27) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * 64 * 27 + e];
+    dw[e] = accumulate ? dw[e] + (float)s : (float)s;
+}
+
+}  // namespace
+
+extern "C" int kd_relu_bn_bwd(int32_t dtype, const void *g, int32_t ldg, const void *mask, int32_t ldm, const float *scale,
+                              const void *res, int32_t ldres, void *y, int32_t ldy, int64_t M, int32_t C, kd_stream_t stream)
+{
+    KD_REQUIRE(g && mask && scale && y && M > 0 && C > 0, KD_ERR_INVALID, "kd_relu_bn_bwd: bad argument");
+    KD_REQUIRE(ok_dt(dtype), KD_ERR_INVALID, "kd_relu_bn_bwd: bad dtype");
+    const int es = kd_elem_size(dtype);
+    KD_REQUIRE(C % 8 == 0 && vec_ok(g, ldg, es) && vec_ok(mask, ldm, es) && vec_ok(res, ldres, es) && vec_ok(y, ldy, es) &&
+                   kd_aligned16(scale),
+               KD_ERR_INVALID, "kd_relu_bn_bwd: C %% 8 and 16-B aligned views required");
+    const int nb = grid_for((long long)M * (C / 8));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == KD_BF16)
+        hipLaunchKernelGGL(relu_bn_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t *)g, ldg, (const bf16_t *)mask, ldm,
+                           scale, (const bf16_t *)res, ldres, (bf16_t *)y, ldy, (long long)M, C / 8);
+    else
+        hipLaunchKernelGGL(relu_bn_bwd_kernel<float>, dim3(nb), dim3(256), 0, s, (const float *)g, ldg, (const float *)mask, ldm, scale,
+                           (const float *)res, ldres, (float *)y, ldy, (long long)M, C / 8);
+    KD_CHECK_LAUNCH("kd_relu_bn_bwd");
+    return KD_OK;
+}
+
+static int cs_chunks(long long rows)
+{
+    long long c = (rows + 2047) / 2048;      // >= 2048 rows per block
+    return (int)(c < 1 ? 1 : (c > 256 ? 256 : c));
+}
+
+extern "C" size_t kd_channel_sums_workspace(int32_t groups, int64_t rows_per_group, int32_t C)
+{
+    return (size_t)groups * cs_chunks(rows_per_group) * 2 * (size_t)C * sizeof(float);
+}
+
+extern "C" int kd_channel_sums(int32_t dtype, const void *g, int32_t ldg, const void *sub, int32_t ldsub, const void *a, int32_t lda,
+                               int32_t groups, int64_t rows_per_group, int32_t C, float *s1, float *s2, void *workspace,
+                               size_t workspace_bytes, kd_stream_t stream)
+{
+    KD_REQUIRE(g && s1 && workspace && groups > 0 && rows_per_group > 0 && C > 0, KD_ERR_INVALID, "kd_channel_sums: bad argument");
+    KD_REQUIRE(ok_dt(dtype), KD_ERR_INVALID, "kd_channel_sums: bad dtype");
+    KD_REQUIRE(!a || s2, KD_ERR_INVALID, "kd_channel_sums: `a` given without s2");
+    KD_REQUIRE(workspace_bytes >= kd_channel_sums_workspace(groups, rows_per_group, C), KD_ERR_WORKSPACE,
+               "kd_channel_sums: workspace too small");
+    const int chunks = cs_chunks(rows_per_group);
+    const dim3 grid((unsigned)chunks, (unsigned)((C + 255) / 256), (unsigned)groups);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == KD_BF16)
+        hipLaunchKernelGGL(channel_sums_partial_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t *)g, ldg, (const bf16_t *)sub, ldsub,
+                           (const bf16_t *)a, lda, (long long)rows_per_group, C, chunks, (float *)workspace);
+    else
+        hipLaunchKernelGGL(channel_sums_partial_kernel<float>, grid, dim3(256), 0, s, (const float *)g, ldg, (const float *)sub, ldsub,
+                           (const float *)a, lda, (long long)rows_per_group, C, chunks, (float *)workspace);
+    KD_CHECK_LAUNCH("kd_channel_sums");
+    hipLaunchKernelGGL(channel_sums_finish_kernel, dim3((groups * C + 255) / 256), dim3(256), 0, s, (const float *)workspace, groups,
+                       chunks, C, s1, a ? s2 : (float *)nullptr);
+    KD_CHECK_LAUNCH("kd_channel_sums(finish)");
+    return KD_OK;
+}
+
+extern "C" int kd_bn_eval_param_grads(const float *s1, const float *s2, const float *scale, const float *gamma, const float *beta,
+                                      float *dgamma, float *dbeta, int32_t C, int32_t accumulate, kd_stream_t stream)
+{
+    KD_REQUIRE(s1 && s2 && scale && gamma && beta && dgamma && dbeta && C > 0, KD_ERR_INVALID, "kd_bn_eval_param_grads: bad argument");
+    hipLaunchKernelGGL(bn_eval_param_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, s1, s2, scale, gamma, beta,
+                       dgamma, dbeta, C, accumulate);
+    KD_CHECK_LAUNCH("kd_bn_eval_param_grads");
+    return KD_OK;
+}
+
+extern "C" int kd_maxpool3x3s2_bwd(int32_t dtype, const void *x, int32_t ldx, const void *gy, int32_t ldgy, void *gx, int32_t ldgx,
+                                   int32_t N, int32_t H, int32_t W, int32_t C, kd_stream_t stream)
+{
+    KD_REQUIRE(x && gy && gx && N > 0 && H > 0 && W > 0 && C > 0, KD_ERR_INVALID, "kd_maxpool3x3s2_bwd: bad argument");
+    KD_REQUIRE(ok_dt(dtype), KD_ERR_INVALID, "kd_maxpool3x3s2_bwd: bad dtype");
+    const int es = kd_elem_size(dtype);
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const bool vec = C % 8 == 0 && vec_ok(x, ldx, es) && vec_ok(gy, ldgy, es) && vec_ok(gx, ldgx, es);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g((unsigned)((W * (vec ? C / 8 : C) + 255) / 256), (unsigned)H, (unsigned)N);
+    if (dtype == KD_BF16) {
+        if (vec) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 8>), g, dim3(256), 0, s, (const bf16_t *)x, ldx, (const bf16_t *)gy, ldgy, (bf16_t *)gx, ldgx, N, H, W, C, Ho, Wo);
+        else hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 1>), g, dim3(256), 0, s, (const bf16_t *)x, ldx, (const bf16_t *)gy, ldgy, (bf16_t *)gx, ldgx, N, H, W, C, Ho, Wo);
+    } else {
+        if (vec) hipLaunchKernelGGL((maxpool_bwd_kernel<float, 8>), g, dim3(256), 0, s, (const float *)x, ldx, (const float *)gy, ldgy, (float *)gx, ldgx, N, H, W, C, Ho, Wo);
+        else hipLaunchKernelGGL((maxpool_bwd_kernel<float, 1>), g, dim3(256), 0, s, (const float *)x, ldx, (const float *)gy, ldgy, (float *)gx, ldgx, N, H, W, C, Ho, Wo);
+    }
+    KD_CHECK_LAUNCH("kd_maxpool3x3s2_bwd");
+    return KD_OK;
+}
+
+extern "C" size_t kd_upsample_bilinear_ac_bwd_workspace(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo)
+{
+    (void)H; (void)Wo;
+    return (size_t)N * Ho * W * C * sizeof(float);
+}
+
+extern "C" int kd_upsample_bilinear_ac_bwd(const void *gy, int32_t gy_dtype, int32_t ldgy, void *gx, int32_t gx_dtype, int32_t ldgx,
+                                           int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, void *workspace,
+                                           size_t workspace_bytes, kd_stream_t stream)
+{
+    KD_REQUIRE(gy && gx && workspace && N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0, KD_ERR_INVALID,
+               "kd_upsample_bilinear_ac_bwd: bad argument");
+    KD_REQUIRE(ok_dt(gy_dtype) && ok_dt(gx_dtype), KD_ERR_INVALID, "kd_upsample_bilinear_ac_bwd: bad dtype");
+    KD_REQUIRE(workspace_bytes >= kd_upsample_bilinear_ac_bwd_workspace(N, H, W, C, Ho, Wo), KD_ERR_WORKSPACE,
+               "kd_upsample_bilinear_ac_bwd: workspace too small");
+    const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;   // the forward kernel's scales (kd_upsample_bilinear_ac)
+    const float sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    hipStream_t s = (hipStream_t)stream;
+    float *tmp = (float *)workspace;
+    const dim3 g1((unsigned)((W * C + 255) / 256), (unsigned)Ho, (unsigned)N);
+    if (gy_dtype == KD_BF16) hipLaunchKernelGGL(upsample_bwd_w_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t *)gy, ldgy, tmp, N, Ho, Wo, W, C, sw);
+    else hipLaunchKernelGGL(upsample_bwd_w_kernel<float>, g1, dim3(256), 0, s, (const float *)gy, ldgy, tmp, N, Ho, Wo, W, C, sw);
+    KD_CHECK_LAUNCH("kd_upsample_bilinear_ac_bwd(w)");
+    const dim3 g2((unsigned)((W * C + 255) / 256), (unsigned)H, (unsigned)N);
+    if (gx_dtype == KD_BF16) hipLaunchKernelGGL(upsample_bwd_h_kernel<bf16_t>, g2, dim3(256), 0, s, (const float *)tmp, (bf16_t *)gx, ldgx, N, Ho, H, W, C, sh);
+    else hipLaunchKernelGGL(upsample_bwd_h_kernel<float>, g2, dim3(256), 0, s, (const float *)tmp, (float *)gx, ldgx, N, Ho, H, W, C, sh);
+    KD_CHECK_LAUNCH("kd_upsample_bilinear_ac_bwd(h)");
+    return KD_OK;
+}
+
+extern "C" int kd_zero_insert(int32_t dtype, const void *x, int32_t ldx, void *y, int32_t ldy, int32_t N, int32_t H, int32_t W,
+                              int32_t C, int32_t stride, int32_t Hy, int32_t Wy, kd_stream_t stream)
+{
+    KD_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && stride >= 1, KD_ERR_INVALID, "kd_zero_insert: bad argument");
+    KD_REQUIRE(ok_dt(dtype), KD_ERR_INVALID, "kd_zero_insert: bad dtype");
+    KD_REQUIRE(Hy >= (H - 1) * stride + 1 && Wy >= (W - 1) * stride + 1, KD_ERR_INVALID, "kd_zero_insert: output too small");
+    const int es = kd_elem_size(dtype);
+    KD_REQUIRE(C % 8 == 0 && vec_ok(x, ldx, es) && vec_ok(y, ldy, es), KD_ERR_INVALID, "kd_zero_insert: C %% 8 and 16-B alignment required");
+    const dim3 g((unsigned)((Wy * (C / 8) + 255) / 256), (unsigned)Hy, (unsigned)N);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == KD_BF16) hipLaunchKernelGGL(zero_insert_kernel<bf16_t>, g, dim3(256), 0, s, (const bf16_t *)x, ldx, (bf16_t *)y, ldy, H, W, C / 8, stride, Hy, Wy);
+    else hipLaunchKernelGGL(zero_insert_kernel<float>, g, dim3(256), 0, s, (const float *)x, ldx, (float *)y, ldy, H, W, C / 8, stride, Hy, Wy);
+    KD_CHECK_LAUNCH("kd_zero_insert");
+    return KD_OK;
+}
+
+extern "C" int kd_broadcast_add(int32_t dtype, const float *v, void *y, int32_t ldy, int32_t N, int64_t HW, int32_t C, float alpha,
+                                int32_t accumulate, kd_stream_t stream)
+{
+    KD_REQUIRE(v && y && N > 0 && HW > 0 && C > 0, KD_ERR_INVALID, "kd_broadcast_add: bad argument");
+    KD_REQUIRE(ok_dt(dtype), KD_ERR_INVALID, "kd_broadcast_add: bad dtype");
+    KD_REQUIRE(C % 8 == 0 && kd_aligned16(v) && vec_ok(y, ldy, kd_elem_size(dtype)), KD_ERR_INVALID,
+               "kd_broadcast_add: C %% 8 and 16-B alignment required");
+    const int nb = grid_for((long long)N * HW * (C / 8));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == KD_BF16) hipLaunchKernelGGL(broadcast_add_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, v, (bf16_t *)y, ldy, N, (long long)HW, C / 8, alpha, accumulate);
+    else hipLaunchKernelGGL(broadcast_add_kernel<float>, dim3(nb), dim3(256), 0, s, v, (float *)y, ldy, N, (long long)HW, C / 8, alpha, accumulate);
+    KD_CHECK_LAUNCH("kd_broadcast_add");
+    return KD_OK;
+}
+
+static int stem_blocks(int N, int H, int W)
+{
+    const long long items = (long long)N * H * ((W + SW_SEG - 1) / SW_SEG);
+    return (int)(items < 1024 ? items : 1024);
+}
+
+extern "C" size_t kd_stem_wgrad_workspace(int32_t N, int32_t H, int32_t W)
+{
+    return (size_t)stem_blocks(N, H, W) * 64 * 27 * sizeof(float);
+}
+
+extern "C" int kd_stem_wgrad(int32_t dtype, const float *x_nchw, const void *dy, int32_t ld_dy, float *dw, int32_t N, int32_t H,
+                             int32_t W, int32_t accumulate, void *workspace, size_t workspace_bytes, kd_stream_t stream)
+{
+    KD_REQUIRE(x_nchw && dy && dw && workspace && N > 0 && H > 0 && W > 0 && ld_dy >= 64, KD_ERR_INVALID, "kd_stem_wgrad: bad argument");
+    KD_REQUIRE(ok_dt(dtype), KD_ERR_INVALID, "kd_stem_wgrad: bad dtype");
+    KD_REQUIRE(workspace_bytes >= kd_stem_wgrad_workspace(N, H, W), KD_ERR_WORKSPACE, "kd_stem_wgrad: workspace too small");
+    const int nb = stem_blocks(N, H, W);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == KD_BF16) hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, x_nchw, (const bf16_t *)dy, ld_dy, N, H, W, (float *)workspace);
+    else hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(nb), dim3(256), 0, s, x_nchw, (const float *)dy, ld_dy, N, H, W, (float *)workspace);
+    KD_CHECK_LAUNCH("kd_stem_wgrad");
+    hipLaunchKernelGGL(stem_wgrad_finish_kernel, dim3((64 * 27 + 255) / 256), dim3(256), 0, s, (const float *)workspace, nb, dw, accumulate);
+    KD_CHECK_LAUNCH("kd_stem_wgrad(finish)");
+    return KD_OK;
+}

@@ -17,10 +17,32 @@ constexpr int STAGE_BYTES = (TM + TN) * IG_ROWB;  // 32 KiB
 struct WgradParams {
     const void *a;
     const void *dy;
-    float *part;  // [splits][Cout][Cin]
+    float *part;  // [splits][taps][Cout][Cin]
     int M, Cin, Cout, lda, ldy;
     int tiles_ci, rows_per_split, splits;
+    // conv geometry of the A operand (kd_conv2d_wgrad): GEMM row m = output pixel (n, ho, wo) reads input pixel
+    // (n, ho*stride - pad + ky*dil, wo*stride - pad + kx*dil) for the tap blockIdx.z = ky*kw + kx, zeros outside the image
+    int geom, H, W, Ho, Wo, kw, stride, pad, dil;
+    uint32_t mg_howo, sh_howo, mg_wo, sh_wo;   // magic numbers: m / (Ho*Wo), rem / Wo without integer division
 };
+
+__device__ __forceinline__ uint32_t fastdiv(uint32_t n, uint32_t magic, uint32_t shift)
+{
+    return (__umulhi(n, magic) + n) >> shift;   // exact for n < 2^31 (host-side magic: see fastdiv_magic)
+}
+
+// input-pixel index (in pixels, not elements) of GEMM row m for tap (ky, kx), or -1 when the tap falls outside the image
+__device__ __forceinline__ int a_row(const WgradParams &p, int m, int ky, int kx)
+{
+    if (!p.geom) return m;
+    const uint32_t n = fastdiv((uint32_t)m, p.mg_howo, p.sh_howo);
+    const uint32_t rem = (uint32_t)m - n * (uint32_t)(p.Ho * p.Wo);
+    const uint32_t ho = fastdiv(rem, p.mg_wo, p.sh_wo);
+    const uint32_t wo = rem - ho * (uint32_t)p.Wo;
+    const int hi = (int)ho * p.stride - p.pad + ky * p.dil, wi = (int)wo * p.stride - p.pad + kx * p.dil;
+    if (hi < 0 || hi >= p.H || wi < 0 || wi >= p.W) return -1;
+    return ((int)n * p.H + hi) * p.W + wi;
+}
 
 // transposing stage loader: rows = pixels, 16-B chunks of channels -> LDS [channel][k]
 template <typename T> struct Stager {
@@ -45,6 +67,27 @@ template <typename T> struct Stager {
                 __attribute__((aligned(16))) T tmp[EPC];
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) tmp[e] = (m < M && c + e < C) ? g[(size_t)m * ld + c + e] : (T)0;
+                r[i] = *(const uint4 *)tmp;
+            }
+        }
+    }
+    // A operand of a general conv: the row's source pixel comes from a_row()
+    __device__ static __forceinline__ void load_a(const WgradParams &p, const T *g, int m_base, int M, int c_base, int wv,
+                                                  int lane, int ky, int kx, uint4 (&r)[4])
+    {
+        const int mrow = lane % KROWS, sub = lane / KROWS;
+        const int m = m_base + mrow;
+        const int px = m < M ? a_row(p, m, ky, kx) : -1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cch = (wv * 4 + i) * SUBS + sub;
+            const int c = c_base + cch * EPC;
+            if (px >= 0 && c + EPC <= p.Cin) {
+                r[i] = *(const uint4 *)(g + (size_t)px * p.lda + c);
+            } else {
+                __attribute__((aligned(16))) T tmp[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) tmp[e] = (px >= 0 && c + e < p.Cin) ? g[(size_t)px * p.lda + c + e] : (T)0;
                 r[i] = *(const uint4 *)tmp;
             }
         }
@@ -74,7 +117,8 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const WgradParams p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1;
-    const int tile = blockIdx.x, split = blockIdx.y;
+    const int tile = blockIdx.x, split = blockIdx.y, tap = blockIdx.z;
+    const int ky = tap / p.kw, kx = tap - ky * p.kw;
     const int t_ci = tile % p.tiles_ci, t_co = tile / p.tiles_ci;
     const int co0 = t_co * TM, ci0 = t_ci * TN;
     const int m_begin = split * p.rows_per_split;
@@ -93,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const WgradParams p)
     uint4 ra[4], rb[4];
     if (nst > 0) {
         S::load(dy, p.ldy, m_begin, m_end, co0, p.Cout, wv, lane, ra);
-        S::load(a, p.lda, m_begin, m_end, ci0, p.Cin, wv, lane, rb);
+        S::load_a(p, a, m_begin, m_end, ci0, wv, lane, ky, kx, rb);
         S::store(lds, wv, lane, ra);
         S::store(lds + TM * IG_ROWB, wv, lane, rb);
     }
@@ -104,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const WgradParams p)
         if (more) {
             const int mb = m_begin + (st + 1) * S::KROWS;
             S::load(dy, p.ldy, mb, m_end, co0, p.Cout, wv, lane, ra);
-            S::load(a, p.lda, mb, m_end, ci0, p.Cin, wv, lane, rb);
+            S::load_a(p, a, mb, m_end, ci0, wv, lane, ky, kx, rb);
         }
         const char *sA = lds + cur * STAGE_BYTES;
         ig_compute_stage<T>(sA, sA + TM * IG_ROWB, wm, wn, lane, acc);
@@ -117,8 +161,8 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const WgradParams p)
         cur ^= 1;
     }
 
-    // partial tile -> slab [split][Cout][Cin]
-    float *out = p.part + (size_t)split * p.Cout * p.Cin;
+    // partial tile -> slab [split][tap][Cout][Cin]
+    float *out = p.part + ((size_t)split * gridDim.z + tap) * p.Cout * p.Cin;
     const int frow = lane & 15, fq = lane >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -148,7 +192,8 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(const WgradParams p
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1;
-    const int tile = blockIdx.x, split = blockIdx.y;
+    const int tile = blockIdx.x, split = blockIdx.y, tap = blockIdx.z;
+    const int ky = tap / p.kw, kx = tap - ky * p.kw;
     const int t_ci = tile % p.tiles_ci, t_co = tile / p.tiles_ci;
     const int co0 = t_co * TM, ci0 = t_ci * TN;
     const int m_begin = split * p.rows_per_split;
@@ -168,8 +213,9 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(const WgradParams p
             const int m = m_begin + st * 64 + r;
             const int c = (slot ^ (tr_f(r) << 1)) * 8;      // source-side swizzle (8 channels per 16-B chunk)
             const bool mok = m < m_end;
+            const int px = mok ? a_row(p, m, ky, kx) : -1;
             const bf16_t *s0 = (mok && co0 + c < p.Cout) ? dy + (size_t)m * p.ldy + co0 + c : zero;
-            const bf16_t *s1 = (mok && ci0 + c < p.Cin) ? a + (size_t)m * p.lda + ci0 + c : zero;
+            const bf16_t *s1 = (px >= 0 && ci0 + c < p.Cin) ? a + (size_t)px * p.lda + ci0 + c : zero;
             glds16(s0, base + (wv * 4 + j) * 1024);
             glds16(s1, base + 16384 + (wv * 4 + j) * 1024);
         }
@@ -216,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(const WgradParams p
         wait_vm_barrier<0>();   // next stage landed everywhere; everybody is done reading this one
     }
 
-    float *out = p.part + (size_t)split * p.Cout * p.Cin;
+    float *out = p.part + ((size_t)split * gridDim.z + tap) * p.Cout * p.Cin;
     const int frow = lane & 15, fq = lane >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -230,6 +276,20 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(const WgradParams p
             }
 }
 
+// slabs [split][tap][Cout][Cin] -> dw (Cout, Cin, kh, kw) like nn.Conv2d.weight.grad; fixed summation order
+__global__ void slab_reduce_taps_kernel(const float *__restrict__ part, float *__restrict__ dw, int Cout, int Cin, int taps,
+                                        int splits, int accumulate)
+{
+    const size_t plane = (size_t)Cout * Cin, n = plane * taps;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % taps);
+        const size_t cc = i / taps;                  // co * Cin + ci
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += part[((size_t)k * taps + t) * plane + cc];
+        dw[i] = accumulate ? dw[i] + s : s;
+    }
+}
+
 __global__ void slab_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, size_t n, int splits,
                                    int accumulate)
 {
@@ -240,13 +300,13 @@ __global__ void slab_reduce_kernel(const float *__restrict__ part, float *__rest
     }
 }
 
-void plan(int dtype, int M, int Cin, int Cout, int &tiles, int &tiles_ci, int &splits, int &rows_per_split)
+void plan(int dtype, int M, int Cin, int Cout, int &tiles, int &tiles_ci, int &splits, int &rows_per_split, int taps = 1)
 {
     const int krows = IG_ROWB / kd_elem_size(dtype);
     tiles_ci = (Cin + TN - 1) / TN;
     tiles = tiles_ci * ((Cout + TM - 1) / TM);
     const int stages = (M + krows - 1) / krows;
-    int want = (1024 + tiles - 1) / tiles;          // aim for ~1024 workgroups (4 per CU)
+    int want = (1024 + tiles * taps - 1) / (tiles * taps);   // aim for ~1024 workgroups (4 per CU)
     const int max_splits = (stages + 3) / 4;        // keep >= 4 stages per split
     splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
     if (splits < 1) splits = 1;
@@ -286,6 +346,8 @@ extern "C" int kd_pw_wgrad(int32_t dtype, int32_t M, int32_t Cin, int32_t Cout, 
     p.a = a; p.dy = dy; p.part = (float *)workspace;
     p.M = M; p.Cin = Cin; p.Cout = Cout; p.lda = lda; p.ldy = ldy;
     p.tiles_ci = tiles_ci; p.rows_per_split = rps; p.splits = splits;
+    p.geom = 0; p.kw = 1; p.H = p.W = p.Ho = p.Wo = 0; p.stride = 1; p.pad = 0; p.dil = 1;
+    p.mg_howo = p.sh_howo = p.mg_wo = p.sh_wo = 0;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)tiles, (unsigned)splits);
     if (dtype == KD_BF16 && Cin % 8 == 0 && Cout % 8 == 0) hipLaunchKernelGGL(pw_wgrad_tr_kernel, grid, dim3(256), 0, s, p);
@@ -296,5 +358,74 @@ extern "C" int kd_pw_wgrad(int32_t dtype, int32_t M, int32_t Cin, int32_t Cout, 
     const int rb = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(256), 0, s, (const float *)workspace, dw, n, splits, accumulate);
     KD_CHECK_LAUNCH("kd_pw_wgrad(reduce)");
+    return KD_OK;
+}
+
+// ---- general convolution weight gradient (kd_conv2d_wgrad): the same TN GEMM per tap, A rows gathered through the conv's
+// pixel map (stride, padding, dilation; zeros outside the image).  grid = (Cout x Cin tiles, pixel splits, taps).
+namespace {
+void fastdiv_magic(uint32_t d, uint32_t &magic, uint32_t &shift)
+{
+    // n / d == (umulhi(n, magic) + n) >> shift for 0 <= n < 2^31 (round-up method, 33-bit magic with the top bit implicit)
+    shift = 0;
+    while ((1ull << shift) < d) ++shift;
+    magic = (uint32_t)(((1ull << 32) * ((1ull << shift) - d)) / d + 1);
+}
+}  // namespace
+
+extern "C" size_t kd_conv2d_wgrad_workspace(const kd_conv_desc *d)
+{
+    if (!d) return 0;
+    const int M = d->N * d->Ho * d->Wo, taps = d->kh * d->kw;
+    int tiles, tiles_ci, s0, s1, rps;
+    plan(KD_F32, M, d->Cin, d->Cout, tiles, tiles_ci, s0, rps, taps);
+    plan(KD_BF16, M, d->Cin, d->Cout, tiles, tiles_ci, s1, rps, taps);
+    const int splits = s0 > s1 ? s0 : s1;
+    return (size_t)splits * taps * d->Cout * d->Cin * sizeof(float);
+}
+
+extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void *dy, int32_t ld_dy, float *dw,
+                               int32_t accumulate, void *workspace, size_t workspace_bytes, kd_stream_t stream)
+{
+    KD_REQUIRE(d && x && dy && dw && workspace, KD_ERR_INVALID, "kd_conv2d_wgrad: null argument");
+    KD_REQUIRE(d->dtype == KD_F32 || d->dtype == KD_BF16, KD_ERR_INVALID, "kd_conv2d_wgrad: bad dtype");
+    KD_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->kh > 0 && d->kw > 0 && d->stride >= 1 &&
+                   d->dil >= 1 && d->pad >= 0,
+               KD_ERR_INVALID, "kd_conv2d_wgrad: bad descriptor");
+    const int ho = (d->H + 2 * d->pad - d->dil * (d->kh - 1) - 1) / d->stride + 1;
+    const int wo = (d->W + 2 * d->pad - d->dil * (d->kw - 1) - 1) / d->stride + 1;
+    KD_REQUIRE(ho == d->Ho && wo == d->Wo && ho > 0 && wo > 0, KD_ERR_INVALID, "kd_conv2d_wgrad: Ho/Wo (%d,%d) inconsistent, expect (%d,%d)",
+               d->Ho, d->Wo, ho, wo);
+    const int es = kd_elem_size(d->dtype);
+    KD_REQUIRE(d->ldx >= d->Cin && ld_dy >= d->Cout && (d->ldx * es) % 16 == 0 && (ld_dy * es) % 16 == 0 && kd_aligned16(x) &&
+                   kd_aligned16(dy),
+               KD_ERR_INVALID, "kd_conv2d_wgrad: operands must be 16-B aligned with 16-B multiple pixel strides");
+    const long long M = (long long)d->N * d->Ho * d->Wo;
+    KD_REQUIRE(M < (1ll << 31) && (long long)d->N * d->H * d->W < (1ll << 31), KD_ERR_UNSUPPORTED, "kd_conv2d_wgrad: too many pixels");
+    const int taps = d->kh * d->kw;
+    KD_REQUIRE(taps <= 65535, KD_ERR_UNSUPPORTED, "kd_conv2d_wgrad: kernel too large");
+    int tiles, tiles_ci, splits, rps;
+    plan(d->dtype, (int)M, d->Cin, d->Cout, tiles, tiles_ci, splits, rps, taps);
+    const size_t need = (size_t)splits * taps * d->Cout * d->Cin * sizeof(float);
+    KD_REQUIRE(workspace_bytes >= need, KD_ERR_WORKSPACE, "kd_conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
+    WgradParams p;
+    p.a = x; p.dy = dy; p.part = (float *)workspace;
+    p.M = (int)M; p.Cin = d->Cin; p.Cout = d->Cout; p.lda = d->ldx; p.ldy = ld_dy;
+    p.tiles_ci = tiles_ci; p.rows_per_split = rps; p.splits = splits;
+    p.geom = !(taps == 1 && d->stride == 1 && d->pad == 0);
+    p.H = d->H; p.W = d->W; p.Ho = d->Ho; p.Wo = d->Wo; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+    fastdiv_magic((uint32_t)(d->Ho * d->Wo), p.mg_howo, p.sh_howo);
+    fastdiv_magic((uint32_t)d->Wo, p.mg_wo, p.sh_wo);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)tiles, (unsigned)splits, (unsigned)taps);
+    if (d->dtype == KD_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0) hipLaunchKernelGGL(pw_wgrad_tr_kernel, grid, dim3(256), 0, s, p);
+    else if (d->dtype == KD_BF16) hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(pw_wgrad_kernel<float>, grid, dim3(256), 0, s, p);
+    KD_CHECK_LAUNCH("kd_conv2d_wgrad");
+    const size_t n = (size_t)d->Cout * d->Cin * taps;
+    const int rb = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(slab_reduce_taps_kernel, dim3(rb), dim3(256), 0, s, (const float *)workspace, dw, d->Cout, d->Cin, taps,
+                       splits, accumulate);
+    KD_CHECK_LAUNCH("kd_conv2d_wgrad(reduce)");
     return KD_OK;
 }

@@ -151,6 +151,33 @@ def pw_wgrad(a, dy, dw, accumulate=False, workspace=None):
     return dw
 
 
+def conv2d_wgrad(x, dy, dw, stride=1, pad=0, dil=1, accumulate=False, workspace=None):
+    """dw (Cout,Cin,kh,kw) fp32 = weight gradient of conv2d(x; stride, pad, dil) given dy (N,Ho,Wo,Cout)."""
+    _need_cuda(x, dy, dw)
+    N, H, W, Cin = x.shape
+    Cout, Cin_w, kh, kw = dw.shape
+    Ho, Wo = conv_out_size(H, kh, stride, pad, dil), conv_out_size(W, kw, stride, pad, dil)
+    if Cin_w != Cin or tuple(dy.shape) != (N, Ho, Wo, Cout) or dy.dtype != x.dtype:
+        raise ValueError(f"conv2d_wgrad: x {tuple(x.shape)} / dy {tuple(dy.shape)} / dw {tuple(dw.shape)} mismatch")
+    if dw.dtype != torch.float32 or not dw.is_contiguous():
+        raise ValueError("conv2d_wgrad: dw must be contiguous fp32 (Cout,Cin,kh,kw)")
+    d = ConvDesc(dt_of(x), N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil, nhwc_ld(x))
+    need = _lib.lib().kd_conv2d_wgrad_workspace(C.byref(d))
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+    prof = PROFILER
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_lib.lib().kd_conv2d_wgrad(C.byref(d), _ptr(x), _ptr(dy), nhwc_ld(dy), _ptr(dw), int(accumulate), _ptr(workspace),
+                                     workspace.numel() * workspace.element_size(), stream_ptr()), "kd_conv2d_wgrad")
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        prof.append(("conv_wgrad", 2.0 * N * Ho * Wo * Cout * kh * kw * Cin, e0, e1))
+    return dw
+
+
 # --------------------------------------------------------------------------- depthwise conv
 def pack_dw_weight(w, flip=False):
     """(C,1,k,k) fp32 -> tap-major [k*k][C] fp32 (flip=True: the dgrad operand)."""
@@ -262,6 +289,121 @@ def aspp_image_pool(x, w, scale, shift, out):
     check(_lib.lib().kd_aspp_image_pool(dt_of(x), _ptr(x), nhwc_ld(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(out),
                                         nhwc_ld(out), N, H, W, Cin, Cout, _ptr(ws), need, stream_ptr()), "kd_aspp_image_pool")
     return out
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def stem_wgrad(x_nchw, dy, dw, accumulate=False):
+    """dw (64,3,3,3) fp32 from the NCHW fp32 batch and dy (N,H,W,64)."""
+    _need_cuda(x_nchw, dy, dw)
+    N, _, H, W = x_nchw.shape
+    if x_nchw.dtype != torch.float32 or not x_nchw.is_contiguous() or x_nchw.shape[1] != 3 or tuple(dy.shape) != (N, H, W, 64):
+        raise ValueError("stem_wgrad: expects a contiguous fp32 (N,3,H,W) batch and dy (N,H,W,64)")
+    if tuple(dw.shape) != (64, 3, 3, 3) or dw.dtype != torch.float32 or not dw.is_contiguous():
+        raise ValueError("stem_wgrad: dw must be contiguous fp32 (64,3,3,3)")
+    need = _lib.lib().kd_stem_wgrad_workspace(N, H, W)
+    ws = _ws(need, dy.device)
+    check(_lib.lib().kd_stem_wgrad(dt_of(dy), _ptr(x_nchw), _ptr(dy), nhwc_ld(dy), _ptr(dw), N, H, W, int(accumulate), _ptr(ws), need,
+                                   stream_ptr()), "kd_stem_wgrad")
+    return dw
+
+
+def maxpool3x3s2_bwd(x, gy, out=None):
+    _need_cuda(x, gy, out)
+    N, H, W, Cc = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if tuple(gy.shape) != (N, Ho, Wo, Cc) or gy.dtype != x.dtype:
+        raise ValueError("maxpool3x3s2_bwd: gy must be (N,Ho,Wo,C) of the input dtype")
+    if out is None:
+        out = torch.empty((N, H, W, Cc), dtype=x.dtype, device=x.device)
+    check(_lib.lib().kd_maxpool3x3s2_bwd(dt_of(x), _ptr(x), nhwc_ld(x), _ptr(gy), nhwc_ld(gy), _ptr(out), nhwc_ld(out), N, H, W, Cc,
+                                         stream_ptr()), "kd_maxpool3x3s2_bwd")
+    return out
+
+
+def upsample_bilinear_ac_bwd(gy, size, out=None, out_dtype=None):
+    """gy (N,Ho,Wo,C) -> gradient w.r.t. the (N,H,W,C) input of upsample_bilinear_ac, size = (H, W)."""
+    _need_cuda(gy, out)
+    N, Ho, Wo, Cc = gy.shape
+    H, W = size
+    if out is None:
+        out = torch.empty((N, H, W, Cc), dtype=out_dtype or gy.dtype, device=gy.device)
+    if tuple(out.shape) != (N, H, W, Cc):
+        raise ValueError("upsample_bilinear_ac_bwd: bad output view")
+    need = _lib.lib().kd_upsample_bilinear_ac_bwd_workspace(N, H, W, Cc, Ho, Wo)
+    ws = _ws(need, gy.device)
+    check(_lib.lib().kd_upsample_bilinear_ac_bwd(_ptr(gy), dt_of(gy), nhwc_ld(gy), _ptr(out), dt_of(out), nhwc_ld(out), N, H, W, Cc,
+                                                 Ho, Wo, _ptr(ws), need, stream_ptr()), "kd_upsample_bilinear_ac_bwd")
+    return out
+
+
+def zero_insert(x, stride, size):
+    _need_cuda(x)
+    N, H, W, Cc = x.shape
+    Hy, Wy = size
+    y = torch.empty((N, Hy, Wy, Cc), dtype=x.dtype, device=x.device)
+    check(_lib.lib().kd_zero_insert(dt_of(x), _ptr(x), nhwc_ld(x), _ptr(y), Cc, N, H, W, Cc, stride, Hy, Wy, stream_ptr()),
+          "kd_zero_insert")
+    return y
+
+
+def relu_bn_bwd(g, mask, scale, res=None, out=None):
+    """(mask > 0 ? g * scale[c] : 0) + res on (N,H,W,C) views."""
+    _need_cuda(g, mask, scale, res, out)
+    N, H, W, Cc = g.shape
+    if tuple(mask.shape) != (N, H, W, Cc) or mask.dtype != g.dtype or scale.dtype != torch.float32 or scale.numel() != Cc:
+        raise ValueError("relu_bn_bwd: operand mismatch")
+    if out is None:
+        out = torch.empty((N, H, W, Cc), dtype=g.dtype, device=g.device)
+    ldg, ldm, ldo = nhwc_ld(g), nhwc_ld(mask), nhwc_ld(out)
+    check(_lib.lib().kd_relu_bn_bwd(dt_of(g), _ptr(g), ldg, _ptr(mask), ldm, _ptr(scale), _ptr(res), nhwc_ld(res) if res is not None else 0,
+                                    _ptr(out), ldo, N * H * W, Cc, stream_ptr()), "kd_relu_bn_bwd")
+    return out
+
+
+def channel_sums(g, sub=None, a=None, per_image=False):
+    """Per-channel sums over the pixels of g (N,H,W,C) [minus sub], optionally also of (g - sub) * a.
+    Returns (s1, s2 | None) fp32 of shape (C,) or, with per_image, (N, C)."""
+    _need_cuda(g, sub, a)
+    N, H, W, Cc = g.shape
+    groups, rows = (N, H * W) if per_image else (1, N * H * W)
+    s1 = torch.empty((groups, Cc), dtype=torch.float32, device=g.device)
+    s2 = torch.empty_like(s1) if a is not None else None
+    need = _lib.lib().kd_channel_sums_workspace(groups, rows, Cc)
+    ws = _ws(need, g.device)
+    ld = lambda t: nhwc_ld(t) if t is not None else 0
+    for t in (sub, a):
+        if t is not None and (tuple(t.shape) != (N, H, W, Cc) or t.dtype != g.dtype):
+            raise ValueError("channel_sums: operand mismatch")
+    check(_lib.lib().kd_channel_sums(dt_of(g), _ptr(g), ld(g), _ptr(sub), ld(sub), _ptr(a), ld(a), groups, rows, Cc, _ptr(s1), _ptr(s2),
+                                     _ptr(ws), need, stream_ptr()), "kd_channel_sums")
+    if not per_image:
+        s1 = s1[0]
+        s2 = s2[0] if s2 is not None else None
+    return s1, s2
+
+
+def bn_eval_param_grads(s1, s2, scale, gamma, beta, dgamma, dbeta, accumulate=False):
+    _need_cuda(s1, s2, scale, gamma, beta, dgamma, dbeta)
+    Cc = s1.numel()
+    for t in (s1, s2, scale, gamma, beta, dgamma, dbeta):
+        if t.dtype != torch.float32 or t.numel() != Cc or not t.is_contiguous():
+            raise ValueError("bn_eval_param_grads: contiguous fp32 (C,) vectors required")
+    check(_lib.lib().kd_bn_eval_param_grads(_ptr(s1), _ptr(s2), _ptr(scale), _ptr(gamma), _ptr(beta), _ptr(dgamma), _ptr(dbeta), Cc,
+                                            int(accumulate), stream_ptr()), "kd_bn_eval_param_grads")
+
+
+def broadcast_add(v, y, alpha=1.0, accumulate=True):
+    """y[n,h,w,c] (+)= alpha * v[n,c]."""
+    _need_cuda(v, y)
+    N, H, W, Cc = y.shape
+    if tuple(v.shape) != (N, Cc) or v.dtype != torch.float32 or not v.is_contiguous():
+        raise ValueError("broadcast_add: v must be contiguous fp32 (N,C)")
+    check(_lib.lib().kd_broadcast_add(dt_of(y), _ptr(v), _ptr(y), nhwc_ld(y), N, H * W, Cc, C.c_float(alpha), int(accumulate),
+                                      stream_ptr()), "kd_broadcast_add")
+    return y
 
 
 def bn_fold(bn):

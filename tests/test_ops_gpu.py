@@ -407,3 +407,122 @@ def test_confusion_exact(K, golden):
     t[:, :2] = 255
     got = K.confusion(dev_nhwc(x, "bf16").permute(0, 3, 1, 2), torch.from_numpy(t).cuda())
     assert np.array_equal(got.cpu().numpy(), orc.confusion(x, t))
+
+
+# ------------------------------------------------------------------------------------------------- backward plumbing (mode B)
+WGRAD_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, dil
+    (2, 12, 20, 64, 128, 3, 1, 1, 1),
+    (1, 17, 23, 72, 40, 3, 1, 2, 2),      # ragged channels (Cin, Cout % 8 == 0 only) and pixels, dilation 2
+    (1, 16, 24, 64, 64, 3, 2, 1, 1),      # stride 2 (mod4.block1.convs.conv1)
+    (2, 10, 14, 128, 256, 1, 2, 0, 1),    # strided projection
+    (1, 9, 31, 304, 256, 3, 1, 1, 1),     # decoder: 304 input channels
+    (1, 8, 8, 256, 19, 1, 1, 0, 1),       # classifier: 19 output channels (generic transposing path)
+    (1, 40, 48, 64, 64, 3, 1, 12, 12),    # ASPP-like dilation: most taps of the border rows fall outside the image
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv_wgrad(K, dt, case):
+    N, H, W, Cin, Cout, k, s, p, d = case
+    x = q(rnd(N, Cin, H, W), dt)
+    Ho, Wo = orc.conv_out(H, k, s, p, d), orc.conv_out(W, k, s, p, d)
+    gy = q(rnd(N, Cout, Ho, Wo), dt)
+    ref = orc.conv2d_wgrad(x, gy, (Cout, Cin, k, k), stride=s, pad=p, dil=d)
+    ldy = ((Cout + 7) // 8) * 8 + 8
+    gyd = dev_nhwc(gy, dt, ld=ldy) if Cout % 8 else dev_nhwc(gy, dt)
+    dw = torch.full((Cout, Cin, k, k), 3.0, device="cuda")
+    K.conv2d_wgrad(dev_nhwc(x, dt, ld=Cin + 16), gyd, dw, s, p, d)
+    assert_close(dw.cpu().numpy(), ref, dt, f"wgrad {case}")
+    K.conv2d_wgrad(dev_nhwc(x, dt), gyd, dw, s, p, d, accumulate=True)
+    assert_close(dw.cpu().numpy(), 2 * ref, dt, f"wgrad accumulate {case}")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_strided_dgrad_via_zero_insert(K, dt):
+    """Input gradient of the stride-2 convs (3x3 pad 1 and the 1x1 projection): zero-insert the output gradient, then the
+    ordinary stride-1 dgrad conv."""
+    from kdcc_amd._lib import KD_PACK_DGRAD
+    for (N, H, W, Cin, Cout, k, p) in [(2, 16, 24, 64, 64, 3, 1), (1, 12, 20, 64, 128, 1, 0)]:
+        w = q(rnd(Cout, Cin, k, k, scale=0.1), dt)
+        Ho, Wo = orc.conv_out(H, k, 2, p, 1), orc.conv_out(W, k, 2, p, 1)
+        gy = q(rnd(N, Cout, Ho, Wo), dt)
+        ref = orc.conv2d_dgrad(gy, w, (N, Cin, H, W), stride=2, pad=p)
+        up = K.zero_insert(dev_nhwc(gy, dt), 2, (H, W))
+        assert float(up[:, 1::2].abs().max()) == 0 and float(up[:, :, 1::2].abs().max()) == 0
+        out = torch.empty((N, H, W, Cin), dtype=DT[dt], device="cuda")
+        K.conv2d(up, K.pack_conv_weight(torch.from_numpy(w).cuda(), DT[dt], KD_PACK_DGRAD), 1, (k - 1) - p, 1, out_raw=out)
+        assert_close(host_nchw(out), ref, dt, f"strided dgrad k={k}")
+
+
+def _torch_ref(fn, *shape_seed):
+    return fn
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_maxpool_upsample_backward(K, dt, golden):
+    """Backward of the pool / bilinear kernels against autograd of the reference's own functional calls (stock torch CPU:
+    nn.MaxPool2d(3,2,1), F.interpolate(bilinear, align_corners=True)); ties in the pool input exercise the first-maximum rule."""
+    import torch.nn.functional as F
+    x = q(rnd(2, 16, 13, 18), dt)
+    x[0, :, 2:5, 3:6] = x[0, :, 2:3, 3:4]          # a plateau: several equal maxima inside windows
+    gy = q(rnd(2, 16, 7, 9), dt)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    F.max_pool2d(xt, 3, 2, 1).backward(torch.from_numpy(gy))
+    got = K.maxpool3x3s2_bwd(dev_nhwc(x, dt), dev_nhwc(gy, dt))
+    assert_close(host_nchw(got), xt.grad.numpy(), dt, "maxpool bwd")
+    for (C, hin, hout) in [(16, (6, 9), (21, 33)), (19, (7, 10), (14, 20)), (8, (16, 32), (64, 128))]:
+        g = q(rnd(2, C, *hout), dt)
+        xi = torch.zeros((2, C) + hin, requires_grad=True)
+        F.interpolate(xi, size=hout, mode="bilinear", align_corners=True).backward(torch.from_numpy(g))
+        gd = torch.from_numpy(np.ascontiguousarray(g.transpose(0, 2, 3, 1))).to(DT[dt]).cuda()
+        got = K.upsample_bilinear_ac_bwd(gd, hin, out_dtype=torch.float32)
+        assert_close(host_nchw(got), xi.grad.numpy(), "f32" if dt == "f32" else dt, f"upsample bwd C={C}")
+    # the ops.npz golden (outputs of the reference run) pins the torch CPU functional used above
+    g = golden("ops")
+    np.testing.assert_allclose(F.max_pool2d(torch.from_numpy(g["x"]), 3, 2, 1).numpy(), g["maxpool"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_relu_bn_bwd_channel_sums_bn_params_stem_wgrad(K, dt):
+    N, H, W, Cc = 2, 9, 14, 32
+    g, pre = q(rnd(N, Cc, H, W), dt), rnd(N, Cc, H, W)
+    gamma, beta, mean, var = np.abs(rnd(Cc)) + 0.5, rnd(Cc) * 0.2, rnd(Cc) * 0.1, np.abs(rnd(Cc)) + 0.5
+    act = q(orc.bn_eval(pre, gamma, beta, mean, var, relu=True), dt)
+    res = q(rnd(N, Cc, H, W), dt)
+    scale = (gamma / np.sqrt(var + 1e-5)).astype(np.float32)
+    ref = orc.bn_eval_bwd(g, act, gamma, var, relu=True)
+    got = K.relu_bn_bwd(dev_nhwc(g, dt), dev_nhwc(act, dt, ld=Cc + 16), torch.from_numpy(scale).cuda(), res=dev_nhwc(res, dt))
+    assert_close(host_nchw(got), ref + res, dt, "relu_bn_bwd")
+    # channel sums (+ product sums), global and per image, with the `sub` operand
+    gq = host_nchw(got)                      # as stored: g_x + res
+    s1, s2 = K.channel_sums(got, sub=dev_nhwc(res, dt), a=dev_nhwc(act, dt))
+    gx = gq.astype(np.float64) - res
+    np.testing.assert_allclose(s1.cpu().numpy(), gx.sum((0, 2, 3)), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(s2.cpu().numpy(), (gx * act).sum((0, 2, 3)), rtol=2e-3, atol=2e-3)
+    p1, _ = K.channel_sums(got, per_image=True)
+    np.testing.assert_allclose(p1.cpu().numpy(), gq.astype(np.float64).sum((2, 3)), rtol=2e-3, atol=2e-3)
+    # eval-BN parameter gradients vs autograd of F.batch_norm(training=False) + relu on the CPU
+    import torch.nn.functional as F
+    gt, bt = torch.from_numpy(gamma).requires_grad_(True), torch.from_numpy(beta).requires_grad_(True)
+    y = torch.relu(F.batch_norm(torch.from_numpy(pre), torch.from_numpy(mean), torch.from_numpy(var), gt, bt, False, 0.0, 1e-5))
+    y.backward(torch.from_numpy(g))
+    gxd = K.relu_bn_bwd(dev_nhwc(g, "f32"), dev_nhwc(y.detach().numpy(), "f32"), torch.from_numpy(scale).cuda())
+    s1, s2 = K.channel_sums(gxd, a=dev_nhwc(y.detach().numpy(), "f32"))
+    dg, db = torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda")
+    cu = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda()
+    K.bn_eval_param_grads(s1, s2, cu(scale), cu(gamma), cu(beta), dg, db)
+    np.testing.assert_allclose(dg.cpu().numpy(), gt.grad.numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(db.cpu().numpy(), bt.grad.numpy(), rtol=1e-3, atol=1e-3)
+    # stem weight gradient
+    xs, gys = rnd(2, 3, 11, 270), q(rnd(2, 64, 11, 270), dt)
+    dw = torch.empty((64, 3, 3, 3), device="cuda")
+    K.stem_wgrad(torch.from_numpy(xs).cuda(), dev_nhwc(gys, dt), dw)
+    assert_close(dw.cpu().numpy(), orc.conv2d_wgrad(xs, gys, (64, 3, 3, 3), pad=1), "f32", "stem wgrad")
+    # broadcast add
+    v = rnd(2, 32)
+    yb = dev_nhwc(q(rnd(2, 32, 5, 7), dt), dt)
+    y0 = host_nchw(yb).copy()
+    K.broadcast_add(torch.from_numpy(v).cuda(), yb, alpha=0.5)
+    assert_close(host_nchw(yb), y0 + 0.5 * v[:, :, None, None], dt, "broadcast add")
