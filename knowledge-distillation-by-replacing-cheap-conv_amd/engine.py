@@ -14,12 +14,19 @@ Design (MI355X-first, not a module-by-module translation):
     scale/shift of the consumer's BN) and, only where something needs it, the raw tensor
     (identity shortcuts, hint features, trunk outputs);
   * the in-place residual add is the conv epilogue's `res_pre`; concatenations are channel-slice
-    writes into one wide buffer (ASPP 1280 ch, decoder 304 -> 320 ch);
-  * backward is hand-scheduled: only the sub-graph between the first trainable block and the
-    last hint is visited; d(ReLU o BN)/dx is the dgrad kernels' mask epilogue; frozen dense convs
-    get no wgrad, trainable ones are the depthwise + pointwise pair;
-  * hint features captured by name at plan time (no Python hooks), reproducing the reference's
-    aliasing: a hint on the last conv of a residual block is the block output.
+    writes into one wide buffer (ASPP 5 x 256 ch, decoder 304 -> 320 ch);
+  * backward is hand-scheduled over the recorded tape and driven by `requires_grad`: a tensor's
+    gradient is computed only when a trainable parameter lies upstream of it, a parameter's only when
+    it is trainable.  The reference-faithful plan (only cheap-conv blocks train, loss = hint loss:
+    SURVEY F1/F4, "mode A") therefore visits just the sub-graph between the first trainable block
+    and the last hint; with `loss = kd + hint` and every student parameter trainable (SURVEY 8d
+    "mode B") the same code walks the whole network: logits -> bilinear/decoder/ASPP -> trunk ->
+    pools -> stem, with dense-conv / BN(eval) / stem weight gradients.  d(ReLU o BN)/dx is the dgrad
+    kernels' mask epilogue; eval-BN weight/bias gradients come from two channel sums of the masked
+    gradient against the saved activation;
+  * hint features are captured by name at plan time (no Python hooks), reproducing the reference's
+    aliasing: a hint on the last conv of a residual block -- or on its `convs` Sequential, or on the
+    block itself -- is the block output; `aspp` is the module's concatenated output.
 Parameters are read from the nn.Module tree (fp32 masters, reference checkpoint keys); packed
 operands are cached per parameter version, so frozen weights are packed once.
 """
@@ -38,6 +45,10 @@ class EngineError(RuntimeError):
 
 def _is_trainable(mod):
     return any(p.requires_grad for p in mod.parameters())
+
+
+def _bn_of(bn_seq):
+    return bn_seq[0] if isinstance(bn_seq, nn.Sequential) else bn_seq
 
 
 class _Site:
@@ -60,9 +71,6 @@ class _Site:
                 raise EngineError(f"{name}: only bias-free dense convs are supported")
             self.k, self.pad, self.dil, self.stride = conv.kernel_size[0], conv.padding[0], conv.dilation[0], conv.stride[0]
         self.trainable = _is_trainable(mod)
-        if self.trainable and not self.cheap:
-            raise EngineError(f"{name}: weight gradients of dense convs are not implemented (only cheap-conv blocks train; "
-                              "reference-faithful mode, SURVEY F4)")
 
 
 class StudentEngine:
@@ -70,8 +78,8 @@ class StudentEngine:
         self.net = net
         self.dtype = dtype
         self.hint_names = []
-        self._pack = {}   # (id(param), version, tag) -> packed tensor
-        self._bn = {}     # id(bn) -> (scale, shift)
+        self._pack = {}   # (id(param), tag) -> (version, packed tensor, param)
+        self._bn = {}     # id(bn) -> (version, (scale, shift), bn)
         self._tape = None
         self.last_hint_names = []
         self.reducer = None   # optional parallel.GradReducer: gradients are written into its buckets and announced
@@ -79,7 +87,7 @@ class StudentEngine:
     def _grad_like(self, p):
         if self.reducer is not None:
             return self.reducer.grad_buffer(p)
-        return torch.empty_like(p, dtype=torch.float32)
+        return torch.empty_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
 
     def _grad_done(self, p):
         if self.reducer is not None:
@@ -105,20 +113,27 @@ class StudentEngine:
         return self._packed(conv.weight, ("fwd", self.dtype, cin_pad),
                             lambda: ops.pack_conv_weight(conv.weight, self.dtype, KD_PACK_FWD, cin_pad))
 
-    def _w_dgrad(self, conv):
-        return self._packed(conv.weight, ("dgrad", self.dtype), lambda: ops.pack_conv_weight(conv.weight, self.dtype, KD_PACK_DGRAD))
+    def _w_dgrad(self, conv, cout_pad=None):
+        """[Cin][flipped taps][Cout] operand of the input-gradient conv; cout_pad zero-fills the contraction axis up to the
+        GEMM's K granule (the 19-class classifier, the 48-channel bot_fine)."""
+        def make():
+            w = conv.weight.detach()
+            if cout_pad is not None and cout_pad != w.shape[0]:
+                wp = torch.zeros((cout_pad,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
+                wp[:w.shape[0]] = w
+                w = wp
+            return ops.pack_conv_weight(w, self.dtype, KD_PACK_DGRAD)
+        return self._packed(conv.weight, ("dgrad", self.dtype, cout_pad), make)
 
     def _w_dw(self, conv, flip):
         return self._packed(conv.weight, ("dw", flip), lambda: ops.pack_dw_weight(conv.weight, flip))
 
     def _bn_fold(self, bn_seq):
         """bnrelu Sequential(BatchNorm2d, ReLU) or a bare BatchNorm2d -> cached (scale, shift)."""
-        bn = bn_seq[0] if isinstance(bn_seq, nn.Sequential) else bn_seq
+        bn = _bn_of(bn_seq)
         if bn.training:
             raise EngineError("the fused student graph implements eval-mode BatchNorm only (LayerwiseTrainer keeps the "
                               "student in eval mode, SURVEY F3)")
-        if bn.weight.requires_grad or bn.bias.requires_grad:
-            raise EngineError("trainable BatchNorm parameters are not supported in the fused graph")
         key = id(bn)
         ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, bn.weight.device)
         ent = self._bn.get(key)
@@ -132,6 +147,14 @@ class StudentEngine:
         return f((N, H, W, C), dtype=dtype or self.dtype, device=self.device)
 
     # ------------------------------------------------------------------ forward
+    def _flat_blocks(self):
+        net = self.net
+        flat = [(f"mod{i}.{bn}", blk) for i in range(2, 8) for bn, blk in getattr(net, f"mod{i}").named_children()]
+        for name, blk in flat:
+            if not isinstance(blk, IdentityResidualBlock):
+                raise EngineError(f"{name}: expected an IdentityResidualBlock")
+        return flat
+
     def forward(self, x, collect_hints=True):
         """x: (N,3,H,W) fp32.  Returns (logits (N,H,W,19) fp32 NHWC, [hint tensors (N,h,w,C) NHWC] in forward order)."""
         net = self.net
@@ -144,10 +167,10 @@ class StudentEngine:
         want = set(self.hint_names) if collect_hints else set()
         seen = []
         hints = []
-        tape = {"blocks": [], "aspp": None, "hint_slots": []}
+        tape = {"blocks": [], "aspp": None, "hint_slots": [], "pools": {}}
 
         def note_hint(name, tensor, slot):
-            # slot: ("block", block_index, site_index | "out") or ("aspp", branch)
+            # slot: ("block", block_index, site_index | "out"), ("aspp", branch) or ("aspp_out",)
             seen.append(name)
             hints.append(tensor)
             tape["hint_slots"].append(slot)
@@ -155,20 +178,17 @@ class StudentEngine:
         xin = x.detach()
         if xin.dtype != torch.float32 or not xin.is_contiguous():
             xin = xin.float().contiguous()
-        stem_w = net.mod1.conv1.weight.detach()
+        stem = net.mod1.conv1
+        stem_w = stem.weight.detach()
         s = ops.stem_conv(xin, stem_w if stem_w.is_contiguous() else stem_w.contiguous(), self.dtype)
+        rg = stem.weight.requires_grad
+        tape["stem"] = dict(x=xin, s=s, rg=rg)
 
-        # trunk: (module name, list of blocks)
-        mods = [(f"mod{i}", getattr(net, f"mod{i}")) for i in range(2, 8)]
-        flat = [(f"{mn}.{bn}", blk) for mn, m in mods for bn, blk in m.named_children()]
-        for name, blk in flat:
-            if not isinstance(blk, IdentityResidualBlock):
-                raise EngineError(f"{name}: expected an IdentityResidualBlock")
-
+        flat = self._flat_blocks()
         # pool2 (+ bn1 of mod2.block1)
         sc1, sh1 = self._bn_fold(flat[0][1].bn1)
         _, a = ops.maxpool3x3s2(s, sc1, sh1, want_raw=False)
-        x_raw, rg = None, False
+        x_raw = None
         m2 = None
         for bi, (name, blk) in enumerate(flat):
             last_of_mod2 = name.startswith("mod2.") and (bi + 1 == len(flat) or not flat[bi + 1][0].startswith("mod2."))
@@ -182,24 +202,36 @@ class StudentEngine:
                 m2 = x_raw
                 sc, sh = self._bn_fold(flat[bi + 1][1].bn1)
                 _, a = ops.maxpool3x3s2(m2, sc, sh, want_raw=False)  # pool3 + bn1 of mod3.block1
+                tape["pools"]["pool3"] = dict(x=m2, after=bi, rg=rg)
                 x_raw = None
-                if rg:
-                    raise EngineError("trainable blocks in mod2 would need a max-pool backward (not implemented)")
         x7, rg7 = x_raw, rg
 
-        # ASPP -> 1280-channel buffer, branches write their slices
-        aspp = net.aspp
-        h8, w8 = x7.shape[1], x7.shape[2]
-        cat = self._new(N, h8, w8, 1280)
+        cat, rg_cat = self._aspp_fwd(net.aspp, x7, rg7, want, note_hint, tape)
+        logits = self._decoder_fwd(cat, rg_cat, m2, tape["pools"]["pool3"]["rg"], (H, W), tape)
+
+        missing = want - set(seen)
+        if missing:
+            raise EngineError(f"hint layers not found in the student graph: {sorted(missing)}")
+        self._tape = tape
+        self.last_hint_names = list(seen)   # forward-execution order (what hooks would have produced)
+        return logits, hints
+
+    def _aspp_fwd(self, aspp, x7, rg7, want, note_hint, tape):
+        """ASPP (deeplabv3.py:64-75): branches write their channel slices of one concat buffer, image branch first."""
+        N, h8, w8, _ = x7.shape
+        red = aspp.img_conv[0].out_channels
+        nb = len(aspp.features)
+        cat = self._new(N, h8, w8, red * (nb + 1))
         sc, sh = self._bn_fold(aspp.img_conv[1])
-        ops.aspp_image_pool(x7, aspp.img_conv[0].weight.detach(), sc, sh, cat[..., 0:256])
-        arec = {"x7": x7, "rg7": rg7, "branches": []}
+        ops.aspp_image_pool(x7, aspp.img_conv[0].weight.detach(), sc, sh, cat[..., 0:red])
+        arec = {"x7": x7, "rg7": rg7, "branches": [], "cat": cat, "red": red, "mod": aspp}
+        rg_cat = rg7 or _is_trainable(aspp.img_conv)
         for i, br in enumerate(aspp.features):
             site = _Site(f"aspp.features.{i}.0", br[0])
             sc, sh = self._bn_fold(br[1])
             hinted = site.name in want
-            raw = self._new(N, h8, w8, 256) if hinted else None
-            out = cat[..., 256 * (i + 1):256 * (i + 2)]
+            raw = self._new(N, h8, w8, red) if hinted else None
+            out = cat[..., red * (i + 1):red * (i + 2)]
             mid = None
             if site.cheap:
                 mid = ops.dwconv(x7, self._w_dw(site.mod.separable_conv, False), site.k, site.pad, site.dil)
@@ -210,39 +242,47 @@ class StudentEngine:
                            act_shift=sh, act_relu=True)
             if hinted:
                 note_hint(site.name, raw, ("aspp", i))
-            arec["branches"].append({"site": site, "mid": mid})
+            arec["branches"].append({"site": site, "mid": mid, "bn": br[1]})
+            rg_cat = rg_cat or site.trainable or _is_trainable(br[1])
+        if "aspp" in want:
+            note_hint("aspp", cat, ("aspp_out",))
         tape["aspp"] = arec
+        return cat, rg_cat
 
-        # decoder (no gradient reaches it in the reference-faithful mode: loss = hint loss only)
-        up_small = self._new(N, h8, w8, 256)
+    def _decoder_fwd(self, cat, rg_cat, m2, rg_m2, size, tape):
+        """bot_aspp / bot_fine / upsample x4 / final / upsample to the input size (deeplabv3.py:141-162)."""
+        net = self.net
+        N, h8, w8, _ = cat.shape
+        up_small = self._new(N, h8, w8, net.bot_aspp.out_channels)
         ops.conv2d(cat, self._w_fwd(net.bot_aspp), out_raw=up_small)
         h2, w2 = m2.shape[1], m2.shape[2]
-        dec0 = self._new(N, h2, w2, 320)  # 48 + 256 = 304 channels, zero-padded to the GEMM K granule
-        dec0[..., 304:320].zero_()       # (only the 16 pad channels: the slices below fill the rest)
-        ops.conv2d(m2, self._w_fwd(net.bot_fine), out_raw=dec0[..., 0:48])
-        ops.upsample_bilinear_ac(up_small, (h2, w2), out=dec0[..., 48:304])
+        nf, nu = net.bot_fine.out_channels, net.bot_aspp.out_channels
+        cdec = nf + nu
+        cpad = ((cdec + 63) // 64) * 64          # 48 + 256 = 304 -> 320: the GEMM K granule
+        dec0 = self._new(N, h2, w2, cpad)
+        if cpad > cdec:
+            dec0[..., cdec:cpad].zero_()         # (only the pad channels: the slices below fill the rest)
+        ops.conv2d(m2, self._w_fwd(net.bot_fine), out_raw=dec0[..., 0:nf])
+        ops.upsample_bilinear_ac(up_small, (h2, w2), out=dec0[..., nf:cdec])
         f = net.final
         sc, sh = self._bn_fold(f[1])
-        d1 = self._new(N, h2, w2, 256)
-        ops.conv2d(dec0, self._w_fwd(f[0], cin_pad=320), 1, 1, 1, out_act=d1, act_scale=sc, act_shift=sh, act_relu=True,
-                   algo_cin=304)
+        d1 = self._new(N, h2, w2, f[0].out_channels)
+        ops.conv2d(dec0, self._w_fwd(f[0], cin_pad=cpad), 1, 1, 1, out_act=d1, act_scale=sc, act_shift=sh, act_relu=True,
+                   algo_cin=cdec)
         sc, sh = self._bn_fold(f[4])
-        d2 = self._new(N, h2, w2, 256)
+        d2 = self._new(N, h2, w2, f[3].out_channels)
         ops.conv2d(d1, self._w_fwd(f[3]), 1, 1, 1, out_act=d2, act_scale=sc, act_shift=sh, act_relu=True)
         ncls = f[6].out_channels
         d3 = self._new(N, h2, w2, ncls, dtype=torch.float32)
         ops.conv2d(d2, self._w_fwd(f[6]), out_raw=d3)
-        logits = ops.upsample_bilinear_ac(d3, (H, W), out_dtype=torch.float32)
-
-        missing = want - set(seen)
-        if missing:
-            raise EngineError(f"hint layers not found in the student graph: {sorted(missing)}")
-        self._tape = tape
-        self.last_hint_names = list(seen)   # forward-execution order (what hooks would have produced)
-        return logits, hints
+        logits = ops.upsample_bilinear_ac(d3, size, out_dtype=torch.float32)
+        tape["dec"] = dict(cat=cat, rg_cat=rg_cat, m2=m2, rg_m2=rg_m2, dec0=dec0, d1=d1, d2=d2, cdec=cdec, nf=nf, size=size,
+                           small=(h8, w8))
+        return logits
 
     def _block_fwd(self, name, blk, x_raw, a1, rg_in, next_bn, need_raw, want, note_hint, bi):
-        """One pre-activation residual block.  a1 = relu(bn1(x)) already produced by the previous kernel."""
+        """One pre-activation residual block.  a1 = relu(bn1(x)) already produced by the previous kernel.
+        rg_in: a trainable parameter lies upstream of the block input."""
         convs = [(n, m) for n, m in blk.convs.named_children() if n.startswith("conv")]
         bns = {n: m for n, m in blk.convs.named_children() if n.startswith("bn")}
         for n, m in blk.convs.named_children():
@@ -252,20 +292,21 @@ class StudentEngine:
         N = a1.shape[0]
         rec = {"name": name, "blk": blk, "sites": sites, "a_in": [], "mid": [], "rg_a": [], "hint_raw": [None] * len(sites),
                "x_raw": x_raw, "rg_in": rg_in, "proj": hasattr(blk, "proj_conv")}
+        rg_a1 = rg_in or _is_trainable(blk.bn1)      # a1 = relu(bn1(x))
         # shortcut
         if rec["proj"]:
             pc = blk.proj_conv
-            if _is_trainable(pc):
-                raise EngineError(f"{name}.proj_conv: trainable projection convs are not supported")
             ho = ops.conv_out_size(a1.shape[1], 1, pc.stride[0], 0, 1)
             wo = ops.conv_out_size(a1.shape[2], 1, pc.stride[0], 0, 1)
             shortcut = self._new(N, ho, wo, pc.out_channels)
             ops.conv2d(a1, self._w_fwd(pc), pc.stride[0], 0, 1, out_raw=shortcut)
+            rg_short = rg_a1 or pc.weight.requires_grad
         else:
             if x_raw is None:
                 raise EngineError(f"{name}: identity shortcut needs the raw block input")
             shortcut = x_raw
-        a, rg = a1, rg_in
+            rg_short = rg_in
+        a, rg = a1, rg_a1
         x_out = a_next = None
         for i, site in enumerate(sites):
             last = i + 1 == len(sites)
@@ -313,31 +354,53 @@ class StudentEngine:
                     note_hint(site.name, raw, ("block", bi, i))
             if not last:
                 a = act
-        rec["rg_out"] = rg  # rg already includes rg_in (shortcut path)
-        return x_out, a_next, rg, rec
+                rg = rg or _is_trainable(bns[f"bn{i + 2}"])
+        rec["rg_out"] = rg or rg_short
+        return x_out, a_next, rec["rg_out"], rec
 
     # ------------------------------------------------------------------ backward
     def grad_production_order(self):
-        """Trainable parameters in the order backward produces their gradients (ASPP branches first, then the trunk
-        blocks from mod7 back to the first trainable block; within a block last conv first, pointwise before depthwise)."""
+        """Trainable parameters in the order backward produces their gradients: decoder (classifier first), ASPP, then the
+        trunk blocks from mod7 back to mod2 (within a block last conv first; pointwise before depthwise; a conv before the
+        BN that feeds it), the stem last.  Used to lay out the all-reduce buckets."""
         net, order = self.net, []
 
-        def add(mod):
+        def add_p(*ps):
+            for p in ps:
+                if p is not None and p.requires_grad and all(p is not q for q in order):
+                    order.append(p)
+
+        def add_conv(mod):
             if isinstance(mod, DepthwiseSeparableBlock):
-                for p in (mod.pointwise_conv.weight, mod.separable_conv.weight):
-                    if p.requires_grad:
-                        order.append(p)
+                add_p(mod.pointwise_conv.weight, mod.separable_conv.weight)
+            else:
+                add_p(mod.weight)
+
+        def add_bn(seq):
+            bn = _bn_of(seq)
+            add_p(bn.weight, bn.bias)
+        f = net.final
+        add_conv(f[6]); add_bn(f[4]); add_conv(f[3]); add_bn(f[1]); add_conv(f[0])
+        add_conv(net.bot_fine); add_conv(net.bot_aspp)
+        add_bn(net.aspp.img_conv[1]); add_conv(net.aspp.img_conv[0])
         for br in net.aspp.features:
-            add(br[0])
-        blocks = [blk for i in range(2, 8) for _, blk in getattr(net, f"mod{i}").named_children()]
-        for blk in reversed(blocks):
-            for _, m in reversed([(n, m) for n, m in blk.convs.named_children() if n.startswith("conv")]):
-                add(m)
+            add_bn(br[1]); add_conv(br[0])
+        for _, blk in reversed(self._flat_blocks()):
+            items = list(blk.convs.named_children())
+            for n, m in reversed(items):
+                if n.startswith("conv"):
+                    add_conv(m)
+                elif n.startswith("bn"):
+                    add_bn(m)
+            if hasattr(blk, "proj_conv"):
+                add_conv(blk.proj_conv)
+            add_bn(blk.bn1)
+        add_conv(net.mod1.conv1)
         return order
 
-    def backward(self, hint_grads):
-        """hint_grads: list aligned with forward()'s hints; entries are (N,h,w,C) NHWC tensors or None.
-        Returns {parameter: fp32 gradient} for every trainable parameter reached."""
+    def backward(self, hint_grads, g_logits=None):
+        """hint_grads: list aligned with forward()'s hints; entries are (N,h,w,C) NHWC tensors or None.  g_logits: gradient
+        w.r.t. the (N,H,W,classes) logits or None.  Returns {parameter: fp32 gradient} for every trainable parameter reached."""
         tape = self._tape
         if tape is None:
             raise EngineError("backward() called without a recorded forward()")
@@ -346,37 +409,35 @@ class StudentEngine:
         grads = {}
         g_block_out = {}   # block index -> grad wrt raw block output
         g_site_hint = {}   # (block index, site index) -> hint grad of that site's raw output
-        g_aspp = {}
+        g_aspp = {}        # branch -> grad wrt the branch conv's raw output
+        g_cat_hint = None  # grad wrt the ASPP module output (behind BN+ReLU)
+
+        def acc(d, k, g):
+            d[k] = g if k not in d else d[k] + g
         for g, slot in zip(hint_grads, tape["hint_slots"]):
             if g is None:
                 continue
             g = self._as_nhwc(g)
             if slot[0] == "aspp":
-                g_aspp[slot[1]] = g if slot[1] not in g_aspp else g_aspp[slot[1]] + g
+                acc(g_aspp, slot[1], g)
+            elif slot[0] == "aspp_out":
+                g_cat_hint = g if g_cat_hint is None else g_cat_hint + g
             elif slot[2] == "out":
-                g_block_out[slot[1]] = g if slot[1] not in g_block_out else g_block_out[slot[1]] + g
+                acc(g_block_out, slot[1], g)
             else:
-                key = (slot[1], slot[2])
-                g_site_hint[key] = g if key not in g_site_hint else g_site_hint[key] + g
+                acc(g_site_hint, (slot[1], slot[2]), g)
 
-        # ASPP branches: the only consumers of mod7's output that carry gradient (decoder is outside the loss)
-        arec = tape["aspp"]
-        g_x7 = None
-        for i, br in enumerate(arec["branches"]):
-            g = g_aspp.get(i)
-            if g is None:
-                continue
-            site = br["site"]
-            if site.cheap:
-                g_in = self._cheap_bwd(site, arec["x7"], br["mid"], g, grads, need_in=arec["rg7"], res_post=g_x7)
-            else:
-                g_in = self._dense_dgrad(site, g, res_post=g_x7) if arec["rg7"] else None
-            if g_in is not None:
-                g_x7 = g_in
         nb = len(tape["blocks"])
+        g_cat = None
+        if g_logits is not None:
+            g_cat, g_m2 = self._decoder_bwd(self._as_nhwc(g_logits, torch.float32), grads)
+            if g_m2 is not None:
+                acc(g_block_out, tape["pools"]["pool3"]["after"], g_m2)
+        g_x7 = self._aspp_bwd(g_cat, g_cat_hint, g_aspp, grads)
         if g_x7 is not None:
             g_block_out[nb - 1] = g_x7 if (nb - 1) not in g_block_out else g_block_out[nb - 1].add_(g_x7)
 
+        pool3 = tape["pools"]["pool3"]
         for bi in range(nb - 1, -1, -1):
             rec = tape["blocks"][bi]
             g_out = g_block_out.pop(bi, None)
@@ -384,37 +445,88 @@ class StudentEngine:
             if g_out is None and not has_inner:
                 continue
             g_xin = self._block_bwd(bi, rec, g_out, g_site_hint, grads)
-            if g_xin is not None:
-                if bi == 0:
-                    raise EngineError("gradient reached the stem: not supported")
-                prev = tape["blocks"][bi - 1]
-                if prev["name"].split(".")[0] != rec["name"].split(".")[0] and prev["name"].startswith("mod2."):
-                    raise EngineError("gradient through pool3 is not supported")
+            if g_xin is None:
+                continue
+            if bi == pool3["after"] + 1:
+                g_prev = ops.maxpool3x3s2_bwd(pool3["x"], g_xin)     # pool3: back to mod2's output
+                g_block_out[bi - 1] = g_prev if (bi - 1) not in g_block_out else g_block_out[bi - 1].add_(g_prev)
+            elif bi == 0:
+                st = tape["stem"]                                     # pool2, then the stem conv's weight gradient
+                g_s = ops.maxpool3x3s2_bwd(st["s"], g_xin)
+                w = self.net.mod1.conv1.weight
+                gw = self._grad_like(w)
+                ops.stem_wgrad(st["x"], g_s, gw)
+                grads[w] = gw
+                self._grad_done(w)
+            else:
                 g_block_out[bi - 1] = g_xin if (bi - 1) not in g_block_out else g_block_out[bi - 1].add_(g_xin)
         self._tape = None
         if self.reducer is not None:
+            for p in self.reducer.params:      # trainable parameters this loss does not reach: zero gradient, bucket complete
+                if p not in grads:
+                    self.reducer.grad_buffer(p).zero_()
+                    self.reducer.grad_ready(p)
             self.reducer.finish()   # current stream waits for the (already overlapped) bucket all-reduces
         return grads
 
-    def _as_nhwc(self, g):
+    def _as_nhwc(self, g, dtype=None):
         """Accept an NCHW-logical gradient (the autograd view) or an NHWC tensor; return dense NHWC in the engine dtype."""
+        dtype = dtype or self.dtype
         if g.dim() != 4:
-            raise EngineError("hint gradients must be 4-D")
+            raise EngineError("gradients must be 4-D")
         if g.stride(1) == 1 and g.stride(3) != 1:  # logical NCHW over NHWC memory
             g = g.permute(0, 2, 3, 1)
         elif g.stride(3) != 1:
             g = g.permute(0, 2, 3, 1).contiguous()
-        if g.dtype != self.dtype:
-            g = g.to(self.dtype)
+        if g.dtype != dtype:
+            g = g.to(dtype)
         if not g.is_contiguous():
             g = g.contiguous()
         return g
 
-    def _dense_dgrad(self, site, g, **ep):
-        if site.stride != 1:
-            raise EngineError(f"{site.name}: input gradient of a strided conv is not implemented")
-        N, H, W, _ = g.shape
+    # ---- parameter gradients ------------------------------------------------------------------------------------------
+    def _conv_wgrad(self, conv, a_in, g, grads, cin=None):
+        """Weight gradient of a dense conv (a_in = its input as stored, g = gradient of its raw output)."""
+        w = conv.weight
+        if not w.requires_grad:
+            return
+        if cin is not None and cin != a_in.shape[3]:
+            a_in = a_in[..., :cin]
+        gw = self._grad_like(w)
+        ops.conv2d_wgrad(a_in, g, gw, conv.stride[0], conv.padding[0], conv.dilation[0])
+        grads[w] = gw
+        self._grad_done(w)
+
+    def _bn_param_grads(self, bn_seq, g_x, act, grads, sub=None):
+        """Eval-mode BN weight/bias gradients.  g_x: gradient w.r.t. the BN input (already through the ReLU mask and the BN
+        scale; `sub` = a tensor that was added to it afterwards, e.g. the shortcut gradient), act = relu(bn(x))."""
+        bn = _bn_of(bn_seq)
+        if not (bn.weight.requires_grad or bn.bias.requires_grad):
+            return
+        scale, _ = self._bn_fold(bn_seq)
+        s1, s2 = ops.channel_sums(g_x, sub=sub, a=act)
+        self._bn_grads_from_sums(bn, scale, s1, s2, grads)
+
+    def _bn_grads_from_sums(self, bn, scale, s1, s2, grads):
+        dg, db = self._grad_like(bn.weight), self._grad_like(bn.bias)
+        ops.bn_eval_param_grads(s1.contiguous(), s2.contiguous(), scale, bn.weight.detach().float().contiguous(),
+                                bn.bias.detach().float().contiguous(), dg, db)
+        for p, gbuf in ((bn.weight, dg), (bn.bias, db)):
+            if p.requires_grad:
+                grads[p] = gbuf
+                self._grad_done(p)
+
+    # ---- input gradients ------------------------------------------------------------------------------------------------
+    def _dense_dgrad(self, site, g, in_hw=None, **ep):
+        """Input gradient of a dense conv: a stride-1 conv with flipped taps; a strided conv's output gradient is first
+        zero-inserted onto the input grid (mod4.block1: conv1 3x3/s2 and the 1x1/s2 projection)."""
         conv = site.mod
+        N, H, W, _ = g.shape
+        if site.stride != 1:
+            if in_hw is None:
+                raise EngineError(f"{site.name}: strided input gradient needs the input size")
+            g = ops.zero_insert(g, site.stride, in_hw)
+            H, W = in_hw
         out = self._new(N, H, W, conv.in_channels)
         ops.conv2d(g, self._w_dgrad(conv), 1, site.dil * (site.k - 1) - site.pad, site.dil, out_raw=out, **ep)
         return out
@@ -441,41 +553,193 @@ class StudentEngine:
             return None
         return ops.dwconv(g_mid, self._w_dw(dw, True), site.k, site.dil * (site.k - 1) - site.pad, site.dil, **ep)
 
+    def _site_bwd(self, site, a_in, mid, g, grads, need_in, **ep):
+        """Weight gradient(s) of one conv site and, when need_in, its input gradient through epilogue `ep`."""
+        if site.cheap:
+            return self._cheap_bwd(site, a_in, mid, g, grads, need_in, **ep)
+        self._conv_wgrad(site.mod, a_in, g, grads)
+        if not need_in:
+            return None
+        return self._dense_dgrad(site, g, in_hw=(a_in.shape[1], a_in.shape[2]), **ep)
+
     def _block_bwd(self, bi, rec, g_out, g_site_hint, grads):
+        """g_out: gradient w.r.t. the block output (or None).  Returns the gradient w.r.t. the raw block input, or None when
+        nothing upstream is trainable."""
         blk, sites = rec["blk"], rec["sites"]
         bns = {n: m for n, m in blk.convs.named_children() if n.startswith("bn")}
         g = g_out  # gradient w.r.t. the raw output of the current site (last site: the block output)
         for i in range(len(sites) - 1, -1, -1):
             site, a_in, need_in = sites[i], rec["a_in"][i], rec["rg_a"][i]
             g_in = None
+            bn_seq = bns[f"bn{i + 1}"] if i > 0 else blk.bn1
             if g is not None and (need_in or site.trainable):
+                sc, _ = self._bn_fold(bn_seq)
+                ep = dict(mask=a_in, mask_scale=sc)
+                sub = None
                 if i > 0:
                     # a_in = relu(bn_{i+1}(c_{i-1})): mask epilogue gives d/dc_{i-1}; add that tensor's own hint gradient
-                    sc, _ = self._bn_fold(bns[f"bn{i + 1}"])
-                    ep = dict(mask=a_in, mask_scale=sc, res_post=g_site_hint.get((bi, i - 1)))
-                else:
-                    sc, _ = self._bn_fold(blk.bn1)
-                    ep = dict(mask=a_in, mask_scale=sc)
-                    if need_in and g_out is not None:
-                        if rec["proj"]:
-                            pc = blk.proj_conv
-                            psite = _Site(f"{rec['name']}.proj_conv", pc)
-                            ep["res_pre"] = self._dense_dgrad(psite, g_out)
-                        else:
-                            ep["res_post"] = g_out
-                if site.cheap:
-                    g_in = self._cheap_bwd(site, a_in, rec["mid"][i], g, grads, need_in, **ep)
-                elif need_in:
-                    g_in = self._dense_dgrad(site, g, **ep)
-            elif i > 0 and need_in and g_site_hint.get((bi, i - 1)) is not None:
-                pass  # handled below: only the hint gradient flows
+                    sub = g_site_hint.get((bi, i - 1))
+                    ep["res_post"] = sub
+                elif g_out is not None:
+                    if rec["proj"]:
+                        psite = _Site(f"{rec['name']}.proj_conv", blk.proj_conv)
+                        self._conv_wgrad(blk.proj_conv, a_in, g_out, grads)
+                        if need_in:
+                            ep["res_pre"] = self._dense_dgrad(psite, g_out, in_hw=(a_in.shape[1], a_in.shape[2]))
+                    elif rec["rg_in"]:
+                        sub = g_out
+                        ep["res_post"] = g_out
+                g_in = self._site_bwd(site, a_in, rec["mid"][i], g, grads, need_in, **ep)
+                if g_in is not None:
+                    self._bn_param_grads(bn_seq, g_in, a_in, grads, sub=sub)
+            elif i == 0 and g is None and g_out is not None:
+                # only the shortcut carries gradient into this block's input
+                if rec["proj"]:
+                    self._conv_wgrad(blk.proj_conv, a_in, g_out, grads)
+                    if need_in:
+                        psite = _Site(f"{rec['name']}.proj_conv", blk.proj_conv)
+                        sc, _ = self._bn_fold(blk.bn1)
+                        g_in = self._dense_dgrad(psite, g_out, in_hw=(a_in.shape[1], a_in.shape[2]), mask=a_in, mask_scale=sc)
+                        self._bn_param_grads(blk.bn1, g_in, a_in, grads)
+                elif rec["rg_in"]:
+                    g_in = g_out
             if i > 0:
                 if g_in is None:
                     g_in = g_site_hint.get((bi, i - 1)) if rec["rg_a"][i] else None
                 g = g_in
             else:
-                return g_in if rec["rg_in"] else None
+                if not rec["rg_in"]:
+                    return None
+                return g_in
         return None
+
+    def _aspp_bwd(self, g_cat, g_cat_hint, g_aspp, grads):
+        """g_cat: gradient w.r.t. the RAW branch outputs as one concat-shaped tensor (already through each branch's
+        BN+ReLU, from the bot_aspp dgrad epilogue) or None; g_cat_hint: gradient w.r.t. the activated concat (an `aspp`
+        hint); g_aspp: {branch: gradient w.r.t. that branch conv's raw output} (hints on aspp.features.N.0).
+        Returns the gradient w.r.t. mod7's output, or None."""
+        arec = self._tape["aspp"]
+        aspp, cat, red, x7, rg7 = arec["mod"], arec["cat"], arec["red"], arec["x7"], arec["rg7"]
+        if g_cat_hint is not None:
+            scale = self._cat_scale(aspp)
+            g_cat = ops.relu_bn_bwd(g_cat_hint, cat, scale, res=g_cat)
+        g_x7 = None
+        for i, br in enumerate(arec["branches"]):
+            sl = slice(red * (i + 1), red * (i + 2))
+            g = g_aspp.get(i)
+            if g_cat is not None:
+                gi = g_cat[..., sl]
+                self._bn_param_grads(br["bn"], gi, cat[..., sl], grads)
+                g = gi if g is None else g + gi
+            if g is None:
+                continue
+            site = br["site"]
+            if site.cheap and not g.is_contiguous():
+                g = g.contiguous()   # the depthwise / pointwise-wgrad kernels take dense views
+            g_in = self._site_bwd(site, x7, br["mid"], g, grads, rg7, res_post=g_x7)
+            if g_in is not None:
+                g_x7 = g_in
+        if g_cat is not None:
+            g_x7 = self._image_pool_bwd(arec, g_cat[..., 0:red], grads, g_x7)
+        return g_x7
+
+    def _cat_scale(self, aspp):
+        """BN scales of [image branch, features 0..] concatenated: the mask_scale of the concat buffer."""
+        bns = [aspp.img_conv[1]] + [br[1] for br in aspp.features]
+        key = tuple(id(_bn_of(b)) for b in bns)
+        vers = tuple(self._bn_fold(b)[0].data_ptr() for b in bns)
+        ent = self._bn.get(("cat", key))
+        if ent is None or ent[0] != vers:
+            ent = (vers, (torch.cat([self._bn_fold(b)[0] for b in bns]).contiguous(), None), None)
+            self._bn[("cat", key)] = ent
+        return ent[1][0]
+
+    def _image_pool_bwd(self, arec, g_img, grads, g_x7):
+        """Backward of the image-pooling branch (deeplabv3.py:59-62,67-70): g_img is the gradient of the broadcast branch
+        output, already masked and scaled per channel.  Per-image (N x 256 / N x 4096) algebra only; the two reductions
+        over pixels and the broadcast are kernels."""
+        aspp, x7, rg7, cat, red = arec["mod"], arec["x7"], arec["rg7"], arec["cat"], arec["red"]
+        conv, bn = aspp.img_conv[0], _bn_of(aspp.img_conv[1])
+        train = conv.weight.requires_grad or bn.weight.requires_grad or bn.bias.requires_grad
+        if not (rg7 or train):
+            return g_x7
+        N, h8, w8, cin = x7.shape
+        gz, _ = ops.channel_sums(g_img, per_image=True)             # (N, red): d loss / d conv output
+        if train:
+            mean, _ = ops.channel_sums(x7, per_image=True)
+            mean = mean / float(h8 * w8)
+            if conv.weight.requires_grad:
+                gw = self._grad_like(conv.weight)
+                gw.copy_((gz.t() @ mean).view_as(gw))
+                grads[conv.weight] = gw
+                self._grad_done(conv.weight)
+            if bn.weight.requires_grad or bn.bias.requires_grad:
+                y = cat[:, 0, 0, 0:red].float()                      # relu(bn(conv(mean))) per image
+                scale, _ = self._bn_fold(aspp.img_conv[1])
+                self._bn_grads_from_sums(bn, scale, gz.sum(0), (gz * y).sum(0), grads)
+        if not rg7:
+            return g_x7
+        vec = (gz @ conv.weight.detach().float().view(red, cin)).contiguous()   # (N, cin)
+        if g_x7 is None:
+            g_x7 = self._new(N, h8, w8, cin)
+            ops.broadcast_add(vec, g_x7, alpha=1.0 / float(h8 * w8), accumulate=False)
+        else:
+            ops.broadcast_add(vec, g_x7, alpha=1.0 / float(h8 * w8), accumulate=True)
+        return g_x7
+
+    def _decoder_bwd(self, g_logits, grads):
+        """Backward of upsample / final / concat / bot_fine / upsample x4 / bot_aspp.  Returns (g_cat, g_m2): the gradient
+        w.r.t. the raw ASPP branch outputs (concat-shaped, through BN+ReLU) and w.r.t. mod2's output -- None where nothing
+        upstream is trainable."""
+        net, dec = self.net, self._tape["dec"]
+        f = net.final
+        N, h2, w2, _ = dec["d2"].shape
+        cdec, nf = dec["cdec"], dec["nf"]
+        rg_dec0 = dec["rg_cat"] or dec["rg_m2"] or _is_trainable(net.bot_aspp) or _is_trainable(net.bot_fine)
+        rg_d1 = rg_dec0 or _is_trainable(f[0]) or _is_trainable(f[1])
+        rg_d2 = rg_d1 or _is_trainable(f[3]) or _is_trainable(f[4])
+        if not (rg_d2 or _is_trainable(f[6])):
+            return None, None
+        ncls = f[6].out_channels
+        kpad = ((ncls + 63) // 64) * 64
+        g_d3 = self._new(N, h2, w2, kpad, zero=True)               # classes padded to the GEMM K granule
+        ops.upsample_bilinear_ac_bwd(g_logits, (h2, w2), out=g_d3[..., :ncls])
+        self._conv_wgrad(f[6], dec["d2"], g_d3[..., :ncls], grads)
+        if not rg_d2:
+            return None, None
+        sc, _ = self._bn_fold(f[4])
+        g_c2 = self._new(N, h2, w2, f[3].out_channels)
+        ops.conv2d(g_d3, self._w_dgrad(f[6], cout_pad=kpad), out_raw=g_c2, mask=dec["d2"], mask_scale=sc)
+        self._bn_param_grads(f[4], g_c2, dec["d2"], grads)
+        self._conv_wgrad(f[3], dec["d1"], g_c2, grads)
+        if not rg_d1:
+            return None, None
+        sc, _ = self._bn_fold(f[1])
+        g_c1 = self._dense_dgrad(_Site("final.3", f[3]), g_c2, mask=dec["d1"], mask_scale=sc)
+        self._bn_param_grads(f[1], g_c1, dec["d1"], grads)
+        self._conv_wgrad(f[0], dec["dec0"], g_c1, grads, cin=cdec)
+        if not rg_dec0:
+            return None, None
+        g_dec0 = self._new(N, h2, w2, cdec)
+        ops.conv2d(g_c1, self._w_dgrad(f[0]), 1, 1, 1, out_raw=g_dec0)
+        # bot_fine (1x1 on mod2's output)
+        g_m2 = None
+        self._conv_wgrad(net.bot_fine, dec["m2"], g_dec0[..., 0:nf], grads)
+        if dec["rg_m2"]:
+            kf = ((nf + 63) // 64) * 64
+            g_m2 = self._new(N, h2, w2, net.bot_fine.in_channels)
+            # K = 48 -> 64: the 16 extra input channels belong to the upsampled part and meet zero weight rows
+            ops.conv2d(g_dec0[..., 0:kf], self._w_dgrad(net.bot_fine, cout_pad=kf), out_raw=g_m2)
+        # upsample x4 and bot_aspp (1x1 on the ASPP concat)
+        g_cat = None
+        if dec["rg_cat"] or _is_trainable(net.bot_aspp):
+            g_up = ops.upsample_bilinear_ac_bwd(g_dec0[..., nf:cdec], dec["small"])
+            self._conv_wgrad(net.bot_aspp, dec["cat"], g_up, grads)
+            if dec["rg_cat"]:
+                cat = dec["cat"]
+                g_cat = self._new(N, cat.shape[1], cat.shape[2], cat.shape[3])
+                ops.conv2d(g_up, self._w_dgrad(net.bot_aspp), out_raw=g_cat, mask=cat, mask_scale=self._cat_scale(net.aspp))
+        return g_cat, g_m2
 
 
 class _StudentFunction(torch.autograd.Function):
@@ -491,10 +755,7 @@ class _StudentFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_logits, *g_hints):
-        if g_logits is not None:
-            raise EngineError("gradients w.r.t. the student logits are not implemented: the reference back-propagates the "
-                              "hint loss only (trainer/layerwise_trainer.py:233-235)")
-        grads = ctx.engine.backward(list(g_hints))
+        grads = ctx.engine.backward(list(g_hints), g_logits)
         return (None, None) + tuple(grads.get(p) for p in ctx.params)
 
 

@@ -78,6 +78,7 @@ def forward(sd, x, hint_names=(), cheap_geom=(9, 20, 5)):
             out = out + shortcut           # reference: out.add_(shortcut) -> hooked tensor == block output
             note(p + ".convs." + last, out)
             note(p + ".convs", out)
+            note(p, out)                   # a hook on the block itself sees its return value: the same tensor
             x = out
         if mod_id == 0:
             m2 = x
@@ -92,6 +93,7 @@ def forward(sd, x, hint_names=(), cheap_geom=(9, 20, 5)):
         note(n, y)
         outs.append(_bnrelu(sd, f"aspp.features.{i}.1", y))
     x = torch.cat(outs, 1)
+    note("aspp", x)                        # hook on the ASPP module: the concatenated, activated branches
     dec0_up = F.conv2d(x, sd["bot_aspp.weight"])
     dec0 = torch.cat([F.conv2d(m2, sd["bot_fine.weight"]), _upsample(dec0_up, m2.shape[2:])], 1)
     y = _bnrelu(sd, "final.1", F.conv2d(dec0, sd["final.0.weight"], None, 1, 1))
@@ -114,12 +116,16 @@ def weighted_hint_loss(s, t, w):  # losses/WeightedHintMSELoss.py:12-16
 
 
 def kd_step(teacher_sd, student_sd, x, target, plan, hint_num_classes=1000, temperature=1.0, cheap_geom=(9, 20, 5),
-            hint_weights=None):
-    """One reference-faithful step (loss = hint loss only).  student_sd tensors with requires_grad=True are the
-    trainable set; returns a dict of losses / outputs / gradients."""
+            hint_weights=None, backprop="hint", hint_names=None):
+    """One step.  backprop="hint": the reference-faithful loss = hint loss only (trainer/layerwise_trainer.py:233-235);
+    backprop="kd+hint": loss = KLDiv(student, teacher logits) + hint loss (SURVEY 8d mode B; the KD term is what
+    trainer/classification_trainer.py:37 back-propagates).  student_sd tensors with requires_grad=True are the trainable set
+    (with every tensor trainable this includes the eval-mode BN weights / biases, like the reference's "identical
+    architecture" branch, layerwise_trainer.py:88-100); returns a dict of losses / outputs / gradients."""
+    hn = plan if hint_names is None else hint_names
     with torch.no_grad():
-        t_logits, t_hints, _ = forward(teacher_sd, x, plan, cheap_geom)
-    s_logits, s_hints, names = forward(student_sd, x, plan, cheap_geom)
+        t_logits, t_hints, _ = forward(teacher_sd, x, hn, cheap_geom)
+    s_logits, s_hints, names = forward(student_sd, x, hn, cheap_geom)
     hint = 0
     per = []
     for i, (s, t) in enumerate(zip(s_hints, t_hints)):
@@ -127,8 +133,14 @@ def kd_step(teacher_sd, student_sd, x, target, plan, hint_num_classes=1000, temp
         per.append(l)
         hint = hint + l
     train = {k: v for k, v in student_sd.items() if v.requires_grad}
-    grads = torch.autograd.grad(hint, list(train.values())) if train else []
-    out = dict(hint_loss=hint.detach(), per_hint=[p.detach() for p in per], student_logits=s_logits.detach(),
+    loss = hint
+    if backprop == "kd+hint":
+        loss = kl_div_loss(s_logits, t_logits, temperature) + hint
+    elif backprop != "hint":
+        raise ValueError(backprop)
+    grads = torch.autograd.grad(loss, list(train.values()), allow_unused=True) if train else []
+    hint = hint.detach() if torch.is_tensor(hint) else torch.tensor(float(hint))
+    out = dict(hint_loss=hint, loss=loss.detach(), per_hint=[p.detach() for p in per], student_logits=s_logits.detach(),
                teacher_logits=t_logits, student_hints=[h.detach() for h in s_hints], teacher_hints=t_hints,
                hint_names=names, grads=dict(zip(train.keys(), grads)),
                kd_loss=kl_div_loss(s_logits.detach(), t_logits, temperature),
@@ -146,6 +158,11 @@ def make_student_sd(teacher_sd, plan, new_weights, trainable=None):
         del sd[name + ".weight"]
         for suffix in ("separable_conv.weight", "pointwise_conv.weight"):
             sd[f"{name}.{suffix}"] = new_weights[f"{name}.{suffix}"].detach().clone()
+    if trainable == "all":      # every parameter (not the BN running statistics)
+        for k, v in sd.items():
+            if not (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked")):
+                v.requires_grad_(True)
+        return sd
     for name in (plan if trainable is None else trainable):
         for suffix in ("separable_conv.weight", "pointwise_conv.weight"):
             sd[f"{name}.{suffix}"].requires_grad_(True)

@@ -85,10 +85,20 @@ def test_engine_rejects_unsupported_graphs(teacher):
     got = [names[id(p)] for p in order]
     assert got[0] == "aspp.features.1.0.pointwise_conv.weight" and got[-1] == "mod4.block2.convs.conv2.separable_conv.weight"
     assert len(got) == 12
-    # dense trainable convs are refused loudly rather than silently skipped
+    # a dense conv made trainable (pruning.unfreeze naming a dense block) joins the production order right after the convs
+    # that follow it in the block; with everything trainable the order covers every parameter exactly once, decoder first
     m.student.mod5.block1.convs.conv1.weight.requires_grad = True
+    assert _Site("mod5.block1.convs.conv1", m.student.mod5.block1.convs.conv1).trainable
+    got2 = [names[id(p)] for p in eng.grad_production_order()]
+    assert len(got2) == 13 and got2.index("mod5.block1.convs.conv1.weight") < got2.index("mod4.block3.convs.conv1.pointwise_conv.weight")
+    for p in m.student.parameters():
+        p.requires_grad = True
+    full = [names[id(p)] for p in eng.grad_production_order()]
+    assert sorted(full) == sorted(n for n, _ in m.student.named_parameters()) and len(set(full)) == len(full)
+    assert full[0] == "final.6.weight" and full[-1] == "mod1.conv1.weight"
+    # unsupported module types inside the graph are still refused loudly
     with pytest.raises(EngineError):
-        _Site("mod5.block1.convs.conv1", m.student.mod5.block1.convs.conv1)
+        _Site("x", torch.nn.ReLU())
 
 
 def test_forgiving_state_restore():

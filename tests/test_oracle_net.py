@@ -39,3 +39,36 @@ def test_net_oracle_matches_reference_step(golden):
     assert sorted(r["grads"]) == sorted(str(s) for s in g["trainable"])
     for n, gr in r["grads"].items():
         _cmp(gr, g, f"grad:{n}", tol=1e-4)
+
+
+def _cmp_k(t, g, key, k, tol):
+    f = t.detach().float().contiguous().reshape(-1)
+    assert list(t.shape) == [int(v) for v in g[f"{key}.shape"]], key
+    ref = g[f"{key}.sample"].astype(np.float64)
+    got = f[sample_idx(f.numel(), k)].numpy().astype(np.float64)
+    assert np.abs(got - ref).max() <= tol * max(np.abs(ref).max(), 1e-12), key
+    ssq = float((f.double() ** 2).sum())
+    assert abs(ssq - float(g[f"{key}.sumsq"][0])) <= 4 * tol * float(g[f"{key}.sumsq"][0]) + 1e-30, key
+
+
+def test_net_oracle_mode_b_matches_reference(golden):
+    """loss = KLDiv + hints with EVERY student parameter trainable (dense convs, eval-mode BN weights / biases, the stem),
+    hints on `convs` / a whole block / the `aspp` module: net_ref reproduces the reference's losses and all gradients."""
+    g = golden("student_step_full_g4")
+    plan, hints = [str(s) for s in g["plan"]], [str(s) for s in g["hints"]]
+    torch.set_num_threads(8)
+    tsd = seeded_teacher_sd()
+    ssd = net_ref.make_student_sd(tsd, plan, seeded_cheap_weights(tsd, plan), trainable="all")
+    x = seeded_input(str(g["x_key"]), (2, 3, 64, 128))
+    r = net_ref.kd_step(tsd, ssd, x, None, plan, backprop="kd+hint", hint_names=hints)
+    assert r["hint_names"] == hints
+    np.testing.assert_allclose(r["hint_loss"].item(), float(g["hint_loss"]), rtol=1e-5)
+    np.testing.assert_allclose([p.item() for p in r["per_hint"]], g["per_hint"], rtol=1e-5)
+    np.testing.assert_allclose(r["kd_loss"].item(), float(g["kd_loss"]), rtol=1e-4)
+    _cmp_k(r["student_logits"], g, "student_logits", 1024, 2e-5)
+    for i in range(len(hints)):
+        _cmp_k(r["student_hints"][i], g, f"hint_s{i}", 512, 2e-5)
+    names = [str(s) for s in g["trainable"]]
+    assert sorted(r["grads"]) == sorted(names) and len(names) == 143
+    for n in names:
+        _cmp_k(r["grads"][n], g, f"grad:{n}", 256, 2e-4)

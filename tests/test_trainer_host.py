@@ -30,7 +30,23 @@ def _cls_config(save_dir, epochs=2):
     return cfg
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _rank_main(rank, world, port, save_dir, out):
+    try:
+        _rank_body(rank, world, port, save_dir, out)
+    except BaseException as e:   # surface the failure in the parent instead of a queue timeout
+        import traceback
+        out.put(dict(rank=rank, error=f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
+        raise
+
+
+def _rank_body(rank, world, port, save_dir, out):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
@@ -73,11 +89,14 @@ def test_two_rank_trainer_gloo(tmp_path):
     broadcast + averaged gradients), the plateau scheduler and the monitor take the same decisions on every rank."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 23000 + os.getpid() % 4000
+    port = _free_port()
     procs = [ctx.Process(target=_rank_main, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=240) for _ in range(2)), key=lambda d: d["rank"])
+    res = [q.get(timeout=240) for _ in range(2)]
+    for r in res:
+        assert "error" not in r, r.get("error")
+    res = sorted(res, key=lambda d: d["rank"])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

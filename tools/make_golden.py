@@ -284,6 +284,41 @@ def g_student_step(plan_name="g4", hw=(64, 128), batch=2):
     save(f"student_step_{plan_name}", **out)
 
 
+FULL_HINTS = ["mod4.block2.convs", "mod4.block3.convs.conv1", "mod7.block1", "aspp"]
+
+
+def g_student_step_full(plan_name="g4", hw=(64, 128), batch=2):
+    """SURVEY 8(d) mode B on the reference itself: the g4 student with EVERY student parameter trainable (what
+    prepare_train_epoch's identical-architecture branch and `pruning.unfreeze` on dense blocks do,
+    trainer/layerwise_trainer.py:88-100, models/students/depthwise_student.py:80-84; the student stays in eval mode),
+    hints on a `convs` Sequential, a raw conv, a whole block and the ASPP module (the names of
+    cfg/cityscapes/51M_deeplab_incremental.json), loss = KLDivergenceLoss(1)(student, teacher logits) + sum of hint MSEs,
+    loss.backward().  Stores the losses and a summary of every parameter's gradient."""
+    plan = PLANS[plan_name]
+    model = build_student(plan)
+    model.register_hint_layers(FULL_HINTS)
+    for p in model.student.parameters():
+        p.requires_grad = True
+    x = seeded_input(f"step.{plan_name}.x", (batch, 3) + hw)
+    out_st, out_tc = model(x)
+    kd = ref_losses.KLDivergenceLoss(1)(out_st, out_tc)
+    crit = ref_losses.MSELoss(num_classes=1000)
+    hint, per = 0, []
+    for s, t in zip(model.student_hidden_outputs, model.teacher_hidden_outputs):
+        l = crit(s, t); per.append(l.item()); hint = hint + l
+    (kd + hint).backward()
+    out = dict(plan=np.array(plan), hints=np.array(FULL_HINTS), x_key=f"step.{plan_name}.x", kd_loss=np.float64(kd.item()),
+               hint_loss=np.float64(hint.item()), per_hint=np.array(per), student_logits=summarize(out_st, 1024))
+    for i, s in enumerate(model.student_hidden_outputs):
+        out[f"hint_s{i}"] = summarize(s, 512)
+    names = []
+    for n, p in model.student.named_parameters():
+        assert p.grad is not None, n
+        names.append(n); out[f"grad:{n}"] = summarize(p.grad, 256)
+    out["trainable"] = np.array(names)
+    save(f"student_step_full_{plan_name}", **out)
+
+
 def trainer_config(plan, lr, len_epoch, save_dir):
     """A config dict in the reference's JSON schema (cfg/cityscapes/*.json) for a tiny synthetic run."""
     ent = [{"name": n, "epoch": 1} for n in plan]
@@ -414,7 +449,7 @@ def g_keys():
     print("wrote", path, len(inv), "entries", sum(int(np.prod(v)) for k, v in inv.items() if "num_batches" not in k and "running" not in k), "params")
 
 
-ALL = dict(keys=g_keys, confusion=g_confusion, trainer_epoch=g_trainer_epoch, classification_epoch=g_classification_epoch, losses=g_losses, dwsep=g_dwsep, resblock=g_resblock, aspp=g_aspp, ops=g_ops, radam=g_radam,
+ALL = dict(keys=g_keys, confusion=g_confusion, student_step_full=g_student_step_full, trainer_epoch=g_trainer_epoch, classification_epoch=g_classification_epoch, losses=g_losses, dwsep=g_dwsep, resblock=g_resblock, aspp=g_aspp, ops=g_ops, radam=g_radam,
            student_step=g_student_step)
 
 if __name__ == "__main__":
