@@ -34,7 +34,7 @@ PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md chip-level ta
 PEAK_F32_TFLOPS = 157.3
 
 
-def build(plan, dtype, device, seed=123):
+def build(plan, dtype, device, seed=123, mode="A"):
     import kdcc_amd
     from kdcc_amd import losses
     from kdcc_amd.models import DeepWV3Plus
@@ -47,12 +47,15 @@ def build(plan, dtype, device, seed=123):
     model.replace([{"name": n, "epoch": 1} for n in plan], kernel_size=9, padding=20, dilation=5)
     model.register_hint_layers(plan)
     model.unfreeze(plan)
+    if mode == "B":   # SURVEY 8(d) mode B: every student parameter trainable (dense convs, eval-mode BN affine, stem)
+        for p in model.student.parameters():
+            p.requires_grad = True
     crit = [losses.CrossEntropyLoss2d(ignore_index=255), losses.KLDivergenceLoss(1), losses.MSELoss(num_classes=1000)]
     opt = RAdam([p for p in model.student.parameters() if p.requires_grad], lr=0.005)
     return model, crit, opt, cpu_sd
 
 
-def kd_step(model, crit, opt, data, target):
+def kd_step(model, crit, opt, data, target, mode="A"):
     out_st, out_tc = model(data)
     sup = crit[0](out_st, target)
     kd = crit[1](out_st, out_tc)
@@ -61,6 +64,8 @@ def kd_step(model, crit, opt, data, target):
     for s, t in zip(model.student_hidden_outputs, model.teacher_hidden_outputs):
         hint = hint + crit[2](s, t)
     loss = hint                      # "Only use hint loss", layerwise_trainer.py:233-235
+    if mode == "B":
+        loss = kd + hint             # north-star mode: the KD term is back-propagated too (classification_trainer.py:37)
     loss.backward()
     opt.step()
     opt.zero_grad()
@@ -164,6 +169,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--plan", default="P92", choices=sorted(PLANS))
+    ap.add_argument("--mode", default="A", choices=["A", "B"],
+                    help="A (default, reference-faithful): loss = hint loss, only the cheap-conv blocks train; B (SURVEY 8d "
+                         "north-star mode): loss = KLDiv + hint, every student parameter trainable (37.74 TFLOP/img for P92)")
     ap.add_argument("--batch", type=int, default=4, help="images per GPU (4 by default: +6 %% img/s over 1, +2 %% over 2 from fuller grids)")
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
@@ -177,6 +185,8 @@ def main():
     ap.add_argument("--ref-logging", action="store_true",
                     help="also do the reference's per-step host syncs (five .item() calls, layerwise_trainer.py:244-250); the "
                          "default measures the step without them, as this trainer runs it (metrics stay on the device)")
+    ap.add_argument("--teacher-stream", default="main", choices=["main", "side"],
+                    help="with --teacher hip: run the engine teacher on a side HIP stream concurrently with the student forward")
     ap.add_argument("--teacher", default="hip", choices=["torch", "hip"],
                     help="hip: frozen teacher graph through the engine's HIP kernels (default); torch: teacher as a PyTorch-ROCm "
                          "module (MIOpen) on a side stream, the split north_star describes")
@@ -192,9 +202,10 @@ def main():
     device = torch.device("cuda", local)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     plan = PLANS[a.plan]
-    model, crit, opt, cpu_sd = build(plan, dtype, device)
+    model, crit, opt, cpu_sd = build(plan, dtype, device, mode=a.mode)
     model.overlap_teacher = not a.no_overlap
     model.teacher_backend = a.teacher
+    model.hip_teacher_side_stream = a.teacher_stream == "side"
     if world > 1:
         eng = model._student_engine()
         eng.reducer = parallel.GradReducer(eng.grad_production_order())
@@ -211,13 +222,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        kd_step(model, crit, opt, data, target)
+        kd_step(model, crit, opt, data, target, a.mode)
     sync()
     prof = []
     ops.PROFILER = prof
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        loss, sup, kd, tl = kd_step(model, crit, opt, data, target)
+        loss, sup, kd, tl = kd_step(model, crit, opt, data, target, a.mode)
         if a.ref_logging:
             _ = (loss.item(), sup.item(), kd.item(), loss.item(), tl.item())
     sync()
@@ -237,11 +248,11 @@ def main():
                 continue
             d_, t_ = data[:nb].contiguous(), target[:nb].contiguous()
             for _ in range(2):
-                kd_step(model, crit, opt, d_, t_)
+                kd_step(model, crit, opt, d_, t_, a.mode)
             sync()
             t1 = time.perf_counter()
             for _ in range(8):
-                kd_step(model, crit, opt, d_, t_)
+                kd_step(model, crit, opt, d_, t_, a.mode)
             sync()
             d1 = time.perf_counter() - t1
             if world > 1:
@@ -250,11 +261,16 @@ def main():
                 d1 = float(tt.item())
             sweep[str(nb)] = {"images_per_sec": world * nb * 8 / d1, "ms_per_step": d1 / 8 * 1e3, "steps": 8}
 
-    overlapped = bool(model.overlap_teacher) and a.teacher == "torch"   # the engine teacher runs in stream order
+    # what actually ran: the PyTorch teacher overlaps on a side stream unless --no-overlap; the engine teacher runs in stream
+    # order unless --teacher-stream side
+    overlapped = bool(model.overlap_teacher) and (a.teacher == "torch" or a.teacher_stream == "side")
     if rank == 0:
         # dominant kernel: the implicit-GEMM conv; live HIP-event timing of every launch on its launching stream
+        wg = [p for p in prof if p[0] == "conv_wgrad"]
+        prof = [p for p in prof if p[0] != "conv_wgrad"]
         flops = sum(p[1] for p in prof)
         ms = sum(p[2].elapsed_time(p[3]) for p in prof)
+        wg_flops, wg_ms = sum(p[1] for p in wg), sum(p[2].elapsed_time(p[3]) for p in wg)
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
         res = {
@@ -262,22 +278,26 @@ def main():
             "value": world * a.batch * a.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"KD train step (frozen teacher fwd + student fwd + CE/KD/hint criteria + hint-loss bwd + "
+            "config": {"workload": f"KD train step (frozen teacher fwd + student fwd + CE/KD/hint criteria + "
+                                   f"{'hint-loss bwd into the cheap-conv blocks' if a.mode == 'A' else 'kd+hint bwd into every student parameter'} + "
                                    f"RAdam), DeepLabV3+(WRN-38) student plan {a.plan} ({len(plan)} cheap-conv blocks, 9x9 d5), "
                                    f"{a.height}x{a.width}, {a.batch} image/GPU, random-init weights",
-                       "plan": a.plan, "per_gpu_batch": a.batch, "global_batch": world * a.batch,
+                       "plan": a.plan, "mode": a.mode, "per_gpu_batch": a.batch, "global_batch": world * a.batch,
                        "parallelism": f"dp{world}", "teacher_overlap": overlapped,
                        "teacher_backend": a.teacher, "per_step_host_syncs": bool(a.ref_logging),
                        "per_gpu_batch_sweep": sweep},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_row_kernel + conv_igemm_kernel (dense conv fwd + dgrad, student" + (" + teacher)" if a.teacher == "hip" else ")"), "achieved": ach,
                          "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                         "traffic": conv_traffic(a.plan, a.batch, a.height, a.width, a.dtype),
+                         "traffic": conv_traffic(a.plan, a.batch, a.height, a.width, a.dtype) if a.mode == "A" else None,
                          "traffic_note": "mean HBM bytes per conv_igemm* launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + "
                                          "WRITE_SIZE, separate passes (profiles/r01_traffic_pmc.json); mean algorithmic "
                                          "FLOP per launch = algorithmic_tflop_per_step / launches_per_step",
                          "launches_per_step": len(prof) / max(a.steps, 1), "ms_per_step_in_kernel": ms / max(a.steps, 1),
                          "algorithmic_tflop_per_step": flops / max(a.steps, 1) / 1e12},
-            "losses": {"hint": float(loss.detach()), "supervised": float(sup), "kd": float(kd), "teacher": float(tl)},
+            "dense_wgrad": ({"kernel": "pw_wgrad_tr_kernel / pw_wgrad_kernel via kd_conv2d_wgrad", "achieved": wg_flops / (wg_ms * 1e-3) / 1e12,
+                             "unit": "TFLOP/s", "launches_per_step": len(wg) / max(a.steps, 1), "ms_per_step_in_kernel": wg_ms / max(a.steps, 1),
+                             "algorithmic_tflop_per_step": wg_flops / max(a.steps, 1) / 1e12} if wg_ms > 0 else None),
+            "losses": {("hint" if a.mode == "A" else "kd+hint"): float(loss.detach()), "supervised": float(sup), "kd": float(kd), "teacher": float(tl)},
         }
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cpu_sd, model, plan, full=a.cpu_baseline == "full")

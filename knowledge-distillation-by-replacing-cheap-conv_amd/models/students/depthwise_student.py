@@ -60,6 +60,7 @@ class DepthwiseStudent(nn.Module):
         #          DeepWV3Plus: 45 % of the step's FLOPs are the teacher's, and it avoids MIOpen's first-run solver search.
         # "torch": the teacher runs as a PyTorch-ROCm module (MIOpen convs) on a side stream (north_star's split).
         self.teacher_backend = "hip"
+        self.hip_teacher_side_stream = False
         self._teacher_engine = None
 
     # ------------------------------------------------------------------ model surgery (host side)
@@ -185,9 +186,11 @@ class DepthwiseStudent(nn.Module):
             raise RuntimeError("the fused DeepWV3Plus student runs on the GPU only (no CPU fallback)")
         from ...engine import run_student
         engine = self._student_engine()
-        if self.overlap_teacher and not (self.teacher_backend == "hip" and isinstance(self.teacher, DeepWV3Plus)):
-            # frozen PyTorch teacher on a side stream: its logits/hints are consumed only by the losses, so it overlaps the
-            # student's forward on the main stream
+        hip_teacher = self.teacher_backend == "hip" and isinstance(self.teacher, DeepWV3Plus)
+        if self.overlap_teacher and (not hip_teacher or self.hip_teacher_side_stream):
+            # frozen teacher on a side stream: its logits/hints are consumed only by the losses, so it can overlap the
+            # student's forward on the main stream (PyTorch-ROCm teacher: always; engine teacher: opt-in, since two
+            # chip-filling MFMA kernel streams only trade tail effects -- measured in DESIGN.md section 5)
             if self._side_stream is None or self._side_stream.device != x.device:
                 self._side_stream = torch.cuda.Stream(device=x.device)
             main = torch.cuda.current_stream()
