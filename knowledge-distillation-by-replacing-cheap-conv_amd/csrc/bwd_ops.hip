@@ -41,36 +41,58 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_kernel(const T *__restrict__ 
 }
 
 // ---- per-group channel sums ------------------------------------------------------------------------------------------------
-// stage 1: block (chunk, channel block of 256, group) sums its rows in fp32 per thread (<= CS_ROWS rows);
-// stage 2: one thread per (group, channel) adds the chunk partials in order, in fp64.
-constexpr int CS_ROWS = 512;
-
-template <typename T>
+// stage 1: block = 32 channel octets (256 channels, 512 B of a bf16 row: fully coalesced 16-B loads) x 8 row lanes; a block
+// owns one chunk of rows of one group, every thread sums its rows (every 8th) in fp32, the 8 row lanes are combined in LDS in
+// fixed order; stage 2: one thread per (group, channel) adds the chunk partials in order, in fp64.
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void channel_sums_partial_kernel(const T *__restrict__ g, int ldg, const T *__restrict__ sub,
                                                                    int ldsub, const T *__restrict__ a, int lda, long long rows,
                                                                    int C, int chunks, float *__restrict__ part)
 {
-    const int c = blockIdx.y * 256 + threadIdx.x;
+    __shared__ float red[2][8][32 * VEC];
+    const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = (blockIdx.y * 32 + cq) * VEC;
     const int chunk = blockIdx.x, grp = blockIdx.z;
-    if (c >= C) return;
     const long long per = (rows + chunks - 1) / chunks;
     const long long r0 = (long long)chunk * per, r1 = min(rows, r0 + per);
     const long long base = (long long)grp * rows;
-    float s1 = 0.f, s2 = 0.f;
-    double d1 = 0.0, d2 = 0.0;
-    int cnt = 0;
-    for (long long r = r0; r < r1; ++r) {
-        const long long m = base + r;
-        float v = Elem<T>::ld(g + m * ldg + c);
-        if (sub) v -= Elem<T>::ld(sub + m * ldsub + c);
-        s1 += v;
-        if (a) s2 += v * Elem<T>::ld(a + m * lda + c);
-        if (++cnt == CS_ROWS) { d1 += s1; d2 += s2; s1 = s2 = 0.f; cnt = 0; }
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) s1[q] = s2[q] = 0.f;
+    if (c < C) {
+        for (long long r = r0 + rl; r < r1; r += 8) {
+            const long long m = base + r;
+            float v[VEC], t[VEC];
+            if constexpr (VEC == 8) ld8(g + m * ldg + c, v);
+            else v[0] = Elem<T>::ld(g + m * ldg + c);
+            if (sub) {
+                if constexpr (VEC == 8) ld8(sub + m * ldsub + c, t);
+                else t[0] = Elem<T>::ld(sub + m * ldsub + c);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) v[q] -= t[q];
+            }
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) s1[q] += v[q];
+            if (a) {
+                if constexpr (VEC == 8) ld8(a + m * lda + c, t);
+                else t[0] = Elem<T>::ld(a + m * lda + c);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) s2[q] += v[q] * t[q];
+            }
+        }
     }
-    d1 += s1; d2 += s2;
-    float *o = part + (((size_t)grp * chunks + chunk) * 2) * C;
-    o[c] = (float)d1;
-    o[C + c] = (float)d2;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) { red[0][rl][cq * VEC + q] = s1[q]; red[1][rl][cq * VEC + q] = s2[q]; }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * 32 * VEC; e += 256) {
+        const int which = e / (32 * VEC), col = e - which * (32 * VEC);
+        const int cc = blockIdx.y * 32 * VEC + col;
+        if (cc >= C) continue;
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[which][k][col];
+        part[(((size_t)grp * chunks + chunk) * 2 + which) * C + cc] = t;
+    }
 }
 
 __global__ __launch_bounds__(256) void channel_sums_finish_kernel(const float *__restrict__ part, int groups, int chunks, int C,
@@ -354,8 +376,8 @@ extern "C" int kd_relu_bn_bwd(int32_t dtype, const void *g, int32_t ldg, const v
 
 static int cs_chunks(long long rows)
 {
-    long long c = (rows + 2047) / 2048;      // >= 2048 rows per block
-    return (int)(c < 1 ? 1 : (c > 256 ? 256 : c));
+    long long c = (rows + 511) / 512;        // >= 512 rows (64 per thread) per block, at most 1024 chunks
+    return (int)(c < 1 ? 1 : (c > 1024 ? 1024 : c));
 }
 
 extern "C" size_t kd_channel_sums_workspace(int32_t groups, int64_t rows_per_group, int32_t C)
@@ -373,14 +395,17 @@ extern "C" int kd_channel_sums(int32_t dtype, const void *g, int32_t ldg, const 
     KD_REQUIRE(workspace_bytes >= kd_channel_sums_workspace(groups, rows_per_group, C), KD_ERR_WORKSPACE,
                "kd_channel_sums: workspace too small");
     const int chunks = cs_chunks(rows_per_group);
-    const dim3 grid((unsigned)chunks, (unsigned)((C + 255) / 256), (unsigned)groups);
+    const int es = kd_elem_size(dtype);
+    const bool vec = C % 8 == 0 && vec_ok(g, ldg, es) && vec_ok(sub, ldsub, es) && vec_ok(a, lda, es);
+    const dim3 grid((unsigned)chunks, (unsigned)((C + (vec ? 255 : 31)) / (vec ? 256 : 32)), (unsigned)groups);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == KD_BF16)
-        hipLaunchKernelGGL(channel_sums_partial_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t *)g, ldg, (const bf16_t *)sub, ldsub,
-                           (const bf16_t *)a, lda, (long long)rows_per_group, C, chunks, (float *)workspace);
-    else
-        hipLaunchKernelGGL(channel_sums_partial_kernel<float>, grid, dim3(256), 0, s, (const float *)g, ldg, (const float *)sub, ldsub,
-                           (const float *)a, lda, (long long)rows_per_group, C, chunks, (float *)workspace);
+    if (dtype == KD_BF16) {
+        if (vec) hipLaunchKernelGGL((channel_sums_partial_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t *)g, ldg, (const bf16_t *)sub, ldsub, (const bf16_t *)a, lda, (long long)rows_per_group, C, chunks, (float *)workspace);
+        else hipLaunchKernelGGL((channel_sums_partial_kernel<bf16_t, 1>), grid, dim3(256), 0, s, (const bf16_t *)g, ldg, (const bf16_t *)sub, ldsub, (const bf16_t *)a, lda, (long long)rows_per_group, C, chunks, (float *)workspace);
+    } else {
+        if (vec) hipLaunchKernelGGL((channel_sums_partial_kernel<float, 8>), grid, dim3(256), 0, s, (const float *)g, ldg, (const float *)sub, ldsub, (const float *)a, lda, (long long)rows_per_group, C, chunks, (float *)workspace);
+        else hipLaunchKernelGGL((channel_sums_partial_kernel<float, 1>), grid, dim3(256), 0, s, (const float *)g, ldg, (const float *)sub, ldsub, (const float *)a, lda, (long long)rows_per_group, C, chunks, (float *)workspace);
+    }
     KD_CHECK_LAUNCH("kd_channel_sums");
     hipLaunchKernelGGL(channel_sums_finish_kernel, dim3((groups * C + 255) / 256), dim3(256), 0, s, (const float *)workspace, groups,
                        chunks, C, s1, a ? s2 : (float *)nullptr);

@@ -6,6 +6,8 @@
 // [channel][128 B of K] swizzled image the conv kernel uses; the MFMA core is shared.
 // Split-K over pixels with fp32 partial slabs in the caller's workspace and a
 // fixed-order reduction (deterministic, unlike float atomics).
+#include <stdlib.h>
+
 #include "igemm_core.h"
 
 namespace {
@@ -290,6 +292,108 @@ __global__ void slab_reduce_taps_kernel(const float *__restrict__ part, float *_
     }
 }
 
+// ---- wide tile: 256 (Cout) x 256 (Cin) per workgroup, 8 waves (2 x 4 of 128 x 64), one workgroup per CU --------------------------
+// The 128 x 128 kernel above keeps one 32-KiB stage in flight per workgroup (two per CU): at the latency of a gathered L2 / HBM
+// read that is ~0.2 of the MFMA peak whatever the shape.  Doubling both tile edges halves the bytes staged per FLOP, so the
+// same bytes in flight feed twice the matrix work -- the trade the forward kernel's 256 x 256 configs make.  Stage = 64 pixels
+// x (256 + 256) channels = four 16-KiB images in the [pixel][128 channels] layout of pw_wgrad_tr_kernel (same source-side
+// swizzle, same transposing fragment reads); double-buffered: 128 KiB.
+__global__ __launch_bounds__(512, 2) void conv_wgrad_wide_kernel(const WgradParams p)
+{
+    __shared__ __attribute__((aligned(16))) char lds[2 * 65536];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 2, wn = wv & 3;
+    const int tile = blockIdx.x, split = blockIdx.y, tap = blockIdx.z;
+    const int ky = tap / p.kw, kx = tap - ky * p.kw;
+    const int t_ci = tile % p.tiles_ci, t_co = tile / p.tiles_ci;
+    const int co0 = t_co * 256, ci0 = t_ci * 256;
+    const int m_begin = split * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+    const int nst = (m_end - m_begin + 63) / 64;
+    const bf16_t *dy = (const bf16_t *)p.dy;
+    const bf16_t *a = (const bf16_t *)p.a;
+    const bf16_t *zero = (const bf16_t *)kd_zero_page_w;
+
+    // staging: a piece = 4 pixel rows x 256 B of one image; image q of a stage: 0/1 = dy channels 0-127 / 128-255, 2/3 = a.
+    // 16 pieces per image, 64 per stage, 8 per wave: wave w stages pieces w*2, w*2+1 of every image (rows (w*2+j)*4 ..)
+    const int prow = lane >> 4, slot = lane & 15;
+    auto stage = [&](int st, int buf) {
+        char *base = lds + buf * 65536;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pc = wv * 2 + j;
+            const int r = pc * 4 + prow;                    // row within the stage (0..63)
+            const int m = m_begin + st * 64 + r;
+            const int c = (slot ^ (tr_f(r) << 1)) * 8;      // source-side swizzle (8 channels per 16-B chunk)
+            const bool mok = m < m_end;
+            const int px = mok ? a_row(p, m, ky, kx) : -1;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int cc = h * 128 + c;
+                const bf16_t *s0 = (mok && co0 + cc < p.Cout) ? dy + (size_t)m * p.ldy + co0 + cc : zero;
+                const bf16_t *s1 = (px >= 0 && ci0 + cc < p.Cin) ? a + (size_t)px * p.lda + ci0 + cc : zero;
+                glds16(s0, base + h * 16384 + pc * 1024);
+                glds16(s1, base + (2 + h) * 16384 + pc * 1024);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int q = lane >> 4, li = lane & 15;
+    auto frag = [&](const char *img, int ks, int t) {
+        const int m0 = ks * 32 + 8 * q + (li >> 2);
+        const int m1 = m0 + 4;
+        const v4i16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4i16_t *)(img + m0 * 256 + ((t ^ tr_f(m0)) << 5) + (li & 3) * 8));
+        const v4i16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4i16_t *)(img + m1 * 256 + ((t ^ tr_f(m1)) << 5) + (li & 3) * 8));
+        return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+
+    if (nst > 0) stage(0, 0);
+    wait_vm_barrier<0>();
+    for (int st = 0; st < nst; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nst) stage(st + 1, cur ^ 1);
+        const char *imgY = lds + cur * 65536 + wm * 16384;                  // this wave's 128 output channels
+        const char *imgA = lds + cur * 65536 + (2 + (wn >> 1)) * 16384;     // ... and its 64 input channels
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t fa[8], fb[4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = frag(imgY, ks, i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = frag(imgA, ks, (wn & 1) * 4 + j);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        wait_vm_barrier<0>();   // next stage landed everywhere; everybody is done reading this one
+    }
+
+    float *out = p.part + ((size_t)split * gridDim.z + tap) * p.Cout * p.Cin;
+    const int frow = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wm * 128 + i * 16 + fq * 4 + r;
+                const int ci = ci0 + wn * 64 + j * 16 + frow;
+                if (co < p.Cout && ci < p.Cin) out[(size_t)co * p.Cin + ci] = acc[i][j][r];
+            }
+}
+
 __global__ void slab_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, size_t n, int splits,
                                    int accumulate)
 {
@@ -380,7 +484,10 @@ extern "C" size_t kd_conv2d_wgrad_workspace(const kd_conv_desc *d)
     int tiles, tiles_ci, s0, s1, rps;
     plan(KD_F32, M, d->Cin, d->Cout, tiles, tiles_ci, s0, rps, taps);
     plan(KD_BF16, M, d->Cin, d->Cout, tiles, tiles_ci, s1, rps, taps);
-    const int splits = s0 > s1 ? s0 : s1;
+    int splits = s0 > s1 ? s0 : s1;
+    const int stages = (M + 63) / 64;
+    const int wsplits = (stages + 7) / 8 < 768 ? (stages + 7) / 8 : 768;   // the wide-tile plan never splits finer
+    if (wsplits > splits) splits = wsplits;
     return (size_t)splits * taps * d->Cout * d->Cin * sizeof(float);
 }
 
@@ -406,6 +513,23 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
     KD_REQUIRE(taps <= 65535, KD_ERR_UNSUPPORTED, "kd_conv2d_wgrad: kernel too large");
     int tiles, tiles_ci, splits, rps;
     plan(d->dtype, (int)M, d->Cin, d->Cout, tiles, tiles_ci, splits, rps, taps);
+    // 256 x 256 tiles (bf16 LDS-DMA path) when they waste little of the weight matrix
+    const long long pad256 = (long long)((d->Cout + 255) / 256) * ((d->Cin + 255) / 256) * 65536;
+    const long long pad128 = (long long)((d->Cout + 127) / 128) * ((d->Cin + 127) / 128) * 16384;
+    bool wide = d->dtype == KD_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->Cout >= 256 && d->Cin >= 256 &&
+                pad256 * 100 <= pad128 * 115;
+    if (const char *e = getenv("KDCC_WGRAD_WIDE")) wide = wide && e[0] != '0';
+    if (wide) {
+        tiles_ci = (d->Cin + 255) / 256;
+        tiles = tiles_ci * ((d->Cout + 255) / 256);
+        const int stages = (int)((M + 63) / 64);
+        int want = (768 + tiles * taps - 1) / (tiles * taps);     // ~3 waves of one-per-CU workgroups
+        const int max_splits = (stages + 7) / 8;                  // >= 8 stages per split
+        splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
+        if (splits < 1) splits = 1;
+        rps = ((stages + splits - 1) / splits) * 64;
+        splits = (int)((M + rps - 1) / rps);
+    }
     const size_t need = (size_t)splits * taps * d->Cout * d->Cin * sizeof(float);
     KD_REQUIRE(workspace_bytes >= need, KD_ERR_WORKSPACE, "kd_conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
     WgradParams p;
@@ -418,7 +542,8 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
     fastdiv_magic((uint32_t)d->Wo, p.mg_wo, p.sh_wo);
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)tiles, (unsigned)splits, (unsigned)taps);
-    if (d->dtype == KD_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0) hipLaunchKernelGGL(pw_wgrad_tr_kernel, grid, dim3(256), 0, s, p);
+    if (wide) hipLaunchKernelGGL(conv_wgrad_wide_kernel, grid, dim3(512), 0, s, p);
+    else if (d->dtype == KD_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0) hipLaunchKernelGGL(pw_wgrad_tr_kernel, grid, dim3(256), 0, s, p);
     else if (d->dtype == KD_BF16) hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(pw_wgrad_kernel<float>, grid, dim3(256), 0, s, p);
     KD_CHECK_LAUNCH("kd_conv2d_wgrad");

@@ -419,6 +419,10 @@ WGRAD_CASES = [
     (1, 9, 31, 304, 256, 3, 1, 1, 1),     # decoder: 304 input channels
     (1, 8, 8, 256, 19, 1, 1, 0, 1),       # classifier: 19 output channels (generic transposing path)
     (1, 40, 48, 64, 64, 3, 1, 12, 12),    # ASPP-like dilation: most taps of the border rows fall outside the image
+    # Cin, Cout >= 256: the 256 x 256 wide-tile kernel (bf16), several pixel splits, ragged last stage
+    (1, 33, 40, 256, 256, 3, 1, 2, 2),
+    (2, 21, 31, 512, 256, 1, 1, 0, 1),
+    (1, 24, 40, 256, 512, 3, 2, 1, 1),
 ]
 
 
