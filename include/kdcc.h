@@ -244,6 +244,34 @@ int kd_copy_cast(const void *src, int32_t src_dtype, int64_t s_sN, int64_t s_sC,
                  void *dst, int32_t dst_dtype, int64_t d_sN, int64_t d_sC, int64_t d_sP,
                  int32_t N, int32_t C, int64_t P, kd_stream_t stream);
 
+/* ------------------------------------------------- small-shape path (CIFAR plumbing config)
+ * NCHW fp32, the reference's own layout, for the shapes the MFMA kernels do not take: CIFAR ResNet-20
+ * (models/cifar_models/resnet.py: 3/16/32/64 channels, 32x32..8x8) and the 3x3 cheap-conv blocks of the CIFAR configs
+ * (depthwise_separable_conv.py:7-9 with groups = C and optional bias).
+ * kd_conv2d_direct_*: nn.Conv2d forward / input gradient / weight (+ bias) gradient for any channels, kernel, stride, padding,
+ *   dilation and groups.  w: (K, C/groups, kh, kw); dw like w; dbias (K) or NULL.
+ * kd_bn2d_fwd / kd_bn2d_bwd: nn.BatchNorm2d forward / backward, optional fused ReLU.  training != 0: batch statistics (biased
+ *   variance), save_mean / save_invstd (C) returned for the backward, running statistics updated in place with `momentum`
+ *   and the unbiased variance (trainer/classification_trainer.py:21: the student runs in train mode);
+ *   training == 0: the running statistics.  bwd: y (the forward output) is needed only with relu != 0; dx / dgamma / dbeta
+ *   may each be NULL. */
+typedef struct kd_dconv_desc {
+    int32_t N, C, H, W;   /* input  (N, C, H, W) */
+    int32_t K;            /* output channels */
+    int32_t kh, kw, stride, pad, dil, groups;
+} kd_dconv_desc;
+int kd_conv2d_direct_fwd(const kd_dconv_desc *d, const float *x, const float *w, const float *bias, float *y,
+                         kd_stream_t stream);
+int kd_conv2d_direct_dgrad(const kd_dconv_desc *d, const float *dy, const float *w, float *dx, kd_stream_t stream);
+int kd_conv2d_direct_wgrad(const kd_dconv_desc *d, const float *x, const float *dy, float *dw, float *dbias,
+                           int32_t accumulate, kd_stream_t stream);
+int kd_bn2d_fwd(const float *x, const float *gamma, const float *beta, float *y, float *save_mean, float *save_invstd,
+                float *running_mean, float *running_var, float momentum, float eps, int32_t training, int32_t relu,
+                int32_t N, int32_t C, int32_t HW, kd_stream_t stream);
+int kd_bn2d_bwd(const float *dy, const float *x, const float *y, const float *gamma, const float *save_mean,
+                const float *save_invstd, float *dx, float *dgamma, float *dbeta, int32_t training, int32_t relu,
+                int32_t accumulate, int32_t N, int32_t C, int32_t HW, kd_stream_t stream);
+
 /* -------------------------------------------------------------------- losses
  * Each writes the scalar loss (fp32, device) and, when grad != NULL, the
  * gradient w.r.t. `s` in one pass.  Views are (N, C, P) with element strides

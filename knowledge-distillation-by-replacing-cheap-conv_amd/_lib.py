@@ -38,6 +38,10 @@ class DwEpilogue(C.Structure):
                 ("res_post", c_vp), ("ld_res_post", c_int)]
 
 
+class DConvDesc(C.Structure):
+    _fields_ = [(n, c_int) for n in ("N", "C", "H", "W", "K", "kh", "kw", "stride", "pad", "dil", "groups")]
+
+
 class View3(C.Structure):
     _fields_ = [("ptr", c_vp), ("dtype", c_int), ("sN", c_i64), ("sC", c_i64), ("sP", c_i64)]
 
@@ -64,6 +68,11 @@ _SIGS = {
     "kd_channel_sums": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_i64, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "kd_bn_eval_param_grads": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     "kd_broadcast_add": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_i64, c_int, c_f, c_int, c_vp]),
+    "kd_conv2d_direct_fwd": (c_int, [_P(DConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "kd_conv2d_direct_dgrad": (c_int, [_P(DConvDesc), c_vp, c_vp, c_vp, c_vp]),
+    "kd_conv2d_direct_wgrad": (c_int, [_P(DConvDesc), c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
+    "kd_bn2d_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "kd_bn2d_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "kd_pack_dw_weight": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "kd_dwconv_fwd": (c_int, [_P(DwDesc), c_vp, c_vp, c_vp, _P(DwEpilogue), c_vp, c_vp]),
     "kd_dwconv_wgrad_workspace": (c_sz, [_P(DwDesc)]),

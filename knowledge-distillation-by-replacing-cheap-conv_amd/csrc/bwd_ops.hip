@@ -376,8 +376,8 @@ extern "C" int kd_relu_bn_bwd(int32_t dtype, const void *g, int32_t ldg, const v
 
 static int cs_chunks(long long rows)
 {
-    long long c = (rows + 511) / 512;        // >= 512 rows (64 per thread) per block, at most 1024 chunks
-    return (int)(c < 1 ? 1 : (c > 1024 ? 1024 : c));
+    long long c = (rows + 511) / 512;        // >= 512 rows (64 per thread) per block; at most 256 chunks (the finishing
+    return (int)(c < 1 ? 1 : (c > 256 ? 256 : c));   // kernel adds them serially per channel)
 }
 
 extern "C" size_t kd_channel_sums_workspace(int32_t groups, int64_t rows_per_group, int32_t C)

@@ -517,7 +517,7 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
     const long long pad256 = (long long)((d->Cout + 255) / 256) * ((d->Cin + 255) / 256) * 65536;
     const long long pad128 = (long long)((d->Cout + 127) / 128) * ((d->Cin + 127) / 128) * 16384;
     bool wide = d->dtype == KD_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->Cout >= 256 && d->Cin >= 256 &&
-                pad256 * 100 <= pad128 * 115;
+                pad256 * 100 <= pad128 * 135;   // (the decoder's 304-channel conv: 2 x 256 vs 3 x 128 columns)
     if (const char *e = getenv("KDCC_WGRAD_WIDE")) wide = wide && e[0] != '0';
     if (wide) {
         tiles_ci = (d->Cin + 255) / 256;

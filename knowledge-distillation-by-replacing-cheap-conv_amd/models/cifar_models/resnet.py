@@ -1,10 +1,14 @@
 """CIFAR ResNet-20/32/44/56/110 (He et al., option-A parameter-free shortcuts) with the reference's module names
 (models/cifar_models/resnet.py:57-140: conv1, bn1, layer{1,2,3}.{i}.{conv1,bn1,conv2,bn2}, linear), so the shipped
 `checkpoints/cifar10/resnet20.th` ('module.'-prefixed state dict) loads through forgiving_state_restore.
-Used by BASELINE config 0 (KLDiv-only KD, ClassificationTrainer).  The module graph itself runs on PyTorch-ROCm ops;
-the KD criteria, cheap-conv blocks and optimizer go through the HIP kernels."""
+Used by BASELINE config 0 (KLDiv-only KD, ClassificationTrainer).  Convolutions and BatchNorm (training and eval mode,
+forward and backward) are nn_hip.Conv2d / nn_hip.BatchNorm2d, i.e. the small-shape HIP kernels on GPU tensors -- no MIOpen
+kernel runs; the parameter-free glue (residual add + ReLU, option-A shortcut, 8x8 average pool) and the 64x10 linear layer
+are torch tensor ops."""
 import torch.nn as nn
 import torch.nn.functional as F
+
+from ...nn_hip import BatchNorm2d, Conv2d
 
 
 class BasicBlock(nn.Module):
@@ -12,15 +16,15 @@ class BasicBlock(nn.Module):
 
     def __init__(self, in_planes, planes, stride=1):
         super().__init__()
-        self.conv1 = nn.Conv2d(in_planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
-        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=1, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv1 = Conv2d(in_planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn1 = BatchNorm2d(planes)
+        self.conv2 = Conv2d(planes, planes, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bn2 = BatchNorm2d(planes)
         self.pad_planes = planes // 4 if (stride != 1 or in_planes != planes) else 0
         self.shortcut = nn.Sequential()   # option A has no parameters; kept for state-dict/module-tree parity
 
     def forward(self, x):
-        out = F.relu(self.bn1(self.conv1(x)))
+        out = self.bn1(self.conv1(x), relu=True)
         out = self.bn2(self.conv2(out))
         sc = x
         if self.pad_planes:
@@ -31,8 +35,8 @@ class BasicBlock(nn.Module):
 class ResNet(nn.Module):
     def __init__(self, num_blocks, num_classes=10):
         super().__init__()
-        self.conv1 = nn.Conv2d(3, 16, kernel_size=3, stride=1, padding=1, bias=False)
-        self.bn1 = nn.BatchNorm2d(16)
+        self.conv1 = Conv2d(3, 16, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bn1 = BatchNorm2d(16)
         in_planes = 16
         for i, (planes, stride) in enumerate(((16, 1), (32, 2), (64, 2))):
             blocks = []
@@ -46,7 +50,7 @@ class ResNet(nn.Module):
                 nn.init.kaiming_normal_(m.weight)
 
     def forward(self, x):
-        out = F.relu(self.bn1(self.conv1(x)))
+        out = self.bn1(self.conv1(x), relu=True)
         out = self.layer3(self.layer2(self.layer1(out)))
         out = F.avg_pool2d(out, out.size()[3]).flatten(1)
         return self.linear(out)

@@ -2,13 +2,20 @@
 models/students/transform_blocks/depthwise_separable_conv.py:4-13 (same constructor, same child
 names `separable_conv` / `pointwise_conv`, hence the same checkpoint keys).
 
-As an nn.Module it is a parameter container plus a standalone HIP-backed forward (used by the CIFAR
-path and tests); inside a DeepWV3Plus student the engine fuses it into the surrounding graph.
+As an nn.Module it is a parameter container plus a standalone HIP-backed forward: the NHWC depthwise + MFMA pointwise
+kernels for GEMM-sized channel counts, the direct NCHW kernels (nn_hip.conv2d, groups = C then 1x1, bias supported) for the
+CIFAR configs' 16/32/64-channel 3x3 blocks; inside a DeepWV3Plus student the engine fuses it into the surrounding graph.
 """
 import torch
 from torch import nn
 
 from ... import ops
+
+
+def _small_shape(x, pw):
+    """The MFMA pointwise kernel needs the channel count to be a multiple of its K granule (32 in fp32) and has no bias
+    operand; fp32 blocks outside that (the CIFAR configs' 16-channel blocks, biased blocks) take the direct NCHW kernels."""
+    return x.dtype == torch.float32 and (x.shape[1] % 32 != 0 or pw.bias is not None)
 
 
 class _DwSepFunction(torch.autograd.Function):
@@ -65,5 +72,9 @@ class DepthwiseSeparableBlock(nn.Module):
 
     def forward(self, x):
         k, pad, dil = self.geometry
+        if x.is_cuda and _small_shape(x, self.pointwise_conv):
+            from ...nn_hip import conv2d
+            mid = conv2d(x, self.separable_conv.weight, self.separable_conv.bias, 1, pad, dil, self.in_channels)
+            return conv2d(mid, self.pointwise_conv.weight, self.pointwise_conv.bias)
         return _DwSepFunction.apply(x, self.separable_conv.weight, self.pointwise_conv.weight, self.separable_conv.bias,
                                     self.pointwise_conv.bias, k, pad, dil)

@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (KD_BF16, KD_F32, KD_PACK_DGRAD, KD_PACK_FWD, ConvDesc, ConvEpilogue, DwDesc, DwEpilogue, View3,
+from ._lib import (KD_BF16, KD_F32, KD_PACK_DGRAD, KD_PACK_FWD, ConvDesc, ConvEpilogue, DConvDesc, DwDesc, DwEpilogue, View3,
                    check)
 
 
@@ -414,6 +414,76 @@ def bn_fold(bn):
     check(_lib.lib().kd_bn_fold(_ptr(g.contiguous()), _ptr(b.contiguous()), _ptr(m.contiguous()), _ptr(v.contiguous()),
                                 C.c_float(bn.eps), _ptr(scale), _ptr(shift), g.numel(), stream_ptr()), "kd_bn_fold")
     return scale, shift
+
+
+# ------------------------------------------------------------------------- small-shape path (NCHW fp32)
+def _nchw32(*ts):
+    for t in ts:
+        if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous()):
+            raise ValueError("small-shape kernels take contiguous fp32 device tensors (NCHW)")
+
+
+def _dconv_desc(x_shape, w_shape, stride, pad, dil, groups):
+    N, Cc, H, W = x_shape
+    K, cg, kh, kw = w_shape
+    if cg * groups != Cc:
+        raise ValueError(f"direct conv: weight {tuple(w_shape)} does not match {Cc} input channels / {groups} groups")
+    return DConvDesc(N, Cc, H, W, K, kh, kw, stride, pad, dil, groups), (N, K, conv_out_size(H, kh, stride, pad, dil),
+                                                                         conv_out_size(W, kw, stride, pad, dil))
+
+
+def conv2d_direct(x, w, bias=None, stride=1, pad=0, dil=1, groups=1):
+    _nchw32(x, w, bias)
+    d, oshape = _dconv_desc(x.shape, w.shape, stride, pad, dil, groups)
+    y = torch.empty(oshape, dtype=torch.float32, device=x.device)
+    check(_lib.lib().kd_conv2d_direct_fwd(C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), stream_ptr()), "kd_conv2d_direct_fwd")
+    return y
+
+
+def conv2d_direct_dgrad(dy, w, x_shape, stride=1, pad=0, dil=1, groups=1):
+    _nchw32(dy, w)
+    d, oshape = _dconv_desc(x_shape, w.shape, stride, pad, dil, groups)
+    if tuple(dy.shape) != oshape:
+        raise ValueError(f"direct dgrad: dy {tuple(dy.shape)} != {oshape}")
+    dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    check(_lib.lib().kd_conv2d_direct_dgrad(C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), stream_ptr()), "kd_conv2d_direct_dgrad")
+    return dx
+
+
+def conv2d_direct_wgrad(x, dy, w_shape, stride=1, pad=0, dil=1, groups=1, want_bias=False):
+    _nchw32(x, dy)
+    d, oshape = _dconv_desc(x.shape, w_shape, stride, pad, dil, groups)
+    if tuple(dy.shape) != oshape:
+        raise ValueError(f"direct wgrad: dy {tuple(dy.shape)} != {oshape}")
+    dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
+    db = torch.empty(w_shape[0], dtype=torch.float32, device=x.device) if want_bias else None
+    check(_lib.lib().kd_conv2d_direct_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), 0, stream_ptr()), "kd_conv2d_direct_wgrad")
+    return dw, db
+
+
+def bn2d_fwd(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu=False):
+    """Returns (y, save_mean, save_invstd); updates the running statistics in place when training."""
+    _nchw32(x, gamma, beta, running_mean, running_var)
+    N, Cc = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * Cc)
+    y = torch.empty_like(x)
+    mean, invstd = torch.empty(Cc, device=x.device), torch.empty(Cc, device=x.device)
+    check(_lib.lib().kd_bn2d_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(running_mean),
+                                 _ptr(running_var), C.c_float(momentum), C.c_float(eps), int(training), int(relu), N, Cc, HW,
+                                 stream_ptr()), "kd_bn2d_fwd")
+    return y, mean, invstd
+
+
+def bn2d_bwd(dy, x, y, gamma, mean, invstd, training, relu=False, need_dx=True):
+    """Returns (dx | None, dgamma, dbeta)."""
+    _nchw32(dy, x, y, gamma, mean, invstd)
+    N, Cc = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * Cc)
+    dx = torch.empty_like(x) if need_dx else None
+    dg, db = torch.empty(Cc, device=x.device), torch.empty(Cc, device=x.device)
+    check(_lib.lib().kd_bn2d_bwd(_ptr(dy), _ptr(x), _ptr(y), _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(dx), _ptr(dg), _ptr(db),
+                                 int(training), int(relu), 0, N, Cc, HW, stream_ptr()), "kd_bn2d_bwd")
+    return dx, dg, db
 
 
 # ------------------------------------------------------------------------------------- losses

@@ -1,6 +1,8 @@
 """BASELINE config 0 shape (CIFAR ResNet-20 teacher -> identical student, KLDiv-only KD, ClassificationTrainer): same
 config dict and seeded batches the reference's own ClassificationTrainer was run on (tools/make_golden.py:
-g_classification_epoch).  The module graph runs on PyTorch-ROCm ops; criteria and bookkeeping are this package's."""
+g_classification_epoch).  Student and teacher convolutions / BatchNorm (train mode for the student) run on the
+small-shape HIP kernels (nn_hip.Conv2d / BatchNorm2d: kd_conv2d_direct_*, kd_bn2d_*), the criterion on kd_kldiv; no MIOpen
+kernel is issued (profiles/r02_c_classification_kernel_stats.md is the rocprofv3 trace of this test)."""
 import numpy as np
 import pytest
 import torch
@@ -34,6 +36,9 @@ def test_classification_trainer_epoch_matches_reference(golden, tmp_path):
     teacher.eval()
     model = DepthwiseStudent(teacher, config)
     assert not model.fused
+    from kdcc_amd import nn_hip
+    assert all(isinstance(m, nn_hip.Conv2d) for m in model.student.modules() if isinstance(m, torch.nn.Conv2d))
+    assert all(isinstance(m, nn_hip.BatchNorm2d) for m in model.student.modules() if isinstance(m, torch.nn.BatchNorm2d))
     crit = [config.init_obj(k, losses) for k in ("supervised_loss", "kd_loss", "hint_loss")]
     metrics = [getattr(metric, m) for m in config["metrics"]]
     opt = config.init_obj("optimizer", optim_module, model.student.parameters())

@@ -530,3 +530,81 @@ def test_relu_bn_bwd_channel_sums_bn_params_stem_wgrad(K, dt):
     y0 = host_nchw(yb).copy()
     K.broadcast_add(torch.from_numpy(v).cuda(), yb, alpha=0.5)
     assert_close(host_nchw(yb), y0 + 0.5 * v[:, :, None, None], dt, "broadcast add")
+
+
+# ------------------------------------------------------------------------------------------------- small-shape path (CIFAR)
+DIRECT_CASES = [
+    # N, C, H, W, K, k, stride, pad, dil, groups, bias
+    (4, 3, 32, 32, 16, 3, 1, 1, 1, 1, False),     # ResNet-20 stem
+    (3, 16, 17, 15, 32, 3, 2, 1, 1, 1, False),    # stride 2, odd sizes
+    (2, 16, 12, 12, 16, 3, 1, 1, 1, 16, True),    # depthwise 3x3 with bias (CIFAR cheap conv)
+    (2, 16, 9, 11, 40, 1, 1, 0, 1, 1, True),      # pointwise with bias
+    (1, 8, 20, 20, 8, 9, 1, 20, 5, 8, False),     # 9x9 dilation 5 depthwise on a non-multiple-of-16 channel count
+    (2, 12, 10, 10, 18, 3, 1, 2, 2, 3, False),    # grouped, dilated
+]
+
+
+@pytest.mark.parametrize("case", DIRECT_CASES)
+def test_direct_conv_fwd_dgrad_wgrad(K, case):
+    N, Cc, H, W, Kk, k, s, p, d, g, has_b = case
+    x, w = rnd(N, Cc, H, W), rnd(Kk, Cc // g, k, k, scale=0.3)
+    b = rnd(Kk) if has_b else None
+    cu = lambda a: None if a is None else torch.from_numpy(a).cuda()
+    y = K.conv2d_direct(cu(x), cu(w), cu(b), s, p, d, g)
+    ref = orc.conv2d_fwd(x, w, bias=b, stride=s, pad=p, dil=d, groups=g)
+    assert_close(y.cpu().numpy(), ref, "f32", f"direct fwd {case}")
+    gy = rnd(*ref.shape)
+    gx = K.conv2d_direct_dgrad(cu(gy), cu(w), x.shape, s, p, d, g)
+    assert_close(gx.cpu().numpy(), orc.conv2d_dgrad(gy, w, x.shape, stride=s, pad=p, dil=d, groups=g), "f32", f"direct dgrad {case}")
+    gw, gb = K.conv2d_direct_wgrad(cu(x), cu(gy), w.shape, s, p, d, g, want_bias=has_b)
+    assert_close(gw.cpu().numpy(), orc.conv2d_wgrad(x, gy, w.shape, stride=s, pad=p, dil=d, groups=g), "f32", f"direct wgrad {case}")
+    if has_b:
+        np.testing.assert_allclose(gb.cpu().numpy(), gy.sum((0, 2, 3)), rtol=1e-4, atol=1e-4)
+
+
+def test_bn_train_golden_and_oracle(K, golden):
+    """BatchNorm2d in training mode + fused ReLU: forward, input / weight / bias gradients against the reference's own run
+    (tests/golden/ops.npz, tools/make_golden.py:g_ops) and the oracle; running statistics; eval mode."""
+    g = golden("ops")
+    x, gamma, beta = g["x"], g["bn_gamma"], g["bn_beta"]
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    rm, rv = torch.zeros(6, device="cuda"), torch.ones(6, device="cuda")
+    y, mean, invstd = K.bn2d_fwd(cu(x), cu(gamma), cu(beta), rm, rv, True, 0.1, 1e-5, relu=True)
+    np.testing.assert_allclose(y.cpu().numpy(), g["bn_y"], rtol=1e-4, atol=1e-5)
+    dx, dg, db = K.bn2d_bwd(cu(g["bn_gy"]), cu(x), y, cu(gamma), mean, invstd, True, relu=True)
+    np.testing.assert_allclose(dx.cpu().numpy(), g["bn_gx"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(dg.cpu().numpy(), g["bn_ggamma"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(db.cpu().numpy(), g["bn_gbeta"], rtol=1e-4, atol=1e-5)
+    # oracle agreement (incl. the saved statistics) and nn.BatchNorm2d's running-stat update rule
+    yo, mo, io = orc.bn_train_fwd(x, gamma, beta, relu=True)
+    np.testing.assert_allclose(mean.cpu().numpy(), mo, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(invstd.cpu().numpy(), io, rtol=1e-5)
+    n = x.size // 6
+    xc = x.transpose(1, 0, 2, 3).reshape(6, -1).astype(np.float64)
+    np.testing.assert_allclose(rm.cpu().numpy(), 0.1 * xc.mean(1), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(rv.cpu().numpy(), 0.9 + 0.1 * xc.var(1) * n / (n - 1), rtol=1e-5)
+    # eval mode: running statistics, no update
+    rm0, rv0 = rm.clone(), rv.clone()
+    ye, _, _ = K.bn2d_fwd(cu(x), cu(gamma), cu(beta), rm, rv, False, 0.1, 1e-5, relu=False)
+    np.testing.assert_allclose(ye.cpu().numpy(), orc.bn_eval(x, gamma, beta, rm0.cpu().numpy(), rv0.cpu().numpy()), rtol=1e-4, atol=1e-5)
+    assert torch.equal(rm, rm0) and torch.equal(rv, rv0)
+
+
+def test_cheap_conv_block_module_small_channels(K, golden):
+    """DepthwiseSeparableBlock.forward as a module on the CIFAR geometry (16 channels, 3x3 / d1) and on the golden's
+    k9/d5 case: forward and every gradient against the reference's outputs (tests/golden/dwsep.npz)."""
+    from kdcc_amd.models.students import DepthwiseSeparableBlock
+    g = golden("dwsep")
+    for tag in ("k3d1", "k9d5"):
+        Cc, Co, k, p, d, H, W = [int(v) for v in g[f"{tag}.cfg"]]
+        blk = DepthwiseSeparableBlock(Cc, Co, k, p, d, Cc, None).cuda()
+        with torch.no_grad():
+            blk.separable_conv.weight.copy_(torch.from_numpy(g[f"{tag}.w_dw"]))
+            blk.pointwise_conv.weight.copy_(torch.from_numpy(g[f"{tag}.w_pw"]))
+        x = torch.from_numpy(g[f"{tag}.x"]).cuda().requires_grad_(True)
+        y = blk(x)
+        y.backward(torch.from_numpy(g[f"{tag}.gy"]).cuda())
+        assert_close(y.detach().cpu().numpy(), g[f"{tag}.y"], "f32", f"{tag} y")
+        assert_close(x.grad.cpu().numpy(), g[f"{tag}.gx"], "f32", f"{tag} gx")
+        assert_close(blk.separable_conv.weight.grad.cpu().numpy(), g[f"{tag}.gw_dw"], "f32", f"{tag} gw_dw")
+        assert_close(blk.pointwise_conv.weight.grad.cpu().numpy(), g[f"{tag}.gw_pw"], "f32", f"{tag} gw_pw")
