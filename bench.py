@@ -153,7 +153,7 @@ def cpu_baseline(cpu_sd, model, plan, full=False):
 def conv_traffic(plan, batch, height, width, dtype):
     """HBM bytes per conv_igemm launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate
     passes, same command); None when the profiled configuration is not the one being run."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r02_traffic_pmc.json")
     if not (plan == "P92" and batch == 4 and (height, width) == (1024, 2048) and dtype == "bf16" and os.path.exists(path)):
         return None
     try:
@@ -290,7 +290,7 @@ def main():
                          "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": conv_traffic(a.plan, a.batch, a.height, a.width, a.dtype) if a.mode == "A" else None,
                          "traffic_note": "mean HBM bytes per conv_igemm* launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + "
-                                         "WRITE_SIZE, separate passes (profiles/r01_traffic_pmc.json); mean algorithmic "
+                                         "WRITE_SIZE, separate passes (profiles/r02_traffic_pmc.json); mean algorithmic "
                                          "FLOP per launch = algorithmic_tflop_per_step / launches_per_step",
                          "launches_per_step": len(prof) / max(a.steps, 1), "ms_per_step_in_kernel": ms / max(a.steps, 1),
                          "algorithmic_tflop_per_step": flops / max(a.steps, 1) / 1e12},
