@@ -312,6 +312,12 @@ int kd_weighted_hint_mse(const kd_view3 *s, const kd_view3 *t, const float *w, i
 int kd_ce2d(const kd_view3 *x, const int64_t *target, int32_t ignore_index, int32_t N, int32_t C, int64_t P,
             float *loss, void *workspace, size_t workspace_bytes, kd_stream_t stream);
 
+/* gradient of kd_ce2d w.r.t. x (needed when the supervised loss is back-propagated: trainer/taylor_prune_trainer.py:204-206,
+ * or any loss = supervised + kd + hint mix): grad[n,c,p] = grad_scale * (softmax_c(x[n,:,p]) - [c == target[n,p]]) / #valid,
+ * zero for ignored pixels. */
+int kd_ce2d_grad(const kd_view3 *x, const int64_t *target, int32_t ignore_index, int32_t N, int32_t C, int64_t P,
+                 const kd_mview3 *grad, float grad_scale, void *workspace, size_t workspace_bytes, kd_stream_t stream);
+
 /* CityscapesMetricTracker.update / confusion_for_batch (utils/util.py:108-128), the logged train mIoU, without the
  * reference's two full-logit D2H copies per step (trainer/layerwise_trainer.py:249-250):
  *   for every pixel with 0 <= target < C:  conf[target][argmax_c x(n,c,p)] += 1

@@ -318,6 +318,54 @@ __global__ __launch_bounds__(256) void ce2d_kernel(V3 x, const int64_t *target, 
     if (threadIdx.x == 0) { partial[blockIdx.x] = w1[0] + w1[1] + w1[2] + w1[3]; count[blockIdx.x] = w2[0] + w2[1] + w2[2] + w2[3]; }
 }
 
+// gradient of the cross entropy above: (softmax - onehot) / #valid, zero rows for ignored pixels.  count[] holds the forward's
+// per-block valid-pixel counts (any block count nb); every block sums them in the same order.
+__global__ __launch_bounds__(256) void ce2d_count_kernel(const int64_t *target, int ignore_index, int C, long long total, double *count)
+{
+    double cnt = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int64_t y = target[i];
+        if (!(y == ignore_index || y < 0 || y >= C)) cnt += 1.0;
+    }
+    __shared__ double w2[4];
+    cnt = wave_sum_d(cnt);
+    if ((threadIdx.x & 63) == 0) w2[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) count[blockIdx.x] = w2[0] + w2[1] + w2[2] + w2[3];
+}
+
+__global__ __launch_bounds__(256) void ce2d_grad_kernel(V3 x, const int64_t *target, int ignore_index, int N, int C, long long P, M3 g,
+                                                        float gscale, const double *count, int ncount)
+{
+    __shared__ double tot;
+    if (threadIdx.x == 0) {
+        double c = 0.0;
+        for (int i = 0; i < ncount; ++i) c += count[i];
+        tot = c;
+    }
+    __syncthreads();
+    const float k = tot > 0.0 ? gscale / (float)tot : 0.f;
+    const long long total = (long long)N * P;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int64_t y = target[i];
+        const long long n = i / P, p = i - n * P;
+        const long long b = n * x.sN + p * x.sP, gb = n * g.sN + p * g.sP;
+        if (y == ignore_index || y < 0 || y >= C) {
+            for (int c = 0; c < C; ++c) kd_st(g.p, g.dt, gb + c * g.sC, 0.f);
+            continue;
+        }
+        float m = -INFINITY;
+        for (int c = 0; c < C; ++c) m = fmaxf(m, kd_ld(x.p, x.dt, b + c * x.sC));
+        float z = 0.f;
+        for (int c = 0; c < C; ++c) z += __expf(kd_ld(x.p, x.dt, b + c * x.sC) - m);
+        const float iz = 1.f / z;
+        for (int c = 0; c < C; ++c) {
+            const float pr = __expf(kd_ld(x.p, x.dt, b + c * x.sC) - m) * iz;
+            kd_st(g.p, g.dt, gb + c * g.sC, k * (pr - (c == (int)y ? 1.f : 0.f)));
+        }
+    }
+}
+
 // ---- RAdam ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void radam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                                                     float *__restrict__ v, long long n, float beta1, float beta2, float eps,
@@ -496,6 +544,23 @@ extern "C" int kd_ce2d(const kd_view3 *x, const int64_t *target, int32_t ignore_
     KD_CHECK_LAUNCH("kd_ce2d");
     hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, (const double *)partial, nb, 1.0, (const double *)count, loss);
     KD_CHECK_LAUNCH("kd_ce2d(finish)");
+    return KD_OK;
+}
+
+extern "C" int kd_ce2d_grad(const kd_view3 *x, const int64_t *target, int32_t ignore_index, int32_t N, int32_t C, int64_t P,
+                            const kd_mview3 *grad, float grad_scale, void *workspace, size_t workspace_bytes, kd_stream_t stream)
+{
+    KD_REQUIRE(x && x->ptr && target && grad && grad->ptr && workspace, KD_ERR_INVALID, "kd_ce2d_grad: null argument");
+    KD_REQUIRE(ok_dt(x->dtype) && ok_dt(grad->dtype) && N > 0 && C > 0 && P > 0, KD_ERR_INVALID, "kd_ce2d_grad: bad argument");
+    KD_REQUIRE(workspace_bytes >= kd_loss_workspace(N, C, P), KD_ERR_WORKSPACE, "kd_ce2d_grad: workspace too small");
+    double *count = (double *)workspace;
+    const int nb = blocks_for((long long)N * P);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ce2d_count_kernel, dim3(nb), dim3(256), 0, st, target, ignore_index, C, (long long)N * P, count);
+    KD_CHECK_LAUNCH("kd_ce2d_grad(count)");
+    hipLaunchKernelGGL(ce2d_grad_kernel, dim3(nb), dim3(256), 0, st, v3(x), target, ignore_index, N, C, (long long)P, m3(grad), grad_scale,
+                       (const double *)count, nb);
+    KD_CHECK_LAUNCH("kd_ce2d_grad");
     return KD_OK;
 }
 

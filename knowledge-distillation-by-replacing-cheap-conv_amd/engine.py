@@ -83,6 +83,10 @@ class StudentEngine:
         self._tape = None
         self.last_hint_names = []
         self.reducer = None   # optional parallel.GradReducer: gradients are written into its buckets and announced
+        # Taylor importance probes (models/students/taylor_prune_student.py:58-66): for a conv site named here backward also
+        # returns d loss / d gate of a unit channel gate placed behind the conv, sum_{n,h,w} y * dL/dy, in probe_grads[name]
+        self.probe_names = []
+        self.probe_grads = {}
 
     def _grad_like(self, p):
         if self.reducer is not None:
@@ -165,6 +169,7 @@ class StudentEngine:
         self.device = x.device
         N, _, H, W = x.shape
         want = set(self.hint_names) if collect_hints else set()
+        self._probes = set(self.probe_names) if torch.is_grad_enabled() else set()
         seen = []
         hints = []
         tape = {"blocks": [], "aspp": None, "hint_slots": [], "pools": {}}
@@ -230,7 +235,8 @@ class StudentEngine:
             site = _Site(f"aspp.features.{i}.0", br[0])
             sc, sh = self._bn_fold(br[1])
             hinted = site.name in want
-            raw = self._new(N, h8, w8, red) if hinted else None
+            probed = site.name in self._probes
+            raw = self._new(N, h8, w8, red) if (hinted or probed) else None
             out = cat[..., red * (i + 1):red * (i + 2)]
             mid = None
             if site.cheap:
@@ -242,8 +248,8 @@ class StudentEngine:
                            act_shift=sh, act_relu=True)
             if hinted:
                 note_hint(site.name, raw, ("aspp", i))
-            arec["branches"].append({"site": site, "mid": mid, "bn": br[1]})
-            rg_cat = rg_cat or site.trainable or _is_trainable(br[1])
+            arec["branches"].append({"site": site, "mid": mid, "bn": br[1], "probe_raw": raw if probed else None})
+            rg_cat = rg_cat or site.trainable or _is_trainable(br[1]) or probed
         if "aspp" in want:
             note_hint("aspp", cat, ("aspp_out",))
         tape["aspp"] = arec
@@ -318,9 +324,10 @@ class StudentEngine:
             # hook on either observes the tensor the in-place add turns into the block output; cfg/cityscapes/
             # 51M_deeplab_incremental.json uses 'mod4.block2.convs' and 'mod7.block1')
             hinted = site.name in want or (last and (f"{name}.convs" in want or name in want))
+            probed = site.name in self._probes
             kw = {}
             if last:
-                want_raw = need_raw or hinted
+                want_raw = need_raw or hinted or probed
                 raw = self._new(N, ho, wo, site.cout) if want_raw else None
                 kw["res_pre"] = shortcut
                 if next_bn is not None:
@@ -332,7 +339,7 @@ class StudentEngine:
             else:
                 sc, sh = self._bn_fold(bns[f"bn{i + 2}"])
                 act = self._new(N, ho, wo, site.cout)
-                raw = self._new(N, ho, wo, site.cout) if hinted else None
+                raw = self._new(N, ho, wo, site.cout) if (hinted or probed) else None
                 kw.update(out_raw=raw, out_act=act, act_scale=sc, act_shift=sh, act_relu=True)
             if site.cheap:
                 mid = ops.dwconv(a, self._w_dw(site.mod.separable_conv, False), site.k, site.pad, site.dil)
@@ -341,7 +348,9 @@ class StudentEngine:
                 mid = None
                 ops.conv2d(a, self._w_fwd(site.mod), site.stride, site.pad, site.dil, **kw)
             rec["mid"].append(mid)
-            rg = rg or site.trainable
+            rg = rg or site.trainable or probed
+            if probed:
+                rec.setdefault("probe", {})[i] = (raw, shortcut if last else None)
             if hinted:
                 # forward hooks fire in execution order; the last conv's hooked tensor is mutated by the in-place
                 # residual add, so the hint IS the block output
@@ -407,6 +416,7 @@ class StudentEngine:
         if len(hint_grads) != len(tape["hint_slots"]):
             raise EngineError("hint gradient list does not match the recorded hints")
         grads = {}
+        self.probe_grads = {}
         g_block_out = {}   # block index -> grad wrt raw block output
         g_site_hint = {}   # (block index, site index) -> hint grad of that site's raw output
         g_aspp = {}        # branch -> grad wrt the branch conv's raw output
@@ -483,6 +493,15 @@ class StudentEngine:
         if not g.is_contiguous():
             g = g.contiguous()
         return g
+
+    def _probe(self, name, g, raw, shortcut):
+        """d loss / d (unit channel gate behind the conv `name`) = sum_{n,h,w} y * dL/dy with y the conv's own output: the stored
+        raw tensor, minus the shortcut the epilogue added when the conv closes a residual block."""
+        _, s2 = ops.channel_sums(g, a=raw)
+        if shortcut is not None:
+            _, s2b = ops.channel_sums(g, a=shortcut)
+            s2 = s2 - s2b
+        self.probe_grads[name] = s2
 
     # ---- parameter gradients ------------------------------------------------------------------------------------------
     def _conv_wgrad(self, conv, a_in, g, grads, cin=None):
@@ -572,6 +591,8 @@ class StudentEngine:
             site, a_in, need_in = sites[i], rec["a_in"][i], rec["rg_a"][i]
             g_in = None
             bn_seq = bns[f"bn{i + 1}"] if i > 0 else blk.bn1
+            if g is not None and i in rec.get("probe", {}):
+                self._probe(site.name, g, *rec["probe"][i])
             if g is not None and (need_in or site.trainable):
                 sc, _ = self._bn_fold(bn_seq)
                 ep = dict(mask=a_in, mask_scale=sc)
@@ -634,6 +655,8 @@ class StudentEngine:
             if g is None:
                 continue
             site = br["site"]
+            if br.get("probe_raw") is not None:
+                self._probe(site.name, g, br["probe_raw"], None)
             if site.cheap and not g.is_contiguous():
                 g = g.contiguous()   # the depthwise / pointwise-wgrad kernels take dense views
             g_in = self._site_bwd(site, x7, br["mid"], g, grads, rg7, res_post=g_x7)
@@ -762,7 +785,9 @@ class _StudentFunction(torch.autograd.Function):
 def run_student(engine, x):
     """Differentiable student call: returns (logits NCHW-logical fp32, [hints NCHW-logical])."""
     params = tuple(p for p in engine.net.parameters() if p.requires_grad)
-    if torch.is_grad_enabled() and params:
+    if torch.is_grad_enabled() and (params or engine.probe_names):
+        if not params:   # probes only: autograd still needs one differentiable input to build the node
+            x = x.detach().requires_grad_(True)
         outs = _StudentFunction.apply(engine, x, *params)
     else:
         logits, hints = engine.forward(x)

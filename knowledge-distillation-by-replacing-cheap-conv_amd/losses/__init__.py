@@ -74,9 +74,24 @@ class WeightedHintMSELoss(nn.Module):
         return _FusedLoss.apply("whmse", inputs, _same_device_dtype(inputs, targets), None, filter_weight)
 
 
+class _CEFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inputs, targets, ignore_index):
+        ctx.save_for_backward(inputs.detach(), targets)
+        ctx.ignore_index = ignore_index
+        return ops.ce2d(inputs.detach(), targets, ignore_index)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, tgt = ctx.saved_tensors
+        grad = ops.ce2d_grad(x, tgt, ctx.ignore_index)
+        return grad * g.to(grad.dtype), None, None
+
+
 class CrossEntropyLoss2d(nn.Module):
-    """NLLLoss(ignore_index)(log_softmax(inputs, 1), targets)  (losses/CrossEntropy.py:5-14).  Logged metric in the
-    KD trainers (never back-propagated there), so forward-only."""
+    """NLLLoss(ignore_index)(log_softmax(inputs, 1), targets)  (losses/CrossEntropy.py:5-14).  A logged metric in the KD
+    trainers (forward-only there: `inputs` is detached when nothing asks for its gradient); differentiable for the trainers
+    that back-propagate the supervised loss (trainer/taylor_prune_trainer.py:204-206)."""
 
     def __init__(self, weight=None, size_average=True, ignore_index=255):
         super().__init__()
@@ -86,5 +101,5 @@ class CrossEntropyLoss2d(nn.Module):
 
     def forward(self, inputs, targets):
         if inputs.requires_grad and torch.is_grad_enabled():
-            inputs = inputs.detach()
+            return _CEFunction.apply(inputs, targets, self.ignore_index)
         return ops.ce2d(inputs, targets, self.ignore_index)

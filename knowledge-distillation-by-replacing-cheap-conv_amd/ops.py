@@ -575,6 +575,21 @@ def ce2d(x, target, ignore_index=255):
     return loss
 
 
+def ce2d_grad(x, target, ignore_index=255, grad_scale=1.0):
+    """d ce2d / d x, same layout as x."""
+    _need_cuda(x, target)
+    vx, (N, Cc, P) = view3(x)
+    tgt = target.contiguous()
+    if tgt.dtype != torch.int64 or tgt.numel() != N * P:
+        raise ValueError("ce2d_grad: target must be int64 with one label per pixel")
+    grad = torch.empty_like(x)
+    vg, _ = view3(grad)
+    ws, need = loss_workspace(N, Cc, P, x.device)
+    check(_lib.lib().kd_ce2d_grad(C.byref(vx), _ptr(tgt), ignore_index, N, Cc, P, C.byref(vg), C.c_float(grad_scale), _ptr(ws), need,
+                                  stream_ptr()), "kd_ce2d_grad")
+    return grad
+
+
 def confusion(x, target, conf=None, accumulate=False):
     """conf (C,C) int64 [label][prediction] of argmax_c x vs target; pixels whose label is outside [0, C) are skipped."""
     _need_cuda(x, target, conf)

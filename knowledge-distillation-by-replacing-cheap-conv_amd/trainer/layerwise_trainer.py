@@ -175,7 +175,7 @@ class LayerwiseTrainer(BaseTrainer):
                 table = self.__dict__.setdefault('_fw_table', None) or torch.load(spec, map_location='cpu')
                 self._fw_table = table
                 names = getattr(self.model, 'student_hint_names', None) or self.model.hint_block_names
-                w = table[names[index]].float()
+                w = torch.as_tensor(table[names[index]]).float()
             cache[key] = w.to(device)
         return cache[key]
 

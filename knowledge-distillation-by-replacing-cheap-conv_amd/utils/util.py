@@ -156,3 +156,33 @@ class EarlyStopTracker:
         self.last = new_value
         self.last_update_success = ok
         return ok
+
+
+class ImportanceFilterTracker:
+    """Running mean of per-filter Taylor importances, normalised to sum 1 per layer (reference utils/util.py:191-216).
+    Values may be numpy vectors (the reference's type) or tensors; average() returns {name: float32 tensor}, the table
+    LayerwiseTrainer reads as `hint_filter_weight` for WeightedHintMSELoss."""
+
+    def __init__(self, writer=None):
+        self.writer = writer
+        self.importance_dict = dict()
+        self.counter = dict()
+        self.temperature = 1
+        self.scale_factor = 1e5
+
+    def update_importance_list(self, added_gates):
+        for name, gate_layer in added_gates.items():
+            self.importance_dict[name] = torch.zeros(gate_layer.num_features, dtype=torch.float64)
+            self.counter[name] = 0.
+
+    def update(self, new_importance_dict):
+        for name, vector in new_importance_dict.items():
+            self.importance_dict[name] += torch.as_tensor(vector, dtype=torch.float64).cpu()
+            self.counter[name] += 1
+
+    def average(self):
+        result = dict()
+        for name, vector in self.importance_dict.items():
+            mean_vector = vector / self.counter[name] * self.scale_factor
+            result[name] = (mean_vector / mean_vector.sum()).float()
+        return result

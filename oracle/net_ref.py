@@ -27,7 +27,13 @@ def _bnrelu(sd, p, x, relu=True):
 
 
 def _conv(sd, name, x, stride, pad, dil, cheap_geom):
-    """Dense conv `name`, or -- when the student's dict holds a replaced block there -- depthwise k x k then 1x1."""
+    """Dense conv `name`, or -- when the student's dict holds a replaced block there -- depthwise k x k then 1x1.  A
+    `<name>.gate` entry is the GateLayer the reference's TaylorPruneStudent puts behind the conv
+    (models/students/taylor_prune_student.py:37-40, transform_blocks/gate.py:11-12)."""
+    if name + ".gate" in sd:
+        gate = sd[name + ".gate"]
+        rest = {k: v for k, v in sd.items() if k != name + ".gate"}
+        return _conv(rest, name, x, stride, pad, dil, cheap_geom) * gate.view(1, -1, 1, 1)
     if name + ".weight" in sd:
         return F.conv2d(x, sd[name + ".weight"], None, stride, pad, dil)
     k, p, d = cheap_geom
@@ -167,3 +173,19 @@ def make_student_sd(teacher_sd, plan, new_weights, trainable=None):
         for suffix in ("separable_conv.weight", "pointwise_conv.weight"):
             sd[f"{name}.{suffix}"].requires_grad_(True)
     return sd
+
+
+def taylor_importance(teacher_sd, x, target, gates):
+    """trainer/taylor_prune_trainer.py:196-211 for one step: unit gates behind the named convs of a copy of the teacher,
+    loss = cross entropy of the student logits, importance = (gate * d loss / d gate)^2.  gates: {conv name: channels}.
+    Returns (loss, {name: gate gradient}, {name: importance})."""
+    sd = {k: v.detach().clone() for k, v in teacher_sd.items()}
+    gs = {}
+    for name, c in gates.items():
+        gs[name] = torch.ones(c, requires_grad=True)
+        sd[name + ".gate"] = gs[name]
+    logits, _, _ = forward(sd, x)
+    loss = F.cross_entropy(logits, target, ignore_index=255)
+    grads = torch.autograd.grad(loss, list(gs.values()))
+    gg = dict(zip(gs.keys(), grads))
+    return loss.detach(), gg, {n: (gs[n].detach() * g) ** 2 for n, g in gg.items()}

@@ -72,3 +72,19 @@ def test_net_oracle_mode_b_matches_reference(golden):
     assert sorted(r["grads"]) == sorted(names) and len(names) == 143
     for n in names:
         _cmp_k(r["grads"][n], g, f"grad:{n}", 256, 2e-4)
+
+
+def test_taylor_importance_matches_reference(golden):
+    """net_ref.taylor_importance (unit gates behind three convs, supervised loss) vs the reference's TaylorPruneStudent run."""
+    g = golden("taylor")
+    names = [str(s) for s in g["names"]]
+    torch.set_num_threads(8)
+    tsd = seeded_teacher_sd()
+    x = seeded_input("taylor.x", (2, 3, 64, 128))
+    tgt = torch.from_numpy(g["target"].astype(np.int64))
+    loss, gg, imp = net_ref.taylor_importance(tsd, x, tgt, {n: len(g[f"imp:{n}"]) for n in names})
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=1e-5)
+    for n in names:
+        ref = g[f"gate_grad:{n}"].astype(np.float64)
+        assert np.abs(gg[n].numpy() - ref).max() <= 2e-4 * np.abs(ref).max(), n
+        np.testing.assert_allclose(imp[n].numpy(), g[f"imp:{n}"], rtol=2e-3, atol=1e-6 * g[f"imp:{n}"].max())

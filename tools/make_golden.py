@@ -319,6 +319,39 @@ def g_student_step_full(plan_name="g4", hw=(64, 128), batch=2):
     save(f"student_step_full_{plan_name}", **out)
 
 
+TAYLOR_GATES = [("mod4.block2.convs.conv2", 512), ("mod7.block1.convs.conv2", 2048), ("aspp.features.1.0", 256)]
+
+
+def g_taylor(hw=(64, 128), batch=2):
+    """models/students/taylor_prune_student.py + trainer/taylor_prune_trainer.py:196-211 on the reference: gates behind the last
+    conv of a residual block, a bottleneck's middle conv and an ASPP branch conv; loss = CrossEntropyLoss2d(student logits,
+    target); importance = (gate * d loss / d gate)^2 from get_gate_importance(); ImportanceFilterTracker.average()."""
+    from models.students.taylor_prune_student import TaylorPruneStudent
+    from utils.util import ImportanceFilterTracker
+    teacher = DeepWV3Plus(num_classes=19)
+    seeded_fill_(teacher, "teacher.")
+    teacher.eval()
+    model = TaylorPruneStudent(teacher, config=None)
+    model.replace([{"name": n, "epoch": 1, "num_features": c} for n, c in TAYLOR_GATES])
+    x = seeded_input("taylor.x", (batch, 3) + hw)
+    tgt = torch.randint(0, 19, (batch,) + hw, generator=torch.Generator().manual_seed(21))
+    tgt[:, :4] = 255
+    out_st, _ = model(x)
+    loss = ref_losses.CrossEntropyLoss2d(ignore_index=255)(out_st, tgt)
+    loss.backward()
+    imp = model.get_gate_importance()
+    tr = ImportanceFilterTracker(writer=None)
+    tr.update_importance_list(model.added_gates)
+    tr.update(imp)
+    avg = tr.average()
+    out = dict(names=np.array([n for n, _ in TAYLOR_GATES]), target=tgt.numpy().astype(np.uint8), loss=np.float64(loss.item()))
+    for n, _ in TAYLOR_GATES:
+        out[f"imp:{n}"] = np.asarray(imp[n], np.float64)
+        out[f"gate_grad:{n}"] = model.added_gates[n].weight.grad.numpy()
+        out[f"avg:{n}"] = np.asarray(avg[n], np.float64)
+    save("taylor", **out)
+
+
 def trainer_config(plan, lr, len_epoch, save_dir):
     """A config dict in the reference's JSON schema (cfg/cityscapes/*.json) for a tiny synthetic run."""
     ent = [{"name": n, "epoch": 1} for n in plan]
@@ -449,7 +482,7 @@ def g_keys():
     print("wrote", path, len(inv), "entries", sum(int(np.prod(v)) for k, v in inv.items() if "num_batches" not in k and "running" not in k), "params")
 
 
-ALL = dict(keys=g_keys, confusion=g_confusion, student_step_full=g_student_step_full, trainer_epoch=g_trainer_epoch, classification_epoch=g_classification_epoch, losses=g_losses, dwsep=g_dwsep, resblock=g_resblock, aspp=g_aspp, ops=g_ops, radam=g_radam,
+ALL = dict(keys=g_keys, confusion=g_confusion, taylor=g_taylor, student_step_full=g_student_step_full, trainer_epoch=g_trainer_epoch, classification_epoch=g_classification_epoch, losses=g_losses, dwsep=g_dwsep, resblock=g_resblock, aspp=g_aspp, ops=g_ops, radam=g_radam,
            student_step=g_student_step)
 
 if __name__ == "__main__":
