@@ -87,6 +87,7 @@ class StudentEngine:
         # returns d loss / d gate of a unit channel gate placed behind the conv, sum_{n,h,w} y * dL/dy, in probe_grads[name]
         self.probe_names = []
         self.probe_grads = {}
+        self._probe_active = False   # set by run_student for differentiable calls (Function.forward runs with grad mode off)
 
     def _grad_like(self, p):
         if self.reducer is not None:
@@ -169,7 +170,7 @@ class StudentEngine:
         self.device = x.device
         N, _, H, W = x.shape
         want = set(self.hint_names) if collect_hints else set()
-        self._probes = set(self.probe_names) if torch.is_grad_enabled() else set()
+        self._probes = set(self.probe_names) if self._probe_active else set()
         seen = []
         hints = []
         tape = {"blocks": [], "aspp": None, "hint_slots": [], "pools": {}}
@@ -788,7 +789,11 @@ def run_student(engine, x):
     if torch.is_grad_enabled() and (params or engine.probe_names):
         if not params:   # probes only: autograd still needs one differentiable input to build the node
             x = x.detach().requires_grad_(True)
-        outs = _StudentFunction.apply(engine, x, *params)
+        engine._probe_active = bool(engine.probe_names)
+        try:
+            outs = _StudentFunction.apply(engine, x, *params)
+        finally:
+            engine._probe_active = False
     else:
         logits, hints = engine.forward(x)
         engine._tape = None
