@@ -221,6 +221,68 @@ class DepthwiseStudent(nn.Module):
             pred, _ = run_student(engine, x)
         return pred
 
+    @staticmethod
+    def sliding_windows(h, w, crop_size, overlap=1 / 3):
+        """Window boxes (x1, y1, x2, y2) of the reference's tiling (utils/tta_process.py:68-101): square crop_size tiles,
+        stride ceil(crop * (1 - overlap)), the last tile of a row / column pulled back inside the image."""
+        from math import ceil
+        stride = ceil(crop_size * (1 - overlap))
+        n_x = int(ceil((w - crop_size) / stride) + 1)
+        n_y = int(ceil((h - crop_size) / stride) + 1)
+        boxes = []
+        for ix in range(n_x):
+            for iy in range(n_y):
+                x2, y2 = min(ix * stride + crop_size, w), min(iy * stride + crop_size, h)
+                boxes.append((max(x2 - crop_size, 0), max(y2 - crop_size, 0), x2, y2))
+        return boxes
+
+    def inference_test(self, data, args, max_windows_per_pass=8):
+        """Sliding-window + horizontal-flip test-time inference of the student (reference depthwise_student.py:187-206 with
+        utils/tta_process.py), entirely on the device: the windows of the image and of its mirror image go through the
+        student in batches, their logits are summed into full-frame maps and divided by the per-pixel window count, the
+        mirrored map is flipped back and the two are averaged.  data: normalised (N,3,H,W) batch, as the trainer feeds it.
+
+        Differences from the reference, on purpose: (1) only `scales == [1.0]` (every shipped config): other scales go
+        through PIL / cv2 resampling there, arithmetic that lives in un-vendored libraries; (2) the reference divides by a
+        window count it indexes as [class, row] instead of [row, column] (tta_process.py:41-48: `count_predictions[y1:y2,
+        x1:x2]` on a (C,h,w) array), i.e. a per-pixel positive rescaling of the logits that leaves the arg-max -- hence the
+        mIoU and the submission -- unchanged; here the count is the true per-pixel one."""
+        self.student_hidden_outputs = []
+        self.teacher_hidden_outputs = []
+        scales = list(args.get('scales', [1.0]))
+        if any(abs(float(sc) - 1.0) > 1e-9 for sc in scales):
+            raise NotImplementedError("inference_test: only scales == [1.0] (resampled scales need PIL/cv2 arithmetic)")
+        crop = int(args['crop_size'])
+        N, _, H, W = data.shape
+        crop_h, crop_w = min(crop, H), min(crop, W)
+        if crop_h != crop_w:
+            crop_h = crop_w = min(crop_h, crop_w)
+        boxes = self.sliding_windows(H, W, crop_h)
+        outs = []
+        with torch.no_grad():
+            for n in range(N):
+                img = data[n:n + 1]
+                acc = None
+                for flipped in (False, True):
+                    src = torch.flip(img, dims=[3]) if flipped else img
+                    full = cnt = None
+                    for i in range(0, len(boxes), max_windows_per_pass):
+                        part = boxes[i:i + max_windows_per_pass]
+                        wins = torch.cat([src[:, :, y1:y2, x1:x2] for (x1, y1, x2, y2) in part], 0).contiguous()
+                        logits = self.inference(wins).float()
+                        if full is None:
+                            full = torch.zeros((logits.shape[1], H, W), dtype=torch.float32, device=data.device)
+                            cnt = torch.zeros((1, H, W), dtype=torch.float32, device=data.device)
+                        for j, (x1, y1, x2, y2) in enumerate(part):
+                            full[:, y1:y2, x1:x2] += logits[j]
+                            cnt[:, y1:y2, x1:x2] += 1
+                    full = full / cnt
+                    if flipped:
+                        full = torch.flip(full, dims=[2])
+                    acc = full if acc is None else (acc + full) / 2
+                outs.append(acc.unsqueeze(0))
+        return torch.cat(outs, 0)
+
     # ------------------------------------------------------------------ bookkeeping
     def dump_trainable_params(self):
         params = sum(p.numel() for p in self.parameters() if p.requires_grad)

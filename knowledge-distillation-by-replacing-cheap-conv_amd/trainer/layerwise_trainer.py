@@ -9,6 +9,7 @@ only read at log points; with torch.distributed initialised each rank runs its o
 parallel.GradReducer from inside backward.
 """
 import gc
+import os
 from functools import reduce
 
 import torch
@@ -280,8 +281,47 @@ class LayerwiseTrainer(BaseTrainer):
         return result
 
     def _test_epoch(self, epoch):
-        raise NotImplementedError("sliding-window test-time inference / submission export is outside the KD hot path "
-                                  "(SURVEY section 2, 'TTA / submission': out of scope)")
+        """Sliding-window + flip inference of the student over the validation loader (reference :340-376): batches are
+        (image names, data, target); config['test']['args'] = {scales, crop_size}; with config['submission']['save_output']
+        the arg-max maps are written as label-id PNGs (needs PIL and a dataset exposing id_to_trainid)."""
+        self._clean_cache()
+        self.model.save_hidden = False
+        self.test_metrics.reset()
+        self.test_iou_metrics.reset()
+        args = self.config['test']['args']
+        sub = self.config['submission'] if 'submission' in self.config else {'save_output': False}
+        if sub.get('save_output'):
+            os.makedirs(sub['path_output'], exist_ok=True)
+        with torch.no_grad():
+            for batch_idx, (img_name, data, target) in enumerate(self.valid_data_loader):
+                data, target = data.to(self.device), target.to(self.device)
+                output = self.model.inference_test(data, args)
+                if sub.get('save_output'):
+                    self.save_for_submission(output, img_name[0])
+                self.writer.set_step((epoch - 1) * len(self.valid_data_loader) + batch_idx, 'test')
+                self.test_metrics.update('supervised_loss', self.criterions[0](output, target))
+                self.test_iou_metrics.update(output, target)
+                for met in self.metric_ftns:
+                    self.test_metrics.update(met.__name__, met(output, target))
+        self.test_metrics.flush()
+        result = self.test_metrics.result()
+        result['mIoU'] = self.test_iou_metrics.get_iou()
+        return result
+
+    def save_for_submission(self, output, image_name):
+        """arg-max -> dataset label ids (trainId -> id through the dataset's id_to_trainid, reference :378-397) -> PNG."""
+        from PIL import Image
+        sub = self.config['submission']
+        pred = torch.argmax(output, dim=1)
+        mapping = getattr(getattr(self.valid_data_loader, 'dataset', None), 'id_to_trainid', None)
+        out = torch.zeros_like(pred)
+        if mapping is not None:
+            for k, v in mapping.items():
+                out[pred == v] = k
+        else:
+            out = pred
+        arr = out[0].to(torch.uint8).cpu().numpy()
+        Image.fromarray(arr).save(os.path.join(sub['path_output'], '{}.{}'.format(image_name, sub['ext'])))
 
     def _clean_cache(self):
         self.model.student_hidden_outputs, self.model.teacher_hidden_outputs = list(), list()
