@@ -198,7 +198,8 @@ int kd_aspp_image_pool(int32_t dtype, const void *x, int32_t ldx, const float *w
  * kd_stem_wgrad: weight gradient of mod1.conv1 (wider_resnet.py:307-309) from the trainer's NCHW fp32 batch:
  *   dw (64,3,3,3) fp32 = sum_pixels dy[n,h,w,:] (x) x[n,:,h-1+ky,w-1+kx].
  * kd_maxpool3x3s2_bwd: gx[n,h,w,c] = sum of gy over the (<= 4) windows whose first maximum is (h,w)
- *   (nn.MaxPool2d(3,2,1) backward, wider_resnet.py:353-356); x is the pool's input.
+ *   (nn.MaxPool2d(3,2,1) backward, wider_resnet.py:353-356); x is the pool's input.  workspace (optional; one byte per window
+ *   and channel, kd_maxpool3x3s2_bwd_workspace) selects the two-pass arg-max-index path; without it a slower gather runs.
  * kd_upsample_bilinear_ac_bwd: transpose of kd_upsample_bilinear_ac (deeplabv3.py:16-18,155,160): gy (N,Ho,Wo,C) ->
  *   gx (N,H,W,C); separable gather, workspace = one (N,Ho,W,C) float plane.
  * kd_zero_insert: y[n, h*stride, w*stride, :] = x[n,h,w,:], zeros elsewhere (Hy x Wy output): turns the input gradient
@@ -214,8 +215,10 @@ int kd_aspp_image_pool(int32_t dtype, const void *x, int32_t ldx, const float *w
 size_t kd_stem_wgrad_workspace(int32_t N, int32_t H, int32_t W);
 int kd_stem_wgrad(int32_t dtype, const float *x_nchw, const void *dy, int32_t ld_dy, float *dw, int32_t N, int32_t H,
                   int32_t W, int32_t accumulate, void *workspace, size_t workspace_bytes, kd_stream_t stream);
+size_t kd_maxpool3x3s2_bwd_workspace(int32_t N, int32_t H, int32_t W, int32_t C);
 int kd_maxpool3x3s2_bwd(int32_t dtype, const void *x, int32_t ldx, const void *gy, int32_t ldgy, void *gx, int32_t ldgx,
-                        int32_t N, int32_t H, int32_t W, int32_t C, kd_stream_t stream);
+                        int32_t N, int32_t H, int32_t W, int32_t C, void *workspace, size_t workspace_bytes,
+                        kd_stream_t stream);
 size_t kd_upsample_bilinear_ac_bwd_workspace(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo);
 int kd_upsample_bilinear_ac_bwd(const void *gy, int32_t gy_dtype, int32_t ldgy, void *gx, int32_t gx_dtype, int32_t ldgx,
                                 int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,

@@ -58,7 +58,8 @@ _SIGS = {
     "kd_conv2d_wgrad": (c_int, [_P(ConvDesc), c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_sz, c_vp]),
     "kd_stem_wgrad_workspace": (c_sz, [c_int, c_int, c_int]),
     "kd_stem_wgrad": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
-    "kd_maxpool3x3s2_bwd": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "kd_maxpool3x3s2_bwd_workspace": (c_sz, [c_int, c_int, c_int, c_int]),
+    "kd_maxpool3x3s2_bwd": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
     "kd_upsample_bilinear_ac_bwd_workspace": (c_sz, [c_int] * 6),
     "kd_upsample_bilinear_ac_bwd": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp,
                                             c_sz, c_vp]),

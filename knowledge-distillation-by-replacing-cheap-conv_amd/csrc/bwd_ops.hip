@@ -185,6 +185,69 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T *__restrict__ 
     else Elem<T>::st(op, acc[0]);
 }
 
+// fast path (C % 8 == 0): (1) per window, the position 0..8 of its first maximum per channel -> one byte per (window, channel);
+// (2) per input pixel, the <= 4 windows covering it: add the window's gradient where the stored position is this pixel's.
+// ~2.6 GB of traffic for the 64-channel 1024x2048 pool at 4 images instead of 32 dependent 16-B loads per pixel.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_argmax_kernel(const T *__restrict__ x, int ldx, uint2 *__restrict__ idx, int N, int H, int W,
+                                                             int C8, int Ho, int Wo)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Wo * C8) return;
+    const int wo = i / C8, cq = i - wo * C8;
+    const int ho = blockIdx.y, n = blockIdx.z;
+    float m[8];
+    uint32_t pos[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { m[q] = -INFINITY; pos[q] = 0xffu; }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int hh = 2 * ho - 1 + ky;
+        if (hh < 0 || hh >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ww = 2 * wo - 1 + kx;
+            if (ww < 0 || ww >= W) continue;
+            float v[8];
+            ld8(x + (((size_t)n * H + hh) * W + ww) * ldx + cq * 8, v);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (v[q] > m[q] || v[q] != v[q] || pos[q] == 0xffu) { m[q] = v[q]; pos[q] = ky * 3 + kx; }   // nn.MaxPool2d's rule
+        }
+    }
+    idx[((size_t)n * Ho + ho) * Wo * C8 + (size_t)wo * C8 + cq] =
+        make_uint2(pos[0] | (pos[1] << 8) | (pos[2] << 16) | (pos[3] << 24), pos[4] | (pos[5] << 8) | (pos[6] << 16) | (pos[7] << 24));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_gather_kernel(const uint2 *__restrict__ idx, const T *__restrict__ gy, int ldgy,
+                                                                 T *__restrict__ gx, int ldgx, int N, int H, int W, int C8, int Ho, int Wo)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= W * C8) return;
+    const int w = i / C8, cq = i - w * C8;
+    const int h = blockIdx.y, n = blockIdx.z;
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    const int ho_lo = h / 2, ho_hi = min(Ho - 1, (h + 1) / 2);
+    const int wo_lo = w / 2, wo_hi = min(Wo - 1, (w + 1) / 2);
+    for (int ho = ho_lo; ho <= ho_hi; ++ho)
+        for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+            const uint32_t mine = (uint32_t)((h - (2 * ho - 1)) * 3 + (w - (2 * wo - 1)));
+            const size_t o = ((size_t)n * Ho + ho) * Wo + wo;
+            const uint2 p = idx[o * C8 + cq];
+            float g[8];
+            ld8(gy + o * ldgy + cq * 8, g);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t pq = ((q < 4 ? p.x : p.y) >> (8 * (q & 3))) & 0xffu;
+                if (pq == mine) acc[q] += g[q];
+            }
+        }
+    st8(gx + (((size_t)n * H + h) * W + w) * ldgx + cq * 8, acc);
+}
+
 // ---- bilinear (align_corners=True) upsample backward, separable gather ---------------------------------------------------------
 // forward: src = o * (I - 1) / (O - 1); i0 = floor(src), i1 = min(i0 + 1, I - 1), f = src - i0; y[o] = (1-f) x[i0] + f x[i1].
 // backward along one axis: gx[i] = sum_o [i0(o) == i] (1 - f(o)) gy[o] + [i1(o) == i] f(o) gy[o]; the candidate range of o is
@@ -423,8 +486,14 @@ extern "C" int kd_bn_eval_param_grads(const float *s1, const float *s2, const fl
     return KD_OK;
 }
 
+extern "C" size_t kd_maxpool3x3s2_bwd_workspace(int32_t N, int32_t H, int32_t W, int32_t C)
+{
+    return (size_t)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * (size_t)((C + 7) / 8) * 8;   // one byte per window and channel
+}
+
 extern "C" int kd_maxpool3x3s2_bwd(int32_t dtype, const void *x, int32_t ldx, const void *gy, int32_t ldgy, void *gx, int32_t ldgx,
-                                   int32_t N, int32_t H, int32_t W, int32_t C, kd_stream_t stream)
+                                   int32_t N, int32_t H, int32_t W, int32_t C, void *workspace, size_t workspace_bytes,
+                                   kd_stream_t stream)
 {
     KD_REQUIRE(x && gy && gx && N > 0 && H > 0 && W > 0 && C > 0, KD_ERR_INVALID, "kd_maxpool3x3s2_bwd: bad argument");
     KD_REQUIRE(ok_dt(dtype), KD_ERR_INVALID, "kd_maxpool3x3s2_bwd: bad dtype");
@@ -432,6 +501,19 @@ extern "C" int kd_maxpool3x3s2_bwd(int32_t dtype, const void *x, int32_t ldx, co
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const bool vec = C % 8 == 0 && vec_ok(x, ldx, es) && vec_ok(gy, ldgy, es) && vec_ok(gx, ldgx, es);
     hipStream_t s = (hipStream_t)stream;
+    if (vec && workspace && workspace_bytes >= kd_maxpool3x3s2_bwd_workspace(N, H, W, C) && ((uintptr_t)workspace & 7) == 0) {
+        const int C8 = C / 8;
+        const dim3 g1((unsigned)((Wo * C8 + 255) / 256), (unsigned)Ho, (unsigned)N), g2((unsigned)((W * C8 + 255) / 256), (unsigned)H, (unsigned)N);
+        if (dtype == KD_BF16) {
+            hipLaunchKernelGGL(maxpool_argmax_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t *)x, ldx, (uint2 *)workspace, N, H, W, C8, Ho, Wo);
+            hipLaunchKernelGGL(maxpool_bwd_gather_kernel<bf16_t>, g2, dim3(256), 0, s, (const uint2 *)workspace, (const bf16_t *)gy, ldgy, (bf16_t *)gx, ldgx, N, H, W, C8, Ho, Wo);
+        } else {
+            hipLaunchKernelGGL(maxpool_argmax_kernel<float>, g1, dim3(256), 0, s, (const float *)x, ldx, (uint2 *)workspace, N, H, W, C8, Ho, Wo);
+            hipLaunchKernelGGL(maxpool_bwd_gather_kernel<float>, g2, dim3(256), 0, s, (const uint2 *)workspace, (const float *)gy, ldgy, (float *)gx, ldgx, N, H, W, C8, Ho, Wo);
+        }
+        KD_CHECK_LAUNCH("kd_maxpool3x3s2_bwd");
+        return KD_OK;
+    }
     const dim3 g((unsigned)((W * (vec ? C / 8 : C) + 255) / 256), (unsigned)H, (unsigned)N);
     if (dtype == KD_BF16) {
         if (vec) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 8>), g, dim3(256), 0, s, (const bf16_t *)x, ldx, (const bf16_t *)gy, ldgy, (bf16_t *)gx, ldgx, N, H, W, C, Ho, Wo);

@@ -151,6 +151,21 @@ class StudentEngine:
         f = torch.zeros if zero else torch.empty
         return f((N, H, W, C), dtype=dtype or self.dtype, device=self.device)
 
+    # ------------------------------------------------------------------ plan-time checks
+    def check_hint_names(self, names):
+        """Raise at registration time (epoch 1 / plan time, not 15 epochs into a run) when a hint name is not one the fused
+        graph can capture: a conv site `modN.blockM.convs.convK`, a block's `modN.blockM.convs` or `modN.blockM` (both the
+        block output), an ASPP branch conv `aspp.features.N.0`, or `aspp` (the module output)."""
+        ok = {"aspp"} | {f"aspp.features.{i}.0" for i in range(len(self.net.aspp.features))}
+        for name, blk in self._flat_blocks():
+            ok.add(name)
+            ok.add(f"{name}.convs")
+            ok.update(f"{name}.convs.{n}" for n, _ in blk.convs.named_children() if n.startswith("conv"))
+        bad = [n for n in names if n not in ok]
+        if bad:
+            raise EngineError(f"hint layers the fused student graph cannot capture: {bad} (supported: conv sites, "
+                              "`<block>.convs`, `<block>`, `aspp.features.N.0`, `aspp`)")
+
     # ------------------------------------------------------------------ forward
     def _flat_blocks(self):
         net = self.net

@@ -65,6 +65,9 @@ class DepthwiseStudent(nn.Module):
 
     # ------------------------------------------------------------------ model surgery (host side)
     def register_hint_layers(self, block_names):
+        if self.fused and len(block_names) > 0:
+            from ...engine import StudentEngine
+            StudentEngine(self.student, self.dtype).check_hint_names(block_names)   # fail at plan time, not mid-run
         if len(block_names) > 0:
             self._remove_hooks()
             self.hint_block_names = []

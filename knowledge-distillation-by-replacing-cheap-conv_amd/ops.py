@@ -318,8 +318,10 @@ def maxpool3x3s2_bwd(x, gy, out=None):
         raise ValueError("maxpool3x3s2_bwd: gy must be (N,Ho,Wo,C) of the input dtype")
     if out is None:
         out = torch.empty((N, H, W, Cc), dtype=x.dtype, device=x.device)
+    need = _lib.lib().kd_maxpool3x3s2_bwd_workspace(N, H, W, Cc)
+    ws = _ws(need, x.device)
     check(_lib.lib().kd_maxpool3x3s2_bwd(dt_of(x), _ptr(x), nhwc_ld(x), _ptr(gy), nhwc_ld(gy), _ptr(out), nhwc_ld(out), N, H, W, Cc,
-                                         stream_ptr()), "kd_maxpool3x3s2_bwd")
+                                         _ptr(ws), need, stream_ptr()), "kd_maxpool3x3s2_bwd")
     return out
 
 

@@ -101,6 +101,19 @@ def test_engine_rejects_unsupported_graphs(teacher):
         _Site("x", torch.nn.ReLU())
 
 
+def test_hint_names_validated_at_registration(teacher):
+    """cfg/cityscapes/51M_deeplab_incremental.json's hint names are accepted; a name the graph cannot capture fails when the
+    plan is applied, not when the first forward of that epoch runs."""
+    from kdcc_amd.engine import EngineError
+    with torch.device("meta"):
+        m = DepthwiseStudent(teacher, None)
+    m.register_hint_layers(["mod4.block2.convs", "mod4.block3.convs.conv1", "mod7.block1", "aspp", "aspp.features.2.0"])
+    assert m.hint_block_names[-2:] == ["aspp", "aspp.features.2.0"]
+    for bad in (["mod4.block2.bn1"], ["final"], ["aspp.features.1"]):
+        with pytest.raises(EngineError):
+            m.register_hint_layers(bad)
+
+
 def test_forgiving_state_restore():
     a, b = nn.Linear(4, 3), nn.Linear(4, 3)
     sd = {"module." + k: v.clone() + 1 for k, v in a.state_dict().items()}   # DataParallel-style checkpoint
