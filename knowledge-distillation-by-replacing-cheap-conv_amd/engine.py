@@ -88,6 +88,7 @@ class StudentEngine:
         self.probe_names = []
         self.probe_grads = {}
         self._probe_active = False   # set by run_student for differentiable calls (Function.forward runs with grad mode off)
+        self._probes = set()
 
     def _grad_like(self, p):
         if self.reducer is not None:
