@@ -147,7 +147,7 @@ def cpu_baseline(cpu_sd, model, plan, full=False):
             "sample": f"bounded sample (the bench must finish in minutes; --cpu-baseline full runs BASELINE.md section 3's 1+2 "
                       f"full-size steps): 1 KD step (teacher fwd + student fwd + hint bwd, fp32 torch CPU ops = "
                       f"oracle/net_ref.py) at {hw[0]}x{hw[1]} = {frac:.4f} of a 1024x2048 image, {dt:.2f} s; value = that "
-                      f"fraction / time (the CPU step is linear in pixels: DESIGN.md section 5)"}
+                      f"fraction / time (measured linear in pixels from this size up: 54.8 s extrapolated vs 56-58 s per full-size step, DESIGN.md section 5)"}
 
 
 def conv_traffic(plan, batch, height, width, dtype):
