@@ -46,18 +46,10 @@ def _upsample(x, size):
     return F.interpolate(x, size=size, mode="bilinear", align_corners=True)
 
 
-def forward(sd, x, hint_names=(), cheap_geom=(9, 20, 5)):
-    """Returns (logits, [hint tensors in forward-execution order], [their names])."""
-    want = set(hint_names)
-    hints, names = [], []
-
-    def note(name, t):
-        if name in want:
-            hints.append(t)
-            names.append(name)
-
+def _trunk(sd, x, note, cheap_geom):
+    """WiderResNetA2 as DeepWV3Plus / GSCNN use it (wider_resnet.py:304-356): returns (m1, m2, m3, m4, m7)."""
     x = F.conv2d(x, sd["mod1.conv1.weight"], None, 1, 1)
-    m2 = None
+    feats = {"m1": x}
     for mod_id, nblocks in enumerate(STRUCTURE):
         mname = f"mod{mod_id + 2}"
         if mod_id < 2:
@@ -86,19 +78,38 @@ def forward(sd, x, hint_names=(), cheap_geom=(9, 20, 5)):
             note(p + ".convs", out)
             note(p, out)                   # a hook on the block itself sees its return value: the same tensor
             x = out
-        if mod_id == 0:
-            m2 = x
-    # ASPP
+        feats[f"m{mod_id + 2}"] = x
+    return feats
+
+
+def _aspp_branches(sd, x, note, cheap_geom):
     size = x.shape[2:]
     img = F.adaptive_avg_pool2d(x, 1)
     img = _bnrelu(sd, "aspp.img_conv.1", F.conv2d(img, sd["aspp.img_conv.0.weight"]))
     outs = [_upsample(img, size)]
+    feats = []
     for i, r in enumerate([None, 12, 24, 36]):
         n = f"aspp.features.{i}.0"
         y = _conv(sd, n, x, 1, 0 if r is None else r, 1 if r is None else r, cheap_geom)
         note(n, y)
-        outs.append(_bnrelu(sd, f"aspp.features.{i}.1", y))
-    x = torch.cat(outs, 1)
+        feats.append(_bnrelu(sd, f"aspp.features.{i}.1", y))
+    return outs, feats
+
+
+def forward(sd, x, hint_names=(), cheap_geom=(9, 20, 5)):
+    """Returns (logits, [hint tensors in forward-execution order], [their names])."""
+    want = set(hint_names)
+    hints, names = [], []
+
+    def note(name, t):
+        if name in want:
+            hints.append(t)
+            names.append(name)
+
+    f = _trunk(sd, x, note, cheap_geom)
+    m2, x = f["m2"], f["m7"]
+    outs, feats = _aspp_branches(sd, x, note, cheap_geom)
+    x = torch.cat(outs + feats, 1)
     note("aspp", x)                        # hook on the ASPP module: the concatenated, activated branches
     dec0_up = F.conv2d(x, sd["bot_aspp.weight"])
     dec0 = torch.cat([F.conv2d(m2, sd["bot_fine.weight"]), _upsample(dec0_up, m2.shape[2:])], 1)
@@ -106,6 +117,70 @@ def forward(sd, x, hint_names=(), cheap_geom=(9, 20, 5)):
     y = _bnrelu(sd, "final.4", F.conv2d(y, sd["final.3.weight"], None, 1, 1))
     y = F.conv2d(y, sd["final.6.weight"])
     return _upsample(y, (y.shape[2] * 2, y.shape[3] * 2)), hints, names
+
+
+# ---- Gated-SCNN (models/gscnn/gscnn.py:183-325): the same trunk plus a full-resolution shape stream -----------------------
+def _bn_plain(sd, p, x):
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.0, EPS)
+
+
+def _basic_block(sd, p, x):
+    """Resnet.BasicBlock, stride 1, no downsample (models/encoders/Resnet.py:64-99)."""
+    out = F.relu(_bn_plain(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"], None, 1, 1)))
+    out = _bn_plain(sd, p + ".bn2", F.conv2d(out, sd[p + ".conv2.weight"], None, 1, 1))
+    return F.relu(out + x)
+
+
+def _gated_conv(sd, p, feat, gate):
+    """GatedSpatialConv2d.forward (models/gscnn/gate_spatial_conv.py:50-60)."""
+    z = _bn_plain(sd, p + "._gate_conv.0", torch.cat([feat, gate], 1))
+    z = F.relu(F.conv2d(z, sd[p + "._gate_conv.1.weight"], sd[p + "._gate_conv.1.bias"]))
+    a = torch.sigmoid(_bn_plain(sd, p + "._gate_conv.4", F.conv2d(z, sd[p + "._gate_conv.3.weight"], sd[p + "._gate_conv.3.bias"])))
+    return F.conv2d(feat * (a + 1), sd[p + ".weight"])
+
+
+def gscnn_forward(sd, x, canny, hint_names=(), cheap_geom=(9, 20, 5), want_aux=False):
+    """GSCNN.forward with the cv2.Canny output given as `canny` (N,1,H,W, values 0/255: gscnn.py:284-288 computes it on the
+    host from the uint8-cast input).  Returns (logits, hints, names[, aux])."""
+    want = set(hint_names)
+    hints, names = [], []
+
+    def note(name, t):
+        if name in want:
+            hints.append(t)
+            names.append(name)
+
+    size = x.shape[2:]
+    f = _trunk(sd, x, note, cheap_geom)
+    up = lambda t: _upsample(t, size)
+    s3 = up(F.conv2d(f["m3"], sd["dsn3.weight"], sd["dsn3.bias"]))
+    s4 = up(F.conv2d(f["m4"], sd["dsn4.weight"], sd["dsn4.bias"]))
+    s7 = up(F.conv2d(f["m7"], sd["dsn7.weight"], sd["dsn7.bias"]))
+    cs = up(_basic_block(sd, "res1", up(f["m1"])))
+    cs = _gated_conv(sd, "gate1", F.conv2d(cs, sd["d1.weight"], sd["d1.bias"]), s3)
+    g1 = cs
+    cs = up(_basic_block(sd, "res2", cs))
+    cs = _gated_conv(sd, "gate2", F.conv2d(cs, sd["d2.weight"], sd["d2.bias"]), s4)
+    cs = up(_basic_block(sd, "res3", cs))
+    cs = _gated_conv(sd, "gate3", F.conv2d(cs, sd["d3.weight"], sd["d3.bias"]), s7)
+    edge_out = torch.sigmoid(up(F.conv2d(cs, sd["fuse.weight"])))
+    acts = torch.sigmoid(F.conv2d(torch.cat((edge_out, canny), 1), sd["cw.weight"]))
+    # edge-aware ASPP (gscnn.py:160-181): [image pooling, edge, 1x1, rates 12/24/36]
+    m7 = f["m7"]
+    outs, feats = _aspp_branches(sd, m7, note, cheap_geom)
+    edge = _bnrelu(sd, "aspp.edge_conv.1", F.conv2d(_upsample(acts, m7.shape[2:]), sd["aspp.edge_conv.0.weight"]))
+    xa = torch.cat(outs + [edge] + feats, 1)
+    note("aspp", xa)
+    dec0_up = F.conv2d(xa, sd["bot_aspp.weight"])
+    m2 = f["m2"]
+    dec0 = torch.cat([F.conv2d(m2, sd["bot_fine.weight"]), _upsample(dec0_up, m2.shape[2:])], 1)
+    y = _bnrelu(sd, "final_seg.1", F.conv2d(dec0, sd["final_seg.0.weight"], None, 1, 1))
+    y = _bnrelu(sd, "final_seg.4", F.conv2d(y, sd["final_seg.3.weight"], None, 1, 1))
+    y = F.conv2d(y, sd["final_seg.6.weight"])
+    logits = F.interpolate(y, size=size, mode="bilinear", align_corners=False)      # gscnn.py:323: no align_corners
+    if want_aux:
+        return logits, hints, names, dict(acts=acts, aspp=xa, gate1=g1)
+    return logits, hints, names
 
 
 def kl_div_loss(s, t, T=1.0):  # losses/KLDiv.py:19-23

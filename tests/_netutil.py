@@ -53,3 +53,24 @@ def trainer_config(plan, lr, len_epoch, save_dir, n_gpu=1, dtype="fp32"):
         "weight_scheduler": {"alpha": {"value": 0.0001, "anneal_rate": 2, "max": 0}, "beta": {"value": 0.99, "anneal_rate": 0.95, "min": 0.99},
                              "gamma": {"value": 1, "anneal_rate": 1}},
     }
+
+
+def gscnn_key_inventory():
+    with open(os.path.join(_HERE, "golden", "gscnn_keys.json")) as f:
+        return json.load(f)
+
+
+def seeded_gscnn_sd(dtype=torch.float32):
+    """Seeded GSCNN(19) state dict (prefix 'gscnn.', as tools/make_golden.py:g_gscnn filled the reference's module)."""
+    sd = {}
+    for k, shape in gscnn_key_inventory().items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        sd[k] = seeded_value("gscnn." + k, torch.empty(shape)).to(dtype)
+    return sd
+
+
+def canny_stub_map(shape, seed):
+    """The seeded 0/255 edge map the GSCNN goldens were generated with in place of cv2.Canny (tools/make_golden.py)."""
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) < 0.12).float() * 255.0

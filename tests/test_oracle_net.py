@@ -88,3 +88,38 @@ def test_taylor_importance_matches_reference(golden):
         ref = g[f"gate_grad:{n}"].astype(np.float64)
         assert np.abs(gg[n].numpy() - ref).max() <= 2e-4 * np.abs(ref).max(), n
         np.testing.assert_allclose(imp[n].numpy(), g[f"imp:{n}"], rtol=2e-3, atol=1e-6 * g[f"imp:{n}"].max())
+
+
+def test_gscnn_oracle_matches_reference(golden):
+    """oracle/net_ref.gscnn_forward (trunk + shape stream + gated convs + edge-aware ASPP + decoder, Canny map given) vs the
+    reference's GSCNN(19).forward on the same seeded weights / inputs; plus the two building blocks alone."""
+    from _netutil import canny_stub_map, seeded_gscnn_sd
+    from _seeded import seeded_value
+    g = golden("gscnn")
+    torch.set_num_threads(8)
+    sd = seeded_gscnn_sd()
+    x = seeded_input(str(g["x_key"]), (2, 3, 64, 128), scale=float(g["x_scale"]))
+    canny = torch.stack([canny_stub_map((64, 128), int(s)) for s in g["canny_seeds"]]).unsqueeze(1)
+    with torch.no_grad():
+        logits, _, _, aux = net_ref.gscnn_forward(sd, x, canny, want_aux=True)
+    _cmp(logits, g, "logits")
+    _cmp(aux["acts"], g, "acts")
+    _cmp(aux["aspp"], g, "aspp")
+    _cmp(aux["gate1"], g, "gate1")
+    # building blocks
+    def blk_sd(prefix, keys):
+        return {k: seeded_value(prefix + k, torch.empty(shape)) for k, shape in keys.items()}
+    gk = {"weight": (16, 16, 1, 1), "_gate_conv.0.weight": (17,), "_gate_conv.0.bias": (17,), "_gate_conv.0.running_mean": (17,),
+          "_gate_conv.0.running_var": (17,), "_gate_conv.1.weight": (17, 17, 1, 1), "_gate_conv.1.bias": (17,),
+          "_gate_conv.3.weight": (1, 17, 1, 1), "_gate_conv.3.bias": (1,), "_gate_conv.4.weight": (1,), "_gate_conv.4.bias": (1,),
+          "_gate_conv.4.running_mean": (1,), "_gate_conv.4.running_var": (1,)}
+    gsd = {"g." + k: v for k, v in blk_sd("gscnn.blk.gate.", gk).items()}
+    y = net_ref._gated_conv(gsd, "g", seeded_input("gscnn.blk.gate.f", (2, 16, 12, 20)), seeded_input("gscnn.blk.gate.a", (2, 1, 12, 20)))
+    np.testing.assert_allclose(y.numpy(), g["blk_gate.y"], rtol=1e-4, atol=1e-5)
+    rk = {"conv1.weight": (16, 16, 3, 3), "conv2.weight": (16, 16, 3, 3)}
+    for b in ("bn1", "bn2"):
+        for s_ in ("weight", "bias", "running_mean", "running_var"):
+            rk[f"{b}.{s_}"] = (16,)
+    rsd = {"r." + k: v for k, v in blk_sd("gscnn.blk.res.", rk).items()}
+    y = net_ref._basic_block(rsd, "r", seeded_input("gscnn.blk.res.x", (2, 16, 12, 20)))
+    np.testing.assert_allclose(y.numpy(), g["blk_res.y"], rtol=1e-4, atol=1e-5)

@@ -352,6 +352,60 @@ def g_taylor(hw=(64, 128), batch=2):
     save("taylor", **out)
 
 
+def _canny_stub_map(shape, seed):
+    """The edge map handed to both sides in place of cv2.Canny's output (0 / 255, like cv2): parity of the Canny operator
+    itself is unpinned (opencv-python is not vendored); everything downstream of it is pinned by these goldens."""
+    g = torch.Generator().manual_seed(seed)
+    return ((torch.rand(shape, generator=g) < 0.12).float() * 255.0).numpy()
+
+
+def g_gscnn(hw=(64, 128), batch=2):
+    """models/gscnn/gscnn.py:183-325 GSCNN(19).forward in eval mode on seeded weights, with cv2.Canny replaced by a seeded
+    0/255 map (recorded by seed): logits + the sub-graph anchors (edge attention `acts`, ASPP output); plus the building
+    blocks alone: GatedSpatialConv2d (gate_spatial_conv.py:17-65) and Resnet.BasicBlock (encoders/Resnet.py:64-99)."""
+    import json
+    import cv2 as cv2_stub
+    from models.gscnn.gscnn import GSCNN
+    from models.gscnn import gate_spatial_conv as gsc
+    from models.encoders import Resnet
+    torch.Tensor.cuda = lambda self, *a, **k: self          # gscnn.py:288 calls .cuda() on the canny tensor
+    with torch.device("meta"):
+        m = GSCNN(num_classes=19)
+    inv = {k: list(v.shape) for k, v in m.state_dict().items()}
+    with open(os.path.join(OUT, "gscnn_keys.json"), "w") as f:
+        json.dump(inv, f)
+    net = GSCNN(num_classes=19)
+    seeded_fill_(net, "gscnn.")
+    net.eval()
+    x = seeded_input("gscnn.x", (batch, 3) + hw, scale=40.0)   # spread so that the uint8 cast is not all 0 / 1
+    calls = []
+
+    def fake_canny(img, lo, hi):
+        calls.append((img.shape, img.dtype, lo, hi))
+        return _canny_stub_map(hw, 500 + len(calls) - 1)
+    cv2_stub.Canny = fake_canny
+    keep = {}
+    net.cw.register_forward_hook(lambda mod, i, o: keep.__setitem__("cw", o.detach()))
+    net.aspp.register_forward_hook(lambda mod, i, o: keep.__setitem__("aspp", o.detach()))
+    net.gate1.register_forward_hook(lambda mod, i, o: keep.__setitem__("gate1", o.detach()))
+    with torch.no_grad():
+        y = net(x)
+    assert calls == [((hw[0], hw[1], 3), np.dtype("uint8"), 10, 100)] * batch, calls
+    out = dict(x_key="gscnn.x", x_scale=np.float64(40.0), canny_seeds=np.array([500 + i for i in range(batch)]),
+               logits=summarize(y), acts=summarize(torch.sigmoid(keep["cw"])), aspp=summarize(keep["aspp"]),
+               gate1=summarize(keep["gate1"]))
+    # building blocks
+    g = gsc.GatedSpatialConv2d(16, 16); seeded_fill_(g, "gscnn.blk.gate."); g.eval()
+    f, a = seeded_input("gscnn.blk.gate.f", (2, 16, 12, 20)), seeded_input("gscnn.blk.gate.a", (2, 1, 12, 20))
+    with torch.no_grad():
+        out["blk_gate.y"] = g(f, a).numpy()
+    b = Resnet.BasicBlock(16, 16, stride=1, downsample=None); seeded_fill_(b, "gscnn.blk.res."); b.eval()
+    xb = seeded_input("gscnn.blk.res.x", (2, 16, 12, 20))
+    with torch.no_grad():
+        out["blk_res.y"] = b(xb).numpy()
+    save("gscnn", **out)
+
+
 def trainer_config(plan, lr, len_epoch, save_dir):
     """A config dict in the reference's JSON schema (cfg/cityscapes/*.json) for a tiny synthetic run."""
     ent = [{"name": n, "epoch": 1} for n in plan]
@@ -482,7 +536,7 @@ def g_keys():
     print("wrote", path, len(inv), "entries", sum(int(np.prod(v)) for k, v in inv.items() if "num_batches" not in k and "running" not in k), "params")
 
 
-ALL = dict(keys=g_keys, confusion=g_confusion, taylor=g_taylor, student_step_full=g_student_step_full, trainer_epoch=g_trainer_epoch, classification_epoch=g_classification_epoch, losses=g_losses, dwsep=g_dwsep, resblock=g_resblock, aspp=g_aspp, ops=g_ops, radam=g_radam,
+ALL = dict(keys=g_keys, gscnn=g_gscnn, confusion=g_confusion, taylor=g_taylor, student_step_full=g_student_step_full, trainer_epoch=g_trainer_epoch, classification_epoch=g_classification_epoch, losses=g_losses, dwsep=g_dwsep, resblock=g_resblock, aspp=g_aspp, ops=g_ops, radam=g_radam,
            student_step=g_student_step)
 
 if __name__ == "__main__":
