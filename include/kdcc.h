@@ -182,6 +182,12 @@ int kd_upsample_bilinear_ac(const void *x, int32_t x_dtype, int32_t ldx, void *y
                             int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
                             kd_stream_t stream);
 
+/* The same with the align_corners flag: GSCNN's last upsample (models/gscnn/gscnn.py:323) omits align_corners, i.e.
+ * src = max((o + 0.5) * I/O - 0.5, 0). */
+int kd_upsample_bilinear(const void *x, int32_t x_dtype, int32_t ldx, void *y, int32_t y_dtype, int32_t ldy,
+                         int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, int32_t align_corners,
+                         kd_stream_t stream);
+
 /* ASPP image-pooling branch (deeplabv3.py:59-62,67-70): AdaptiveAvgPool2d(1) ->
  * 1x1 conv (w fp32 (Cout,Cin)) -> BN(eval) scale/shift -> ReLU -> broadcast
  * ("upsample" of a 1x1 map) into y[.., 0:Cout] of an NHWC view with stride ldy.
@@ -274,6 +280,32 @@ int kd_bn2d_fwd(const float *x, const float *gamma, const float *beta, float *y,
 int kd_bn2d_bwd(const float *dy, const float *x, const float *y, const float *gamma, const float *save_mean,
                 const float *save_invstd, float *dx, float *dgamma, float *dbeta, int32_t training, int32_t relu,
                 int32_t accumulate, int32_t N, int32_t C, int32_t HW, kd_stream_t stream);
+
+/* ------------------------------------------------- Gated-SCNN shape stream (BASELINE config 5)
+ * The full-resolution pieces of models/gscnn/gscnn.py:183-325 that are not MFMA-sized convolutions.
+ * kd_gated_conv: GatedSpatialConv2d.forward (models/gscnn/gate_spatial_conv.py:50-60) fused per pixel, C in {8,16,32}:
+ *     u = [feat(C); gate(1)];  z = relu(W1 u + b1);  alpha = sigmoid(w2 . z + b2);  out = Wg (feat * (alpha + 1))
+ *   params (fp32, contiguous): W1 [(C+1)*(C+1)], b1 [C+1], w2 [C+1], b2 [1], Wg [C*C] -- the module's two eval-mode
+ *   BatchNorms folded in by the caller.  feat / out: NHWC views (ld), gate: one value per pixel (stride ldg).
+ * kd_edge_attention: acts = sigmoid(cw0 * sigmoid(fuse . cs) + cw1 * canny) (gscnn.py:308-314); weights = fuse[8], cw[2].
+ * kd_edge_aspp: edge branch of the ASPP module (gscnn.py:168-171): acts (N,H,W) float resampled bilinearly (align_corners)
+ *   to Ho x Wo, then 1x1 conv 1 -> C (w), BN scale/shift, ReLU, written into a channel slice y (ld).
+ * kd_canny: the edge map the reference gets from cv2.Canny(uint8(image), low, high) on the host (gscnn.py:284-288), on the
+ *   device: Sobel 3x3 per colour channel (largest L1 magnitude wins), non-maximum suppression, hysteresis sweeps.  x: the
+ *   trainer's NCHW float batch; out: (N,H,W) float 0 / 255.  `sweeps` hysteresis sweeps run; *changed (device int) ends as
+ *   the number of blocks that still promoted a pixel in the last sweep: call kd_canny_continue until it reads 0.
+ *   Parity of this operator is unpinned (the reference's arithmetic lives in opencv-python, not vendored). */
+int kd_gated_conv(int32_t dtype, const void *feat, int32_t ldf, const void *gate, int32_t ldg, const float *params,
+                  void *out, int32_t ldo, int64_t npix, int32_t C, kd_stream_t stream);
+int kd_edge_attention(int32_t dtype, const void *cs, int32_t ldc, const float *canny, const float *weights, float *acts,
+                      int64_t npix, kd_stream_t stream);
+int kd_edge_aspp(int32_t dtype, const float *acts, int32_t H, int32_t W, const float *w, const float *scale,
+                 const float *shift, void *y, int32_t ldy, int32_t N, int32_t Ho, int32_t Wo, int32_t C, kd_stream_t stream);
+size_t kd_canny_workspace(int32_t N, int32_t H, int32_t W);
+int kd_canny(const float *x, int32_t N, int32_t H, int32_t W, int32_t low, int32_t high, int32_t sweeps, float *out,
+             int32_t *changed, void *workspace, size_t workspace_bytes, kd_stream_t stream);
+int kd_canny_continue(int32_t N, int32_t H, int32_t W, int32_t sweeps, float *out, int32_t *changed, void *workspace,
+                      size_t workspace_bytes, kd_stream_t stream);
 
 /* -------------------------------------------------------------------- losses
  * Each writes the scalar loss (fp32, device) and, when grad != NULL, the

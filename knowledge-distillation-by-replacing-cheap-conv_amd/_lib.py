@@ -81,6 +81,13 @@ _SIGS = {
     "kd_stem_conv": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "kd_maxpool3x3s2": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "kd_upsample_bilinear_ac": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "kd_upsample_bilinear": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "kd_gated_conv": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_i64, c_int, c_vp]),
+    "kd_edge_attention": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "kd_edge_aspp": (c_int, [c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "kd_canny_workspace": (c_sz, [c_int, c_int, c_int]),
+    "kd_canny": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "kd_canny_continue": (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "kd_aspp_image_pool_workspace": (c_sz, [c_int, c_int, c_int]),
     "kd_aspp_image_pool": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_vp, c_sz, c_vp]),

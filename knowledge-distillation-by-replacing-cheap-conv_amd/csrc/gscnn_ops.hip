@@ -1,0 +1,320 @@
+// Gated-SCNN shape stream (BASELINE config 5; reference models/gscnn/gscnn.py:183-325): the full-resolution pieces that are
+// not convolutions the MFMA kernels can take -- 8/16/32-channel per-pixel algebra at 2 M pixels per image, all HBM-bound:
+//   kd_gated_conv      GatedSpatialConv2d.forward (models/gscnn/gate_spatial_conv.py:50-60), one fused pass per pixel
+//   kd_edge_attention  fuse (8 -> 1) -> sigmoid -> cat with the Canny map -> cw (2 -> 1) -> sigmoid   (gscnn.py:308-314)
+//   kd_edge_aspp       edge branch of the ASPP module: bilinear resample + 1x1 (1 -> 256) + BN + ReLU    (gscnn.py:168-171)
+//   kd_canny           the Canny edge map the reference computes on the host with cv2.Canny(uint8 image, 10, 100)
+//                      (gscnn.py:284-288): Sobel 3x3, L1 magnitude, non-maximum suppression, hysteresis.  Parity of this
+//                      one operator is UNPINNED (opencv-python is not vendored); it follows the published algorithm.
+#include "kd_common.h"
+
+namespace {
+
+inline bool ok_dt(int d) { return d == KD_F32 || d == KD_BF16; }
+inline int blocks_for(long long total, int cap = 1 << 20)
+{
+    long long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// ---- gated spatial conv -----------------------------------------------------------------------------------------------------
+// per pixel, with u = [feat(C); gate(1)]:
+//   z = relu(W1 u + b1)        (C+1 hidden units; the leading eval-BN is folded into W1 / b1 by the caller)
+//   alpha = sigmoid(w2 . z + b2)   (trailing BN(1) folded into w2 / b2)
+//   out = Wg (feat * (alpha + 1))
+// params (fp32): W1 [(C+1)][(C+1)], b1 [C+1], w2 [C+1], b2 [1], Wg [C][C], in this order.
+template <typename T, int C>
+__global__ __launch_bounds__(256) void gated_conv_kernel(const T *__restrict__ feat, int ldf, const T *__restrict__ gate, int ldg,
+                                                         const float *__restrict__ prm, T *__restrict__ out, int ldo, long long npix)
+{
+    constexpr int H = C + 1;
+    __shared__ float sW1[H * H], sb1[H], sw2[H], sWg[C * C];
+    __shared__ float sb2;
+    for (int i = threadIdx.x; i < H * H; i += 256) sW1[i] = prm[i];
+    for (int i = threadIdx.x; i < H; i += 256) { sb1[i] = prm[H * H + i]; sw2[i] = prm[H * H + H + i]; }
+    if (threadIdx.x == 0) sb2 = prm[H * H + 2 * H];
+    for (int i = threadIdx.x; i < C * C; i += 256) sWg[i] = prm[H * H + 2 * H + 1 + i];
+    __syncthreads();
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
+        float u[H];
+#pragma unroll
+        for (int q = 0; q < C / 8; ++q) {
+            float v[8];
+            ld8(feat + p * ldf + q * 8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[q * 8 + e] = v[e];
+        }
+        u[C] = Elem<T>::ld(gate + p * ldg);
+        float a = sb2;
+#pragma unroll 1
+        for (int j = 0; j < H; ++j) {
+            float z = sb1[j];
+#pragma unroll
+            for (int i = 0; i < H; ++i) z = fmaf(sW1[j * H + i], u[i], z);
+            a = fmaf(sw2[j], fmaxf(z, 0.f), a);
+        }
+        const float k = 1.f / (1.f + __expf(-a)) + 1.f;
+#pragma unroll
+        for (int i = 0; i < C; ++i) u[i] *= k;
+#pragma unroll
+        for (int q = 0; q < C / 8; ++q) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < C; ++i) s = fmaf(sWg[(q * 8 + e) * C + i], u[i], s);
+                v[e] = s;
+            }
+            st8(out + p * ldo + q * 8, v);
+        }
+    }
+}
+
+// ---- edge attention -----------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void edge_attention_kernel(const T *__restrict__ cs, int ldc, const float *__restrict__ canny,
+                                                             const float *__restrict__ w /* fuse[8], cw[2] */, float *__restrict__ acts,
+                                                             long long npix)
+{
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
+        float v[8];
+        ld8(cs + p * ldc, v);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = fmaf(w[e], v[e], s);
+        const float edge = 1.f / (1.f + __expf(-s));
+        const float a = w[8] * edge + w[9] * canny[p];
+        acts[p] = 1.f / (1.f + __expf(-a));
+    }
+}
+
+// ---- edge branch of the ASPP module -----------------------------------------------------------------------------------------
+// y[n,ho,wo,c] = relu(bilinear_ac(acts)[n,ho,wo] * w[c] * scale[c] + shift[c]); acts (N,H,W) float, y a channel slice (ld)
+template <typename T>
+__global__ __launch_bounds__(256) void edge_aspp_kernel(const float *__restrict__ acts, int H, int W, const float *__restrict__ w,
+                                                        const float *__restrict__ scale, const float *__restrict__ shift,
+                                                        T *__restrict__ y, int ldy, int N, int Ho, int Wo, int C8, float sh, float sw)
+{
+    const long long total = (long long)N * Ho * Wo * C8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cq = (int)(i % C8);
+        long long r = i / C8;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho), n = (int)(r / Ho);
+        const float fh = ho * sh, fw = wo * sw;
+        int h0 = (int)fh; h0 = h0 > H - 1 ? H - 1 : h0;
+        int w0 = (int)fw; w0 = w0 > W - 1 ? W - 1 : w0;
+        const int h1 = h0 + 1 < H ? h0 + 1 : H - 1, w1 = w0 + 1 < W ? w0 + 1 : W - 1;
+        const float ah = fh - h0, aw = fw - w0;
+        const float *b = acts + (size_t)n * H * W;
+        const float e = (1.f - ah) * ((1.f - aw) * b[(size_t)h0 * W + w0] + aw * b[(size_t)h0 * W + w1]) +
+                        ah * ((1.f - aw) * b[(size_t)h1 * W + w0] + aw * b[(size_t)h1 * W + w1]);
+        float wv[8], sc[8], sf[8], o[8];
+        ld8(w + cq * 8, wv); ld8(scale + cq * 8, sc); ld8(shift + cq * 8, sf);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = fmaxf(fmaf(e * wv[q], sc[q], sf[q]), 0.f);
+        st8(y + (((size_t)n * Ho + ho) * Wo + wo) * ldy + cq * 8, o);
+    }
+}
+
+// ---- Canny ----------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int u8_of(float v)
+{
+    // numpy's float -> uint8 cast as the reference applies it to the normalised image (gscnn.py:284): truncation toward zero,
+    // modulo 256 for out-of-range values
+    return (int)((unsigned int)(int)v & 0xffu);
+}
+__device__ __forceinline__ int px(const float *img, int H, int W, int y, int x)
+{
+    y = y < 0 ? 0 : (y >= H ? H - 1 : y);   // BORDER_REPLICATE
+    x = x < 0 ? 0 : (x >= W ? W - 1 : x);
+    return u8_of(img[(size_t)y * W + x]);
+}
+
+// gradient (Sobel 3x3 on every colour channel, keep the channel with the largest L1 magnitude): dx, dy as shorts, mag as int
+__global__ __launch_bounds__(256) void canny_grad_kernel(const float *__restrict__ x, int N, int H, int W, short2 *__restrict__ grad,
+                                                         int *__restrict__ mag)
+{
+    const long long total = (long long)N * H * W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int xx = (int)(i % W);
+        const long long r = i / W;
+        const int yy = (int)(r % H), n = (int)(r / H);
+        int bx = 0, by = 0, bm = -1;
+        for (int c = 0; c < 3; ++c) {
+            const float *im = x + ((size_t)n * 3 + c) * H * W;
+            const int a00 = px(im, H, W, yy - 1, xx - 1), a01 = px(im, H, W, yy - 1, xx), a02 = px(im, H, W, yy - 1, xx + 1);
+            const int a10 = px(im, H, W, yy, xx - 1), a12 = px(im, H, W, yy, xx + 1);
+            const int a20 = px(im, H, W, yy + 1, xx - 1), a21 = px(im, H, W, yy + 1, xx), a22 = px(im, H, W, yy + 1, xx + 1);
+            const int gx = (a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20);
+            const int gy = (a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02);
+            const int m = abs(gx) + abs(gy);
+            if (m > bm) { bm = m; bx = gx; by = gy; }
+        }
+        grad[i] = make_short2((short)bx, (short)by);
+        mag[i] = bm;
+    }
+}
+
+// non-maximum suppression + double threshold: state 0 = no edge, 1 = weak (candidate), 2 = strong
+__global__ __launch_bounds__(256) void canny_nms_kernel(const short2 *__restrict__ grad, const int *__restrict__ mag, int N, int H, int W,
+                                                        int low, int high, unsigned char *__restrict__ state)
+{
+    const long long total = (long long)N * H * W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int xx = (int)(i % W);
+        const long long r = i / W;
+        const int yy = (int)(r % H);
+        const int *mg = mag + (i - (long long)yy * W - xx);
+        auto M = [&](int y, int x) { return (y < 0 || y >= H || x < 0 || x >= W) ? 0 : mg[(size_t)y * W + x]; };
+        const int m = M(yy, xx);
+        unsigned char st = 0;
+        if (m > low) {
+            const int xs = grad[i].x, ys = grad[i].y;
+            const int ax = abs(xs), ay = abs(ys) << 15;
+            const int tg22x = ax * 13573;                       // tan(22.5 deg) * 2^15
+            bool keep;
+            if (ay < tg22x) keep = m > M(yy, xx - 1) && m >= M(yy, xx + 1);
+            else {
+                const int tg67x = tg22x + (ax << 16);
+                if (ay > tg67x) keep = m > M(yy - 1, xx) && m >= M(yy + 1, xx);
+                else {
+                    const int s = (xs ^ ys) < 0 ? -1 : 1;
+                    keep = m > M(yy - 1, xx - s) && m > M(yy + 1, xx + s);
+                }
+            }
+            if (keep) st = m > high ? 2 : 1;
+        }
+        state[i] = st;
+    }
+}
+
+// one hysteresis sweep: a weak pixel with a strong 8-neighbour becomes strong; *changed counts promotions
+__global__ __launch_bounds__(256) void canny_hyst_kernel(unsigned char *__restrict__ state, int N, int H, int W, int *__restrict__ changed)
+{
+    const long long total = (long long)N * H * W;
+    int local = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        if (state[i] != 1) continue;
+        const int xx = (int)(i % W);
+        const long long r = i / W;
+        const int yy = (int)(r % H);
+        unsigned char *s = state + (i - (long long)yy * W - xx);
+        bool strong = false;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int y = yy + dy, x = xx + dx;
+                if ((dy || dx) && y >= 0 && y < H && x >= 0 && x < W && s[(size_t)y * W + x] == 2) strong = true;
+            }
+        if (strong) { state[i] = 2; local = 1; }   // racing promotions only speed the fixed point up; the result is unique
+    }
+    if (local) atomicAdd(changed, 1);
+}
+
+__global__ __launch_bounds__(256) void canny_finish_kernel(const unsigned char *__restrict__ state, float *__restrict__ out, long long total)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+        out[i] = state[i] == 2 ? 255.f : 0.f;
+}
+
+}  // namespace
+
+extern "C" int kd_gated_conv(int32_t dtype, const void *feat, int32_t ldf, const void *gate, int32_t ldg, const float *params,
+                             void *out, int32_t ldo, int64_t npix, int32_t C, kd_stream_t stream)
+{
+    KD_REQUIRE(feat && gate && params && out && npix > 0, KD_ERR_INVALID, "kd_gated_conv: bad argument");
+    KD_REQUIRE(ok_dt(dtype), KD_ERR_INVALID, "kd_gated_conv: bad dtype");
+    KD_REQUIRE(C == 8 || C == 16 || C == 32, KD_ERR_UNSUPPORTED, "kd_gated_conv: C must be 8, 16 or 32 (got %d)", C);
+    const int es = kd_elem_size(dtype);
+    KD_REQUIRE(kd_aligned16(feat) && kd_aligned16(out) && (ldf * es) % 16 == 0 && (ldo * es) % 16 == 0, KD_ERR_INVALID,
+               "kd_gated_conv: 16-B aligned feature views required");
+    const int nb = blocks_for(npix, 65536);
+    hipStream_t s = (hipStream_t)stream;
+#define KD_GC(T, CC) hipLaunchKernelGGL((gated_conv_kernel<T, CC>), dim3(nb), dim3(256), 0, s, (const T *)feat, ldf, (const T *)gate, ldg, params, (T *)out, ldo, (long long)npix)
+    if (dtype == KD_BF16) { if (C == 8) KD_GC(bf16_t, 8); else if (C == 16) KD_GC(bf16_t, 16); else KD_GC(bf16_t, 32); }
+    else { if (C == 8) KD_GC(float, 8); else if (C == 16) KD_GC(float, 16); else KD_GC(float, 32); }
+#undef KD_GC
+    KD_CHECK_LAUNCH("kd_gated_conv");
+    return KD_OK;
+}
+
+extern "C" int kd_edge_attention(int32_t dtype, const void *cs, int32_t ldc, const float *canny, const float *weights, float *acts,
+                                 int64_t npix, kd_stream_t stream)
+{
+    KD_REQUIRE(cs && canny && weights && acts && npix > 0, KD_ERR_INVALID, "kd_edge_attention: bad argument");
+    KD_REQUIRE(ok_dt(dtype), KD_ERR_INVALID, "kd_edge_attention: bad dtype");
+    KD_REQUIRE(kd_aligned16(cs) && (ldc * kd_elem_size(dtype)) % 16 == 0, KD_ERR_INVALID, "kd_edge_attention: 16-B aligned view required");
+    const int nb = blocks_for(npix, 65536);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == KD_BF16) hipLaunchKernelGGL(edge_attention_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t *)cs, ldc, canny, weights, acts, (long long)npix);
+    else hipLaunchKernelGGL(edge_attention_kernel<float>, dim3(nb), dim3(256), 0, s, (const float *)cs, ldc, canny, weights, acts, (long long)npix);
+    KD_CHECK_LAUNCH("kd_edge_attention");
+    return KD_OK;
+}
+
+extern "C" int kd_edge_aspp(int32_t dtype, const float *acts, int32_t H, int32_t W, const float *w, const float *scale, const float *shift,
+                            void *y, int32_t ldy, int32_t N, int32_t Ho, int32_t Wo, int32_t C, kd_stream_t stream)
+{
+    KD_REQUIRE(acts && w && scale && shift && y && N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0, KD_ERR_INVALID, "kd_edge_aspp: bad argument");
+    KD_REQUIRE(ok_dt(dtype), KD_ERR_INVALID, "kd_edge_aspp: bad dtype");
+    KD_REQUIRE(C % 8 == 0 && kd_aligned16(y) && (ldy * kd_elem_size(dtype)) % 16 == 0 && kd_aligned16(w) && kd_aligned16(scale) && kd_aligned16(shift),
+               KD_ERR_INVALID, "kd_edge_aspp: C %% 8 and 16-B alignment required");
+    const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const int nb = blocks_for((long long)N * Ho * Wo * (C / 8), 65536);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == KD_BF16) hipLaunchKernelGGL(edge_aspp_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, acts, H, W, w, scale, shift, (bf16_t *)y, ldy, N, Ho, Wo, C / 8, sh, sw);
+    else hipLaunchKernelGGL(edge_aspp_kernel<float>, dim3(nb), dim3(256), 0, s, acts, H, W, w, scale, shift, (float *)y, ldy, N, Ho, Wo, C / 8, sh, sw);
+    KD_CHECK_LAUNCH("kd_edge_aspp");
+    return KD_OK;
+}
+
+extern "C" size_t kd_canny_workspace(int32_t N, int32_t H, int32_t W)
+{
+    const size_t n = (size_t)N * H * W;
+    return n * (sizeof(short2) + sizeof(int) + 1) + 256;
+}
+
+// x: (N,3,H,W) float NCHW (the trainer's batch); out: (N,H,W) float, 0 / 255.  `changed` is a device int the caller reads
+// back between sweeps: kd_canny runs the gradient / NMS stages and `sweeps` hysteresis sweeps, adding the number of blocks
+// that promoted a pixel in the LAST sweep to *changed (zeroed first); call kd_canny_continue until it reads 0.
+extern "C" int kd_canny(const float *x, int32_t N, int32_t H, int32_t W, int32_t low, int32_t high, int32_t sweeps, float *out,
+                        int32_t *changed, void *workspace, size_t workspace_bytes, kd_stream_t stream)
+{
+    KD_REQUIRE(x && out && changed && workspace && N > 0 && H > 0 && W > 0 && sweeps >= 0, KD_ERR_INVALID, "kd_canny: bad argument");
+    KD_REQUIRE(workspace_bytes >= kd_canny_workspace(N, H, W), KD_ERR_WORKSPACE, "kd_canny: workspace too small");
+    const long long n = (long long)N * H * W;
+    short2 *grad = (short2 *)workspace;
+    int *mag = (int *)(grad + n);
+    unsigned char *state = (unsigned char *)(mag + n);
+    const int nb = blocks_for(n, 65536);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(canny_grad_kernel, dim3(nb), dim3(256), 0, s, x, N, H, W, grad, mag);
+    hipLaunchKernelGGL(canny_nms_kernel, dim3(nb), dim3(256), 0, s, (const short2 *)grad, (const int *)mag, N, H, W, low, high, state);
+    KD_CHECK_LAUNCH("kd_canny");
+    for (int i = 0; i < sweeps; ++i) {
+        if (hipMemsetAsync(changed, 0, sizeof(int), s) != hipSuccess) { kd_set_error("kd_canny: memset failed"); return KD_ERR_HIP; }
+        hipLaunchKernelGGL(canny_hyst_kernel, dim3(nb), dim3(256), 0, s, state, N, H, W, changed);
+    }
+    hipLaunchKernelGGL(canny_finish_kernel, dim3(nb), dim3(256), 0, s, (const unsigned char *)state, out, n);
+    KD_CHECK_LAUNCH("kd_canny(hysteresis)");
+    return KD_OK;
+}
+
+extern "C" int kd_canny_continue(int32_t N, int32_t H, int32_t W, int32_t sweeps, float *out, int32_t *changed, void *workspace,
+                                 size_t workspace_bytes, kd_stream_t stream)
+{
+    KD_REQUIRE(out && changed && workspace && N > 0 && H > 0 && W > 0 && sweeps > 0, KD_ERR_INVALID, "kd_canny_continue: bad argument");
+    KD_REQUIRE(workspace_bytes >= kd_canny_workspace(N, H, W), KD_ERR_WORKSPACE, "kd_canny_continue: workspace too small");
+    const long long n = (long long)N * H * W;
+    unsigned char *state = (unsigned char *)workspace + n * (sizeof(short2) + sizeof(int));
+    const int nb = blocks_for(n, 65536);
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < sweeps; ++i) {
+        if (hipMemsetAsync(changed, 0, sizeof(int), s) != hipSuccess) { kd_set_error("kd_canny_continue: memset failed"); return KD_ERR_HIP; }
+        hipLaunchKernelGGL(canny_hyst_kernel, dim3(nb), dim3(256), 0, s, state, N, H, W, changed);
+    }
+    hipLaunchKernelGGL(canny_finish_kernel, dim3(nb), dim3(256), 0, s, (const unsigned char *)state, out, n);
+    KD_CHECK_LAUNCH("kd_canny_continue");
+    return KD_OK;
+}

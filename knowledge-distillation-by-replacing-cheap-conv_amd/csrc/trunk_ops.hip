@@ -198,14 +198,15 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T *__restrict__ x, i
 // weights are block-uniform and the only per-thread division is a 32-bit one by C/VEC.
 template <typename TI, typename TO, int VEC>
 __global__ __launch_bounds__(256) void upsample_kernel(const TI *__restrict__ x, int ldx, TO *__restrict__ y, int ldy, int N,
-                                                       int H, int W, int C, int Ho, int Wo, float sh, float sw)
+                                                       int H, int W, int C, int Ho, int Wo, float sh, float sw, float oh, float ow)
 {
     const unsigned cv = (unsigned)C / VEC;
     const unsigned e = blockIdx.x * 256u + threadIdx.x;
     if (e >= (unsigned)Wo * cv) return;
     const unsigned wo = e / cv, cq = e - wo * cv;
     const int ho = blockIdx.y, n = blockIdx.z;
-    const float fh = ho * sh, fw = wo * sw;
+    // align_corners=True: src = o * (I-1)/(O-1) (oh = ow = 0); align_corners=False: src = max((o + 0.5) * I/O - 0.5, 0)
+    const float fh = fmaxf(ho * sh + oh, 0.f), fw = fmaxf(wo * sw + ow, 0.f);
     int h0 = (int)fh; h0 = h0 > H - 1 ? H - 1 : h0;
     int w0 = (int)fw; w0 = w0 > W - 1 ? W - 1 : w0;
     const int h1 = h0 + 1 < H ? h0 + 1 : H - 1, w1 = w0 + 1 < W ? w0 + 1 : W - 1;
@@ -380,25 +381,40 @@ extern "C" int kd_maxpool3x3s2(int32_t dtype, const void *x, int32_t ldx, void *
 
 template <typename TI, typename TO>
 static void launch_up(const void *x, int ldx, void *y, int ldy, int N, int H, int W, int C, int Ho, int Wo, bool vec,
-                      hipStream_t s)
+                      hipStream_t s, bool align = true)
 {
-    const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
-    const float sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+    float sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    float oh = 0.f, ow = 0.f;
+    if (!align) {
+        sh = (float)H / (float)Ho; sw = (float)W / (float)Wo;
+        oh = 0.5f * sh - 0.5f; ow = 0.5f * sw - 0.5f;
+    }
     if (vec) {
         const dim3 g((unsigned)((Wo * (C / 8) + 255) / 256), (unsigned)Ho, (unsigned)N);
         hipLaunchKernelGGL((upsample_kernel<TI, TO, 8>), g, dim3(256), 0, s, (const TI *)x, ldx, (TO *)y, ldy, N, H, W, C, Ho, Wo,
-                           sh, sw);
+                           sh, sw, oh, ow);
     } else {
         const dim3 g((unsigned)((Wo * C + 255) / 256), (unsigned)Ho, (unsigned)N);
         hipLaunchKernelGGL((upsample_kernel<TI, TO, 1>), g, dim3(256), 0, s, (const TI *)x, ldx, (TO *)y, ldy, N, H, W, C, Ho, Wo,
-                           sh, sw);
+                           sh, sw, oh, ow);
     }
 }
+
+extern "C" int kd_upsample_bilinear(const void *x, int32_t x_dtype, int32_t ldx, void *y, int32_t y_dtype, int32_t ldy, int32_t N,
+                                    int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, int32_t align_corners, kd_stream_t stream);
 
 extern "C" int kd_upsample_bilinear_ac(const void *x, int32_t x_dtype, int32_t ldx, void *y, int32_t y_dtype, int32_t ldy,
                                        int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
                                        kd_stream_t stream)
 {
+    return kd_upsample_bilinear(x, x_dtype, ldx, y, y_dtype, ldy, N, H, W, C, Ho, Wo, 1, stream);
+}
+
+extern "C" int kd_upsample_bilinear(const void *x, int32_t x_dtype, int32_t ldx, void *y, int32_t y_dtype, int32_t ldy, int32_t N,
+                                    int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, int32_t align_corners, kd_stream_t stream)
+{
+    const bool al = align_corners != 0;
     KD_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0, KD_ERR_INVALID,
                "kd_upsample_bilinear_ac: bad argument");
     KD_REQUIRE((x_dtype == KD_F32 || x_dtype == KD_BF16) && (y_dtype == KD_F32 || y_dtype == KD_BF16), KD_ERR_INVALID,
@@ -406,10 +422,10 @@ extern "C" int kd_upsample_bilinear_ac(const void *x, int32_t x_dtype, int32_t l
     const bool vec = C % 8 == 0 && kd_aligned16(x) && kd_aligned16(y) && (ldx * kd_elem_size(x_dtype)) % 16 == 0 &&
                      (ldy * kd_elem_size(y_dtype)) % 16 == 0;
     hipStream_t s = (hipStream_t)stream;
-    if (x_dtype == KD_BF16 && y_dtype == KD_BF16) launch_up<bf16_t, bf16_t>(x, ldx, y, ldy, N, H, W, C, Ho, Wo, vec, s);
-    else if (x_dtype == KD_BF16) launch_up<bf16_t, float>(x, ldx, y, ldy, N, H, W, C, Ho, Wo, vec, s);
-    else if (y_dtype == KD_BF16) launch_up<float, bf16_t>(x, ldx, y, ldy, N, H, W, C, Ho, Wo, vec, s);
-    else launch_up<float, float>(x, ldx, y, ldy, N, H, W, C, Ho, Wo, vec, s);
+    if (x_dtype == KD_BF16 && y_dtype == KD_BF16) launch_up<bf16_t, bf16_t>(x, ldx, y, ldy, N, H, W, C, Ho, Wo, vec, s, al);
+    else if (x_dtype == KD_BF16) launch_up<bf16_t, float>(x, ldx, y, ldy, N, H, W, C, Ho, Wo, vec, s, al);
+    else if (y_dtype == KD_BF16) launch_up<float, bf16_t>(x, ldx, y, ldy, N, H, W, C, Ho, Wo, vec, s, al);
+    else launch_up<float, float>(x, ldx, y, ldy, N, H, W, C, Ho, Wo, vec, s, al);
     KD_CHECK_LAUNCH("kd_upsample_bilinear_ac");
     return KD_OK;
 }

@@ -89,6 +89,17 @@ class StudentEngine:
         self.probe_grads = {}
         self._probe_active = False   # set by run_student for differentiable calls (Function.forward runs with grad mode off)
         self._probes = set()
+        # Gated-SCNN (models/gscnn.py): the same trunk + a full-resolution shape stream whose edge attention feeds one more
+        # ASPP branch; decoder `final_seg`, last upsample without align_corners
+        self.is_gscnn = net is not None and hasattr(net, "gate1")
+        self._gate_prm = {}
+
+    def _final(self):
+        return self.net.final_seg if self.is_gscnn else self.net.final
+
+    def _aspp_lead(self, aspp):
+        """Leading non-conv slices of the ASPP concat: image pooling (+ the edge branch of GSCNN)."""
+        return 2 if hasattr(aspp, "edge_conv") else 1
 
     def _grad_like(self, p):
         if self.reducer is not None:
@@ -157,7 +168,9 @@ class StudentEngine:
         """Raise at registration time (epoch 1 / plan time, not 15 epochs into a run) when a hint name is not one the fused
         graph can capture: a conv site `modN.blockM.convs.convK`, a block's `modN.blockM.convs` or `modN.blockM` (both the
         block output), an ASPP branch conv `aspp.features.N.0`, or `aspp` (the module output)."""
-        ok = {"aspp"} | {f"aspp.features.{i}.0" for i in range(len(self.net.aspp.features))}
+        ok = {f"aspp.features.{i}.0" for i in range(len(self.net.aspp.features))}
+        if not self.is_gscnn:
+            ok.add("aspp")   # (GSCNN's `aspp` output carries the edge branch, whose gradient re-enters the trunk: not built)
         for name, blk in self._flat_blocks():
             ok.add(name)
             ok.add(f"{name}.convs")
@@ -217,9 +230,14 @@ class StudentEngine:
             is_last = bi + 1 == len(flat)
             nxt = None if (is_last or last_of_mod2) else flat[bi + 1][1]
             need_raw = is_last or last_of_mod2 or (nxt is not None and not hasattr(nxt, "proj_conv"))
+            mod_end = is_last or flat[bi + 1][0].split(".")[0] != name.split(".")[0]
+            if self.is_gscnn and mod_end and name.split(".")[0] in ("mod3", "mod4"):
+                need_raw = True   # dsn3 / dsn4 read the raw module outputs
             x_raw, a, rg, rec = self._block_fwd(name, blk, x_raw, a, rg, nxt.bn1 if nxt is not None else None, need_raw,
                                                 want, note_hint, bi)
             tape["blocks"].append(rec)
+            if self.is_gscnn and mod_end:
+                tape.setdefault("mods", {})[name.split(".")[0]] = x_raw
             if last_of_mod2:
                 m2 = x_raw
                 sc, sh = self._bn_fold(flat[bi + 1][1].bn1)
@@ -228,6 +246,8 @@ class StudentEngine:
                 x_raw = None
         x7, rg7 = x_raw, rg
 
+        if self.is_gscnn:
+            tape["acts"] = self._shape_stream(xin, s, tape["mods"]["mod3"], tape["mods"]["mod4"], x7)
         cat, rg_cat = self._aspp_fwd(net.aspp, x7, rg7, want, note_hint, tape)
         logits = self._decoder_fwd(cat, rg_cat, m2, tape["pools"]["pool3"]["rg"], (H, W), tape)
 
@@ -243,10 +263,14 @@ class StudentEngine:
         N, h8, w8, _ = x7.shape
         red = aspp.img_conv[0].out_channels
         nb = len(aspp.features)
-        cat = self._new(N, h8, w8, red * (nb + 1))
+        lead = self._aspp_lead(aspp)
+        cat = self._new(N, h8, w8, red * (nb + lead))
         sc, sh = self._bn_fold(aspp.img_conv[1])
         ops.aspp_image_pool(x7, aspp.img_conv[0].weight.detach(), sc, sh, cat[..., 0:red])
-        arec = {"x7": x7, "rg7": rg7, "branches": [], "cat": cat, "red": red, "mod": aspp}
+        if lead == 2:   # edge branch: resampled edge attention -> 1x1 (1 -> red) -> BN -> ReLU
+            sc, sh = self._bn_fold(aspp.edge_conv[1])
+            ops.edge_aspp(tape["acts"], aspp.edge_conv[0].weight.detach().float().reshape(-1).contiguous(), sc, sh, cat[..., red:2 * red])
+        arec = {"x7": x7, "rg7": rg7, "branches": [], "cat": cat, "red": red, "mod": aspp, "lead": lead}
         rg_cat = rg7 or _is_trainable(aspp.img_conv)
         for i, br in enumerate(aspp.features):
             site = _Site(f"aspp.features.{i}.0", br[0])
@@ -254,7 +278,7 @@ class StudentEngine:
             hinted = site.name in want
             probed = site.name in self._probes
             raw = self._new(N, h8, w8, red) if (hinted or probed) else None
-            out = cat[..., red * (i + 1):red * (i + 2)]
+            out = cat[..., red * (i + lead):red * (i + lead + 1)]
             mid = None
             if site.cheap:
                 mid = ops.dwconv(x7, self._w_dw(site.mod.separable_conv, False), site.k, site.pad, site.dil)
@@ -272,6 +296,82 @@ class StudentEngine:
         tape["aspp"] = arec
         return cat, rg_cat
 
+    # ------------------------------------------------------------------ Gated-SCNN shape stream (frozen: forward only)
+    def _w_bn_folded(self, conv, bn, cpad):
+        """3x3 conv followed by eval-mode BN, as one packed operand: w * scale[co], zero-padded to cpad x cpad channels (the
+        shape stream's 32 / 16 channels live in 64-channel buffers so the MFMA kernels can take them), + the padded shift."""
+        def make():
+            scale, shift = self._bn_fold(bn)
+            w = conv.weight.detach().float() * scale.view(-1, 1, 1, 1)
+            wp = torch.zeros((cpad, cpad) + tuple(w.shape[2:]), dtype=torch.float32, device=w.device)
+            wp[:w.shape[0], :w.shape[1]] = w
+            sp = torch.zeros(cpad, dtype=torch.float32, device=w.device)
+            sp[:shift.numel()] = shift
+            return (ops.pack_conv_weight(wp, self.dtype, KD_PACK_FWD), sp)
+        return self._packed(conv.weight, ("bnfold", self.dtype, cpad, id(bn)), make)
+
+    def _basic_block(self, blk, x, cpad=64):
+        """Resnet.BasicBlock (encoders/Resnet.py:64-99) on a cpad-channel buffer: two row-buffer 3x3 convs, BN folded into the
+        weights, bias + ReLU (+ identity shortcut) in the epilogues."""
+        for p in blk.parameters():
+            if p.requires_grad:
+                raise EngineError("trainable shape-stream parameters are not supported (the GSCNN plan keeps them frozen)")
+        N, H, W, _ = x.shape
+        w1, s1 = self._w_bn_folded(blk.conv1, blk.bn1, cpad)
+        w2, s2 = self._w_bn_folded(blk.conv2, blk.bn2, cpad)
+        t = self._new(N, H, W, cpad)
+        ops.conv2d(x, w1, 1, 1, 1, out_act=t, act_shift=s1, act_relu=True)
+        y = self._new(N, H, W, cpad)
+        ops.conv2d(t, w2, 1, 1, 1, res_pre=x, out_act=y, act_shift=s2, act_relu=True)
+        return y
+
+    def _gate_params(self, gate):
+        """GatedSpatialConv2d -> the packed fp32 vector kd_gated_conv takes (both eval-mode BNs folded)."""
+        ent = self._gate_prm.get(id(gate))
+        if ent is not None and ent[0] is gate:
+            return ent[1]
+        bn0, c1, _, c2, bn4, _ = gate._gate_conv
+        hdim = c1.in_channels
+        s0, t0 = self._bn_fold(bn0)
+        s4, t4 = self._bn_fold(bn4)
+        w1 = c1.weight.detach().float().view(hdim, hdim)
+        prm = torch.cat([(w1 * s0.view(1, -1)).reshape(-1), c1.bias.detach().float() + w1 @ t0,
+                         c2.weight.detach().float().view(hdim) * s4, c2.bias.detach().float() * s4 + t4,
+                         gate.weight.detach().float().reshape(-1)]).contiguous()
+        self._gate_prm[id(gate)] = (gate, prm)
+        return prm
+
+    def _shape_stream(self, x_nchw, m1, m3, m4, m7):
+        """gscnn.py:269-314: edge attention `acts` (N,H,W) fp32 from the stem output, the three side outputs and the Canny
+        prior.  The reference's interpolations of full-resolution tensors to the full resolution are identities."""
+        net = self.net
+        N, H, W, _ = m1.shape
+
+        def side(conv, t):   # dsnK: 1x1 (C -> 1) + bias, then bilinear (align_corners) to the input size
+            o = self._new(N, t.shape[1], t.shape[2], 1)
+            ops.conv2d(t, self._w_fwd(conv), out_act=o, act_shift=conv.bias.detach().float().contiguous())
+            return ops.upsample_bilinear_ac(o, (H, W))
+
+        def squeeze(conv, x, cout):   # dK: 1x1 + bias into the first `cout` channels of a zeroed 64-channel buffer
+            buf = self._new(N, H, W, 64, zero=True)
+            ops.conv2d(x, self._w_fwd(conv, cin_pad=64 if conv.in_channels < 64 else None), out_act=buf[..., :cout],
+                       act_shift=conv.bias.detach().float().contiguous())
+            return buf
+
+        def gated(gate, buf, side_map, c):
+            out = self._new(N, H, W, 64, zero=True)
+            ops.gated_conv(buf, side_map, self._gate_params(gate), c, out=out[..., :c])
+            return out
+
+        s3, s4, s7 = side(net.dsn3, m3), side(net.dsn4, m4), side(net.dsn7, m7)
+        cs = gated(net.gate1, squeeze(net.d1, self._basic_block(net.res1, m1), 32), s3, 32)
+        cs = gated(net.gate2, squeeze(net.d2, self._basic_block(net.res2, cs), 16), s4, 16)
+        cs = gated(net.gate3, squeeze(net.d3, self._basic_block(net.res3, cs), 8), s7, 8)
+        fn = getattr(net, "canny_fn", None)   # plug point for a caller-supplied edge prior (tests feed the goldens' map)
+        canny = ops.canny(x_nchw) if fn is None else fn(x_nchw).reshape(N, H, W).float().contiguous()
+        w = torch.cat([net.fuse.weight.detach().float().reshape(-1), net.cw.weight.detach().float().reshape(-1)]).contiguous()
+        return ops.edge_attention(cs, canny, w)
+
     def _decoder_fwd(self, cat, rg_cat, m2, rg_m2, size, tape):
         """bot_aspp / bot_fine / upsample x4 / final / upsample to the input size (deeplabv3.py:141-162)."""
         net = self.net
@@ -287,7 +387,7 @@ class StudentEngine:
             dec0[..., cdec:cpad].zero_()         # (only the pad channels: the slices below fill the rest)
         ops.conv2d(m2, self._w_fwd(net.bot_fine), out_raw=dec0[..., 0:nf])
         ops.upsample_bilinear_ac(up_small, (h2, w2), out=dec0[..., nf:cdec])
-        f = net.final
+        f = self._final()
         sc, sh = self._bn_fold(f[1])
         d1 = self._new(N, h2, w2, f[0].out_channels)
         ops.conv2d(dec0, self._w_fwd(f[0], cin_pad=cpad), 1, 1, 1, out_act=d1, act_scale=sc, act_shift=sh, act_relu=True,
@@ -298,7 +398,7 @@ class StudentEngine:
         ncls = f[6].out_channels
         d3 = self._new(N, h2, w2, ncls, dtype=torch.float32)
         ops.conv2d(d2, self._w_fwd(f[6]), out_raw=d3)
-        logits = ops.upsample_bilinear_ac(d3, size, out_dtype=torch.float32)
+        logits = ops.upsample_bilinear_ac(d3, size, out_dtype=torch.float32, align_corners=not self.is_gscnn)
         tape["dec"] = dict(cat=cat, rg_cat=rg_cat, m2=m2, rg_m2=rg_m2, dec0=dec0, d1=d1, d2=d2, cdec=cdec, nf=nf, size=size,
                            small=(h8, w8))
         return logits
@@ -405,7 +505,7 @@ class StudentEngine:
         def add_bn(seq):
             bn = _bn_of(seq)
             add_p(bn.weight, bn.bias)
-        f = net.final
+        f = self._final()
         add_conv(f[6]); add_bn(f[4]); add_conv(f[3]); add_bn(f[1]); add_conv(f[0])
         add_conv(net.bot_fine); add_conv(net.bot_aspp)
         add_bn(net.aspp.img_conv[1]); add_conv(net.aspp.img_conv[0])
@@ -658,12 +758,13 @@ class StudentEngine:
         Returns the gradient w.r.t. mod7's output, or None."""
         arec = self._tape["aspp"]
         aspp, cat, red, x7, rg7 = arec["mod"], arec["cat"], arec["red"], arec["x7"], arec["rg7"]
+        lead = arec.get("lead", 1)
         if g_cat_hint is not None:
             scale = self._cat_scale(aspp)
             g_cat = ops.relu_bn_bwd(g_cat_hint, cat, scale, res=g_cat)
         g_x7 = None
         for i, br in enumerate(arec["branches"]):
-            sl = slice(red * (i + 1), red * (i + 2))
+            sl = slice(red * (i + lead), red * (i + lead + 1))
             g = g_aspp.get(i)
             if g_cat is not None:
                 gi = g_cat[..., sl]
@@ -685,7 +786,7 @@ class StudentEngine:
 
     def _cat_scale(self, aspp):
         """BN scales of [image branch, features 0..] concatenated: the mask_scale of the concat buffer."""
-        bns = [aspp.img_conv[1]] + [br[1] for br in aspp.features]
+        bns = [aspp.img_conv[1]] + ([aspp.edge_conv[1]] if hasattr(aspp, "edge_conv") else []) + [br[1] for br in aspp.features]
         key = tuple(id(_bn_of(b)) for b in bns)
         vers = tuple(self._bn_fold(b)[0].data_ptr() for b in bns)
         ent = self._bn.get(("cat", key))
@@ -732,6 +833,9 @@ class StudentEngine:
         w.r.t. the raw ASPP branch outputs (concat-shaped, through BN+ReLU) and w.r.t. mod2's output -- None where nothing
         upstream is trainable."""
         net, dec = self.net, self._tape["dec"]
+        if self.is_gscnn:
+            raise EngineError("gradients w.r.t. the GSCNN logits are not built (mode B through the shape stream); the shipped "
+                              "GSCNN plan back-propagates hint losses only (cfg/cityscapes/51M_gscnn_all.json)")
         f = net.final
         N, h2, w2, _ = dec["d2"].shape
         cdec, nf = dec["cdec"], dec["nf"]

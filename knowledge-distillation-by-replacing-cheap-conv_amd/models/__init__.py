@@ -8,6 +8,7 @@ from torch import nn
 
 from . import cifar_models, metric  # noqa: F401
 from .deeplabv3 import DeepWV3Plus  # noqa: F401
+from .gscnn import GSCNN  # noqa: F401
 
 
 def forgiving_state_restore(net, loaded_dict):

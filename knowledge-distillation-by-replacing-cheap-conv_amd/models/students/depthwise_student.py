@@ -17,6 +17,7 @@ import torch
 from torch import nn
 
 from ..deeplabv3 import DeepWV3Plus
+from ..gscnn import GSCNN
 from .transform_blocks import DepthwiseSeparableBlock
 
 BLOCKS_LEVEL_SPLIT_CHAR = '.'
@@ -143,7 +144,7 @@ class DepthwiseStudent(nn.Module):
     # ------------------------------------------------------------------ execution
     @property
     def fused(self):
-        return isinstance(self.student, DeepWV3Plus)
+        return isinstance(self.student, (DeepWV3Plus, GSCNN))
 
     def _student_engine(self):
         from ...engine import StudentEngine
@@ -160,7 +161,7 @@ class DepthwiseStudent(nn.Module):
             self._teacher_ready = key
 
     def _teacher_forward(self, x):
-        if self.teacher_backend == "hip" and isinstance(self.teacher, DeepWV3Plus):
+        if self.teacher_backend == "hip" and isinstance(self.teacher, (DeepWV3Plus, GSCNN)):
             from ...engine import StudentEngine
             if self._teacher_engine is None or self._teacher_engine.net is not self.teacher or \
                     self._teacher_engine.dtype != self.dtype:
@@ -189,7 +190,7 @@ class DepthwiseStudent(nn.Module):
             raise RuntimeError("the fused DeepWV3Plus student runs on the GPU only (no CPU fallback)")
         from ...engine import run_student
         engine = self._student_engine()
-        hip_teacher = self.teacher_backend == "hip" and isinstance(self.teacher, DeepWV3Plus)
+        hip_teacher = self.teacher_backend == "hip" and isinstance(self.teacher, (DeepWV3Plus, GSCNN))
         if self.overlap_teacher and (not hip_teacher or self.hip_teacher_side_stream):
             # frozen teacher on a side stream: its logits/hints are consumed only by the losses, so it can overlap the
             # student's forward on the main stream (PyTorch-ROCm teacher: always; engine teacher: opt-in, since two

@@ -263,7 +263,7 @@ def maxpool3x3s2(x, scale=None, shift=None, want_raw=True):
     return y_raw, y_act
 
 
-def upsample_bilinear_ac(x, size, out=None, out_dtype=None):
+def upsample_bilinear_ac(x, size, out=None, out_dtype=None, align_corners=True):
     _need_cuda(x, out)
     N, H, W, Cc = x.shape
     Ho, Wo = size
@@ -271,8 +271,8 @@ def upsample_bilinear_ac(x, size, out=None, out_dtype=None):
         out = torch.empty((N, Ho, Wo, Cc), dtype=out_dtype or x.dtype, device=x.device)
     if tuple(out.shape) != (N, Ho, Wo, Cc):
         raise ValueError("upsample: bad output view")
-    check(_lib.lib().kd_upsample_bilinear_ac(_ptr(x), dt_of(x), nhwc_ld(x), _ptr(out), dt_of(out), nhwc_ld(out), N, H, W, Cc,
-                                             Ho, Wo, stream_ptr()), "kd_upsample_bilinear_ac")
+    check(_lib.lib().kd_upsample_bilinear(_ptr(x), dt_of(x), nhwc_ld(x), _ptr(out), dt_of(out), nhwc_ld(out), N, H, W, Cc,
+                                          Ho, Wo, int(bool(align_corners)), stream_ptr()), "kd_upsample_bilinear")
     return out
 
 
@@ -486,6 +486,65 @@ def bn2d_bwd(dy, x, y, gamma, mean, invstd, training, relu=False, need_dx=True):
     check(_lib.lib().kd_bn2d_bwd(_ptr(dy), _ptr(x), _ptr(y), _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(dx), _ptr(dg), _ptr(db),
                                  int(training), int(relu), 0, N, Cc, HW, stream_ptr()), "kd_bn2d_bwd")
     return dx, dg, db
+
+
+# ------------------------------------------------------------------------- Gated-SCNN shape stream
+def gated_conv(feat, gate, params, C_, out=None):
+    """feat (N,H,W,>=C) view whose first C channels are the features; gate (N,H,W,1); params: packed fp32 vector
+    (W1, b1, w2, b2, Wg with the BNs folded); out: (N,H,W,C) view."""
+    _need_cuda(feat, gate, params, out)
+    N, H, W, _ = feat.shape
+    f = feat[..., :C_]
+    if out is None:
+        out = torch.empty((N, H, W, C_), dtype=feat.dtype, device=feat.device)
+    need = (C_ + 1) * (C_ + 1) + 2 * (C_ + 1) + 1 + C_ * C_
+    if params.dtype != torch.float32 or params.numel() != need or not params.is_contiguous() or gate.dtype != feat.dtype:
+        raise ValueError("gated_conv: bad parameter vector / gate dtype")
+    check(_lib.lib().kd_gated_conv(dt_of(feat), _ptr(f), nhwc_ld(f), _ptr(gate), gate.stride(2), _ptr(params), _ptr(out), nhwc_ld(out),
+                                   N * H * W, C_, stream_ptr()), "kd_gated_conv")
+    return out
+
+
+def edge_attention(cs, canny, weights):
+    """cs (N,H,W,>=8) view, canny (N,H,W) fp32 0/255, weights fp32 (10,) = fuse[8] + cw[2] -> acts (N,H,W) fp32."""
+    _need_cuda(cs, canny, weights)
+    N, H, W, _ = cs.shape
+    c8 = cs[..., :8]
+    acts = torch.empty((N, H, W), dtype=torch.float32, device=cs.device)
+    if canny.dtype != torch.float32 or not canny.is_contiguous() or tuple(canny.shape) != (N, H, W) or weights.numel() != 10:
+        raise ValueError("edge_attention: bad operands")
+    check(_lib.lib().kd_edge_attention(dt_of(cs), _ptr(c8), nhwc_ld(c8), _ptr(canny), _ptr(weights), _ptr(acts), N * H * W, stream_ptr()),
+          "kd_edge_attention")
+    return acts
+
+
+def edge_aspp(acts, w, scale, shift, out):
+    """acts (N,H,W) fp32 -> out (N,Ho,Wo,C) slice: relu(bilinear(acts) * w[c] * scale[c] + shift[c])."""
+    _need_cuda(acts, w, scale, shift, out)
+    N, H, W = acts.shape
+    _, Ho, Wo, Cc = out.shape
+    check(_lib.lib().kd_edge_aspp(dt_of(out), _ptr(acts), H, W, _ptr(w), _ptr(scale), _ptr(shift), _ptr(out), nhwc_ld(out), N, Ho, Wo, Cc,
+                                  stream_ptr()), "kd_edge_aspp")
+    return out
+
+
+def canny(x_nchw, low=10, high=100, sweeps=8, max_rounds=64):
+    """Device Canny of the uint8-cast batch (N,3,H,W) -> (N,H,W) fp32 0/255.  Hysteresis runs `sweeps` sweeps per round and
+    reads one device int between rounds (the reference round-trips the whole image through the host here)."""
+    _need_cuda(x_nchw)
+    if x_nchw.dtype != torch.float32 or not x_nchw.is_contiguous() or x_nchw.shape[1] != 3:
+        raise ValueError("canny: expects a contiguous fp32 (N,3,H,W) batch")
+    N, _, H, W = x_nchw.shape
+    out = torch.empty((N, H, W), dtype=torch.float32, device=x_nchw.device)
+    changed = torch.zeros(1, dtype=torch.int32, device=x_nchw.device)
+    need = _lib.lib().kd_canny_workspace(N, H, W)
+    ws = _ws(need, x_nchw.device)
+    check(_lib.lib().kd_canny(_ptr(x_nchw), N, H, W, low, high, sweeps, _ptr(out), _ptr(changed), _ptr(ws), need, stream_ptr()), "kd_canny")
+    for _ in range(max_rounds):
+        if int(changed.item()) == 0:
+            break
+        check(_lib.lib().kd_canny_continue(N, H, W, sweeps, _ptr(out), _ptr(changed), _ptr(ws), need, stream_ptr()), "kd_canny_continue")
+    return out
 
 
 # ------------------------------------------------------------------------------------- losses

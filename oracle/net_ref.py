@@ -197,16 +197,17 @@ def weighted_hint_loss(s, t, w):  # losses/WeightedHintMSELoss.py:12-16
 
 
 def kd_step(teacher_sd, student_sd, x, target, plan, hint_num_classes=1000, temperature=1.0, cheap_geom=(9, 20, 5),
-            hint_weights=None, backprop="hint", hint_names=None):
+            hint_weights=None, backprop="hint", hint_names=None, canny=None):
     """One step.  backprop="hint": the reference-faithful loss = hint loss only (trainer/layerwise_trainer.py:233-235);
     backprop="kd+hint": loss = KLDiv(student, teacher logits) + hint loss (SURVEY 8d mode B; the KD term is what
     trainer/classification_trainer.py:37 back-propagates).  student_sd tensors with requires_grad=True are the trainable set
     (with every tensor trainable this includes the eval-mode BN weights / biases, like the reference's "identical
     architecture" branch, layerwise_trainer.py:88-100); returns a dict of losses / outputs / gradients."""
     hn = plan if hint_names is None else hint_names
+    fwd = forward if canny is None else (lambda sd, xx, h, cg: gscnn_forward(sd, xx, canny, h, cg))   # canny given: GSCNN
     with torch.no_grad():
-        t_logits, t_hints, _ = forward(teacher_sd, x, hn, cheap_geom)
-    s_logits, s_hints, names = forward(student_sd, x, hn, cheap_geom)
+        t_logits, t_hints, _ = fwd(teacher_sd, x, hn, cheap_geom)
+    s_logits, s_hints, names = fwd(student_sd, x, hn, cheap_geom)
     hint = 0
     per = []
     for i, (s, t) in enumerate(zip(s_hints, t_hints)):

@@ -197,6 +197,51 @@ def miou(conf):
         return float(np.nanmean(tp / (conf.sum(0) + conf.sum(1) - tp)))
 
 
+def canny_ref(img_u8, low=10, high=100):
+    """Canny edge map of an (H, W, 3) uint8 image as cv2.Canny(img, low, high) documents it (aperture 3, L1 gradient):
+    Sobel per channel with replicated borders, the channel of largest |gx| + |gy| wins, non-maximum suppression on the
+    quantised direction (tan 22.5 / 67.5 degrees in 2^15 fixed point), double threshold, 8-connected hysteresis.
+    PARITY UNPINNED: opencv-python is not in this image; this restates the published algorithm and is what
+    the device kernel kd_canny is checked against.  Returns (H, W) uint8 with values 0 / 255."""
+    img = np.asarray(img_u8, dtype=np.int64)
+    H, W, _ = img.shape
+    p = np.pad(img, ((1, 1), (1, 1), (0, 0)), mode="edge")
+    gx = (p[:-2, 2:] + 2 * p[1:-1, 2:] + p[2:, 2:]) - (p[:-2, :-2] + 2 * p[1:-1, :-2] + p[2:, :-2])
+    gy = (p[2:, :-2] + 2 * p[2:, 1:-1] + p[2:, 2:]) - (p[:-2, :-2] + 2 * p[:-2, 1:-1] + p[:-2, 2:])
+    mag3 = np.abs(gx) + np.abs(gy)
+    best = np.argmax(mag3, axis=2)                     # first channel of the largest magnitude
+    ii, jj = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    xs, ys, mag = gx[ii, jj, best], gy[ii, jj, best], mag3[ii, jj, best]
+    mp = np.pad(mag, 1)                                # magnitudes outside the image count as 0
+    M = lambda dy, dx: mp[1 + dy:1 + dy + H, 1 + dx:1 + dx + W]
+    ax, ay = np.abs(xs), np.abs(ys) << 15
+    tg22 = ax * 13573
+    tg67 = tg22 + (ax << 16)
+    horiz = ay < tg22
+    vert = (~horiz) & (ay > tg67)
+    s = np.where((xs ^ ys) < 0, -1, 1)
+    up = np.where(s == 1, M(-1, -1), M(-1, 1))
+    dn = np.where(s == 1, M(1, 1), M(1, -1))
+    keep = np.where(horiz, (mag > M(0, -1)) & (mag >= M(0, 1)),
+                    np.where(vert, (mag > M(-1, 0)) & (mag >= M(1, 0)), (mag > up) & (mag > dn)))
+    keep &= mag > low
+    strong = keep & (mag > high)
+    weak = keep & ~strong
+    while True:
+        sp = np.pad(strong, 1)
+        near = np.zeros_like(strong)
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                if dy or dx:
+                    near |= sp[1 + dy:1 + dy + H, 1 + dx:1 + dx + W]
+        grow = weak & near
+        if not grow.any():
+            break
+        strong |= grow
+        weak &= ~grow
+    return (strong * 255).astype(np.uint8)
+
+
 def radam_step(p, g, m, v, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
     """In-place on p, m, v (float32 contiguous)."""
     lib().orc_radam_step(_p(p), _p(_c(g)), _p(m), _p(v), ctypes.c_size_t(p.size), int(step),

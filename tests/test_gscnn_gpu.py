@@ -1,0 +1,164 @@
+"""Gated-SCNN (BASELINE config 5) on the GPU: shape-stream kernels, the full GSCNN forward through the engine against the
+reference's own forward (tests/golden/gscnn.npz: cv2.Canny replaced on both sides by the same seeded 0/255 map -- the
+Canny operator itself is parity-unpinned and checked against oracle.canny_ref), and a KD step of the shipped GSCNN plan
+against oracle/net_ref.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from _netutil import canny_stub_map, gscnn_key_inventory, seeded_cheap_weights, seeded_gscnn_sd  # noqa: E402
+from _seeded import seeded_fill_, seeded_input, seeded_value  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+from test_modeb_gpu import _check  # noqa: E402
+
+
+def _gscnn(dtype=torch.float32):
+    import kdcc_amd
+    from kdcc_amd.models import GSCNN
+    net = GSCNN(num_classes=19)
+    seeded_fill_(net, "gscnn.")
+    return net.eval()
+
+
+def test_gated_conv_and_basic_block_goldens(golden):
+    """kd_gated_conv (C = 16) and the BN-folded BasicBlock (16 channels in a 64-channel buffer) vs the reference's modules."""
+    from kdcc_amd import ops
+    from kdcc_amd.engine import StudentEngine
+    from kdcc_amd.models.gscnn import BasicBlock, GatedSpatialConv2d
+    g = golden("gscnn")
+    gate = GatedSpatialConv2d(16, 16)
+    seeded_fill_(gate, "gscnn.blk.gate.")
+    gate = gate.eval().cuda()
+    eng = StudentEngine(None, torch.float32)
+    eng.device = torch.device("cuda")
+    f, a = seeded_input("gscnn.blk.gate.f", (2, 16, 12, 20)), seeded_input("gscnn.blk.gate.a", (2, 1, 12, 20))
+    buf = torch.zeros((2, 12, 20, 64), device="cuda")
+    buf[..., :16] = f.permute(0, 2, 3, 1).cuda()
+    y = ops.gated_conv(buf, a.permute(0, 2, 3, 1).contiguous().cuda(), eng._gate_params(gate), 16)
+    ref = g["blk_gate.y"]
+    assert np.abs(y.cpu().numpy().transpose(0, 3, 1, 2) - ref).max() < 1e-3 * np.abs(ref).max()
+    with torch.no_grad():   # the torch container agrees as well (teacher_backend="torch" path)
+        assert np.abs(gate(f.cuda(), a.cuda()).cpu().numpy() - ref).max() < 1e-3 * np.abs(ref).max()
+    blk = BasicBlock(16)
+    seeded_fill_(blk, "gscnn.blk.res.")
+    blk = blk.eval().cuda()
+    for p in blk.parameters():
+        p.requires_grad = False
+    xb = seeded_input("gscnn.blk.res.x", (2, 16, 12, 20))
+    bx = torch.zeros((2, 12, 20, 64), device="cuda")
+    bx[..., :16] = xb.permute(0, 2, 3, 1).cuda()
+    yb = eng._basic_block(blk, bx)
+    ref = g["blk_res.y"]
+    assert np.abs(yb[..., :16].cpu().numpy().transpose(0, 3, 1, 2) - ref).max() < 1e-3 * np.abs(ref).max()
+    assert float(yb[..., 16:].abs().max()) == 0.0
+
+
+def test_canny_kernel_vs_published_algorithm():
+    """kd_canny == oracle.canny_ref (numpy restatement of cv2.Canny's documented algorithm), bit for bit, on images with real
+    structure (blurred blobs + noise: long weak chains exercise the hysteresis rounds) and on the normalised-float regime the
+    reference actually feeds it (values around 0 cast to uint8)."""
+    from kdcc_amd import ops
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:96, 0:160]
+    base = 120 + 100 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + 25 * np.sin((xx + 2 * yy) / 3.0)
+    img = np.stack([base + rng.normal(0, s, base.shape) for s in (2.0, 6.0, 12.0)], 0)        # (3, H, W) floats in ~[0, 255]
+    batch = np.stack([img, rng.normal(0, 1.2, img.shape) * 3.0]).astype(np.float32)           # second image: "normalised" input
+    got = ops.canny(torch.from_numpy(batch).cuda(), 10, 100, sweeps=2).cpu().numpy()
+    for n in range(2):
+        u8 = (batch[n].transpose(1, 2, 0).astype(np.int64) & 0xFF).astype(np.uint8)           # the kernel's (and numpy's) cast
+        ref = orc.canny_ref(u8, 10, 100)
+        assert set(np.unique(got[n])) <= {0.0, 255.0}
+        assert np.array_equal(got[n].astype(np.uint8), ref), f"image {n}: {(got[n] != ref).sum()} pixels differ"
+    assert got[0].sum() > 0
+
+
+def test_edge_attention_and_edge_aspp():
+    from kdcc_amd import ops
+    rng = np.random.default_rng(9)
+    cs = rng.standard_normal((2, 10, 14, 8)).astype(np.float32)
+    canny = (rng.random((2, 10, 14)) < 0.2).astype(np.float32) * 255
+    w = rng.standard_normal(10).astype(np.float32) * 0.3
+    w[9] *= 0.02
+    buf = torch.zeros((2, 10, 14, 64), device="cuda")
+    buf[..., :8] = torch.from_numpy(cs).cuda()
+    acts = ops.edge_attention(buf, torch.from_numpy(canny).cuda(), torch.from_numpy(w).cuda())
+    sig = lambda v: 1 / (1 + np.exp(-v))
+    ref = sig(w[8] * sig(cs @ w[:8]) + w[9] * canny)
+    np.testing.assert_allclose(acts.cpu().numpy(), ref, rtol=1e-4, atol=1e-6)
+    wc, sc, sh = rng.standard_normal(16).astype(np.float32), rng.random(16).astype(np.float32) + 0.5, rng.standard_normal(16).astype(np.float32) * 0.1
+    out = torch.zeros((2, 4, 6, 48), device="cuda")
+    ops.edge_aspp(acts, torch.from_numpy(wc).cuda(), torch.from_numpy(sc).cuda(), torch.from_numpy(sh).cuda(), out[..., 16:32])
+    e = orc.upsample_bilinear_ac(ref[:, None].astype(np.float32), (4, 6))[:, 0]
+    exp = np.maximum(e[..., None] * wc * sc + sh, 0)
+    np.testing.assert_allclose(out[..., 16:32].cpu().numpy(), exp, rtol=1e-4, atol=1e-5)
+    assert float(out[..., :16].abs().max()) == 0 and float(out[..., 32:].abs().max()) == 0
+
+
+def test_gscnn_forward_matches_reference(golden):
+    """GSCNN(19) through the engine (fp32 parity mode) == the reference's forward: logits, edge attention, ASPP output."""
+    from kdcc_amd.engine import StudentEngine
+    g = golden("gscnn")
+    net = _gscnn().cuda()
+    assert {k: list(v.shape) for k, v in net.state_dict().items()} == gscnn_key_inventory()
+    maps = torch.stack([canny_stub_map((64, 128), int(s)) for s in g["canny_seeds"]]).cuda()
+    net.canny_fn = lambda x: maps
+    x = seeded_input(str(g["x_key"]), (2, 3, 64, 128), scale=float(g["x_scale"])).cuda()
+    eng = StudentEngine(net, torch.float32)
+    eng.hint_names = []
+    with torch.no_grad():
+        logits, _ = eng.forward(x)
+        tape = eng._tape
+    _check(logits.permute(0, 3, 1, 2), g, "logits", 4096, 1e-3, "GSCNN logits")
+    _check(tape["acts"].unsqueeze(1), g, "acts", 4096, 1e-3, "edge attention")
+    _check(tape["aspp"]["cat"].permute(0, 3, 1, 2), g, "aspp", 4096, 1e-3, "edge-aware ASPP output")
+    # the torch container (teacher_backend="torch") agrees too
+    net.canny_fn = lambda x: maps.unsqueeze(1)
+    with torch.no_grad():
+        _check(net(x), g, "logits", 4096, 1e-3, "GSCNN logits (torch container)")
+
+
+def test_gscnn_kd_step_vs_network_oracle():
+    """The shipped GSCNN plan's shape (cfg/cityscapes/51M_gscnn_all.json: cheap convs in mod4 / mod7 / ASPP, hints = plan,
+    loss = hint MSE): DepthwiseStudent(GSCNN) forward + backward vs oracle/net_ref.py (gscnn_forward), fp32."""
+    from kdcc_amd import losses
+    from kdcc_amd.models.students import DepthwiseStudent
+    from oracle import net_ref
+    plan = ["mod4.block2.convs.conv2", "mod4.block3.convs.conv1", "mod7.block1.convs.conv2", "aspp.features.1.0", "aspp.features.3.0"]
+    teacher = _gscnn()
+    model = DepthwiseStudent(teacher, None, dtype=torch.float32)
+    model.replace([{"name": n, "epoch": 1} for n in plan], kernel_size=9, padding=20, dilation=5)
+    model.register_hint_layers(plan)
+    model.unfreeze(plan)
+    for n in plan:
+        seeded_fill_(model.get_block(n, model.student), f"student.{n}.")
+    model = model.cuda()
+    maps = torch.stack([canny_stub_map((64, 128), 700 + i) for i in range(2)])
+    for net in (model.teacher, model.student):
+        net.canny_fn = lambda x: maps.cuda()
+    x = seeded_input("gscnn.step.x", (2, 3, 64, 128), scale=30.0)
+    out_st, out_tc = model(x.cuda())
+    crit = losses.MSELoss(num_classes=1000)
+    hint = 0
+    for s, t in zip(model.student_hidden_outputs, model.teacher_hidden_outputs):
+        hint = hint + crit(s, t)
+    hint.backward()
+    torch.cuda.synchronize()
+    tsd = seeded_gscnn_sd()
+    ssd = net_ref.make_student_sd(tsd, plan, seeded_cheap_weights(tsd, plan))
+    torch.set_num_threads(8)
+    r = net_ref.kd_step(tsd, ssd, x, None, plan, canny=maps.unsqueeze(1))
+    np.testing.assert_allclose(hint.item(), r["hint_loss"].item(), rtol=1e-3)
+    for name, got, ref in [("student logits", out_st, r["student_logits"]), ("teacher logits", out_tc, r["teacher_logits"])]:
+        d = np.abs(got.detach().float().cpu().numpy() - ref.numpy()).max() / np.abs(ref.numpy()).max()
+        assert d < 1e-3, (name, d)
+    for n, p in model.student.named_parameters():
+        if p.requires_grad:
+            ref = r["grads"][n].numpy().astype(np.float64)
+            got = p.grad.cpu().numpy().astype(np.float64)
+            assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-3, n
+    # mode B / `aspp` hints are refused loudly for GSCNN rather than silently dropping the edge-branch gradient
+    from kdcc_amd.engine import EngineError
+    with pytest.raises(EngineError):
+        model.register_hint_layers(["aspp"])
