@@ -30,18 +30,22 @@ PLANS = {
             "mod4.block5.convs.conv2", "mod4.block6.convs.conv2", "mod5.block2.convs.conv2", "mod7.block1.convs.conv2",
             "aspp.features.1.0", "aspp.features.2.0", "aspp.features.3.0"],
 }
+PLANS["P86"] = ["mod4.block2.convs.conv2", "mod4.block3.convs.conv1", "mod4.block3.convs.conv2", "mod4.block4.convs.conv2",
+                "mod4.block6.convs.conv2", "mod7.block1.convs.conv2", "aspp.features.1.0", "aspp.features.2.0",
+                "aspp.features.3.0"]   # cfg/cityscapes/51M_gscnn_all.json verbatim (the README's 86 M GSCNN student)
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md chip-level table
 PEAK_F32_TFLOPS = 157.3
 
 
-def build(plan, dtype, device, seed=123, mode="A"):
+def build(plan, dtype, device, seed=123, mode="A", arch="deeplab"):
     import kdcc_amd
     from kdcc_amd import losses
-    from kdcc_amd.models import DeepWV3Plus
+    from kdcc_amd.models import GSCNN, DeepWV3Plus
     from kdcc_amd.models.students import DepthwiseStudent
     from kdcc_amd.utils.optim import RAdam
     torch.manual_seed(seed)                       # train.py:17-21 of the reference
-    teacher = DeepWV3Plus(num_classes=19).eval()  # random init: the Cityscapes checkpoint is not shipped
+    # random init: the Cityscapes checkpoints are not shipped
+    teacher = (GSCNN(num_classes=19) if arch == "gscnn" else DeepWV3Plus(num_classes=19)).eval()
     cpu_sd = {k: v.detach().clone() for k, v in teacher.state_dict().items() if not k.endswith("num_batches_tracked")}
     model = DepthwiseStudent(teacher, None, dtype=dtype).to(device)
     model.replace([{"name": n, "epoch": 1} for n in plan], kernel_size=9, padding=20, dilation=5)
@@ -169,6 +173,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--plan", default="P92", choices=sorted(PLANS))
+    ap.add_argument("--arch", default="deeplab", choices=["deeplab", "gscnn"],
+                    help="deeplab: DeepLabV3+(WRN-38), the headline (BASELINE configs 2-4); gscnn: Gated-SCNN teacher/student "
+                         "(BASELINE config 5; use --plan P86, the shipped 51M_gscnn_all.json plan; mode A only)")
     ap.add_argument("--mode", default="A", choices=["A", "B"],
                     help="A (default, reference-faithful): loss = hint loss, only the cheap-conv blocks train; B (SURVEY 8d "
                          "north-star mode): loss = KLDiv + hint, every student parameter trainable (37.74 TFLOP/img for P92)")
@@ -202,7 +209,7 @@ def main():
     device = torch.device("cuda", local)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     plan = PLANS[a.plan]
-    model, crit, opt, cpu_sd = build(plan, dtype, device, mode=a.mode)
+    model, crit, opt, cpu_sd = build(plan, dtype, device, mode=a.mode, arch=a.arch)
     model.overlap_teacher = not a.no_overlap
     model.teacher_backend = a.teacher
     model.hip_teacher_side_stream = a.teacher_stream == "side"
@@ -299,7 +306,10 @@ def main():
                              "algorithmic_tflop_per_step": wg_flops / max(a.steps, 1) / 1e12} if wg_ms > 0 else None),
             "losses": {("hint" if a.mode == "A" else "kd+hint"): float(loss.detach()), "supervised": float(sup), "kd": float(kd), "teacher": float(tl)},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if a.arch == "gscnn":
+            res["metric"] = "images/sec KD train step, Gated-SCNN (WRN38) student 1024x2048"
+            res["config"]["workload"] = res["config"]["workload"].replace("DeepLabV3+(WRN-38) student", "Gated-SCNN (WRN-38 + shape stream, device Canny) student")
+        if world == 1 and not a.no_cpu_baseline and a.arch == "deeplab":
             res["cpu_baseline"] = cpu_baseline(cpu_sd, model, plan, full=a.cpu_baseline == "full")
         print(json.dumps(res))
     if world > 1:

@@ -19,6 +19,8 @@ def _gscnn(dtype=torch.float32):
     from kdcc_amd.models import GSCNN
     net = GSCNN(num_classes=19)
     seeded_fill_(net, "gscnn.")
+    for p in net.parameters():      # DepthwiseStudent freezes its teacher / student copies the same way
+        p.requires_grad = False
     return net.eval()
 
 
