@@ -93,6 +93,15 @@ class StudentEngine:
         # ASPP branch; decoder `final_seg`, last upsample without align_corners
         self.is_gscnn = net is not None and hasattr(net, "gate1")
         self._gate_prm = {}
+        self.edge_prior = None   # (N,H,W) fp32 Canny map handed in by the caller (teacher and student share one per batch)
+
+    def compute_edge_prior(self, x_nchw):
+        """The Canny prior of the batch: the device kernel, or the model's `canny_fn` plug point (tests feed the goldens' map)."""
+        fn = getattr(self.net, "canny_fn", None)
+        N, _, H, W = x_nchw.shape
+        if fn is None:
+            return ops.canny(x_nchw.detach().float().contiguous())
+        return fn(x_nchw).reshape(N, H, W).float().contiguous()
 
     def _final(self):
         return self.net.final_seg if self.is_gscnn else self.net.final
@@ -116,7 +125,9 @@ class StudentEngine:
         # matching small _version) to a new one while the entry is alive, and `ent[2] is p` catches any other aliasing
         key = (id(p), tag)
         ent = self._pack.get(key)
-        if ent is None or ent[2] is not p or ent[0] != p._version or ent[1].device != p.device:
+        if ent is not None:
+            first = ent[1][0] if isinstance(ent[1], tuple) else ent[1]
+        if ent is None or ent[2] is not p or ent[0] != p._version or first.device != p.device:
             ent = (p._version, fn(), p)
             self._pack[key] = ent
         return ent[1]
@@ -367,8 +378,7 @@ class StudentEngine:
         cs = gated(net.gate1, squeeze(net.d1, self._basic_block(net.res1, m1), 32), s3, 32)
         cs = gated(net.gate2, squeeze(net.d2, self._basic_block(net.res2, cs), 16), s4, 16)
         cs = gated(net.gate3, squeeze(net.d3, self._basic_block(net.res3, cs), 8), s7, 8)
-        fn = getattr(net, "canny_fn", None)   # plug point for a caller-supplied edge prior (tests feed the goldens' map)
-        canny = ops.canny(x_nchw) if fn is None else fn(x_nchw).reshape(N, H, W).float().contiguous()
+        canny = self.edge_prior if self.edge_prior is not None else self.compute_edge_prior(x_nchw)
         w = torch.cat([net.fuse.weight.detach().float().reshape(-1), net.cw.weight.detach().float().reshape(-1)]).contiguous()
         return ops.edge_attention(cs, canny, w)
 

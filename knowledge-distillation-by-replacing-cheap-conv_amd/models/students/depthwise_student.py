@@ -167,6 +167,7 @@ class DepthwiseStudent(nn.Module):
                     self._teacher_engine.dtype != self.dtype:
                 self._teacher_engine = StudentEngine(self.teacher, self.dtype)
             eng = self._teacher_engine
+            eng.edge_prior = getattr(self, "_shared_prior", None) if eng.is_gscnn else None
             eng.hint_names = list(self.hint_block_names) if self.save_hidden else []
             with torch.no_grad():
                 logits, hints = eng.forward(x)
@@ -190,6 +191,11 @@ class DepthwiseStudent(nn.Module):
             raise RuntimeError("the fused DeepWV3Plus student runs on the GPU only (no CPU fallback)")
         from ...engine import run_student
         engine = self._student_engine()
+        if engine.is_gscnn:   # one Canny prior per batch, shared by teacher and student (the reference computes it twice, on the host)
+            engine.edge_prior = engine.compute_edge_prior(x)
+            if self._teacher_engine is not None:
+                self._teacher_engine.edge_prior = engine.edge_prior
+            self._shared_prior = engine.edge_prior
         hip_teacher = self.teacher_backend == "hip" and isinstance(self.teacher, (DeepWV3Plus, GSCNN))
         if self.overlap_teacher and (not hip_teacher or self.hip_teacher_side_stream):
             # frozen teacher on a side stream: its logits/hints are consumed only by the losses, so it can overlap the
@@ -211,6 +217,10 @@ class DepthwiseStudent(nn.Module):
         if self.save_hidden:
             self.student_hidden_outputs = hints
             self.student_hint_names = list(engine.last_hint_names)
+        engine.edge_prior = None
+        self._shared_prior = None
+        if self._teacher_engine is not None:
+            self._teacher_engine.edge_prior = None
         return student_pred, teacher_pred
 
     def inference(self, x):
