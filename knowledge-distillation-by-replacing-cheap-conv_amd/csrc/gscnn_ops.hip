@@ -23,49 +23,92 @@ inline int blocks_for(long long total, int cap = 1 << 20)
 //   alpha = sigmoid(w2 . z + b2)   (trailing BN(1) folded into w2 / b2)
 //   out = Wg (feat * (alpha + 1))
 // params (fp32): W1 [(C+1)][(C+1)], b1 [C+1], w2 [C+1], b2 [1], Wg [C][C], in this order.
-// The weights are the same for every pixel: they are read through uniform (scalar) loads straight from `prm` -- s_load into
-// SGPRs, FMAs with a scalar operand -- instead of LDS broadcasts (one ds_read per FMA made the first version LDS-issue-bound:
-// 4.4 ms for the 32-channel gate at 4 x 1024 x 2048 pixels).
+// Weights live in LDS with rows padded to a multiple of four floats; a thread owns PIX = 4 consecutive pixels, so one
+// broadcast ds_read_b128 (four weights) feeds 16 FMAs.  (One LDS read per FMA made the first version LDS-issue-bound at 4.4 ms
+// for the 32-channel gate at 4 x 1024 x 2048 pixels; streaming the weights through scalar loads was slower still, 5.4 ms.)
 template <typename T, int C>
 __global__ __launch_bounds__(256) void gated_conv_kernel(const T *__restrict__ feat, int ldf, const T *__restrict__ gate, int ldg,
                                                          const float *__restrict__ prm, T *__restrict__ out, int ldo, long long npix)
 {
-    constexpr int H = C + 1;
-    const float *__restrict__ W1 = prm, *__restrict__ b1 = prm + H * H, *__restrict__ w2 = prm + H * H + H;
-    const float *__restrict__ Wg = prm + H * H + 2 * H + 1;
-    const float b2 = prm[H * H + 2 * H];
-    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
-        float u[H];
+    constexpr int H = C + 1, HP = (H + 3) & ~3, PIX = C >= 32 ? 2 : 4;
+    __shared__ __attribute__((aligned(16))) float sW1[H * HP];
+    __shared__ __attribute__((aligned(16))) float sWg[C * C];
+    __shared__ float sb1[H], sw2[H];
+    __shared__ float sb2;
+    for (int i = threadIdx.x; i < H * HP; i += 256) {
+        const int j = i / HP, k = i - j * HP;
+        sW1[i] = k < H ? prm[j * H + k] : 0.f;
+    }
+    for (int i = threadIdx.x; i < H; i += 256) { sb1[i] = prm[H * H + i]; sw2[i] = prm[H * H + H + i]; }
+    if (threadIdx.x == 0) sb2 = prm[H * H + 2 * H];
+    for (int i = threadIdx.x; i < C * C; i += 256) sWg[i] = prm[H * H + 2 * H + 1 + i];
+    __syncthreads();
+    const long long ngroups = (npix + PIX - 1) / PIX;
+    for (long long gidx = (long long)blockIdx.x * 256 + threadIdx.x; gidx < ngroups; gidx += (long long)gridDim.x * 256) {
+        const long long p0 = gidx * PIX;
+        float u[PIX][HP];
 #pragma unroll
-        for (int q = 0; q < C / 8; ++q) {
-            float v[8];
-            ld8(feat + p * ldf + q * 8, v);
+        for (int px = 0; px < PIX; ++px) {
+            const long long p = min(p0 + px, npix - 1);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) u[q * 8 + e] = v[e];
+            for (int q = 0; q < C / 8; ++q) {
+                float v[8];
+                ld8(feat + p * ldf + q * 8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) u[px][q * 8 + e] = v[e];
+            }
+            u[px][C] = Elem<T>::ld(gate + p * ldg);
+#pragma unroll
+            for (int k = H; k < HP; ++k) u[px][k] = 0.f;
         }
-        u[C] = Elem<T>::ld(gate + p * ldg);
-        float a = b2;
+        float a[PIX];
 #pragma unroll
+        for (int px = 0; px < PIX; ++px) a[px] = sb2;
+#pragma unroll 1
         for (int j = 0; j < H; ++j) {
-            float z = b1[j];
+            asm volatile("" ::: "memory");   // keep the (loop-invariant) LDS weight reads inside the loop: hoisted, they spill
+            float z[PIX];
 #pragma unroll
-            for (int i = 0; i < H; ++i) z = fmaf(W1[j * H + i], u[i], z);
-            a = fmaf(w2[j], fmaxf(z, 0.f), a);
+            for (int px = 0; px < PIX; ++px) z[px] = sb1[j];
+#pragma unroll
+            for (int k = 0; k < HP; k += 4) {
+                const float4 w = *(const float4 *)&sW1[j * HP + k];
+#pragma unroll
+                for (int px = 0; px < PIX; ++px)
+                    z[px] = fmaf(w.w, u[px][k + 3], fmaf(w.z, u[px][k + 2], fmaf(w.y, u[px][k + 1], fmaf(w.x, u[px][k], z[px]))));
+            }
+            const float wj = sw2[j];
+#pragma unroll
+            for (int px = 0; px < PIX; ++px) a[px] = fmaf(wj, fmaxf(z[px], 0.f), a[px]);
         }
-        const float k = 1.f / (1.f + __expf(-a)) + 1.f;
 #pragma unroll
-        for (int i = 0; i < C; ++i) u[i] *= k;
+        for (int px = 0; px < PIX; ++px) {
+            const float k = 1.f / (1.f + __expf(-a[px])) + 1.f;
 #pragma unroll
+            for (int i = 0; i < C; ++i) u[px][i] *= k;
+        }
+#pragma unroll 1
         for (int q = 0; q < C / 8; ++q) {
-            float v[8];
+            float v[PIX][8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float s = 0.f;
+                asm volatile("" ::: "memory");
+                float s[PIX];
 #pragma unroll
-                for (int i = 0; i < C; ++i) s = fmaf(Wg[(q * 8 + e) * C + i], u[i], s);
-                v[e] = s;
+                for (int px = 0; px < PIX; ++px) s[px] = 0.f;
+#pragma unroll
+                for (int i = 0; i < C; i += 4) {
+                    const float4 w = *(const float4 *)&sWg[(q * 8 + e) * C + i];
+#pragma unroll
+                    for (int px = 0; px < PIX; ++px)
+                        s[px] = fmaf(w.w, u[px][i + 3], fmaf(w.z, u[px][i + 2], fmaf(w.y, u[px][i + 1], fmaf(w.x, u[px][i], s[px]))));
+                }
+#pragma unroll
+                for (int px = 0; px < PIX; ++px) v[px][e] = s[px];
             }
-            st8(out + p * ldo + q * 8, v);
+#pragma unroll
+            for (int px = 0; px < PIX; ++px)
+                if (p0 + px < npix) st8(out + (p0 + px) * ldo + q * 8, v[px]);
         }
     }
 }
@@ -228,7 +271,7 @@ extern "C" int kd_gated_conv(int32_t dtype, const void *feat, int32_t ldf, const
     const int es = kd_elem_size(dtype);
     KD_REQUIRE(kd_aligned16(feat) && kd_aligned16(out) && (ldf * es) % 16 == 0 && (ldo * es) % 16 == 0, KD_ERR_INVALID,
                "kd_gated_conv: 16-B aligned feature views required");
-    const int nb = blocks_for(npix, 65536);
+    const int nb = blocks_for((npix + (C >= 32 ? 1 : 3)) / (C >= 32 ? 2 : 4), 65536);
     hipStream_t s = (hipStream_t)stream;
 #define KD_GC(T, CC) hipLaunchKernelGGL((gated_conv_kernel<T, CC>), dim3(nb), dim3(256), 0, s, (const T *)feat, ldf, (const T *)gate, ldg, params, (T *)out, ldo, (long long)npix)
     if (dtype == KD_BF16) { if (C == 8) KD_GC(bf16_t, 8); else if (C == 16) KD_GC(bf16_t, 16); else KD_GC(bf16_t, 32); }
