@@ -114,6 +114,30 @@ def test_hint_names_validated_at_registration(teacher):
             m.register_hint_layers(bad)
 
 
+def test_gscnn_checkpoint_contract_and_plan():
+    """GSCNN(19): state-dict names / shapes / order equal the reference's (tests/golden/gscnn_keys.json, captured by
+    tools/make_golden.py), 137 278 190 parameters (README "137M"); the shipped GSCNN plan gives the 86.1 M student."""
+    from kdcc_amd.models import GSCNN
+    with torch.device("meta"):
+        net = GSCNN(num_classes=19)
+    ref = json.load(open(os.path.join(HERE, "golden", "gscnn_keys.json")))
+    mine = {k: list(v.shape) for k, v in net.state_dict().items()}
+    assert list(mine) == list(ref) and mine == ref
+    assert nparams(net) == 137278190
+    plan = ["mod4.block2.convs.conv2", "mod4.block3.convs.conv1", "mod4.block3.convs.conv2", "mod4.block4.convs.conv2",
+            "mod4.block6.convs.conv2", "mod7.block1.convs.conv2", "aspp.features.1.0", "aspp.features.2.0", "aspp.features.3.0"]
+    with torch.device("meta"):
+        m = DepthwiseStudent(net, None)
+        m.replace([{"name": n, "epoch": 1} for n in plan], kernel_size=9, padding=20, dilation=5)
+    assert m.fused and nparams(m.student) == 86135022          # SURVEY F10: 51M_gscnn_all.json -> 86 135 022
+    m.register_hint_layers(plan)
+    from kdcc_amd.engine import EngineError
+    with pytest.raises(EngineError):
+        m.register_hint_layers(["aspp"])                        # GSCNN: the edge branch's gradient path is not built
+    with pytest.raises(RuntimeError):
+        net.forward(torch.zeros(1, 3, 8, 8, device="meta") if False else torch.zeros(1, 3, 8, 8))   # host tensors need canny_fn
+
+
 def test_forgiving_state_restore():
     a, b = nn.Linear(4, 3), nn.Linear(4, 3)
     sd = {"module." + k: v.clone() + 1 for k, v in a.state_dict().items()}   # DataParallel-style checkpoint

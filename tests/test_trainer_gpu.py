@@ -100,3 +100,39 @@ def test_sliding_window_test_epoch(tmp_path):
     assert (tmp_path / "submission" / "frankfurt_000000.png").exists()
     with pytest.raises(NotImplementedError):
         model.inference_test(x, {"scales": [0.5, 1.0], "crop_size": 64})
+
+
+def test_gscnn_config_is_drop_in(tmp_path):
+    """BASELINE config 5's shape through the reference's own plug points: `teacher.type = "GSCNN"` resolved by init_obj,
+    DepthwiseStudent + LayerwiseTrainer on the shipped GSCNN plan's layer names, bf16 (the measured dtype): one epoch of two
+    steps runs, the hint loss is finite and positive, the cheap-conv parameters move, the shape stream stays frozen."""
+    import kdcc_amd
+    from kdcc_amd import ConfigParser, losses, models
+    from kdcc_amd.models.students import DepthwiseStudent
+    from kdcc_amd.trainer import LayerwiseTrainer
+    from kdcc_amd.utils import WeightScheduler
+    from kdcc_amd.utils import optim as optim_module
+    plan = ["mod4.block2.convs.conv2", "mod7.block1.convs.conv2", "aspp.features.2.0"]
+    cfg = trainer_config(plan, lr=1e-3, len_epoch=1, save_dir=str(tmp_path), dtype="bf16")
+    cfg["teacher"] = {"type": "GSCNN", "args": {"num_classes": 19}}
+    config = ConfigParser(cfg, run_id="gscnn")
+    teacher = config.init_obj("teacher", models)
+    assert type(teacher).__name__ == "GSCNN"
+    seeded_fill_(teacher, "gscnn.")
+    teacher.eval()
+    model = DepthwiseStudent(teacher, config)
+    assert model.fused and model.dtype == torch.bfloat16
+    crit = [config.init_obj(k, losses) for k in ("supervised_loss", "kd_loss", "hint_loss")]
+    opt = config.init_obj("optimizer", optim_module, model.student.parameters())
+    sched = config.init_obj("lr_scheduler", optim_module.lr_scheduler, opt)
+    batches = [(seeded_input(f"gs.x{i}", (1, 3, 64, 256), scale=30.0), torch.randint(0, 19, (1, 64, 256), generator=torch.Generator().manual_seed(i)))
+               for i in range(2)]
+    tr = LayerwiseTrainer(model, crit, [], opt, config, batches, None, sched, WeightScheduler(config["weight_scheduler"]))
+    before = {n: p.detach().clone() for n, p in model.student.named_parameters() if "gate1" in n or "res1" in n}
+    log = tr._train_epoch(1)
+    assert np.isfinite(log["hint_loss"]) and log["hint_loss"] > 0 and np.isfinite(log["supervised_loss"])
+    moved = [n for n, p in model.student.named_parameters() if p.requires_grad]
+    assert len(moved) == 6 and all("separable_conv" in n or "pointwise_conv" in n for n in moved)
+    for n, p in model.student.named_parameters():
+        if n in before:
+            assert torch.equal(p, before[n].to(p.device)), n
