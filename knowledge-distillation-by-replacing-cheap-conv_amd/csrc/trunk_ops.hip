@@ -4,6 +4,8 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "kd_common.h"
 
 static thread_local char g_err[512] = "";

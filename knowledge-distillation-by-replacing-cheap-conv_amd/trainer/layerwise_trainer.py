@@ -56,6 +56,9 @@ class LayerwiseTrainer(BaseTrainer):
         self.criterions = nn.ModuleList(criterions).to(self.device)
         del self.criterion
         self.track_miou = bool(self.config['trainer'].get('track_train_miou', True))
+        self.backprop = str(self.config['trainer'].get('backprop', 'hint'))
+        if self.backprop not in ('hint', 'kd+hint'):
+            raise ValueError("trainer.backprop must be 'hint' (reference behaviour) or 'kd+hint'")
         self._reducer = None
         if 'resume_path' in self.config['trainer']:
             self.resume(self.config['trainer']['resume_path'])
@@ -208,7 +211,9 @@ class LayerwiseTrainer(BaseTrainer):
             teacher_loss = self.criterions[0](output_tc, target)   # for comparison
             hint_loss = self._hint_loss() / self.accumulation_steps
 
-            loss = hint_loss                                        # only use hint loss
+            loss = hint_loss                                        # only use hint loss (reference :233-235)
+            if self.backprop == 'kd+hint':                          # SURVEY 8(d) mode B, opt-in: trainer.backprop
+                loss = kd_loss + hint_loss
             loss.backward()
             self._reduce_unfused_grads()
             if batch_idx % self.accumulation_steps == 0:

@@ -304,6 +304,17 @@ def test_stem_pool_upsample_imagepool(K, dt):
     lgd2 = torch.from_numpy(np.ascontiguousarray(lg2.transpose(0, 2, 3, 1))).cuda()
     o2 = K.upsample_bilinear_ac(lgd2, (42, 666), out_dtype=torch.float32)
     assert_close(host_nchw(o2), orc.upsample_bilinear_ac(lg2, (42, 666)), "f32", "logit upsample (segments)")
+    # odd channel count (the 19-class logits), both corner modes
+    import torch.nn.functional as F
+    lg3 = rnd(2, 19, 9, 10)
+    lgd3 = torch.from_numpy(np.ascontiguousarray(lg3.transpose(0, 2, 3, 1))).cuda()
+    for align in (True, False):
+        o3 = K.upsample_bilinear_ac(lgd3, (18, 20), out_dtype=torch.float32, align_corners=align)
+        ref3 = F.interpolate(torch.from_numpy(lg3), size=(18, 20), mode="bilinear", align_corners=align).numpy()
+        assert_close(host_nchw(o3), ref3, "f32", f"logit upsample align={align}")
+    o4 = K.upsample_bilinear_ac(raw, (40, 56), align_corners=False)     # vector path, GSCNN's non-aligned mode
+    ref4 = F.interpolate(torch.from_numpy(host_nchw(raw)), size=(40, 56), mode="bilinear", align_corners=False).numpy()
+    assert_close(host_nchw(o4), ref4, dt, "upsample align_corners=False")
     # ASPP image pooling branch
     Cin, Cout = 64, 16
     xi = q(rnd(2, Cin, 6, 10), dt)
