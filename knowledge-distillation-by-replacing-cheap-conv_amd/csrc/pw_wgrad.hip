@@ -188,9 +188,13 @@ typedef short v4i16_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int tr_f(int m) { return (m & 3) | (((m >> 3) & 1) << 2); }
 
-__global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(const WgradParams p)
+// NST stages resident (32 KiB each), NST-1 in flight ahead of the one being consumed (counted vmcnt: a wave's DMA pieces retire
+// in issue order, 8 per stage).  NST = 2: two workgroups per CU, one stage in flight each; NST = 4: one workgroup per CU with
+// three stages (96 KiB) in flight -- the kernel is bound by the latency of its gathered stage, not by MFMA or LDS.
+template <int NST>
+__global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void pw_wgrad_tr_kernel(const WgradParams p)
 {
-    __shared__ __attribute__((aligned(16))) char lds[2 * 32768];
+    __shared__ __attribute__((aligned(16))) char lds[NST * 32768];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1;
@@ -404,6 +408,15 @@ __global__ void slab_reduce_kernel(const float *__restrict__ part, float *__rest
     }
 }
 
+void launch_tr(dim3 grid, hipStream_t s, const WgradParams &p)
+{
+    static int nst = -1;
+    if (nst < 0) { const char *e = getenv("KDCC_WGRAD_NST"); nst = e ? atoi(e) : 2; }   // A/B hook: 2 | 3 | 4 (measured: 128->128 3x3 at 512x1024 1.70 ms with 2, 2.44 with 3 or 4: occupancy beats depth)
+    if (nst == 2) hipLaunchKernelGGL(pw_wgrad_tr_kernel<2>, grid, dim3(256), 0, s, p);
+    else if (nst == 3) hipLaunchKernelGGL(pw_wgrad_tr_kernel<3>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(pw_wgrad_tr_kernel<4>, grid, dim3(256), 0, s, p);
+}
+
 void plan(int dtype, int M, int Cin, int Cout, int &tiles, int &tiles_ci, int &splits, int &rows_per_split, int taps = 1)
 {
     const int krows = IG_ROWB / kd_elem_size(dtype);
@@ -454,7 +467,7 @@ extern "C" int kd_pw_wgrad(int32_t dtype, int32_t M, int32_t Cin, int32_t Cout, 
     p.mg_howo = p.sh_howo = p.mg_wo = p.sh_wo = 0;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)tiles, (unsigned)splits);
-    if (dtype == KD_BF16 && Cin % 8 == 0 && Cout % 8 == 0) hipLaunchKernelGGL(pw_wgrad_tr_kernel, grid, dim3(256), 0, s, p);
+    if (dtype == KD_BF16 && Cin % 8 == 0 && Cout % 8 == 0) launch_tr(grid, s, p);
     else if (dtype == KD_BF16) hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(pw_wgrad_kernel<float>, grid, dim3(256), 0, s, p);
     KD_CHECK_LAUNCH("kd_pw_wgrad");
@@ -543,7 +556,7 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)tiles, (unsigned)splits, (unsigned)taps);
     if (wide) hipLaunchKernelGGL(conv_wgrad_wide_kernel, grid, dim3(512), 0, s, p);
-    else if (d->dtype == KD_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0) hipLaunchKernelGGL(pw_wgrad_tr_kernel, grid, dim3(256), 0, s, p);
+    else if (d->dtype == KD_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0) launch_tr(grid, s, p);
     else if (d->dtype == KD_BF16) hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(pw_wgrad_kernel<float>, grid, dim3(256), 0, s, p);
     KD_CHECK_LAUNCH("kd_conv2d_wgrad");
