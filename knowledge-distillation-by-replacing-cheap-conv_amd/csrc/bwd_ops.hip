@@ -95,20 +95,29 @@ __global__ __launch_bounds__(256) void channel_sums_partial_kernel(const T *__re
     }
 }
 
+// block = 64 channels x 4 chunk lanes: lane l adds chunks l, l+4, ... in order (fp64), the four lane sums are combined in
+// lane order -- a fixed summation tree, hence bit-reproducible
 __global__ __launch_bounds__(256) void channel_sums_finish_kernel(const float *__restrict__ part, int groups, int chunks, int C,
                                                                   float *__restrict__ s1, float *__restrict__ s2)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= groups * C) return;
-    const int grp = i / C, c = i - grp * C;
+    __shared__ double sh[2][4][64];
+    const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6;
+    const int cblocks = (C + 63) / 64;
+    const int grp = blockIdx.x / cblocks, c = (blockIdx.x - grp * cblocks) * 64 + cl;
     double a = 0.0, b = 0.0;
-    for (int k = 0; k < chunks; ++k) {
-        const float *o = part + (((size_t)grp * chunks + k) * 2) * C;
-        a += o[c];
-        b += o[C + c];
+    if (c < C)
+        for (int k = lane; k < chunks; k += 4) {
+            const float *o = part + (((size_t)grp * chunks + k) * 2) * C;
+            a += o[c];
+            b += o[C + c];
+        }
+    sh[0][lane][cl] = a;
+    sh[1][lane][cl] = b;
+    __syncthreads();
+    if (lane == 0 && c < C) {
+        s1[(size_t)grp * C + c] = (float)((sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]));
+        if (s2) s2[(size_t)grp * C + c] = (float)((sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]));
     }
-    s1[i] = (float)a;
-    if (s2) s2[i] = (float)b;
 }
 
 // eval-mode BN parameter gradients from the two channel sums of the gradient w.r.t. the BN INPUT (post ReLU mask):
@@ -439,8 +448,8 @@ extern "C" int kd_relu_bn_bwd(int32_t dtype, const void *g, int32_t ldg, const v
 
 static int cs_chunks(long long rows)
 {
-    long long c = (rows + 511) / 512;        // >= 512 rows (64 per thread) per block; at most 256 chunks (the finishing
-    return (int)(c < 1 ? 1 : (c > 256 ? 256 : c));   // kernel adds them serially per channel)
+    long long c = (rows + 511) / 512;        // >= 512 rows (64 per thread) per block, at most 1024 chunks
+    return (int)(c < 1 ? 1 : (c > 1024 ? 1024 : c));
 }
 
 extern "C" size_t kd_channel_sums_workspace(int32_t groups, int64_t rows_per_group, int32_t C)
@@ -470,8 +479,8 @@ extern "C" int kd_channel_sums(int32_t dtype, const void *g, int32_t ldg, const 
         else hipLaunchKernelGGL((channel_sums_partial_kernel<float, 1>), grid, dim3(256), 0, s, (const float *)g, ldg, (const float *)sub, ldsub, (const float *)a, lda, (long long)rows_per_group, C, chunks, (float *)workspace);
     }
     KD_CHECK_LAUNCH("kd_channel_sums");
-    hipLaunchKernelGGL(channel_sums_finish_kernel, dim3((groups * C + 255) / 256), dim3(256), 0, s, (const float *)workspace, groups,
-                       chunks, C, s1, a ? s2 : (float *)nullptr);
+    hipLaunchKernelGGL(channel_sums_finish_kernel, dim3((unsigned)(groups * ((C + 63) / 64))), dim3(256), 0, s, (const float *)workspace,
+                       groups, chunks, C, s1, a ? s2 : (float *)nullptr);
     KD_CHECK_LAUNCH("kd_channel_sums(finish)");
     return KD_OK;
 }
