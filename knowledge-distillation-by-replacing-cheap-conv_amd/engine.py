@@ -94,6 +94,8 @@ class StudentEngine:
         self.is_gscnn = net is not None and hasattr(net, "gate1")
         self._gate_prm = {}
         self.edge_prior = None   # (N,H,W) fp32 Canny map handed in by the caller (teacher and student share one per batch)
+        self.exported = None     # inputs of block k kept for the student (forward(export_at=k))
+        self._next_prefix = None
 
     def compute_edge_prior(self, x_nchw):
         """The Canny prior of the batch: the device kernel, or the model's `canny_fn` plug point (tests feed the goldens' map)."""
@@ -200,8 +202,44 @@ class StudentEngine:
                 raise EngineError(f"{name}: expected an IdentityResidualBlock")
         return flat
 
-    def forward(self, x, collect_hints=True):
-        """x: (N,3,H,W) fp32.  Returns (logits (N,H,W,19) fp32 NHWC, [hint tensors (N,h,w,C) NHWC] in forward order)."""
+    # ------------------------------------------------------------------ frozen-prefix sharing (opt-in)
+    def shareable_prefix(self, teacher_engine):
+        """Number of leading residual blocks (after the stem / pool2) this student shares with the teacher: same module
+        types and bit-identical, frozen parameters and buffers -- which is how DepthwiseStudent builds the student (a deep copy
+        of the frozen teacher) up to the first replaced or unfrozen block.  Activations of that prefix are then
+        identical in both networks and can be computed once.  Hinted / probed blocks end the prefix."""
+        if self.is_gscnn or teacher_engine.is_gscnn or self.dtype != teacher_engine.dtype:
+            return 0
+        sn, tn = self.net, teacher_engine.net
+        key = tuple((id(p), p._version, p.requires_grad) for p in sn.parameters()) + tuple(self.hint_names) + tuple(self.probe_names)
+        ent = getattr(self, "_prefix_cache", None)
+        if ent is not None and ent[0] == key and ent[1] is tn:
+            return ent[2]
+
+        def same(a, b):
+            sa, sb = a.state_dict(), b.state_dict()
+            if list(sa) != list(sb) or any(p.requires_grad for p in a.parameters()):
+                return False
+            return all(type(x) is type(y) for x, y in zip(a.modules(), b.modules())) and \
+                all(sa[k].shape == sb[k].shape and sa[k].device == sb[k].device and torch.equal(sa[k], sb[k]) for k in sa)
+        k = 0
+        if same(sn.mod1, tn.mod1):
+            sflat, tflat = self._flat_blocks(), teacher_engine._flat_blocks()
+            named = set(self.hint_names) | set(self.probe_names)
+            for (name, sb), (_, tb) in zip(sflat, tflat):
+                if any(h == name or h.startswith(name + ".") for h in named) or not same(sb, tb):
+                    break
+                k += 1
+            # block k itself starts from a tensor the previous epilogue produced with block k's bn1: that must be shared too
+            while k > 0 and k < len(sflat) and not same(sflat[k][1].bn1, tflat[k][1].bn1):
+                k -= 1
+        self._prefix_cache = (key, tn, k)
+        return k
+
+    def forward(self, x, collect_hints=True, export_at=None, prefix=None):
+        """x: (N,3,H,W) fp32.  Returns (logits (N,H,W,19) fp32 NHWC, [hint tensors (N,h,w,C) NHWC] in forward order).
+        export_at = k: also keep the inputs of residual block k in self.exported (the teacher's side of prefix sharing);
+        prefix: such an export from the teacher -- the stem, the pools and the blocks before k are not recomputed."""
         net = self.net
         if x.dim() != 4 or x.shape[1] != 3:
             raise EngineError(f"expected an (N,3,H,W) batch, got {tuple(x.shape)}")
@@ -224,19 +262,30 @@ class StudentEngine:
         xin = x.detach()
         if xin.dtype != torch.float32 or not xin.is_contiguous():
             xin = xin.float().contiguous()
-        stem = net.mod1.conv1
-        stem_w = stem.weight.detach()
-        s = ops.stem_conv(xin, stem_w if stem_w.is_contiguous() else stem_w.contiguous(), self.dtype)
-        rg = stem.weight.requires_grad
-        tape["stem"] = dict(x=xin, s=s, rg=rg)
-
         flat = self._flat_blocks()
-        # pool2 (+ bn1 of mod2.block1)
-        sc1, sh1 = self._bn_fold(flat[0][1].bn1)
-        _, a = ops.maxpool3x3s2(s, sc1, sh1, want_raw=False)
-        x_raw = None
-        m2 = None
+        start = 0
+        if prefix is None:
+            stem = net.mod1.conv1
+            stem_w = stem.weight.detach()
+            s = ops.stem_conv(xin, stem_w if stem_w.is_contiguous() else stem_w.contiguous(), self.dtype)
+            rg = stem.weight.requires_grad
+            tape["stem"] = dict(x=xin, s=s, rg=rg)
+            # pool2 (+ bn1 of mod2.block1)
+            sc1, sh1 = self._bn_fold(flat[0][1].bn1)
+            _, a = ops.maxpool3x3s2(s, sc1, sh1, want_raw=False)
+            x_raw = None
+            m2 = None
+        else:   # the teacher computed everything up to block `start` on identical frozen weights
+            start, a, x_raw, m2, s, rg = prefix["k"], prefix["a"], prefix["x_raw"], prefix["m2"], None, False
+            tape["blocks"] = [None] * start
+            if prefix["pool3"] is not None:
+                tape["pools"]["pool3"] = dict(prefix["pool3"], rg=False)
+        self.exported = None
         for bi, (name, blk) in enumerate(flat):
+            if bi < start:
+                continue
+            if export_at is not None and bi == export_at:
+                self.exported = dict(k=bi, a=a, x_raw=x_raw, m2=m2, pool3=tape["pools"].get("pool3"))
             last_of_mod2 = name.startswith("mod2.") and (bi + 1 == len(flat) or not flat[bi + 1][0].startswith("mod2."))
             is_last = bi + 1 == len(flat)
             nxt = None if (is_last or last_of_mod2) else flat[bi + 1][1]
@@ -577,6 +626,8 @@ class StudentEngine:
         pool3 = tape["pools"]["pool3"]
         for bi in range(nb - 1, -1, -1):
             rec = tape["blocks"][bi]
+            if rec is None:     # a block of the shared frozen prefix: nothing trainable lies there
+                continue
             g_out = g_block_out.pop(bi, None)
             has_inner = any((bi, i) in g_site_hint for i in range(len(rec["sites"])))
             if g_out is None and not has_inner:
@@ -902,7 +953,7 @@ class _StudentFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine, x, *params):
         ctx.set_materialize_grads(False)
-        logits, hints = engine.forward(x)
+        logits, hints = engine.forward(x, prefix=engine._next_prefix)
         ctx.engine, ctx.params = engine, params
         outs = (logits.permute(0, 3, 1, 2),) + tuple(h.permute(0, 3, 1, 2) for h in hints)
         return outs
@@ -913,8 +964,17 @@ class _StudentFunction(torch.autograd.Function):
         return (None, None) + tuple(grads.get(p) for p in ctx.params)
 
 
-def run_student(engine, x):
-    """Differentiable student call: returns (logits NCHW-logical fp32, [hints NCHW-logical])."""
+def run_student(engine, x, prefix=None):
+    """Differentiable student call: returns (logits NCHW-logical fp32, [hints NCHW-logical]).  prefix: the teacher engine's
+    export of the shared frozen prefix (StudentEngine.shareable_prefix), or None."""
+    engine._next_prefix = prefix
+    try:
+        return _run_student(engine, x, prefix)
+    finally:
+        engine._next_prefix = None
+
+
+def _run_student(engine, x, prefix):
     params = tuple(p for p in engine.net.parameters() if p.requires_grad)
     if torch.is_grad_enabled() and (params or engine.probe_names):
         if not params:   # probes only: autograd still needs one differentiable input to build the node
@@ -925,7 +985,7 @@ def run_student(engine, x):
         finally:
             engine._probe_active = False
     else:
-        logits, hints = engine.forward(x)
+        logits, hints = engine.forward(x, prefix=prefix)
         engine._tape = None
         outs = (logits.permute(0, 3, 1, 2),) + tuple(h.permute(0, 3, 1, 2) for h in hints)
     return outs[0], list(outs[1:])

@@ -225,3 +225,37 @@ def test_p92_step_midsize_vs_network_oracle():
             n_grads += 1
             assert relerr(p.grad, r["grads"][n])[1] < 1e-3, n
     assert n_grads == 12
+
+
+def test_shared_frozen_prefix_is_bit_identical(golden):
+    """Opt-in prefix sharing: the student reuses the teacher's activations of the layers both networks hold bit-identical and
+    frozen (stem .. the block before the first cheap conv).  Everything -- logits, hints, every gradient -- must equal the
+    two-full-forwards result bit for bit (same kernels on the same inputs), and the prefix must end where the plan starts."""
+    from kdcc_amd import losses
+    g = golden("student_step_g4")
+    plan = [str(s) for s in g["plan"]]
+    x = seeded_input(str(g["x_key"]), (2, 3, 64, 128)).cuda()
+
+    def run(share):
+        model = build_model(plan, torch.bfloat16)
+        model.share_frozen_prefix = share
+        out_st, out_tc = model(x)
+        crit = losses.MSELoss(num_classes=1000)
+        hint = 0
+        for s, t in zip(model.student_hidden_outputs, model.teacher_hidden_outputs):
+            hint = hint + crit(s, t)
+        hint.backward()
+        torch.cuda.synchronize()
+        return model, out_st, out_tc, hint
+    m0, s0, t0, h0 = run(False)
+    m1, s1, t1, h1 = run(True)
+    k = m1._student_engine().shareable_prefix(m1._teacher_engine)
+    names = [n for n, _ in m1._student_engine()._flat_blocks()]
+    assert names[k] == "mod4.block2"          # first block holding a cheap conv (plan g4): mod2, mod3, mod4.block1 are shared
+    assert torch.equal(s0, s1) and torch.equal(t0, t1) and torch.equal(h0.detach(), h1.detach())
+    for (n0, p0), (n1, p1) in zip(m0.student.named_parameters(), m1.student.named_parameters()):
+        if p0.requires_grad:
+            assert torch.equal(p0.grad, p1.grad), n0
+    # unfreezing a prefix layer or hinting inside it shortens the shared part
+    m1.student.mod3.block2.convs.conv1.weight.requires_grad = True
+    assert names[m1._student_engine().shareable_prefix(m1._teacher_engine)] == "mod3.block2"
