@@ -54,6 +54,7 @@ struct DwMfmaParams {
     int N, H, W, C, dil, ldx, ldy;
     int nty, ntx, ncg;
     int nitems, nseg;    // work items per (image, channel group); segments they are split into
+    int dbg;             // timing-only ablation hook (KDCC_DW_DBG): 1 = no MFMA phase, 2 = no output phase, 4 = no LDS fill of the next tile
 };
 
 struct Item {
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
                         if (step == 9) fetch_unit(3, p, xb, wn, tid, st);
                         if (step == 12) fetch_unit(4, p, xb, wn, tid, st);
                     }
-                    if (mt < nmt && jt < njt) {
+                    if (mt < nmt && jt < njt && !(p.dbg & 1)) {
                         const char *xa = xc + ((mt ? m1 : 0) + fi) * RSTR + min(jt * 16, jlast) * 2;
 #pragma unroll
                         for (int ky = 0; ky < 9; ++ky) {
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
         // ---- 3. accumulators -> [pixel][16 ch] bf16 -> NHWC ------------------------------------------------------------------
         // staging rows are OPX pixels wide so the last (overlapping) column tile can be written whole; the 4-B channel
         // pair of wave w goes to slot w ^ (col & 7) of the pixel's 32 B (spreads the 16 lanes of a tile row over banks)
-        {
+        if (!(p.dbg & 2)) {
             char *ob = X + ((kg * 4) * OPX + fi) * OSTR;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
             }
         }
         __syncthreads();
-        {
+        if (!(p.dbg & 2)) {
             // thread = (8-channel half, column, row mod 4): no divisions, 16-B loads/stores
             const int h = tid & 1, col = (tid >> 1) & 63, rq = tid >> 7;
             if (col < CV) {
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
 
         // ---- 4. prefetched registers -> the other X buffer -----------------------------------------------------------------
         buf ^= 1;
-        write_item(smem + buf * XBYTES, tid, st);
+        if (!(p.dbg & 4)) write_item(smem + buf * XBYTES, tid, st);
         __syncthreads();
         cur = nxt;
         wi = wn;
@@ -528,6 +529,7 @@ int kd_internal_dw_mfma_fwd(const kd_dw_desc *d, const void *x, const float *w_t
     }
     if (!enabled) return 0;
     p.x = (const bf16_t *)x; p.w = w_taps; p.y = (bf16_t *)y;
+    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("KDCC_DW_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.dil = d->dil; p.ldx = d->ldx; p.ldy = d->ldy;
     dw_mfma_split(d->N, d->C, d->H, d->W, d->dil, &p.nty, &p.ntx, &p.nitems, &p.nseg);
     p.ncg = d->C / CG;
