@@ -187,6 +187,7 @@ def main():
     ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full"],
                     help="sample: one 512x1024 CPU step scaled by pixels (default, bounded); full: BASELINE.md section 3 "
                          "(1 warm-up + 2 steps at 1024x2048 + 5 steps at 256x512; several minutes)")
+    ap.add_argument("--layer-table", default=None, help="write a per-conv-shape timing table (tsv) to this path")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the 1 and 2 images/GPU side measurements")
     ap.add_argument("--no-overlap", action="store_true", help="with --teacher torch: run the teacher on the main stream")
     ap.add_argument("--ref-logging", action="store_true",
@@ -246,6 +247,18 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     ops.PROFILER = None
+    if a.layer_table and rank == 0:
+        # per conv shape: launches per step, mean duration, TFLOP/s (live HIP events, same records as the roofline)
+        agg = {}
+        for p in prof:
+            if p[0] == "conv_igemm":
+                e = agg.setdefault(p[4], [0, 0.0, p[1]])
+                e[0] += 1
+                e[1] += p[2].elapsed_time(p[3])
+        with open(a.layer_table, "w") as f:
+            f.write("shape\tlaunches_per_step\tavg_ms\tTFLOP/s\tms_per_step\n")
+            for k, (cnt, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                f.write(f"{k}\t{cnt / a.steps:g}\t{ms / cnt:.4f}\t{fl * cnt / ms / 1e9:.0f}\t{ms / a.steps:.3f}\n")
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

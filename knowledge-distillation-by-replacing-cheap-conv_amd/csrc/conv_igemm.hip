@@ -36,25 +36,27 @@ template <int MI_, int WM_, int WN_, int NST_, int RB_, int WPE_ = 2, int PIPE_ 
     static constexpr int BM = WM * MI * 16, BN = WN * 64;
     static constexpr int STAGE_A = BM * RB, STAGE_B = BN * RB, STAGE = STAGE_A + STAGE_B;
     static constexpr int PR = 1024 / RB;                        // rows per 1-KiB LDS-DMA piece
-    static constexpr int GA = BM / PR / 8, GB = BN / PR / 8;    // pieces per wave per stage (A, B)
+    static constexpr int NW = WM * WN;                           // waves per workgroup
+    static constexpr int GA = BM / PR / NW, GB = BN / PR / NW;  // pieces per wave per stage (A, B)
     static constexpr int LDS_BYTES = NST * STAGE;
-    static_assert(WM * WN == 8, "8 waves");
-    static_assert(8 * 32 * EP_LD * 4 <= LDS_BYTES && 8 * 16 * MI * 128 <= LDS_BYTES, "epilogue patches must fit the stage buffers");
+    static_assert(NW * 32 * EP_LD * 4 <= LDS_BYTES && NW * 16 * MI * 128 <= LDS_BYTES, "epilogue patches must fit the stage buffers");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 typedef Cfg<4, 4, 2, 3, 128> CfgNarrow;
 typedef Cfg<8, 2, 4, 2, 128, 2, 1> CfgWide;   // bf16: software-pipelined main loop (see conv_igemm_row_kernel)
 typedef Cfg<8, 2, 4, 2, 128> CfgWideF;        // fp32 parity path
 typedef Cfg<8, 2, 4, 4, 64> CfgDeep;     // A/B runs only: KDCC_CONV_CFG=deep
+typedef Cfg<8, 2, 2, 3, 64, 2> CfgHalf;      // 256 x 128, FOUR waves of 128x64, 72 KiB: two workgroups per CU (A/B: KDCC_CONV_CFG=half)
 typedef Cfg<4, 4, 2, 3, 64, 4> CfgNarrow2;   // 256 x 128 with 64-B K stages, 72 KiB, <= 128 VGPRs: two workgroups per CU
 
 __device__ __attribute__((aligned(256))) uint32_t kd_zero_page[64];  // zero-initialised
+__device__ unsigned long long kd_conv_tlog[256 * 32 * 8 + 256 * 64];   // KDCC_CONV_TUNE=512: per-workgroup, per-tile timestamps (debug)
 
 struct ConvParams {
     const void *x;
     const void *w;
     int M, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil, ldx;
-    int HoWo, nkc, nk, Ktot, tiles_n;
+    int HoWo, nkc, nk, Ktot, tiles_n, ntiles;
     int vec_ok;  // every epilogue pointer/stride is 16-B friendly
     int epi_batch;  // A/B hook: 0 = one pass at a time (KDCC_EPI_BATCH=0)
     int tune;       // A/B hook (KDCC_CONV_TUNE)
@@ -104,7 +106,8 @@ __device__ __forceinline__ void ig_epilogue(const ConvParams &p, char *lds, f32x
     float mscale[8], ascale[8], ashift[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { mscale[q] = 1.f; ascale[q] = 1.f; ashift[q] = 0.f; }
-    if (!(p.tune & 32) && __all(valid == 8)) {
+    if (p.tune & 256) {
+    } else if (!(p.tune & 32) && __all(valid == 8)) {
         if (e.mask_scale) ld8(e.mask_scale + c0, mscale);
         if (e.act_scale) ld8(e.act_scale + c0, ascale);
         if (e.act_shift) ld8(e.act_shift + c0, ashift);
@@ -212,7 +215,7 @@ __device__ __forceinline__ void ig_epilogue(const ConvParams &p, char *lds, f32x
 #pragma unroll
                         for (int q = 0; q < 8; ++q) v[q] += t[q];
                     }
-                    if (e.out_raw) {
+                    if (e.out_raw && !(p.tune & 128)) {
                         if (e.raw_f32) st8((float *)e.out_raw + (size_t)m * e.ld_raw + c0, v);
                         else if (p16 && !e.res_pre && !e.mask && !e.res_post) *(uint4 *)((T *)e.out_raw + (size_t)m * e.ld_raw + c0) = rawv;
                         else st8((T *)e.out_raw + (size_t)m * e.ld_raw + c0, v);
@@ -223,7 +226,7 @@ __device__ __forceinline__ void ig_epilogue(const ConvParams &p, char *lds, f32x
                             const float a = v[q] * ascale[q] + ashift[q];
                             t[q] = e.act_relu ? fmaxf(a, 0.f) : a;
                         }
-                        st8((T *)e.out_act + (size_t)m * e.ld_act + c0, t);
+                        if (!(p.tune & 128) || t[0] == 1.2345f) st8((T *)e.out_act + (size_t)m * e.ld_act + c0, t);   // 128: timing ablation
                     }
                 }
                 }
@@ -288,7 +291,7 @@ __device__ __forceinline__ void ig_epilogue(const ConvParams &p, char *lds, f32x
 }
 
 template <typename T, typename CF>
-__global__ __launch_bounds__(512, CF::WPE) void conv_igemm_kernel(const ConvParams p)
+__global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_kernel(const ConvParams p)
 {
     // One LDS array: the DMA is issued through inline asm, so hipcc sees only the fragment reads and inserts no waits.
     __shared__ __attribute__((aligned(16))) char lds[CF::LDS_BYTES];
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(512, CF::WPE) void conv_igemm_kernel(const ConvPara
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();  // every wave is done reading the stage buffers
 
-    ig_epilogue<T, MI, (CF::WPE > 2 ? 1 : 4)>(p, lds, acc, m0, n0, wm, wn, wv, lane);
+    if (!(p.tune & 64)) ig_epilogue<T, MI, (CF::WPE > 2 ? 1 : 4)>(p, lds, acc, m0, n0, wm, wn, wv, lane);   // 64: timing ablation
 }
 
 // ---- 3x3 / stride 1 / 'same' convolutions whose 256-pixel tiles are segments of one image row -----------------------------
@@ -472,6 +475,8 @@ typedef CfgRowT<8, 2, 4, 128, 320, 2, 2, 4, 1> CfgRow;    // 256 x 256, 144 KiB:
 typedef CfgRowT<8, 2, 4, 128, 384, 2, 2, 4, 1> CfgRowX;   // 256 x 256, 160 KiB: dil <= 64 (ASPP rate 36)
 typedef CfgRowT<8, 2, 4, 128, 320, 2, 2> CfgRowF;         // fp32 parity path: plain loop (blocked accumulation)
 typedef CfgRowT<8, 2, 4, 128, 384, 2, 2> CfgRowXF;
+typedef CfgRowT<8, 2, 2, 64, 320, 3, 2> CfgRowH;    // 256 x 128, FOUR waves of 128x64, 64-B K stages, 64 KiB: two workgroups per CU
+typedef CfgRowT<8, 2, 2, 64, 384, 3, 2> CfgRowHX;   // ... dil <= 64, 72 KiB
 typedef CfgRowT<4, 4, 2, 64, 384, 3, 4> CfgRowN;    // 256 x 128 with 64-B K stages, 72 KiB, <= 128 VGPRs: two workgroups per CU
 
 template <typename T, typename CF>
@@ -675,7 +680,466 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_row_kernel(co
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();  // every wave is done reading the buffers
-    ig_epilogue<T, MI, (CF::WPE > 2 ? 1 : 4), NJ>(p, lds, acc, m0, n0, wm, wn, wv, lane);
+    if (!(p.tune & 64)) ig_epilogue<T, MI, (CF::WPE > 2 ? 1 : 4), NJ>(p, lds, acc, m0, n0, wm, wn, wv, lane);
+}
+
+// ---- persistent bf16 kernels: one workgroup per CU walks its XCD's tiles -----------------------------------------------------
+// Measured on the one-tile-per-workgroup kernels above (KDCC_CONV_TUNE=64/128 ablations, r02): the epilogue is 21 % of the
+// conv time of a train step, more than half of that the output stores themselves -- every CU reaches its epilogue at the
+// same moment, the burst drains at the fabric's ~5 TB/s with nothing else running, and a workgroup cannot retire (nor its
+// successor start: LDS) before its stores are acknowledged.  Two workgroups per CU (256 x 128 tiles) hide that but lose more
+// in the main loop (1.5x the staging traffic): -10 %.  Here instead the workgroup stays resident and walks tiles:
+//   * the epilogue transposes through a small wave-private LDS patch that lies outside the stage buffers (16 KiB in all);
+//   * the stage buffers are therefore free when the main loop ends: the first stages of the NEXT tile are issued before the epilogue, so
+//     its pipeline fill overlaps the epilogue, and -- vmcnt retiring in issue order -- those DMAs are OLDER than the
+//     epilogue's stores: the next main loop starts after a counted wait that leaves exactly the stores outstanding, which
+//     then drain under its first two K stages instead of in front of an idle CU.
+// Conditions (host side): bf16 in and out, M % 256 == 0, Cout % BN == 0, 16-B friendly epilogue operands, dil <= 32.
+__device__ __forceinline__ void wait_vm_stores(int nst)
+{
+    // at most nst (= 16 * outputs) younger stores may stay outstanding; everything older -- the prologue DMAs -- has landed
+    if (nst == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+    else if (nst == 32) asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
+    else if (nst == 48) asm volatile("s_waitcnt vmcnt(48) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+// Accumulators -> memory through a wave-private 2-KiB LDS patch OUTSIDE the stage buffers (which the next tile's prologue is
+// already filling): one 16-pixel x 64-channel row tile at a time is written as bf16 (8-B chunk c of row r at c ^ r), then
+// read back as two passes of 8 rows x 128 B, 16 B per lane -- whole 128-B lines per pixel for the operand loads and the
+// stores (8-B accumulator-layout accesses straight to memory, 32-B pieces of 32 lines per instruction, measured 7-40 %
+// slower per layer).  Arithmetic and rounding are those of ig_epilogue's bf16 fast path.
+// Operand loads (residuals, mask): vmcnt retires in issue order, so a load issued after a batch of stores returns only once
+// those stores are acknowledged -- with load -> store -> load per 32 rows the [res_pre, raw, act] epilogue of a 512-channel
+// 3x3 tile took 21 us against 5.6 us without operands (tools/conv_timeline.py).  The host passes at most two operands
+// (slot 0 / slot 1 in the order res_pre, mask, res_post): a single operand is loaded for the whole 128-row sub-tile up
+// front, two operands for 64 rows at a time (one store -> load hand-over instead of three).  Issues exactly 16 stores per
+// output and lane.
+template <int MI, int NOPS>
+__device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *patch, f32x4_t (&acc)[MI][4], int mw, int nw,
+                                                   int lane)
+{
+    typedef bf16_t T;
+    static_assert(MI == 8 && NOPS >= 0 && NOPS <= 2, "128-row wave sub-tiles, at most two operands");
+    const kd_conv_epilogue &e = p.ep;
+    // every per-lane address below derives from this copy: the compiler cannot hoist them out of the tile loop into
+    // registers that would stay live through the main loop (which runs at the 256-VGPR limit)
+    asm volatile("" : "+v"(lane));
+    const int frow = lane & 15, fq = lane >> 4;
+    const int c0 = nw + (lane & 7) * 8, lrow = lane >> 3, c2 = (lane & 7) * 2;
+    float mscale[8], ascale[8], ashift[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { mscale[q] = 1.f; ascale[q] = 1.f; ashift[q] = 0.f; }
+    if (e.mask_scale) ld8(e.mask_scale + c0, mscale);
+    if (e.act_scale) ld8(e.act_scale + c0, ascale);
+    if (e.act_shift) ld8(e.act_shift + c0, ashift);
+    // operand slots
+    const bool has_p = e.res_pre != nullptr, has_m = e.mask != nullptr, has_q = e.res_post != nullptr;
+    const T *s0 = (const T *)(has_p ? e.res_pre : has_m ? e.mask : e.res_post);
+    const int ld0 = has_p ? e.ld_res_pre : has_m ? e.ld_mask : e.ld_res_post;
+    const T *s1 = (const T *)(has_p && has_m ? e.mask : e.res_post);
+    const int ld1 = has_p && has_m ? e.ld_mask : e.ld_res_post;
+    constexpr int nops = NOPS;   // == operands present (host)
+    const bool m_in1 = has_p && has_m, q_in1 = has_q && nops == 2;
+    // 64 rows (8 passes) of up to two operands in flight: one operand -> ra = rows 0..63, rb = rows 64..127, both loaded up
+    // front; two operands -> ra / rb = slot 0 / slot 1 of the current 64 rows.  The accumulators are rounded to packed bf16
+    // in place right after the first loads are issued (the patch holds bf16 anyway), which halves their registers.
+    uint4 ra[8], rb[8];
+    auto rowof = [&](int pass) { return (size_t)(mw + pass * 8 + lrow); };
+    auto load64 = [&](const T *src, int ld, int hb, uint4 (&r)[8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) r[ps] = *(const uint4 *)(src + rowof(hb * 8 + ps) * ld + c0);
+    };
+    // pack first (frees half the accumulator registers), then the loads: no spills
+    uint2 pk[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pk[i][j] = make_uint2(pack_bf16x2(acc[i][j][0], acc[i][j][1]), pack_bf16x2(acc[i][j][2], acc[i][j][3]));
+    if (nops >= 1) load64(s0, ld0, 0, ra);
+    if (nops == 2) load64(s1, ld1, 0, rb);
+    if (nops == 1) load64(s0, ld0, 1, rb);
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {   // 64 rows each
+        if (nops == 2 && hb == 1) { load64(s0, ld0, 1, ra); load64(s1, ld1, 1, rb); }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = 4 * hb + ii;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(uint2 *)(patch + frow * 128 + (((j * 4 + fq) ^ frow) << 3)) = pk[i][j];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = h * 8 + lrow, ps = 2 * ii + h;       // ps: 8-row group inside the 64 rows
+                const size_t m = rowof(hb * 8 + ps);
+                const uint2 lo = *(const uint2 *)(patch + row * 128 + ((c2 ^ row) << 3));
+                const uint2 hi = *(const uint2 *)(patch + row * 128 + (((c2 + 1) ^ row) << 3));
+                const uint4 rawv = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                float v[8], t[8];
+                ld8((const bf16_t *)&rawv, v);
+                const uint4 o0 = (hb == 1 && nops == 1) ? rb[ps] : ra[ps], o1 = rb[ps];
+                if (has_p) {
+                    ld8((const T *)&o0, t);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] += t[q];
+                }
+                if (has_m) {
+                    const uint4 om = m_in1 ? o1 : o0;
+                    ld8((const T *)&om, t);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = t[q] > 0.f ? v[q] * mscale[q] : 0.f;
+                }
+                if (has_q) {
+                    const uint4 oq = q_in1 ? o1 : o0;
+                    ld8((const T *)&oq, t);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] += t[q];
+                }
+                if (e.out_raw && !(p.tune & 128)) {
+                    if (nops == 0) *(uint4 *)((T *)e.out_raw + m * e.ld_raw + c0) = rawv;
+                    else st8((T *)e.out_raw + m * e.ld_raw + c0, v);
+                }
+                if (e.out_act) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float a = v[q] * ascale[q] + ashift[q];
+                        t[q] = e.act_relu ? fmaxf(a, 0.f) : a;
+                    }
+                    if (!(p.tune & 128) || t[0] == 1.2345f) st8((T *)e.out_act + m * e.ld_act + c0, t);   // 128: timing ablation
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+// the tiles of this workgroup: XCD x owns a contiguous range of tile ids (as xcd_remap deals them), its workgroups take
+// them round-robin, so the tiles in flight on one XCD at any time are neighbours (shared image rows / weight slabs in L2)
+struct TileWalk {
+    int t, t_end, step;
+    __device__ __forceinline__ TileWalk(int nt)
+    {
+        const int xcd = blockIdx.x & 7, q = nt >> 3, r = nt & 7;
+        t = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        t_end = t + q + (xcd < r ? 1 : 0);
+        t += blockIdx.x >> 3;
+        step = gridDim.x >> 3;
+    }
+};
+
+template <typename CF, int NOPS, bool DBG = false>
+__global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_row_persist_kernel(const ConvParams p)
+{
+    typedef bf16_t T;
+    static_assert(CF::PIPE && CF::RB == 128 && CF::NBS == 2, "bf16 pipelined configuration");
+    static_assert(CF::NEED + CF::NW * 2048 <= 160 * 1024, "stage buffers + epilogue patches");
+    __shared__ __attribute__((aligned(16))) char lds[CF::NEED + CF::NW * 2048];
+    constexpr int RB = CF::RB, BK = RB / 2, EPC = 8;
+    constexpr int MI = CF::MI, NJ = CF::NJ, GAR = CF::GAR, GB = CF::GB, PR = CF::PR, CPR = RB / 16;
+    char *const ldsB = lds + 2 * CF::ABUF;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv / CF::WN, wn = wv % CF::WN;
+    const T *__restrict__ xg = (const T *)p.x;
+    const T *__restrict__ wg = (const T *)p.w;
+    const T *zero = (const T *)kd_zero_page;
+    const int d = p.dil;
+    TileWalk walk(p.ntiles);
+    if (walk.t >= walk.t_end) return;
+
+    const int srow = lane / CPR;
+    const int chunk = (lane & 7) ^ srow;
+    const int frow = lane & 15, fq = lane >> 4;
+
+    // ---- per-tile staging state (see conv_igemm_row_kernel) ------------------------------------------------------------------
+    int m0 = 0, n0 = 0, ky_lo = 0, ky_hi = 0, nu = 0, ns = 0;
+    // Every wave stages its own GAR / GB pieces of a stage, but the two waves of a SIMD (wv and wv + NW/2: a workgroup's waves
+    // go to the SIMDs cyclically) do so at different points of the stage.  Phase clocks (KDCC_CONV_TUNE=512,
+    // tools/conv_timeline.py) show the hand-over as the main loop's loss: the ~45 KiB of a stage are 45 LDS-DMA instructions
+    // on the CU's one vector-memory path, each holds its wave for 100-160 cycles while the others queue, and with all eight
+    // waves issuing right after the barrier no MFMA is issued for 620-820 cycles of a 3150-cycle stage (its MFMAs need 2048).
+    // The "early" waves issue after the barrier, the "late" ones after their second MFMA block, so one wave of each SIMD has
+    // MFMAs to issue meanwhile: -1.4 % step time.  (Pieces placed between the MFMAs of the block cost 200+ cycles each:
+    // 3150 -> 4000 cycles per stage; one wave per SIMD issuing everything: 3060.)
+    // Piece j of a wave lies j * PR rows after its piece 0: no offset arrays; the pieces of a group share one M0 value.
+    constexpr int GAR2 = GAR, GB2 = GB;
+    const bool early = (p.tune & 2048) ? true : wv < CF::NW / 2;   // 2048: A/B, every wave issues right after the barrier
+    int a_off0 = 0, b_off0 = 0;
+    uint32_t a_ok = 0;
+    int u_cb = 0, u_ky = 0, u_idx = 0, s_cb = 0, s_ky = 0, s_kx = 0, s_idx = 0;
+    auto setup = [&](int tile) {
+        const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+        m0 = tm * CF::BM;
+        n0 = tn * CF::BN;
+        const int n = m0 / p.HoWo, rem = m0 - n * p.HoWo;
+        const int ho = rem / p.W, x0 = rem - ho * p.W;
+        ky_lo = ho - d < 0 ? 1 : 0;
+        ky_hi = ho + d >= p.H ? 1 : 2;
+        nu = p.nkc * (ky_hi - ky_lo + 1);
+        ns = nu * 3;
+        a_ok = 0;
+        const int r0 = wv * GAR2 * PR + srow;            // buffer row of piece 0: pixel x0 - d + r0 (loader waves)
+#pragma unroll
+        for (int j = 0; j < GAR2; ++j) {
+            const int r = r0 + j * PR, x = x0 - d + r;
+            a_ok |= (r < CF::BM + 2 * d && x >= 0 && x < p.W) ? (1u << j) : 0u;
+        }
+        a_off0 = ((n * p.H + ho) * p.W + (x0 - d + r0)) * p.ldx + chunk * EPC;   // may point before the row: masked by a_ok
+        b_off0 = (n0 + wv * GB2 * PR + srow) * p.Ktot + chunk * EPC;
+        u_cb = 0; u_ky = ky_lo; u_idx = 0;
+        s_cb = 0; s_ky = ky_lo; s_kx = 0; s_idx = 0;
+    };
+    auto stage_a = [&]() {
+        const int row_off = ((u_ky - 1) * d * p.W) * p.ldx + u_cb * BK;
+        char *la = lds + (u_idx & 1) * CF::ABUF + wv * (GAR2 * 1024);
+        static_assert(GAR2 == 5 && GB2 == 4, "piece groups below");
+        const char *ga[GAR2];
+#pragma unroll
+        for (int j = 0; j < GAR2; ++j)   // source of piece j, reduced by the instruction offset of that piece
+            ga[j] = (const char *)(((a_ok >> j) & 1u) ? xg + (a_off0 + j * PR * p.ldx + row_off) : zero) - (j - 2) * 1024;
+        glds16_x5(ga[0], ga[1], ga[2], ga[3], ga[4], la + 2048);
+        ++u_idx;
+        if (++u_ky > ky_hi) { u_ky = ky_lo; ++u_cb; }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto stage_b = [&]() {
+        const int w_off = (s_ky * 3 + s_kx) * p.Cin + s_cb * BK;
+        char *lb = ldsB + (s_idx & 1) * CF::BSTAGE + wv * (GB2 * 1024);
+        const char *gb[GB2];
+#pragma unroll
+        for (int j = 0; j < GB2; ++j) gb[j] = (const char *)(wg + (b_off0 + j * PR * p.Ktot + w_off)) - j * 1024;
+        glds16_x4(gb[0], gb[1], gb[2], gb[3], lb);
+        ++s_idx;
+        if (++s_kx == 3) {
+            s_kx = 0;
+            if (++s_ky > ky_hi) { s_ky = ky_lo; ++s_cb; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto prologue = [&]() {   // both row buffers and both B stages are free
+        stage_a();
+        stage_b();
+        stage_b();            // ns >= 6
+        if (nu > 1) stage_a();
+    };
+
+    f32x4_t acc[MI][NJ];
+    uint4 a0[MI], b0[NJ], a1[MI], b1[NJ];
+    auto read_frags = [&](int s, int ks, uint4 (&a)[MI], uint4 (&b)[NJ]) __attribute__((always_inline)) {
+        const int u = s / 3, kx = s - u * 3;
+        const int rsh = frow + kx * d;
+        const char *A = lds + (u & 1) * CF::ABUF + (wm * (16 * MI) + rsh) * RB + (((fq + 4 * ks) ^ (rsh & 7)) << 4);
+        const char *B = ldsB + (s & 1) * CF::BSTAGE + (wn * (16 * NJ) + frow) * RB + (((fq + 4 * ks) ^ (lane & 7)) << 4);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *(const uint4 *)(A + i * 16 * RB);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[j] = *(const uint4 *)(B + j * 16 * RB);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mfmas = [&](const uint4 (&a)[MI], const uint4 (&b)[NJ]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) Mma<T>::run(b[j], a[i], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const int nst_epi = 2 * MI * ((p.ep.out_raw ? 1 : 0) + (p.ep.out_act ? 1 : 0));
+    int nst = 0;   // stores issued after the pending prologue
+    int tcount = 0;
+    setup(walk.t);
+    prologue();
+#pragma unroll 1
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const bool tl = (p.tune & 512) && tid == 0 && tcount < 32;
+        unsigned long long *tlp = kd_conv_tlog + ((size_t)blockIdx.x * 32 + (tcount & 31)) * 8;
+        if (tl) tlp[0] = wall_clock64();
+        wait_vm_stores(nst);
+        if (tl) tlp[1] = wall_clock64();   // the prologue has landed for every wave; the previous tile's stores may still drain
+        read_frags(0, 0, a0, b0);
+        unsigned long long cprev = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ph4 = 0, ph5 = 0;
+#pragma unroll 1
+        for (int s = 0; s < ns; ++s) {
+            if (DBG && s == 1) cprev = clock64();
+            read_frags(s, 1, a1, b1);
+            mfmas(a0, b0);
+            if (s + 1 < ns) {
+                // stage s+1 (and its row buffer) has landed: for s == 0 the prologue wait covered it, and a vmcnt(0) here
+                // would wait for the previous tile's stores
+                if (s == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+                else if (DBG) {   // debug: phase clocks (shader cycles) of this wave, see tools/conv_timeline.py
+                    c1 = clock64();
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    c2 = clock64();
+                    __builtin_amdgcn_s_barrier();
+                    c3 = clock64();
+                }
+                else wait_vm_barrier<0>();
+                if (early) {
+                    if (s + 2 < ns) stage_b();
+                    if ((s + 1) % 3 == 0 && (s + 1) / 3 + 1 < nu) stage_a();
+                }
+                if (DBG) c4 = clock64();
+                read_frags(s + 1, 0, a0, b0);
+                if (DBG) c5 = clock64();
+            }
+            mfmas(a1, b1);
+            if (!early && s + 1 < ns) {
+                if (s + 2 < ns) stage_b();
+                if ((s + 1) % 3 == 0 && (s + 1) / 3 + 1 < nu) stage_a();
+            }
+            if (DBG && s > 0 && s + 1 < ns) {
+                const unsigned long long c6 = clock64();
+                ph0 += c1 - cprev; ph1 += c2 - c1; ph2 += c3 - c2; ph3 += c4 - c3; ph4 += c5 - c4; ph5 += c6 - c5;
+                cprev = c6;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // every wave is done reading the buffers
+        const int mw = m0 + wm * (16 * MI), nw = n0 + wn * (16 * NJ);
+        walk.t += walk.step;
+        const bool more = walk.t < walk.t_end;
+        if (tl) tlp[4] = wall_clock64();
+        if (DBG && lane == 0 && tcount == 1) {   // per-wave phase totals of the second tile
+            unsigned long long *o = kd_conv_tlog + 256 * 32 * 8 + (blockIdx.x * 8 + wv) * 8;
+            o[0] = ph0; o[1] = ph1; o[2] = ph2; o[3] = ph3; o[4] = ph4; o[5] = ph5;
+        }
+        if (more) { setup(walk.t); if (tl) tlp[7] = wall_clock64(); prologue(); }
+        if (tl) tlp[5] = wall_clock64();
+        if (!(p.tune & 64)) ig_epilogue_rows16<MI, NOPS>(p, lds + CF::NEED + wv * 2048, acc, mw, nw, lane);
+        if (tl) tlp[6] = wall_clock64();
+        ++tcount;
+        if (!more) break;
+        nst = (p.tune & (64 | 128)) ? 0 : nst_epi;
+    }
+}
+
+template <typename CF, int NOPS>
+__global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_persist_kernel(const ConvParams p)
+{
+    typedef bf16_t T;
+    static_assert(CF::PIPE && CF::RB == 128 && CF::NST == 2, "bf16 pipelined configuration");
+    static_assert(CF::LDS_BYTES + CF::NW * 2048 <= 160 * 1024, "stage buffers + epilogue patches");
+    __shared__ __attribute__((aligned(16))) char lds[CF::LDS_BYTES + CF::NW * 2048];
+    constexpr int RB = CF::RB, BK = RB / 2, EPC = 8;
+    constexpr int MI = CF::MI, GA = CF::GA, GB = CF::GB, PR = CF::PR, CPR = RB / 16;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv / CF::WN, wn = wv % CF::WN;
+    const T *__restrict__ xg = (const T *)p.x;
+    const T *__restrict__ wg = (const T *)p.w;
+    TileWalk walk(p.ntiles);
+    if (walk.t >= walk.t_end) return;
+
+    const int srow = lane / CPR;
+    const int chunk = (lane & 7) ^ srow;
+    const int frow = lane & 15, fq = lane >> 4;
+    const bool early = (p.tune & 2048) ? true : wv < CF::NW / 2;   // see conv_row_persist_kernel
+
+    // 1x1 / stride 1 / no padding only (host): output pixel m is input pixel m, one tap; piece j of a wave lies j * PR rows
+    // after its piece 0
+    int m0 = 0, n0 = 0, a_off0 = 0, b_off0 = 0, s_kt = 0;
+    auto setup = [&](int tile) {
+        const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+        m0 = tm * CF::BM;
+        n0 = tn * CF::BN;
+        a_off0 = (m0 + wv * GA * PR + srow) * p.ldx + chunk * EPC;
+        b_off0 = (n0 + wv * GB * PR + srow) * p.Ktot + chunk * EPC;
+        s_kt = 0;
+    };
+    auto stage = [&]() {
+        char *la = lds + (s_kt & 1) * CF::STAGE + wv * (GA * 1024);
+        char *lb = lds + (s_kt & 1) * CF::STAGE + CF::STAGE_A + wv * (GB * 1024);
+        static_assert(GA == 4 && GB == 4, "piece groups below");
+        const char *ga[GA], *gb[GB];   // sources reduced by the instruction offset of the piece (one M0 value per group)
+#pragma unroll
+        for (int j = 0; j < GA; ++j) ga[j] = (const char *)(xg + (a_off0 + j * PR * p.ldx + s_kt * BK)) - j * 1024;
+        glds16_x4(ga[0], ga[1], ga[2], ga[3], la);
+#pragma unroll
+        for (int j = 0; j < GB; ++j) gb[j] = (const char *)(wg + (b_off0 + j * PR * p.Ktot + s_kt * BK)) - j * 1024;
+        glds16_x4(gb[0], gb[1], gb[2], gb[3], lb);
+        ++s_kt;
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const int nk = p.nk;
+    auto prologue = [&]() {
+        stage();
+        if (nk > 1) stage();
+    };
+
+    f32x4_t acc[MI][4];
+    uint4 a0[MI], b0[4], a1[MI], b1[4];
+    auto read_frags = [&](int kt, int ks, uint4 (&a)[MI], uint4 (&b)[4]) __attribute__((always_inline)) {
+        const char *sA = lds + (kt & 1) * CF::STAGE;
+        const int sw = ((fq + 4 * ks) ^ (lane & 7)) << 4;
+        const char *A = sA + (wm * 16 * MI + frow) * RB + sw, *B = sA + CF::STAGE_A + (wn * 64 + frow) * RB + sw;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *(const uint4 *)(A + i * 16 * RB);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *(const uint4 *)(B + j * 16 * RB);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mfmas = [&](const uint4 (&a)[MI], const uint4 (&b)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Mma<T>::run(b[j], a[i], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    const int nst_epi = 2 * MI * ((p.ep.out_raw ? 1 : 0) + (p.ep.out_act ? 1 : 0));
+    int nst = 0, tcount = 0;
+    setup(walk.t);
+    prologue();
+#pragma unroll 1
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const bool tl = (p.tune & 512) && tid == 0 && tcount < 32;
+        unsigned long long *tlp = kd_conv_tlog + ((size_t)blockIdx.x * 32 + (tcount & 31)) * 8;
+        if (tl) tlp[0] = wall_clock64();
+        wait_vm_stores(nst);
+        if (tl) tlp[1] = wall_clock64();
+        read_frags(0, 0, a0, b0);
+#pragma unroll 1
+        for (int kt = 0; kt < nk; ++kt) {
+            read_frags(kt, 1, a1, b1);
+            mfmas(a0, b0);
+            if (kt + 1 < nk) {
+                if (kt == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+                else wait_vm_barrier<0>();
+                if (early && kt + 2 < nk) stage();
+                read_frags(kt + 1, 0, a0, b0);
+            }
+            mfmas(a1, b1);
+            if (!early && kt + 2 < nk) stage();   // the sibling wave of the SIMD issued its pieces before this block
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int mw = m0 + wm * (16 * MI), nw = n0 + wn * 64;
+        walk.t += walk.step;
+        const bool more = walk.t < walk.t_end;
+        if (tl) tlp[4] = wall_clock64();
+        if (more) { setup(walk.t); if (tl) tlp[7] = wall_clock64(); prologue(); }
+        if (tl) tlp[5] = wall_clock64();
+        if (!(p.tune & 64)) ig_epilogue_rows16<MI, NOPS>(p, lds + CF::LDS_BYTES + wv * 2048, acc, mw, nw, lane);
+        if (tl) tlp[6] = wall_clock64();
+        ++tcount;
+        if (!more) break;
+        nst = (p.tune & (64 | 128)) ? 0 : nst_epi;
+    }
 }
 
 // ---- weight packing ------------------------------------------------------------------
@@ -754,11 +1218,12 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
     // wide tiles only when they still fill the chip (one workgroup per CU, 256 CUs); e.g. the ASPP 4096->256 1x1 at
     // 128x256 pixels would give 128 wide tiles, so it runs on the narrow config (256 tiles)
     const long long wide_tiles = (long long)((p.M + CfgWide::BM - 1) / CfgWide::BM) * ((d->Cout + CfgWide::BN - 1) / CfgWide::BN);
-    bool norow = false;
+    bool norow = false, half = false;
     int cfg = (d->Cout > 128 && wide_tiles >= 224) ? 1 : 0;   // 0 narrow2, 1 wide, 2 deep, 3 narrow (one workgroup per CU)
     if (const char *e = getenv("KDCC_CONV_CFG")) {              // tuning hook
         if (!strcmp(e, "narrow")) cfg = 0;
         else if (!strcmp(e, "norow")) norow = true;
+        else if (!strcmp(e, "half")) half = true;
         else if (!strcmp(e, "deep") && cfg == 1) cfg = 2;
         else if (!strcmp(e, "narrow1") && cfg == 0) cfg = 3;
     }
@@ -771,7 +1236,7 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         p.nk = d->kh * d->kw * p.nkc;
         p.tiles_n = (d->Cout + CF::BN - 1) / CF::BN;
         const int tiles_m = (p.M + CF::BM - 1) / CF::BM;
-        hipLaunchKernelGGL((conv_igemm_kernel<T, CF>), dim3((unsigned)(tiles_m * p.tiles_n)), dim3(512), 0, s, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, CF>), dim3((unsigned)(tiles_m * p.tiles_n)), dim3(64 * CF::NW), 0, s, p);
     };
     // 256-pixel tiles that are segments of one image row, 3x3 / stride 1 / 'same': row-buffer kernels (the narrow one is
     // compiled for <= 128 VGPRs, which the fp32 parity path's blocked accumulation does not fit)
@@ -779,7 +1244,49 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
     const bool row_wide = row_geom && cfg == 1 && d->dil <= CfgRowX::MAXDIL;
     const bool row_x = row_wide && d->dil > CfgRow::MAXDIL;
     const bool row_narrow = row_geom && cfg == 0 && d->dtype == KD_BF16 && d->dil <= CfgRowN::MAXDIL;
-    if (row_wide || row_narrow) {
+    // persistent kernels (bf16 wide tiles, whole tiles, vector-friendly epilogue): one workgroup per CU walks the tiles
+    static int persist = -1, ncu = 0;
+    if (persist < 0) {
+        const char *v = getenv("KDCC_CONV_PERSIST");
+        persist = !(v && v[0] == '0');
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+            ncu = 256;
+    }
+    const int nops = (ep->res_pre ? 1 : 0) + (ep->mask ? 1 : 0) + (ep->res_post ? 1 : 0);
+    const bool persist_ok = persist && !half && d->dtype == KD_BF16 && cfg == 1 && p.vec_ok && !ep->raw_f32 && nops <= 2 && p.M % 256 == 0 && d->Cout % 256 == 0;
+    auto persist_grid = [&]() {
+        p.tiles_n = d->Cout / 256;
+        p.ntiles = (p.M / 256) * p.tiles_n;
+        const int nwg = p.ntiles < ncu ? p.ntiles : ncu;
+        return dim3((unsigned)((nwg + 7) / 8 * 8));
+    };
+    if (persist_ok && row_wide && !row_x) {
+        p.nkc = d->Cin / (CfgRow::RB / es);
+        p.nk = 9 * p.nkc;
+        const dim3 grid = persist_grid();
+        if (p.tune & 512) {   // phase clocks (tools/conv_timeline.py)
+            if (nops == 0) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 0, true>), grid, dim3(512), 0, s, p);
+            else if (nops == 1) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 1, true>), grid, dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 2, true>), grid, dim3(512), 0, s, p);
+        } else if (nops == 0) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 0>), grid, dim3(512), 0, s, p);
+        else if (nops == 1) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 1>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 2>), grid, dim3(512), 0, s, p);
+    } else if (persist_ok && d->kh == 1 && d->stride == 1 && d->pad == 0) {
+        p.nkc = d->Cin / (CfgWide::RB / es);
+        p.nk = d->kh * d->kw * p.nkc;
+        const dim3 grid = persist_grid();
+        if (nops == 0) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 0>), grid, dim3(512), 0, s, p);
+        else if (nops == 1) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 1>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 2>), grid, dim3(512), 0, s, p);
+    } else if (row_wide && half && d->dtype == KD_BF16) {
+        p.nkc = d->Cin / (CfgRowH::RB / es);
+        p.nk = 9 * p.nkc;
+        p.tiles_n = (d->Cout + CfgRowH::BN - 1) / CfgRowH::BN;
+        const dim3 grid((unsigned)((p.M / 256) * p.tiles_n));
+        if (row_x) hipLaunchKernelGGL((conv_igemm_row_kernel<bf16_t, CfgRowHX>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_row_kernel<bf16_t, CfgRowH>), grid, dim3(256), 0, s, p);
+    } else if (row_wide || row_narrow) {
         p.nkc = d->Cin / ((row_wide ? CfgRow::RB : CfgRowN::RB) / es);
         p.nk = 9 * p.nkc;
         p.tiles_n = (d->Cout + (row_wide ? CfgRow::BN : CfgRowN::BN) - 1) / (row_wide ? CfgRow::BN : CfgRowN::BN);
@@ -791,6 +1298,7 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         else hipLaunchKernelGGL((conv_igemm_row_kernel<float, CfgRowF>), grid, dim3(512), 0, s, p);
     } else if (d->dtype == KD_BF16) {
         if (cfg == 1 && (p.tune & 8)) launch(CfgWideF{}, bf16_t{});   // A/B: plain main loop
+        else if (cfg == 1 && half) launch(CfgHalf{}, bf16_t{});
         else if (cfg == 1) launch(CfgWide{}, bf16_t{});
         else if (cfg == 2) launch(CfgDeep{}, bf16_t{});
         else if (cfg == 3) launch(CfgNarrow{}, bf16_t{});
@@ -802,6 +1310,12 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
     }
     KD_CHECK_LAUNCH("kd_conv2d_fwd");
     return KD_OK;
+}
+
+extern "C" int kd_debug_conv_tlog(unsigned long long *dst, size_t bytes)
+{
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(kd_conv_tlog), bytes < sizeof(kd_conv_tlog) ? bytes : sizeof(kd_conv_tlog), 0,
+                               hipMemcpyDeviceToHost) == hipSuccess ? KD_OK : KD_ERR_HIP;
 }
 
 extern "C" int kd_pack_conv_weight(const float *src, void *dst, int32_t dtype, int32_t mode, int32_t Cout, int32_t Cin,

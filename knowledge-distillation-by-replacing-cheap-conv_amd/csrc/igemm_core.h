@@ -26,6 +26,44 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
 }
 
 
+// Several LDS-DMA pieces under ONE M0 value: the instruction's immediate offset applies to both the global and the LDS address,
+// so piece j goes to (lds_base + OFFj + lane*16) from (gsrc_j + OFFj) -- callers pass gsrc_j already reduced by OFFj bytes.
+// Rewriting M0 per piece serialises a wave's DMA issue at ~110 cycles per piece (measured: the next s_mov m0 waits until the
+// previous global_load_lds has read it); with one M0 per group the pieces issue back to back.
+__device__ __forceinline__ void glds16_x4(const void *g0, const void *g1, const void *g2, const void *g3, void *lds_base)
+{
+    const uint32_t lds_addr =
+        __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)lds_base);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %2, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %3, off offset:2048\n\t"
+                 "global_load_lds_dwordx4 %4, off offset:3072\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "s"(lds_addr)
+                 : "memory");
+}
+// five pieces: lds_base is the address of piece 2 (offsets -2048 .. +2048)
+__device__ __forceinline__ void glds16_x5(const void *g0, const void *g1, const void *g2, const void *g3, const void *g4,
+                                          void *lds_base)
+{
+    const uint32_t lds_addr =
+        __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)lds_base);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:-2048\n\t"
+                 "global_load_lds_dwordx4 %2, off offset:-1024\n\t"
+                 "global_load_lds_dwordx4 %3, off\n\t"
+                 "global_load_lds_dwordx4 %4, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %5, off offset:2048\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "v"(g4), "s"(lds_addr)
+                 : "memory");
+}
+
 // Wait until at most N of this wave's vector-memory operations (here: LDS-DMA pieces) are outstanding and all LDS
 // reads have returned; then a bare barrier.  Unlike __syncthreads() this does not drain the DMA of the stages still
 // in flight, which is what lets the prefetch run NST-1 K stages ahead.

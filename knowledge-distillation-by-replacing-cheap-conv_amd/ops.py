@@ -128,7 +128,9 @@ def conv2d(x, w_packed, stride=1, pad=0, dil=1, *, res_pre=None, mask=None, mask
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        prof.append(("conv_igemm", 2.0 * N * Ho * Wo * Cout * kh * kw * (algo_cin or Cin), e0, e1))
+        epi = "".join(c for c, t in (("p", res_pre), ("m", mask), ("q", res_post), ("r", out_raw), ("a", out_act)) if t is not None)
+        prof.append(("conv_igemm", 2.0 * N * Ho * Wo * Cout * kh * kw * (algo_cin or Cin), e0, e1,
+                     f"{kh}x{kw} s{stride} d{dil} {H}x{W} {Cin}->{Cout} [{epi}]"))
     return out_raw, out_act
 
 

@@ -120,7 +120,12 @@ WIDE_EPI_CASES = [
     # N, H, W, Cin, Cout, k, pad, dil -- every one selects a 256 x 256 tile config (>= 224 wide tiles, Cout > 128)
     (1, 112, 512, 64, 256, 1, 0, 1),      # gathered 1x1 (CfgWide, pipelined loop in bf16)
     (1, 112, 512, 64, 256, 3, 1, 1),      # row-buffer 3x3 (CfgRow)
-    (1, 120, 480, 64, 256, 3, 2, 2),      # gathered 3x3 (CfgWide), ragged last M tile
+    (1, 120, 480, 64, 256, 3, 2, 2),      # gathered 3x3 (CfgWide)
+    # more tiles than CUs: the persistent bf16 kernels walk two tiles per workgroup on a quarter of the chip (next tile's
+    # first stages issued before the epilogue, counted wait that leaves the epilogue's stores outstanding)
+    (1, 160, 512, 64, 256, 1, 0, 1),      # 320 tiles, gathered
+    (1, 80, 512, 64, 512, 3, 1, 1),       # 160 x 2 tiles, row buffers, two N tiles
+    (1, 121, 480, 64, 256, 3, 2, 2),      # M % 256 != 0: ragged last M tile, one-tile-per-workgroup kernel
 ]
 
 

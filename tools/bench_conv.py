@@ -30,11 +30,12 @@ SHAPES = [
 ]
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--dtype", default="bf16"); ap.add_argument("--iters", type=int, default=10)
+    ap = argparse.ArgumentParser(); ap.add_argument("--dtype", default="bf16"); ap.add_argument("--iters", type=int, default=10); ap.add_argument("--only", default="")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     tot_f, tot_t = 0.0, 0.0
     for name, H, W, Cin, Cout, k, s, d, cnt in SHAPES:
+        if a.only and not any(t in name for t in a.only.split(",")): continue
         NB = int(os.environ.get("KDCC_BENCH_BATCH", "2")); x = torch.randn(NB, H, W, Cin, device="cuda").to(dt)
         w = (torch.randn(Cout, k, k, Cin, device="cuda") * 0.05).to(dt)
         pad = d * (k - 1) // 2
