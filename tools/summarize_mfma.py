@@ -12,7 +12,9 @@ import csv
 import json
 import sys
 
-FAMILIES = [("conv_igemm_row<CfgRow 256x256>", ("conv_igemm_row_kernel", "CfgRowT<8, 2, 4, 128, 320")),
+FAMILIES = [("conv_igemm_row_persist<CfgRow 256x256>", ("conv_row_persist_kernel",)),
+            ("conv_igemm_persist<CfgWide 256x256 1x1>", ("conv_igemm_persist_kernel",)),
+            ("conv_igemm_row<CfgRow 256x256>", ("conv_igemm_row_kernel", "CfgRowT<8, 2, 4, 128, 320")),
             ("conv_igemm_row<CfgRowX 256x256 rate-36>", ("conv_igemm_row_kernel", "CfgRowT<8, 2, 4, 128, 384")),
             ("conv_igemm_row<CfgRowN 256x128>", ("conv_igemm_row_kernel", "CfgRowT<4, 4, 2, 64")),
             ("conv_igemm<CfgWide 256x256 gathered>", ("conv_igemm_kernel", "Cfg<8, 2, 4, 2, 128")),

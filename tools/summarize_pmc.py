@@ -5,7 +5,7 @@ usage: summarize_pmc.py <fetch counter_collection.csv> <write counter_collection
 FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled (gfx950 reads half the bytes a wide coalesced stream fetches)."""
 import csv, json, sys
 
-FAMILIES = {"conv_igemm": "conv_igemm", "dw_mfma_fwd": "dw_mfma_fwd", "dw_mfma_wgrad": "dw_mfma_wgrad",
+FAMILIES = {"conv_igemm": ("conv_igemm", "conv_row_persist"), "dw_mfma_fwd": "dw_mfma_fwd", "dw_mfma_wgrad": "dw_mfma_wgrad",
             "dwconv_fwd": "dwconv_fwd_kernel", "pw_wgrad": "pw_wgrad"}
 
 
@@ -15,7 +15,7 @@ def collect(path, counter):
         if r["Counter_Name"] != counter:
             continue
         for fam, key in FAMILIES.items():
-            if key in r["Kernel_Name"]:
+            if any(k in r["Kernel_Name"] for k in ((key,) if isinstance(key, str) else key)):
                 tot[fam] = tot.get(fam, 0.0) + float(r["Counter_Value"])
                 cnt[fam] = cnt.get(fam, 0) + 1
                 break
