@@ -56,7 +56,7 @@ struct ConvParams {
     const void *x;
     const void *w;
     int M, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil, ldx;
-    int HoWo, nkc, nk, Ktot, tiles_n, ntiles;
+    int HoWo, nkc, nk, Ktot, tiles_n, ntiles, tiles_m, tn_group;
     int vec_ok;  // every epilogue pointer/stride is 16-B friendly
     int epi_batch;  // A/B hook: 0 = one pass at a time (KDCC_EPI_BATCH=0)
     int tune;       // A/B hook (KDCC_CONV_TUNE)
@@ -874,7 +874,15 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_row_persist_kernel(
     uint32_t a_ok = 0;
     int u_cb = 0, u_ky = 0, u_idx = 0, s_cb = 0, s_ky = 0, s_kx = 0, s_idx = 0;
     auto setup = [&](int tile) {
-        const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+        int tn, tm;
+        if (p.tn_group > 0) {   // tn-blocked order: p.tn_group N tiles x all M tiles, then the next N block
+            const int per = p.tiles_m * p.tn_group, blk = tile / per, r = tile - blk * per;
+            tm = r / p.tn_group;
+            tn = blk * p.tn_group + (r - tm * p.tn_group);
+        } else {
+            tn = tile % p.tiles_n;
+            tm = tile / p.tiles_n;
+        }
         m0 = tm * CF::BM;
         n0 = tn * CF::BN;
         const int n = m0 / p.HoWo, rem = m0 - n * p.HoWo;
@@ -1050,7 +1058,15 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_persist_kerne
     // after its piece 0
     int m0 = 0, n0 = 0, a_off0 = 0, b_off0 = 0, s_kt = 0;
     auto setup = [&](int tile) {
-        const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+        int tn, tm;
+        if (p.tn_group > 0) {   // tn-blocked order: p.tn_group N tiles x all M tiles, then the next N block
+            const int per = p.tiles_m * p.tn_group, blk = tile / per, r = tile - blk * per;
+            tm = r / p.tn_group;
+            tn = blk * p.tn_group + (r - tm * p.tn_group);
+        } else {
+            tn = tile % p.tiles_n;
+            tm = tile / p.tiles_n;
+        }
         m0 = tm * CF::BM;
         n0 = tn * CF::BN;
         a_off0 = (m0 + wv * GA * PR + srow) * p.ldx + chunk * EPC;
@@ -1257,7 +1273,13 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
     const bool persist_ok = persist && !half && d->dtype == KD_BF16 && cfg == 1 && p.vec_ok && !ep->raw_f32 && nops <= 2 && p.M % 256 == 0 && d->Cout % 256 == 0;
     auto persist_grid = [&]() {
         p.tiles_n = d->Cout / 256;
-        p.ntiles = (p.M / 256) * p.tiles_n;
+        p.tiles_m = p.M / 256;
+        p.ntiles = p.tiles_m * p.tiles_n;
+        static int tng = -1;
+        // N tiles walked four at a time over all M tiles (Cout >= 2048): an XCD then keeps 4 weight slabs (K x 256) in its L2 for
+        // the whole launch instead of cycling all 8-16 of them per round of tiles; +3-4 % on the 4096-wide 1x1 layers
+        if (tng < 0) { const char *v = getenv("KDCC_CONV_TNGROUP"); tng = v ? atoi(v) : 4; }
+        p.tn_group = (tng > 0 && p.tiles_n > tng && p.tiles_n % tng == 0) ? tng : 0;
         const int nwg = p.ntiles < ncu ? p.ntiles : ncu;
         return dim3((unsigned)((nwg + 7) / 8 * 8));
     };

@@ -159,6 +159,54 @@ def test_conv_wide_tile_full_epilogue(K, dt, raw_f32, case):
     assert_close(host_nchw(out_act), act_ref, dt, f"act {case}")
 
 
+PERSIST_CASES = [
+    # (N, H, W, Cin, Cout, k, pad, dil), operands, outputs -- bf16 persistent kernels: more tiles than CUs, one or two epilogue
+    # operands (the template variants), both tile orders (Cout = 2048: N tiles walked four at a time)
+    ((1, 160, 512, 64, 256, 1, 0, 1), ("pre",), ("raw", "act")),
+    ((1, 160, 512, 64, 256, 1, 0, 1), ("mask", "post"), ("raw",)),
+    ((1, 80, 512, 64, 512, 3, 1, 1), ("mask",), ("raw",)),
+    ((1, 80, 512, 64, 512, 3, 2, 2), ("pre", "post"), ("act",)),
+    ((1, 80, 512, 128, 512, 3, 1, 1), ("pre", "mask"), ("raw", "act")),
+    ((1, 20, 512, 64, 2048, 1, 0, 1), ("post",), ("raw", "act")),
+    ((1, 20, 512, 64, 2048, 1, 0, 1), (), ("act",)),
+]
+
+
+@pytest.mark.parametrize("case,opnds,outs", PERSIST_CASES)
+def test_conv_persistent_epilogues(K, case, opnds, outs):
+    """v = acc (+ res_pre); v = mask > 0 ? v * mask_scale : 0 (if mask); v += res_post; raw = v; act = relu(v * s + b)."""
+    dt = "bf16"
+    N, H, W, Cin, Cout, k, p, d = case
+    x = q(rnd(N, Cin, H, W), dt)
+    w = q(rnd(Cout, Cin, k, k, scale=(2.0 / (Cin * k * k)) ** 0.5), dt)
+    pre, post = q(rnd(N, Cout, H, W), dt), q(rnd(N, Cout, H, W), dt)
+    mask = q(np.maximum(rnd(N, Cout, H, W), 0), dt)
+    mscale, ascale, ashift = rnd(Cout) * 0.2 + 1.0, rnd(Cout) * 0.2 + 1.0, rnd(Cout) * 0.3
+    bc = lambda v: v[None, :, None, None]
+    ref = orc.conv2d_fwd(x, w, pad=p, dil=d)
+    if "pre" in opnds:
+        ref = ref + pre
+    if "mask" in opnds:
+        ref = np.where(mask > 0, ref * bc(mscale), 0.0)
+    if "post" in opnds:
+        ref = ref + post
+    act_ref = np.maximum(ref * bc(ascale) + bc(ashift), 0)
+    wp = K.pack_conv_weight(torch.from_numpy(w).cuda(), DT[dt])
+    cu = lambda v: torch.from_numpy(v).cuda()
+    out_raw = torch.zeros((N, H, W, Cout + 32), dtype=DT[dt], device="cuda")[..., 16:16 + Cout] if "raw" in outs else None
+    out_act = torch.zeros((N, H, W, 2 * Cout), dtype=DT[dt], device="cuda")[..., Cout:] if "act" in outs else None
+    K.conv2d(dev_nhwc(x, dt), wp, 1, p, d,
+             res_pre=dev_nhwc(pre, dt, ld=Cout + 16) if "pre" in opnds else None,
+             mask=dev_nhwc(mask, dt) if "mask" in opnds else None, mask_scale=cu(mscale) if "mask" in opnds else None,
+             res_post=dev_nhwc(post, dt, ld=Cout + 24) if "post" in opnds else None,
+             out_raw=out_raw, out_act=out_act, act_scale=cu(ascale) if "act" in outs else None,
+             act_shift=cu(ashift) if "act" in outs else None, act_relu="act" in outs)
+    if out_raw is not None:
+        assert_close(host_nchw(out_raw), ref, dt, f"raw {case} {opnds}")
+    if out_act is not None:
+        assert_close(host_nchw(out_act), act_ref, dt, f"act {case} {opnds}")
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_conv_wide_tile_dgrad_epilogue(K, dt):
     """Backward use of the wide tiles: dgrad (KD_PACK_DGRAD weights) of a 3x3 dil-2 conv on row-buffer tiles and of a 1x1 on

@@ -22,6 +22,10 @@ SHAPES = [
     ("1x1 1024->2048", 128, 256, 1024, 2048, 1, 1, 1, 3),
     ("1x1 2048->4096", 128, 256, 2048, 4096, 1, 1, 1, 2),
     ("1x1 4096->256", 128, 256, 4096, 256, 1, 1, 1, 4),
+    ("1x1 256->4096", 128, 256, 256, 4096, 1, 1, 1, 3),
+    ("1x1 4096->2048", 128, 256, 4096, 2048, 1, 1, 1, 2),
+    ("1x1 2048->1024", 128, 256, 2048, 1024, 1, 1, 1, 5),
+    ("mod7 3x3 d4 1024->2048", 128, 256, 1024, 2048, 3, 1, 4, 1),
     ("1x1 1280->256", 128, 256, 1280, 256, 1, 1, 1, 1),
     ("final 3x3 320->256", 512, 1024, 320, 256, 3, 1, 1, 1),
     ("final 3x3 256->256", 512, 1024, 256, 256, 3, 1, 1, 1),
