@@ -251,7 +251,7 @@ def main():
         # per conv shape: launches per step, mean duration, TFLOP/s (live HIP events, same records as the roofline)
         agg = {}
         for p in prof:
-            if p[0] == "conv_igemm":
+            if len(p) > 4:
                 e = agg.setdefault(p[4], [0, 0.0, p[1]])
                 e[0] += 1
                 e[1] += p[2].elapsed_time(p[3])

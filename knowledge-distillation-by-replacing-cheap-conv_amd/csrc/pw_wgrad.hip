@@ -398,6 +398,144 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide_kernel(const WgradPara
             }
 }
 
+// ---- row-buffer tile for 3x3 / stride 1 / 'same' convs: 128 (Cout) x [3 taps kx] x 128 (Cin) per workgroup -------------------------
+// Per tap the kernels above stage dy and the (shifted) activations again: nine passes over both tensors.  Here a K stage is 64
+// consecutive pixels of ONE image row (W % 64 == 0): dy is staged once and serves the three kx taps of a kernel row, and the
+// activations go to LDS as a ROW BUFFER of 64 + 2*dil pixels (halo included, zero outside the image) that the three taps read
+// at row offsets kx*dil -- the trick of conv_igemm_row_kernel; the transposing fragment reads' swizzle is keyed on the buffer
+// row, so the shifted reads stay conflict-free.  Bytes staged per MAC: (64*128 + 96*128) * 2 B per 128 x 384 x 64 MACs = 1/77
+// against 1/32 for the 128 x 128 kernel and 1/64 for the 256 x 256 one.  8 waves (2 x 4 of 64 x 96), grid.z = ky; a
+// four-stage ring of 40 KiB stages (160 KiB, one workgroup per CU): three stages in flight behind a counted vmcnt.
+constexpr int WR_XROWS = 96;                        // row-buffer rows: 64 + 2 * dil <= 96
+constexpr int WR_STAGE = 16384 + WR_XROWS * 256;    // dy image + row buffer
+constexpr int WR_NST = 4;
+__global__ __launch_bounds__(512, 2) void conv_wgrad_row_kernel(const WgradParams p)
+{
+    __shared__ __attribute__((aligned(16))) char lds[WR_NST * WR_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 2, wn = wv & 3;
+    const int tile = blockIdx.x, split = blockIdx.y, ky = blockIdx.z;
+    const int t_ci = tile % p.tiles_ci, t_co = tile / p.tiles_ci;
+    const int co0 = t_co * 128, ci0 = t_ci * 128;
+    const int m_begin = split * p.rows_per_split;           // multiples of 64; M % 64 == 0 (host)
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+    const int nst = (m_end - m_begin) / 64;
+    const int d = p.dil;
+    const bf16_t *dy = (const bf16_t *)p.dy;
+    const bf16_t *a = (const bf16_t *)p.a;
+    const bf16_t *zero = (const bf16_t *)kd_zero_page_w;
+
+    const int prow = lane >> 4, slot = lane & 15;
+    auto stage = [&](int st) {
+        char *base = lds + (st % WR_NST) * WR_STAGE;
+        const int m0 = m_begin + st * 64;
+        const uint32_t n = fastdiv((uint32_t)m0, p.mg_howo, p.sh_howo);
+        const uint32_t rem = (uint32_t)m0 - n * (uint32_t)(p.H * p.W);
+        const int ho = (int)fastdiv(rem, p.mg_wo, p.sh_wo);
+        const int x0 = (int)rem - ho * p.W;
+        const int hi = ho + (ky - 1) * d;
+        const bool rowok = hi >= 0 && hi < p.H;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                       // dy: 16 pieces of 4 pixel rows x 256 B
+            const int pc = wv * 2 + j, r = pc * 4 + prow;
+            const int c = (slot ^ (tr_f(r) << 1)) * 8;      // source-side swizzle (8 channels per 16-B chunk)
+            const bf16_t *s0 = co0 + c < p.Cout ? dy + (size_t)(m0 + r) * p.ldy + co0 + c : zero;
+            glds16(s0, base + pc * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {                       // row buffer: 24 pieces; row r = pixel x0 - dil + r
+            const int pc = wv * 3 + j, r = pc * 4 + prow;
+            const int c = (slot ^ (tr_f(r) << 1)) * 8;
+            const int x = x0 - d + r;
+            const bool ok = rowok && r < 64 + 2 * d && x >= 0 && x < p.W && ci0 + c < p.Cin;
+            const bf16_t *s1 = ok ? a + ((size_t)((int)n * p.H + hi) * p.W + x) * p.lda + ci0 + c : zero;
+            glds16(s1, base + 16384 + pc * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    f32x4_t acc[4][6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int q = lane >> 4, li = lane & 15;
+    auto frag = [&](const char *img, int mrow, int t) {
+        const int m0 = mrow + 8 * q + (li >> 2);
+        const int m1 = m0 + 4;
+        const v4i16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4i16_t *)(img + m0 * 256 + ((t ^ tr_f(m0)) << 5) + (li & 3) * 8));
+        const v4i16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4i16_t *)(img + m1 * 256 + ((t ^ tr_f(m1)) << 5) + (li & 3) * 8));
+        return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+
+    // this wave's six 16-column tiles of the 3 x 128 (kx, ci) columns
+    int jkx[6], jct[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { const int jt = wn * 6 + j; jkx[j] = jt >> 3; jct[j] = jt & 7; }
+
+    constexpr int G = 5;   // pieces per wave per stage
+    for (int st = 0; st < WR_NST - 1 && st < nst; ++st) stage(st);
+    for (int st = 0; st < nst; ++st) {
+        // stage st has landed once at most the stages issued after it are outstanding
+        const int ahead = min(nst - 1 - st, WR_NST - 2);
+        if (ahead >= 2) wait_vm_barrier<2 * G>();
+        else if (ahead == 1) wait_vm_barrier<G>();
+        else wait_vm_barrier<0>();
+        if (st + WR_NST - 1 < nst) stage(st + WR_NST - 1);   // into the buffer every wave left before this barrier
+        const char *imgY = lds + (st % WR_NST) * WR_STAGE, *imgX = imgY + 16384;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t fa[4], fb[6];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = frag(imgY, ks * 32, wm * 4 + i);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) fb[j] = frag(imgX, ks * 32 + jkx[j] * d, jct[j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    const int frow = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float *out = p.part + ((size_t)split * 9 + ky * 3 + jkx[j]) * p.Cout * p.Cin;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wm * 64 + i * 16 + fq * 4 + r;
+                const int ci = ci0 + jct[j] * 16 + frow;
+                if (co < p.Cout && ci < p.Cin) out[(size_t)co * p.Cin + ci] = acc[i][j][r];
+            }
+    }
+}
+
+// plan of the row-buffer kernel: ~2.5 one-per-CU workgroups per CU, >= 8 stages per split
+void row_plan(long long M, int Cin, int Cout, int &tiles, int &tiles_ci, int &splits, int &rps)
+{
+    tiles_ci = (Cin + 127) / 128;
+    tiles = tiles_ci * ((Cout + 127) / 128);
+    const int stages = (int)(M / 64);
+    int want = (640 + tiles * 3 - 1) / (tiles * 3);
+    const int max_splits = (stages + 7) / 8;
+    splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
+    if (splits < 1) splits = 1;
+    rps = ((stages + splits - 1) / splits) * 64;
+    splits = (int)((M + rps - 1) / rps);
+}
+bool row_eligible(const kd_conv_desc *d)
+{
+    return d->dtype == KD_BF16 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == d->dil && 2 * d->dil + 64 <= WR_XROWS &&
+           d->W % 64 == 0 && d->Cin % 8 == 0 && d->Cout % 8 == 0;
+}
+
 __global__ void slab_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, size_t n, int splits,
                                    int accumulate)
 {
@@ -501,6 +639,11 @@ extern "C" size_t kd_conv2d_wgrad_workspace(const kd_conv_desc *d)
     const int stages = (M + 63) / 64;
     const int wsplits = (stages + 7) / 8 < 768 ? (stages + 7) / 8 : 768;   // the wide-tile plan never splits finer
     if (wsplits > splits) splits = wsplits;
+    if (row_eligible(d)) {
+        int rt, rtc, rs, rr;
+        row_plan(M, d->Cin, d->Cout, rt, rtc, rs, rr);
+        if (rs > splits) splits = rs;
+    }
     return (size_t)splits * taps * d->Cout * d->Cin * sizeof(float);
 }
 
@@ -532,7 +675,16 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
     bool wide = d->dtype == KD_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->Cout >= 256 && d->Cin >= 256 &&
                 pad256 * 100 <= pad128 * 135;   // (the decoder's 304-channel conv: 2 x 256 vs 3 x 128 columns)
     if (const char *e = getenv("KDCC_WGRAD_WIDE")) wide = wide && e[0] != '0';
-    if (wide) {
+    // A/B hook KDCC_WGRAD_ROW: 0 = never, 1 = only where the 256 x 256 tile is not chosen, 2 = wherever eligible (default: it is
+    // faster on every 3x3 layer of the net, tools/bench_wgrad.py at 4 images: 128->128 1.70 -> 1.06 ms, 304->256 7.25 -> 4.69,
+    // 256->256 1.04 -> 0.88, 512->512 0.87 -> 0.78, 512->1024 dil 2 1.60 -> 1.43, 64->128 1.51 -> 0.83)
+    static int rowmode = -1;
+    if (rowmode < 0) { const char *e = getenv("KDCC_WGRAD_ROW"); rowmode = e ? atoi(e) : 2; }
+    const bool row = row_eligible(d) && (rowmode == 2 || (rowmode == 1 && !wide));
+    if (row) {
+        wide = false;
+        row_plan(M, d->Cin, d->Cout, tiles, tiles_ci, splits, rps);
+    } else if (wide) {
         tiles_ci = (d->Cin + 255) / 256;
         tiles = tiles_ci * ((d->Cout + 255) / 256);
         const int stages = (int)((M + 63) / 64);
@@ -555,7 +707,11 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
     fastdiv_magic((uint32_t)d->Wo, p.mg_wo, p.sh_wo);
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)tiles, (unsigned)splits, (unsigned)taps);
-    if (wide) hipLaunchKernelGGL(conv_wgrad_wide_kernel, grid, dim3(512), 0, s, p);
+    if (row) {
+        fastdiv_magic((uint32_t)(d->H * d->W), p.mg_howo, p.sh_howo);
+        fastdiv_magic((uint32_t)d->W, p.mg_wo, p.sh_wo);
+        hipLaunchKernelGGL(conv_wgrad_row_kernel, dim3((unsigned)tiles, (unsigned)splits, 3u), dim3(512), 0, s, p);
+    } else if (wide) hipLaunchKernelGGL(conv_wgrad_wide_kernel, grid, dim3(512), 0, s, p);
     else if (d->dtype == KD_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0) launch_tr(grid, s, p);
     else if (d->dtype == KD_BF16) hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(pw_wgrad_kernel<float>, grid, dim3(256), 0, s, p);

@@ -176,7 +176,8 @@ def conv2d_wgrad(x, dy, dw, stride=1, pad=0, dil=1, accumulate=False, workspace=
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        prof.append(("conv_wgrad", 2.0 * N * Ho * Wo * Cout * kh * kw * Cin, e0, e1))
+        prof.append(("conv_wgrad", 2.0 * N * Ho * Wo * Cout * kh * kw * Cin, e0, e1,
+                     f"wgrad {kh}x{kw} s{stride} d{dil} {H}x{W} {Cin}->{Cout}"))
     return dw
 
 

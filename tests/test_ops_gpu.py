@@ -487,6 +487,12 @@ WGRAD_CASES = [
     (1, 33, 40, 256, 256, 3, 1, 2, 2),
     (2, 21, 31, 512, 256, 1, 1, 0, 1),
     (1, 24, 40, 256, 512, 3, 2, 1, 1),
+    # W % 64 == 0, 3x3 / stride 1 / 'same': the row-buffer kernel (bf16; one dy stage per kernel row, taps at row offsets)
+    (2, 9, 64, 64, 128, 3, 1, 1, 1),      # 18 stages: ring fill, steady state and drain; border rows
+    (1, 20, 128, 128, 128, 3, 1, 2, 2),   # dilation 2, two stages per image row
+    (1, 12, 64, 304, 256, 3, 1, 1, 1),    # 304 input channels: ragged third Cin tile, two Cout tiles
+    (1, 40, 64, 72, 40, 3, 1, 16, 16),    # largest dilation the row buffer holds, ragged channels
+    (1, 6, 64, 64, 64, 3, 1, 1, 1),       # fewer stages than the ring holds
 ]
 
 

@@ -12,7 +12,8 @@ from kdcc_amd import ops  # noqa: E402
 
 SHAPES = [  # N, H, W, Cin, Cout, k, dil   (P92 mode-B layer classes at 4 images)
     (4, 512, 1024, 128, 128, 3, 1), (4, 256, 512, 256, 256, 3, 1), (4, 128, 256, 512, 512, 3, 1), (4, 128, 256, 512, 1024, 3, 2),
-    (4, 128, 256, 2048, 4096, 1, 1), (4, 128, 256, 4096, 256, 1, 1), (4, 512, 1024, 304, 256, 3, 1), (4, 128, 256, 512, 512, 1, 1)]
+    (4, 128, 256, 2048, 4096, 1, 1), (4, 128, 256, 4096, 256, 1, 1), (4, 512, 1024, 304, 256, 3, 1), (4, 128, 256, 512, 512, 1, 1),
+    (4, 512, 1024, 64, 128, 3, 1), (4, 256, 512, 128, 256, 3, 1), (4, 512, 1024, 256, 256, 3, 1), (4, 128, 256, 1024, 512, 3, 2)]
 g = torch.Generator(device="cuda").manual_seed(0)
 for (N, H, W, Ci, Co, k, d) in SHAPES:
     x = torch.randn((N, H, W, Ci), device="cuda", generator=g).to(torch.bfloat16)
