@@ -570,6 +570,29 @@ void plan(int dtype, int M, int Cin, int Cout, int &tiles, int &tiles_ci, int &s
     splits = (M + rows_per_split - 1) / rows_per_split;
 }
 
+// plan of the 256 x 256 tile (bf16 LDS-DMA path): ~3 waves of one-per-CU workgroups, >= 8 stages per split
+bool wide_tile_pays(int dtype, int Cin, int Cout)
+{
+    const long long pad256 = (long long)((Cout + 255) / 256) * ((Cin + 255) / 256) * 65536;
+    const long long pad128 = (long long)((Cout + 127) / 128) * ((Cin + 127) / 128) * 16384;
+    bool wide = dtype == KD_BF16 && Cin % 8 == 0 && Cout % 8 == 0 && Cout >= 256 && Cin >= 256 &&
+                pad256 * 100 <= pad128 * 135;   // (the decoder's 304-channel conv: 2 x 256 vs 3 x 128 columns)
+    if (const char *e = getenv("KDCC_WGRAD_WIDE")) wide = wide && e[0] != '0';
+    return wide;
+}
+void wide_plan(long long M, int Cin, int Cout, int taps, int &tiles, int &tiles_ci, int &splits, int &rps)
+{
+    tiles_ci = (Cin + 255) / 256;
+    tiles = tiles_ci * ((Cout + 255) / 256);
+    const int stages = (int)((M + 63) / 64);
+    int want = (768 + tiles * taps - 1) / (tiles * taps);
+    const int max_splits = (stages + 7) / 8;
+    splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
+    if (splits < 1) splits = 1;
+    rps = ((stages + splits - 1) / splits) * 64;
+    splits = (int)((M + rps - 1) / rps);
+}
+
 }  // namespace
 
 extern "C" size_t kd_pw_wgrad_workspace(int32_t M, int32_t Cin, int32_t Cout)
@@ -578,7 +601,10 @@ extern "C" size_t kd_pw_wgrad_workspace(int32_t M, int32_t Cin, int32_t Cout)
     int tiles, tiles_ci, s0, s1, rps;
     plan(KD_F32, M, Cin, Cout, tiles, tiles_ci, s0, rps);
     plan(KD_BF16, M, Cin, Cout, tiles, tiles_ci, s1, rps);
-    const int splits = s0 > s1 ? s0 : s1;
+    int splits = s0 > s1 ? s0 : s1;
+    const int stages = (M + 63) / 64;
+    const int wsplits = (stages + 7) / 8 < 768 ? (stages + 7) / 8 : 768;   // the wide-tile plan never splits finer
+    if (wsplits > splits) splits = wsplits;
     return (size_t)splits * Cout * Cin * sizeof(float);
 }
 
@@ -595,6 +621,8 @@ extern "C" int kd_pw_wgrad(int32_t dtype, int32_t M, int32_t Cin, int32_t Cout, 
                KD_ERR_INVALID, "kd_pw_wgrad: operands must be 16-B aligned with 16-B multiple row strides");
     int tiles, tiles_ci, splits, rps;
     plan(dtype, M, Cin, Cout, tiles, tiles_ci, splits, rps);
+    const bool wide = wide_tile_pays(dtype, Cin, Cout);   // the 256 x 256 tile of kd_conv2d_wgrad (444 -> 624 TFLOP/s on large layers)
+    if (wide) wide_plan(M, Cin, Cout, 1, tiles, tiles_ci, splits, rps);
     KD_REQUIRE(workspace_bytes >= (size_t)splits * Cout * Cin * sizeof(float), KD_ERR_WORKSPACE,
                "kd_pw_wgrad: workspace %zu < %zu", workspace_bytes, (size_t)splits * Cout * Cin * sizeof(float));
     WgradParams p;
@@ -605,7 +633,8 @@ extern "C" int kd_pw_wgrad(int32_t dtype, int32_t M, int32_t Cin, int32_t Cout, 
     p.mg_howo = p.sh_howo = p.mg_wo = p.sh_wo = 0;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)tiles, (unsigned)splits);
-    if (dtype == KD_BF16 && Cin % 8 == 0 && Cout % 8 == 0) launch_tr(grid, s, p);
+    if (wide) hipLaunchKernelGGL(conv_wgrad_wide_kernel, grid, dim3(512), 0, s, p);
+    else if (dtype == KD_BF16 && Cin % 8 == 0 && Cout % 8 == 0) launch_tr(grid, s, p);
     else if (dtype == KD_BF16) hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(pw_wgrad_kernel<float>, grid, dim3(256), 0, s, p);
     KD_CHECK_LAUNCH("kd_pw_wgrad");
@@ -669,12 +698,7 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
     KD_REQUIRE(taps <= 65535, KD_ERR_UNSUPPORTED, "kd_conv2d_wgrad: kernel too large");
     int tiles, tiles_ci, splits, rps;
     plan(d->dtype, (int)M, d->Cin, d->Cout, tiles, tiles_ci, splits, rps, taps);
-    // 256 x 256 tiles (bf16 LDS-DMA path) when they waste little of the weight matrix
-    const long long pad256 = (long long)((d->Cout + 255) / 256) * ((d->Cin + 255) / 256) * 65536;
-    const long long pad128 = (long long)((d->Cout + 127) / 128) * ((d->Cin + 127) / 128) * 16384;
-    bool wide = d->dtype == KD_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->Cout >= 256 && d->Cin >= 256 &&
-                pad256 * 100 <= pad128 * 135;   // (the decoder's 304-channel conv: 2 x 256 vs 3 x 128 columns)
-    if (const char *e = getenv("KDCC_WGRAD_WIDE")) wide = wide && e[0] != '0';
+    bool wide = wide_tile_pays(d->dtype, d->Cin, d->Cout);
     // A/B hook KDCC_WGRAD_ROW: 0 = never, 1 = only where the 256 x 256 tile is not chosen, 2 = wherever eligible (default: it is
     // faster on every 3x3 layer of the net, tools/bench_wgrad.py at 4 images: 128->128 1.70 -> 1.06 ms, 304->256 7.25 -> 4.69,
     // 256->256 1.04 -> 0.88, 512->512 0.87 -> 0.78, 512->1024 dil 2 1.60 -> 1.43, 64->128 1.51 -> 0.83)
@@ -685,15 +709,7 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
         wide = false;
         row_plan(M, d->Cin, d->Cout, tiles, tiles_ci, splits, rps);
     } else if (wide) {
-        tiles_ci = (d->Cin + 255) / 256;
-        tiles = tiles_ci * ((d->Cout + 255) / 256);
-        const int stages = (int)((M + 63) / 64);
-        int want = (768 + tiles * taps - 1) / (tiles * taps);     // ~3 waves of one-per-CU workgroups
-        const int max_splits = (stages + 7) / 8;                  // >= 8 stages per split
-        splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
-        if (splits < 1) splits = 1;
-        rps = ((stages + splits - 1) / splits) * 64;
-        splits = (int)((M + rps - 1) / rps);
+        wide_plan(M, d->Cin, d->Cout, taps, tiles, tiles_ci, splits, rps);
     }
     const size_t need = (size_t)splits * taps * d->Cout * d->Cin * sizeof(float);
     KD_REQUIRE(workspace_bytes >= need, KD_ERR_WORKSPACE, "kd_conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
