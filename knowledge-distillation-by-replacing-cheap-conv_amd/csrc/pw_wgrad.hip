@@ -296,6 +296,24 @@ __global__ void slab_reduce_taps_kernel(const float *__restrict__ part, float *_
     }
 }
 
+// the same with one thread per (co, ci) and the taps in registers: the slab reads are coalesced along ci for every tap (the kernel
+// above walks the output index, so neighbouring threads read nine different planes), the output is nine consecutive floats
+template <int TAPS>
+__global__ void slab_reduce_taps_cc_kernel(const float *__restrict__ part, float *__restrict__ dw, size_t plane, int splits,
+                                           int accumulate)
+{
+    for (size_t cc = (size_t)blockIdx.x * blockDim.x + threadIdx.x; cc < plane; cc += (size_t)gridDim.x * blockDim.x) {
+        float s[TAPS];
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) s[t] = 0.f;
+        for (int k = 0; k < splits; ++k)
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) s[t] += part[((size_t)k * TAPS + t) * plane + cc];
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) dw[cc * TAPS + t] = accumulate ? dw[cc * TAPS + t] + s[t] : s[t];
+    }
+}
+
 // ---- wide tile: 256 (Cout) x 256 (Cin) per workgroup, 8 waves (2 x 4 of 128 x 64), one workgroup per CU --------------------------
 // The 128 x 128 kernel above keeps one 32-KiB stage in flight per workgroup (two per CU): at the latency of a gathered L2 / HBM
 // read that is ~0.2 of the MFMA peak whatever the shape.  Doubling both tile edges halves the bytes staged per FLOP, so the
@@ -546,6 +564,33 @@ __global__ void slab_reduce_kernel(const float *__restrict__ part, float *__rest
     }
 }
 
+// n % 4 == 0, 16-B aligned slabs: four sums per thread, 16-B loads
+__global__ void slab_reduce4_kernel(const float4 *__restrict__ part, float4 *__restrict__ dw, size_t n4, int splits,
+                                    int accumulate)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < splits; ++k) {
+            const float4 v = part[(size_t)k * n4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (accumulate) { const float4 o = dw[i]; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+        dw[i] = s;
+    }
+}
+
+void launch_slab_reduce(const float *part, float *dw, size_t n, int splits, int accumulate, hipStream_t s)
+{
+    if (n % 4 == 0 && kd_aligned16(part) && kd_aligned16(dw)) {
+        const size_t n4 = n / 4;
+        const int rb = (int)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
+        hipLaunchKernelGGL(slab_reduce4_kernel, dim3(rb), dim3(256), 0, s, (const float4 *)part, (float4 *)dw, n4, splits, accumulate);
+    } else {
+        const int rb = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(256), 0, s, part, dw, n, splits, accumulate);
+    }
+}
+
 void launch_tr(dim3 grid, hipStream_t s, const WgradParams &p)
 {
     static int nst = -1;
@@ -638,9 +683,7 @@ extern "C" int kd_pw_wgrad(int32_t dtype, int32_t M, int32_t Cin, int32_t Cout, 
     else if (dtype == KD_BF16) hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(pw_wgrad_kernel<float>, grid, dim3(256), 0, s, p);
     KD_CHECK_LAUNCH("kd_pw_wgrad");
-    const size_t n = (size_t)Cout * Cin;
-    const int rb = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(256), 0, s, (const float *)workspace, dw, n, splits, accumulate);
+    launch_slab_reduce((const float *)workspace, dw, (size_t)Cout * Cin, splits, accumulate, s);
     KD_CHECK_LAUNCH("kd_pw_wgrad(reduce)");
     return KD_OK;
 }
@@ -734,8 +777,16 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
     KD_CHECK_LAUNCH("kd_conv2d_wgrad");
     const size_t n = (size_t)d->Cout * d->Cin * taps;
     const int rb = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
-    hipLaunchKernelGGL(slab_reduce_taps_kernel, dim3(rb), dim3(256), 0, s, (const float *)workspace, dw, d->Cout, d->Cin, taps,
-                       splits, accumulate);
+    if (taps == 1) {
+        launch_slab_reduce((const float *)workspace, dw, (size_t)d->Cout * d->Cin, splits, accumulate, s);
+    } else if (taps == 9) {
+        const size_t plane = (size_t)d->Cout * d->Cin;
+        const int rb9 = (int)((plane + 255) / 256 > 4096 ? 4096 : (plane + 255) / 256);
+        hipLaunchKernelGGL(slab_reduce_taps_cc_kernel<9>, dim3(rb9), dim3(256), 0, s, (const float *)workspace, dw, plane, splits,
+                           accumulate);
+    } else
+        hipLaunchKernelGGL(slab_reduce_taps_kernel, dim3(rb), dim3(256), 0, s, (const float *)workspace, dw, d->Cout, d->Cin, taps,
+                           splits, accumulate);
     KD_CHECK_LAUNCH("kd_conv2d_wgrad(reduce)");
     return KD_OK;
 }
