@@ -832,7 +832,7 @@ struct TileWalk {
     }
 };
 
-template <typename CF, int NOPS, bool DBG = false>
+template <typename CF, int NOPS, bool DBG = false, bool PP = false>   // PP: see conv_igemm_persist_kernel
 __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_row_persist_kernel(const ConvParams p)
 {
     typedef bf16_t T;
@@ -892,37 +892,61 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_row_persist_kernel(
         nu = p.nkc * (ky_hi - ky_lo + 1);
         ns = nu * 3;
         a_ok = 0;
-        const int r0 = wv * GAR2 * PR + srow;            // buffer row of piece 0: pixel x0 - d + r0 (loader waves)
+        // PP: group 0 (waves 0-3) stages the row-buffer rows it reads, 0 .. 191 (128 + 2 * dil <= 192), 6 pieces each, and all of
+        // B, 8 pieces each; group 1 stages rows 192 .. 319, 4 pieces each
+        const int pbase = PP ? (wv < 4 ? wv * 6 : 24 + (wv - 4) * 4) : wv * GAR2;
+        const int r0 = pbase * PR + srow;                // buffer row of piece 0: pixel x0 - d + r0
 #pragma unroll
-        for (int j = 0; j < GAR2; ++j) {
+        for (int j = 0; j < (PP ? 6 : GAR2); ++j) {
             const int r = r0 + j * PR, x = x0 - d + r;
             a_ok |= (r < CF::BM + 2 * d && x >= 0 && x < p.W) ? (1u << j) : 0u;
         }
         a_off0 = ((n * p.H + ho) * p.W + (x0 - d + r0)) * p.ldx + chunk * EPC;   // may point before the row: masked by a_ok
-        b_off0 = (n0 + wv * GB2 * PR + srow) * p.Ktot + chunk * EPC;
+        b_off0 = (n0 + wv * (PP ? 2 : 1) * GB2 * PR + srow) * p.Ktot + chunk * EPC;
         u_cb = 0; u_ky = ky_lo; u_idx = 0;
         s_cb = 0; s_ky = ky_lo; s_kx = 0; s_idx = 0;
     };
     auto stage_a = [&]() {
         const int row_off = ((u_ky - 1) * d * p.W) * p.ldx + u_cb * BK;
-        char *la = lds + (u_idx & 1) * CF::ABUF + wv * (GAR2 * 1024);
         static_assert(GAR2 == 5 && GB2 == 4, "piece groups below");
-        const char *ga[GAR2];
+        if constexpr (PP) {
+            const int pbase = wv < 4 ? wv * 6 : 24 + (wv - 4) * 4, np = wv < 4 ? 6 : 4;
+            char *la = lds + (u_idx & 1) * CF::ABUF + pbase * 1024;
 #pragma unroll
-        for (int j = 0; j < GAR2; ++j)   // source of piece j, reduced by the instruction offset of that piece
-            ga[j] = (const char *)(((a_ok >> j) & 1u) ? xg + (a_off0 + j * PR * p.ldx + row_off) : zero) - (j - 2) * 1024;
-        glds16_x5(ga[0], ga[1], ga[2], ga[3], ga[4], la + 2048);
+            for (int j = 0; j < 6; ++j)
+                if (j < np) glds16(((a_ok >> j) & 1u) ? xg + (a_off0 + j * PR * p.ldx + row_off) : zero, la + j * 1024);
+        } else {
+            char *la = lds + (u_idx & 1) * CF::ABUF + wv * (GAR2 * 1024);
+            const char *ga[GAR2];
+#pragma unroll
+            for (int j = 0; j < GAR2; ++j)   // source of piece j, reduced by the instruction offset of that piece
+                ga[j] = (const char *)(((a_ok >> j) & 1u) ? xg + (a_off0 + j * PR * p.ldx + row_off) : zero) - (j - 2) * 1024;
+            glds16_x5(ga[0], ga[1], ga[2], ga[3], ga[4], la + 2048);
+        }
         ++u_idx;
         if (++u_ky > ky_hi) { u_ky = ky_lo; ++u_cb; }
         __builtin_amdgcn_sched_barrier(0);
     };
     auto stage_b = [&]() {
         const int w_off = (s_ky * 3 + s_kx) * p.Cin + s_cb * BK;
-        char *lb = ldsB + (s_idx & 1) * CF::BSTAGE + wv * (GB2 * 1024);
         const char *gb[GB2];
+        if constexpr (PP) {
+            if (wv < 4) {
+                char *lb = ldsB + (s_idx & 1) * CF::BSTAGE + wv * (2 * GB2 * 1024);
 #pragma unroll
-        for (int j = 0; j < GB2; ++j) gb[j] = (const char *)(wg + (b_off0 + j * PR * p.Ktot + w_off)) - j * 1024;
-        glds16_x4(gb[0], gb[1], gb[2], gb[3], lb);
+                for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+                    for (int j = 0; j < GB2; ++j)
+                        gb[j] = (const char *)(wg + (b_off0 + (h2 * GB2 + j) * PR * p.Ktot + w_off)) - j * 1024;
+                    glds16_x4(gb[0], gb[1], gb[2], gb[3], lb + h2 * GB2 * 1024);
+                }
+            }
+        } else {
+            char *lb = ldsB + (s_idx & 1) * CF::BSTAGE + wv * (GB2 * 1024);
+#pragma unroll
+            for (int j = 0; j < GB2; ++j) gb[j] = (const char *)(wg + (b_off0 + j * PR * p.Ktot + w_off)) - j * 1024;
+            glds16_x4(gb[0], gb[1], gb[2], gb[3], lb);
+        }
         ++s_idx;
         if (++s_kx == 3) {
             s_kx = 0;
@@ -973,8 +997,41 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_row_persist_kernel(
         if (tl) tlp[0] = wall_clock64();
         wait_vm_stores(nst);
         if (tl) tlp[1] = wall_clock64();   // the prologue has landed for every wave; the previous tile's stores may still drain
-        read_frags(0, 0, a0, b0);
         unsigned long long cprev = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ph4 = 0, ph5 = 0;
+        if constexpr (PP) {
+            // roles and barriers as in conv_igemm_persist_kernel<.., PP>: group 0 computes stage sc in half-period 2*sc, group 1
+            // in 2*sc + 1; row buffer u + 2 replaces u once group 1 has read stage 3*u + 2
+            if (wv < 4) {
+#pragma unroll 1
+                for (int sc = 0; sc < ns; ++sc) {
+                    read_frags(sc, 0, a0, b0);
+                    read_frags(sc, 1, a1, b1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();          // half-period 2*sc
+                    mfmas(a0, b0);
+                    mfmas(a1, b1);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage sc + 1 (issued a stage ago)
+                    __builtin_amdgcn_s_barrier();          // half-period 2*sc + 1: group 1 has read stage sc
+                    if (sc + 2 < ns) stage_b();
+                    if (sc % 3 == 2 && sc / 3 + 2 < nu) stage_a();
+                }
+            } else {
+#pragma unroll 1
+                for (int sc = 0; sc < ns; ++sc) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's row-buffer rows (issued >= a stage ago)
+                    __builtin_amdgcn_s_barrier();          // half-period 2*sc
+                    if (sc % 3 == 0 && sc >= 3 && sc / 3 + 1 < nu) stage_a();   // rows 192.. of row buffer sc/3 + 1
+                    if (sc + 2 < ns) stage_b();            // bookkeeping only (group 0 stages B)
+                    read_frags(sc, 0, a0, b0);
+                    read_frags(sc, 1, a1, b1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();          // half-period 2*sc + 1
+                    mfmas(a0, b0);
+                    mfmas(a1, b1);
+                }
+            }
+        } else {
+        read_frags(0, 0, a0, b0);
 #pragma unroll 1
         for (int s = 0; s < ns; ++s) {
             if (DBG && s == 1) cprev = clock64();
@@ -1013,6 +1070,7 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_row_persist_kernel(
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // every wave is done reading the buffers
+        }
         const int mw = m0 + wm * (16 * MI), nw = n0 + wn * (16 * NJ);
         walk.t += walk.step;
         const bool more = walk.t < walk.t_end;
@@ -1031,7 +1089,14 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_row_persist_kernel(
     }
 }
 
-template <typename CF, int NOPS>
+// PP ("ping-pong"): the two waves of a SIMD run half a stage out of phase -- while one issues its 64 MFMAs of a stage, the other
+// does everything else (its share of the next stage's DMA, then the 24 fragment reads of the stage it computes next), and they
+// swap behind ONE barrier per half stage.  Measured (tools/ubench/mfma_issue.hip): a wave alone on its SIMD issues MFMAs at
+// 17.1-17.3 cycles each -- one wave saturates the matrix pipe -- whether or not its sibling streams LDS-DMA or ds_reads; with
+// both waves in their MFMA blocks the older one takes the pipe (17 vs 33 cycles per MFMA).  In lock-step both waves of a SIMD
+// leave the pipe idle during the hand-over (barrier, ~45 DMA pieces through the CU's one vector-memory path, fragment reads:
+// ~1100 of a 3100-cycle stage).
+template <typename CF, int NOPS, bool PP = false>
 __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_persist_kernel(const ConvParams p)
 {
     typedef bf16_t T;
@@ -1070,20 +1135,35 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_persist_kerne
         m0 = tm * CF::BM;
         n0 = tn * CF::BN;
         a_off0 = (m0 + wv * GA * PR + srow) * p.ldx + chunk * EPC;
-        b_off0 = (n0 + wv * GB * PR + srow) * p.Ktot + chunk * EPC;
+        b_off0 = (n0 + wv * (PP ? 2 : 1) * GB * PR + srow) * p.Ktot + chunk * EPC;   // PP: waves 0-3 stage all of B, 64 rows each
         s_kt = 0;
     };
     auto stage = [&]() {
         char *la = lds + (s_kt & 1) * CF::STAGE + wv * (GA * 1024);
-        char *lb = lds + (s_kt & 1) * CF::STAGE + CF::STAGE_A + wv * (GB * 1024);
         static_assert(GA == 4 && GB == 4, "piece groups below");
         const char *ga[GA], *gb[GB];   // sources reduced by the instruction offset of the piece (one M0 value per group)
 #pragma unroll
         for (int j = 0; j < GA; ++j) ga[j] = (const char *)(xg + (a_off0 + j * PR * p.ldx + s_kt * BK)) - j * 1024;
         glds16_x4(ga[0], ga[1], ga[2], ga[3], la);
+        if constexpr (PP) {
+            // the rows only this wave's group reads (A: rows wv*32 ..) come from every wave; B, which both groups read, from
+            // group 0 alone, whose pieces have three half-periods to land and are published by its own counted wait
+            if (wv < 4) {
+                char *lb = lds + (s_kt & 1) * CF::STAGE + CF::STAGE_A + wv * (2 * GB * 1024);
 #pragma unroll
-        for (int j = 0; j < GB; ++j) gb[j] = (const char *)(wg + (b_off0 + j * PR * p.Ktot + s_kt * BK)) - j * 1024;
-        glds16_x4(gb[0], gb[1], gb[2], gb[3], lb);
+                for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+                    for (int j = 0; j < GB; ++j)
+                        gb[j] = (const char *)(wg + (b_off0 + (h2 * GB + j) * PR * p.Ktot + s_kt * BK)) - j * 1024;
+                    glds16_x4(gb[0], gb[1], gb[2], gb[3], lb + h2 * GB * 1024);
+                }
+            }
+        } else {
+            char *lb = lds + (s_kt & 1) * CF::STAGE + CF::STAGE_A + wv * (GB * 1024);
+#pragma unroll
+            for (int j = 0; j < GB; ++j) gb[j] = (const char *)(wg + (b_off0 + j * PR * p.Ktot + s_kt * BK)) - j * 1024;
+            glds16_x4(gb[0], gb[1], gb[2], gb[3], lb);
+        }
         ++s_kt;
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -1128,6 +1208,41 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_persist_kerne
         if (tl) tlp[0] = wall_clock64();
         wait_vm_stores(nst);
         if (tl) tlp[1] = wall_clock64();
+        if constexpr (PP) {
+            // group g = wv >> 2 (0: waves 0-3, one per SIMD; 1: their siblings) computes stage sc in half-period h = 2*sc + g.
+            // Buffer of stage st is free once group 1 has read stage st - 2 (before barrier 2*st - 3); group 0 issues its pieces of
+            // stage st in half-period 2*st - 3, group 1 in 2*st - 2.  Group 1 drains its DMA before every compute phase (its
+            // youngest pieces are read by group 0 behind the next barrier), group 0 leaves its youngest stage in flight.
+            // One loop per role, two barriers per stage each.  Every DMA wait is a plain vmcnt(0) placed right before a barrier
+            // and two half-periods after the pieces were issued.
+            if (wv < 4) {
+#pragma unroll 1
+                for (int sc = 0; sc < nk; ++sc) {
+                    read_frags(sc, 0, a0, b0);             // (stage sc was published behind the previous barrier)
+                    read_frags(sc, 1, a1, b1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();          // half-period 2*sc: group 1 may stage its rows of stage sc + 1
+                    mfmas(a0, b0);
+                    mfmas(a1, b1);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage sc + 1 (issued a stage ago)
+                    __builtin_amdgcn_s_barrier();          // half-period 2*sc + 1: group 1 has read stage sc
+                    if (sc + 2 < nk) stage();
+                }
+            } else {
+#pragma unroll 1
+                for (int sc = 0; sc < nk; ++sc) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's A rows of stage sc (issued a stage ago)
+                    __builtin_amdgcn_s_barrier();          // half-period 2*sc
+                    if (sc >= 1 && sc + 1 < nk) stage();   // A rows of stage sc + 1 (stage 1 came with the prologue)
+                    read_frags(sc, 0, a0, b0);
+                    read_frags(sc, 1, a1, b1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();          // half-period 2*sc + 1
+                    mfmas(a0, b0);
+                    mfmas(a1, b1);
+                }
+            }
+        } else {
         read_frags(0, 0, a0, b0);
 #pragma unroll 1
         for (int kt = 0; kt < nk; ++kt) {
@@ -1144,6 +1259,7 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_persist_kerne
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        }
         const int mw = m0 + wm * (16 * MI), nw = n0 + wn * 64;
         walk.t += walk.step;
         const bool more = walk.t < walk.t_end;
@@ -1185,6 +1301,13 @@ __global__ void pack_conv_weight_kernel(const float *__restrict__ src, T *__rest
 }
 
 }  // namespace
+
+static bool pp_row()
+{
+    static int pp = -1;
+    if (pp < 0) { const char *v = getenv("KDCC_CONV_PP"); pp = !(v && v[0] == '0'); }   // A/B: KDCC_CONV_PP=0 = lock-step waves
+    return pp != 0;
+}
 
 extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w_packed, const kd_conv_epilogue *ep,
                              kd_stream_t stream)
@@ -1291,6 +1414,10 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
             if (nops == 0) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 0, true>), grid, dim3(512), 0, s, p);
             else if (nops == 1) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 1, true>), grid, dim3(512), 0, s, p);
             else hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 2, true>), grid, dim3(512), 0, s, p);
+        } else if (pp_row() && d->dil <= 32) {
+            if (nops == 0) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 0, false, true>), grid, dim3(512), 0, s, p);
+            else if (nops == 1) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 1, false, true>), grid, dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 2, false, true>), grid, dim3(512), 0, s, p);
         } else if (nops == 0) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 0>), grid, dim3(512), 0, s, p);
         else if (nops == 1) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 1>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 2>), grid, dim3(512), 0, s, p);
@@ -1298,7 +1425,11 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         p.nkc = d->Cin / (CfgWide::RB / es);
         p.nk = d->kh * d->kw * p.nkc;
         const dim3 grid = persist_grid();
-        if (nops == 0) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 0>), grid, dim3(512), 0, s, p);
+        if (pp_row()) {
+            if (nops == 0) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 0, true>), grid, dim3(512), 0, s, p);
+            else if (nops == 1) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 1, true>), grid, dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 2, true>), grid, dim3(512), 0, s, p);
+        } else if (nops == 0) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 0>), grid, dim3(512), 0, s, p);
         else if (nops == 1) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 1>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 2>), grid, dim3(512), 0, s, p);
     } else if (row_wide && half && d->dtype == KD_BF16) {
