@@ -1001,33 +1001,49 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_row_persist_kernel(
         if constexpr (PP) {
             // roles and barriers as in conv_igemm_persist_kernel<.., PP>: group 0 computes stage sc in half-period 2*sc, group 1
             // in 2*sc + 1; row buffer u + 2 replaces u once group 1 has read stage 3*u + 2
+            // (DBG: phase clocks per wave -- group 0: reads | barrier | MFMAs | DMA wait | barrier | DMA issue;
+            //  group 1: DMA wait | barrier | DMA issue | reads | barrier | MFMAs)
             if (wv < 4) {
 #pragma unroll 1
                 for (int sc = 0; sc < ns; ++sc) {
+                    if (DBG) cprev = clock64();
                     read_frags(sc, 0, a0, b0);
                     read_frags(sc, 1, a1, b1);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (DBG) c1 = clock64();
                     __builtin_amdgcn_s_barrier();          // half-period 2*sc
+                    if (DBG) c2 = clock64();
                     mfmas(a0, b0);
                     mfmas(a1, b1);
+                    if (DBG) c3 = clock64();
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage sc + 1 (issued a stage ago)
+                    if (DBG) c4 = clock64();
                     __builtin_amdgcn_s_barrier();          // half-period 2*sc + 1: group 1 has read stage sc
+                    if (DBG) c5 = clock64();
                     if (sc + 2 < ns) stage_b();
                     if (sc % 3 == 2 && sc / 3 + 2 < nu) stage_a();
+                    if (DBG) { const unsigned long long c6 = clock64(); ph0 += c1 - cprev; ph1 += c2 - c1; ph2 += c3 - c2; ph3 += c4 - c3; ph4 += c5 - c4; ph5 += c6 - c5; }
                 }
             } else {
 #pragma unroll 1
                 for (int sc = 0; sc < ns; ++sc) {
+                    if (DBG) cprev = clock64();
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's row-buffer rows (issued >= a stage ago)
+                    if (DBG) c1 = clock64();
                     __builtin_amdgcn_s_barrier();          // half-period 2*sc
+                    if (DBG) c2 = clock64();
                     if (sc % 3 == 0 && sc >= 3 && sc / 3 + 1 < nu) stage_a();   // rows 192.. of row buffer sc/3 + 1
                     if (sc + 2 < ns) stage_b();            // bookkeeping only (group 0 stages B)
+                    if (DBG) c3 = clock64();
                     read_frags(sc, 0, a0, b0);
                     read_frags(sc, 1, a1, b1);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (DBG) c4 = clock64();
                     __builtin_amdgcn_s_barrier();          // half-period 2*sc + 1
+                    if (DBG) c5 = clock64();
                     mfmas(a0, b0);
                     mfmas(a1, b1);
+                    if (DBG) { const unsigned long long c6 = clock64(); ph0 += c1 - cprev; ph1 += c2 - c1; ph2 += c3 - c2; ph3 += c4 - c3; ph4 += c5 - c4; ph5 += c6 - c5; }
                 }
             }
         } else {
@@ -1411,9 +1427,9 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         p.nk = 9 * p.nkc;
         const dim3 grid = persist_grid();
         if (p.tune & 512) {   // phase clocks (tools/conv_timeline.py)
-            if (nops == 0) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 0, true>), grid, dim3(512), 0, s, p);
-            else if (nops == 1) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 1, true>), grid, dim3(512), 0, s, p);
-            else hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 2, true>), grid, dim3(512), 0, s, p);
+            if (nops == 0) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 0, true, true>), grid, dim3(512), 0, s, p);
+            else if (nops == 1) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 1, true, true>), grid, dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 2, true, true>), grid, dim3(512), 0, s, p);
         } else if (pp_row() && d->dil <= 32) {
             if (nops == 0) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 0, false, true>), grid, dim3(512), 0, s, p);
             else if (nops == 1) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 1, false, true>), grid, dim3(512), 0, s, p);

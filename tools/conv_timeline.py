@@ -28,8 +28,8 @@ def run(name, H, W, Cin, Cout, k, d, NB=4, res=False):
     t = buf[:256 * 32 * 8].reshape(256, 32, 8).astype(np.float64) / 100.0   # us
     ntile = int((t[0, :, 0] > 0).sum())
     print(f"== {name}: tiles per workgroup {ntile}")
-    nst = H * 0 + (9 if k == 3 else 1) * Cin // 64 - 2
-    print("   phase cycles per stage (reads+mfma0 | dma wait | barrier | dma issue | frag reads | mfma1):")
+    nst = H * 0 + (9 if k == 3 else 1) * Cin // 64
+    print("   phase cycles per stage -- waves 0-3: reads | barrier | MFMAs | DMA wait | barrier | DMA issue; waves 4-7: DMA wait | barrier | DMA issue | reads | barrier | MFMAs")
     for wv in range(8):
         print(f"     wave {wv}: " + " ".join(f"{v / nst:7.0f}" for v in pw[wv, :6]), f"  sum {pw[wv, :6].sum() / nst:7.0f}")
     for i in range(min(ntile, 6)):
