@@ -731,11 +731,13 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
     float mscale[8], ascale[8], ashift[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { mscale[q] = 1.f; ascale[q] = 1.f; ashift[q] = 0.f; }
-    if (e.mask_scale) ld8(e.mask_scale + c0, mscale);
+    // operand slots
+    // (NOPS == 0: compile-time false -- as run-time flags the three blocks below become 24 selects per row)
+    const bool has_p = NOPS > 0 && e.res_pre != nullptr, has_m = NOPS > 0 && e.mask != nullptr, has_q = NOPS > 0 && e.res_post != nullptr;
+    const float relu_lo = e.act_relu ? 0.f : -INFINITY;   // max(a, -inf) = a: no select per element
+    if (has_m && e.mask_scale) ld8(e.mask_scale + c0, mscale);
     if (e.act_scale) ld8(e.act_scale + c0, ascale);
     if (e.act_shift) ld8(e.act_shift + c0, ashift);
-    // operand slots
-    const bool has_p = e.res_pre != nullptr, has_m = e.mask != nullptr, has_q = e.res_post != nullptr;
     const T *s0 = (const T *)(has_p ? e.res_pre : has_m ? e.mask : e.res_post);
     const int ld0 = has_p ? e.ld_res_pre : has_m ? e.ld_mask : e.ld_res_post;
     const T *s1 = (const T *)(has_p && has_m ? e.mask : e.res_post);
@@ -760,6 +762,17 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
     if (nops >= 1) load64(s0, ld0, 0, ra);
     if (nops == 2) load64(s1, ld1, 0, rb);
     if (nops == 1) load64(s0, ld0, 1, rb);
+    // hipcc's wait-count insertion is path-insensitive: a load whose uses sit under run-time conditions counts as pending on
+    // the paths that skip them, and the wait it then needs lands in front of the main loop's first ds_read (which reuses the
+    // registers) -- inside the hand-scheduled loop, draining the LDS-DMA every stage (tools/check_loop_waits.py).  The empty
+    // asm statements below and in the row loop are unconditional uses: the waits are inserted here, where the first row's
+    // arithmetic would have waited anyway.
+    asm volatile("" ::"v"(ascale[0]), "v"(ascale[1]), "v"(ascale[2]), "v"(ascale[3]), "v"(ascale[4]), "v"(ascale[5]), "v"(ascale[6]),
+                 "v"(ascale[7]), "v"(ashift[0]), "v"(ashift[1]), "v"(ashift[2]), "v"(ashift[3]), "v"(ashift[4]), "v"(ashift[5]),
+                 "v"(ashift[6]), "v"(ashift[7]));
+    if (NOPS > 0)
+        asm volatile("" ::"v"(mscale[0]), "v"(mscale[1]), "v"(mscale[2]), "v"(mscale[3]), "v"(mscale[4]), "v"(mscale[5]), "v"(mscale[6]),
+                     "v"(mscale[7]));
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {   // 64 rows each
         if (nops == 2 && hb == 1) { load64(s0, ld0, 1, ra); load64(s1, ld1, 1, rb); }
@@ -781,6 +794,8 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
                 float v[8], t[8];
                 ld8((const bf16_t *)&rawv, v);
                 const uint4 o0 = (hb == 1 && nops == 1) ? rb[ps] : ra[ps], o1 = rb[ps];
+                if (NOPS >= 1) asm volatile("" ::"v"(o0.x), "v"(o0.y), "v"(o0.z), "v"(o0.w));
+                if (NOPS == 2) asm volatile("" ::"v"(o1.x), "v"(o1.y), "v"(o1.z), "v"(o1.w));
                 if (has_p) {
                     ld8((const T *)&o0, t);
 #pragma unroll
@@ -798,17 +813,16 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
 #pragma unroll
                     for (int q = 0; q < 8; ++q) v[q] += t[q];
                 }
-                if (e.out_raw && !(p.tune & 128)) {
+                if (e.out_raw) {
                     if (nops == 0) *(uint4 *)((T *)e.out_raw + m * e.ld_raw + c0) = rawv;
                     else st8((T *)e.out_raw + m * e.ld_raw + c0, v);
                 }
                 if (e.out_act) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        const float a = v[q] * ascale[q] + ashift[q];
-                        t[q] = e.act_relu ? fmaxf(a, 0.f) : a;
+                        t[q] = fmaxf(v[q] * ascale[q] + ashift[q], relu_lo);
                     }
-                    if (!(p.tune & 128) || t[0] == 1.2345f) st8((T *)e.out_act + m * e.ld_act + c0, t);   // 128: timing ablation
+                    st8((T *)e.out_act + m * e.ld_act + c0, t);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1101,7 +1115,7 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_row_persist_kernel(
         if (tl) tlp[6] = wall_clock64();
         ++tcount;
         if (!more) break;
-        nst = (p.tune & (64 | 128)) ? 0 : nst_epi;
+        nst = (p.tune & 64) ? 0 : nst_epi;
     }
 }
 
@@ -1286,7 +1300,7 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_persist_kerne
         if (tl) tlp[6] = wall_clock64();
         ++tcount;
         if (!more) break;
-        nst = (p.tune & (64 | 128)) ? 0 : nst_epi;
+        nst = (p.tune & 64) ? 0 : nst_epi;
     }
 }
 
