@@ -55,3 +55,17 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def test_no_compiler_waits_inside_the_conv_main_loops():
+    """The persistent conv kernels wait for their LDS-DMA by hand (counted s_waitcnt in inline asm).  hipcc's own wait-count
+    insertion must not add an s_waitcnt vmcnt inside those loops -- it does when it believes an epilogue load may still be
+    pending at the loop header -- or every stage drains the DMA (measured: 1x1 layers 1.5x slower).  tools/check_loop_waits.py
+    compiles conv_igemm.hip to assembly and looks."""
+    import shutil
+    import subprocess
+    import sys
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_loop_waits.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
