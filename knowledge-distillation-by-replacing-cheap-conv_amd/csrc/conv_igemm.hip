@@ -1304,6 +1304,162 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_persist_kerne
     }
 }
 
+// ---- ping-pong row kernel for Cout = 128 layers (mod2, the GSCNN shape stream): 512 pixels x 128 channels per workgroup ---------
+// The 256 x 128 two-workgroups-per-CU config runs these layers at 0.36-0.39 of the MFMA peak (short K, 16 MFMAs per wave between
+// barriers).  Here the tile is twice as long in M so that a wave again owns 128 x 64 outputs (the wide kernels' sub-tile and
+// epilogue), waves 4 x 2, and the ping-pong schedule of conv_row_persist_kernel<.., PP> applies: group 0 = waves 0-3 (output
+// pixels 0-255), group 1 = waves 4-7 (pixels 256-511).  64-B K stages (one MFMA k-step, 32 MFMAs per wave and half-period):
+// two row buffers of 576 pixels x 64 B (dil <= 16) + two B stages of 128 x 64 B + the epilogue patches = 104 KiB.
+// Group 0 stages row-buffer rows 0-319 (it reads 0 .. 255 + 2*dil) and B; group 1 rows 320-575.
+template <int NOPS>
+__global__ __launch_bounds__(512, 2) void conv_row_pp128_kernel(const ConvParams p)
+{
+    typedef bf16_t T;
+    constexpr int RB = 64, BK = 32, EPC = 8, PR = 16, MI = 8;
+    constexpr int BM = 512, BN = 128, AROWS = 576, ABUF = AROWS * RB, BSTAGE = BN * RB, NEED = 2 * ABUF + 2 * BSTAGE;
+    static_assert(NEED + 8 * 2048 <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) char lds[NEED + 8 * 2048];
+    char *const ldsB = lds + 2 * ABUF;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const T *__restrict__ xg = (const T *)p.x;
+    const T *__restrict__ wg = (const T *)p.w;
+    const T *zero = (const T *)kd_zero_page;
+    const int d = p.dil;
+    TileWalk walk(p.ntiles);
+    if (walk.t >= walk.t_end) return;
+
+    // 64-B rows: LDS slot s of row r holds chunk s ^ ((r >> 1) & 3); a piece = 16 rows, lane -> (row lane / 4, slot lane & 3)
+    const int srow = lane >> 2;
+    const int chunk = (lane & 3) ^ ((srow >> 1) & 3);
+    const int frow = lane & 15, fq = lane >> 4;
+    const int pbase = wv < 4 ? wv * 5 : 20 + (wv - 4) * 4, np = wv < 4 ? 5 : 4;   // row-buffer pieces of this wave
+
+    int m0 = 0, n0 = 0, ky_lo = 0, ky_hi = 0, nu = 0, ns = 0, a_off0 = 0, b_off0 = 0;
+    uint32_t a_ok = 0;
+    int u_cb = 0, u_ky = 0, u_idx = 0, s_cb = 0, s_ky = 0, s_kx = 0, s_idx = 0;
+    auto setup = [&](int tile) {
+        const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+        m0 = tm * BM;
+        n0 = tn * BN;
+        const int n = m0 / p.HoWo, rem = m0 - n * p.HoWo;
+        const int ho = rem / p.W, x0 = rem - ho * p.W;
+        ky_lo = ho - d < 0 ? 1 : 0;
+        ky_hi = ho + d >= p.H ? 1 : 2;
+        nu = p.nkc * (ky_hi - ky_lo + 1);
+        ns = nu * 3;
+        a_ok = 0;
+        const int r0 = pbase * PR + srow;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int r = r0 + j * PR, x = x0 - d + r;
+            a_ok |= (r < BM + 2 * d && x >= 0 && x < p.W) ? (1u << j) : 0u;
+        }
+        a_off0 = ((n * p.H + ho) * p.W + (x0 - d + r0)) * p.ldx + chunk * EPC;   // may point before the row: masked by a_ok
+        b_off0 = (n0 + wv * 2 * PR + srow) * p.Ktot + chunk * EPC;               // group 0: 32 rows of B per wave
+        u_cb = 0; u_ky = ky_lo; u_idx = 0;
+        s_cb = 0; s_ky = ky_lo; s_kx = 0; s_idx = 0;
+    };
+    auto stage_a = [&]() {
+        const int row_off = ((u_ky - 1) * d * p.W) * p.ldx + u_cb * BK;
+        char *la = lds + (u_idx & 1) * ABUF + pbase * 1024;
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+            if (j < np) glds16(((a_ok >> j) & 1u) ? xg + (a_off0 + j * PR * p.ldx + row_off) : zero, la + j * 1024);
+        ++u_idx;
+        if (++u_ky > ky_hi) { u_ky = ky_lo; ++u_cb; }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto stage_b = [&]() {
+        const int w_off = (s_ky * 3 + s_kx) * p.Cin + s_cb * BK;
+        if (wv < 4) {
+            char *lb = ldsB + (s_idx & 1) * BSTAGE + wv * 2048;
+            glds16(wg + (b_off0 + w_off), lb);
+            glds16(wg + (b_off0 + PR * p.Ktot + w_off), lb + 1024);
+        }
+        ++s_idx;
+        if (++s_kx == 3) {
+            s_kx = 0;
+            if (++s_ky > ky_hi) { s_ky = ky_lo; ++s_cb; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto prologue = [&]() {
+        stage_a();
+        stage_b();
+        stage_b();            // ns >= 6
+        if (nu > 1) stage_a();
+    };
+
+    f32x4_t acc[MI][4];
+    uint4 a0[MI], b0[4];
+    auto read_frags = [&](int s) __attribute__((always_inline)) {
+        const int u = s / 3, kx = s - u * 3;
+        const int rsh = frow + kx * d;
+        const char *A = lds + (u & 1) * ABUF + (wm * 128 + rsh) * RB + ((fq ^ ((rsh >> 1) & 3)) << 4);
+        const char *B = ldsB + (s & 1) * BSTAGE + (wn * 64 + frow) * RB + ((fq ^ ((frow >> 1) & 3)) << 4);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a0[i] = *(const uint4 *)(A + i * 16 * RB);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b0[j] = *(const uint4 *)(B + j * 16 * RB);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mfmas = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Mma<T>::run(b0[j], a0[i], acc[i][j]);   // transposed tile: see ig_epilogue
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    const int nst_epi = 2 * MI * ((p.ep.out_raw ? 1 : 0) + (p.ep.out_act ? 1 : 0));
+    int nst = 0;
+    setup(walk.t);
+    prologue();
+#pragma unroll 1
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        wait_vm_stores(nst);
+        if (wv < 4) {
+#pragma unroll 1
+            for (int sc = 0; sc < ns; ++sc) {
+                read_frags(sc);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();          // half-period 2*sc
+                mfmas();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage sc + 1 (issued a stage ago)
+                __builtin_amdgcn_s_barrier();          // half-period 2*sc + 1: group 1 has read stage sc
+                if (sc + 2 < ns) stage_b();
+                if (sc % 3 == 2 && sc / 3 + 2 < nu) stage_a();
+            }
+        } else {
+#pragma unroll 1
+            for (int sc = 0; sc < ns; ++sc) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's row-buffer rows (issued >= a stage ago)
+                __builtin_amdgcn_s_barrier();          // half-period 2*sc
+                if (sc % 3 == 0 && sc >= 3 && sc / 3 + 1 < nu) stage_a();
+                if (sc + 2 < ns) stage_b();            // bookkeeping only (group 0 stages B)
+                read_frags(sc);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();          // half-period 2*sc + 1
+                mfmas();
+            }
+        }
+        const int mw = m0 + wm * 128, nw = n0 + wn * 64;
+        walk.t += walk.step;
+        const bool more = walk.t < walk.t_end;
+        if (more) { setup(walk.t); prologue(); }
+        if (!(p.tune & 64)) ig_epilogue_rows16<MI, NOPS>(p, lds + NEED + wv * 2048, acc, mw, nw, lane);
+        if (!more) break;
+        nst = (p.tune & 64) ? 0 : nst_epi;
+    }
+}
+
 // ---- weight packing ------------------------------------------------------------------
 template <typename T>
 __global__ void pack_conv_weight_kernel(const float *__restrict__ src, T *__restrict__ dst, int mode, int Cout,
@@ -1469,6 +1625,20 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         const dim3 grid((unsigned)((p.M / 256) * p.tiles_n));
         if (row_x) hipLaunchKernelGGL((conv_igemm_row_kernel<bf16_t, CfgRowHX>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((conv_igemm_row_kernel<bf16_t, CfgRowH>), grid, dim3(256), 0, s, p);
+    } else if (row_narrow && pp_row() && persist && p.vec_ok && !ep->raw_f32 && nops <= 2 && d->Cout % 128 == 0 && d->W % 512 == 0 &&
+               d->dil <= 16 && d->Cin % 32 == 0) {
+        // Cout = 128 layers: 512 x 128 ping-pong tiles
+        p.nkc = d->Cin / 32;
+        p.nk = 9 * p.nkc;
+        p.tiles_n = d->Cout / 128;
+        p.tiles_m = p.M / 512;
+        p.ntiles = p.tiles_m * p.tiles_n;
+        p.tn_group = 0;
+        const int nwg = p.ntiles < ncu ? p.ntiles : ncu;
+        const dim3 grid((unsigned)((nwg + 7) / 8 * 8));
+        if (nops == 0) hipLaunchKernelGGL((conv_row_pp128_kernel<0>), grid, dim3(512), 0, s, p);
+        else if (nops == 1) hipLaunchKernelGGL((conv_row_pp128_kernel<1>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv_row_pp128_kernel<2>), grid, dim3(512), 0, s, p);
     } else if (row_wide || row_narrow) {
         p.nkc = d->Cin / ((row_wide ? CfgRow::RB : CfgRowN::RB) / es);
         p.nk = 9 * p.nkc;

@@ -169,6 +169,11 @@ PERSIST_CASES = [
     ((1, 80, 512, 128, 512, 3, 1, 1), ("pre", "mask"), ("raw", "act")),
     ((1, 20, 512, 64, 2048, 1, 0, 1), ("post",), ("raw", "act")),
     ((1, 20, 512, 64, 2048, 1, 0, 1), (), ("act",)),
+    # Cout = 128, W % 512 == 0: the 512 x 128 ping-pong kernel (64-B K stages)
+    ((1, 24, 512, 64, 128, 3, 1, 1), ("pre",), ("raw", "act")),
+    ((1, 20, 1024, 128, 128, 3, 2, 2), (), ("act",)),
+    ((2, 150, 512, 64, 128, 3, 1, 1), ("mask", "post"), ("raw",)),      # 300 tiles: two per workgroup on part of the chip
+    ((1, 40, 512, 64, 128, 3, 16, 16), ("post",), ("raw", "act")),      # largest dilation of that kernel
 ]
 
 

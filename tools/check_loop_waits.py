@@ -23,9 +23,9 @@ def production(name):
 
 bad = 0
 for idx, (i, l) in enumerate(starts):
-    if "persist_kernel" not in l:
+    if "persist_kernel" not in l and "pp128_kernel" not in l:
         continue
-    prod = production(l)
+    prod = production(l) or "pp128_kernel" in l
     end = starts[idx + 1][0] if idx + 1 < len(starts) else len(lines)
     depth2, inasm, cur = False, False, ""
     for k in range(i, end):
