@@ -721,7 +721,7 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
                                                    int lane)
 {
     typedef bf16_t T;
-    static_assert(MI == 8 && NOPS >= 0 && NOPS <= 2, "128-row wave sub-tiles, at most two operands");
+    static_assert(MI == 8 && NOPS >= 0 && NOPS <= 3, "128-row wave sub-tiles");
     const kd_conv_epilogue &e = p.ep;
     // every per-lane address below derives from this copy: the compiler cannot hoist them out of the tile loop into
     // registers that would stay live through the main loop (which runs at the 256-VGPR limit)
@@ -733,7 +733,8 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
     for (int q = 0; q < 8; ++q) { mscale[q] = 1.f; ascale[q] = 1.f; ashift[q] = 0.f; }
     // operand slots
     // (NOPS == 0: compile-time false -- as run-time flags the three blocks below become 24 selects per row)
-    const bool has_p = NOPS > 0 && e.res_pre != nullptr, has_m = NOPS > 0 && e.mask != nullptr, has_q = NOPS > 0 && e.res_post != nullptr;
+    const bool has_p = NOPS == 3 || (NOPS > 0 && e.res_pre != nullptr), has_m = NOPS == 3 || (NOPS > 0 && e.mask != nullptr),
+               has_q = NOPS == 3 || (NOPS > 0 && e.res_post != nullptr);   // (three operands: all of them, compile-time)
     const float relu_lo = e.act_relu ? 0.f : -INFINITY;   // max(a, -inf) = a: no select per element
     if (has_m && e.mask_scale) ld8(e.mask_scale + c0, mscale);
     if (e.act_scale) ld8(e.act_scale + c0, ascale);
@@ -747,7 +748,7 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
     // 64 rows (8 passes) of up to two operands in flight: one operand -> ra = rows 0..63, rb = rows 64..127, both loaded up
     // front; two operands -> ra / rb = slot 0 / slot 1 of the current 64 rows.  The accumulators are rounded to packed bf16
     // in place right after the first loads are issued (the patch holds bf16 anyway), which halves their registers.
-    uint4 ra[8], rb[8];
+    uint4 ra[8], rb[8], rc[NOPS == 3 ? 8 : 1];   // three operands: 64 rows of res_pre / mask / res_post
     auto rowof = [&](int pass) { return (size_t)(mw + pass * 8 + lrow); };
     auto load64 = [&](const T *src, int ld, int hb, uint4 (&r)[8]) __attribute__((always_inline)) {
 #pragma unroll
@@ -760,8 +761,9 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
 #pragma unroll
         for (int j = 0; j < 4; ++j) pk[i][j] = make_uint2(pack_bf16x2(acc[i][j][0], acc[i][j][1]), pack_bf16x2(acc[i][j][2], acc[i][j][3]));
     if (nops >= 1) load64(s0, ld0, 0, ra);
-    if (nops == 2) load64(s1, ld1, 0, rb);
+    if (nops >= 2) load64(s1, ld1, 0, rb);
     if (nops == 1) load64(s0, ld0, 1, rb);
+    if constexpr (NOPS == 3) load64((const T *)e.res_post, e.ld_res_post, 0, rc);
     // hipcc's wait-count insertion is path-insensitive: a load whose uses sit under run-time conditions counts as pending on
     // the paths that skip them, and the wait it then needs lands in front of the main loop's first ds_read (which reuses the
     // registers) -- inside the hand-scheduled loop, draining the LDS-DMA every stage (tools/check_loop_waits.py).  The empty
@@ -775,7 +777,8 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
                      "v"(mscale[7]));
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {   // 64 rows each
-        if (nops == 2 && hb == 1) { load64(s0, ld0, 1, ra); load64(s1, ld1, 1, rb); }
+        if (nops >= 2 && hb == 1) { load64(s0, ld0, 1, ra); load64(s1, ld1, 1, rb); }
+        if constexpr (NOPS == 3) { if (hb == 1) load64((const T *)e.res_post, e.ld_res_post, 1, rc); }
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
             const int i = 4 * hb + ii;
@@ -795,7 +798,8 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
                 ld8((const bf16_t *)&rawv, v);
                 const uint4 o0 = (hb == 1 && nops == 1) ? rb[ps] : ra[ps], o1 = rb[ps];
                 if (NOPS >= 1) asm volatile("" ::"v"(o0.x), "v"(o0.y), "v"(o0.z), "v"(o0.w));
-                if (NOPS == 2) asm volatile("" ::"v"(o1.x), "v"(o1.y), "v"(o1.z), "v"(o1.w));
+                if (NOPS >= 2) asm volatile("" ::"v"(o1.x), "v"(o1.y), "v"(o1.z), "v"(o1.w));
+                if constexpr (NOPS == 3) asm volatile("" ::"v"(rc[ps].x), "v"(rc[ps].y), "v"(rc[ps].z), "v"(rc[ps].w));
                 if (has_p) {
                     ld8((const T *)&o0, t);
 #pragma unroll
@@ -808,7 +812,7 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
                     for (int q = 0; q < 8; ++q) v[q] = t[q] > 0.f ? v[q] * mscale[q] : 0.f;
                 }
                 if (has_q) {
-                    const uint4 oq = q_in1 ? o1 : o0;
+                    const uint4 oq = NOPS == 3 ? rc[NOPS == 3 ? ps : 0] : (q_in1 ? o1 : o0);
                     ld8((const T *)&oq, t);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) v[q] += t[q];
@@ -1579,7 +1583,8 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
             ncu = 256;
     }
     const int nops = (ep->res_pre ? 1 : 0) + (ep->mask ? 1 : 0) + (ep->res_post ? 1 : 0);
-    const bool persist_ok = persist && !half && d->dtype == KD_BF16 && cfg == 1 && p.vec_ok && !ep->raw_f32 && nops <= 2 && p.M % 256 == 0 && d->Cout % 256 == 0;
+    const bool persist_ok = persist && !half && d->dtype == KD_BF16 && cfg == 1 && p.vec_ok && !ep->raw_f32 && p.M % 256 == 0 && d->Cout % 256 == 0 &&
+                            (nops <= 2 || (pp_row() && !(p.tune & 512)));   // three operands: the default (ping-pong) instantiations only
     auto persist_grid = [&]() {
         p.tiles_n = d->Cout / 256;
         p.tiles_m = p.M / 256;
@@ -1603,7 +1608,8 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         } else if (pp_row() && d->dil <= 32) {
             if (nops == 0) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 0, false, true>), grid, dim3(512), 0, s, p);
             else if (nops == 1) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 1, false, true>), grid, dim3(512), 0, s, p);
-            else hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 2, false, true>), grid, dim3(512), 0, s, p);
+            else if (nops == 2) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 2, false, true>), grid, dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 3, false, true>), grid, dim3(512), 0, s, p);
         } else if (nops == 0) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 0>), grid, dim3(512), 0, s, p);
         else if (nops == 1) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 1>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 2>), grid, dim3(512), 0, s, p);
@@ -1614,7 +1620,8 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         if (pp_row()) {
             if (nops == 0) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 0, true>), grid, dim3(512), 0, s, p);
             else if (nops == 1) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 1, true>), grid, dim3(512), 0, s, p);
-            else hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 2, true>), grid, dim3(512), 0, s, p);
+            else if (nops == 2) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 2, true>), grid, dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 3, true>), grid, dim3(512), 0, s, p);
         } else if (nops == 0) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 0>), grid, dim3(512), 0, s, p);
         else if (nops == 1) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 1>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 2>), grid, dim3(512), 0, s, p);

@@ -169,6 +169,8 @@ PERSIST_CASES = [
     ((1, 80, 512, 128, 512, 3, 1, 1), ("pre", "mask"), ("raw", "act")),
     ((1, 20, 512, 64, 2048, 1, 0, 1), ("post",), ("raw", "act")),
     ((1, 20, 512, 64, 2048, 1, 0, 1), (), ("act",)),
+    ((1, 160, 512, 64, 256, 1, 0, 1), ("pre", "mask", "post"), ("raw",)),          # three operands (dgrad: mask + both residuals)
+    ((1, 80, 512, 64, 512, 3, 2, 2), ("pre", "mask", "post"), ("raw", "act")),
     # Cout = 128, W % 512 == 0: the 512 x 128 ping-pong kernel (64-B K stages)
     ((1, 24, 512, 64, 128, 3, 1, 1), ("pre",), ("raw", "act")),
     ((1, 20, 1024, 128, 128, 3, 2, 2), (), ("act",)),
