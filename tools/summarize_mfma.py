@@ -13,13 +13,14 @@ import json
 import sys
 
 FAMILIES = [("conv_igemm_row_persist<CfgRow 256x256>", ("conv_row_persist_kernel",)),
+            ("conv_igemm_row_pp128<512x128>", ("conv_row_pp128_kernel",)),
             ("conv_igemm_persist<CfgWide 256x256 1x1>", ("conv_igemm_persist_kernel",)),
             ("conv_igemm_row<CfgRow 256x256>", ("conv_igemm_row_kernel", "CfgRowT<8, 2, 4, 128, 320")),
             ("conv_igemm_row<CfgRowX 256x256 rate-36>", ("conv_igemm_row_kernel", "CfgRowT<8, 2, 4, 128, 384")),
             ("conv_igemm_row<CfgRowN 256x128>", ("conv_igemm_row_kernel", "CfgRowT<4, 4, 2, 64")),
             ("conv_igemm<CfgWide 256x256 gathered>", ("conv_igemm_kernel", "Cfg<8, 2, 4, 2, 128")),
             ("conv_igemm<CfgNarrow2 256x128 gathered>", ("conv_igemm_kernel", "Cfg<4, 4, 2, 3, 64")),
-            ("conv_wgrad_wide", ("conv_wgrad_wide_kernel",)), ("pw_wgrad_tr", ("pw_wgrad_tr_kernel",)),
+            ("conv_wgrad_wide", ("conv_wgrad_wide_kernel",)), ("conv_wgrad_row", ("conv_wgrad_row_kernel",)), ("pw_wgrad_tr", ("pw_wgrad_tr_kernel",)),
             ("dw_mfma_fwd", ("dw_mfma_fwd_kernel",)), ("dw_mfma_wgrad", ("dw_mfma_wgrad_kernel",))]
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 n = collections.Counter()
