@@ -21,7 +21,7 @@ struct WgradParams {
     const void *dy;
     float *part;  // [splits][taps][Cout][Cin]
     int M, Cin, Cout, lda, ldy;
-    int tiles_ci, rows_per_split, splits;
+    int tiles_ci, rows_per_split, splits, tiles;
     // conv geometry of the A operand (kd_conv2d_wgrad): GEMM row m = output pixel (n, ho, wo) reads input pixel
     // (n, ho*stride - pad + ky*dil, wo*stride - pad + kx*dil) for the tap blockIdx.z = ky*kw + kx, zeros outside the image
     int geom, H, W, Ho, Wo, kw, stride, pad, dil;
@@ -433,7 +433,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row_kernel(const WgradParam
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 2, wn = wv & 3;
-    const int tile = blockIdx.x, split = blockIdx.y, ky = blockIdx.z;
+    // 1-D grid, XCD-aware: the three kernel rows of one (pixel split, tile) are neighbours on ONE XCD -- they stream the same dy
+    // stages and (shifted by +-dil rows) the same activations at the same time, so two of the three reads hit that XCD's L2
+    // (with ky as the slowest grid dimension the three passes over the tensors ran minutes apart in GPU terms: 3x the HBM reads)
+    int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int ky = lin % 3; lin /= 3;
+    const int tile = lin % p.tiles, split = lin / p.tiles;
     const int t_ci = tile % p.tiles_ci, t_co = tile / p.tiles_ci;
     const int co0 = t_co * 128, ci0 = t_ci * 128;
     const int m_begin = split * p.rows_per_split;           // multiples of 64; M % 64 == 0 (host)
@@ -673,7 +678,7 @@ extern "C" int kd_pw_wgrad(int32_t dtype, int32_t M, int32_t Cin, int32_t Cout, 
     WgradParams p;
     p.a = a; p.dy = dy; p.part = (float *)workspace;
     p.M = M; p.Cin = Cin; p.Cout = Cout; p.lda = lda; p.ldy = ldy;
-    p.tiles_ci = tiles_ci; p.rows_per_split = rps; p.splits = splits;
+    p.tiles_ci = tiles_ci; p.rows_per_split = rps; p.splits = splits; p.tiles = tiles;
     p.geom = 0; p.kw = 1; p.H = p.W = p.Ho = p.Wo = 0; p.stride = 1; p.pad = 0; p.dil = 1;
     p.mg_howo = p.sh_howo = p.mg_wo = p.sh_wo = 0;
     hipStream_t s = (hipStream_t)stream;
@@ -759,7 +764,7 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
     WgradParams p;
     p.a = x; p.dy = dy; p.part = (float *)workspace;
     p.M = (int)M; p.Cin = d->Cin; p.Cout = d->Cout; p.lda = d->ldx; p.ldy = ld_dy;
-    p.tiles_ci = tiles_ci; p.rows_per_split = rps; p.splits = splits;
+    p.tiles_ci = tiles_ci; p.rows_per_split = rps; p.splits = splits; p.tiles = tiles;
     p.geom = !(taps == 1 && d->stride == 1 && d->pad == 0);
     p.H = d->H; p.W = d->W; p.Ho = d->Ho; p.Wo = d->Wo; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     fastdiv_magic((uint32_t)(d->Ho * d->Wo), p.mg_howo, p.sh_howo);
@@ -769,7 +774,8 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
     if (row) {
         fastdiv_magic((uint32_t)(d->H * d->W), p.mg_howo, p.sh_howo);
         fastdiv_magic((uint32_t)d->W, p.mg_wo, p.sh_wo);
-        hipLaunchKernelGGL(conv_wgrad_row_kernel, dim3((unsigned)tiles, (unsigned)splits, 3u), dim3(512), 0, s, p);
+        p.tiles = tiles;
+        hipLaunchKernelGGL(conv_wgrad_row_kernel, dim3((unsigned)(tiles * splits * 3)), dim3(512), 0, s, p);
     } else if (wide) hipLaunchKernelGGL(conv_wgrad_wide_kernel, grid, dim3(512), 0, s, p);
     else if (d->dtype == KD_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0) launch_tr(grid, s, p);
     else if (d->dtype == KD_BF16) hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, p);
