@@ -312,7 +312,7 @@ def main():
                        "teacher_backend": a.teacher, "per_step_host_syncs": bool(a.ref_logging),
                        "share_frozen_prefix": bool(a.share_prefix),
                        "per_gpu_batch_sweep": sweep},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_row_kernel + conv_igemm_kernel (dense conv fwd + dgrad, student" + (" + teacher)" if a.teacher == "hip" else ")"), "achieved": ach,
+            "roofline": {"bound": "mfma", "kernel": "kd_conv2d_fwd: conv_row_persist_kernel + conv_igemm_persist_kernel + conv_row_pp128_kernel + conv_igemm_row_kernel + conv_igemm_kernel (dense conv fwd + dgrad, student" + (" + teacher)" if a.teacher == "hip" else ")"), "achieved": ach,
                          "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": conv_traffic(a.plan, a.batch, a.height, a.width, a.dtype) if a.mode == "A" else None,
                          "traffic_note": "mean HBM bytes per conv_igemm* launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + "
