@@ -196,8 +196,13 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T *__restrict__ x, i
 }
 
 // ---- bilinear upsample, align_corners=True ---------------------------------------------
-// grid: x = chunks of one output row's (Wo * C/VEC) elements, y = output row, z = image: the row interpolation
-// weights are block-uniform and the only per-thread division is a 32-bit one by C/VEC.
+// grid: x = chunks of one output row's (Wo * C/VEC) elements, y = groups of UP_RO output rows, z = image.  A thread produces
+// the UP_RO rows of its (column, channel vector): the column weights are computed once, and when enlarging, consecutive
+// output rows interpolate between the same two input rows, whose four taps stay in registers (x8: 4 + 2 loads per 8 outputs
+// instead of 32).  One thread per output element made 16 M short-lived threads with four dependent gathers each: 0.41 ms for
+// a 1.07-GB output that a fill writes in 0.15 ms.  Rows are interpolated along x when loaded ((1-aw)*a + aw*b, as the reference
+// does per output), then along y per output: the same expression tree, 2 instead of 7 operations per element.
+constexpr int UP_RO = 8;
 template <typename TI, typename TO, int VEC>
 __global__ __launch_bounds__(256) void upsample_kernel(const TI *__restrict__ x, int ldx, TO *__restrict__ y, int ldy, int N,
                                                        int H, int W, int C, int Ho, int Wo, float sh, float sw, float oh, float ow)
@@ -206,29 +211,56 @@ __global__ __launch_bounds__(256) void upsample_kernel(const TI *__restrict__ x,
     const unsigned e = blockIdx.x * 256u + threadIdx.x;
     if (e >= (unsigned)Wo * cv) return;
     const unsigned wo = e / cv, cq = e - wo * cv;
-    const int ho = blockIdx.y, n = blockIdx.z;
+    const int n = blockIdx.z;
     // align_corners=True: src = o * (I-1)/(O-1) (oh = ow = 0); align_corners=False: src = max((o + 0.5) * I/O - 0.5, 0)
-    const float fh = fmaxf(ho * sh + oh, 0.f), fw = fmaxf(wo * sw + ow, 0.f);
-    int h0 = (int)fh; h0 = h0 > H - 1 ? H - 1 : h0;
+    const float fw = fmaxf(wo * sw + ow, 0.f);
     int w0 = (int)fw; w0 = w0 > W - 1 ? W - 1 : w0;
-    const int h1 = h0 + 1 < H ? h0 + 1 : H - 1, w1 = w0 + 1 < W ? w0 + 1 : W - 1;
-    const float ah = fh - h0, aw = fw - w0;
+    const int w1 = w0 + 1 < W ? w0 + 1 : W - 1;
+    const float aw = fw - w0;
     const TI *b = x + (size_t)n * H * W * ldx + cq * VEC;
-    const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * ldy + cq * VEC;
-    if constexpr (VEC == 8) {
-        float a00[8], a01[8], a10[8], a11[8], v[8];
-        ld8(b + ((size_t)h0 * W + w0) * ldx, a00);
-        ld8(b + ((size_t)h0 * W + w1) * ldx, a01);
-        ld8(b + ((size_t)h1 * W + w0) * ldx, a10);
-        ld8(b + ((size_t)h1 * W + w1) * ldx, a11);
+    float la[VEC], lb[VEC];                // the two cached input rows, already interpolated along x
+    int ia = -1, ib = -1;                  // their row indices (block-uniform)
+    auto load_row = [&](int h, float (&l)[VEC]) __attribute__((always_inline)) {
+        float r0[VEC], r1[VEC];
+        if constexpr (VEC == 8) {
+            ld8(b + ((size_t)h * W + w0) * ldx, r0);
+            ld8(b + ((size_t)h * W + w1) * ldx, r1);
+        } else {
+            r0[0] = Elem<TI>::ld(b + ((size_t)h * W + w0) * ldx);
+            r1[0] = Elem<TI>::ld(b + ((size_t)h * W + w1) * ldx);
+        }
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
-            v[q] = (1.f - ah) * ((1.f - aw) * a00[q] + aw * a01[q]) + ah * ((1.f - aw) * a10[q] + aw * a11[q]);
-        st8(y + o, v);
-    } else {
-        const float a00 = Elem<TI>::ld(b + ((size_t)h0 * W + w0) * ldx), a01 = Elem<TI>::ld(b + ((size_t)h0 * W + w1) * ldx);
-        const float a10 = Elem<TI>::ld(b + ((size_t)h1 * W + w0) * ldx), a11 = Elem<TI>::ld(b + ((size_t)h1 * W + w1) * ldx);
-        Elem<TO>::st(y + o, (1.f - ah) * ((1.f - aw) * a00 + aw * a01) + ah * ((1.f - aw) * a10 + aw * a11));
+        for (int q = 0; q < VEC; ++q) l[q] = (1.f - aw) * r0[q] + aw * r1[q];
+    };
+#pragma unroll
+    for (int rr = 0; rr < UP_RO; ++rr) {
+        const int ho = blockIdx.y * UP_RO + rr;
+        if (ho >= Ho) break;
+        const float fh = fmaxf(ho * sh + oh, 0.f);
+        int h0 = (int)fh; h0 = h0 > H - 1 ? H - 1 : h0;
+        const int h1 = h0 + 1 < H ? h0 + 1 : H - 1;
+        const float ah = fh - h0;
+        if (h0 == ib && ia != h0) {        // slide: the lower row becomes the upper one
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) la[q] = lb[q];
+            ia = ib;
+        }
+        if (ia != h0) { load_row(h0, la); ia = h0; }
+        if (ib != h1) {
+            if (h1 == ia) {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) lb[q] = la[q];
+            } else {
+                load_row(h1, lb);
+            }
+            ib = h1;
+        }
+        const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * ldy + cq * VEC;
+        float v[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) v[q] = (1.f - ah) * la[q] + ah * lb[q];
+        if constexpr (VEC == 8) st8(y + o, v);
+        else Elem<TO>::st(y + o, v[0]);
     }
 }
 
@@ -393,11 +425,11 @@ static void launch_up(const void *x, int ldx, void *y, int ldy, int N, int H, in
         oh = 0.5f * sh - 0.5f; ow = 0.5f * sw - 0.5f;
     }
     if (vec) {
-        const dim3 g((unsigned)((Wo * (C / 8) + 255) / 256), (unsigned)Ho, (unsigned)N);
+        const dim3 g((unsigned)((Wo * (C / 8) + 255) / 256), (unsigned)((Ho + UP_RO - 1) / UP_RO), (unsigned)N);
         hipLaunchKernelGGL((upsample_kernel<TI, TO, 8>), g, dim3(256), 0, s, (const TI *)x, ldx, (TO *)y, ldy, N, H, W, C, Ho, Wo,
                            sh, sw, oh, ow);
     } else {
-        const dim3 g((unsigned)((Wo * C + 255) / 256), (unsigned)Ho, (unsigned)N);
+        const dim3 g((unsigned)((Wo * C + 255) / 256), (unsigned)((Ho + UP_RO - 1) / UP_RO), (unsigned)N);
         hipLaunchKernelGGL((upsample_kernel<TI, TO, 1>), g, dim3(256), 0, s, (const TI *)x, ldx, (TO *)y, ldy, N, H, W, C, Ho, Wo,
                            sh, sw, oh, ow);
     }
