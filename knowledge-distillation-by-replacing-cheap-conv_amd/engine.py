@@ -139,21 +139,27 @@ class StudentEngine:
         self._pack.clear()
         self._bn.clear()
 
-    def _w_fwd(self, conv, cin_pad=None):
-        return self._packed(conv.weight, ("fwd", self.dtype, cin_pad),
-                            lambda: ops.pack_conv_weight(conv.weight, self.dtype, KD_PACK_FWD, cin_pad))
+    def _w_fwd(self, conv, cin_pad=None, cin_rot=0):
+        """cin_rot = r: the conv reads its input channels rotated left by r (engine buffer order [r:], [:r]) -- the decoder keeps
+        its concat as [upsampled | fine] so that the 512-B-per-pixel upsample output starts on a 128-B line."""
+        def make():
+            w = conv.weight if not cin_rot else torch.cat([conv.weight.detach()[:, cin_rot:], conv.weight.detach()[:, :cin_rot]], 1).contiguous()
+            return ops.pack_conv_weight(w, self.dtype, KD_PACK_FWD, cin_pad)
+        return self._packed(conv.weight, ("fwd", self.dtype, cin_pad, cin_rot), make)
 
-    def _w_dgrad(self, conv, cout_pad=None):
+    def _w_dgrad(self, conv, cout_pad=None, cin_rot=0):
         """[Cin][flipped taps][Cout] operand of the input-gradient conv; cout_pad zero-fills the contraction axis up to the
         GEMM's K granule (the 19-class classifier, the 48-channel bot_fine)."""
         def make():
             w = conv.weight.detach()
+            if cin_rot:
+                w = torch.cat([w[:, cin_rot:], w[:, :cin_rot]], 1).contiguous()
             if cout_pad is not None and cout_pad != w.shape[0]:
                 wp = torch.zeros((cout_pad,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
                 wp[:w.shape[0]] = w
                 w = wp
             return ops.pack_conv_weight(w, self.dtype, KD_PACK_DGRAD)
-        return self._packed(conv.weight, ("dgrad", self.dtype, cout_pad), make)
+        return self._packed(conv.weight, ("dgrad", self.dtype, cout_pad, cin_rot), make)
 
     def _w_dw(self, conv, flip):
         return self._packed(conv.weight, ("dw", flip), lambda: ops.pack_dw_weight(conv.weight, flip))
@@ -444,12 +450,15 @@ class StudentEngine:
         dec0 = self._new(N, h2, w2, cpad)
         if cpad > cdec:
             dec0[..., cdec:cpad].zero_()         # (only the pad channels: the slices below fill the rest)
-        ops.conv2d(m2, self._w_fwd(net.bot_fine), out_raw=dec0[..., 0:nf])
-        ops.upsample_bilinear_ac(up_small, (h2, w2), out=dec0[..., nf:cdec])
+        # buffer order [upsampled (nu) | fine (nf) | pad]: the reference concatenates [fine, upsampled] (deeplabv3.py:152), the
+        # final conv reads its input channels rotated by nf instead.  The upsample writes 512 B per pixel; starting 96 B into
+        # a line it took 0.43 ms, line-aligned 0.25 (tools/ubench/upsample_align.py)
+        ops.conv2d(m2, self._w_fwd(net.bot_fine), out_raw=dec0[..., nu:cdec])
+        ops.upsample_bilinear_ac(up_small, (h2, w2), out=dec0[..., 0:nu])
         f = self._final()
         sc, sh = self._bn_fold(f[1])
         d1 = self._new(N, h2, w2, f[0].out_channels)
-        ops.conv2d(dec0, self._w_fwd(f[0], cin_pad=cpad), 1, 1, 1, out_act=d1, act_scale=sc, act_shift=sh, act_relu=True,
+        ops.conv2d(dec0, self._w_fwd(f[0], cin_pad=cpad, cin_rot=nf), 1, 1, 1, out_act=d1, act_scale=sc, act_shift=sh, act_relu=True,
                    algo_cin=cdec)
         sc, sh = self._bn_fold(f[4])
         d2 = self._new(N, h2, w2, f[3].out_channels)
@@ -458,7 +467,7 @@ class StudentEngine:
         d3 = self._new(N, h2, w2, ncls, dtype=torch.float32)
         ops.conv2d(d2, self._w_fwd(f[6]), out_raw=d3)
         logits = ops.upsample_bilinear_ac(d3, size, out_dtype=torch.float32, align_corners=not self.is_gscnn)
-        tape["dec"] = dict(cat=cat, rg_cat=rg_cat, m2=m2, rg_m2=rg_m2, dec0=dec0, d1=d1, d2=d2, cdec=cdec, nf=nf, size=size,
+        tape["dec"] = dict(cat=cat, rg_cat=rg_cat, m2=m2, rg_m2=rg_m2, dec0=dec0, d1=d1, d2=d2, cdec=cdec, nf=nf, nu=nu, size=size,
                            small=(h8, w8))
         return logits
 
@@ -682,15 +691,23 @@ class StudentEngine:
         self.probe_grads[name] = s2
 
     # ---- parameter gradients ------------------------------------------------------------------------------------------
-    def _conv_wgrad(self, conv, a_in, g, grads, cin=None):
-        """Weight gradient of a dense conv (a_in = its input as stored, g = gradient of its raw output)."""
+    def _conv_wgrad(self, conv, a_in, g, grads, cin=None, cin_rot=0):
+        """Weight gradient of a dense conv (a_in = its input as stored, g = gradient of its raw output).  cin_rot: a_in holds
+        the conv's input channels rotated left by that many (see _w_fwd); the gradient is rotated back."""
         w = conv.weight
         if not w.requires_grad:
             return
         if cin is not None and cin != a_in.shape[3]:
             a_in = a_in[..., :cin]
         gw = self._grad_like(w)
-        ops.conv2d_wgrad(a_in, g, gw, conv.stride[0], conv.padding[0], conv.dilation[0])
+        if cin_rot:
+            tmp = torch.empty_like(gw)
+            ops.conv2d_wgrad(a_in, g, tmp, conv.stride[0], conv.padding[0], conv.dilation[0])
+            k = w.shape[1] - cin_rot
+            gw[:, cin_rot:].copy_(tmp[:, :k])
+            gw[:, :cin_rot].copy_(tmp[:, k:])
+        else:
+            ops.conv2d_wgrad(a_in, g, gw, conv.stride[0], conv.padding[0], conv.dilation[0])
         grads[w] = gw
         self._grad_done(w)
 
@@ -922,23 +939,26 @@ class StudentEngine:
         sc, _ = self._bn_fold(f[1])
         g_c1 = self._dense_dgrad(_Site("final.3", f[3]), g_c2, mask=dec["d1"], mask_scale=sc)
         self._bn_param_grads(f[1], g_c1, dec["d1"], grads)
-        self._conv_wgrad(f[0], dec["dec0"], g_c1, grads, cin=cdec)
+        self._conv_wgrad(f[0], dec["dec0"], g_c1, grads, cin=cdec, cin_rot=nf)
         if not rg_dec0:
             return None, None
-        g_dec0 = self._new(N, h2, w2, cdec)
-        ops.conv2d(g_c1, self._w_dgrad(f[0]), 1, 1, 1, out_raw=g_dec0)
+        nu = dec["nu"]
+        kf = ((nf + 63) // 64) * 64
+        g_dec0 = self._new(N, h2, w2, nu + kf)                     # [upsampled | fine | pad] like dec0
+        if nu + kf > cdec:
+            g_dec0[..., cdec:].zero_()
+        ops.conv2d(g_c1, self._w_dgrad(f[0], cin_rot=nf), 1, 1, 1, out_raw=g_dec0[..., 0:cdec])
         # bot_fine (1x1 on mod2's output)
         g_m2 = None
-        self._conv_wgrad(net.bot_fine, dec["m2"], g_dec0[..., 0:nf], grads)
+        self._conv_wgrad(net.bot_fine, dec["m2"], g_dec0[..., nu:cdec], grads)
         if dec["rg_m2"]:
-            kf = ((nf + 63) // 64) * 64
             g_m2 = self._new(N, h2, w2, net.bot_fine.in_channels)
-            # K = 48 -> 64: the 16 extra input channels belong to the upsampled part and meet zero weight rows
-            ops.conv2d(g_dec0[..., 0:kf], self._w_dgrad(net.bot_fine, cout_pad=kf), out_raw=g_m2)
+            # K = 48 -> 64: the 16 extra input channels are the zeroed pad and meet zero weight rows
+            ops.conv2d(g_dec0[..., nu:nu + kf], self._w_dgrad(net.bot_fine, cout_pad=kf), out_raw=g_m2)
         # upsample x4 and bot_aspp (1x1 on the ASPP concat)
         g_cat = None
         if dec["rg_cat"] or _is_trainable(net.bot_aspp):
-            g_up = ops.upsample_bilinear_ac_bwd(g_dec0[..., nf:cdec], dec["small"])
+            g_up = ops.upsample_bilinear_ac_bwd(g_dec0[..., 0:nu], dec["small"])
             self._conv_wgrad(net.bot_aspp, dec["cat"], g_up, grads)
             if dec["rg_cat"]:
                 cat = dec["cat"]
