@@ -705,6 +705,15 @@ __device__ __forceinline__ void wait_vm_stores(int nst)
     __builtin_amdgcn_s_barrier();
 }
 
+// the same without the barrier
+__device__ __forceinline__ void wait_vm_only(int nst)
+{
+    if (nst == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (nst == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if (nst == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // Accumulators -> memory through a wave-private 2-KiB LDS patch OUTSIDE the stage buffers (which the next tile's prologue is
 // already filling): one 16-pixel x 64-channel row tile at a time is written as bf16 (8-B chunk c of row r at c ^ r), then
 // read back as two passes of 8 rows x 128 B, 16 B per lane -- whole 128-B lines per pixel for the operand loads and the
@@ -1228,6 +1237,102 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_persist_kerne
     };
 
     const int nst_epi = 2 * MI * ((p.ep.out_raw ? 1 : 0) + (p.ep.out_act ? 1 : 0));
+    if constexpr (PP) {
+        // Ping-pong with seamless tile transitions: the staging runs ahead of the compute ACROSS tiles -- group 0 always issues
+        // the stage two ahead of the one it computes, group 1 its rows of the stage one ahead, whichever tile that stage
+        // belongs to -- so there is no per-tile pipeline fill and no barrier at the top of a tile; a tile boundary is just the
+        // epilogue between two stages.  Stage buffers alternate over the global stage count.
+        auto offsets = [&](int tile, int &tm0, int &tn0, int &ao, int &bo) {
+            int tn, tm;
+            if (p.tn_group > 0) {
+                const int per = p.tiles_m * p.tn_group, blk = tile / per, r = tile - blk * per;
+                tm = r / p.tn_group;
+                tn = blk * p.tn_group + (r - tm * p.tn_group);
+            } else {
+                tn = tile % p.tiles_n;
+                tm = tile / p.tiles_n;
+            }
+            tm0 = tm * CF::BM;
+            tn0 = tn * CF::BN;
+            ao = (tm0 + wv * GA * PR + srow) * p.ldx + chunk * EPC;
+            bo = (tn0 + wv * 2 * GB * PR + srow) * p.Ktot + chunk * EPC;
+        };
+        // issue iterator: (tile, k stage) of the next stage this wave stages, and the global count of stages it has staged
+        int it_tile = walk.t, it_k = 0, it_g = 0, it_ao = 0, it_bo = 0, it_m0, it_n0;
+        offsets(it_tile, it_m0, it_n0, it_ao, it_bo);
+        auto issue = [&]() {
+            if (it_tile >= walk.t_end) return;
+            char *la = lds + (it_g & 1) * CF::STAGE + wv * (GA * 1024);
+            const char *ga[GA], *gb[GB];
+#pragma unroll
+            for (int j = 0; j < GA; ++j) ga[j] = (const char *)(xg + (it_ao + j * PR * p.ldx + it_k * BK)) - j * 1024;
+            glds16_x4(ga[0], ga[1], ga[2], ga[3], la);
+            if (wv < 4) {   // B, which both groups read, comes from group 0 alone (published by its wait a full stage early)
+                char *lb = lds + (it_g & 1) * CF::STAGE + CF::STAGE_A + wv * (2 * GB * 1024);
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+                    for (int j = 0; j < GB; ++j)
+                        gb[j] = (const char *)(wg + (it_bo + (h2 * GB + j) * PR * p.Ktot + it_k * BK)) - j * 1024;
+                    glds16_x4(gb[0], gb[1], gb[2], gb[3], lb + h2 * GB * 1024);
+                }
+            }
+            ++it_g;
+            if (++it_k == nk) {
+                it_k = 0;
+                it_tile += walk.step;
+                if (it_tile < walk.t_end) offsets(it_tile, it_m0, it_n0, it_ao, it_bo);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto read_all = [&](int g) __attribute__((always_inline)) {
+            read_frags(g, 0, a0, b0);
+            read_frags(g, 1, a1, b1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        int g = 0;                       // global index of the stage being computed
+        bool first = true;
+        if (wv < 4) { issue(); issue(); } else { issue(); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();    // the first stages have landed for every wave
+#pragma unroll 1
+        for (int tile = walk.t; tile < walk.t_end; tile += walk.step) {
+            int a_dummy, b_dummy;
+            offsets(tile, m0, n0, a_dummy, b_dummy);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            if (wv < 4) {
+#pragma unroll 1
+                for (int sc = 0; sc < nk; ++sc, ++g) {
+                    read_all(g);                           // (stage g was published behind the previous barrier)
+                    __builtin_amdgcn_s_barrier();          // half-period 2*g: group 1 may stage its rows of stage g + 1
+                    mfmas(a0, b0);
+                    mfmas(a1, b1);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage g + 1 (issued a stage ago)
+                    __builtin_amdgcn_s_barrier();          // half-period 2*g + 1: group 1 has read stage g
+                    issue();                               // stage g + 2
+                }
+            } else {
+#pragma unroll 1
+                for (int sc = 0; sc < nk; ++sc, ++g) {
+                    // this wave's A rows of stage g (issued a stage ago); right after an epilogue its stores may still drain
+                    if (sc == 0 && !first) wait_vm_only((p.tune & 64) ? 0 : nst_epi);
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();          // half-period 2*g
+                    issue();                               // A rows of stage g + 1
+                    read_all(g);
+                    __builtin_amdgcn_s_barrier();          // half-period 2*g + 1
+                    mfmas(a0, b0);
+                    mfmas(a1, b1);
+                }
+            }
+            first = false;
+            if (!(p.tune & 64)) ig_epilogue_rows16<MI, NOPS>(p, lds + CF::LDS_BYTES + wv * 2048, acc, m0 + wm * (16 * MI), n0 + wn * 64, lane);
+        }
+        return;
+    }
     int nst = 0, tcount = 0;
     setup(walk.t);
     prologue();
@@ -1242,41 +1347,7 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_persist_kerne
         if (tl) tlp[0] = wall_clock64();
         wait_vm_stores(nst);
         if (tl) tlp[1] = wall_clock64();
-        if constexpr (PP) {
-            // group g = wv >> 2 (0: waves 0-3, one per SIMD; 1: their siblings) computes stage sc in half-period h = 2*sc + g.
-            // Buffer of stage st is free once group 1 has read stage st - 2 (before barrier 2*st - 3); group 0 issues its pieces of
-            // stage st in half-period 2*st - 3, group 1 in 2*st - 2.  Group 1 drains its DMA before every compute phase (its
-            // youngest pieces are read by group 0 behind the next barrier), group 0 leaves its youngest stage in flight.
-            // One loop per role, two barriers per stage each.  Every DMA wait is a plain vmcnt(0) placed right before a barrier
-            // and two half-periods after the pieces were issued.
-            if (wv < 4) {
-#pragma unroll 1
-                for (int sc = 0; sc < nk; ++sc) {
-                    read_frags(sc, 0, a0, b0);             // (stage sc was published behind the previous barrier)
-                    read_frags(sc, 1, a1, b1);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();          // half-period 2*sc: group 1 may stage its rows of stage sc + 1
-                    mfmas(a0, b0);
-                    mfmas(a1, b1);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage sc + 1 (issued a stage ago)
-                    __builtin_amdgcn_s_barrier();          // half-period 2*sc + 1: group 1 has read stage sc
-                    if (sc + 2 < nk) stage();
-                }
-            } else {
-#pragma unroll 1
-                for (int sc = 0; sc < nk; ++sc) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's A rows of stage sc (issued a stage ago)
-                    __builtin_amdgcn_s_barrier();          // half-period 2*sc
-                    if (sc >= 1 && sc + 1 < nk) stage();   // A rows of stage sc + 1 (stage 1 came with the prologue)
-                    read_frags(sc, 0, a0, b0);
-                    read_frags(sc, 1, a1, b1);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();          // half-period 2*sc + 1
-                    mfmas(a0, b0);
-                    mfmas(a1, b1);
-                }
-            }
-        } else {
+        {
         read_frags(0, 0, a0, b0);
 #pragma unroll 1
         for (int kt = 0; kt < nk; ++kt) {
