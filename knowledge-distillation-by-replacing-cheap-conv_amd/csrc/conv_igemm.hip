@@ -1386,7 +1386,7 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_persist_kerne
 // pixels 0-255), group 1 = waves 4-7 (pixels 256-511).  64-B K stages (one MFMA k-step, 32 MFMAs per wave and half-period):
 // two row buffers of 576 pixels x 64 B (dil <= 16) + two B stages of 128 x 64 B + the epilogue patches = 104 KiB.
 // Group 0 stages row-buffer rows 0-319 (it reads 0 .. 255 + 2*dil) and B; group 1 rows 320-575.
-template <int NOPS>
+template <int NOPS, bool DBG = false>
 __global__ __launch_bounds__(512, 2) void conv_row_pp128_kernel(const ConvParams p)
 {
     typedef bf16_t T;
@@ -1490,7 +1490,7 @@ __global__ __launch_bounds__(512, 2) void conv_row_pp128_kernel(const ConvParams
     };
 
     const int nst_epi = 2 * MI * ((p.ep.out_raw ? 1 : 0) + (p.ep.out_act ? 1 : 0));
-    int nst = 0;
+    int nst = 0, tcount = 0;
     setup(walk.t);
     prologue();
 #pragma unroll 1
@@ -1500,31 +1500,54 @@ __global__ __launch_bounds__(512, 2) void conv_row_pp128_kernel(const ConvParams
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         wait_vm_stores(nst);
+        unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
         if (wv < 4) {
 #pragma unroll 1
             for (int sc = 0; sc < ns; ++sc) {
+                unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+                if (DBG) c0 = clock64();
                 read_frags(sc);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (DBG) c1 = clock64();
                 __builtin_amdgcn_s_barrier();          // half-period 2*sc
+                if (DBG) c2 = clock64();
                 mfmas();
+                if (DBG) c3 = clock64();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage sc + 1 (issued a stage ago)
+                if (DBG) c4 = clock64();
                 __builtin_amdgcn_s_barrier();          // half-period 2*sc + 1: group 1 has read stage sc
+                if (DBG) c5 = clock64();
                 if (sc + 2 < ns) stage_b();
                 if (sc % 3 == 2 && sc / 3 + 2 < nu) stage_a();
+                if (DBG) { const unsigned long long c6 = clock64(); ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[3] += c4 - c3; ph[4] += c5 - c4; ph[5] += c6 - c5; }
             }
         } else {
 #pragma unroll 1
             for (int sc = 0; sc < ns; ++sc) {
+                unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+                if (DBG) c0 = clock64();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's row-buffer rows (issued >= a stage ago)
+                if (DBG) c1 = clock64();
                 __builtin_amdgcn_s_barrier();          // half-period 2*sc
+                if (DBG) c2 = clock64();
                 if (sc % 3 == 0 && sc >= 3 && sc / 3 + 1 < nu) stage_a();
                 if (sc + 2 < ns) stage_b();            // bookkeeping only (group 0 stages B)
+                if (DBG) c3 = clock64();
                 read_frags(sc);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (DBG) c4 = clock64();
                 __builtin_amdgcn_s_barrier();          // half-period 2*sc + 1
+                if (DBG) c5 = clock64();
                 mfmas();
+                if (DBG) { const unsigned long long c6 = clock64(); ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[3] += c4 - c3; ph[4] += c5 - c4; ph[5] += c6 - c5; }
             }
         }
+        if (DBG && lane == 0 && tcount == 1) {   // per-wave phase totals of the second tile (tools/conv_timeline.py)
+            unsigned long long *o = kd_conv_tlog + 256 * 32 * 8 + (blockIdx.x * 8 + wv) * 8;
+            for (int q = 0; q < 6; ++q) o[q] = ph[q];
+            o[6] = ns;
+        }
+        ++tcount;
         const int mw = m0 + wm * 128, nw = n0 + wn * 64;
         walk.t += walk.step;
         const bool more = walk.t < walk.t_end;
@@ -1714,7 +1737,8 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         p.tn_group = 0;
         const int nwg = p.ntiles < ncu ? p.ntiles : ncu;
         const dim3 grid((unsigned)((nwg + 7) / 8 * 8));
-        if (nops == 0) hipLaunchKernelGGL((conv_row_pp128_kernel<0>), grid, dim3(512), 0, s, p);
+        if (p.tune & 512) hipLaunchKernelGGL((conv_row_pp128_kernel<0, true>), grid, dim3(512), 0, s, p);   // phase clocks (no-operand form only)
+        else if (nops == 0) hipLaunchKernelGGL((conv_row_pp128_kernel<0>), grid, dim3(512), 0, s, p);
         else if (nops == 1) hipLaunchKernelGGL((conv_row_pp128_kernel<1>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv_row_pp128_kernel<2>), grid, dim3(512), 0, s, p);
     } else if (row_wide || row_narrow) {

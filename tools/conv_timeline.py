@@ -44,3 +44,26 @@ run("3x3 512->512 [a]", 128, 256, 512, 512, 3, 1)
 run("3x3 512->512 [pra]", 128, 256, 512, 512, 3, 1, res=True)
 run("1x1 1024->2048 [a]", 128, 256, 1024, 2048, 1, 1)
 run("1x1 1024->2048 [pra]", 128, 256, 1024, 2048, 1, 1, res=True)
+
+
+def run_pp128(name, H, W, Cin, NB=4):
+    """phase clocks of the 512 x 128 ping-pong kernel (no-operand epilogue)"""
+    dt = torch.bfloat16
+    x = torch.randn(NB, H, W, Cin, device="cuda").to(dt)
+    w = (torch.randn(128, 3, 3, Cin, device="cuda") * 0.05).to(dt)
+    out = torch.empty(NB, H, W, 128, device="cuda", dtype=dt)
+    sc = torch.ones(128, device="cuda"); sh = torch.zeros(128, device="cuda")
+    for _ in range(3):
+        ops.conv2d(x, w, 1, 1, 1, out_act=out, act_scale=sc, act_shift=sh, act_relu=True)
+    torch.cuda.synchronize()
+    buf = np.zeros(256 * 32 * 8 + 256 * 64, dtype=np.uint64)
+    lib = _lib.lib()
+    lib.kd_debug_conv_tlog.argtypes = [C.c_void_p, C.c_size_t]
+    lib.kd_debug_conv_tlog(buf.ctypes.data, buf.nbytes)
+    pw = buf[256 * 32 * 8:].reshape(256, 8, 8).astype(np.float64).mean(0)
+    print(f"== {name}: phase cycles per 64-B stage -- waves 0-3: reads | barrier | MFMAs | DMA wait | barrier | DMA issue; waves 4-7: DMA wait | barrier | DMA issue | reads | barrier | MFMAs")
+    for wv in range(8):
+        nst = max(pw[wv, 6], 1.0)
+        print(f"     wave {wv}: " + " ".join(f"{v / nst:7.0f}" for v in pw[wv, :6]), f"  sum {pw[wv, :6].sum() / nst:7.0f}")
+
+run_pp128("3x3 128->128 @512x1024 (pp128)", 512, 1024, 128)
