@@ -725,7 +725,8 @@ __device__ __forceinline__ void wait_vm_only(int nst)
 // (slot 0 / slot 1 in the order res_pre, mask, res_post): a single operand is loaded for the whole 128-row sub-tile up
 // front, two operands for 64 rows at a time (one store -> load hand-over instead of three).  Issues exactly 16 stores per
 // output and lane.
-template <int MI, int NOPS>
+// PT: row tiles (2 KiB each) per LDS round trip -- the patch is PT * 2 KiB per wave where the stage buffers leave room
+template <int MI, int NOPS, int PT = 1>
 __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *patch, f32x4_t (&acc)[MI][4], int mw, int nw,
                                                    int lane)
 {
@@ -789,19 +790,26 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
         if (nops >= 2 && hb == 1) { load64(s0, ld0, 1, ra); load64(s1, ld1, 1, rb); }
         if constexpr (NOPS == 3) { if (hb == 1) load64((const T *)e.res_post, e.ld_res_post, 1, rc); }
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int i = 4 * hb + ii;
+        for (int ig = 0; ig < 4; ig += PT) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *(uint2 *)(patch + frow * 128 + (((j * 4 + fq) ^ frow) << 3)) = pk[i][j];
+            for (int it = 0; it < PT; ++it) {
+                const int i = 4 * hb + ig + it;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *(uint2 *)(patch + it * 2048 + frow * 128 + (((j * 4 + fq) ^ frow) << 3)) = pk[i][j];
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
+            for (int it = 0; it < PT; ++it) {
+            const int ii = ig + it;
+            const char *pt = patch + it * 2048;
+#pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int row = h * 8 + lrow, ps = 2 * ii + h;       // ps: 8-row group inside the 64 rows
                 const size_t m = rowof(hb * 8 + ps);
-                const uint2 lo = *(const uint2 *)(patch + row * 128 + ((c2 ^ row) << 3));
-                const uint2 hi = *(const uint2 *)(patch + row * 128 + (((c2 + 1) ^ row) << 3));
+                const uint2 lo = *(const uint2 *)(pt + row * 128 + ((c2 ^ row) << 3));
+                const uint2 hi = *(const uint2 *)(pt + row * 128 + (((c2 + 1) ^ row) << 3));
                 const uint4 rawv = make_uint4(lo.x, lo.y, hi.x, hi.y);
                 float v[8], t[8];
                 ld8((const bf16_t *)&rawv, v);
@@ -837,6 +845,7 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
                     }
                     st8((T *)e.out_act + m * e.ld_act + c0, t);
                 }
+            }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1144,8 +1153,8 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_persist_kerne
 {
     typedef bf16_t T;
     static_assert(CF::PIPE && CF::RB == 128 && CF::NST == 2, "bf16 pipelined configuration");
-    static_assert(CF::LDS_BYTES + CF::NW * 2048 <= 160 * 1024, "stage buffers + epilogue patches");
-    __shared__ __attribute__((aligned(16))) char lds[CF::LDS_BYTES + CF::NW * 2048];
+    static_assert(CF::LDS_BYTES + CF::NW * 4096 <= 160 * 1024, "stage buffers + epilogue patches");
+    __shared__ __attribute__((aligned(16))) char lds[CF::LDS_BYTES + CF::NW * 4096];
     constexpr int RB = CF::RB, BK = RB / 2, EPC = 8;
     constexpr int MI = CF::MI, GA = CF::GA, GB = CF::GB, PR = CF::PR, CPR = RB / 16;
 
@@ -1329,7 +1338,7 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_persist_kerne
                 }
             }
             first = false;
-            if (!(p.tune & 64)) ig_epilogue_rows16<MI, NOPS>(p, lds + CF::LDS_BYTES + wv * 2048, acc, m0 + wm * (16 * MI), n0 + wn * 64, lane);
+            if (!(p.tune & 64)) ig_epilogue_rows16<MI, NOPS, 2>(p, lds + CF::LDS_BYTES + wv * 4096, acc, m0 + wm * (16 * MI), n0 + wn * 64, lane);
         }
         return;
     }
@@ -1371,7 +1380,7 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_persist_kerne
         if (tl) tlp[4] = wall_clock64();
         if (more) { setup(walk.t); if (tl) tlp[7] = wall_clock64(); prologue(); }
         if (tl) tlp[5] = wall_clock64();
-        if (!(p.tune & 64)) ig_epilogue_rows16<MI, NOPS>(p, lds + CF::LDS_BYTES + wv * 2048, acc, mw, nw, lane);
+        if (!(p.tune & 64)) ig_epilogue_rows16<MI, NOPS, 2>(p, lds + CF::LDS_BYTES + wv * 4096, acc, mw, nw, lane);
         if (tl) tlp[6] = wall_clock64();
         ++tcount;
         if (!more) break;
@@ -1392,8 +1401,8 @@ __global__ __launch_bounds__(512, 2) void conv_row_pp128_kernel(const ConvParams
     typedef bf16_t T;
     constexpr int RB = 64, BK = 32, EPC = 8, PR = 16, MI = 8;
     constexpr int BM = 512, BN = 128, AROWS = 576, ABUF = AROWS * RB, BSTAGE = BN * RB, NEED = 2 * ABUF + 2 * BSTAGE;
-    static_assert(NEED + 8 * 2048 <= 160 * 1024, "LDS");
-    __shared__ __attribute__((aligned(16))) char lds[NEED + 8 * 2048];
+    static_assert(NEED + 8 * 8192 <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) char lds[NEED + 8 * 8192];
     char *const ldsB = lds + 2 * ABUF;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1552,7 +1561,7 @@ __global__ __launch_bounds__(512, 2) void conv_row_pp128_kernel(const ConvParams
         walk.t += walk.step;
         const bool more = walk.t < walk.t_end;
         if (more) { setup(walk.t); prologue(); }
-        if (!(p.tune & 64)) ig_epilogue_rows16<MI, NOPS>(p, lds + NEED + wv * 2048, acc, mw, nw, lane);
+        if (!(p.tune & 64)) ig_epilogue_rows16<MI, NOPS, 4>(p, lds + NEED + wv * 8192, acc, mw, nw, lane);
         if (!more) break;
         nst = (p.tune & 64) ? 0 : nst_epi;
     }
