@@ -21,7 +21,7 @@ struct WgradParams {
     const void *dy;
     float *part;  // [splits][taps][Cout][Cin]
     int M, Cin, Cout, lda, ldy;
-    int tiles_ci, rows_per_split, splits, tiles;
+    int tiles_ci, rows_per_split, splits, tiles, dbg;
     // conv geometry of the A operand (kd_conv2d_wgrad): GEMM row m = output pixel (n, ho, wo) reads input pixel
     // (n, ho*stride - pad + ky*dil, wo*stride - pad + kx*dil) for the tap blockIdx.z = ky*kw + kx, zeros outside the image
     int geom, H, W, Ho, Wo, kw, stride, pad, dil;
@@ -427,6 +427,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide_kernel(const WgradPara
 constexpr int WR_XROWS = 96;                        // row-buffer rows: 64 + 2 * dil <= 96
 constexpr int WR_STAGE = 16384 + WR_XROWS * 256;    // dy image + row buffer
 constexpr int WR_NST = 4;
+__device__ unsigned long long kd_wgrad_tlog[256 * 8 * 8];   // KDCC_WGRAD_DBG=1: per-wave phase clocks of conv_wgrad_row_kernel (debug)
 __global__ __launch_bounds__(512, 2) void conv_wgrad_row_kernel(const WgradParams p)
 {
     __shared__ __attribute__((aligned(16))) char lds[WR_NST * WR_STAGE];
@@ -450,6 +451,25 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row_kernel(const WgradParam
     const bf16_t *zero = (const bf16_t *)kd_zero_page_w;
 
     const int prow = lane >> 4, slot = lane & 15;
+    // per-lane invariants of this wave's pieces (phase clocks, tools/wgrad_timeline.py: with the whole address arithmetic per
+    // stage the DMA issue took 1130-1625 of a 3740-cycle stage): element offsets relative to the stage's first dy pixel / first
+    // row-buffer pixel, and the lane-invariant halves of the validity tests
+    int voy[2], vox[3];
+    uint32_t vy = 0, vx = 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {                           // dy: 16 pieces of 4 pixel rows x 256 B
+        const int r = (wv * 2 + j) * 4 + prow;
+        const int c = (slot ^ (tr_f(r) << 1)) * 8;          // source-side swizzle (8 channels per 16-B chunk)
+        voy[j] = r * p.ldy + co0 + c;
+        vy |= co0 + c < p.Cout ? (1u << j) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {                           // row buffer: 24 pieces; row r = pixel x0 - dil + r
+        const int r = (wv * 3 + j) * 4 + prow;
+        const int c = (slot ^ (tr_f(r) << 1)) * 8;
+        vox[j] = r * p.lda + ci0 + c;
+        vx |= (r < 64 + 2 * d && ci0 + c < p.Cin) ? (1u << j) : 0u;
+    }
     auto stage = [&](int st) {
         char *base = lds + (st % WR_NST) * WR_STAGE;
         const int m0 = m_begin + st * 64;
@@ -459,21 +479,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row_kernel(const WgradParam
         const int x0 = (int)rem - ho * p.W;
         const int hi = ho + (ky - 1) * d;
         const bool rowok = hi >= 0 && hi < p.H;
+        const bf16_t *yb = dy + (size_t)m0 * p.ldy;                                                   // wave-uniform bases
+        const bf16_t *xb = a + ((long long)((int)n * p.H + (rowok ? hi : 0)) * p.W + (x0 - d)) * p.lda;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {                       // dy: 16 pieces of 4 pixel rows x 256 B
-            const int pc = wv * 2 + j, r = pc * 4 + prow;
-            const int c = (slot ^ (tr_f(r) << 1)) * 8;      // source-side swizzle (8 channels per 16-B chunk)
-            const bf16_t *s0 = co0 + c < p.Cout ? dy + (size_t)(m0 + r) * p.ldy + co0 + c : zero;
-            glds16(s0, base + pc * 1024);
-        }
+        for (int j = 0; j < 2; ++j) glds16(((vy >> j) & 1u) ? yb + voy[j] : zero, base + (wv * 2 + j) * 1024);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {                       // row buffer: 24 pieces; row r = pixel x0 - dil + r
-            const int pc = wv * 3 + j, r = pc * 4 + prow;
-            const int c = (slot ^ (tr_f(r) << 1)) * 8;
-            const int x = x0 - d + r;
-            const bool ok = rowok && r < 64 + 2 * d && x >= 0 && x < p.W && ci0 + c < p.Cin;
-            const bf16_t *s1 = ok ? a + ((size_t)((int)n * p.H + hi) * p.W + x) * p.lda + ci0 + c : zero;
-            glds16(s1, base + 16384 + pc * 1024);
+        for (int j = 0; j < 3; ++j) {
+            const int x = x0 - d + (wv * 3 + j) * 4 + prow;
+            const bool ok = rowok && ((vx >> j) & 1u) && x >= 0 && x < p.W;
+            glds16(ok ? xb + vox[j] : zero, base + 16384 + (wv * 3 + j) * 1024);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -501,14 +515,28 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row_kernel(const WgradParam
     for (int j = 0; j < 6; ++j) { const int jt = wn * 6 + j; jkx[j] = jt >> 3; jct[j] = jt & 7; }
 
     constexpr int G = 5;   // pieces per wave per stage
+    unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0;
+    const bool dbg = p.dbg != 0;
     for (int st = 0; st < WR_NST - 1 && st < nst; ++st) stage(st);
     for (int st = 0; st < nst; ++st) {
+        unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        if (dbg) c0 = clock64();
         // stage st has landed once at most the stages issued after it are outstanding
         const int ahead = min(nst - 1 - st, WR_NST - 2);
+        if (dbg) {
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            c1 = clock64();
+            __builtin_amdgcn_s_barrier();
+            c2 = clock64();
+        } else {
         if (ahead >= 2) wait_vm_barrier<2 * G>();
         else if (ahead == 1) wait_vm_barrier<G>();
         else wait_vm_barrier<0>();
+        }
         if (st + WR_NST - 1 < nst) stage(st + WR_NST - 1);   // into the buffer every wave left before this barrier
+        if (dbg) c3 = clock64();
         const char *imgY = lds + (st % WR_NST) * WR_STAGE, *imgX = imgY + 16384;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -523,6 +551,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row_kernel(const WgradParam
                 for (int j = 0; j < 6; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
+        if (dbg) { const unsigned long long c4 = clock64(); ph0 += c1 - c0; ph1 += c2 - c1; ph2 += c3 - c2; ph3 += c4 - c3; }
+    }
+    if (dbg && lane == 0 && blockIdx.x < 256) {
+        unsigned long long *o = kd_wgrad_tlog + (blockIdx.x * 8 + wv) * 8;
+        o[0] = ph0; o[1] = ph1; o[2] = ph2; o[3] = ph3; o[4] = nst;
     }
 
     const int frow = lane & 15, fq = lane >> 4;
@@ -679,6 +712,7 @@ extern "C" int kd_pw_wgrad(int32_t dtype, int32_t M, int32_t Cin, int32_t Cout, 
     p.a = a; p.dy = dy; p.part = (float *)workspace;
     p.M = M; p.Cin = Cin; p.Cout = Cout; p.lda = lda; p.ldy = ldy;
     p.tiles_ci = tiles_ci; p.rows_per_split = rps; p.splits = splits; p.tiles = tiles;
+    { static int wd = -1; if (wd < 0) { const char *e = getenv("KDCC_WGRAD_DBG"); wd = e ? atoi(e) : 0; } p.dbg = wd; }
     p.geom = 0; p.kw = 1; p.H = p.W = p.Ho = p.Wo = 0; p.stride = 1; p.pad = 0; p.dil = 1;
     p.mg_howo = p.sh_howo = p.mg_wo = p.sh_wo = 0;
     hipStream_t s = (hipStream_t)stream;
@@ -704,6 +738,12 @@ void fastdiv_magic(uint32_t d, uint32_t &magic, uint32_t &shift)
     magic = (uint32_t)(((1ull << 32) * ((1ull << shift) - d)) / d + 1);
 }
 }  // namespace
+
+extern "C" int kd_debug_wgrad_tlog(unsigned long long *dst, size_t bytes)
+{
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(kd_wgrad_tlog), bytes < sizeof(kd_wgrad_tlog) ? bytes : sizeof(kd_wgrad_tlog), 0,
+                               hipMemcpyDeviceToHost) == hipSuccess ? KD_OK : KD_ERR_HIP;
+}
 
 extern "C" size_t kd_conv2d_wgrad_workspace(const kd_conv_desc *d)
 {
@@ -765,6 +805,7 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
     p.a = x; p.dy = dy; p.part = (float *)workspace;
     p.M = (int)M; p.Cin = d->Cin; p.Cout = d->Cout; p.lda = d->ldx; p.ldy = ld_dy;
     p.tiles_ci = tiles_ci; p.rows_per_split = rps; p.splits = splits; p.tiles = tiles;
+    { static int wd = -1; if (wd < 0) { const char *e = getenv("KDCC_WGRAD_DBG"); wd = e ? atoi(e) : 0; } p.dbg = wd; }
     p.geom = !(taps == 1 && d->stride == 1 && d->pad == 0);
     p.H = d->H; p.W = d->W; p.Ho = d->Ho; p.Wo = d->Wo; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     fastdiv_magic((uint32_t)(d->Ho * d->Wo), p.mg_howo, p.sh_howo);
