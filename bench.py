@@ -259,10 +259,18 @@ def main():
             f.write("shape\tlaunches_per_step\tavg_ms\tTFLOP/s\tms_per_step\n")
             for k, (cnt, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 f.write(f"{k}\t{cnt / a.steps:g}\t{ms / cnt:.4f}\t{fl * cnt / ms / 1e9:.0f}\t{ms / a.steps:.3f}\n")
+    replicas_identical = None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+        # every rank trained on its own shard: the replicas stay bit-identical only if every gradient bucket was
+        # all-reduced before the optimizer read it (fp64 sums of the trainable parameters, min == max over ranks)
+        cs = torch.stack([p.detach().double().sum() for p in model.student.parameters() if p.requires_grad])
+        lo, hi = cs.clone(), cs.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        replicas_identical = bool(torch.equal(lo, hi)) and bool(torch.isfinite(cs).all())
 
     # SURVEY 8(d) defines the metric at 1 and 2 images per GPU; the headline uses --batch (fuller grids).  Measure both
     # side by side (short: 2 warm-up + 8 timed steps each) so one record carries all three.
@@ -308,7 +316,8 @@ def main():
                                    f"RAdam), DeepLabV3+(WRN-38) student plan {a.plan} ({len(plan)} cheap-conv blocks, 9x9 d5), "
                                    f"{a.height}x{a.width}, {a.batch} image/GPU, random-init weights",
                        "plan": a.plan, "mode": a.mode, "per_gpu_batch": a.batch, "global_batch": world * a.batch,
-                       "parallelism": f"dp{world}", "teacher_overlap": overlapped,
+                       "parallelism": f"dp{world}", "replicas_identical_after_run": replicas_identical,
+                       "teacher_overlap": overlapped,
                        "teacher_backend": a.teacher, "per_step_host_syncs": bool(a.ref_logging),
                        "share_frozen_prefix": bool(a.share_prefix),
                        "per_gpu_batch_sweep": sweep},

@@ -155,6 +155,12 @@ int kd_pack_dw_weight(const float *src /* (C,1,k,k) */, float *dst /* [k*k][C] *
                       int32_t C, int32_t k, int32_t flip, kd_stream_t stream);
 int kd_dwconv_fwd(const kd_dw_desc *d, const void *x, const float *w_taps, const float *bias,
                   const kd_dw_epilogue *ep, void *y, kd_stream_t stream);
+/* y = sum_{i<n} dwconv(xs[i], w_taps[i]): the gradient of ONE tensor read by n depthwise convs of one geometry -- the
+ * ASPP input under its replaced branches (models/deeplabv3/deeplabv3.py:64-75: every branch of `features` reads the same
+ * x, so autograd sums their input gradients; with flipped tap tables and pad' as above each term is a dwconv).  All inputs
+ * share d (shape, ldx); y must not alias an input.  n <= 3 bf16 9x9 inputs are summed in registers inside one launch. */
+int kd_dwconv_fwd_sum(const kd_dw_desc *d, int32_t n, const void *const *xs, const float *const *w_taps, void *y,
+                      kd_stream_t stream);
 /* dw[c][ky][kx] = sum_{n,h,w} dy[n,h,w,c] * x[n,h-pad+ky*dil,w-pad+kx*dil,c]; fp32 (C,1,k,k). */
 size_t kd_dwconv_wgrad_workspace(const kd_dw_desc *d);
 int kd_dwconv_wgrad(const kd_dw_desc *d, const void *x, const void *dy, int32_t ld_dy,

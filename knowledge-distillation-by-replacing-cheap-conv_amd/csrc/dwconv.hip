@@ -398,6 +398,8 @@ int check_desc(const kd_dw_desc *d, const char *who)
 int kd_internal_dw_mfma_fwd(const kd_dw_desc *d, const void *x, const float *w_taps, const float *bias,
                             const kd_dw_epilogue *ep, void *y, hipStream_t s);
 
+int kd_internal_dw_mfma_fwd_n(const kd_dw_desc *d, int nb, const void *const *xs, const float *const *ws, const float *bias,
+                              const kd_dw_epilogue *ep, void *y, hipStream_t s);
 int kd_internal_dw_mfma_wgrad_slabs(const kd_dw_desc *d);
 int kd_internal_dw_mfma_wgrad(const kd_dw_desc *d, const void *x, const void *dy, int ld_dy, float *part, hipStream_t s);
 
@@ -462,6 +464,34 @@ extern "C" int kd_dwconv_fwd(const kd_dw_desc *d, const void *x, const float *w_
         else KD_DW_TILES(float, 3);
     }
     KD_CHECK_LAUNCH("kd_dwconv_fwd");
+    return KD_OK;
+}
+
+extern "C" int kd_dwconv_fwd_sum(const kd_dw_desc *d, int32_t n, const void *const *xs, const float *const *w_taps, void *y,
+                                 kd_stream_t stream)
+{
+    int rc = check_desc(d, "kd_dwconv_fwd_sum");
+    if (rc) return rc;
+    KD_REQUIRE(n >= 1 && xs && w_taps && y, KD_ERR_INVALID, "kd_dwconv_fwd_sum: null argument or n < 1");
+    for (int i = 0; i < n; ++i) {
+        KD_REQUIRE(xs[i] && w_taps[i], KD_ERR_INVALID, "kd_dwconv_fwd_sum: null input / tap table %d", i);
+        KD_REQUIRE(xs[i] != y, KD_ERR_INVALID, "kd_dwconv_fwd_sum: y must not alias an input");
+    }
+    // up to three inputs per launch on the matrix cores; longer lists and every other shape chain through res_post
+    int done = 0;
+    if (n <= 3) {
+        const int took = kd_internal_dw_mfma_fwd_n(d, n, xs, w_taps, nullptr, nullptr, y, (hipStream_t)stream);
+        if (took < 0) return took;
+        if (took) return KD_OK;
+    }
+    for (; done < n; ++done) {
+        kd_dw_epilogue ep;
+        memset(&ep, 0, sizeof(ep));
+        ep.res_post = y;
+        ep.ld_res_post = d->ldy;
+        rc = kd_dwconv_fwd(d, xs[done], w_taps[done], nullptr, done ? &ep : nullptr, y, stream);
+        if (rc) return rc;
+    }
     return KD_OK;
 }
 

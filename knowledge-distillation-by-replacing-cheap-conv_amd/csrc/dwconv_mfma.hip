@@ -38,18 +38,21 @@ constexpr int RSTR = CG * CSTR + 32;        // row stride: == 32 (mod 256) -> co
 constexpr int XBYTES = (RY * RSTR + 64 + 15) & ~15;   // one X buffer (+ tail: K padding of the last column tile)
 constexpr int WT_OFF = 2 * XBYTES;
 constexpr int WTBYTES = CG * 9 * 16 * 2;    // bf16 taps [channel][ky][16] (kx 9..15 zero)
-constexpr int LDS_BYTES = WT_OFF + WTBYTES;
+constexpr int LDS_BYTES = WT_OFF + WTBYTES;   // + WTBYTES per additional summed input
 constexpr int OSTR = CG * 2;                // output staging: bytes per pixel
 constexpr int ITEMS = RY * 32 * 2;          // stage-in units per work item: (row, column pair, 8-channel half)
 constexpr int NIT = (ITEMS + NT - 1) / NT;
 constexpr int OPX = 56;                     // output staging: pixels per row (last column tile starts at <= 40)
 static_assert(TLY * OPX * OSTR <= RY * RSTR, "output staging must fit in the input buffer it aliases");
 static_assert(TLY <= 28 && TLX <= 64 && NT == 512, "store phase: thread = (half, 64 columns, row mod 4), 7 rows each");
-static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(LDS_BYTES + 2 * WTBYTES <= 160 * 1024, "LDS budget (three summed inputs)");
 
+constexpr int MAXB = 3;                     // inputs one launch can sum (the three ASPP branches)
 struct DwMfmaParams {
-    const bf16_t *x;
-    const float *w;      // [81][C]
+    const bf16_t *x;     // input 0
+    const float *w;      // its taps [81][C]
+    const bf16_t *xs[MAXB - 1];   // inputs 1.. of the summing kernel (same geometry and pixel stride), taps ws[]
+    const float *ws[MAXB - 1];
     bf16_t *y;
     int N, H, W, C, dil, ldx, ldy;
     int nty, ntx, ncg;
@@ -60,6 +63,24 @@ struct DwMfmaParams {
 struct Item {
     int ry, rx, ty, tx, RV, CV;
 };
+
+// Tile cells outside the image (the zero padding of the stencil: 8 of the 34 staged rows and 8 of the 60 columns when a
+// residue class is one tile) must not cost memory requests: the tile is fetched with BUFFER loads whose offset is pushed
+// past num_records for such cells -- the hardware range check returns zeros without sending anything to the L1/L2 (a clamped
+// address would be served from cache, but each 32-B piece still occupies a request slot, and the request rate is what bounds
+// this kernel).  No branch, no exec masking; a wave whose row is outside the image issues an instruction that fetches nothing.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr uint32_t BUF_OOB = 0x80000000u;   // >= num_records (eligibility keeps an image below 2 GiB)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t image_rsrc(const bf16_t *base, int H, int W, int ld)
+{
+    // bytes reachable from `base` (= image n, channel c0): up to the 16 channels of the last pixel
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)((((size_t)H * W - 1) * ld + CG) * 2), 0x00020000);
+}
+__device__ __forceinline__ uint4 bload16(__amdgpu_buffer_rsrc_t r, uint32_t off)
+{
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 
 __device__ __forceinline__ Item decode_item(const DwMfmaParams &p, int e)
 {
@@ -81,24 +102,24 @@ struct Staged {
 };
 
 // global -> registers: unit (row r, column pair lp, half h) = two pixels of the residue lattice, 8 channels each
-__device__ __forceinline__ void fetch_unit(int it, const DwMfmaParams &p, const bf16_t *xb, const Item &w, int tid, Staged &s)
+__device__ __forceinline__ void fetch_unit(int it, const DwMfmaParams &p, __amdgpu_buffer_rsrc_t xr, const Item &w, int tid, Staged &s)
 {
     const int d = p.dil;
     {
-        const int unit = min(tid + it * NT, ITEMS - 1);
+        const int unit = tid + it * NT;
         const int h = unit & 1, lp = (unit >> 1) & 31, r = unit >> 6;
         const int ly = w.ty * TLY + r - 4, lx = w.tx * TLX + 2 * lp - 4;
         const int yy = w.ry + d * ly, xa = w.rx + d * lx, xb2 = xa + d;
-        const bool rok = ly >= 0 && yy < p.H && lp < 30;
+        const bool rok = ly >= 0 && yy < p.H && lp < 30 && unit < ITEMS;
         const bool aok = rok && lx >= 0 && xa < p.W, bok = rok && lx + 1 >= 0 && xb2 < p.W;
-        const int yc = min(max(yy, 0), p.H - 1);
-        const bf16_t *row = xb + (size_t)yc * p.W * p.ldx + h * 8;
-        s.a[it] = *(const uint4 *)(row + (size_t)min(max(xa, 0), p.W - 1) * p.ldx);
-        s.b[it] = *(const uint4 *)(row + (size_t)min(max(xb2, 0), p.W - 1) * p.ldx);
+        const uint32_t pb = (uint32_t)p.ldx * 2u;
+        const uint32_t oa = (uint32_t)(yy * p.W + xa) * pb + (uint32_t)h * 16u;
+        s.a[it] = bload16(xr, aok ? oa : BUF_OOB);
+        s.b[it] = bload16(xr, bok ? oa + (uint32_t)d * pb : BUF_OOB);
         s.ok[it] = (aok ? 0x0000ffffu : 0u) | (bok ? 0xffff0000u : 0u);
     }
 }
-__device__ __forceinline__ void fetch_item(const DwMfmaParams &p, const bf16_t *xb, const Item &w, int tid, Staged &s)
+__device__ __forceinline__ void fetch_item(const DwMfmaParams &p, __amdgpu_buffer_rsrc_t xb, const Item &w, int tid, Staged &s)
 {
     fetch_unit(0, p, xb, w, tid, s); fetch_unit(1, p, xb, w, tid, s); fetch_unit(2, p, xb, w, tid, s);
     fetch_unit(3, p, xb, w, tid, s); fetch_unit(4, p, xb, w, tid, s);
@@ -130,6 +151,34 @@ __device__ __forceinline__ void write_item(char *X, int tid, const Staged &s)
     }
 }
 
+// Toeplitz operands of this wave's two channels from the bf16 tap table of input `b`
+__device__ __forceinline__ void build_toeplitz(const char *smem, int b, int wave, int fi, int kg, uint4 (&B)[2][9])
+{
+    int widx[8];   // byte offset of tap kx = kg*8 + q - fi in a table row (slot 15 holds zero)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int kx = kg * 8 + q - fi;
+        widx[q] = (kx >= 0 && kx < 9 ? kx : 15) * 2;
+    }
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int ky = 0; ky < 9; ++ky) {
+            const char *wr = smem + WT_OFF + b * WTBYTES + ((wave * 2 + cc) * 9 + ky) * 32;
+            uint32_t v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = *(const bf16_t *)(wr + widx[q]);
+            B[cc][ky] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+        }
+}
+
+// NB = 1: y = dwconv(x, w).  NB = 2, 3: y = sum_b dwconv(x_b, w_b) -- the gradient of a tensor that feeds NB depthwise convs
+// of one geometry (the ASPP input under the three replaced branches).  The work list becomes (item, input) pairs: the
+// accumulators live across the NB inputs of an item, the output phase runs once per item, and the Toeplitz operands of the
+// next input are rebuilt from its tap table (144 2-byte LDS reads per wave, under the barrier that publishes the next tile)
+// -- three register sets of them would not fit.  Against NB chained launches that is one output pass instead of NB and no
+// read-modify-write of the running sum.
+template <int NB>
 __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -140,7 +189,11 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
     const int n = lin / p.nseg;
     const int c0 = cgi * CG;
     const int ibeg = (int)((long long)p.nitems * seg / p.nseg), iend = (int)((long long)p.nitems * (seg + 1) / p.nseg);
-    const bf16_t *xb = p.x + (size_t)n * p.H * p.W * p.ldx + c0;
+    const size_t img = (size_t)n * p.H * p.W * p.ldx + c0;
+    const __amdgpu_buffer_rsrc_t xb0 = image_rsrc(p.x + img, p.H, p.W, p.ldx);
+    const __amdgpu_buffer_rsrc_t xb1 = image_rsrc((NB > 1 ? p.xs[0] : p.x) + img, p.H, p.W, p.ldx);
+    const __amdgpu_buffer_rsrc_t xb2 = image_rsrc((NB > 2 ? p.xs[1] : p.x) + img, p.H, p.W, p.ldx);
+    auto rsrc_of = [&](int b) { return NB > 2 && b == 2 ? xb2 : (NB > 1 && b == 1 ? xb1 : xb0); };
     const int d = p.dil;
 
     // first valid item's loads go out before anything else
@@ -149,62 +202,56 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
     while (cur < iend && (wi.RV <= 0 || wi.CV <= 0)) { ++cur; if (cur < iend) wi = decode_item(p, cur); }
     if (cur >= iend) return;   // block-uniform
     Staged st;
-    fetch_item(p, xb, wi, tid, st);
+    fetch_item(p, xb0, wi, tid, st);
 
-    // taps -> bf16 table (loads issued together, then converted)
+    // taps -> bf16 tables (loads issued together, then converted)
     {
-        bf16_t *wt = (bf16_t *)(smem + WT_OFF);
         constexpr int NW = (CG * 81 + NT - 1) / NT;
-        float wv[NW];
+        float wv[NB][NW];
 #pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const int e = min(tid + i * NT, CG * 81 - 1);
-            wv[i] = p.w[(size_t)(e >> 4) * p.C + c0 + (e & 15)];
-        }
-        for (int e = tid; e < CG * 9 * 16; e += NT) wt[e] = 0;
-        __syncthreads();
+        for (int b = 0; b < NB; ++b) {
+            const float *wsrc = b == 0 ? p.w : p.ws[b > 0 ? b - 1 : 0];
 #pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const int e = tid + i * NT;
-            if (e < CG * 81) {
-                const int c = e & 15, tap = e >> 4, ky = tap / 9, kx = tap - ky * 9;
-                wt[(c * 9 + ky) * 16 + kx] = f32_to_bf16(wv[i]);
+            for (int i = 0; i < NW; ++i) {
+                const int e = min(tid + i * NT, CG * 81 - 1);
+                wv[b][i] = wsrc[(size_t)(e >> 4) * p.C + c0 + (e & 15)];
             }
         }
+        bf16_t *wt = (bf16_t *)(smem + WT_OFF);
+        for (int e = tid; e < NB * CG * 9 * 16; e += NT) wt[e] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const int e = tid + i * NT;
+                if (e < CG * 81) {
+                    const int c = e & 15, tap = e >> 4, ky = tap / 9, kx = tap - ky * 9;
+                    wt[b * (WTBYTES / 2) + (c * 9 + ky) * 16 + kx] = f32_to_bf16(wv[b][i]);
+                }
+            }
     }
     write_item(smem, tid, st);
     __syncthreads();
 
-    // Toeplitz operands of this wave's two channels
     const int fi = lane & 15, kg = lane >> 4;
     uint4 B[2][9];
-    {
-        int widx[8];   // byte offset of tap kx = kg*8 + q - fi in a table row (slot 15 holds zero)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int kx = kg * 8 + q - fi;
-            widx[q] = (kx >= 0 && kx < 9 ? kx : 15) * 2;
-        }
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-            for (int ky = 0; ky < 9; ++ky) {
-                const char *wr = smem + WT_OFF + ((wave * 2 + cc) * 9 + ky) * 32;
-                uint32_t v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = *(const bf16_t *)(wr + widx[q]);
-                B[cc][ky] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
-            }
-    }
+    build_toeplitz(smem, 0, wave, fi, kg, B);
 
-    int buf = 0;
+    int buf = 0, b = 0;
+    f32x4_t acc[2][2][4];
     while (true) {
-        // ---- 1. next item's loads ------------------------------------------------------------------------------------------
-        int nxt = cur + 1;
+        // ---- 1. next (item, input) ------------------------------------------------------------------------------------------
+        int nxt = cur, nb = b + 1;
         Item wn = wi;
-        if (nxt < iend) wn = decode_item(p, nxt);
-        while (nxt < iend && (wn.RV <= 0 || wn.CV <= 0)) { ++nxt; if (nxt < iend) wn = decode_item(p, nxt); }
+        if (nb == NB) {
+            nb = 0;
+            nxt = cur + 1;
+            if (nxt < iend) wn = decode_item(p, nxt);
+            while (nxt < iend && (wn.RV <= 0 || wn.CV <= 0)) { ++nxt; if (nxt < iend) wn = decode_item(p, nxt); }
+        }
         const bool more = nxt < iend;
+        const __amdgpu_buffer_rsrc_t xn = rsrc_of(nb);
 
         // ---- 2. MFMA ---------------------------------------------------------------------------------------------------------
         char *X = smem + buf * XBYTES;
@@ -212,7 +259,6 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
         const int nmt = RV > 16 ? 2 : 1, njt = (CV + 15) >> 4;
         const int m1 = RV - 16;                                  // second row tile overlaps the first
         const int jlast = max(((CV + 7) & ~7) - 16, 0);          // last column tile start (multiple of 8: 16-B reads)
-        f32x4_t acc[2][2][4];
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
             const char *xc = X + (wave * 2 + cc) * CSTR + kg * 16;
@@ -220,16 +266,16 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
             for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) {
-                    acc[cc][mt][jt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                    // the next item's loads go out a unit at a time between the tiles, so they trickle through the
+                    if (NB == 1 || b == 0) acc[cc][mt][jt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                    // the next tile's loads go out a unit at a time between the MFMA tiles, so they trickle through the
                     // memory pipeline under the MFMAs instead of stalling the wave's issue in one burst
                     const int step = cc * 8 + mt * 4 + jt;
                     if (more) {
-                        if (step == 0) fetch_unit(0, p, xb, wn, tid, st);
-                        if (step == 3) fetch_unit(1, p, xb, wn, tid, st);
-                        if (step == 6) fetch_unit(2, p, xb, wn, tid, st);
-                        if (step == 9) fetch_unit(3, p, xb, wn, tid, st);
-                        if (step == 12) fetch_unit(4, p, xb, wn, tid, st);
+                        if (step == 0) fetch_unit(0, p, xn, wn, tid, st);
+                        if (step == 3) fetch_unit(1, p, xn, wn, tid, st);
+                        if (step == 6) fetch_unit(2, p, xn, wn, tid, st);
+                        if (step == 9) fetch_unit(3, p, xn, wn, tid, st);
+                        if (step == 12) fetch_unit(4, p, xn, wn, tid, st);
                     }
                     if (mt < nmt && jt < njt && !(p.dbg & 1)) {
                         const char *xa = xc + ((mt ? m1 : 0) + fi) * RSTR + min(jt * 16, jlast) * 2;
@@ -243,57 +289,61 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
                 }
             }
         }
-        __syncthreads();   // every wave is done reading X: the output staging may overwrite it
+        if (NB == 1 || b == NB - 1) {
+            __syncthreads();   // every wave is done reading X: the output staging may overwrite it
 
-        // ---- 3. accumulators -> [pixel][16 ch] bf16 -> NHWC ------------------------------------------------------------------
-        // staging rows are OPX pixels wide so the last (overlapping) column tile can be written whole; the 4-B channel
-        // pair of wave w goes to slot w ^ (col & 7) of the pixel's 32 B (spreads the 16 lanes of a tile row over banks)
-        if (!(p.dbg & 2)) {
-            char *ob = X + ((kg * 4) * OPX + fi) * OSTR;
+            // ---- 3. accumulators -> [pixel][16 ch] bf16 -> NHWC --------------------------------------------------------------
+            // staging rows are OPX pixels wide so the last (overlapping) column tile can be written whole; the 4-B channel
+            // pair of wave w goes to slot w ^ (col & 7) of the pixel's 32 B (spreads the 16 lanes of a tile row over banks)
+            if (!(p.dbg & 2)) {
+                char *ob = X + ((kg * 4) * OPX + fi) * OSTR;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+                for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt) {
-                    if (mt < nmt && jt < njt) {
-                        const int cb = min(jt * 16, jlast);
-                        char *o = ob + ((mt ? m1 : 0) * OPX + cb) * OSTR + ((wave ^ ((cb + fi) & 7)) << 2);
+                    for (int jt = 0; jt < 4; ++jt) {
+                        if (mt < nmt && jt < njt) {
+                            const int cb = min(jt * 16, jlast);
+                            char *o = ob + ((mt ? m1 : 0) * OPX + cb) * OSTR + ((wave ^ ((cb + fi) & 7)) << 2);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            *(uint32_t *)(o + r * OPX * OSTR) = pack_bf16x2(acc[0][mt][jt][r], acc[1][mt][jt][r]);
+                            for (int r = 0; r < 4; ++r)
+                                *(uint32_t *)(o + r * OPX * OSTR) = pack_bf16x2(acc[0][mt][jt][r], acc[1][mt][jt][r]);
+                        }
                     }
                 }
             }
-        }
-        __syncthreads();
-        if (!(p.dbg & 2)) {
-            // thread = (8-channel half, column, row mod 4): no divisions, 16-B loads/stores
-            const int h = tid & 1, col = (tid >> 1) & 63, rq = tid >> 7;
-            if (col < CV) {
-                const int xx = wi.rx + d * (wi.tx * TLX + col);
-                const char *osrc = X + col * OSTR + ((h ^ ((col >> 2) & 1)) << 4);
-                const bool s1 = col & 1, s2 = col & 2;
-                bf16_t *ycol = p.y + ((size_t)n * p.H * p.W + xx) * p.ldy + c0 + h * 8;
+            __syncthreads();
+            if (!(p.dbg & 2)) {
+                // thread = (8-channel half, column, row mod 4): no divisions, 16-B loads/stores
+                const int h = tid & 1, col = (tid >> 1) & 63, rq = tid >> 7;
+                if (col < CV) {
+                    const int xx = wi.rx + d * (wi.tx * TLX + col);
+                    const char *osrc = X + col * OSTR + ((h ^ ((col >> 2) & 1)) << 4);
+                    const bool s1 = col & 1, s2 = col & 2;
+                    bf16_t *ycol = p.y + ((size_t)n * p.H * p.W + xx) * p.ldy + c0 + h * 8;
 #pragma unroll
-                for (int k = 0; k < (TLY + 3) / 4; ++k) {
-                    const int row = rq + 4 * k;
-                    if (row < RV) {
-                        // un-swizzle: this half's four channel pairs sit in half h ^ bit2(col), permuted by col & 3
-                        const uint4 o = *(const uint4 *)(osrc + row * OPX * OSTR);
-                        const uint32_t a0 = s1 ? o.y : o.x, a1 = s1 ? o.x : o.y, a2 = s1 ? o.w : o.z, a3 = s1 ? o.z : o.w;
-                        const int yy = wi.ry + d * (wi.ty * TLY + row);
-                        *(uint4 *)(ycol + (size_t)yy * p.W * p.ldy) = make_uint4(s2 ? a2 : a0, s2 ? a3 : a1, s2 ? a0 : a2, s2 ? a1 : a3);
+                    for (int k = 0; k < (TLY + 3) / 4; ++k) {
+                        const int row = rq + 4 * k;
+                        if (row < RV) {
+                            // un-swizzle: this half's four channel pairs sit in half h ^ bit2(col), permuted by col & 3
+                            const uint4 o = *(const uint4 *)(osrc + row * OPX * OSTR);
+                            const uint32_t a0 = s1 ? o.y : o.x, a1 = s1 ? o.x : o.y, a2 = s1 ? o.w : o.z, a3 = s1 ? o.z : o.w;
+                            const int yy = wi.ry + d * (wi.ty * TLY + row);
+                            *(uint4 *)(ycol + (size_t)yy * p.W * p.ldy) = make_uint4(s2 ? a2 : a0, s2 ? a3 : a1, s2 ? a0 : a2, s2 ? a1 : a3);
+                        }
                     }
                 }
             }
         }
         if (!more) break;
 
-        // ---- 4. prefetched registers -> the other X buffer -----------------------------------------------------------------
+        // ---- 4. prefetched registers -> the other X buffer (last read two steps ago, behind that step's closing barrier) -----
         buf ^= 1;
         if (!(p.dbg & 4)) write_item(smem + buf * XBYTES, tid, st);
+        if (NB > 1) build_toeplitz(smem, nb, wave, fi, kg, B);
         __syncthreads();
         cur = nxt;
         wi = wn;
+        b = nb;
     }
 }
 
@@ -330,15 +380,15 @@ template <int NU> struct StagedW {
 // stage-in unit (row r, column pair lp, 8-channel half h) of the x tile (HALO = 4) or the g tile (HALO = 0: cells past
 // this tile's valid outputs belong to another tile or to no pixel and are zeroed)
 template <int HALO, int NU>
-__device__ __forceinline__ void fetch_unit_w(int it, const bf16_t *base, int ld, int H, int W, int d, const Item &w, int tid,
+__device__ __forceinline__ void fetch_unit_w(int it, __amdgpu_buffer_rsrc_t base, int ld, int H, int W, int d, const Item &w, int tid,
                                              StagedW<NU> &s)
 {
     constexpr int UNITS = HALO ? ITEMS : GUNITS;
-    const int unit = min(tid + it * NTW, UNITS - 1);
+    const int unit = tid + it * NTW;
     const int h = unit & 1, lp = (unit >> 1) & 31, r = unit >> 6;
     const int ly = w.ty * TLY + r - HALO, lx = w.tx * TLX + 2 * lp - HALO;
     const int yy = w.ry + d * ly, xa = w.rx + d * lx, xb2 = xa + d;
-    bool rok = ly >= 0 && yy < H, aok = lx >= 0 && xa < W, bok = lx + 1 >= 0 && xb2 < W;
+    bool rok = ly >= 0 && yy < H && unit < UNITS, aok = lx >= 0 && xa < W, bok = lx + 1 >= 0 && xb2 < W;
     if (HALO) {
         rok = rok && lp < 30;
     } else {
@@ -346,9 +396,10 @@ __device__ __forceinline__ void fetch_unit_w(int it, const bf16_t *base, int ld,
         aok = aok && 2 * lp < w.CV;
         bok = bok && 2 * lp + 1 < w.CV;
     }
-    const bf16_t *row = base + (size_t)min(max(yy, 0), H - 1) * W * ld + h * 8;
-    s.a[it] = *(const uint4 *)(row + (size_t)min(max(xa, 0), W - 1) * ld);
-    s.b[it] = *(const uint4 *)(row + (size_t)min(max(xb2, 0), W - 1) * ld);
+    const uint32_t pb = (uint32_t)ld * 2u;
+    const uint32_t oa = (uint32_t)(yy * W + xa) * pb + (uint32_t)h * 16u;
+    s.a[it] = bload16(base, rok && aok ? oa : BUF_OOB);
+    s.b[it] = bload16(base, rok && bok ? oa + (uint32_t)d * pb : BUF_OOB);
     s.ok[it] = (rok && aok ? 0x0000ffffu : 0u) | (rok && bok ? 0xffff0000u : 0u);
 }
 
@@ -389,8 +440,8 @@ __global__ __launch_bounds__(NTW, 1) void dw_mfma_wgrad_kernel(DwWgMfmaParams p)
     const int n = lin / p.nseg;
     const int c0 = cgi * CG;
     const int ibeg = (int)((long long)p.nitems * seg / p.nseg), iend = (int)((long long)p.nitems * (seg + 1) / p.nseg);
-    const bf16_t *xb = p.x + (size_t)n * p.H * p.W * p.ldx + c0;
-    const bf16_t *gb = p.g + (size_t)n * p.H * p.W * p.ldg + c0;
+    const __amdgpu_buffer_rsrc_t xb = image_rsrc(p.x + (size_t)n * p.H * p.W * p.ldx + c0, p.H, p.W, p.ldx);
+    const __amdgpu_buffer_rsrc_t gb = image_rsrc(p.g + (size_t)n * p.H * p.W * p.ldg + c0, p.H, p.W, p.ldg);
     DwMfmaParams px;   // decode_item reads only the geometry
     px.H = p.H; px.W = p.W; px.dil = p.dil; px.ldx = p.ldx; px.ntx = p.ntx;
 
@@ -510,13 +561,17 @@ static void dw_mfma_split(int N, int C, int H, int W, int dil, int *nty, int *nt
 
 }  // namespace
 
-// Returns 1 if the MFMA path took the call, 0 if the shape is not eligible (caller falls back to the register kernel),
-// < 0 on a launch error.
-int kd_internal_dw_mfma_fwd(const kd_dw_desc *d, const void *x, const float *w_taps, const float *bias,
-                            const kd_dw_epilogue *ep, void *y, hipStream_t s)
+// y = sum_{b < nb} dwconv(xs[b], ws[b]) on the matrix cores.  Returns 1 if the MFMA path took the call, 0 if the shape is
+// not eligible (caller falls back to the register kernel, chained through res_post for nb > 1), < 0 on a launch error.
+int kd_internal_dw_mfma_fwd_n(const kd_dw_desc *d, int nb, const void *const *xs, const float *const *ws, const float *bias,
+                              const kd_dw_epilogue *ep, void *y, hipStream_t s)
 {
+    if (nb < 1 || nb > MAXB) return 0;
     if (d->dtype != KD_BF16 || d->k != 9 || d->C % CG != 0 || d->ldx % 8 != 0 || d->ldy % 8 != 0) return 0;
-    if (!kd_aligned16(x) || !kd_aligned16(y)) return 0;
+    for (int b = 0; b < nb; ++b)
+        if (!xs[b] || !ws[b] || !kd_aligned16(xs[b])) return 0;
+    if (!kd_aligned16(y)) return 0;
+    if ((long long)d->H * d->W * d->ldx * 2 >= (long long)BUF_OOB) return 0;   // buffer-load offsets are 32-bit per image
     // Calls with a bias or an epilogue stay on the register kernel: their extra operands are read per pixel in 32-B
     // (16-channel) pieces here, which the memory system serves at about a third of the rate of the register kernel's
     // 128-B-per-pixel rows (measured: 1.22 vs 0.99 ms at 4096 channels, mask + residual, 2 images).
@@ -528,7 +583,11 @@ int kd_internal_dw_mfma_fwd(const kd_dw_desc *d, const void *x, const float *w_t
         enabled = !(e && e[0] == '0');
     }
     if (!enabled) return 0;
-    p.x = (const bf16_t *)x; p.w = w_taps; p.y = (bf16_t *)y;
+    p.x = (const bf16_t *)xs[0]; p.w = ws[0]; p.y = (bf16_t *)y;
+    for (int b = 1; b < MAXB; ++b) {
+        p.xs[b - 1] = (const bf16_t *)(b < nb ? xs[b] : xs[0]);
+        p.ws[b - 1] = b < nb ? ws[b] : ws[0];
+    }
     { static int dbg = -1; if (dbg < 0) { const char *e = getenv("KDCC_DW_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.dil = d->dil; p.ldx = d->ldx; p.ldy = d->ldy;
     dw_mfma_split(d->N, d->C, d->H, d->W, d->dil, &p.nty, &p.ntx, &p.nitems, &p.nseg);
@@ -536,16 +595,19 @@ int kd_internal_dw_mfma_fwd(const kd_dw_desc *d, const void *x, const float *w_t
     if (p.nitems <= 0) return 0;
     const long long blocks = (long long)d->N * p.ncg * p.nseg;
     if (blocks > 0x7fffffffLL || (long long)d->N * d->H * d->W > 0x7fffffffLL) return 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)dw_mfma_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
-            hipSuccess) {
-            kd_set_error("kd_dwconv_fwd: cannot reserve %d B of LDS", LDS_BYTES);
+    const int lds = LDS_BYTES + (nb - 1) * WTBYTES;
+    const void *fn = nb == 1 ? (const void *)dw_mfma_fwd_kernel<1> : nb == 2 ? (const void *)dw_mfma_fwd_kernel<2> : (const void *)dw_mfma_fwd_kernel<3>;
+    static bool attr_set[MAXB + 1] = {};
+    if (!attr_set[nb]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            kd_set_error("kd_dwconv_fwd: cannot reserve %d B of LDS", lds);
             return KD_ERR_HIP;
         }
-        attr_set = true;
+        attr_set[nb] = true;
     }
-    hipLaunchKernelGGL(dw_mfma_fwd_kernel, dim3((unsigned)blocks), dim3(NT), LDS_BYTES, s, p);
+    if (nb == 1) hipLaunchKernelGGL(dw_mfma_fwd_kernel<1>, dim3((unsigned)blocks), dim3(NT), lds, s, p);
+    else if (nb == 2) hipLaunchKernelGGL(dw_mfma_fwd_kernel<2>, dim3((unsigned)blocks), dim3(NT), lds, s, p);
+    else hipLaunchKernelGGL(dw_mfma_fwd_kernel<3>, dim3((unsigned)blocks), dim3(NT), lds, s, p);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
         kd_set_error("kd_dwconv_fwd(mfma): launch failed: %s", hipGetErrorString(err));
@@ -554,11 +616,18 @@ int kd_internal_dw_mfma_fwd(const kd_dw_desc *d, const void *x, const float *w_t
     return 1;
 }
 
+int kd_internal_dw_mfma_fwd(const kd_dw_desc *d, const void *x, const float *w_taps, const float *bias,
+                            const kd_dw_epilogue *ep, void *y, hipStream_t s)
+{
+    return kd_internal_dw_mfma_fwd_n(d, 1, &x, &w_taps, bias, ep, y, s);
+}
+
 static bool dw_mfma_wgrad_eligible(const kd_dw_desc *d, const void *x, const void *dy, int ld_dy)
 {
     if (d->dtype != KD_BF16 || d->k != 9 || d->C % CG != 0 || d->ldx % 8 != 0 || ld_dy % 8 != 0) return false;
     if ((x && !kd_aligned16(x)) || (dy && !kd_aligned16(dy))) return false;
     if ((long long)d->N * d->H * d->W > 0x7fffffffLL) return false;
+    if ((long long)d->H * d->W * (d->ldx > ld_dy ? d->ldx : ld_dy) * 2 >= (long long)BUF_OOB) return false;   // 32-bit buffer offsets
     static int enabled = -1;
     if (enabled < 0) {
         const char *e = getenv("KDCC_DW_MFMA");

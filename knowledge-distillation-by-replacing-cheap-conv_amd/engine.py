@@ -30,6 +30,8 @@ Design (MI355X-first, not a module-by-module translation):
 Parameters are read from the nn.Module tree (fp32 masters, reference checkpoint keys); packed
 operands are cached per parameter version, so frozen weights are packed once.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -37,6 +39,8 @@ from . import ops
 from ._lib import KD_PACK_DGRAD, KD_PACK_FWD
 from .models.students.transform_blocks import DepthwiseSeparableBlock
 from .models.wider_resnet import IdentityResidualBlock
+
+_DW_SUM = os.environ.get("KDCC_DW_SUM", "1") != "0"   # A/B: 0 = one depthwise input-gradient launch per ASPP branch
 
 
 class EngineError(RuntimeError):
@@ -745,8 +749,10 @@ class StudentEngine:
         ops.conv2d(g, self._w_dgrad(conv), 1, site.dil * (site.k - 1) - site.pad, site.dil, out_raw=out, **ep)
         return out
 
-    def _cheap_bwd(self, site, a_in, mid, g, grads, need_in, **ep):
-        """Backward of dw -> pw: both weight gradients, and (optionally) the input gradient with epilogue `ep`."""
+    def _cheap_bwd(self, site, a_in, mid, g, grads, need_in, defer=None, **ep):
+        """Backward of dw -> pw: both weight gradients, and (optionally) the input gradient with epilogue `ep`.  With a
+        `defer` list the depthwise input gradient is not run: (gradient of the depthwise output, flipped taps, site) is
+        appended instead, for a caller that sums several of them in one launch (`ops.dwconv_sum`)."""
         dw, pw = site.mod.separable_conv, site.mod.pointwise_conv
         if pw.weight.requires_grad:
             gw = self._grad_like(pw.weight)
@@ -764,6 +770,9 @@ class StudentEngine:
             grads[dw.weight] = gw
             self._grad_done(dw.weight)
         if not need_in:
+            return None
+        if defer is not None:
+            defer.append((g_mid, self._w_dw(dw, True), site))
             return None
         return ops.dwconv(g_mid, self._w_dw(dw, True), site.k, site.dil * (site.k - 1) - site.pad, site.dil, **ep)
 
@@ -840,7 +849,12 @@ class StudentEngine:
         if g_cat_hint is not None:
             scale = self._cat_scale(aspp)
             g_cat = ops.relu_bn_bwd(g_cat_hint, cat, scale, res=g_cat)
+        # x7 feeds every branch: its gradient is the sum of the branches' input gradients.  The replaced (cheap) branches go
+        # first -- weight gradients per branch, their depthwise input gradients summed inside ONE launch per geometry
+        # (registers instead of a read-modify-write of the running 4096-channel sum per branch) -- then the dense branches
+        # chain onto that sum through their dgrad epilogue.
         g_x7 = None
+        todo = []
         for i, br in enumerate(arec["branches"]):
             sl = slice(red * (i + lead), red * (i + lead + 1))
             g = g_aspp.get(i)
@@ -855,9 +869,31 @@ class StudentEngine:
                 self._probe(site.name, g, br["probe_raw"], None)
             if site.cheap and not g.is_contiguous():
                 g = g.contiguous()   # the depthwise / pointwise-wgrad kernels take dense views
-            g_in = self._site_bwd(site, x7, br["mid"], g, grads, rg7, res_post=g_x7)
-            if g_in is not None:
-                g_x7 = g_in
+            todo.append((site, br, g))
+        deferred = []
+        for site, br, g in todo:
+            if site.cheap and _DW_SUM:
+                self._cheap_bwd(site, x7, br["mid"], g, grads, rg7, defer=deferred)
+            elif site.cheap:   # A/B: one launch per branch, the running sum chained through res_post
+                g_in = self._cheap_bwd(site, x7, br["mid"], g, grads, rg7, res_post=g_x7)
+                if g_in is not None:
+                    g_x7 = g_in
+        groups = {}
+        for g_mid, w_t, site in deferred:
+            groups.setdefault((site.k, site.pad, site.dil, tuple(g_mid.shape), g_mid.dtype), []).append((g_mid, w_t))
+        for (k, pad, dil, _, _), items in groups.items():
+            for j in range(0, len(items), 3):
+                part = items[j:j + 3]
+                if g_x7 is None:
+                    g_x7 = ops.dwconv_sum([a for a, _ in part], [w for _, w in part], k, dil * (k - 1) - pad, dil)
+                else:   # a second geometry / a fourth branch: chain onto the running sum
+                    for a, w in part:
+                        g_x7 = ops.dwconv(a, w, k, dil * (k - 1) - pad, dil, res_post=g_x7)
+        for site, br, g in todo:
+            if not site.cheap:
+                g_in = self._site_bwd(site, x7, br["mid"], g, grads, rg7, res_post=g_x7)
+                if g_in is not None:
+                    g_x7 = g_in
         if g_cat is not None:
             g_x7 = self._image_pool_bwd(arec, g_cat[..., 0:red], grads, g_x7)
         return g_x7

@@ -225,6 +225,32 @@ def dwconv(x, w_taps, k, pad, dil, bias=None, out=None, res_pre=None, mask=None,
     return out
 
 
+def dwconv_sum(xs, w_taps, k, pad, dil, out=None):
+    """out = sum_i dwconv(xs[i], w_taps[i]): the input gradient of a tensor that feeds several depthwise convs of one geometry
+    (deeplabv3.py:64-75, the ASPP input under its replaced branches), summed inside one launch where the shape allows."""
+    xs, w_taps = list(xs), list(w_taps)
+    if not xs or len(xs) != len(w_taps):
+        raise ValueError("dwconv_sum: need as many tap tables as inputs")
+    _need_cuda(*xs, *w_taps, out)
+    N, H, W, Cc = xs[0].shape
+    ld = nhwc_ld(xs[0])
+    for x, w in zip(xs, w_taps):
+        if tuple(x.shape) != (N, H, W, Cc) or x.dtype != xs[0].dtype or nhwc_ld(x) != ld:
+            raise ValueError("dwconv_sum: inputs must share shape, dtype and pixel stride")
+        if tuple(w.shape) != (k * k, Cc) or w.dtype != torch.float32 or not w.is_contiguous():
+            raise ValueError("dwconv_sum: w_taps must be contiguous fp32 [k*k][C]")
+    if out is None:
+        out = torch.empty((N, H, W, Cc), dtype=xs[0].dtype, device=xs[0].device)
+    if tuple(out.shape) != (N, H, W, Cc) or out.dtype != xs[0].dtype:
+        raise ValueError("dwconv_sum: bad output view")
+    d = _dw_desc(xs[0], k, pad, dil, out)
+    n = len(xs)
+    xp = (C.c_void_p * n)(*[_ptr(x) for x in xs])
+    wp = (C.c_void_p * n)(*[_ptr(w) for w in w_taps])
+    check(_lib.lib().kd_dwconv_fwd_sum(C.byref(d), n, xp, wp, _ptr(out), stream_ptr()), "kd_dwconv_fwd_sum")
+    return out
+
+
 def dwconv_wgrad(x, dy, dw, k, pad, dil, accumulate=False, workspace=None):
     _need_cuda(x, dy, dw)
     N, H, W, Cc = x.shape

@@ -93,18 +93,25 @@ class GradReducer:
 def init_distributed(use_cuda=None):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run) and, when WORLD_SIZE > 1, creates the
     process group once: backend "nccl" (= RCCL over xGMI) when the run uses the GPUs, "gloo" otherwise.  Idempotent --
-    ConfigParser, BaseTrainer and bench.py all call it.  Returns (rank, local_rank, world)."""
+    ConfigParser, BaseTrainer and bench.py all call it.  Returns (rank, local_rank, world).
+
+    Rehearsal hooks for a one-GPU box (never set on the node): KDCC_DIST_SHARE_GPU=1 maps every local rank onto the
+    devices that exist (local_rank % device_count) and KDCC_DIST_BACKEND=gloo exchanges the device tensors through gloo,
+    since RCCL refuses two ranks on one device -- the N > 1 code path of bench.py / the trainers then runs end to end."""
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     cuda = torch.cuda.is_available() if use_cuda is None else (bool(use_cuda) and torch.cuda.is_available())
     if cuda:
+        if os.environ.get("KDCC_DIST_SHARE_GPU") == "1":
+            local %= torch.cuda.device_count()
         torch.cuda.set_device(local)
     if dist.is_initialized():
         return dist.get_rank(), local, dist.get_world_size()
     if world > 1:
-        dist.init_process_group(backend="nccl" if cuda else "gloo", rank=rank, world_size=world)
+        backend = os.environ.get("KDCC_DIST_BACKEND") or ("nccl" if cuda else "gloo")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 
 

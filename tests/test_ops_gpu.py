@@ -288,6 +288,34 @@ def test_dwconv_fwd_dgrad_wgrad(K, dt, case):
     assert_close(dw.cpu().numpy(), orc.conv2d_wgrad(x, gy, w.shape, pad=p, dil=d, groups=Cc), dt, "dw wgrad")
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [
+    # N, H, W, C, k, pad, dil, inputs
+    (2, 24, 32, 16, 9, 20, 5, 3),        # one lattice tile per residue class (the ASPP shape in small)
+    (1, 140, 270, 32, 9, 20, 5, 3),      # several tiles with real halos, ragged last tiles
+    (1, 40, 70, 16, 9, 4, 1, 2),         # two inputs, dil 1
+    (2, 64, 128, 48, 9, 20, 5, 3),       # three channel groups
+    (1, 23, 37, 72, 9, 20, 5, 3),        # C % 16 != 0: register kernels chained through res_post
+    (1, 24, 32, 16, 9, 20, 5, 4),        # more inputs than one launch sums
+    (1, 8, 8, 16, 3, 1, 1, 2),           # 3x3
+])
+def test_dwconv_sum(K, dt, case):
+    """kd_dwconv_fwd_sum: the ASPP input gradient = sum of the branches' depthwise input gradients (deeplabv3.py:64-75),
+    against the sum of the oracle's per-branch dgrads; bf16 sums in fp32 registers inside one launch (n <= 3)."""
+    N, H, W, Cc, k, p, d, n = case
+    gs = [q(rnd(N, Cc, H, W), dt) for _ in range(n)]
+    ws = [rnd(Cc, 1, k, k, scale=1.0 / k) for _ in range(n)]
+    ref = sum(orc.conv2d_dgrad(g, w, g.shape, pad=p, dil=d, groups=Cc) for g, w in zip(gs, ws))
+    taps = [K.pack_dw_weight(torch.from_numpy(w).cuda(), flip=True) for w in ws]
+    out = K.dwconv_sum([dev_nhwc(g, dt) for g in gs], taps, k, d * (k - 1) - p, d)
+    assert_close(host_nchw(out), ref, dt, f"dw sum of {n}")
+    if n <= 3:   # same numbers as the chained launches up to the rounding of the running bf16 sum
+        run = None
+        for g, t in zip(gs, taps):
+            run = K.dwconv(dev_nhwc(g, dt), t, k, d * (k - 1) - p, d, res_post=run)
+        assert_close(host_nchw(out), host_nchw(run), dt, "dw sum vs chain")
+
+
 @pytest.mark.parametrize("case", [(2, 24, 32, 16, 5), (1, 131, 261, 32, 5), (1, 30, 60, 16, 2)])
 def test_dwconv_epilogue_bf16(K, case):
     """bias + res_pre + BN/ReLU mask + res_post through the depthwise epilogue, multi-tile shapes included."""

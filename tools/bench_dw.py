@@ -5,6 +5,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import kdcc_amd
+if os.environ.get("KDCC_LIB"):   # A/B against another build of the library (same ABI)
+    kdcc_amd._lib.LIB_PATH = os.environ["KDCC_LIB"]
 from kdcc_amd import ops
 
 def t(fn, it=10):
@@ -31,6 +33,17 @@ for C in (512, 1024, 2048, 4096):
     print(f"dw fwd   C={C:5d}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TFLOP/s  {by/ms/1e6:7.1f} GB/s (algorithmic in+out)")
     ms = t(lambda: ops.dwconv(x, wt, k, p, d, out=y, mask=g, mask_scale=torch.ones(C, device='cuda'), res_post=g))
     print(f"dw dgrad(mask+res) C={C:5d}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TFLOP/s")
+    if C == 4096:   # the ASPP input gradient: three branches summed in one launch vs chained through res_post
+        g2, g3 = torch.randn_like(g), torch.randn_like(g)
+        ms = t(lambda: ops.dwconv_sum([x, g2, g3], [wt, wt, wt], k, p, d, out=y))
+        print(f"dw sum3 (one launch) C={C:5d}: {ms:7.3f} ms")
+        def chain():
+            r = ops.dwconv(x, wt, k, p, d, out=y)
+            r = ops.dwconv(g2, wt, k, p, d, out=y, res_post=r)
+            ops.dwconv(g3, wt, k, p, d, out=y, res_post=r)
+        ms = t(chain)
+        print(f"dw sum3 (chained)    C={C:5d}: {ms:7.3f} ms")
+        del g2, g3
     ms = t(lambda: ops.dwconv_wgrad(x, g, dw, k, p, d, workspace=ws))
     print(f"dw wgrad C={C:5d}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TFLOP/s")
 
