@@ -161,6 +161,11 @@ int kd_dwconv_fwd(const kd_dw_desc *d, const void *x, const float *w_taps, const
  * share d (shape, ldx); y must not alias an input.  n <= 3 bf16 9x9 inputs are summed in registers inside one launch. */
 int kd_dwconv_fwd_sum(const kd_dw_desc *d, int32_t n, const void *const *xs, const float *const *w_taps, void *y,
                       kd_stream_t stream);
+/* ys[i] = dwconv(x, w_taps[i]), i < n: the forward of the same fan-out (deeplabv3.py:71-75, `for f in self.features:
+ * out = torch.cat((out, f(x)), 1)` with each f's 3x3 conv replaced by a DepthwiseSeparableBlock): one pass over x for up to
+ * three bf16 9x9 outputs per launch.  Outputs share d->ldy and must not alias x or each other. */
+int kd_dwconv_fwd_fanout(const kd_dw_desc *d, int32_t n, const void *x, const float *const *w_taps, void *const *ys,
+                         kd_stream_t stream);
 /* dw[c][ky][kx] = sum_{n,h,w} dy[n,h,w,c] * x[n,h-pad+ky*dil,w-pad+kx*dil,c]; fp32 (C,1,k,k). */
 size_t kd_dwconv_wgrad_workspace(const kd_dw_desc *d);
 int kd_dwconv_wgrad(const kd_dw_desc *d, const void *x, const void *dy, int32_t ld_dy,

@@ -77,6 +77,7 @@ _SIGS = {
     "kd_pack_dw_weight": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "kd_dwconv_fwd": (c_int, [_P(DwDesc), c_vp, c_vp, c_vp, _P(DwEpilogue), c_vp, c_vp]),
     "kd_dwconv_fwd_sum": (c_int, [_P(DwDesc), c_int, c_vp, c_vp, c_vp, c_vp]),
+    "kd_dwconv_fwd_fanout": (c_int, [_P(DwDesc), c_int, c_vp, c_vp, c_vp, c_vp]),
     "kd_dwconv_wgrad_workspace": (c_sz, [_P(DwDesc)]),
     "kd_dwconv_wgrad": (c_int, [_P(DwDesc), c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_sz, c_vp]),
     "kd_stem_conv": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),

@@ -398,8 +398,8 @@ int check_desc(const kd_dw_desc *d, const char *who)
 int kd_internal_dw_mfma_fwd(const kd_dw_desc *d, const void *x, const float *w_taps, const float *bias,
                             const kd_dw_epilogue *ep, void *y, hipStream_t s);
 
-int kd_internal_dw_mfma_fwd_n(const kd_dw_desc *d, int nb, const void *const *xs, const float *const *ws, const float *bias,
-                              const kd_dw_epilogue *ep, void *y, hipStream_t s);
+int kd_internal_dw_mfma_fwd_n(const kd_dw_desc *d, int nb, int fan, const void *const *xs, const float *const *ws, void *const *ys,
+                              const float *bias, const kd_dw_epilogue *ep, hipStream_t s);
 int kd_internal_dw_mfma_wgrad_slabs(const kd_dw_desc *d);
 int kd_internal_dw_mfma_wgrad(const kd_dw_desc *d, const void *x, const void *dy, int ld_dy, float *part, hipStream_t s);
 
@@ -480,7 +480,7 @@ extern "C" int kd_dwconv_fwd_sum(const kd_dw_desc *d, int32_t n, const void *con
     // up to three inputs per launch on the matrix cores; longer lists and every other shape chain through res_post
     int done = 0;
     if (n <= 3) {
-        const int took = kd_internal_dw_mfma_fwd_n(d, n, xs, w_taps, nullptr, nullptr, y, (hipStream_t)stream);
+        const int took = kd_internal_dw_mfma_fwd_n(d, n, 0, xs, w_taps, &y, nullptr, nullptr, (hipStream_t)stream);
         if (took < 0) return took;
         if (took) return KD_OK;
     }
@@ -491,6 +491,32 @@ extern "C" int kd_dwconv_fwd_sum(const kd_dw_desc *d, int32_t n, const void *con
         ep.ld_res_post = d->ldy;
         rc = kd_dwconv_fwd(d, xs[done], w_taps[done], nullptr, done ? &ep : nullptr, y, stream);
         if (rc) return rc;
+    }
+    return KD_OK;
+}
+
+extern "C" int kd_dwconv_fwd_fanout(const kd_dw_desc *d, int32_t n, const void *x, const float *const *w_taps, void *const *ys,
+                                    kd_stream_t stream)
+{
+    int rc = check_desc(d, "kd_dwconv_fwd_fanout");
+    if (rc) return rc;
+    KD_REQUIRE(n >= 1 && x && w_taps && ys, KD_ERR_INVALID, "kd_dwconv_fwd_fanout: null argument or n < 1");
+    for (int i = 0; i < n; ++i) {
+        KD_REQUIRE(ys[i] && w_taps[i], KD_ERR_INVALID, "kd_dwconv_fwd_fanout: null output / tap table %d", i);
+        KD_REQUIRE(ys[i] != x, KD_ERR_INVALID, "kd_dwconv_fwd_fanout: an output must not alias the input");
+        for (int j = 0; j < i; ++j) KD_REQUIRE(ys[i] != ys[j], KD_ERR_INVALID, "kd_dwconv_fwd_fanout: outputs %d and %d alias", j, i);
+    }
+    // up to three outputs per launch on the matrix cores (the tile of x staged once); everything else one launch per output
+    for (int done = 0; done < n;) {
+        const int m = n - done < 3 ? n - done : 3;
+        const int took = kd_internal_dw_mfma_fwd_n(d, m, 1, &x, w_taps + done, ys + done, nullptr, nullptr, (hipStream_t)stream);
+        if (took < 0) return took;
+        if (took) { done += m; continue; }
+        for (int i = 0; i < m; ++i) {
+            rc = kd_dwconv_fwd(d, x, w_taps[done + i], nullptr, nullptr, ys[done + i], stream);
+            if (rc) return rc;
+        }
+        done += m;
     }
     return KD_OK;
 }

@@ -52,8 +52,9 @@ struct DwMfmaParams {
     const bf16_t *x;     // input 0
     const float *w;      // its taps [81][C]
     const bf16_t *xs[MAXB - 1];   // inputs 1.. of the summing kernel (same geometry and pixel stride), taps ws[]
-    const float *ws[MAXB - 1];
+    const float *ws[MAXB - 1];    // taps of input / output 1..
     bf16_t *y;
+    bf16_t *ys[MAXB - 1];         // outputs 1.. of the fan-out kernel (same pixel stride as y)
     int N, H, W, C, dil, ldx, ldy;
     int nty, ntx, ncg;
     int nitems, nseg;    // work items per (image, channel group); segments they are split into
@@ -172,15 +173,20 @@ __device__ __forceinline__ void build_toeplitz(const char *smem, int b, int wave
         }
 }
 
-// NB = 1: y = dwconv(x, w).  NB = 2, 3: y = sum_b dwconv(x_b, w_b) -- the gradient of a tensor that feeds NB depthwise convs
-// of one geometry (the ASPP input under the three replaced branches).  The work list becomes (item, input) pairs: the
-// accumulators live across the NB inputs of an item, the output phase runs once per item, and the Toeplitz operands of the
-// next input are rebuilt from its tap table (144 2-byte LDS reads per wave, under the barrier that publishes the next tile)
-// -- three register sets of them would not fit.  Against NB chained launches that is one output pass instead of NB and no
+// NB = 1: y = dwconv(x, w).
+// NB = 2, 3, FAN = false: y = sum_b dwconv(x_b, w_b) -- the gradient of a tensor that feeds NB depthwise convs of one geometry
+// (the ASPP input under the three replaced branches).  The work list becomes (item, input) pairs: the accumulators live
+// across the NB inputs of an item, the output phase runs once per item, and the Toeplitz operands of the next input are
+// rebuilt from its tap table (144 2-byte LDS reads per wave, under the barrier that publishes the next tile) -- three
+// register sets of them would not fit.  Against NB chained launches that is one output pass instead of NB and no
 // read-modify-write of the running sum.
-template <int NB>
+// NB = 2, 3, FAN = true: y_b = dwconv(x, w_b) -- the forward of those NB convs: the tile of x is staged ONCE per item and
+// stays in its buffer while the NB outputs are computed one after the other (operands rebuilt per output, the output staging
+// uses the idle second buffer); the next item's loads go out under the first output's MFMAs.  One read of x instead of NB.
+template <int NB, bool FAN>
 __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
 {
+    static_assert(NB >= 1 && NB <= MAXB && (NB > 1 || !FAN), "one to three inputs (sum) or outputs (fan-out)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int lin = xcd_remap(blockIdx.x, gridDim.x);
@@ -191,8 +197,8 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
     const int ibeg = (int)((long long)p.nitems * seg / p.nseg), iend = (int)((long long)p.nitems * (seg + 1) / p.nseg);
     const size_t img = (size_t)n * p.H * p.W * p.ldx + c0;
     const __amdgpu_buffer_rsrc_t xb0 = image_rsrc(p.x + img, p.H, p.W, p.ldx);
-    const __amdgpu_buffer_rsrc_t xb1 = image_rsrc((NB > 1 ? p.xs[0] : p.x) + img, p.H, p.W, p.ldx);
-    const __amdgpu_buffer_rsrc_t xb2 = image_rsrc((NB > 2 ? p.xs[1] : p.x) + img, p.H, p.W, p.ldx);
+    const __amdgpu_buffer_rsrc_t xb1 = image_rsrc((NB > 1 && !FAN ? p.xs[0] : p.x) + img, p.H, p.W, p.ldx);
+    const __amdgpu_buffer_rsrc_t xb2 = image_rsrc((NB > 2 && !FAN ? p.xs[1] : p.x) + img, p.H, p.W, p.ldx);
     auto rsrc_of = [&](int b) { return NB > 2 && b == 2 ? xb2 : (NB > 1 && b == 1 ? xb1 : xb0); };
     const int d = p.dil;
 
@@ -240,18 +246,26 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
 
     int buf = 0, b = 0;
     f32x4_t acc[2][2][4];
+    // the tile to prefetch: sum mode = the next (item, input) pair, every step; fan-out = the next item, found at output 0
+    int nxt = cur;
+    Item wn = wi;
+    bool more = false;
     while (true) {
-        // ---- 1. next (item, input) ------------------------------------------------------------------------------------------
-        int nxt = cur, nb = b + 1;
-        Item wn = wi;
-        if (nb == NB) {
-            nb = 0;
+        // ---- 1. what comes next -----------------------------------------------------------------------------------------------
+        int nb = b + 1;
+        if (FAN ? b == 0 : nb == NB) {
             nxt = cur + 1;
             if (nxt < iend) wn = decode_item(p, nxt);
             while (nxt < iend && (wn.RV <= 0 || wn.CV <= 0)) { ++nxt; if (nxt < iend) wn = decode_item(p, nxt); }
+            more = nxt < iend;
+        } else if (!FAN) {
+            nxt = cur;
+            wn = wi;
+            more = true;
         }
-        const bool more = nxt < iend;
-        const __amdgpu_buffer_rsrc_t xn = rsrc_of(nb);
+        if (nb == NB) nb = 0;
+        const bool fetch = more && (!FAN || b == 0);
+        const __amdgpu_buffer_rsrc_t xn = FAN ? xb0 : rsrc_of(nb);
 
         // ---- 2. MFMA ---------------------------------------------------------------------------------------------------------
         char *X = smem + buf * XBYTES;
@@ -266,11 +280,11 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
             for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) {
-                    if (NB == 1 || b == 0) acc[cc][mt][jt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                    if (NB == 1 || FAN || b == 0) acc[cc][mt][jt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
                     // the next tile's loads go out a unit at a time between the MFMA tiles, so they trickle through the
                     // memory pipeline under the MFMAs instead of stalling the wave's issue in one burst
                     const int step = cc * 8 + mt * 4 + jt;
-                    if (more) {
+                    if (fetch) {
                         if (step == 0) fetch_unit(0, p, xn, wn, tid, st);
                         if (step == 3) fetch_unit(1, p, xn, wn, tid, st);
                         if (step == 6) fetch_unit(2, p, xn, wn, tid, st);
@@ -289,14 +303,18 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
                 }
             }
         }
-        if (NB == 1 || b == NB - 1) {
-            __syncthreads();   // every wave is done reading X: the output staging may overwrite it
+        const bool last = b == NB - 1;
+        if (NB == 1 || FAN || last) {
+            // every wave is done reading X (plain / sum: the output staging overwrites it) or is done reading the staging
+            // of the previous output (fan-out: the staging lives in the idle second buffer, X stays for the next output)
+            __syncthreads();
 
             // ---- 3. accumulators -> [pixel][16 ch] bf16 -> NHWC --------------------------------------------------------------
             // staging rows are OPX pixels wide so the last (overlapping) column tile can be written whole; the 4-B channel
             // pair of wave w goes to slot w ^ (col & 7) of the pixel's 32 B (spreads the 16 lanes of a tile row over banks)
+            char *S = FAN ? smem + (buf ^ 1) * XBYTES : X;
             if (!(p.dbg & 2)) {
-                char *ob = X + ((kg * 4) * OPX + fi) * OSTR;
+                char *ob = S + ((kg * 4) * OPX + fi) * OSTR;
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -317,9 +335,10 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
                 const int h = tid & 1, col = (tid >> 1) & 63, rq = tid >> 7;
                 if (col < CV) {
                     const int xx = wi.rx + d * (wi.tx * TLX + col);
-                    const char *osrc = X + col * OSTR + ((h ^ ((col >> 2) & 1)) << 4);
+                    const char *osrc = S + col * OSTR + ((h ^ ((col >> 2) & 1)) << 4);
                     const bool s1 = col & 1, s2 = col & 2;
-                    bf16_t *ycol = p.y + ((size_t)n * p.H * p.W + xx) * p.ldy + c0 + h * 8;
+                    bf16_t *yb = FAN && NB > 2 && b == 2 ? p.ys[1] : (FAN && b == 1 ? p.ys[0] : p.y);
+                    bf16_t *ycol = yb + ((size_t)n * p.H * p.W + xx) * p.ldy + c0 + h * 8;
 #pragma unroll
                     for (int k = 0; k < (TLY + 3) / 4; ++k) {
                         const int row = rq + 4 * k;
@@ -334,9 +353,17 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
                 }
             }
         }
+        if (FAN && !last) {   // same tile, next output: only the operands change
+            build_toeplitz(smem, nb, wave, fi, kg, B);
+            b = nb;
+            continue;
+        }
         if (!more) break;
 
-        // ---- 4. prefetched registers -> the other X buffer (last read two steps ago, behind that step's closing barrier) -----
+        // ---- 4. prefetched registers -> the other X buffer ---------------------------------------------------------------------
+        // (plain / sum: last read two steps ago, behind that step's closing barrier; fan-out: it held the output staging the
+        // waves have just been reading)
+        if (FAN) __syncthreads();
         buf ^= 1;
         if (!(p.dbg & 4)) write_item(smem + buf * XBYTES, tid, st);
         if (NB > 1) build_toeplitz(smem, nb, wave, fi, kg, B);
@@ -561,16 +588,20 @@ static void dw_mfma_split(int N, int C, int H, int W, int dil, int *nty, int *nt
 
 }  // namespace
 
-// y = sum_{b < nb} dwconv(xs[b], ws[b]) on the matrix cores.  Returns 1 if the MFMA path took the call, 0 if the shape is
-// not eligible (caller falls back to the register kernel, chained through res_post for nb > 1), < 0 on a launch error.
-int kd_internal_dw_mfma_fwd_n(const kd_dw_desc *d, int nb, const void *const *xs, const float *const *ws, const float *bias,
-                              const kd_dw_epilogue *ep, void *y, hipStream_t s)
+// fan == 0: ys[0] = sum_{b < nb} dwconv(xs[b], ws[b]);  fan != 0: ys[b] = dwconv(xs[0], ws[b]) for b < nb -- on the matrix
+// cores.  Returns 1 if the MFMA path took the call, 0 if the shape is not eligible (caller falls back to the register kernel,
+// one launch per term), < 0 on a launch error.
+int kd_internal_dw_mfma_fwd_n(const kd_dw_desc *d, int nb, int fan, const void *const *xs, const float *const *ws, void *const *ys,
+                              const float *bias, const kd_dw_epilogue *ep, hipStream_t s)
 {
     if (nb < 1 || nb > MAXB) return 0;
+    if (nb == 1) fan = 0;
     if (d->dtype != KD_BF16 || d->k != 9 || d->C % CG != 0 || d->ldx % 8 != 0 || d->ldy % 8 != 0) return 0;
-    for (int b = 0; b < nb; ++b)
-        if (!xs[b] || !ws[b] || !kd_aligned16(xs[b])) return 0;
-    if (!kd_aligned16(y)) return 0;
+    for (int b = 0; b < nb; ++b) {
+        if (!ws[b]) return 0;
+        if (!(fan ? ys[b] && kd_aligned16(ys[b]) : xs[b] && kd_aligned16(xs[b]))) return 0;
+    }
+    if (!xs[0] || !ys[0] || !kd_aligned16(xs[0]) || !kd_aligned16(ys[0])) return 0;
     if ((long long)d->H * d->W * d->ldx * 2 >= (long long)BUF_OOB) return 0;   // buffer-load offsets are 32-bit per image
     // Calls with a bias or an epilogue stay on the register kernel: their extra operands are read per pixel in 32-B
     // (16-channel) pieces here, which the memory system serves at about a third of the rate of the register kernel's
@@ -583,9 +614,10 @@ int kd_internal_dw_mfma_fwd_n(const kd_dw_desc *d, int nb, const void *const *xs
         enabled = !(e && e[0] == '0');
     }
     if (!enabled) return 0;
-    p.x = (const bf16_t *)xs[0]; p.w = ws[0]; p.y = (bf16_t *)y;
+    p.x = (const bf16_t *)xs[0]; p.w = ws[0]; p.y = (bf16_t *)ys[0];
     for (int b = 1; b < MAXB; ++b) {
-        p.xs[b - 1] = (const bf16_t *)(b < nb ? xs[b] : xs[0]);
+        p.xs[b - 1] = (const bf16_t *)(!fan && b < nb ? xs[b] : xs[0]);
+        p.ys[b - 1] = (bf16_t *)(fan && b < nb ? ys[b] : ys[0]);
         p.ws[b - 1] = b < nb ? ws[b] : ws[0];
     }
     { static int dbg = -1; if (dbg < 0) { const char *e = getenv("KDCC_DW_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
@@ -596,18 +628,19 @@ int kd_internal_dw_mfma_fwd_n(const kd_dw_desc *d, int nb, const void *const *xs
     const long long blocks = (long long)d->N * p.ncg * p.nseg;
     if (blocks > 0x7fffffffLL || (long long)d->N * d->H * d->W > 0x7fffffffLL) return 0;
     const int lds = LDS_BYTES + (nb - 1) * WTBYTES;
-    const void *fn = nb == 1 ? (const void *)dw_mfma_fwd_kernel<1> : nb == 2 ? (const void *)dw_mfma_fwd_kernel<2> : (const void *)dw_mfma_fwd_kernel<3>;
-    static bool attr_set[MAXB + 1] = {};
-    if (!attr_set[nb]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+    typedef void (*kern_t)(DwMfmaParams);
+    const kern_t fn = nb == 1 ? dw_mfma_fwd_kernel<1, false>
+                    : nb == 2 ? (fan ? dw_mfma_fwd_kernel<2, true> : dw_mfma_fwd_kernel<2, false>)
+                              : (fan ? dw_mfma_fwd_kernel<3, true> : dw_mfma_fwd_kernel<3, false>);
+    static bool attr_set[2][MAXB + 1] = {};
+    if (!attr_set[fan ? 1 : 0][nb]) {
+        if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             kd_set_error("kd_dwconv_fwd: cannot reserve %d B of LDS", lds);
             return KD_ERR_HIP;
         }
-        attr_set[nb] = true;
+        attr_set[fan ? 1 : 0][nb] = true;
     }
-    if (nb == 1) hipLaunchKernelGGL(dw_mfma_fwd_kernel<1>, dim3((unsigned)blocks), dim3(NT), lds, s, p);
-    else if (nb == 2) hipLaunchKernelGGL(dw_mfma_fwd_kernel<2>, dim3((unsigned)blocks), dim3(NT), lds, s, p);
-    else hipLaunchKernelGGL(dw_mfma_fwd_kernel<3>, dim3((unsigned)blocks), dim3(NT), lds, s, p);
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(NT), lds, s, p);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
         kd_set_error("kd_dwconv_fwd(mfma): launch failed: %s", hipGetErrorString(err));
@@ -619,7 +652,7 @@ int kd_internal_dw_mfma_fwd_n(const kd_dw_desc *d, int nb, const void *const *xs
 int kd_internal_dw_mfma_fwd(const kd_dw_desc *d, const void *x, const float *w_taps, const float *bias,
                             const kd_dw_epilogue *ep, void *y, hipStream_t s)
 {
-    return kd_internal_dw_mfma_fwd_n(d, 1, &x, &w_taps, bias, ep, y, s);
+    return kd_internal_dw_mfma_fwd_n(d, 1, 0, &x, &w_taps, &y, bias, ep, s);
 }
 
 static bool dw_mfma_wgrad_eligible(const kd_dw_desc *d, const void *x, const void *dy, int ld_dy)

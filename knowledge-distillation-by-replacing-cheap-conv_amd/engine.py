@@ -342,6 +342,17 @@ class StudentEngine:
             ops.edge_aspp(tape["acts"], aspp.edge_conv[0].weight.detach().float().reshape(-1).contiguous(), sc, sh, cat[..., red:2 * red])
         arec = {"x7": x7, "rg7": rg7, "branches": [], "cat": cat, "red": red, "mod": aspp, "lead": lead}
         rg_cat = rg7 or _is_trainable(aspp.img_conv)
+        # the replaced branches' depthwise convs all read x7: one pass over it per geometry computes (up to three of) them
+        mids, fan = {}, {}
+        if _DW_SUM:
+            for i, br in enumerate(aspp.features):
+                site = _Site(f"aspp.features.{i}.0", br[0])
+                if site.cheap:
+                    fan.setdefault((site.k, site.pad, site.dil), []).append((i, site))
+            for (k, pad, dil), members in fan.items():
+                if len(members) > 1:
+                    outs = ops.dwconv_fanout(x7, [self._w_dw(st.mod.separable_conv, False) for _, st in members], k, pad, dil)
+                    mids.update({i: o for (i, _), o in zip(members, outs)})
         for i, br in enumerate(aspp.features):
             site = _Site(f"aspp.features.{i}.0", br[0])
             sc, sh = self._bn_fold(br[1])
@@ -351,7 +362,9 @@ class StudentEngine:
             out = cat[..., red * (i + lead):red * (i + lead + 1)]
             mid = None
             if site.cheap:
-                mid = ops.dwconv(x7, self._w_dw(site.mod.separable_conv, False), site.k, site.pad, site.dil)
+                mid = mids.get(i)
+                if mid is None:
+                    mid = ops.dwconv(x7, self._w_dw(site.mod.separable_conv, False), site.k, site.pad, site.dil)
                 ops.conv2d(mid, self._w_fwd(site.mod.pointwise_conv), out_raw=raw, out_act=out, act_scale=sc, act_shift=sh,
                            act_relu=True)
             else:

@@ -251,6 +251,34 @@ def dwconv_sum(xs, w_taps, k, pad, dil, out=None):
     return out
 
 
+def dwconv_fanout(x, w_taps, k, pad, dil, outs=None):
+    """[dwconv(x, w) for w in w_taps]: several depthwise convs of one geometry reading the same tensor (deeplabv3.py:71-75,
+    the ASPP branches), one pass over x where the shape allows."""
+    w_taps = list(w_taps)
+    if not w_taps:
+        raise ValueError("dwconv_fanout: no tap tables")
+    _need_cuda(x, *w_taps, *(outs or []))
+    N, H, W, Cc = x.shape
+    for w in w_taps:
+        if tuple(w.shape) != (k * k, Cc) or w.dtype != torch.float32 or not w.is_contiguous():
+            raise ValueError("dwconv_fanout: w_taps must be contiguous fp32 [k*k][C]")
+    if outs is None:
+        outs = [torch.empty((N, H, W, Cc), dtype=x.dtype, device=x.device) for _ in w_taps]
+    outs = list(outs)
+    if len(outs) != len(w_taps):
+        raise ValueError("dwconv_fanout: need one output per tap table")
+    ld = nhwc_ld(outs[0])
+    for o in outs:
+        if tuple(o.shape) != (N, H, W, Cc) or o.dtype != x.dtype or nhwc_ld(o) != ld:
+            raise ValueError("dwconv_fanout: outputs must share shape, dtype and pixel stride")
+    d = _dw_desc(x, k, pad, dil, outs[0])
+    n = len(outs)
+    wp = (C.c_void_p * n)(*[_ptr(w) for w in w_taps])
+    yp = (C.c_void_p * n)(*[_ptr(o) for o in outs])
+    check(_lib.lib().kd_dwconv_fwd_fanout(C.byref(d), n, _ptr(x), wp, yp, stream_ptr()), "kd_dwconv_fwd_fanout")
+    return outs
+
+
 def dwconv_wgrad(x, dy, dw, k, pad, dil, accumulate=False, workspace=None):
     _need_cuda(x, dy, dw)
     N, H, W, Cc = x.shape

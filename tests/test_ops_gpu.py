@@ -316,6 +316,25 @@ def test_dwconv_sum(K, dt, case):
         assert_close(host_nchw(out), host_nchw(run), dt, "dw sum vs chain")
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [
+    (2, 24, 32, 16, 9, 20, 5, 3), (1, 140, 270, 32, 9, 20, 5, 3), (1, 40, 70, 16, 9, 4, 1, 2), (2, 64, 128, 48, 9, 20, 5, 3),
+    (1, 23, 37, 72, 9, 20, 5, 3), (1, 24, 32, 16, 9, 20, 5, 5), (1, 8, 8, 16, 3, 1, 1, 2),
+])
+def test_dwconv_fanout(K, dt, case):
+    """kd_dwconv_fwd_fanout: the ASPP branches' depthwise convs over one input (deeplabv3.py:71-75), each output against the
+    oracle and bit for bit against the single-output launch (same arithmetic per output, the tile is only staged once)."""
+    N, H, W, Cc, k, p, d, n = case
+    x = q(rnd(N, Cc, H, W), dt)
+    ws = [rnd(Cc, 1, k, k, scale=1.0 / k) for _ in range(n)]
+    taps = [K.pack_dw_weight(torch.from_numpy(w).cuda()) for w in ws]
+    xd = dev_nhwc(x, dt)
+    outs = K.dwconv_fanout(xd, taps, k, p, d)
+    for i, (o, w) in enumerate(zip(outs, ws)):
+        assert_close(host_nchw(o), orc.conv2d_fwd(x, w, pad=p, dil=d, groups=Cc), dt, f"dw fan-out {i}")
+        assert torch.equal(o, K.dwconv(xd, taps[i], k, p, d)), f"fan-out output {i} differs from the single launch"
+
+
 @pytest.mark.parametrize("case", [(2, 24, 32, 16, 5), (1, 131, 261, 32, 5), (1, 30, 60, 16, 2)])
 def test_dwconv_epilogue_bf16(K, case):
     """bias + res_pre + BN/ReLU mask + res_post through the depthwise epilogue, multi-tile shapes included."""

@@ -43,7 +43,12 @@ for C in (512, 1024, 2048, 4096):
             ops.dwconv(g3, wt, k, p, d, out=y, res_post=r)
         ms = t(chain)
         print(f"dw sum3 (chained)    C={C:5d}: {ms:7.3f} ms")
-        del g2, g3
+        ys = [torch.empty_like(x) for _ in range(3)]
+        ms = t(lambda: ops.dwconv_fanout(x, [wt, wt, wt], k, p, d, outs=ys))
+        print(f"dw fan-out 3 (one launch) C={C:5d}: {ms:7.3f} ms")
+        ms = t(lambda: [ops.dwconv(x, wt, k, p, d, out=o) for o in ys])
+        print(f"dw fan-out 3 (3 launches) C={C:5d}: {ms:7.3f} ms")
+        del g2, g3, ys
     ms = t(lambda: ops.dwconv_wgrad(x, g, dw, k, p, d, workspace=ws))
     print(f"dw wgrad C={C:5d}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TFLOP/s")
 
