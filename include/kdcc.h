@@ -178,6 +178,13 @@ int kd_dwconv_wgrad(const kd_dw_desc *d, const void *x, const void *dy, int32_t 
  * w: fp32 (64,3,3,3) as in the reference.  y: NHWC `dtype`, 64 channels. */
 int kd_stem_conv(int32_t dtype, const float *x_nchw, const float *w, void *y,
                  int32_t N, int32_t H, int32_t W, kd_stream_t stream);
+/* The same conv followed by pool2 = MaxPool2d(3, stride=2, padding=1) (wider_resnet.py:307-309, 353-356: mod1's output
+ * has no other reader in DeepWV3Plus) and, for y_act, the BN(eval)+ReLU of mod2.block1 (scale/shift as in
+ * kd_maxpool3x3s2), without the 64-channel full-resolution tensor ever reaching memory: for a frozen stem whose
+ * output nothing else needs.  bf16 outputs (N,Ho,Wo,64), Ho = (H-1)/2+1; bit-identical to
+ * kd_stem_conv(KD_BF16) + kd_maxpool3x3s2.  y_raw or y_act may be NULL. */
+int kd_stem_conv_pool(const float *x_nchw, const float *w, void *y_raw, void *y_act, const float *scale,
+                      const float *shift, int32_t N, int32_t H, int32_t W, kd_stream_t stream);
 
 /* MaxPool2d(3, stride=2, padding=1) (wider_resnet.py:353-356), optionally followed
  * by the next block's BN(eval)+ReLU: y_raw (may be NULL) = pool, y_act (may be NULL) =

@@ -153,6 +153,138 @@ __global__ __launch_bounds__(256) void stem_conv_mfma_kernel(const float *__rest
     }
 }
 
+// ---- stem conv + pool2 in one pass (frozen stem, bf16) ------------------------------------------------------------------
+// mod1's 64-channel full-resolution output has one reader in DeepWV3Plus -- pool2 (wider_resnet.py: mod1 -> pool2 -> mod2) --
+// so when nothing else needs it (frozen stem, no shape stream) it never has to reach HBM: 1.07 GB written and read back per
+// network and step at 4 x 1024 x 2048.  A wave owns 7 pooled columns (16 stem columns 2*w0-1 .. 2*w0+14) and walks down a
+// segment of pooled rows: per row it computes the two new stem rows on the matrix cores (same K = 27 -> 32 MFMA as above,
+// operands swapped so a lane holds 4 consecutive channels of one pixel), keeps the previous odd row as the carry, takes the
+// vertical maximum in fp32 registers, rounds it to bf16 into a 16-pixel LDS patch and finishes the horizontal maximum + the
+// consumer's BN/ReLU when the patch is read back as 16-B channel vectors.  Rounding is monotone, so round(max) == max(round):
+// the result is bit for bit what stem_conv_mfma_kernel + maxpool_kernel produce.
+constexpr int SP_COLS = 7;      // pooled columns per wave
+constexpr int SP_ROWS = 16;     // pooled rows per wave segment
+__global__ __launch_bounds__(256) void stem_pool_kernel(const float *__restrict__ x, const float *__restrict__ w, bf16_t *__restrict__ y_raw,
+                                                        bf16_t *__restrict__ y_act, const float *__restrict__ scale,
+                                                        const float *__restrict__ shift, int N, int H, int W, int Ho, int Wo,
+                                                        int ngx, int nseg)
+{
+    constexpr int PSTR = 64 * 2 + 16;   // patch row stride (bytes): one pixel's 64 channels bf16, padded
+    __shared__ __attribute__((aligned(16))) char patch[4][16 * PSTR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, kg = lane >> 4;
+    long long wid = (long long)blockIdx.x * 4 + wave;
+    const long long nw = (long long)N * ngx * nseg;
+    if (wid >= nw) return;   // wave-private work: no block-wide barrier below
+    const int gx = (int)(wid % ngx); wid /= ngx;
+    const int sg = (int)(wid % nseg);
+    const int n = (int)(wid / nseg);
+    const int w0 = gx * SP_COLS;
+    const int col = 2 * w0 - 1 + fi;                 // this lane's stem column
+    const bool col_ok = col >= 0 && col < W;
+    // this lane's 8 taps: k = kg*8 + q = ci*9 + ky*3 + kx (k >= 27: zero)
+    int tdy[8], tdx[8], tci[8];
+    uint32_t tvalid = 0;
+    const size_t HW = (size_t)H * W;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k = kg * 8 + q, kc = k < 27 ? k : 0;
+        tci[q] = kc / 9; tdy[q] = (kc % 9) / 3 - 1; tdx[q] = kc % 3 - 1;
+        tvalid |= k < 27 ? (1u << q) : 0u;
+    }
+    // weight fragments as the A operand: lane (channel i = fi of tile t, k-group kg)
+    uint4 bw[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = kg * 8 + q;
+            v[q] = k < 27 ? w[(t * 16 + fi) * 27 + k] : 0.f;
+        }
+        bw[t] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    }
+    const float *xn = x + (size_t)n * 3 * HW;
+    const float NINF = -INFINITY;
+    // one stem row for the 16 columns: D[channel][pixel], lane (pixel fi, kg) holds channels 16t + 4kg .. +3; rows / columns
+    // outside the image are the pool's padding (-inf)
+    auto stem_row = [&](int h, stem_f32x4_t (&o)[4]) __attribute__((always_inline)) {
+        if (h < 0 || h >= H) {   // wave-uniform
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o[t] = (stem_f32x4_t){NINF, NINF, NINF, NINF};
+            return;
+        }
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int hi = h + tdy[q], wi = col + tdx[q];
+            const bool ok = ((tvalid >> q) & 1u) && hi >= 0 && hi < H && wi >= 0 && wi < W;
+            const int hc = min(max(hi, 0), H - 1), wc = min(max(wi, 0), W - 1);
+            const float tv = xn[(size_t)tci[q] * HW + (size_t)hc * W + wc];   // unconditional load, select after
+            v[q] = ok ? tv : 0.f;
+        }
+        const uint4 a = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            stem_f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(stem_bf16x8_t, bw[t]), __builtin_bit_cast(stem_bf16x8_t, a),
+                                                          acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[t][r] = col_ok ? acc[r] : NINF;
+        }
+    };
+    // read-back role: lane = (pooled column m of the group, 8-channel vector c8)
+    const int m = lane >> 3, c8 = lane & 7;
+    float sc[8], sf[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        sc[q] = y_act ? scale[c8 * 8 + q] : 1.f;
+        sf[q] = y_act ? shift[c8 * 8 + q] : 0.f;
+    }
+    char *pw = patch[wave];
+    const int ho0 = sg * SP_ROWS, ho1 = min(ho0 + SP_ROWS, Ho);
+    stem_f32x4_t carry[4], r0[4], r1[4];
+    stem_row(2 * ho0 - 1, carry);
+    for (int ho = ho0; ho < ho1; ++ho) {
+        stem_row(2 * ho, r0);
+        stem_row(2 * ho + 1, r1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = fmaxf(fmaxf(carry[t][r], r0[t][r]), r1[t][r]);
+                carry[t][r] = r1[t][r];
+            }
+            *(uint2 *)(pw + fi * PSTR + (t * 16 + kg * 4) * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (m < SP_COLS && w0 + m < Wo) {
+            float mx[8], t8[8];
+            ld8((const bf16_t *)(pw + (2 * m) * PSTR + c8 * 16), mx);
+            ld8((const bf16_t *)(pw + (2 * m + 1) * PSTR + c8 * 16), t8);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) mx[q] = fmaxf(mx[q], t8[q]);
+            ld8((const bf16_t *)(pw + (2 * m + 2) * PSTR + c8 * 16), t8);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) mx[q] = fmaxf(mx[q], t8[q]);
+            const size_t op = (((size_t)n * Ho + ho) * Wo + w0 + m) * 64 + c8 * 8;
+            if (y_raw) st8(y_raw + op, mx);
+            if (y_act) {
+                float a8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a8[q] = fmaxf(fmaf(mx[q], sc[q], sf[q]), 0.f);
+                st8(y_act + op, a8);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // ---- max-pool 3x3 / stride 2 / pad 1 (+ optional BN-eval + ReLU second output) ---------
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_kernel(const T *__restrict__ x, int ldx, T *__restrict__ y_raw, int ld_raw,
@@ -386,6 +518,23 @@ extern "C" int kd_stem_conv(int32_t dtype, const float *x_nchw, const float *w, 
         hipLaunchKernelGGL(stem_conv_kernel<float>, grid, dim3(256), 0, s, x_nchw, w, (float *)y, N, H, W);
     }
     KD_CHECK_LAUNCH("kd_stem_conv");
+    return KD_OK;
+}
+
+extern "C" int kd_stem_conv_pool(const float *x_nchw, const float *w, void *y_raw, void *y_act, const float *scale,
+                                 const float *shift, int32_t N, int32_t H, int32_t W, kd_stream_t stream)
+{
+    KD_REQUIRE(x_nchw && w && (y_raw || y_act) && N > 0 && H > 0 && W > 0, KD_ERR_INVALID, "kd_stem_conv_pool: bad argument");
+    KD_REQUIRE(!y_act || (scale && shift), KD_ERR_INVALID, "kd_stem_conv_pool: y_act needs scale/shift");
+    KD_REQUIRE((!y_raw || kd_aligned16(y_raw)) && (!y_act || kd_aligned16(y_act)), KD_ERR_INVALID,
+               "kd_stem_conv_pool: outputs must be 16-B aligned");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int ngx = (Wo + SP_COLS - 1) / SP_COLS, nseg = (Ho + SP_ROWS - 1) / SP_ROWS;
+    const long long waves = (long long)N * ngx * nseg;
+    KD_REQUIRE((waves + 3) / 4 <= 0x7fffffffLL, KD_ERR_UNSUPPORTED, "kd_stem_conv_pool: image too large");
+    hipLaunchKernelGGL(stem_pool_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x_nchw, w,
+                       (bf16_t *)y_raw, (bf16_t *)y_act, scale, shift, N, H, W, Ho, Wo, ngx, nseg);
+    KD_CHECK_LAUNCH("kd_stem_conv_pool");
     return KD_OK;
 }
 

@@ -40,6 +40,7 @@ from ._lib import KD_PACK_DGRAD, KD_PACK_FWD
 from .models.students.transform_blocks import DepthwiseSeparableBlock
 from .models.wider_resnet import IdentityResidualBlock
 
+_STEM_POOL = os.environ.get("KDCC_STEM_POOL", "1") != "0"   # A/B: 0 = stem conv and pool2 as two kernels
 _DW_SUM = os.environ.get("KDCC_DW_SUM", "1") != "0"   # A/B: 0 = one depthwise input-gradient launch per ASPP branch
 
 
@@ -277,12 +278,17 @@ class StudentEngine:
         if prefix is None:
             stem = net.mod1.conv1
             stem_w = stem.weight.detach()
-            s = ops.stem_conv(xin, stem_w if stem_w.is_contiguous() else stem_w.contiguous(), self.dtype)
+            stem_w = stem_w if stem_w.is_contiguous() else stem_w.contiguous()
             rg = stem.weight.requires_grad
+            sc1, sh1 = self._bn_fold(flat[0][1].bn1)   # pool2 is followed by bn1 of mod2.block1
+            if _STEM_POOL and self.dtype == torch.bfloat16 and not rg and not self.is_gscnn:
+                # frozen stem, no shape stream: pool2 is the only reader of mod1's full-resolution output -- one fused pass
+                s = None
+                _, a = ops.stem_conv_pool(xin, stem_w, sc1, sh1, want_raw=False)
+            else:
+                s = ops.stem_conv(xin, stem_w, self.dtype)
+                _, a = ops.maxpool3x3s2(s, sc1, sh1, want_raw=False)
             tape["stem"] = dict(x=xin, s=s, rg=rg)
-            # pool2 (+ bn1 of mod2.block1)
-            sc1, sh1 = self._bn_fold(flat[0][1].bn1)
-            _, a = ops.maxpool3x3s2(s, sc1, sh1, want_raw=False)
             x_raw = None
             m2 = None
         else:   # the teacher computed everything up to block `start` on identical frozen weights

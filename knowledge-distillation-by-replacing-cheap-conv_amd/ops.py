@@ -309,6 +309,23 @@ def stem_conv(x_nchw, w, dtype):
     return y
 
 
+def stem_conv_pool(x_nchw, w, scale=None, shift=None, want_raw=True):
+    """stem conv -> pool2 (-> BN/ReLU of the consumer) in one pass, bf16, the full-resolution tensor never stored
+    (wider_resnet.py:307-309, 353-356).  Returns (raw, act) like maxpool3x3s2; bit-identical to stem_conv + maxpool3x3s2."""
+    _need_cuda(x_nchw, w, scale, shift)
+    if x_nchw.dtype != torch.float32 or not x_nchw.is_contiguous() or x_nchw.shape[1] != 3:
+        raise ValueError("stem_conv_pool: expects a contiguous fp32 (N,3,H,W) batch")
+    if tuple(w.shape) != (64, 3, 3, 3) or w.dtype != torch.float32 or not w.is_contiguous():
+        raise ValueError("stem_conv_pool: expects a contiguous fp32 (64,3,3,3) weight")
+    N, _, H, W = x_nchw.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y_raw = torch.empty((N, Ho, Wo, 64), dtype=torch.bfloat16, device=x_nchw.device) if want_raw else None
+    y_act = torch.empty((N, Ho, Wo, 64), dtype=torch.bfloat16, device=x_nchw.device) if scale is not None else None
+    check(_lib.lib().kd_stem_conv_pool(_ptr(x_nchw), _ptr(w), _ptr(y_raw), _ptr(y_act), _ptr(scale), _ptr(shift), N, H, W,
+                                       stream_ptr()), "kd_stem_conv_pool")
+    return y_raw, y_act
+
+
 def maxpool3x3s2(x, scale=None, shift=None, want_raw=True):
     _need_cuda(x, scale, shift)
     N, H, W, Cc = x.shape

@@ -385,6 +385,27 @@ def test_dwsep_block_golden(K, golden):
         assert_close(host_nchw(gx)[:, :Cc], g[f"{tag}.gx"], "f32", f"{tag} gx")
 
 
+@pytest.mark.parametrize("shape", [(2, 20, 28), (1, 64, 128), (1, 37, 45), (1, 33, 100), (2, 2, 2), (1, 70, 29)])
+def test_stem_conv_pool_fused(K, shape):
+    """kd_stem_conv_pool (mod1 -> pool2 -> bn1/relu of mod2.block1, wider_resnet.py:307-309, 353-356) against the oracle's
+    conv + max-pool, and bit for bit against the two-kernel path (round(max) == max(round)); odd sizes: ragged last column
+    group, last pooled row with one stem row, several row segments."""
+    N, H, W = shape
+    x = rnd(N, 3, H, W)
+    w = rnd(64, 3, 3, 3, scale=0.2)
+    scale, shift = rnd(64) * 0.2 + 1.0, rnd(64) * 0.2
+    xd, wd, sd, hd = (torch.from_numpy(a).cuda() for a in (x, w, scale, shift))
+    raw, act = K.stem_conv_pool(xd, wd, sd, hd)
+    y = K.stem_conv(xd, wd, torch.bfloat16)
+    raw2, act2 = K.maxpool3x3s2(y, sd, hd)
+    assert torch.equal(raw, raw2) and torch.equal(act, act2)
+    _, act3 = K.stem_conv_pool(xd, wd, sd, hd, want_raw=False)
+    assert torch.equal(act3, act2)
+    pref = orc.maxpool3x3s2(orc.conv2d_fwd(q(x, "bf16"), q(w, "bf16"), pad=1))
+    assert_close(host_nchw(raw), pref, "bf16", "stem+pool raw")
+    assert_close(host_nchw(act), np.maximum(pref * scale[None, :, None, None] + shift[None, :, None, None], 0), "bf16", "stem+pool act")
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_stem_pool_upsample_imagepool(K, dt):
     x = rnd(2, 3, 20, 28)
