@@ -380,6 +380,11 @@ int kd_ce2d_grad(const kd_view3 *x, const int64_t *target, int32_t ignore_index,
 int kd_confusion(const kd_view3 *x, const int64_t *target, int32_t N, int32_t C, int64_t P,
                  int64_t *conf, int32_t accumulate, kd_stream_t stream);
 
+/* x *= *scale with the test `*scale == 1` made on the device (then nothing is read or written): the backward of the fused
+ * loss Functions, whose stored gradient is multiplied by autograd's upstream d(total)/d(loss) -- exactly 1 for
+ * `loss = hint_loss` (trainer/layerwise_trainer.py:229-235).  scale: one fp32 on the device. */
+int kd_scale_by_device_scalar(void *x, int32_t dtype, int64_t n, const float *scale, kd_stream_t stream);
+
 /* ----------------------------------------------------------------- optimizer
  * RAdam.step for one tensor, utils/optim/radam.py:30-98 (fp32 params/state).
  * `step` is the per-tensor step count after the increment (radam.py:62). */

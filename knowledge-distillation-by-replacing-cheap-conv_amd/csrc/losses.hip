@@ -408,6 +408,28 @@ inline bool dense_same(const kd_view3 *a, const kd_view3 *b, const kd_mview3 *g,
     return ((long long)N * C * P) % 8 == 0;
 }
 
+// ---- upstream-gradient scale of a fused loss gradient ---------------------------------------------------------------------
+// autograd hands the loss Function d(total)/d(loss) as a device scalar; for `loss = sum of hint losses` (layerwise_trainer.py:
+// 229-235) it is exactly 1 and grad * 1 is a full read + write of every hint-sized gradient for nothing.  The test is made on
+// the device (no host sync): every thread reads the scalar and leaves when it is 1.
+template <typename T>
+__global__ __launch_bounds__(256) void scale_by_device_scalar_kernel(T *x, long long n8, long long n, const float *s)
+{
+    const float sv = *s;
+    if (sv == 1.0f) return;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        float v[8];
+        ld8(x + i * 8, v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] *= sv;
+        st8(x + i * 8, v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - n8 * 8)) {
+        const long long i = n8 * 8 + threadIdx.x;
+        Elem<T>::st(x + i, Elem<T>::ld(x + i) * sv);
+    }
+}
+
 }  // namespace
 
 extern "C" size_t kd_loss_workspace(int32_t N, int32_t C, int64_t P)
@@ -613,5 +635,22 @@ extern "C" int kd_radam_step(float *p, const float *g, float *exp_avg, float *ex
     hipLaunchKernelGGL(radam_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg, exp_avg_sq,
                        (long long)n, beta1, beta2, eps, (float)((double)weight_decay * lr), (float)(step_size * lr), rect);
     KD_CHECK_LAUNCH("kd_radam_step");
+    return KD_OK;
+}
+
+extern "C" int kd_scale_by_device_scalar(void *x, int32_t dtype, int64_t n, const float *scale, kd_stream_t stream)
+{
+    KD_REQUIRE(x && scale && n > 0, KD_ERR_INVALID, "kd_scale_by_device_scalar: bad argument");
+    KD_REQUIRE(dtype == KD_F32 || dtype == KD_BF16, KD_ERR_INVALID, "kd_scale_by_device_scalar: bad dtype");
+    KD_REQUIRE(kd_aligned16(x), KD_ERR_INVALID, "kd_scale_by_device_scalar: x must be 16-B aligned");
+    const long long n8 = n / 8;
+    const unsigned blocks = blocks_for(n8 > 0 ? n8 : 1);
+    if (dtype == KD_BF16)
+        hipLaunchKernelGGL(scale_by_device_scalar_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t *)x, n8,
+                           (long long)n, scale);
+    else
+        hipLaunchKernelGGL(scale_by_device_scalar_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float *)x, n8,
+                           (long long)n, scale);
+    KD_CHECK_LAUNCH("kd_scale_by_device_scalar");
     return KD_OK;
 }

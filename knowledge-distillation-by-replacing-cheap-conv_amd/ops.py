@@ -225,6 +225,23 @@ def dwconv(x, w_taps, k, pad, dil, bias=None, out=None, res_pre=None, mask=None,
     return out
 
 
+def scale_by_device_scalar_(x, scale):
+    """x *= scale (0-dim / 1-element device tensor) in place; when the scalar is exactly 1 -- decided on the device, no host
+    sync -- nothing is read or written.  The upstream-gradient factor of the fused loss Functions (layerwise_trainer.py:229-235)."""
+    _need_cuda(x, scale)
+    if scale.numel() != 1:
+        raise ValueError("scale_by_device_scalar_: scale must hold one element")
+    dense = x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))
+    if not dense:
+        x.mul_(scale.to(x.dtype))     # a strided view: plain torch
+        return x
+    scale = scale.detach().reshape(1)
+    if scale.dtype != torch.float32:
+        scale = scale.float()
+    check(_lib.lib().kd_scale_by_device_scalar(_ptr(x), dt_of(x), x.numel(), _ptr(scale), stream_ptr()), "kd_scale_by_device_scalar")
+    return x
+
+
 def dwconv_sum(xs, w_taps, k, pad, dil, out=None):
     """out = sum_i dwconv(xs[i], w_taps[i]): the input gradient of a tensor that feeds several depthwise convs of one geometry
     (deeplabv3.py:64-75, the ASPP input under its replaced branches), summed inside one launch where the shape allows."""

@@ -385,6 +385,22 @@ def test_dwsep_block_golden(K, golden):
         assert_close(host_nchw(gx)[:, :Cc], g[f"{tag}.gx"], "f32", f"{tag} gx")
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_scale_by_device_scalar(K, dt):
+    """Upstream-gradient factor of the fused loss Functions: x * 1 is skipped on the device, any other factor is applied in place."""
+    for n in (8 * 1000, 8 * 37 + 5, 3):
+        x = torch.from_numpy(rnd(n)).to(DT[dt]).cuda()
+        keep = x.clone()
+        K.scale_by_device_scalar_(x, torch.ones((), device="cuda"))
+        assert torch.equal(x, keep)
+        K.scale_by_device_scalar_(x, torch.tensor(0.37, device="cuda"))
+        ref = (keep.float() * torch.tensor(0.37, device="cuda")).to(DT[dt])
+        assert torch.equal(x, ref)
+    x4 = torch.from_numpy(rnd(2, 5, 4, 6)).cuda().contiguous(memory_format=torch.channels_last)
+    K.scale_by_device_scalar_(x4, torch.tensor([2.0], device="cuda"))
+    assert x4.is_contiguous(memory_format=torch.channels_last)
+
+
 @pytest.mark.parametrize("shape", [(2, 20, 28), (1, 64, 128), (1, 37, 45), (1, 33, 100), (2, 2, 2), (1, 70, 29)])
 def test_stem_conv_pool_fused(K, shape):
     """kd_stem_conv_pool (mod1 -> pool2 -> bn1/relu of mod2.block1, wider_resnet.py:307-309, 353-356) against the oracle's
