@@ -144,13 +144,18 @@ class StudentEngine:
         self._pack.clear()
         self._bn.clear()
 
-    def _w_fwd(self, conv, cin_pad=None, cin_rot=0):
+    def _w_fwd(self, conv, cin_pad=None, cin_rot=0, cout_pad=None):
         """cin_rot = r: the conv reads its input channels rotated left by r (engine buffer order [r:], [:r]) -- the decoder keeps
-        its concat as [upsampled | fine] so that the 512-B-per-pixel upsample output starts on a 128-B line."""
+        its concat as [upsampled | fine] so that the 512-B-per-pixel upsample output starts on a 128-B line.  cout_pad: zero
+        filters appended up to that many outputs (bot_fine writes the concat buffer's pad channels as zeros itself)."""
         def make():
             w = conv.weight if not cin_rot else torch.cat([conv.weight.detach()[:, cin_rot:], conv.weight.detach()[:, :cin_rot]], 1).contiguous()
+            if cout_pad is not None and cout_pad > w.shape[0]:
+                wp = torch.zeros((cout_pad,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
+                wp[:w.shape[0]] = w.detach()
+                w = wp
             return ops.pack_conv_weight(w, self.dtype, KD_PACK_FWD, cin_pad)
-        return self._packed(conv.weight, ("fwd", self.dtype, cin_pad, cin_rot), make)
+        return self._packed(conv.weight, ("fwd", self.dtype, cin_pad, cin_rot, cout_pad), make)
 
     def _w_dgrad(self, conv, cout_pad=None, cin_rot=0):
         """[Cin][flipped taps][Cout] operand of the input-gradient conv; cout_pad zero-fills the contraction axis up to the
@@ -471,12 +476,12 @@ class StudentEngine:
         cdec = nf + nu
         cpad = ((cdec + 63) // 64) * 64          # 48 + 256 = 304 -> 320: the GEMM K granule
         dec0 = self._new(N, h2, w2, cpad)
-        if cpad > cdec:
-            dec0[..., cdec:cpad].zero_()         # (only the pad channels: the slices below fill the rest)
         # buffer order [upsampled (nu) | fine (nf) | pad]: the reference concatenates [fine, upsampled] (deeplabv3.py:152), the
         # final conv reads its input channels rotated by nf instead.  The upsample writes 512 B per pixel; starting 96 B into
         # a line it took 0.43 ms, line-aligned 0.25 (tools/ubench/upsample_align.py)
-        ops.conv2d(m2, self._w_fwd(net.bot_fine), out_raw=dec0[..., nu:cdec])
+        # (bot_fine carries cpad - cdec zero filters: the pad channels, which the final conv multiplies by zero weights, must
+        # be finite, and a strided fill of them was a 58-us kernel of its own)
+        ops.conv2d(m2, self._w_fwd(net.bot_fine, cout_pad=cpad - nu), out_raw=dec0[..., nu:cpad], algo_cout=nf)
         ops.upsample_bilinear_ac(up_small, (h2, w2), out=dec0[..., 0:nu])
         f = self._final()
         sc, sh = self._bn_fold(f[1])

@@ -83,7 +83,7 @@ def pack_conv_weight(w, dtype, mode=KD_PACK_FWD, cin_pad=None):
 
 
 def conv2d(x, w_packed, stride=1, pad=0, dil=1, *, res_pre=None, mask=None, mask_scale=None, res_post=None,
-           out_raw=None, out_act=None, act_scale=None, act_shift=None, act_relu=False, algo_cin=None):
+           out_raw=None, out_act=None, act_scale=None, act_shift=None, act_relu=False, algo_cin=None, algo_cout=None):
     """Implicit-GEMM conv; w_packed is (Cout,kh,kw,Cin). Outputs are caller-provided NHWC views."""
     _need_cuda(x, w_packed)
     N, H, W, Cin = x.shape
@@ -129,7 +129,7 @@ def conv2d(x, w_packed, stride=1, pad=0, dil=1, *, res_pre=None, mask=None, mask
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         epi = "".join(c for c, t in (("p", res_pre), ("m", mask), ("q", res_post), ("r", out_raw), ("a", out_act)) if t is not None)
-        prof.append(("conv_igemm", 2.0 * N * Ho * Wo * Cout * kh * kw * (algo_cin or Cin), e0, e1,
+        prof.append(("conv_igemm", 2.0 * N * Ho * Wo * (algo_cout or Cout) * kh * kw * (algo_cin or Cin), e0, e1,
                      f"{kh}x{kw} s{stride} d{dil} {H}x{W} {Cin}->{Cout} [{epi}]"))
     return out_raw, out_act
 
