@@ -3,6 +3,8 @@
 // All are HBM-bound streaming kernels.  Loss scalars are reduced in two fixed-order
 // stages (per-block partials in fp64 -> one finishing block), so results are
 // bit-reproducible run to run.
+#include <type_traits>
+
 #include "kd_common.h"
 
 namespace {
@@ -137,6 +139,33 @@ __global__ __launch_bounds__(256) void kldiv_kernel(V3 s, V3 t, M3 g, float invT
     block_partial(acc, partial);
 }
 
+// global -> LDS staging of `nel` consecutive elements (scaled): 16-B vectors when the operand is fp32, the chunk is whole and
+// 16-B aligned (19 scalar loads per thread and operand otherwise: the 19-class logit kernels ran at 2.5 TB/s)
+template <typename T> __device__ __forceinline__ void stage_scaled(float *dst, const T *src, int nel, float mul)
+{
+    if (std::is_same<T, float>::value && (nel & 3) == 0 && ((uintptr_t)src & 15) == 0) {
+        const float4 *s4 = (const float4 *)src;
+        float4 *d4 = (float4 *)dst;
+        for (int i = threadIdx.x; i < (nel >> 2); i += 256) {
+            float4 v = s4[i];
+            v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
+            d4[i] = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < nel; i += 256) dst[i] = Elem<T>::ld(src + i) * mul;
+    }
+}
+template <typename T> __device__ __forceinline__ void unstage(T *dst, const float *src, int nel)
+{
+    if (std::is_same<T, float>::value && (nel & 3) == 0 && ((uintptr_t)dst & 15) == 0) {
+        const float4 *s4 = (const float4 *)src;
+        float4 *d4 = (float4 *)dst;
+        for (int i = threadIdx.x; i < (nel >> 2); i += 256) d4[i] = s4[i];
+    } else {
+        for (int i = threadIdx.x; i < nel; i += 256) Elem<T>::st(dst + i, src[i]);
+    }
+}
+
 // NHWC-dense fast path (the engine's logits layout): a block stages 256 pixels x C channels of both operands in LDS
 // with fully coalesced loads, each thread then owns one pixel (row stride C words: conflict-free for odd C), and
 // the gradient goes back out through the same LDS rows, coalesced.
@@ -144,15 +173,16 @@ template <typename TS, typename TT, typename TG>
 __global__ __launch_bounds__(256) void kldiv_nhwc_kernel(const TS *__restrict__ s, const TT *__restrict__ t, TG *__restrict__ g,
                                                          int C, long long npix, float invT, float gscale, double *partial)
 {
-    extern __shared__ float sm[];
-    float *ss = sm, *st = sm + 256 * C;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *ss = sm, *st = sm + 256 * C;   // 256 * C * 4 B: a multiple of 16
     double acc = 0.0;
     for (long long base = (long long)blockIdx.x * 256; base < npix; base += (long long)gridDim.x * 256) {
         const int np = (int)min((long long)256, npix - base);
         const int nel = np * C;
         const TS *sp = s + base * C;
         const TT *tp = t + base * C;
-        for (int i = threadIdx.x; i < nel; i += 256) { ss[i] = Elem<TS>::ld(sp + i) * invT; st[i] = Elem<TT>::ld(tp + i) * invT; }
+        stage_scaled(ss, sp, nel, invT);
+        stage_scaled(st, tp, nel, invT);
         __syncthreads();
         if ((int)threadIdx.x < np) {
             float *a = ss + threadIdx.x * C, *b = st + threadIdx.x * C;
@@ -172,8 +202,7 @@ __global__ __launch_bounds__(256) void kldiv_nhwc_kernel(const TS *__restrict__ 
         }
         __syncthreads();
         if (g) {
-            TG *gp = g + base * C;
-            for (int i = threadIdx.x; i < nel; i += 256) Elem<TG>::st(gp + i, ss[i]);
+            unstage(g + base * C, ss, nel);
         }
         __syncthreads();
     }
@@ -184,13 +213,13 @@ template <typename TX>
 __global__ __launch_bounds__(256) void ce2d_nhwc_kernel(const TX *__restrict__ x, const int64_t *__restrict__ target, int ignore_index,
                                                         int C, long long npix, double *partial, double *count)
 {
-    extern __shared__ float sm[];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     double acc = 0.0, cnt = 0.0;
     for (long long base = (long long)blockIdx.x * 256; base < npix; base += (long long)gridDim.x * 256) {
         const int np = (int)min((long long)256, npix - base);
         const int nel = np * C;
         const TX *xp = x + base * C;
-        for (int i = threadIdx.x; i < nel; i += 256) sm[i] = Elem<TX>::ld(xp + i);
+        stage_scaled(sm, xp, nel, 1.0f);
         __syncthreads();
         if ((int)threadIdx.x < np) {
             const int64_t y = target[base + threadIdx.x];
