@@ -49,9 +49,14 @@ __global__ __launch_bounds__(256) void channel_sums_partial_kernel(const T *__re
                                                                    int ldsub, const T *__restrict__ a, int lda, long long rows,
                                                                    int C, int chunks, float *__restrict__ part)
 {
-    __shared__ float red[2][8][32 * VEC];
-    const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c = (blockIdx.y * 32 + cq) * VEC;
+    // lanes along channels: 32 vectors (256 channels with VEC = 8), or fewer for narrow tensors so that the other lanes take
+    // more rows instead of idling (C = 64 / 128 at full resolution are the longest calls of a mode-B step)
+    __shared__ float red[2][256 * VEC];
+    const int nvec = (C + VEC - 1) / VEC;
+    const int lc = nvec >= 32 ? 32 : (nvec > 16 ? 32 : (nvec > 8 ? 16 : (nvec > 4 ? 8 : 4)));
+    const int nrl = 256 / lc;
+    const int cq = threadIdx.x % lc, rl = threadIdx.x / lc;
+    const int c = (blockIdx.y * lc + cq) * VEC;
     const int chunk = blockIdx.x, grp = blockIdx.z;
     const long long per = (rows + chunks - 1) / chunks;
     const long long r0 = (long long)chunk * per, r1 = min(rows, r0 + per);
@@ -60,37 +65,53 @@ __global__ __launch_bounds__(256) void channel_sums_partial_kernel(const T *__re
 #pragma unroll
     for (int q = 0; q < VEC; ++q) s1[q] = s2[q] = 0.f;
     if (c < C) {
-        for (long long r = r0 + rl; r < r1; r += 8) {
+        // four rows per trip: their (up to 12) loads are issued together, then accumulated in row order -- the sums are the
+        // same fp32 chains as a row-at-a-time loop, but a thread keeps 8-12 loads in flight instead of 2-3 (1.7 -> HBM rate)
+        auto load_row = [&](long long r, float (&v)[VEC], float (&t)[VEC]) __attribute__((always_inline)) {
             const long long m = base + r;
-            float v[VEC], t[VEC];
             if constexpr (VEC == 8) ld8(g + m * ldg + c, v);
             else v[0] = Elem<T>::ld(g + m * ldg + c);
             if (sub) {
-                if constexpr (VEC == 8) ld8(sub + m * ldsub + c, t);
-                else t[0] = Elem<T>::ld(sub + m * ldsub + c);
+                float u[VEC];
+                if constexpr (VEC == 8) ld8(sub + m * ldsub + c, u);
+                else u[0] = Elem<T>::ld(sub + m * ldsub + c);
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) v[q] -= t[q];
+                for (int q = 0; q < VEC; ++q) v[q] -= u[q];
             }
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) s1[q] += v[q];
             if (a) {
                 if constexpr (VEC == 8) ld8(a + m * lda + c, t);
                 else t[0] = Elem<T>::ld(a + m * lda + c);
+            }
+        };
+        auto add_row = [&](const float (&v)[VEC], const float (&t)[VEC]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) s1[q] += v[q];
+            if (a) {
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) s2[q] += v[q] * t[q];
             }
+        };
+        long long r = r0 + rl;
+        for (; r + 3 * nrl < r1; r += 4 * nrl) {
+            float v0[VEC], v1[VEC], v2[VEC], v3[VEC], t0[VEC], t1[VEC], t2[VEC], t3[VEC];
+            load_row(r, v0, t0); load_row(r + nrl, v1, t1); load_row(r + 2 * nrl, v2, t2); load_row(r + 3 * nrl, v3, t3);
+            add_row(v0, t0); add_row(v1, t1); add_row(v2, t2); add_row(v3, t3);
+        }
+        for (; r < r1; r += nrl) {
+            float v[VEC], t[VEC];
+            load_row(r, v, t);
+            add_row(v, t);
         }
     }
 #pragma unroll
-    for (int q = 0; q < VEC; ++q) { red[0][rl][cq * VEC + q] = s1[q]; red[1][rl][cq * VEC + q] = s2[q]; }
+    for (int q = 0; q < VEC; ++q) { red[0][(rl * lc + cq) * VEC + q] = s1[q]; red[1][(rl * lc + cq) * VEC + q] = s2[q]; }
     __syncthreads();
-    for (int e = threadIdx.x; e < 2 * 32 * VEC; e += 256) {
-        const int which = e / (32 * VEC), col = e - which * (32 * VEC);
-        const int cc = blockIdx.y * 32 * VEC + col;
+    for (int e = threadIdx.x; e < 2 * lc * VEC; e += 256) {
+        const int which = e / (lc * VEC), col = e - which * (lc * VEC);
+        const int cc = blockIdx.y * lc * VEC + col;
         if (cc >= C) continue;
         float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[which][k][col];
+        for (int k = 0; k < nrl; ++k) t += red[which][k * lc * VEC + col];   // fixed order
         part[(((size_t)grp * chunks + chunk) * 2 + which) * C + cc] = t;
     }
 }
@@ -469,7 +490,9 @@ extern "C" int kd_channel_sums(int32_t dtype, const void *g, int32_t ldg, const 
     const int chunks = cs_chunks(rows_per_group);
     const int es = kd_elem_size(dtype);
     const bool vec = C % 8 == 0 && vec_ok(g, ldg, es) && vec_ok(sub, ldsub, es) && vec_ok(a, lda, es);
-    const dim3 grid((unsigned)chunks, (unsigned)((C + (vec ? 255 : 31)) / (vec ? 256 : 32)), (unsigned)groups);
+    const int nvec = vec ? (C + 7) / 8 : C;
+    const int lc = nvec > 16 ? 32 : (nvec > 8 ? 16 : (nvec > 4 ? 8 : 4));   // channel lanes of a block, as in the kernel
+    const dim3 grid((unsigned)chunks, (unsigned)((nvec + lc - 1) / lc), (unsigned)groups);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == KD_BF16) {
         if (vec) hipLaunchKernelGGL((channel_sums_partial_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t *)g, ldg, (const bf16_t *)sub, ldsub, (const bf16_t *)a, lda, (long long)rows_per_group, C, chunks, (float *)workspace);
