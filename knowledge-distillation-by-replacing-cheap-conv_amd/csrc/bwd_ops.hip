@@ -116,28 +116,36 @@ __global__ __launch_bounds__(256) void channel_sums_partial_kernel(const T *__re
     }
 }
 
-// block = 64 channels x 4 chunk lanes: lane l adds chunks l, l+4, ... in order (fp64), the four lane sums are combined in
-// lane order -- a fixed summation tree, hence bit-reproducible
+// block = 16 channels x 16 chunk lanes: lane l adds chunks l, l+16, ... in order (fp64), the sixteen lane sums are combined
+// as a fixed binary tree -- bit-reproducible.  (64 channels x 4 lanes left a 256-channel tensor with four blocks walking
+// 1024 partials each: 37 us per call, 44 calls per mode-B step.)
 __global__ __launch_bounds__(256) void channel_sums_finish_kernel(const float *__restrict__ part, int groups, int chunks, int C,
                                                                   float *__restrict__ s1, float *__restrict__ s2)
 {
-    __shared__ double sh[2][4][64];
-    const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6;
-    const int cblocks = (C + 63) / 64;
-    const int grp = blockIdx.x / cblocks, c = (blockIdx.x - grp * cblocks) * 64 + cl;
+    __shared__ double sh[2][16][16];
+    const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int cblocks = (C + 15) / 16;
+    const int grp = blockIdx.x / cblocks, c = (blockIdx.x - grp * cblocks) * 16 + cl;
     double a = 0.0, b = 0.0;
     if (c < C)
-        for (int k = lane; k < chunks; k += 4) {
+        for (int k = lane; k < chunks; k += 16) {
             const float *o = part + (((size_t)grp * chunks + k) * 2) * C;
             a += o[c];
-            b += o[C + c];
+            if (s2) b += o[C + c];
         }
     sh[0][lane][cl] = a;
     sh[1][lane][cl] = b;
     __syncthreads();
+    for (int w = 8; w >= 1; w >>= 1) {
+        if (lane < w) {
+            sh[0][lane][cl] += sh[0][lane + w][cl];
+            sh[1][lane][cl] += sh[1][lane + w][cl];
+        }
+        __syncthreads();
+    }
     if (lane == 0 && c < C) {
-        s1[(size_t)grp * C + c] = (float)((sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]));
-        if (s2) s2[(size_t)grp * C + c] = (float)((sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]));
+        s1[(size_t)grp * C + c] = (float)sh[0][0][cl];
+        if (s2) s2[(size_t)grp * C + c] = (float)sh[1][0][cl];
     }
 }
 
@@ -487,11 +495,19 @@ extern "C" int kd_channel_sums(int32_t dtype, const void *g, int32_t ldg, const 
     KD_REQUIRE(!a || s2, KD_ERR_INVALID, "kd_channel_sums: `a` given without s2");
     KD_REQUIRE(workspace_bytes >= kd_channel_sums_workspace(groups, rows_per_group, C), KD_ERR_WORKSPACE,
                "kd_channel_sums: workspace too small");
-    const int chunks = cs_chunks(rows_per_group);
     const int es = kd_elem_size(dtype);
     const bool vec = C % 8 == 0 && vec_ok(g, ldg, es) && vec_ok(sub, ldsub, es) && vec_ok(a, lda, es);
     const int nvec = vec ? (C + 7) / 8 : C;
     const int lc = nvec > 16 ? 32 : (nvec > 8 ? 16 : (nvec > 4 ? 8 : 4));   // channel lanes of a block, as in the kernel
+    // row chunks: ~2048 blocks over (groups, channel blocks, chunks) fill the chip; more only lengthens the second stage
+    // (never more than the workspace was sized for)
+    int chunks = cs_chunks(rows_per_group);
+    {
+        const long long other = (long long)groups * ((nvec + lc - 1) / lc);
+        const long long want = (2048 + other - 1) / other;
+        if (want < chunks) chunks = (int)(want < 16 ? 16 : want);
+        if (chunks > cs_chunks(rows_per_group)) chunks = cs_chunks(rows_per_group);
+    }
     const dim3 grid((unsigned)chunks, (unsigned)((nvec + lc - 1) / lc), (unsigned)groups);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == KD_BF16) {
@@ -502,7 +518,7 @@ extern "C" int kd_channel_sums(int32_t dtype, const void *g, int32_t ldg, const 
         else hipLaunchKernelGGL((channel_sums_partial_kernel<float, 1>), grid, dim3(256), 0, s, (const float *)g, ldg, (const float *)sub, ldsub, (const float *)a, lda, (long long)rows_per_group, C, chunks, (float *)workspace);
     }
     KD_CHECK_LAUNCH("kd_channel_sums");
-    hipLaunchKernelGGL(channel_sums_finish_kernel, dim3((unsigned)(groups * ((C + 63) / 64))), dim3(256), 0, s, (const float *)workspace,
+    hipLaunchKernelGGL(channel_sums_finish_kernel, dim3((unsigned)(groups * ((C + 15) / 16))), dim3(256), 0, s, (const float *)workspace,
                        groups, chunks, C, s1, a ? s2 : (float *)nullptr);
     KD_CHECK_LAUNCH("kd_channel_sums(finish)");
     return KD_OK;
