@@ -390,6 +390,15 @@ int kd_scale_by_device_scalar(void *x, int32_t dtype, int64_t n, const float *sc
  * `step` is the per-tensor step count after the increment (radam.py:62). */
 int kd_radam_step(float *p, const float *g, float *exp_avg, float *exp_avg_sq, int64_t n, int32_t step,
                   float lr, float beta1, float beta2, float eps, float weight_decay, kd_stream_t stream);
+/* The same update for many tensors in one launch (mode B steps ~150 tensors): per-tensor hyper-parameters and
+ * step counts, exactly the arithmetic of kd_radam_step.  `ts` is a HOST array; nothing is copied to the device besides the
+ * kernel arguments. */
+typedef struct kd_radam_tensor {
+    float *p; const float *g; float *exp_avg; float *exp_avg_sq;
+    int64_t n; int32_t step;
+    float lr, beta1, beta2, eps, weight_decay;
+} kd_radam_tensor;
+int kd_radam_step_multi(const kd_radam_tensor *ts, int32_t count, kd_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,11 @@ class DwDesc(C.Structure):
     _fields_ = [(n, c_int) for n in ("dtype", "N", "H", "W", "C", "k", "pad", "dil", "ldx", "ldy")]
 
 
+class RadamTensor(C.Structure):
+    _fields_ = [("p", c_vp), ("g", c_vp), ("exp_avg", c_vp), ("exp_avg_sq", c_vp), ("n", c_i64), ("step", c_int),
+                ("lr", c_f), ("beta1", c_f), ("beta2", c_f), ("eps", c_f), ("weight_decay", c_f)]
+
+
 class DwEpilogue(C.Structure):
     _fields_ = [("res_pre", c_vp), ("ld_res_pre", c_int), ("mask", c_vp), ("ld_mask", c_int), ("mask_scale", c_vp),
                 ("res_post", c_vp), ("ld_res_post", c_int)]
@@ -106,6 +111,7 @@ _SIGS = {
     "kd_ce2d_grad": (c_int, [_P(View3), c_vp, c_int, c_int, c_int, c_i64, _P(View3), c_f, c_vp, c_sz, c_vp]),
     "kd_confusion": (c_int, [_P(View3), c_vp, c_int, c_int, c_i64, c_vp, c_int, c_vp]),
     "kd_radam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f, c_f, c_f, c_f, c_f, c_vp]),
+    "kd_radam_step_multi": (c_int, [_P(RadamTensor), c_int, c_vp]),
 }
 
 _lib = None

@@ -412,6 +412,51 @@ __global__ __launch_bounds__(256) void radam_kernel(float *__restrict__ p, const
     }
 }
 
+// Multi-tensor form: one launch updates up to RADAM_MAXT tensors.  The per-tensor constants travel by value in the kernel
+// argument (no device-side table to fill, hence no copy and no sync); a block finds its tensor by a short search in the
+// block-prefix table.  Element-wise arithmetic identical to radam_kernel.
+constexpr int RADAM_MAXT = 48;
+constexpr int RADAM_BLK = 256 * 8;   // elements per block
+struct RadamBatch {
+    float *p[RADAM_MAXT];
+    const float *g[RADAM_MAXT];
+    float *m[RADAM_MAXT];
+    float *v[RADAM_MAXT];
+    long long n[RADAM_MAXT];
+    int blk0[RADAM_MAXT + 1];        // first block of tensor t
+    float wd_lr[RADAM_MAXT], step_lr[RADAM_MAXT], beta1[RADAM_MAXT], beta2[RADAM_MAXT], eps[RADAM_MAXT];
+    int rect[RADAM_MAXT];
+    int count;
+};
+static_assert(sizeof(RadamBatch) <= 4096, "kernel argument space");
+__global__ __launch_bounds__(256) void radam_multi_kernel(const RadamBatch b)
+{
+    int lo = 0, hi = b.count - 1;
+    while (lo < hi) {   // block-uniform
+        const int mid = (lo + hi + 1) >> 1;
+        if (b.blk0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int t = lo;
+    float *__restrict__ p = b.p[t];
+    const float *__restrict__ g = b.g[t];
+    float *__restrict__ m = b.m[t];
+    float *__restrict__ v = b.v[t];
+    const float beta1 = b.beta1[t], beta2 = b.beta2[t], eps = b.eps[t], wd_lr = b.wd_lr[t], step_lr = b.step_lr[t];
+    const int rectified = b.rect[t];
+    const long long base = (long long)((int)blockIdx.x - b.blk0[t]) * RADAM_BLK;
+    const long long end = min(b.n[t], base + RADAM_BLK);
+    for (long long i = base + threadIdx.x; i < end; i += 256) {
+        const float gi = g[i];
+        const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+        const float mi = m[i] * beta1 + (1.f - beta1) * gi;
+        v[i] = vi; m[i] = mi;
+        float pi = p[i];
+        if (wd_lr != 0.f) pi += -wd_lr * pi;
+        pi += rectified ? -step_lr * mi / (sqrtf(vi) + eps) : -step_lr * mi;
+        p[i] = pi;
+    }
+}
+
 inline V3 v3(const kd_view3 *v) { return V3{v->ptr, v->dtype, (long long)v->sN, (long long)v->sC, (long long)v->sP}; }
 inline M3 m3(const kd_mview3 *v)
 {
@@ -681,5 +726,51 @@ extern "C" int kd_scale_by_device_scalar(void *x, int32_t dtype, int64_t n, cons
         hipLaunchKernelGGL(scale_by_device_scalar_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float *)x, n8,
                            (long long)n, scale);
     KD_CHECK_LAUNCH("kd_scale_by_device_scalar");
+    return KD_OK;
+}
+
+// (N_sma, step_size) exactly as utils/optim/radam.py:64-83 computes (and caches) them
+static void radam_constants(int step, float beta1, float beta2, int *rect, double *step_size)
+{
+    const double beta2_t = pow((double)beta2, step);
+    const double nmax = 2.0 / (1.0 - (double)beta2) - 1.0;
+    const double nsma = nmax - 2.0 * step * beta2_t / (1.0 - beta2_t);
+    *rect = nsma >= 5.0;
+    if (*rect)
+        *step_size = sqrt((1 - beta2_t) * (nsma - 4) / (nmax - 4) * (nsma - 2) / nsma * nmax / (nmax - 2)) / (1 - pow((double)beta1, step));
+    else
+        *step_size = 1.0 / (1 - pow((double)beta1, step));
+}
+
+extern "C" int kd_radam_step_multi(const kd_radam_tensor *ts, int32_t count, kd_stream_t stream)
+{
+    KD_REQUIRE(ts && count > 0, KD_ERR_INVALID, "kd_radam_step_multi: bad argument");
+    for (int i = 0; i < count; ++i)
+        KD_REQUIRE(ts[i].p && ts[i].g && ts[i].exp_avg && ts[i].exp_avg_sq && ts[i].n > 0 && ts[i].step >= 1, KD_ERR_INVALID,
+                   "kd_radam_step_multi: bad tensor %d", i);
+    for (int done = 0; done < count;) {
+        RadamBatch b;
+        int nb = 0, k = 0;
+        for (; k < RADAM_MAXT && done + k < count; ++k) {
+            const kd_radam_tensor &t = ts[done + k];
+            const long long blocks = (t.n + RADAM_BLK - 1) / RADAM_BLK;
+            if (k > 0 && nb + blocks > 0x3fffffffLL) break;
+            KD_REQUIRE(blocks <= 0x3fffffffLL, KD_ERR_UNSUPPORTED, "kd_radam_step_multi: tensor too large");
+            int rect;
+            double step_size;
+            radam_constants(t.step, t.beta1, t.beta2, &rect, &step_size);
+            b.p[k] = t.p; b.g[k] = t.g; b.m[k] = t.exp_avg; b.v[k] = t.exp_avg_sq; b.n[k] = t.n;
+            b.blk0[k] = nb;
+            b.wd_lr[k] = (float)((double)t.weight_decay * t.lr);
+            b.step_lr[k] = (float)(step_size * t.lr);
+            b.beta1[k] = t.beta1; b.beta2[k] = t.beta2; b.eps[k] = t.eps; b.rect[k] = rect;
+            nb += (int)blocks;
+        }
+        b.blk0[k] = nb;
+        b.count = k;
+        hipLaunchKernelGGL(radam_multi_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, b);
+        KD_CHECK_LAUNCH("kd_radam_step_multi");
+        done += k;
+    }
     return KD_OK;
 }

@@ -757,6 +757,28 @@ def confusion(x, target, conf=None, accumulate=False):
     return conf
 
 
+def radam_step_multi(items):
+    """items: [(p, g, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay), ...] -- kd_radam_step for all of them in one
+    launch per 48 tensors; same arithmetic per element as radam_step."""
+    if not items:
+        return
+    arr = (_lib.RadamTensor * len(items))()
+    for i, (p, g, m, v, step, lr, beta1, beta2, eps, wd) in enumerate(items):
+        _need_cuda(p, g, m, v)
+        for t in (p, g, m, v):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != p.numel():
+                raise ValueError("radam_step_multi: fp32 contiguous tensors of equal size required")
+        a = arr[i]
+        a.p, a.g, a.exp_avg, a.exp_avg_sq = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+        a.n, a.step = p.numel(), int(step)
+        a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = lr, beta1, beta2, eps, wd
+    check(_lib.lib().kd_radam_step_multi(arr, len(items), stream_ptr()), "kd_radam_step_multi")
+    # the kernel wrote through raw pointers: tell autograd / version-keyed caches (engine weight packs) about it
+    for (p, _, m, v, *_rest) in items:
+        for t in (p, m, v):
+            torch.autograd.graph.increment_version(t)
+
+
 def radam_step(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay):
     _need_cuda(p, g, m, v)
     for t in (p, g, m, v):

@@ -44,6 +44,7 @@ class RAdam(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        batch = []   # device tensors: one multi-tensor launch for all of them (kd_radam_step_multi)
         for group in self.param_groups:
             beta1, beta2 = group['betas']
             for p in group['params']:
@@ -66,8 +67,8 @@ class RAdam(Optimizer):
                         state['exp_avg'].mul_(beta1).add_(g, alpha=1 - beta1)
                         continue
                     g = p.grad if (p.grad.dtype == torch.float32 and p.grad.is_contiguous()) else p.grad.float().contiguous()
-                    ops.radam_step(p, g, state['exp_avg'], state['exp_avg_sq'], step, group['lr'], beta1, beta2,
-                                   group['eps'], group['weight_decay'])
+                    batch.append((p, g, state['exp_avg'], state['exp_avg_sq'], step, group['lr'], beta1, beta2,
+                                  group['eps'], group['weight_decay']))
                     continue
                 # torch path (CPU tensors)
                 grad = p.grad.float()
@@ -86,4 +87,8 @@ class RAdam(Optimizer):
                         p32.add_(p32, alpha=-group['weight_decay'] * group['lr'])
                     p32.add_(exp_avg, alpha=-step_size * group['lr'])
                     p.copy_(p32)
+        if len(batch) == 1:
+            ops.radam_step(*batch[0])
+        elif batch:
+            ops.radam_step_multi(batch)
         return loss

@@ -532,6 +532,28 @@ def test_radam_golden(K, golden):
         np.testing.assert_allclose(p.cpu().numpy(), g["p"][i + 1], rtol=2e-6, atol=1e-7)
 
 
+def test_radam_multi_tensor_matches_single(K, golden):
+    """kd_radam_step_multi: the reference's 8-step golden through the batched launch, next to 60 other tensors of
+    odd sizes and different step counts / hyper-parameters, each bit for bit equal to its own kd_radam_step."""
+    g = golden("radam")
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    sizes = [1, 7, 2048, 2049, 5000, 300001] * 10
+    others = [dict(p=torch.randn(n, device="cuda", generator=gen), m=torch.zeros(n, device="cuda"), v=torch.zeros(n, device="cuda"),
+                   lr=1e-3 * (1 + i % 3), wd=0.0 if i % 2 else 1e-2, step0=i % 7) for i, n in enumerate(sizes)]
+    single = [dict(p=o["p"].clone(), m=o["m"].clone(), v=o["v"].clone()) for o in others]
+    p = torch.from_numpy(g["p"][0].copy()).cuda()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for i in range(8):
+        grads = [torch.randn(o["p"].numel(), device="cuda", generator=gen) for o in others]
+        items = [(p, torch.from_numpy(g["g"][i]).cuda(), m, v, i + 1, float(g["lr"]), 0.9, 0.999, 1e-8, 0.0)]
+        items += [(o["p"], gr, o["m"], o["v"], o["step0"] + i + 1, o["lr"], 0.9, 0.99, 1e-8, o["wd"]) for o, gr in zip(others, grads)]
+        K.radam_step_multi(items)
+        np.testing.assert_allclose(p.cpu().numpy(), g["p"][i + 1], rtol=2e-6, atol=1e-7)
+        for o, sgl, gr in zip(others, single, grads):
+            K.radam_step(sgl["p"], gr, sgl["m"], sgl["v"], o["step0"] + i + 1, o["lr"], 0.9, 0.99, 1e-8, o["wd"])
+            assert torch.equal(o["p"], sgl["p"]) and torch.equal(o["m"], sgl["m"]) and torch.equal(o["v"], sgl["v"])
+
+
 def test_errors_are_loud(K):
     from kdcc_amd._lib import KdccError
     x = torch.zeros((1, 4, 4, 48), device="cuda")  # Cin not a multiple of 32
