@@ -473,7 +473,7 @@ __global__ __launch_bounds__(NTW, 1) void dw_mfma_wgrad_kernel(DwWgMfmaParams p)
     px.H = p.H; px.W = p.W; px.dil = p.dil; px.ldx = p.ldx; px.ntx = p.ntx;
 
     const int fi = lane & 15, kg = lane >> 4;
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};   // even / odd staged x rows (see `rows` below)
 
     int cur = ibeg;
     Item wi = decode_item(px, cur < iend ? cur : 0);
@@ -502,23 +502,30 @@ __global__ __launch_bounds__(NTW, 1) void dw_mfma_wgrad_kernel(DwWgMfmaParams p)
             const bool more = nxt < iend;
 
             const int RV = wi.RV;
-            // rows in pairs: the pair's 4 x (5 + 4) fragment dwords are read first, then shifted, then the 4 MFMAs issue
+            // rows in pairs.  Both x rows of a pair multiply the SAME 16 rows of g (R0 - 8 + j): for the odd row R0 + 1 that
+            // is tap row ky = 9 - j instead of 8 - j, still all nine of them (j = 1 .. 9), so it accumulates into a second tile
+            // that is shifted by one lane when the partial sums are written -- one g fragment read per two MFMAs instead of
+            // one each (the kernel is LDS-bound: 5 + 5 + 4 fragment dwords per pair and lane instead of 5 + 4 + 5 + 4).
+            // The pair's fragment dwords are read first, then shifted, then the MFMAs issue.
             auto rows = [&](auto ncb_tag, int R0) __attribute__((always_inline)) {
                 constexpr int NCB = decltype(ncb_tag)::value;
                 uint32_t dd[2][NCB][5];
-                uint4 bv[2][NCB];
+                uint4 bv[NCB];
+                {
+                    const int ly = R0 - 8 + fi;
+                    const bool ok = ly >= 0 && ly < RV;
+                    const char *gr = gc + (ok ? ly : TLY) * RSTR;
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) bv[cb] = *(const uint4 *)(gr + cb * 64);
+                }
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr) {
-                    const int R = R0 + rr, ly = R - 8 + fi;
-                    const bool ok = ly >= 0 && ly < RV && R < RV + 8;
-                    const char *gr = gc + (ok ? ly : TLY) * RSTR;
-                    const char *xr = xc + min(R, RY - 1) * RSTR;
+                    const char *xr = xc + min(R0 + rr, RY - 1) * RSTR;
 #pragma unroll
                     for (int cb = 0; cb < NCB; ++cb) {
                         const uint32_t *xw = (const uint32_t *)(xr + cb * 64);
 #pragma unroll
                         for (int q = 0; q < 5; ++q) dd[rr][cb][q] = xw[q];
-                        bv[rr][cb] = *(const uint4 *)(gr + cb * 64);
                     }
                 }
 #pragma unroll
@@ -528,7 +535,8 @@ __global__ __launch_bounds__(NTW, 1) void dw_mfma_wgrad_kernel(DwWgMfmaParams p)
                         const uint32_t *d5 = dd[rr][cb];
                         const uint4 av = make_uint4(__builtin_amdgcn_alignbit(d5[1], d5[0], sh), __builtin_amdgcn_alignbit(d5[2], d5[1], sh),
                                                     __builtin_amdgcn_alignbit(d5[3], d5[2], sh), __builtin_amdgcn_alignbit(d5[4], d5[3], sh));
-                        Mma<bf16_t>::run(av, bv[rr][cb], acc);
+                        if (rr == 0) Mma<bf16_t>::run(av, bv[cb], acc);
+                        else Mma<bf16_t>::run(av, bv[cb], acc1);
                     }
             };
 #pragma unroll 1
@@ -561,12 +569,14 @@ __global__ __launch_bounds__(NTW, 1) void dw_mfma_wgrad_kernel(DwWgMfmaParams p)
             wi = wn;
         }
     }
-    // D[kx = 4*kg + r][j = fi] -> part[slab][ky = 8 - fi][kx][channel]
+    // D[kx = 4*kg + r][j = fi] -> part[slab][ky = 8 - fi][kx][channel]; the odd-row tile holds ky = 9 - j, i.e. tap row
+    // 8 - fi sits one lane up
     float *part = p.part + (size_t)(n * p.nseg + seg) * 81 * p.C + c0 + wave;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int kx = kg * 4 + r;
-        if (kx < 9 && fi < 9) part[(size_t)((8 - fi) * 9 + kx) * p.C] = acc[r];
+        const float odd = __shfl_down(acc1[r], 1, 16);
+        if (kx < 9 && fi < 9) part[(size_t)((8 - fi) * 9 + kx) * p.C] = acc[r] + odd;
     }
 }
 
