@@ -260,6 +260,135 @@ __global__ __launch_bounds__(256) void canny_finish_kernel(const unsigned char *
         out[i] = state[i] == 2 ? 255.f : 0.f;
 }
 
+// ---- 3x3 conv on 16 / 32 channels (the BasicBlocks of the shape stream at full resolution) ------------------------------------
+// res2 / res3 (encoders/Resnet.py:64-99 via gscnn.py:237-243) are 32- and 16-channel 3x3 convs on 2 M pixels per image: 0.16 / 0.04
+// TFLOP per launch at 4 images against 0.5-1.1 GB of activations -- HBM-bound by a wide margin.  Zero-padded to the 64-channel
+// granule of the implicit-GEMM kernels they cost 4x / 16x the MACs and the padded bytes (1.4 ms each).  Here a workgroup owns a
+// 256-pixel row segment and walks down SC_ROWS output rows with a four-slot ring of input rows in LDS (every input row is
+// fetched once per workgroup, fully coalesced); per 16 pixels one v_mfma_f32_16x16x32_bf16 per tap (C = 32) or per pair of
+// taps (C = 16: K = 2 taps x 16 channels) with the weights as the A operand, so a lane ends up with four consecutive output
+// channels of one pixel; bias (the folded BatchNorm shift), residual and ReLU in fp32 before the single rounding to bf16.
+constexpr int SC_SEG = 256, SC_ROWS = 16;
+typedef __attribute__((ext_vector_type(8))) short sc_bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float sc_f32x4_t;
+struct SmallConvParams {
+    const bf16_t *x; const bf16_t *w; const float *bias; const bf16_t *res; bf16_t *y;
+    int ldx, ldres, ldy, N, H, W, relu, nsx, nsy;
+};
+template <int C>
+__global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallConvParams p)
+{
+    constexpr int PXB = C * 2;                      // bytes per pixel in LDS
+    constexpr int ROWB = (SC_SEG + 2) * PXB;        // one ring slot: the segment + one halo pixel each side
+    constexpr int CPP = PXB / 16;                   // 16-B chunks per pixel
+    constexpr int NCH = (SC_SEG + 2) * CPP;         // chunks per row
+    constexpr int NLD = (NCH + 255) / 256;
+    constexpr int NT = C == 32 ? 9 : 5;             // MFMA k-steps per 16 pixels (C = 16: taps in pairs)
+    constexpr int NCT = C / 16;                     // 16-channel output tiles
+    __shared__ __attribute__((aligned(16))) char ring[4 * ROWB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, kg = lane >> 4;
+    int b = blockIdx.x;
+    const int sx = b % p.nsx; b /= p.nsx;
+    const int sy = b % p.nsy;
+    const int n = b / p.nsy;
+    const int x0 = sx * SC_SEG, r0 = sy * SC_ROWS, r1 = min(r0 + SC_ROWS, p.H);
+    const bf16_t *xn = p.x + (size_t)n * p.H * p.W * p.ldx;
+
+    // weight fragments (A operand): lane (output channel fi of tile ct, k-group kg)
+    uint4 wf[NT][NCT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            int tap, cin;
+            if (C == 32) { tap = t; cin = kg * 8; }
+            else { tap = 2 * t + (kg >> 1); cin = (kg & 1) * 8; }
+            wf[t][ct] = tap < 9 ? *(const uint4 *)(p.w + ((size_t)(ct * 16 + fi) * 9 + tap) * C + cin) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    // per-lane LDS offsets of the pixel fragments (B operand) relative to (slot of the row above, first pixel of a group)
+    int boff[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int tap, cin;
+        if (C == 32) { tap = t; cin = kg * 8; }
+        else { tap = min(2 * t + (kg >> 1), 8); cin = (kg & 1) * 8; }
+        boff[t] = ((tap / 3) << 16) | ((fi + tap % 3) * PXB + cin * 2);   // high half: ring row 0..2, low half: byte offset
+    }
+    float bias[NCT][4];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[ct][r] = p.bias ? p.bias[ct * 16 + kg * 4 + r] : 0.f;
+
+    uint4 st[NLD];
+    auto fetch_row = [&](int hr) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int c = tid + i * 256;
+            const int px = c / CPP, part = c - px * CPP, gx = x0 - 1 + px;
+            const bool ok = c < NCH && hr >= 0 && hr < p.H && gx >= 0 && gx < p.W;
+            st[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (ok) st[i] = *(const uint4 *)(xn + ((size_t)hr * p.W + gx) * p.ldx + part * 8);
+        }
+    };
+    auto put_row = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int c = tid + i * 256;
+            if (c < NCH) *(uint4 *)(ring + slot * ROWB + c * 16) = st[i];
+        }
+    };
+    // slot of input row hr: (hr - r0 + 1) & 3
+    fetch_row(r0 - 1); put_row(0);
+    fetch_row(r0); put_row(1);
+    fetch_row(r0 + 1); put_row(2);
+    __syncthreads();
+    for (int r = r0; r < r1; ++r) {
+        const bool more = r + 1 < r1;
+        if (more) fetch_row(r + 2);
+        const int s0 = (r - r0) & 3;   // slot of row r - 1
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int gx = wave * 64 + g * 16;   // first pixel of the group within the segment
+            sc_f32x4_t acc[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[ct] = (sc_f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int slot = (s0 + (boff[t] >> 16)) & 3;
+                const uint4 bv = *(const uint4 *)(ring + slot * ROWB + gx * PXB + (boff[t] & 0xffff));
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sc_bf16x8_t, wf[t][ct]),
+                                                                      __builtin_bit_cast(sc_bf16x8_t, bv), acc[ct], 0, 0, 0);
+            }
+            const int xx = x0 + gx + fi;
+            if (xx < p.W) {
+                const size_t pix = ((size_t)n * p.H + r) * p.W + xx;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = acc[ct][q] + bias[ct][q];
+                    if (p.res) {
+                        const uint2 rv = *(const uint2 *)(p.res + pix * p.ldres + ct * 16 + kg * 4);
+                        v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+                        v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                    }
+                    *(uint2 *)(p.y + pix * p.ldy + ct * 16 + kg * 4) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                }
+            }
+        }
+        if (more) put_row((r - r0 + 3) & 3);   // row r + 2 -> the slot row r - 2 left free
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" int kd_gated_conv(int32_t dtype, const void *feat, int32_t ldf, const void *gate, int32_t ldg, const float *params,
@@ -358,5 +487,29 @@ extern "C" int kd_canny_continue(int32_t N, int32_t H, int32_t W, int32_t sweeps
     }
     hipLaunchKernelGGL(canny_finish_kernel, dim3(nb), dim3(256), 0, s, (const unsigned char *)state, out, n);
     KD_CHECK_LAUNCH("kd_canny_continue");
+    return KD_OK;
+}
+
+extern "C" int kd_conv3x3_small(const void *x, int32_t ldx, const void *w, const float *bias, const void *res, int32_t ldres, void *y,
+                                int32_t ldy, int32_t N, int32_t H, int32_t W, int32_t C, int32_t relu, kd_stream_t stream)
+{
+    KD_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0, KD_ERR_INVALID, "kd_conv3x3_small: bad argument");
+    KD_REQUIRE(C == 16 || C == 32, KD_ERR_UNSUPPORTED, "kd_conv3x3_small: C must be 16 or 32 (got %d)", C);
+    KD_REQUIRE(ldx >= C && ldy >= C && ldx % 8 == 0 && ldy % 4 == 0 && kd_aligned16(x) && kd_aligned16(w) && ((uintptr_t)y % 8) == 0,
+               KD_ERR_INVALID, "kd_conv3x3_small: x needs 16-B aligned pixels (ldx %% 8), y 8-B aligned channel quads (ldy %% 4)");
+    KD_REQUIRE(!res || (ldres >= C && ldres % 4 == 0 && ((uintptr_t)res % 8) == 0), KD_ERR_INVALID,
+               "kd_conv3x3_small: res needs 8-B aligned channel quads");
+    KD_REQUIRE(x != y, KD_ERR_INVALID, "kd_conv3x3_small: y must not alias x");
+    SmallConvParams p;
+    p.x = (const bf16_t *)x; p.w = (const bf16_t *)w; p.bias = bias; p.res = (const bf16_t *)res; p.y = (bf16_t *)y;
+    p.ldx = ldx; p.ldres = ldres; p.ldy = ldy; p.N = N; p.H = H; p.W = W; p.relu = relu;
+    p.nsx = (W + SC_SEG - 1) / SC_SEG;
+    p.nsy = (H + SC_ROWS - 1) / SC_ROWS;
+    const long long blocks = (long long)N * p.nsx * p.nsy;
+    KD_REQUIRE(blocks <= 0x7fffffffLL, KD_ERR_UNSUPPORTED, "kd_conv3x3_small: image too large");
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 32) hipLaunchKernelGGL(conv3x3_small_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(conv3x3_small_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    KD_CHECK_LAUNCH("kd_conv3x3_small");
     return KD_OK;
 }

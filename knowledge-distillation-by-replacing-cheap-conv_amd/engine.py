@@ -40,6 +40,7 @@ from ._lib import KD_PACK_DGRAD, KD_PACK_FWD
 from .models.students.transform_blocks import DepthwiseSeparableBlock
 from .models.wider_resnet import IdentityResidualBlock
 
+_SMALL_CONV = os.environ.get("KDCC_SMALL_CONV", "1") != "0"  # A/B: 0 = GSCNN res2 / res3 zero-padded to 64 channels on the GEMM kernels
 _STEM_POOL = os.environ.get("KDCC_STEM_POOL", "1") != "0"   # A/B: 0 = stem conv and pool2 as two kernels
 _DW_SUM = os.environ.get("KDCC_DW_SUM", "1") != "0"   # A/B: 0 = one depthwise input-gradient launch per ASPP branch
 
@@ -98,6 +99,7 @@ class StudentEngine:
         # ASPP branch; decoder `final_seg`, last upsample without align_corners
         self.is_gscnn = net is not None and hasattr(net, "gate1")
         self._gate_prm = {}
+        self._persist = {}   # zero-padded buffers that live across steps (_zero_padded)
         self.edge_prior = None   # (N,H,W) fp32 Canny map handed in by the caller (teacher and student share one per batch)
         self.exported = None     # inputs of block k kept for the student (forward(export_at=k))
         self._next_prefix = None
@@ -406,11 +408,23 @@ class StudentEngine:
 
     def _basic_block(self, blk, x, cpad=64):
         """Resnet.BasicBlock (encoders/Resnet.py:64-99) on a cpad-channel buffer: two row-buffer 3x3 convs, BN folded into the
-        weights, bias + ReLU (+ identity shortcut) in the epilogues."""
+        weights, bias + ReLU (+ identity shortcut) in the epilogues.  bf16 blocks of 16 / 32 channels (res2, res3) run on
+        kd_conv3x3_small instead: dense C-channel input and intermediate, the result in the first C channels of a 64-channel
+        buffer whose pad channels were zeroed once (its reader is a 1x1 conv padded to the 64-channel GEMM granule)."""
         for p in blk.parameters():
             if p.requires_grad:
                 raise EngineError("trainable shape-stream parameters are not supported (the GSCNN plan keeps them frozen)")
-        N, H, W, _ = x.shape
+        N, H, W, cx = x.shape
+        planes = blk.conv1.out_channels
+        if _SMALL_CONV and self.dtype == torch.bfloat16 and planes in (16, 32) and blk.conv1.in_channels == planes:
+            w1, s1 = self._w_bn_folded(blk.conv1, blk.bn1, planes)
+            w2, s2 = self._w_bn_folded(blk.conv2, blk.bn2, planes)
+            xin = x if cx == planes else x[..., :planes]
+            t = self._new(N, H, W, planes)
+            ops.conv3x3_small(xin, w1, s1, relu=True, out=t)
+            y = self._zero_padded(("basic_block", id(blk)), N, H, W, cpad)
+            ops.conv3x3_small(t, w2, s2, res=xin, relu=True, out=y[..., :planes])
+            return y
         w1, s1 = self._w_bn_folded(blk.conv1, blk.bn1, cpad)
         w2, s2 = self._w_bn_folded(blk.conv2, blk.bn2, cpad)
         t = self._new(N, H, W, cpad)
@@ -418,6 +432,17 @@ class StudentEngine:
         y = self._new(N, H, W, cpad)
         ops.conv2d(t, w2, 1, 1, 1, res_pre=x, out_act=y, act_shift=s2, act_relu=True)
         return y
+
+    def _zero_padded(self, tag, N, H, W, C):
+        """A buffer that persists across steps and was zero-filled ONCE: callers write the same leading channels every step and
+        rely on the rest staying zero (a per-step fill of these full-resolution buffers was 12 x 0.14 ms of a GSCNN step).
+        Only for tensors consumed inside the forward that produced them (the frozen shape stream keeps nothing for backward)."""
+        key = (tag, N, H, W, C, self.dtype)
+        buf = self._persist.get(key)
+        if buf is None or buf.device != self.device:
+            buf = torch.zeros((N, H, W, C), dtype=self.dtype, device=self.device)
+            self._persist[key] = buf
+        return buf
 
     def _gate_params(self, gate):
         """GatedSpatialConv2d -> the packed fp32 vector kd_gated_conv takes (both eval-mode BNs folded)."""
@@ -446,14 +471,20 @@ class StudentEngine:
             ops.conv2d(t, self._w_fwd(conv), out_act=o, act_shift=conv.bias.detach().float().contiguous())
             return ops.upsample_bilinear_ac(o, (H, W))
 
-        def squeeze(conv, x, cout):   # dK: 1x1 + bias into the first `cout` channels of a zeroed 64-channel buffer
-            buf = self._new(N, H, W, 64, zero=True)
-            ops.conv2d(x, self._w_fwd(conv, cin_pad=64 if conv.in_channels < 64 else None), out_act=buf[..., :cout],
+        small = _SMALL_CONV and self.dtype == torch.bfloat16
+
+        def squeeze(conv, x, cout):   # dK: 1x1 + bias -> `cout` dense channels (its only reader is the gated conv)
+            buf = self._new(N, H, W, cout)
+            ops.conv2d(x, self._w_fwd(conv, cin_pad=64 if conv.in_channels < 64 else None), out_act=buf,
                        act_shift=conv.bias.detach().float().contiguous())
             return buf
 
         def gated(gate, buf, side_map, c):
-            out = self._new(N, H, W, 64, zero=True)
+            # its reader is a BasicBlock: dense c channels for kd_conv3x3_small, else the first c channels of a 64-channel buffer
+            # with zero pad channels (the GEMM kernels read all 64)
+            if small:
+                return ops.gated_conv(buf, side_map, self._gate_params(gate), c, out=self._new(N, H, W, c))
+            out = self._zero_padded(("gated", id(gate)), N, H, W, 64)
             ops.gated_conv(buf, side_map, self._gate_params(gate), c, out=out[..., :c])
             return out
 

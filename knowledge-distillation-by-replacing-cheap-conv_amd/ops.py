@@ -580,6 +580,26 @@ def bn2d_bwd(dy, x, y, gamma, mean, invstd, training, relu=False, need_dx=True):
 
 
 # ------------------------------------------------------------------------- Gated-SCNN shape stream
+def conv3x3_small(x, w_packed, bias=None, res=None, relu=True, out=None):
+    """3x3 / stride 1 / pad 1 conv on 16 or 32 channels (bf16): x (N,H,W,C) view, w_packed (C,3,3,C) bf16, bias fp32 (C),
+    res (N,H,W,C) view added before the ReLU (Resnet.py:64-99 BasicBlock)."""
+    _need_cuda(x, w_packed, bias, res, out)
+    N, H, W, Cc = x.shape
+    if x.dtype != torch.bfloat16 or tuple(w_packed.shape) != (Cc, 3, 3, Cc) or w_packed.dtype != torch.bfloat16 or not w_packed.is_contiguous():
+        raise ValueError("conv3x3_small: bf16 (N,H,W,C) input and a contiguous bf16 (C,3,3,C) packed weight required")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != Cc or not bias.is_contiguous()):
+        raise ValueError("conv3x3_small: bias must be contiguous fp32 (C,)")
+    if res is not None and (tuple(res.shape) != (N, H, W, Cc) or res.dtype != x.dtype):
+        raise ValueError("conv3x3_small: res must match the output shape/dtype")
+    if out is None:
+        out = torch.empty((N, H, W, Cc), dtype=x.dtype, device=x.device)
+    if tuple(out.shape) != (N, H, W, Cc) or out.dtype != x.dtype:
+        raise ValueError("conv3x3_small: bad output view")
+    check(_lib.lib().kd_conv3x3_small(_ptr(x), nhwc_ld(x), _ptr(w_packed), _ptr(bias), _ptr(res), nhwc_ld(res) if res is not None else 0,
+                                      _ptr(out), nhwc_ld(out), N, H, W, Cc, int(bool(relu)), stream_ptr()), "kd_conv3x3_small")
+    return out
+
+
 def gated_conv(feat, gate, params, C_, out=None):
     """feat (N,H,W,>=C) view whose first C channels are the features; gate (N,H,W,1); params: packed fp32 vector
     (W1, b1, w2, b2, Wg with the BNs folded); out: (N,H,W,C) view."""

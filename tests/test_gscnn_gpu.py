@@ -57,6 +57,59 @@ def test_gated_conv_and_basic_block_goldens(golden):
     assert float(yb[..., 16:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("C", [16, 32])
+@pytest.mark.parametrize("shape", [(1, 16, 256), (2, 37, 45), (1, 20, 300), (1, 33, 513), (1, 3, 7)])
+def test_conv3x3_small_vs_oracle(C, shape):
+    """kd_conv3x3_small (the 16 / 32-channel BasicBlock convs of the shape stream, Resnet.py:64-99) against the oracle's conv on
+    bf16-rounded operands: bias + residual + ReLU, views into wider buffers, ragged segments and row groups."""
+    from kdcc_amd import ops
+    from kdcc_amd._lib import KD_PACK_FWD
+    N, H, W = shape
+    rng = np.random.default_rng(100 + C + H + W)
+    bf = lambda a: torch.from_numpy(a).to(torch.bfloat16).float().numpy()
+    x, r = bf(rng.standard_normal((N, C, H, W)).astype(np.float32)), bf(rng.standard_normal((N, C, H, W)).astype(np.float32))
+    w = bf((rng.standard_normal((C, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32))
+    b = rng.standard_normal(C).astype(np.float32)
+    nhwc = lambda a: torch.from_numpy(np.ascontiguousarray(a.transpose(0, 2, 3, 1))).to(torch.bfloat16).cuda()
+    wp = ops.pack_conv_weight(torch.from_numpy(w).cuda(), torch.bfloat16, KD_PACK_FWD)
+    conv = orc.conv2d_fwd(x, w, pad=1)
+    # plain, dense
+    y = ops.conv3x3_small(nhwc(x), wp, relu=False)
+    ref = conv
+    assert np.abs(y.float().cpu().numpy().transpose(0, 3, 1, 2) - ref).max() < 1.5e-2 * np.abs(ref).max()
+    # bias + residual + relu, input / residual / output as channel slices of 64-channel buffers
+    xb = torch.zeros((N, H, W, 64), dtype=torch.bfloat16, device="cuda"); xb[..., :C] = nhwc(x)
+    rb = torch.zeros((N, H, W, 64), dtype=torch.bfloat16, device="cuda"); rb[..., 8:8 + C] = nhwc(r)
+    ob = torch.full((N, H, W, 64), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.conv3x3_small(xb[..., :C], wp, torch.from_numpy(b).cuda(), res=rb[..., 8:8 + C], relu=True, out=ob[..., :C])
+    ref = np.maximum(conv + b[None, :, None, None] + r, 0)
+    assert np.abs(ob[..., :C].float().cpu().numpy().transpose(0, 3, 1, 2) - ref).max() < 1.5e-2 * max(np.abs(ref).max(), 1e-6)
+    assert float((ob[..., C:] - 7.0).abs().max()) == 0.0   # nothing written outside the slice
+
+
+def test_basic_block_small_channels_bf16(golden):
+    """The bf16 engine path of res2 / res3: BasicBlock on kd_conv3x3_small (dense 16 channels in, zero-padded 64-channel buffer
+    out) against the reference module's golden, and the zero pad that the next 1x1 conv relies on, over two calls (the padded
+    buffer persists)."""
+    from kdcc_amd.engine import StudentEngine
+    from kdcc_amd.models.gscnn import BasicBlock
+    g = golden("gscnn")
+    eng = StudentEngine(None, torch.bfloat16)
+    eng.device = torch.device("cuda")
+    blk = BasicBlock(16)
+    seeded_fill_(blk, "gscnn.blk.res.")
+    blk = blk.eval().cuda()
+    for p in blk.parameters():
+        p.requires_grad = False
+    xb = seeded_input("gscnn.blk.res.x", (2, 16, 12, 20)).permute(0, 2, 3, 1).contiguous().cuda().bfloat16()
+    ref = g["blk_res.y"]
+    for _ in range(2):
+        yb = eng._basic_block(blk, xb)
+        assert tuple(yb.shape) == (2, 12, 20, 64)
+        assert np.abs(yb[..., :16].float().cpu().numpy().transpose(0, 3, 1, 2) - ref).max() < 2e-2 * np.abs(ref).max()
+        assert float(yb[..., 16:].abs().max()) == 0.0
+
+
 def test_canny_kernel_vs_published_algorithm():
     """kd_canny == oracle.canny_ref (numpy restatement of cv2.Canny's documented algorithm), bit for bit, on images with real
     structure (blurred blobs + noise: long weak chains exercise the hysteresis rounds) and on the normalised-float regime the
