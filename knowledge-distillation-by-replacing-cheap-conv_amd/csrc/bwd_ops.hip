@@ -298,53 +298,83 @@ __device__ __forceinline__ void up_src(int o, float sc, int I, int &i0, int &i1,
     f = src - (float)i0;
 }
 
-// pass 1: along W.  gy (N, Ho, Wo, C) -> tmp (N, Ho, W, C) float
-template <typename T>
+// pass 1: along W.  gy (N, Ho, Wo, C) -> tmp (N, Ho, W, C) float.  VEC = 8: a thread owns 8 channels (16-B loads; the 256-channel
+// decoder gradient took 1.33 ms one element per thread), VEC = 1: any C (the 19-class logits).
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void upsample_bwd_w_kernel(const T *__restrict__ gy, int ldgy, float *__restrict__ tmp, int N,
                                                              int Ho, int Wo, int W, int C, float sw)
 {
+    const int CV = C / VEC;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= W * C) return;
-    const int w = i / C, c = i - w * C;
+    if (i >= W * CV) return;
+    const int w = i / CV, c = (i - w * CV) * VEC;
     const int ho = blockIdx.y, n = blockIdx.z;
     const float inv = sw > 0.f ? 1.f / sw : 0.f;
     int lo = sw > 0.f ? (int)((w - 1) * inv) - 1 : 0, hi = sw > 0.f ? (int)((w + 1) * inv) + 2 : Wo - 1;
     lo = max(lo, 0); hi = min(hi, Wo - 1);
     const T *row = gy + (((size_t)n * Ho + ho) * Wo) * ldgy + c;
-    float acc = 0.f;
+    float acc[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
     for (int o = lo; o <= hi; ++o) {
         int i0, i1; float f;
         up_src(o, sw, W, i0, i1, f);
         float wgt = 0.f;
         if (i0 == w) wgt += 1.f - f;
         if (i1 == w) wgt += f;
-        if (wgt != 0.f) acc += wgt * Elem<T>::ld(row + (size_t)o * ldgy);
+        if (wgt != 0.f) {
+            if constexpr (VEC == 8) {
+                float v[8];
+                ld8(row + (size_t)o * ldgy, v);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] += wgt * v[q];
+            } else {
+                acc[0] += wgt * Elem<T>::ld(row + (size_t)o * ldgy);
+            }
+        }
     }
-    tmp[(((size_t)n * Ho + ho) * W + w) * C + c] = acc;
+    float *dst = tmp + (((size_t)n * Ho + ho) * W + w) * C + c;
+    if constexpr (VEC == 8) st8(dst, acc);
+    else dst[0] = acc[0];
 }
 
 // pass 2: along H.  tmp (N, Ho, W, C) float -> gx (N, H, W, C)
-template <typename T>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void upsample_bwd_h_kernel(const float *__restrict__ tmp, T *__restrict__ gx, int ldgx, int N, int Ho,
                                                              int H, int W, int C, float sh)
 {
+    const int CV = C / VEC;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= W * C) return;
-    const int w = i / C, c = i - w * C;
+    if (i >= W * CV) return;
+    const int w = i / CV, c = (i - w * CV) * VEC;
     const int h = blockIdx.y, n = blockIdx.z;
     const float inv = sh > 0.f ? 1.f / sh : 0.f;
     int lo = sh > 0.f ? (int)((h - 1) * inv) - 1 : 0, hi = sh > 0.f ? (int)((h + 1) * inv) + 2 : Ho - 1;
     lo = max(lo, 0); hi = min(hi, Ho - 1);
-    float acc = 0.f;
+    float acc[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
     for (int o = lo; o <= hi; ++o) {
         int i0, i1; float f;
         up_src(o, sh, H, i0, i1, f);
         float wgt = 0.f;
         if (i0 == h) wgt += 1.f - f;
         if (i1 == h) wgt += f;
-        if (wgt != 0.f) acc += wgt * tmp[(((size_t)n * Ho + o) * W + w) * C + c];
+        if (wgt != 0.f) {
+            const float *src = tmp + (((size_t)n * Ho + o) * W + w) * C + c;
+            if constexpr (VEC == 8) {
+                float v[8];
+                ld8(src, v);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] += wgt * v[q];
+            } else {
+                acc[0] += wgt * src[0];
+            }
+        }
     }
-    Elem<T>::st(gx + (((size_t)n * H + h) * W + w) * ldgx + c, acc);
+    T *dst = gx + (((size_t)n * H + h) * W + w) * ldgx + c;
+    if constexpr (VEC == 8) st8(dst, acc);
+    else Elem<T>::st(dst, acc[0]);
 }
 
 // ---- zero insertion (the transposed view of a strided conv's output gradient) -----------------------------------------------
@@ -593,13 +623,25 @@ extern "C" int kd_upsample_bilinear_ac_bwd(const void *gy, int32_t gy_dtype, int
     const float sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
     hipStream_t s = (hipStream_t)stream;
     float *tmp = (float *)workspace;
-    const dim3 g1((unsigned)((W * C + 255) / 256), (unsigned)Ho, (unsigned)N);
-    if (gy_dtype == KD_BF16) hipLaunchKernelGGL(upsample_bwd_w_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t *)gy, ldgy, tmp, N, Ho, Wo, W, C, sw);
-    else hipLaunchKernelGGL(upsample_bwd_w_kernel<float>, g1, dim3(256), 0, s, (const float *)gy, ldgy, tmp, N, Ho, Wo, W, C, sw);
+    const bool vec = C % 8 == 0 && vec_ok(gy, ldgy, kd_elem_size(gy_dtype)) && vec_ok(gx, ldgx, kd_elem_size(gx_dtype)) && kd_aligned16(tmp);
+    const int cv = vec ? C / 8 : C;
+    const dim3 g1((unsigned)((W * cv + 255) / 256), (unsigned)Ho, (unsigned)N);
+    if (vec) {
+        if (gy_dtype == KD_BF16) hipLaunchKernelGGL((upsample_bwd_w_kernel<bf16_t, 8>), g1, dim3(256), 0, s, (const bf16_t *)gy, ldgy, tmp, N, Ho, Wo, W, C, sw);
+        else hipLaunchKernelGGL((upsample_bwd_w_kernel<float, 8>), g1, dim3(256), 0, s, (const float *)gy, ldgy, tmp, N, Ho, Wo, W, C, sw);
+    } else {
+        if (gy_dtype == KD_BF16) hipLaunchKernelGGL((upsample_bwd_w_kernel<bf16_t, 1>), g1, dim3(256), 0, s, (const bf16_t *)gy, ldgy, tmp, N, Ho, Wo, W, C, sw);
+        else hipLaunchKernelGGL((upsample_bwd_w_kernel<float, 1>), g1, dim3(256), 0, s, (const float *)gy, ldgy, tmp, N, Ho, Wo, W, C, sw);
+    }
     KD_CHECK_LAUNCH("kd_upsample_bilinear_ac_bwd(w)");
-    const dim3 g2((unsigned)((W * C + 255) / 256), (unsigned)H, (unsigned)N);
-    if (gx_dtype == KD_BF16) hipLaunchKernelGGL(upsample_bwd_h_kernel<bf16_t>, g2, dim3(256), 0, s, (const float *)tmp, (bf16_t *)gx, ldgx, N, Ho, H, W, C, sh);
-    else hipLaunchKernelGGL(upsample_bwd_h_kernel<float>, g2, dim3(256), 0, s, (const float *)tmp, (float *)gx, ldgx, N, Ho, H, W, C, sh);
+    const dim3 g2((unsigned)((W * cv + 255) / 256), (unsigned)H, (unsigned)N);
+    if (vec) {
+        if (gx_dtype == KD_BF16) hipLaunchKernelGGL((upsample_bwd_h_kernel<bf16_t, 8>), g2, dim3(256), 0, s, (const float *)tmp, (bf16_t *)gx, ldgx, N, Ho, H, W, C, sh);
+        else hipLaunchKernelGGL((upsample_bwd_h_kernel<float, 8>), g2, dim3(256), 0, s, (const float *)tmp, (float *)gx, ldgx, N, Ho, H, W, C, sh);
+    } else {
+        if (gx_dtype == KD_BF16) hipLaunchKernelGGL((upsample_bwd_h_kernel<bf16_t, 1>), g2, dim3(256), 0, s, (const float *)tmp, (bf16_t *)gx, ldgx, N, Ho, H, W, C, sh);
+        else hipLaunchKernelGGL((upsample_bwd_h_kernel<float, 1>), g2, dim3(256), 0, s, (const float *)tmp, (float *)gx, ldgx, N, Ho, H, W, C, sh);
+    }
     KD_CHECK_LAUNCH("kd_upsample_bilinear_ac_bwd(h)");
     return KD_OK;
 }
