@@ -41,6 +41,7 @@ from .models.students.transform_blocks import DepthwiseSeparableBlock
 from .models.wider_resnet import IdentityResidualBlock
 
 _SMALL_CONV = os.environ.get("KDCC_SMALL_CONV", "1") != "0"  # A/B: 0 = GSCNN res2 / res3 zero-padded to 64 channels on the GEMM kernels
+_SPLIT_DEC_DGRAD = os.environ.get("KDCC_SPLIT_DEC_DGRAD", "1") != "0"   # A/B: 0 = the decoder's 304-channel input gradient in one launch
 _STEM_POOL = os.environ.get("KDCC_STEM_POOL", "1") != "0"   # A/B: 0 = stem conv and pool2 as two kernels
 _DW_SUM = os.environ.get("KDCC_DW_SUM", "1") != "0"   # A/B: 0 = one depthwise input-gradient launch per ASPP branch
 
@@ -1038,7 +1039,14 @@ class StudentEngine:
         g_dec0 = self._new(N, h2, w2, nu + kf)                     # [upsampled | fine | pad] like dec0
         if nu + kf > cdec:
             g_dec0[..., cdec:].zero_()
-        ops.conv2d(g_c1, self._w_dgrad(f[0], cin_rot=nf), 1, 1, 1, out_raw=g_dec0[..., 0:cdec])
+        wd = self._w_dgrad(f[0], cin_rot=nf)                       # (cdec, 3, 3, 256): rows = gradient channels of dec0
+        if _SPLIT_DEC_DGRAD and self.dtype == torch.bfloat16 and nu % 256 == 0 and cdec > nu:
+            # 304 output channels take the one-tile-per-workgroup row kernel with a ragged second N tile (0.73 PFLOP/s); the
+            # 256 upsampled channels alone fit the persistent kernel, the 48 fine channels a narrow tile
+            ops.conv2d(g_c1, wd[:nu], 1, 1, 1, out_raw=g_dec0[..., 0:nu])
+            ops.conv2d(g_c1, wd[nu:cdec], 1, 1, 1, out_raw=g_dec0[..., nu:cdec])
+        else:
+            ops.conv2d(g_c1, wd, 1, 1, 1, out_raw=g_dec0[..., 0:cdec])
         # bot_fine (1x1 on mod2's output)
         g_m2 = None
         self._conv_wgrad(net.bot_fine, dec["m2"], g_dec0[..., nu:cdec], grads)
