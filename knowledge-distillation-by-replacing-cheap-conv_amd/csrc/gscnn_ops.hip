@@ -6,6 +6,8 @@
 //   kd_canny           the Canny edge map the reference computes on the host with cv2.Canny(uint8 image, 10, 100)
 //                      (gscnn.py:284-288): Sobel 3x3, L1 magnitude, non-maximum suppression, hysteresis.  Parity of this
 //                      one operator is UNPINNED (opencv-python is not vendored); it follows the published algorithm.
+#include <stdlib.h>
+
 #include "kd_common.h"
 
 namespace {
@@ -260,6 +262,96 @@ __global__ __launch_bounds__(256) void canny_finish_kernel(const unsigned char *
         out[i] = state[i] == 2 ? 255.f : 0.f;
 }
 
+// bf16 form on the matrix cores.  Per 16 pixels the two per-pixel matrix products become MFMAs that share ONE operand: with
+// F = the 16 pixels' features as the B operand (lane (pixel, k-group) = 8 consecutive channels = one 16-B global load, no LDS),
+//   Z = W1[:, :C] F  (+ W1[:, C] gate + b1 as a rank-1 update in registers),   alpha = sigmoid(w2 . relu(Z) + b2),
+//   out = Wg (F (alpha + 1)) = (alpha + 1) (Wg F)        -- alpha is a per-pixel scalar, so the second product does not wait for it
+// and both sets of weights sit in registers as A operands (a lane ends up with four consecutive hidden units / output channels
+// of its pixel; the dot with w2 is finished across the four k-group lanes of a pixel by two lane swaps).  ~80 VALU
+// instructions per 16 pixels instead of ~2100 FMAs per pixel: the kernel becomes HBM-bound like its neighbours.
+typedef __attribute__((ext_vector_type(8))) short gc_bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float gc_f32x4_t;
+template <int C>
+__global__ __launch_bounds__(256) void gated_conv_mfma_kernel(const bf16_t *__restrict__ feat, int ldf, const bf16_t *__restrict__ gate,
+                                                              int ldg, const float *__restrict__ prm, bf16_t *__restrict__ out, int ldo,
+                                                              long long npix)
+{
+    constexpr int H = C + 1;
+    constexpr int NT1 = (H + 15) / 16;   // 16-row tiles of hidden units
+    constexpr int NT2 = (C + 15) / 16;   // 16-row tiles of output channels
+    const int lane = threadIdx.x & 63, fi = lane & 15, kg = lane >> 4;
+    const float *W1 = prm, *b1p = prm + H * H, *w2p = b1p + H, *b2p = w2p + H, *Wgp = b2p + 1;
+    // A operands: lane (row fi of tile t, k-group kg) holds input channels 8kg .. 8kg+7 (zero beyond C)
+    uint4 a1[NT1], a2[NT2];
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int h = t * 16 + fi, k = kg * 8 + q;
+            v[q] = (h < H && k < C) ? W1[h * H + k] : 0.f;
+        }
+        a1[t] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    }
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c = t * 16 + fi, k = kg * 8 + q;
+            v[q] = (c < C && k < C) ? Wgp[c * C + k] : 0.f;
+        }
+        a2[t] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    }
+    // per-lane constants of its D rows h = 16t + 4kg + r: gate column of W1, b1, w2 (zero for padded rows: relu(0) * 0)
+    float wg1[NT1][4], bb1[NT1][4], ww2[NT1][4];
+#pragma unroll
+    for (int t = 0; t < NT1; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int h = t * 16 + kg * 4 + r;
+            wg1[t][r] = h < H ? W1[h * H + C] : 0.f;
+            bb1[t][r] = h < H ? b1p[h] : 0.f;
+            ww2[t][r] = h < H ? w2p[h] : 0.f;
+        }
+    const float b2 = *b2p;
+    const long long ngroups = (npix + 15) / 16;
+    const long long wave_id = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * 256) >> 6;
+    for (long long g = wave_id; g < ngroups; g += nwaves) {
+        const long long pix = g * 16 + fi;
+        const bool ok = pix < npix;
+        const long long pc = ok ? pix : npix - 1;
+        uint4 bv = make_uint4(0u, 0u, 0u, 0u);
+        if (kg * 8 < C) bv = *(const uint4 *)(feat + pc * ldf + kg * 8);
+        const float gv = bf16_to_f32(gate[pc * ldg]);
+        gc_f32x4_t z[NT1], o[NT2];
+#pragma unroll
+        for (int t = 0; t < NT1; ++t)
+            z[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gc_bf16x8_t, a1[t]), __builtin_bit_cast(gc_bf16x8_t, bv),
+                                                           (gc_f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT2; ++t)
+            o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gc_bf16x8_t, a2[t]), __builtin_bit_cast(gc_bf16x8_t, bv),
+                                                           (gc_f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        float dot = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT1; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dot = fmaf(ww2[t][r], fmaxf(fmaf(wg1[t][r], gv, z[t][r] + bb1[t][r]), 0.f), dot);
+        dot += __shfl_xor(dot, 16);
+        dot += __shfl_xor(dot, 32);
+        const float k1 = 1.f / (1.f + __expf(-(dot + b2))) + 1.f;
+        if (ok) {
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) {
+                const int c = t * 16 + kg * 4;
+                if (c < C)
+                    *(uint2 *)(out + pix * ldo + c) = make_uint2(pack_bf16x2(o[t][0] * k1, o[t][1] * k1), pack_bf16x2(o[t][2] * k1, o[t][3] * k1));
+            }
+        }
+    }
+}
+
 // ---- 3x3 conv on 16 / 32 channels (the BasicBlocks of the shape stream at full resolution) ------------------------------------
 // res2 / res3 (encoders/Resnet.py:64-99 via gscnn.py:237-243) are 32- and 16-channel 3x3 convs on 2 M pixels per image: 0.16 / 0.04
 // TFLOP per launch at 4 images against 0.5-1.1 GB of activations -- HBM-bound by a wide margin.  Zero-padded to the 64-channel
@@ -400,8 +492,21 @@ extern "C" int kd_gated_conv(int32_t dtype, const void *feat, int32_t ldf, const
     const int es = kd_elem_size(dtype);
     KD_REQUIRE(kd_aligned16(feat) && kd_aligned16(out) && (ldf * es) % 16 == 0 && (ldo * es) % 16 == 0, KD_ERR_INVALID,
                "kd_gated_conv: 16-B aligned feature views required");
-    const int nb = blocks_for((npix + (C >= 32 ? 1 : 3)) / (C >= 32 ? 2 : 4), 65536);
     hipStream_t s = (hipStream_t)stream;
+    {
+        static int mfma = -1;
+        if (mfma < 0) { const char *e = getenv("KDCC_GATED_MFMA"); mfma = !(e && e[0] == '0'); }   // A/B: 0 = the VALU kernel
+        if (mfma && dtype == KD_BF16 && (ldo * es) % 8 == 0) {
+            const long long waves = (npix + 15) / 16;
+            const int nbm = blocks_for((waves + 3) / 4 * 256, 256 * 32);   // <= 32 workgroups per CU, grid-stride over the rest
+#define KD_GCM(CC) hipLaunchKernelGGL((gated_conv_mfma_kernel<CC>), dim3(nbm), dim3(256), 0, s, (const bf16_t *)feat, ldf, (const bf16_t *)gate, ldg, params, (bf16_t *)out, ldo, (long long)npix)
+            if (C == 8) KD_GCM(8); else if (C == 16) KD_GCM(16); else KD_GCM(32);
+#undef KD_GCM
+            KD_CHECK_LAUNCH("kd_gated_conv(mfma)");
+            return KD_OK;
+        }
+    }
+    const int nb = blocks_for((npix + (C >= 32 ? 1 : 3)) / (C >= 32 ? 2 : 4), 65536);
 #define KD_GC(T, CC) hipLaunchKernelGGL((gated_conv_kernel<T, CC>), dim3(nb), dim3(256), 0, s, (const T *)feat, ldf, (const T *)gate, ldg, params, (T *)out, ldo, (long long)npix)
     if (dtype == KD_BF16) { if (C == 8) KD_GC(bf16_t, 8); else if (C == 16) KD_GC(bf16_t, 16); else KD_GC(bf16_t, 32); }
     else { if (C == 8) KD_GC(float, 8); else if (C == 16) KD_GC(float, 16); else KD_GC(float, 32); }

@@ -57,6 +57,33 @@ def test_gated_conv_and_basic_block_goldens(golden):
     assert float(yb[..., 16:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("C", [8, 16, 32])
+def test_gated_conv_bf16_matrix_core_kernel(C):
+    """The bf16 kd_gated_conv (two MFMAs sharing the feature operand, gate_spatial_conv.py:50-60) against the fp32 per-pixel
+    kernel on the same bf16-rounded features: ragged last group of 16 pixels, features as a slice of a wider buffer."""
+    from kdcc_amd import ops
+    from kdcc_amd.engine import StudentEngine
+    from kdcc_amd.models.gscnn import GatedSpatialConv2d
+    gate = GatedSpatialConv2d(C, C)
+    seeded_fill_(gate, f"gscnn.gate{C}.")
+    gate = gate.eval().cuda()
+    eng = StudentEngine(None, torch.float32)
+    eng.device = torch.device("cuda")
+    prm = eng._gate_params(gate)
+    N, H, W = 2, 13, 21   # 546 pixels: not a multiple of 16
+    gen = torch.Generator(device="cuda").manual_seed(3 + C)
+    buf = torch.zeros((N, H, W, 64), device="cuda", dtype=torch.bfloat16)
+    buf[..., :C] = torch.randn((N, H, W, C), device="cuda", generator=gen).bfloat16()
+    side = torch.randn((N, H, W, 1), device="cuda", generator=gen).bfloat16()
+    ref = ops.gated_conv(buf.float(), side.float(), prm, C)
+    got = ops.gated_conv(buf, side, prm, C)
+    assert got.dtype == torch.bfloat16 and tuple(got.shape) == (N, H, W, C)
+    err = (got.float() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+    assert err < 2e-2, f"C={C}: {err:.3e}"
+    dense = ops.gated_conv(buf[..., :C].contiguous(), side, prm, C)   # dense features: same numbers
+    assert torch.equal(dense, got)
+
+
 @pytest.mark.parametrize("C", [16, 32])
 @pytest.mark.parametrize("shape", [(1, 16, 256), (2, 37, 45), (1, 20, 300), (1, 33, 513), (1, 3, 7)])
 def test_conv3x3_small_vs_oracle(C, shape):
