@@ -313,7 +313,7 @@ int kd_bn2d_bwd(const float *dy, const float *x, const float *y, const float *ga
  *   trainer's NCHW float batch; out: (N,H,W) float 0 / 255.  `sweeps` hysteresis sweeps run; *changed (device int) ends as
  *   the number of blocks that still promoted a pixel in the last sweep: call kd_canny_continue until it reads 0.
  *   Parity of this operator is unpinned (the reference's arithmetic lives in opencv-python, not vendored). */
-/* 3x3 / stride 1 / pad 1 convolution on C = 16 or 32 channels, bf16 NHWC: the two convs of the shape stream's BasicBlocks res2 / res3
+/* 3x3 / stride 1 / pad 1 convolution on C = 16, 32 or 64 channels, bf16 NHWC: the two convs of the shape stream's BasicBlocks res1 / res2 / res3
  * (models/encoders/Resnet.py:64-99, models/gscnn/gscnn.py:237-243) without padding them to the 64-channel GEMM granule.
  * w: bf16 [C][3][3][C] (kd_pack_conv_weight, KD_PACK_FWD; an eval-mode BatchNorm folded in by the caller), bias: fp32 (C) or NULL
  * (the folded BN shift), res: optional residual added before the ReLU (the block's identity shortcut), relu: 0 / 1.

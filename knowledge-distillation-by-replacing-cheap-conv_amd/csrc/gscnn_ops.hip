@@ -368,18 +368,28 @@ struct SmallConvParams {
     int ldx, ldres, ldy, N, H, W, relu, nsx, nsy;
 };
 template <int C>
-__global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallConvParams p)
+__global__ __launch_bounds__(C == 64 ? 512 : 256) void conv3x3_small_kernel(const SmallConvParams p)
 {
-    constexpr int PXB = C * 2;                      // bytes per pixel in LDS
-    constexpr int ROWB = (SC_SEG + 2) * PXB;        // one ring slot: the segment + one halo pixel each side
+    // C = 64 (res1): eight waves -- a wave owns two of the four 16-channel output tiles and a quarter of the segment's pixels,
+    // so its weight fragments (9 taps x 2 k-steps x 2 tiles) fit in registers; C = 32 / 16: four waves, all output tiles each
+    constexpr int NTHR = C == 64 ? 512 : 256;
+    constexpr int PXB = C * 2;                      // bytes per pixel
+    constexpr int PXL = C == 64 ? PXB + 16 : PXB;   // pixel stride in LDS.  C = 64: 144 B = 16 B x an odd number, so the 16 pixels
+                                                    // of a fragment read land in 16 different 16-B bank groups (a 128-B stride puts them
+                                                    // all in one: 1.00 -> 0.85 ms).  C = 32 / 16 stay dense: the padding costs them a
+                                                    // workgroup per CU (66 -> 82 KiB), which is worth more than their 2- / 4-way conflicts
+    constexpr int ROWB = (SC_SEG + 2) * PXL;        // one ring slot: the segment + one halo pixel each side
     constexpr int CPP = PXB / 16;                   // 16-B chunks per pixel
     constexpr int NCH = (SC_SEG + 2) * CPP;         // chunks per row
-    constexpr int NLD = (NCH + 255) / 256;
-    constexpr int NT = C == 32 ? 9 : 5;             // MFMA k-steps per 16 pixels (C = 16: taps in pairs)
-    constexpr int NCT = C / 16;                     // 16-channel output tiles
-    __shared__ __attribute__((aligned(16))) char ring[4 * ROWB];
+    constexpr int NLD = (NCH + NTHR - 1) / NTHR;
+    constexpr int NT = C == 16 ? 5 : 9;             // taps (C = 16: tap pairs) per 16 pixels
+    constexpr int NKS = C == 64 ? 2 : 1;            // 32-deep k-steps per tap
+    constexpr int NCT = C == 16 ? 1 : 2;            // 16-channel output tiles per wave
+    extern __shared__ __attribute__((aligned(16))) char ring[];   // 4 * ROWB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, kg = lane >> 4;
+    const int ct0 = C == 64 ? (wave & 1) * 2 : 0;   // first output tile of this wave
+    const int pq = C == 64 ? wave >> 1 : wave;      // pixel quarter of the segment
     int b = blockIdx.x;
     const int sx = b % p.nsx; b /= p.nsx;
     const int sy = b % p.nsy;
@@ -388,36 +398,41 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallConvParam
     const bf16_t *xn = p.x + (size_t)n * p.H * p.W * p.ldx;
 
     // weight fragments (A operand): lane (output channel fi of tile ct, k-group kg)
-    uint4 wf[NT][NCT];
+    uint4 wf[NT][NKS][NCT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            int tap, cin;
-            if (C == 32) { tap = t; cin = kg * 8; }
-            else { tap = 2 * t + (kg >> 1); cin = (kg & 1) * 8; }
-            wf[t][ct] = tap < 9 ? *(const uint4 *)(p.w + ((size_t)(ct * 16 + fi) * 9 + tap) * C + cin) : make_uint4(0u, 0u, 0u, 0u);
-        }
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                int tap, cin;
+                if (C == 16) { tap = 2 * t + (kg >> 1); cin = (kg & 1) * 8; }
+                else { tap = t; cin = ks * 32 + kg * 8; }
+                wf[t][ks][ct] = tap < 9 ? *(const uint4 *)(p.w + ((size_t)((ct0 + ct) * 16 + fi) * 9 + tap) * C + cin) : make_uint4(0u, 0u, 0u, 0u);
+            }
     // per-lane LDS offsets of the pixel fragments (B operand) relative to (slot of the row above, first pixel of a group)
     int boff[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         int tap, cin;
-        if (C == 32) { tap = t; cin = kg * 8; }
-        else { tap = min(2 * t + (kg >> 1), 8); cin = (kg & 1) * 8; }
-        boff[t] = ((tap / 3) << 16) | ((fi + tap % 3) * PXB + cin * 2);   // high half: ring row 0..2, low half: byte offset
+        if (C == 16) { tap = min(2 * t + (kg >> 1), 8); cin = (kg & 1) * 8; }
+        else { tap = t; cin = kg * 8; }
+        boff[t] = ((tap / 3) << 16) | ((fi + tap % 3) * PXL + cin * 2);   // high half: ring row 0..2, low half: byte offset
     }
     float bias[NCT][4];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bias[ct][r] = p.bias ? p.bias[ct * 16 + kg * 4 + r] : 0.f;
+        for (int r = 0; r < 4; ++r) bias[ct][r] = p.bias ? p.bias[(ct0 + ct) * 16 + kg * 4 + r] : 0.f;
+    float bias8[8];   // the 8 channels this lane owns after the k-group pair swap (two-tile instantiations)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bias8[q] = (NCT == 2 && p.bias) ? p.bias[(ct0 + (kg & 1)) * 16 + (kg & ~1) * 4 + q] : 0.f;
 
     uint4 st[NLD];
     auto fetch_row = [&](int hr) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int c = tid + i * 256;
+            const int c = tid + i * NTHR;
             const int px = c / CPP, part = c - px * CPP, gx = x0 - 1 + px;
             const bool ok = c < NCH && hr >= 0 && hr < p.H && gx >= 0 && gx < p.W;
             st[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -427,8 +442,8 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallConvParam
     auto put_row = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int c = tid + i * 256;
-            if (c < NCH) *(uint4 *)(ring + slot * ROWB + c * 16) = st[i];
+            const int c = tid + i * NTHR;
+            if (c < NCH) *(uint4 *)(ring + slot * ROWB + (c / CPP) * PXL + (c % CPP) * 16) = st[i];
         }
     };
     // slot of input row hr: (hr - r0 + 1) & 3
@@ -442,29 +457,65 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallConvParam
         const int s0 = (r - r0) & 3;   // slot of row r - 1
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int gx = wave * 64 + g * 16;   // first pixel of the group within the segment
+            const int gx = pq * 64 + g * 16;   // first pixel of the group within the segment
             sc_f32x4_t acc[NCT];
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) acc[ct] = (sc_f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int slot = (s0 + (boff[t] >> 16)) & 3;
-                const uint4 bv = *(const uint4 *)(ring + slot * ROWB + gx * PXB + (boff[t] & 0xffff));
+                const char *bp = ring + slot * ROWB + gx * PXL + (boff[t] & 0xffff);
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct)
-                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sc_bf16x8_t, wf[t][ct]),
-                                                                      __builtin_bit_cast(sc_bf16x8_t, bv), acc[ct], 0, 0, 0);
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const uint4 bv = *(const uint4 *)(bp + ks * 64);
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct)
+                        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sc_bf16x8_t, wf[t][ks][ct]),
+                                                                          __builtin_bit_cast(sc_bf16x8_t, bv), acc[ct], 0, 0, 0);
+                }
             }
             const int xx = x0 + gx + fi;
-            if (xx < p.W) {
+            if constexpr (NCT == 2) {
+                // a lane holds channels 4kg..4kg+3 of BOTH tiles; the k-group pair (kg, kg ^ 1) swaps one tile's quad so that the
+                // even lane owns 8 consecutive channels of the first tile and the odd lane 8 of the second: 16-B residual loads
+                // and stores instead of two 8-B ones each (the epilogue was store-issue-bound: 8.2 us per 256-pixel row at C = 64)
+                const bool odd = kg & 1;
+                float lo[4], hi[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float send = odd ? acc[0][q] : acc[1][q];
+                    const float recv = __shfl_xor(send, 16);
+                    lo[q] = odd ? recv : acc[0][q];
+                    hi[q] = odd ? acc[1][q] : recv;
+                }
+                if (xx < p.W) {
+                    const size_t pix = ((size_t)n * p.H + r) * p.W + xx;
+                    const int ch = (ct0 + (odd ? 1 : 0)) * 16 + (kg & ~1) * 4;
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { v[q] = lo[q] + bias8[q]; v[4 + q] = hi[q] + bias8[4 + q]; }
+                    if (p.res) {
+                        float rv[8];
+                        ld8(p.res + pix * p.ldres + ch, rv);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] += rv[q];
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+                    }
+                    st8(p.y + pix * p.ldy + ch, v);
+                }
+            } else if (xx < p.W) {
                 const size_t pix = ((size_t)n * p.H + r) * p.W + xx;
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
+                    const int ch = (ct0 + ct) * 16 + kg * 4;
                     float v[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = acc[ct][q] + bias[ct][q];
                     if (p.res) {
-                        const uint2 rv = *(const uint2 *)(p.res + pix * p.ldres + ct * 16 + kg * 4);
+                        const uint2 rv = *(const uint2 *)(p.res + pix * p.ldres + ch);
                         v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
                         v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
                     }
@@ -472,7 +523,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallConvParam
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
                     }
-                    *(uint2 *)(p.y + pix * p.ldy + ct * 16 + kg * 4) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                    *(uint2 *)(p.y + pix * p.ldy + ch) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                 }
             }
         }
@@ -599,11 +650,11 @@ extern "C" int kd_conv3x3_small(const void *x, int32_t ldx, const void *w, const
                                 int32_t ldy, int32_t N, int32_t H, int32_t W, int32_t C, int32_t relu, kd_stream_t stream)
 {
     KD_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0, KD_ERR_INVALID, "kd_conv3x3_small: bad argument");
-    KD_REQUIRE(C == 16 || C == 32, KD_ERR_UNSUPPORTED, "kd_conv3x3_small: C must be 16 or 32 (got %d)", C);
-    KD_REQUIRE(ldx >= C && ldy >= C && ldx % 8 == 0 && ldy % 4 == 0 && kd_aligned16(x) && kd_aligned16(w) && ((uintptr_t)y % 8) == 0,
-               KD_ERR_INVALID, "kd_conv3x3_small: x needs 16-B aligned pixels (ldx %% 8), y 8-B aligned channel quads (ldy %% 4)");
-    KD_REQUIRE(!res || (ldres >= C && ldres % 4 == 0 && ((uintptr_t)res % 8) == 0), KD_ERR_INVALID,
-               "kd_conv3x3_small: res needs 8-B aligned channel quads");
+    KD_REQUIRE(C == 16 || C == 32 || C == 64, KD_ERR_UNSUPPORTED, "kd_conv3x3_small: C must be 16, 32 or 64 (got %d)", C);
+    KD_REQUIRE(ldx >= C && ldy >= C && ldx % 8 == 0 && ldy % 8 == 0 && kd_aligned16(x) && kd_aligned16(w) && kd_aligned16(y),
+               KD_ERR_INVALID, "kd_conv3x3_small: x / y need 16-B aligned pixels (ld %% 8)");
+    KD_REQUIRE(!res || (ldres >= C && ldres % 8 == 0 && kd_aligned16(res)), KD_ERR_INVALID,
+               "kd_conv3x3_small: res needs 16-B aligned pixels (ld %% 8)");
     KD_REQUIRE(x != y, KD_ERR_INVALID, "kd_conv3x3_small: y must not alias x");
     SmallConvParams p;
     p.x = (const bf16_t *)x; p.w = (const bf16_t *)w; p.bias = bias; p.res = (const bf16_t *)res; p.y = (bf16_t *)y;
@@ -613,8 +664,30 @@ extern "C" int kd_conv3x3_small(const void *x, int32_t ldx, const void *w, const
     const long long blocks = (long long)N * p.nsx * p.nsy;
     KD_REQUIRE(blocks <= 0x7fffffffLL, KD_ERR_UNSUPPORTED, "kd_conv3x3_small: image too large");
     hipStream_t s = (hipStream_t)stream;
-    if (C == 32) hipLaunchKernelGGL(conv3x3_small_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(conv3x3_small_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    const int lds = 4 * (SC_SEG + 2) * (C == 64 ? C * 2 + 16 : C * 2);
+    if (C == 64) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void *)conv3x3_small_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+                kd_set_error("kd_conv3x3_small: cannot reserve %d B of LDS", lds);
+                return KD_ERR_HIP;
+            }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(conv3x3_small_kernel<64>, dim3((unsigned)blocks), dim3(512), lds, s, p);
+    } else if (C == 32) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void *)conv3x3_small_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+                kd_set_error("kd_conv3x3_small: cannot reserve %d B of LDS", lds);
+                return KD_ERR_HIP;
+            }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(conv3x3_small_kernel<32>, dim3((unsigned)blocks), dim3(256), lds, s, p);
+    } else {
+        hipLaunchKernelGGL(conv3x3_small_kernel<16>, dim3((unsigned)blocks), dim3(256), lds, s, p);
+    }
     KD_CHECK_LAUNCH("kd_conv3x3_small");
     return KD_OK;
 }

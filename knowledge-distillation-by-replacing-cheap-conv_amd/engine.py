@@ -146,6 +146,7 @@ class StudentEngine:
         """Forget packed weights / folded BN vectors (called when the module tree is edited: replace(), reset())."""
         self._pack.clear()
         self._bn.clear()
+        self._persist.clear()
 
     def _w_fwd(self, conv, cin_pad=None, cin_rot=0, cout_pad=None):
         """cin_rot = r: the conv reads its input channels rotated left by r (engine buffer order [r:], [:r]) -- the decoder keeps
@@ -409,21 +410,21 @@ class StudentEngine:
 
     def _basic_block(self, blk, x, cpad=64):
         """Resnet.BasicBlock (encoders/Resnet.py:64-99) on a cpad-channel buffer: two row-buffer 3x3 convs, BN folded into the
-        weights, bias + ReLU (+ identity shortcut) in the epilogues.  bf16 blocks of 16 / 32 channels (res2, res3) run on
-        kd_conv3x3_small instead: dense C-channel input and intermediate, the result in the first C channels of a 64-channel
+        weights, bias + ReLU (+ identity shortcut) in the epilogues.  bf16 blocks of 16 / 32 / 64 channels (res3, res2, res1) run
+        on kd_conv3x3_small instead: dense C-channel input and intermediate, the result in the first C channels of a 64-channel
         buffer whose pad channels were zeroed once (its reader is a 1x1 conv padded to the 64-channel GEMM granule)."""
         for p in blk.parameters():
             if p.requires_grad:
                 raise EngineError("trainable shape-stream parameters are not supported (the GSCNN plan keeps them frozen)")
         N, H, W, cx = x.shape
         planes = blk.conv1.out_channels
-        if _SMALL_CONV and self.dtype == torch.bfloat16 and planes in (16, 32) and blk.conv1.in_channels == planes:
+        if _SMALL_CONV and self.dtype == torch.bfloat16 and planes in (16, 32, 64) and blk.conv1.in_channels == planes:
             w1, s1 = self._w_bn_folded(blk.conv1, blk.bn1, planes)
             w2, s2 = self._w_bn_folded(blk.conv2, blk.bn2, planes)
             xin = x if cx == planes else x[..., :planes]
             t = self._new(N, H, W, planes)
             ops.conv3x3_small(xin, w1, s1, relu=True, out=t)
-            y = self._zero_padded(("basic_block", id(blk)), N, H, W, cpad)
+            y = self._zero_padded(("basic_block", id(blk)), N, H, W, cpad) if planes < cpad else self._new(N, H, W, planes)
             ops.conv3x3_small(t, w2, s2, res=xin, relu=True, out=y[..., :planes])
             return y
         w1, s1 = self._w_bn_folded(blk.conv1, blk.bn1, cpad)

@@ -581,7 +581,7 @@ def bn2d_bwd(dy, x, y, gamma, mean, invstd, training, relu=False, need_dx=True):
 
 # ------------------------------------------------------------------------- Gated-SCNN shape stream
 def conv3x3_small(x, w_packed, bias=None, res=None, relu=True, out=None):
-    """3x3 / stride 1 / pad 1 conv on 16 or 32 channels (bf16): x (N,H,W,C) view, w_packed (C,3,3,C) bf16, bias fp32 (C),
+    """3x3 / stride 1 / pad 1 conv on 16, 32 or 64 channels (bf16): x (N,H,W,C) view, w_packed (C,3,3,C) bf16, bias fp32 (C),
     res (N,H,W,C) view added before the ReLU (Resnet.py:64-99 BasicBlock)."""
     _need_cuda(x, w_packed, bias, res, out)
     N, H, W, Cc = x.shape

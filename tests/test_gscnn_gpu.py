@@ -84,7 +84,7 @@ def test_gated_conv_bf16_matrix_core_kernel(C):
     assert torch.equal(dense, got)
 
 
-@pytest.mark.parametrize("C", [16, 32])
+@pytest.mark.parametrize("C", [16, 32, 64])
 @pytest.mark.parametrize("shape", [(1, 16, 256), (2, 37, 45), (1, 20, 300), (1, 33, 513), (1, 3, 7)])
 def test_conv3x3_small_vs_oracle(C, shape):
     """kd_conv3x3_small (the 16 / 32-channel BasicBlock convs of the shape stream, Resnet.py:64-99) against the oracle's conv on
@@ -105,9 +105,9 @@ def test_conv3x3_small_vs_oracle(C, shape):
     ref = conv
     assert np.abs(y.float().cpu().numpy().transpose(0, 3, 1, 2) - ref).max() < 1.5e-2 * np.abs(ref).max()
     # bias + residual + relu, input / residual / output as channel slices of 64-channel buffers
-    xb = torch.zeros((N, H, W, 64), dtype=torch.bfloat16, device="cuda"); xb[..., :C] = nhwc(x)
-    rb = torch.zeros((N, H, W, 64), dtype=torch.bfloat16, device="cuda"); rb[..., 8:8 + C] = nhwc(r)
-    ob = torch.full((N, H, W, 64), 7.0, dtype=torch.bfloat16, device="cuda")
+    xb = torch.zeros((N, H, W, 80), dtype=torch.bfloat16, device="cuda"); xb[..., :C] = nhwc(x)
+    rb = torch.zeros((N, H, W, 80), dtype=torch.bfloat16, device="cuda"); rb[..., 8:8 + C] = nhwc(r)
+    ob = torch.full((N, H, W, 80), 7.0, dtype=torch.bfloat16, device="cuda")
     ops.conv3x3_small(xb[..., :C], wp, torch.from_numpy(b).cuda(), res=rb[..., 8:8 + C], relu=True, out=ob[..., :C])
     ref = np.maximum(conv + b[None, :, None, None] + r, 0)
     assert np.abs(ob[..., :C].float().cpu().numpy().transpose(0, 3, 1, 2) - ref).max() < 1.5e-2 * max(np.abs(ref).max(), 1e-6)
