@@ -320,6 +320,10 @@ int kd_bn2d_bwd(const float *dy, const float *x, const float *y, const float *ga
  *   y = relu?(conv(x, w) + bias + res) */
 int kd_conv3x3_small(const void *x, int32_t ldx, const void *w, const float *bias, const void *res, int32_t ldres, void *y,
                      int32_t ldy, int32_t N, int32_t H, int32_t W, int32_t C, int32_t relu, kd_stream_t stream);
+/* 1x1 conv + bias on few channels, bf16 NHWC: the squeezes d1 / d2 / d3 of the shape stream (models/gscnn/gscnn.py:232-235,
+ * Conv2d(64, 32, 1), Conv2d(32, 16, 1), Conv2d(16, 8, 1) at full resolution).  w: fp32 (Cout, Cin), bias: fp32 (Cout) or NULL. */
+int kd_pointwise_small(const void *x, int32_t ldx, const float *w, const float *bias, void *y, int32_t ldy, int64_t npix,
+                       int32_t Cin, int32_t Cout, kd_stream_t stream);
 int kd_gated_conv(int32_t dtype, const void *feat, int32_t ldf, const void *gate, int32_t ldg, const float *params,
                   void *out, int32_t ldo, int64_t npix, int32_t C, kd_stream_t stream);
 int kd_edge_attention(int32_t dtype, const void *cs, int32_t ldc, const float *canny, const float *weights, float *acts,

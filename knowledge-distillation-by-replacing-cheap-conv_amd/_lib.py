@@ -87,6 +87,7 @@ _SIGS = {
     "kd_dwconv_wgrad": (c_int, [_P(DwDesc), c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_sz, c_vp]),
     "kd_stem_conv": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "kd_scale_by_device_scalar": (c_int, [c_vp, c_int, c_i64, c_vp, c_vp]),
+    "kd_pointwise_small": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_vp]),
     "kd_conv3x3_small": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "kd_stem_conv_pool": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "kd_maxpool3x3s2": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),

@@ -352,6 +352,61 @@ __global__ __launch_bounds__(256) void gated_conv_mfma_kernel(const bf16_t *__re
     }
 }
 
+// 1x1 conv + bias on few channels (the squeezes d1 / d2 / d3 of the shape stream, gscnn.py:232-235: 64 -> 32, 32 -> 16, 16 -> 8 at full
+// resolution), bf16: like the gated conv above, the pixels' channels are the B operand straight from global memory and the
+// weights sit in registers as the A operand; a lane ends up with four consecutive output channels of its pixel.  Reads the
+// CIN channels that exist instead of a tensor padded to the GEMM kernels' 64-channel granule.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void pointwise_small_kernel(const bf16_t *__restrict__ x, int ldx, const float *__restrict__ w,
+                                                              const float *__restrict__ bias, bf16_t *__restrict__ y, int ldy, long long npix)
+{
+    constexpr int NKS = (CIN + 31) / 32, NT = (COUT + 15) / 16;
+    const int lane = threadIdx.x & 63, fi = lane & 15, kg = lane >> 4;
+    uint4 a[NT][NKS];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int c = t * 16 + fi, k = ks * 32 + kg * 8 + q;
+                v[q] = (c < COUT && k < CIN) ? w[c * CIN + k] : 0.f;
+            }
+            a[t][ks] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+        }
+    float bb[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = t * 16 + kg * 4 + r;
+            bb[t][r] = (bias && c < COUT) ? bias[c] : 0.f;
+        }
+    const long long ngroups = (npix + 15) / 16;
+    const long long wave_id = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * 256) >> 6;
+    for (long long g = wave_id; g < ngroups; g += nwaves) {
+        const long long pix = g * 16 + fi;
+        const bool ok = pix < npix;
+        const long long pc = ok ? pix : npix - 1;
+        uint4 bv[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            bv[ks] = make_uint4(0u, 0u, 0u, 0u);
+            if (ks * 32 + kg * 8 < CIN) bv[ks] = *(const uint4 *)(x + pc * ldx + ks * 32 + kg * 8);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            gc_f32x4_t o = {bb[t][0], bb[t][1], bb[t][2], bb[t][3]};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gc_bf16x8_t, a[t][ks]), __builtin_bit_cast(gc_bf16x8_t, bv[ks]), o, 0, 0, 0);
+            const int c = t * 16 + kg * 4;
+            if (ok && c < COUT) *(uint2 *)(y + pix * ldy + c) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+        }
+    }
+}
+
 // ---- 3x3 conv on 16 / 32 channels (the BasicBlocks of the shape stream at full resolution) ------------------------------------
 // res2 / res3 (encoders/Resnet.py:64-99 via gscnn.py:237-243) are 32- and 16-channel 3x3 convs on 2 M pixels per image: 0.16 / 0.04
 // TFLOP per launch at 4 images against 0.5-1.1 GB of activations -- HBM-bound by a wide margin.  Zero-padded to the 64-channel
@@ -689,5 +744,23 @@ extern "C" int kd_conv3x3_small(const void *x, int32_t ldx, const void *w, const
         hipLaunchKernelGGL(conv3x3_small_kernel<16>, dim3((unsigned)blocks), dim3(256), lds, s, p);
     }
     KD_CHECK_LAUNCH("kd_conv3x3_small");
+    return KD_OK;
+}
+
+extern "C" int kd_pointwise_small(const void *x, int32_t ldx, const float *w, const float *bias, void *y, int32_t ldy, int64_t npix,
+                                  int32_t Cin, int32_t Cout, kd_stream_t stream)
+{
+    KD_REQUIRE(x && w && y && npix > 0, KD_ERR_INVALID, "kd_pointwise_small: bad argument");
+    KD_REQUIRE((Cin == 64 && Cout == 32) || (Cin == 32 && Cout == 16) || (Cin == 16 && Cout == 8), KD_ERR_UNSUPPORTED,
+               "kd_pointwise_small: (Cin, Cout) must be (64, 32), (32, 16) or (16, 8) (got %d, %d)", Cin, Cout);
+    KD_REQUIRE(ldx >= Cin && ldy >= Cout && ldx % 8 == 0 && ldy % 4 == 0 && kd_aligned16(x) && ((uintptr_t)y % 8) == 0, KD_ERR_INVALID,
+               "kd_pointwise_small: x needs 16-B aligned pixels (ldx %% 8), y 8-B aligned channel quads (ldy %% 4)");
+    const long long waves = (npix + 15) / 16;
+    const int nb = blocks_for((waves + 3) / 4 * 256, 256 * 32);
+    hipStream_t s = (hipStream_t)stream;
+#define KD_PWS(CI, CO) hipLaunchKernelGGL((pointwise_small_kernel<CI, CO>), dim3(nb), dim3(256), 0, s, (const bf16_t *)x, ldx, w, bias, (bf16_t *)y, ldy, (long long)npix)
+    if (Cin == 64) KD_PWS(64, 32); else if (Cin == 32) KD_PWS(32, 16); else KD_PWS(16, 8);
+#undef KD_PWS
+    KD_CHECK_LAUNCH("kd_pointwise_small");
     return KD_OK;
 }

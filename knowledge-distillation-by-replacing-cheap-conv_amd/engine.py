@@ -476,6 +476,9 @@ class StudentEngine:
         small = _SMALL_CONV and self.dtype == torch.bfloat16
 
         def squeeze(conv, x, cout):   # dK: 1x1 + bias -> `cout` dense channels (its only reader is the gated conv)
+            if small and (conv.in_channels, cout) in ((64, 32), (32, 16), (16, 8)) and x.shape[3] == conv.in_channels:
+                return ops.pointwise_small(x, conv.weight.detach().float().reshape(cout, -1).contiguous(),
+                                           conv.bias.detach().float().contiguous())
             buf = self._new(N, H, W, cout)
             ops.conv2d(x, self._w_fwd(conv, cin_pad=64 if conv.in_channels < 64 else None), out_act=buf,
                        act_shift=conv.bias.detach().float().contiguous())
@@ -491,9 +494,10 @@ class StudentEngine:
             return out
 
         s3, s4, s7 = side(net.dsn3, m3), side(net.dsn4, m4), side(net.dsn7, m7)
+        # (small: the BasicBlocks hand dense C-channel tensors to kd_pointwise_small; else 64-channel buffers to the GEMM kernels)
         cs = gated(net.gate1, squeeze(net.d1, self._basic_block(net.res1, m1), 32), s3, 32)
-        cs = gated(net.gate2, squeeze(net.d2, self._basic_block(net.res2, cs), 16), s4, 16)
-        cs = gated(net.gate3, squeeze(net.d3, self._basic_block(net.res3, cs), 8), s7, 8)
+        cs = gated(net.gate2, squeeze(net.d2, self._basic_block(net.res2, cs, 32 if small else 64), 16), s4, 16)
+        cs = gated(net.gate3, squeeze(net.d3, self._basic_block(net.res3, cs, 16 if small else 64), 8), s7, 8)
         canny = self.edge_prior if self.edge_prior is not None else self.compute_edge_prior(x_nchw)
         w = torch.cat([net.fuse.weight.detach().float().reshape(-1), net.cw.weight.detach().float().reshape(-1)]).contiguous()
         return ops.edge_attention(cs, canny, w)

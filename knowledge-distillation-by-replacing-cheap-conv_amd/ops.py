@@ -580,6 +580,25 @@ def bn2d_bwd(dy, x, y, gamma, mean, invstd, training, relu=False, need_dx=True):
 
 
 # ------------------------------------------------------------------------- Gated-SCNN shape stream
+def pointwise_small(x, w, bias=None, out=None):
+    """1x1 conv + bias, bf16, (Cin, Cout) in {(64, 32), (32, 16), (16, 8)}: x (N,H,W,Cin) view, w fp32 (Cout,Cin[,1,1]) (gscnn.py:232-235)."""
+    _need_cuda(x, w, bias, out)
+    N, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    w = w.detach().reshape(Cout, -1)
+    if x.dtype != torch.bfloat16 or w.shape[1] != Cin or w.dtype != torch.float32 or not w.is_contiguous():
+        raise ValueError("pointwise_small: bf16 (N,H,W,Cin) input and a contiguous fp32 (Cout,Cin) weight required")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != Cout or not bias.is_contiguous()):
+        raise ValueError("pointwise_small: bias must be contiguous fp32 (Cout,)")
+    if out is None:
+        out = torch.empty((N, H, W, Cout), dtype=x.dtype, device=x.device)
+    if tuple(out.shape) != (N, H, W, Cout) or out.dtype != x.dtype:
+        raise ValueError("pointwise_small: bad output view")
+    check(_lib.lib().kd_pointwise_small(_ptr(x), nhwc_ld(x), _ptr(w), _ptr(bias), _ptr(out), nhwc_ld(out), N * H * W, Cin, Cout,
+                                        stream_ptr()), "kd_pointwise_small")
+    return out
+
+
 def conv3x3_small(x, w_packed, bias=None, res=None, relu=True, out=None):
     """3x3 / stride 1 / pad 1 conv on 16, 32 or 64 channels (bf16): x (N,H,W,C) view, w_packed (C,3,3,C) bf16, bias fp32 (C),
     res (N,H,W,C) view added before the ReLU (Resnet.py:64-99 BasicBlock)."""

@@ -84,6 +84,24 @@ def test_gated_conv_bf16_matrix_core_kernel(C):
     assert torch.equal(dense, got)
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 32), (32, 16), (16, 8)])
+def test_pointwise_small_vs_reference(cin, cout):
+    """kd_pointwise_small (the shape stream's squeezes d1 / d2 / d3, gscnn.py:232-235) against torch's fp32 1x1 conv on the same
+    bf16-rounded operands; ragged last pixel group, input as a channel slice."""
+    from kdcc_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(cin)
+    N, H, W = 2, 9, 29   # 522 pixels: not a multiple of 16
+    xb = torch.zeros((N, H, W, cin + 16), device="cuda", dtype=torch.bfloat16)
+    xb[..., :cin] = torch.randn((N, H, W, cin), device="cuda", generator=gen).bfloat16()
+    w = (torch.randn((cout, cin, 1, 1), device="cuda", generator=gen) / cin ** 0.5)
+    b = torch.randn(cout, device="cuda", generator=gen)
+    got = ops.pointwise_small(xb[..., :cin], w, b)
+    wq = w.bfloat16().float()
+    ref = torch.nn.functional.conv2d(xb[..., :cin].float().permute(0, 3, 1, 2), wq, b).permute(0, 2, 3, 1)
+    err = (got.float() - ref).abs().max().item() / ref.abs().max().item()
+    assert got.dtype == torch.bfloat16 and tuple(got.shape) == (N, H, W, cout) and err < 1e-2, err
+
+
 @pytest.mark.parametrize("C", [16, 32, 64])
 @pytest.mark.parametrize("shape", [(1, 16, 256), (2, 37, 45), (1, 20, 300), (1, 33, 513), (1, 3, 7)])
 def test_conv3x3_small_vs_oracle(C, shape):
