@@ -411,6 +411,18 @@ typedef struct kd_radam_tensor {
 } kd_radam_tensor;
 int kd_radam_step_multi(const kd_radam_tensor *ts, int32_t count, kd_stream_t stream);
 
+/* ----------------------------------------------------------------- diagnostics (host side only; no launch changes)
+ * Kernel-selection log: the dispatchers behind kd_conv2d_fwd / kd_conv2d_wgrad / kd_pw_wgrad / kd_dwconv_* /
+ * kd_stem_conv* pick one of several device kernels by shape, dtype and epilogue.  The reference has
+ * nothing to mirror here -- its dispatch is cuDNN's, behind torch.nn.functional.conv2d (models/encoders/wider_resnet.py:
+ * 124-167) -- but a parity test is only worth what it covers, so tests assert the kernel a case reached.
+ *   kd_debug_kernel_log_enable(1) clears the counters and starts counting, (0) stops;
+ *   kd_debug_kernel_log_read writes "name\tcount\n" lines (NUL-terminated, truncated to `bytes`) and returns the length
+ *   needed; kd_debug_last_kernel is the name the calling thread's last dispatch picked ("" before any). */
+int kd_debug_kernel_log_enable(int32_t on);
+int64_t kd_debug_kernel_log_read(char *buf, size_t bytes);
+const char *kd_debug_last_kernel(void);
+
 #ifdef __cplusplus
 }
 #endif

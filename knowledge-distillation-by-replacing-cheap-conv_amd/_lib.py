@@ -8,7 +8,18 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkdcc_hip.so")
+# KDCC_LIB=tuning loads the diagnostics build (`make -C csrc TUNING=1`: timing ablations that alter results, in-kernel
+# timestamps) for tools/; everything else -- tests, bench, trainers -- runs the default library, which compiles them out.
+# (KDCC_LIB=/path/to/other.so: A/B against another build of the same ABI, tools/bench_*.py.)
+_sel = os.environ.get("KDCC_LIB", "")
+LIB_PATH = (os.path.join(_HERE, "libkdcc_hip_tuning.so") if _sel == "tuning" else _sel if _sel.endswith(".so")
+            else os.path.join(_HERE, "libkdcc_hip.so"))
+
+
+def build_tuning():
+    """Compile the diagnostics build next to the default one (tools/ call this before importing the ops)."""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-j", str(min(8, os.cpu_count() or 1)), "-C", os.path.join(_HERE, "csrc"), "TUNING=1"])
 
 KD_F32, KD_BF16 = 0, 1
 KD_PACK_FWD, KD_PACK_DGRAD = 0, 1
@@ -114,6 +125,9 @@ _SIGS = {
     "kd_confusion": (c_int, [_P(View3), c_vp, c_int, c_int, c_i64, c_vp, c_int, c_vp]),
     "kd_radam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f, c_f, c_f, c_f, c_f, c_vp]),
     "kd_radam_step_multi": (c_int, [_P(RadamTensor), c_int, c_vp]),
+    "kd_debug_kernel_log_enable": (c_int, [c_int]),
+    "kd_debug_kernel_log_read": (c_i64, [C.c_char_p, c_sz]),
+    "kd_debug_last_kernel": (C.c_char_p, []),
 }
 
 _lib = None
@@ -136,6 +150,36 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = l
     return _lib
+
+
+class kernel_log:
+    """`with kernel_log() as log: ...; log.counts` -> {device kernel name: launches} for the dispatchers that choose between
+    kernels (kd_debug_kernel_log_*, include/kdcc.h).  Host-side counters; nothing about a launch changes."""
+
+    def __enter__(self):
+        self.counts = {}
+        check(lib().kd_debug_kernel_log_enable(1), "kd_debug_kernel_log_enable")
+        return self
+
+    def snapshot(self):
+        need = int(lib().kd_debug_kernel_log_read(None, 0)) + 1
+        buf = C.create_string_buffer(need)
+        lib().kd_debug_kernel_log_read(buf, need)
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt = line.rsplit("\t", 1)
+            out[name] = int(cnt)
+        return out
+
+    def __exit__(self, *exc):
+        self.counts = self.snapshot()
+        lib().kd_debug_kernel_log_enable(0)
+        return False
+
+
+def last_kernel():
+    """Name of the device kernel the calling thread's last dispatch selected."""
+    return lib().kd_debug_last_kernel().decode()
 
 
 def exported_symbols():

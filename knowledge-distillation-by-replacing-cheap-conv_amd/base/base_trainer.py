@@ -134,13 +134,20 @@ class BaseTrainer:
             self.logger.warning("Warning: There's no GPU available on this machine, training will be performed on CPU.")
             n_gpu = 0
         if n_gpu == 0:
+            # host plumbing run (the reference's CPU configs): the CIFAR modules may take torch's own ops -- explicit, logged,
+            # never the measured path (nn_hip.py)
+            from .. import nn_hip
+            nn_hip.allow_host_tensors(True)
+            self.logger.warning("n_gpu = 0: host plumbing mode, stock torch CPU ops (the HIP kernels are not used)")
             return torch.device('cpu')
         torch.cuda.set_device(self.local_rank)
         return torch.device('cuda', self.local_rank)
 
     def _checkpoint_state(self, epoch):
         return {'arch': type(self.model).__name__, 'epoch': epoch, 'state_dict': self.model.state_dict(),
-                'optimizer': self.optimizer.state_dict(), 'monitor_best': self.mnt_best, 'config': self.config}
+                # (a trainer without trainable parameters -- TaylorPruneTrainer over a frozen student -- has no optimizer)
+                'optimizer': self.optimizer.state_dict() if self.optimizer is not None else None,
+                'monitor_best': self.mnt_best, 'config': self.config}
 
     def _save_checkpoint(self, epoch, save_best=False):
         if self.rank != 0:   # replicas are identical; one writer
@@ -168,6 +175,6 @@ class BaseTrainer:
         self.start_epoch = checkpoint['epoch'] + 1
         self.mnt_best = checkpoint['monitor_best']
         self.model.load_state_dict(checkpoint['state_dict'])
-        if self._optimizer_matches(checkpoint):
+        if self.optimizer is not None and checkpoint.get('optimizer') is not None and self._optimizer_matches(checkpoint):
             self.optimizer.load_state_dict(checkpoint['optimizer'])
         self.logger.info("Checkpoint loaded. Resume training from epoch {}".format(self.start_epoch))

@@ -1644,7 +1644,7 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         if (eb < 0) { const char *v = getenv("KDCC_EPI_BATCH"); eb = !(v && v[0] == '0'); }
         p.epi_batch = eb;
         static int tn = -1;
-        if (tn < 0) { const char *v = getenv("KDCC_CONV_TUNE"); tn = v ? atoi(v) : 0; }
+        if (tn < 0) tn = KD_TUNING_ENV_INT("KDCC_CONV_TUNE");   // timing ablations / timestamps: tuning build only (kd_common.h)
         p.tune = tn;
     }
     // wide tiles only when they still fill the chip (one workgroup per CU, 256 CUs); e.g. the ASPP 4096->256 1x1 at
@@ -1670,6 +1670,7 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         const int tiles_m = (p.M + CF::BM - 1) / CF::BM;
         hipLaunchKernelGGL((conv_igemm_kernel<T, CF>), dim3((unsigned)(tiles_m * p.tiles_n)), dim3(64 * CF::NW), 0, s, p);
     };
+    const bool f32 = d->dtype == KD_F32;
     // 256-pixel tiles that are segments of one image row, 3x3 / stride 1 / 'same': row-buffer kernels (the narrow one is
     // compiled for <= 128 VGPRs, which the fp32 parity path's blocked accumulation does not fit)
     const bool row_geom = !norow && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == d->dil && d->W % 256 == 0;
@@ -1704,6 +1705,7 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         p.nkc = d->Cin / (CfgRow::RB / es);
         p.nk = 9 * p.nkc;
         const dim3 grid = persist_grid();
+        KD_NOTE_KERNEL((p.tune & 512) ? "conv_row_persist_kernel<dbg>" : (pp_row() && d->dil <= 32) ? "conv_row_persist_kernel<pp>" : "conv_row_persist_kernel<lockstep>");
         if (p.tune & 512) {   // phase clocks (tools/conv_timeline.py)
             if (nops == 0) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 0, true, true>), grid, dim3(512), 0, s, p);
             else if (nops == 1) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 1, true, true>), grid, dim3(512), 0, s, p);
@@ -1720,6 +1722,7 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         p.nkc = d->Cin / (CfgWide::RB / es);
         p.nk = d->kh * d->kw * p.nkc;
         const dim3 grid = persist_grid();
+        KD_NOTE_KERNEL(pp_row() ? "conv_igemm_persist_kernel<pp>" : "conv_igemm_persist_kernel<lockstep>");
         if (pp_row()) {
             if (nops == 0) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 0, true>), grid, dim3(512), 0, s, p);
             else if (nops == 1) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 1, true>), grid, dim3(512), 0, s, p);
@@ -1733,6 +1736,7 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         p.nk = 9 * p.nkc;
         p.tiles_n = (d->Cout + CfgRowH::BN - 1) / CfgRowH::BN;
         const dim3 grid((unsigned)((p.M / 256) * p.tiles_n));
+        KD_NOTE_KERNEL("conv_igemm_row_kernel<half>");
         if (row_x) hipLaunchKernelGGL((conv_igemm_row_kernel<bf16_t, CfgRowHX>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((conv_igemm_row_kernel<bf16_t, CfgRowH>), grid, dim3(256), 0, s, p);
     } else if (row_narrow && pp_row() && persist && p.vec_ok && !ep->raw_f32 && nops <= 2 && d->Cout % 128 == 0 && d->W % 512 == 0 &&
@@ -1746,6 +1750,7 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         p.tn_group = 0;
         const int nwg = p.ntiles < ncu ? p.ntiles : ncu;
         const dim3 grid((unsigned)((nwg + 7) / 8 * 8));
+        KD_NOTE_KERNEL("conv_row_pp128_kernel");
         if (p.tune & 512) hipLaunchKernelGGL((conv_row_pp128_kernel<0, true>), grid, dim3(512), 0, s, p);   // phase clocks (no-operand form only)
         else if (nops == 0) hipLaunchKernelGGL((conv_row_pp128_kernel<0>), grid, dim3(512), 0, s, p);
         else if (nops == 1) hipLaunchKernelGGL((conv_row_pp128_kernel<1>), grid, dim3(512), 0, s, p);
@@ -1755,12 +1760,16 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         p.nk = 9 * p.nkc;
         p.tiles_n = (d->Cout + (row_wide ? CfgRow::BN : CfgRowN::BN) - 1) / (row_wide ? CfgRow::BN : CfgRowN::BN);
         const dim3 grid((unsigned)((p.M / 256) * p.tiles_n));
+        KD_NOTE_KERNEL(row_narrow ? "conv_igemm_row_kernel<narrow>" : row_x ? (f32 ? "conv_igemm_row_kernel<f32,x>" : "conv_igemm_row_kernel<x>")
+                                  : (f32 ? "conv_igemm_row_kernel<f32,wide>" : "conv_igemm_row_kernel<wide>"));
         if (row_narrow) hipLaunchKernelGGL((conv_igemm_row_kernel<bf16_t, CfgRowN>), grid, dim3(512), 0, s, p);
         else if (d->dtype == KD_BF16 && row_x) hipLaunchKernelGGL((conv_igemm_row_kernel<bf16_t, CfgRowX>), grid, dim3(512), 0, s, p);
         else if (d->dtype == KD_BF16) hipLaunchKernelGGL((conv_igemm_row_kernel<bf16_t, CfgRow>), grid, dim3(512), 0, s, p);
         else if (row_x) hipLaunchKernelGGL((conv_igemm_row_kernel<float, CfgRowXF>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv_igemm_row_kernel<float, CfgRowF>), grid, dim3(512), 0, s, p);
     } else if (d->dtype == KD_BF16) {
+        KD_NOTE_KERNEL(cfg == 1 ? (half ? "conv_igemm_kernel<half>" : "conv_igemm_kernel<wide>") : cfg == 2 ? "conv_igemm_kernel<deep>"
+                                : cfg == 3 ? "conv_igemm_kernel<narrow>" : "conv_igemm_kernel<narrow2>");
         if (cfg == 1 && (p.tune & 8)) launch(CfgWideF{}, bf16_t{});   // A/B: plain main loop
         else if (cfg == 1 && half) launch(CfgHalf{}, bf16_t{});
         else if (cfg == 1) launch(CfgWide{}, bf16_t{});
@@ -1768,6 +1777,7 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         else if (cfg == 3) launch(CfgNarrow{}, bf16_t{});
         else launch(CfgNarrow2{}, bf16_t{});
     } else {
+        KD_NOTE_KERNEL(cfg == 1 ? "conv_igemm_kernel<f32,wide>" : cfg == 2 ? "conv_igemm_kernel<f32,deep>" : "conv_igemm_kernel<f32,narrow>");
         if (cfg == 1) launch(CfgWideF{}, float{});
         else if (cfg == 2) launch(CfgDeep{}, float{});
         else launch(CfgNarrow{}, float{});   // fp32 parity path: its blocked accumulation does not fit 128 VGPRs

@@ -456,6 +456,7 @@ extern "C" int kd_dwconv_fwd(const kd_dw_desc *d, const void *x, const float *w_
         else if (ts == 4 && tr == 4) KD_DW_LAUNCH(TT, KK, 4, 4); \
         else KD_DW_LAUNCH(TT, KK, 2, 8);                      \
     } while (0)
+    KD_NOTE_KERNEL(d->dtype == KD_BF16 ? "dwconv_fwd_kernel<bf16>" : "dwconv_fwd_kernel<f32>");
     if (d->dtype == KD_BF16) {
         if (d->k == 9) KD_DW_TILES(bf16_t, 9);
         else KD_DW_TILES(bf16_t, 3);
@@ -567,6 +568,7 @@ extern "C" int kd_dwconv_wgrad(const kd_dw_desc *d, const void *x, const void *d
     const int slabs = wgrad_slabs(d);
     p.nslabs = slabs;
     const dim3 grid((unsigned)(slabs * ((d->C + CB - 1) / CB) * d->k));
+    KD_NOTE_KERNEL(d->dtype == KD_BF16 ? "dwconv_wgrad_kernel<bf16>" : "dwconv_wgrad_kernel<f32>");
     if (d->dtype == KD_BF16) {
         if (d->k == 9) hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16_t, 9>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16_t, 3>), grid, dim3(256), 0, s, p);

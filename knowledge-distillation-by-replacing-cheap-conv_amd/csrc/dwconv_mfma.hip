@@ -630,7 +630,7 @@ int kd_internal_dw_mfma_fwd_n(const kd_dw_desc *d, int nb, int fan, const void *
         p.ys[b - 1] = (bf16_t *)(fan && b < nb ? ys[b] : ys[0]);
         p.ws[b - 1] = b < nb ? ws[b] : ws[0];
     }
-    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("KDCC_DW_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
+    { static int dbg = -1; if (dbg < 0) dbg = KD_TUNING_ENV_INT("KDCC_DW_DBG"); p.dbg = dbg; }   // phase ablations: tuning build only
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.dil = d->dil; p.ldx = d->ldx; p.ldy = d->ldy;
     dw_mfma_split(d->N, d->C, d->H, d->W, d->dil, &p.nty, &p.ntx, &p.nitems, &p.nseg);
     p.ncg = d->C / CG;
@@ -650,6 +650,8 @@ int kd_internal_dw_mfma_fwd_n(const kd_dw_desc *d, int nb, int fan, const void *
         }
         attr_set[fan ? 1 : 0][nb] = true;
     }
+    KD_NOTE_KERNEL(nb == 1 ? "dw_mfma_fwd_kernel<1,false>" : nb == 2 ? (fan ? "dw_mfma_fwd_kernel<2,true>" : "dw_mfma_fwd_kernel<2,false>")
+                           : (fan ? "dw_mfma_fwd_kernel<3,true>" : "dw_mfma_fwd_kernel<3,false>"));
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(NT), lds, s, p);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
@@ -709,6 +711,7 @@ int kd_internal_dw_mfma_wgrad(const kd_dw_desc *d, const void *x, const void *dy
         }
         attr_set = true;
     }
+    KD_NOTE_KERNEL("dw_mfma_wgrad_kernel");
     hipLaunchKernelGGL(dw_mfma_wgrad_kernel, dim3((unsigned)blocks), dim3(NTW), WG_LDS, s, p);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) {

@@ -606,6 +606,7 @@ extern "C" int kd_gated_conv(int32_t dtype, const void *feat, int32_t ldf, const
             const long long waves = (npix + 15) / 16;
             const int nbm = blocks_for((waves + 3) / 4 * 256, 256 * 32);   // <= 32 workgroups per CU, grid-stride over the rest
 #define KD_GCM(CC) hipLaunchKernelGGL((gated_conv_mfma_kernel<CC>), dim3(nbm), dim3(256), 0, s, (const bf16_t *)feat, ldf, (const bf16_t *)gate, ldg, params, (bf16_t *)out, ldo, (long long)npix)
+            KD_NOTE_KERNEL("gated_conv_mfma_kernel");
             if (C == 8) KD_GCM(8); else if (C == 16) KD_GCM(16); else KD_GCM(32);
 #undef KD_GCM
             KD_CHECK_LAUNCH("kd_gated_conv(mfma)");
@@ -614,6 +615,7 @@ extern "C" int kd_gated_conv(int32_t dtype, const void *feat, int32_t ldf, const
     }
     const int nb = blocks_for((npix + (C >= 32 ? 1 : 3)) / (C >= 32 ? 2 : 4), 65536);
 #define KD_GC(T, CC) hipLaunchKernelGGL((gated_conv_kernel<T, CC>), dim3(nb), dim3(256), 0, s, (const T *)feat, ldf, (const T *)gate, ldg, params, (T *)out, ldo, (long long)npix)
+    KD_NOTE_KERNEL("gated_conv_kernel");
     if (dtype == KD_BF16) { if (C == 8) KD_GC(bf16_t, 8); else if (C == 16) KD_GC(bf16_t, 16); else KD_GC(bf16_t, 32); }
     else { if (C == 8) KD_GC(float, 8); else if (C == 16) KD_GC(float, 16); else KD_GC(float, 32); }
 #undef KD_GC
@@ -729,6 +731,7 @@ extern "C" int kd_conv3x3_small(const void *x, int32_t ldx, const void *w, const
             }
             attr_set = true;
         }
+        KD_NOTE_KERNEL("conv3x3_small_kernel<64>");
         hipLaunchKernelGGL(conv3x3_small_kernel<64>, dim3((unsigned)blocks), dim3(512), lds, s, p);
     } else if (C == 32) {
         static bool attr_set = false;

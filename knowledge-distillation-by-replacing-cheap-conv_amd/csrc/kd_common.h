@@ -26,6 +26,27 @@ void kd_set_error(const char *fmt, ...);
         }                                                                         \
     } while (0)
 
+// ---- result-altering diagnostics (skip-the-epilogue timing ablations, dropped kernel phases, in-kernel timestamps) ----
+// exist only in a tuning build (`make TUNING=1` -> libkdcc_hip_tuning.so, loaded with KDCC_LIB=tuning by tools/): the default
+// library never reads them, so a stray environment variable cannot change what training computes.
+#ifdef KDCC_TUNING
+#include <stdlib.h>
+static inline int kd_tuning_env_int(const char *name)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : 0;
+}
+#define KD_TUNING_ENV_INT(name) kd_tuning_env_int(name)
+#else
+#define KD_TUNING_ENV_INT(name) 0
+#endif
+
+// ---- kernel-selection log (kd_debug_kernel_log_*: which device kernel each dispatcher picked) ------------------------
+// Host-side counters only; nothing about a launch changes.  `name` must be a string literal (entries are keyed by pointer
+// first, by text second).
+void kd_note_kernel(const char *name);
+#define KD_NOTE_KERNEL(name) kd_note_kernel(name)
+
 static inline bool kd_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int kd_elem_size(int dtype) { return dtype == KD_BF16 ? 2 : 4; }
 

@@ -533,7 +533,9 @@ extern "C" int kd_kldiv(const kd_view3 *s, const kd_view3 *t, float temperature,
     hipStream_t st = (hipStream_t)stream;
     const float gscale = grad_scale * temperature / ((float)N * (float)P);
     auto nhwc = [&](long long sN, long long sC, long long sP) { return sC == 1 && sP == C && (sN == (long long)C * P || N == 1); };
-    const bool fast = C <= 64 && nhwc(s->sN, s->sC, s->sP) && nhwc(t->sN, t->sC, t->sP) &&
+    // (the fast path stages 2 x 256 x C floats in dynamic LDS; it stays inside the 64-KiB default limit, larger class
+    // counts -- e.g. the 100-class CIFAR heads -- take the strided kernel)
+    const bool fast = (size_t)2 * 256 * C * sizeof(float) <= 65536 && nhwc(s->sN, s->sC, s->sP) && nhwc(t->sN, t->sC, t->sP) &&
                       (!grad || nhwc(grad->sN, grad->sC, grad->sP));
     if (fast) {
         const long long npix = (long long)N * P;
@@ -626,8 +628,8 @@ extern "C" int kd_ce2d(const kd_view3 *x, const int64_t *target, int32_t ignore_
     double *partial = (double *)workspace, *count = partial + MAX_BLOCKS;
     const int nb = blocks_for((long long)N * P);
     hipStream_t st = (hipStream_t)stream;
-    if (C <= 128 && x->sC == 1 && x->sP == C && (x->sN == (long long)C * P || N == 1)) {
-        const size_t lds = (size_t)256 * C * sizeof(float);
+    if ((size_t)256 * C * sizeof(float) <= 65536 && x->sC == 1 && x->sP == C && (x->sN == (long long)C * P || N == 1)) {
+        const size_t lds = (size_t)256 * C * sizeof(float);   // <= the 64-KiB default dynamic-LDS limit, else the strided kernel
         if (x->dtype == KD_F32)
             hipLaunchKernelGGL(ce2d_nhwc_kernel<float>, dim3(nb), dim3(256), lds, st, (const float *)x->ptr, target, ignore_index, C,
                                (long long)N * P, partial, count);
@@ -675,7 +677,8 @@ extern "C" int kd_confusion(const kd_view3 *x, const int64_t *target, int32_t N,
         }
     }
     const int nb = blocks_for((long long)N * P);
-    if (x->sC == 1 && x->sP == C && (x->sN == (long long)C * P || N == 1)) {
+    if ((size_t)256 * C * sizeof(float) + (size_t)C * C * sizeof(unsigned int) <= 65536 && x->sC == 1 && x->sP == C &&
+        (x->sN == (long long)C * P || N == 1)) {
         const size_t lds = (size_t)256 * C * sizeof(float) + (size_t)C * C * sizeof(unsigned int);
         if (x->dtype == KD_F32)
             hipLaunchKernelGGL(confusion_nhwc_kernel<float>, dim3(nb), dim3(256), lds, st, (const float *)x->ptr, target, C,

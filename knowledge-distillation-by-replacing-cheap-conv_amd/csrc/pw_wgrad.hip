@@ -633,6 +633,7 @@ void launch_tr(dim3 grid, hipStream_t s, const WgradParams &p)
 {
     static int nst = -1;
     if (nst < 0) { const char *e = getenv("KDCC_WGRAD_NST"); nst = e ? atoi(e) : 2; }   // A/B hook: 2 | 3 | 4 (measured: 128->128 3x3 at 512x1024 1.70 ms with 2, 2.44 with 3 or 4: occupancy beats depth)
+    KD_NOTE_KERNEL("pw_wgrad_tr_kernel");
     if (nst == 2) hipLaunchKernelGGL(pw_wgrad_tr_kernel<2>, grid, dim3(256), 0, s, p);
     else if (nst == 3) hipLaunchKernelGGL(pw_wgrad_tr_kernel<3>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(pw_wgrad_tr_kernel<4>, grid, dim3(256), 0, s, p);
@@ -712,15 +713,15 @@ extern "C" int kd_pw_wgrad(int32_t dtype, int32_t M, int32_t Cin, int32_t Cout, 
     p.a = a; p.dy = dy; p.part = (float *)workspace;
     p.M = M; p.Cin = Cin; p.Cout = Cout; p.lda = lda; p.ldy = ldy;
     p.tiles_ci = tiles_ci; p.rows_per_split = rps; p.splits = splits; p.tiles = tiles;
-    { static int wd = -1; if (wd < 0) { const char *e = getenv("KDCC_WGRAD_DBG"); wd = e ? atoi(e) : 0; } p.dbg = wd; }
+    { static int wd = -1; if (wd < 0) wd = KD_TUNING_ENV_INT("KDCC_WGRAD_DBG"); p.dbg = wd; }   // phase clocks: tuning build only
     p.geom = 0; p.kw = 1; p.H = p.W = p.Ho = p.Wo = 0; p.stride = 1; p.pad = 0; p.dil = 1;
     p.mg_howo = p.sh_howo = p.mg_wo = p.sh_wo = 0;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)tiles, (unsigned)splits);
-    if (wide) hipLaunchKernelGGL(conv_wgrad_wide_kernel, grid, dim3(512), 0, s, p);
+    if (wide) { KD_NOTE_KERNEL("conv_wgrad_wide_kernel"); hipLaunchKernelGGL(conv_wgrad_wide_kernel, grid, dim3(512), 0, s, p); }
     else if (dtype == KD_BF16 && Cin % 8 == 0 && Cout % 8 == 0) launch_tr(grid, s, p);
-    else if (dtype == KD_BF16) hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(pw_wgrad_kernel<float>, grid, dim3(256), 0, s, p);
+    else if (dtype == KD_BF16) { KD_NOTE_KERNEL("pw_wgrad_kernel<bf16>"); hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, p); }
+    else { KD_NOTE_KERNEL("pw_wgrad_kernel<f32>"); hipLaunchKernelGGL(pw_wgrad_kernel<float>, grid, dim3(256), 0, s, p); }
     KD_CHECK_LAUNCH("kd_pw_wgrad");
     launch_slab_reduce((const float *)workspace, dw, (size_t)Cout * Cin, splits, accumulate, s);
     KD_CHECK_LAUNCH("kd_pw_wgrad(reduce)");
@@ -805,7 +806,7 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
     p.a = x; p.dy = dy; p.part = (float *)workspace;
     p.M = (int)M; p.Cin = d->Cin; p.Cout = d->Cout; p.lda = d->ldx; p.ldy = ld_dy;
     p.tiles_ci = tiles_ci; p.rows_per_split = rps; p.splits = splits; p.tiles = tiles;
-    { static int wd = -1; if (wd < 0) { const char *e = getenv("KDCC_WGRAD_DBG"); wd = e ? atoi(e) : 0; } p.dbg = wd; }
+    { static int wd = -1; if (wd < 0) wd = KD_TUNING_ENV_INT("KDCC_WGRAD_DBG"); p.dbg = wd; }   // phase clocks: tuning build only
     p.geom = !(taps == 1 && d->stride == 1 && d->pad == 0);
     p.H = d->H; p.W = d->W; p.Ho = d->Ho; p.Wo = d->Wo; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     fastdiv_magic((uint32_t)(d->Ho * d->Wo), p.mg_howo, p.sh_howo);
@@ -816,11 +817,12 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
         fastdiv_magic((uint32_t)(d->H * d->W), p.mg_howo, p.sh_howo);
         fastdiv_magic((uint32_t)d->W, p.mg_wo, p.sh_wo);
         p.tiles = tiles;
+        KD_NOTE_KERNEL("conv_wgrad_row_kernel");
         hipLaunchKernelGGL(conv_wgrad_row_kernel, dim3((unsigned)(tiles * splits * 3)), dim3(512), 0, s, p);
-    } else if (wide) hipLaunchKernelGGL(conv_wgrad_wide_kernel, grid, dim3(512), 0, s, p);
+    } else if (wide) { KD_NOTE_KERNEL("conv_wgrad_wide_kernel"); hipLaunchKernelGGL(conv_wgrad_wide_kernel, grid, dim3(512), 0, s, p); }
     else if (d->dtype == KD_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0) launch_tr(grid, s, p);
-    else if (d->dtype == KD_BF16) hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(pw_wgrad_kernel<float>, grid, dim3(256), 0, s, p);
+    else if (d->dtype == KD_BF16) { KD_NOTE_KERNEL("pw_wgrad_kernel<bf16>"); hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, p); }
+    else { KD_NOTE_KERNEL("pw_wgrad_kernel<f32>"); hipLaunchKernelGGL(pw_wgrad_kernel<float>, grid, dim3(256), 0, s, p); }
     KD_CHECK_LAUNCH("kd_conv2d_wgrad");
     const size_t n = (size_t)d->Cout * d->Cin * taps;
     const int rb = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);

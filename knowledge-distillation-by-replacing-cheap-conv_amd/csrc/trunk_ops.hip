@@ -2,6 +2,7 @@
 // bilinear align_corners upsample, ASPP image pooling, BN folding, strided copy/cast.
 // Also hosts the error plumbing of the C-ABI.
 #include <stdarg.h>
+#include <pthread.h>
 #include <string.h>
 
 #include <type_traits>
@@ -20,6 +21,59 @@ void kd_set_error(const char *fmt, ...)
 
 extern "C" int kd_version(void) { return 100; }
 extern "C" const char *kd_last_error(void) { return g_err; }
+
+// ---- kernel-selection log ---------------------------------------------------------------------------------------
+// Host-side counters of which device kernel each dispatcher launched (tests assert that a shape reaches the kernel it is
+// meant to cover; bench.py attributes event time to kernel classes).  Off by default: one relaxed load per launch.
+namespace {
+struct KernelLogEntry { const char *name; long long count; };
+constexpr int KLOG_MAX = 128;
+KernelLogEntry g_klog[KLOG_MAX];
+int g_klog_n = 0;
+volatile int g_klog_on = 0;
+pthread_mutex_t g_klog_mu = PTHREAD_MUTEX_INITIALIZER;
+thread_local const char *g_klog_last = "";
+}  // namespace
+
+void kd_note_kernel(const char *name)
+{
+    g_klog_last = name;
+    if (!g_klog_on) return;
+    pthread_mutex_lock(&g_klog_mu);
+    int i = 0;
+    for (; i < g_klog_n; ++i)
+        if (g_klog[i].name == name || !strcmp(g_klog[i].name, name)) break;
+    if (i == g_klog_n && g_klog_n < KLOG_MAX) g_klog[g_klog_n++] = KernelLogEntry{name, 0};
+    if (i < g_klog_n) ++g_klog[i].count;
+    pthread_mutex_unlock(&g_klog_mu);
+}
+
+extern "C" int kd_debug_kernel_log_enable(int32_t on)
+{
+    pthread_mutex_lock(&g_klog_mu);
+    g_klog_on = on ? 1 : 0;
+    if (on) g_klog_n = 0;   // enabling starts a fresh log
+    pthread_mutex_unlock(&g_klog_mu);
+    return KD_OK;
+}
+
+extern "C" const char *kd_debug_last_kernel(void) { return g_klog_last; }
+
+extern "C" int64_t kd_debug_kernel_log_read(char *buf, size_t bytes)
+{
+    // "name\tcount\n" per kernel seen since the log was enabled; returns the bytes needed (excluding the terminator)
+    pthread_mutex_lock(&g_klog_mu);
+    size_t need = 0;
+    for (int i = 0; i < g_klog_n; ++i) {
+        char line[256];
+        const int n = snprintf(line, sizeof(line), "%s\t%lld\n", g_klog[i].name, g_klog[i].count);
+        if (buf && need + (size_t)n < bytes) memcpy(buf + need, line, (size_t)n);
+        need += (size_t)n;
+    }
+    if (buf && bytes) buf[need < bytes ? need : bytes - 1] = 0;
+    pthread_mutex_unlock(&g_klog_mu);
+    return (int64_t)need;
+}
 
 namespace {
 
@@ -513,8 +567,10 @@ extern "C" int kd_stem_conv(int32_t dtype, const float *x_nchw, const float *w, 
         const long long ngroups = (long long)N * H * gpr;
         const long long want = (ngroups + 3) / 4;
         const unsigned blocks = (unsigned)(want < 256 * 16 ? want : 256 * 16);   // persistent-ish: 16 workgroups per CU
+        KD_NOTE_KERNEL("stem_conv_mfma_kernel");
         hipLaunchKernelGGL(stem_conv_mfma_kernel, dim3(blocks), dim3(256), 0, s, x_nchw, w, (bf16_t *)y, N, H, W, gpr);
     } else {
+        KD_NOTE_KERNEL("stem_conv_kernel<f32>");
         hipLaunchKernelGGL(stem_conv_kernel<float>, grid, dim3(256), 0, s, x_nchw, w, (float *)y, N, H, W);
     }
     KD_CHECK_LAUNCH("kd_stem_conv");
@@ -532,6 +588,7 @@ extern "C" int kd_stem_conv_pool(const float *x_nchw, const float *w, void *y_ra
     const int ngx = (Wo + SP_COLS - 1) / SP_COLS, nseg = (Ho + SP_ROWS - 1) / SP_ROWS;
     const long long waves = (long long)N * ngx * nseg;
     KD_REQUIRE((waves + 3) / 4 <= 0x7fffffffLL, KD_ERR_UNSUPPORTED, "kd_stem_conv_pool: image too large");
+    KD_NOTE_KERNEL("stem_pool_kernel");
     hipLaunchKernelGGL(stem_pool_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x_nchw, w,
                        (bf16_t *)y_raw, (bf16_t *)y_act, scale, shift, N, H, W, Ho, Wo, ngx, nseg);
     KD_CHECK_LAUNCH("kd_stem_conv_pool");

@@ -3,14 +3,34 @@ kd_conv2d_direct_*, kd_bn2d_*) when the tensors live on the GPU.  Same construct
 keys as the torch classes, so checkpoints, forward hooks (hint layers) and DepthwiseStudent's module surgery are untouched.
 Used by the CIFAR plumbing config (models/cifar_models): with them a ClassificationTrainer step issues no MIOpen kernel.
 
-Host tensors (n_gpu = 0 runs of the reference's CPU configs, and the CPU-only host-logic tests) take torch's own ops:
-nothing on a GPU run falls back -- a device tensor either goes through the kernels or raises.
+There is no silent fallback: a device tensor either goes through the kernels or raises, and a HOST tensor raises too unless
+host plumbing mode was switched on explicitly (`allow_host_tensors(True)`: BaseTrainer does it for `n_gpu: 0` configs -- the
+reference's CPU plumbing case, BASELINE config 1 -- and the CPU-only host-logic tests do it themselves).  In that mode the
+modules behave exactly like their torch base classes; it is never the measured or parity-tested path.
 """
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 from . import ops
+from ._lib import KdccError
+
+_HOST_OK = False
+
+
+def allow_host_tensors(on=True):
+    """Host plumbing mode (n_gpu = 0): Conv2d / BatchNorm2d given host tensors run their torch base class.  Off by default."""
+    global _HOST_OK
+    _HOST_OK = bool(on)
+
+
+def _host(x):
+    if x.is_cuda:
+        return False
+    if not _HOST_OK:
+        raise KdccError("kdcc nn_hip modules got a host tensor: the HIP kernels need device tensors and there is no silent CPU "
+                        "fallback (host plumbing runs, `n_gpu: 0`, call nn_hip.allow_host_tensors(True) -- BaseTrainer does)")
+    return True
 
 
 class _DirectConv(torch.autograd.Function):
@@ -36,7 +56,7 @@ class _DirectConv(torch.autograd.Function):
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
     """F.conv2d on the direct HIP kernels (device fp32 NCHW) / torch (host tensors)."""
-    if not x.is_cuda:
+    if _host(x):
         return F.conv2d(x, weight, bias, stride, padding, dilation, groups)
     if x.dtype != torch.float32:
         raise TypeError("the small-shape conv kernels are fp32 (the CIFAR path of the reference is fp32)")
@@ -65,7 +85,7 @@ class _BatchNorm(torch.autograd.Function):
 
 class Conv2d(nn.Conv2d):
     def forward(self, x):
-        if not x.is_cuda:
+        if _host(x):
             return super().forward(x)
         if self.padding_mode != "zeros" or isinstance(self.padding, str) or len({*self.stride}) != 1 or len({*self.padding}) != 1 \
                 or len({*self.dilation}) != 1:
@@ -75,7 +95,7 @@ class Conv2d(nn.Conv2d):
 
 class BatchNorm2d(nn.BatchNorm2d):
     def forward(self, x, relu=False):
-        if not x.is_cuda:
+        if _host(x):
             y = super().forward(x)
             return F.relu(y) if relu else y
         if not (self.affine and self.track_running_stats) or self.momentum is None:

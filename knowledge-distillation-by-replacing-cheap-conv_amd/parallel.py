@@ -131,6 +131,15 @@ def mean_scalar(value):
     return float(t.item()) / dist.get_world_size()
 
 
+def barrier():
+    """All ranks meet (no-op without a process group)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
+
+
 def broadcast_object(obj, src=0):
     """Rank `src`'s picklable object on every rank (e.g. the run id that names the checkpoint directory)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -54,13 +54,18 @@ class ConfigParser:
         root = Path(config['trainer']['save_dir'])
         self._save_dir = root / 'models' / config['name'] / run_id
         self._log_dir = root / 'log' / config['name'] / run_id
-        # a fresh timestamped run must not reuse a directory; an explicit run_id ('' included) may, and so may the
-        # non-zero ranks of a distributed run (rank 0 owns the directory)
-        may_exist = (not fresh and run_id == '') or rank != 0
-        for d in (self._save_dir, self._log_dir):
-            d.mkdir(parents=True, exist_ok=may_exist)
+        # a fresh timestamped run must not reuse a directory; an explicit run_id ('' included) may.  Rank 0 owns the run
+        # directory: it creates both directories and writes config.json FIRST, the other ranks wait at the barrier and only
+        # then make sure the directories exist (without that order a non-zero rank's mkdir could win the race and rank 0's
+        # exist_ok=False would kill the job)
         if rank == 0:
+            for d in (self._save_dir, self._log_dir):
+                d.mkdir(parents=True, exist_ok=not fresh and run_id == '')
             write_json(config, self._save_dir / 'config.json')
+        parallel.barrier()
+        if rank != 0:
+            for d in (self._save_dir, self._log_dir):
+                d.mkdir(parents=True, exist_ok=True)
         setup_logging(self._log_dir)
 
     # ------------------------------------------------------------------ construction from the command line

@@ -89,4 +89,5 @@ class ClassificationTrainer(LayerwiseTrainer):
                 for met in self.metric_ftns:
                     self.valid_metrics.update(met.__name__, met(output_st, target), data.shape[0])
                     self.valid_metrics.update('teacher_' + met.__name__, met(output_tc, target), data.shape[0])
+        self.valid_metrics.flush()   # buffered device scalars -> TensorBoard
         return self.valid_metrics.result()

@@ -281,6 +281,7 @@ class LayerwiseTrainer(BaseTrainer):
                 self.valid_iou_metrics.update(output, target)
                 for met in self.metric_ftns:
                     self.valid_metrics.update(met.__name__, met(output, target))
+        self.valid_metrics.flush()   # buffered device scalars -> TensorBoard (the reference writes them every step)
         result = self.valid_metrics.result()
         result['mIoU'] = self.valid_iou_metrics.get_iou()
         return result

@@ -40,6 +40,41 @@ def test_no_cpu_fallback(built):
         losses.MSELoss(num_classes=1000)(torch.zeros(1, 4, 2, 2, requires_grad=True), torch.zeros(1, 4, 2, 2))
 
 
+def test_nn_hip_refuses_host_tensors_unless_told(built):
+    """nn_hip.Conv2d / BatchNorm2d (CIFAR config) raise on host tensors; only the explicit host plumbing mode (n_gpu: 0) may
+    run torch's own ops."""
+    from kdcc_amd import nn_hip
+    from kdcc_amd._lib import KdccError
+    conv, bn = nn_hip.Conv2d(3, 4, 3, padding=1), nn_hip.BatchNorm2d(4)
+    x = torch.zeros(1, 3, 8, 8)
+    nn_hip.allow_host_tensors(False)
+    with pytest.raises(KdccError):
+        conv(x)
+    with pytest.raises(KdccError):
+        bn(torch.zeros(1, 4, 8, 8))
+    nn_hip.allow_host_tensors(True)
+    try:
+        assert tuple(bn(conv(x)).shape) == (1, 4, 8, 8)
+    finally:
+        nn_hip.allow_host_tensors(False)
+
+
+def test_default_library_ignores_the_tuning_switches(built):
+    """KDCC_CONV_TUNE / KDCC_DW_DBG / KDCC_WGRAD_DBG (timing ablations that alter results) are compiled out of the default
+    build: the strings are not even in the library; they exist in libkdcc_hip_tuning.so only (make TUNING=1)."""
+    from kdcc_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"KDCC_CONV_TUNE", b"KDCC_DW_DBG", b"KDCC_WGRAD_DBG"):
+        assert name not in blob, f"{name.decode()} is read by the default library"
+
+
+def test_kernel_log_api(built):
+    from kdcc_amd import _lib
+    with _lib.kernel_log() as log:
+        pass
+    assert log.counts == {} and _lib.last_kernel() == ""
+
+
 def test_missing_library_is_loud(built, monkeypatch):
     from kdcc_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

@@ -5,8 +5,10 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import kdcc_amd
-if os.environ.get("KDCC_LIB"):   # A/B against another build of the library (same ABI)
-    kdcc_amd._lib.LIB_PATH = os.environ["KDCC_LIB"]
+# KDCC_LIB=/path/to/other.so: A/B against another build of the library (same ABI); KDCC_LIB=tuning + KDCC_DW_DBG=bits: the
+# phase ablations of the diagnostics build (kdcc_amd/_lib.py)
+if os.environ.get("KDCC_LIB") == "tuning":
+    kdcc_amd._lib.build_tuning()
 from kdcc_amd import ops
 
 def t(fn, it=10):

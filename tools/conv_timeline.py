@@ -2,11 +2,14 @@
 """Per-tile timeline of the persistent conv kernels (KDCC_CONV_TUNE=512 timestamps, debug only; GPU box)."""
 import os, sys, ctypes as C
 os.environ["KDCC_CONV_TUNE"] = os.environ.get("KDCC_CONV_TUNE", "512")
+os.environ["KDCC_LIB"] = "tuning"   # the timestamps exist only in the diagnostics build (make -C csrc TUNING=1)
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import kdcc_amd
-from kdcc_amd import ops, _lib
+from kdcc_amd import _lib
+_lib.build_tuning()
+from kdcc_amd import ops
 
 def run(name, H, W, Cin, Cout, k, d, NB=4, res=False):
     dt = torch.bfloat16

@@ -3,10 +3,13 @@
 at the barrier, issuing the next stage's DMA, and in the fragment reads + MFMAs."""
 import os, sys, ctypes as C
 os.environ["KDCC_WGRAD_DBG"] = "1"
+os.environ["KDCC_LIB"] = "tuning"   # the timestamps exist only in the diagnostics build (make -C csrc TUNING=1)
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import kdcc_amd
-from kdcc_amd import ops, _lib
+from kdcc_amd import _lib
+_lib.build_tuning()
+from kdcc_amd import ops
 
 for (N, H, W, Ci, Co, d) in [(4, 512, 1024, 128, 128, 1), (4, 128, 256, 512, 512, 1), (4, 256, 512, 256, 256, 1)]:
     x = torch.randn((N, H, W, Ci), device="cuda").to(torch.bfloat16)
