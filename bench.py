@@ -37,7 +37,7 @@ PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md chip-level ta
 PEAK_F32_TFLOPS = 157.3
 
 
-def build(plan, dtype, device, seed=123, mode="A", arch="deeplab"):
+def build(plan, dtype, device, seed=123, mode="A", arch="deeplab", hint_loss="mse"):
     import kdcc_amd
     from kdcc_amd import losses
     from kdcc_amd.models import GSCNN, DeepWV3Plus
@@ -54,19 +54,34 @@ def build(plan, dtype, device, seed=123, mode="A", arch="deeplab"):
     if mode == "B":   # SURVEY 8(d) mode B: every student parameter trainable (dense convs, eval-mode BN affine, stem)
         for p in model.student.parameters():
             p.requires_grad = True
-    crit = [losses.CrossEntropyLoss2d(ignore_index=255), losses.KLDivergenceLoss(1), losses.MSELoss(num_classes=1000)]
+    crit = [losses.CrossEntropyLoss2d(ignore_index=255), losses.KLDivergenceLoss(1),
+            losses.WeightedHintMSELoss() if hint_loss == "weighted" else losses.MSELoss(num_classes=1000)]
     opt = RAdam([p for p in model.student.parameters() if p.requires_grad], lr=0.005)
     return model, crit, opt, cpu_sd
 
 
+_FW = {}
+
+
+def _filter_weight(i, channels, device):
+    """BASELINE config 4 / SURVEY 8(d): filter_weight = rand(C) per hint, generator seed 7 + hint index (what
+    trainer.hint_filter_weight = 'rand:7' gives LayerwiseTrainer)."""
+    key = (i, channels, str(device))
+    if key not in _FW:
+        _FW[key] = torch.rand(channels, generator=torch.Generator().manual_seed(7 + i)).to(device)
+    return _FW[key]
+
+
 def kd_step(model, crit, opt, data, target, mode="A"):
+    from kdcc_amd.losses import WeightedHintMSELoss
     out_st, out_tc = model(data)
     sup = crit[0](out_st, target)
     kd = crit[1](out_st, out_tc)
     tl = crit[0](out_tc, target)
     hint = 0
-    for s, t in zip(model.student_hidden_outputs, model.teacher_hidden_outputs):
-        hint = hint + crit[2](s, t)
+    weighted = isinstance(crit[2], WeightedHintMSELoss)
+    for i, (s, t) in enumerate(zip(model.student_hidden_outputs, model.teacher_hidden_outputs)):
+        hint = hint + (crit[2](s, t, _filter_weight(i, s.shape[1], s.device)) if weighted else crit[2](s, t))
     loss = hint                      # "Only use hint loss", layerwise_trainer.py:233-235
     if mode == "B":
         loss = kd + hint             # north-star mode: the KD term is back-propagated too (classification_trainer.py:37)
@@ -104,18 +119,18 @@ def cpu_share():
     return n if n <= 32 else 16
 
 
-def cpu_baseline(cpu_sd, model, plan, full=False):
+def cpu_baseline(cpu_sd, model, plan, full="step"):
     """The network-level oracle (stock torch CPU ops, fp32) timed on this box's host cores.
 
-    Default: a BOUNDED sample -- one 512x1024 step (a quarter of the pixels, ~15-30 s), scaled by pixel count -- so that the
-    default bench run finishes in minutes.  full=True (--cpu-baseline full) is BASELINE.md section 3's recipe: 1 warm-up +
-    2 timed steps at 1024x2048 (~1-2 min each) plus 5 timed steps at 256x512 for the linear-in-pixels check."""
+    Default ("step"): a small warm-up, the bounded 512x1024 sample, then ONE REAL 1024x2048 KD step, timed; `value` is that
+    measured full-size step (nothing is extrapolated), the 512x1024 sample is reported beside it.  "sample": the 512x1024
+    step only (value = its pixel fraction / time; for quick local runs).  "full" (--cpu-baseline full): BASELINE.md
+    section 3's recipe, 1 warm-up + 2 timed steps at 1024x2048 plus 5 timed steps at 256x512."""
     from oracle import net_ref
     threads = cpu_share()
     torch.set_num_threads(threads)
-    hw = (1024, 2048) if full else (512, 1024)
-    print(f"[bench] cpu_baseline: oracle/net_ref.py on {threads} host threads (os.cpu_count() = {os.cpu_count()}), "
-          f"{'1 warm-up + 2 timed' if full else 'one'} {hw[0]}x{hw[1]} step(s) ...", file=sys.stderr, flush=True)
+    print(f"[bench] cpu_baseline ({full}): oracle/net_ref.py on {threads} host threads (os.cpu_count() = {os.cpu_count()}) ...",
+          file=sys.stderr, flush=True)
     new = {}
     for n in plan:
         blk = model.get_block(n, model.student)
@@ -123,98 +138,120 @@ def cpu_baseline(cpu_sd, model, plan, full=False):
         new[f"{n}.pointwise_conv.weight"] = blk.pointwise_conv.weight.detach().float().cpu()
     ssd = net_ref.make_student_sd(cpu_sd, plan, new)
     g = torch.Generator().manual_seed(1000)
-    x = torch.randn((1, 3) + hw, generator=g)
-    tgt = torch.randint(0, 19, (1,) + hw, generator=g)
-    def timed(xx, tt, reps):
+    x = torch.randn((1, 3, 1024, 2048), generator=g)
+    tgt = torch.randint(0, 19, (1, 1024, 2048), generator=g)
+
+    def timed(h, w, reps):
+        xx, tt = x[:, :, :h, :w].contiguous(), tgt[:, :h, :w].contiguous()
         ts = []
         for _ in range(reps):
             t0 = time.perf_counter()
             net_ref.kd_step(cpu_sd, ssd, xx, tt, plan)
             ts.append(time.perf_counter() - t0)
-            print(f"[bench] cpu_baseline: {tuple(xx.shape[2:])} step {ts[-1]:.2f} s", file=sys.stderr, flush=True)
+            print(f"[bench] cpu_baseline: {h}x{w} step {ts[-1]:.2f} s", file=sys.stderr, flush=True)
         return ts
 
-    if full:
-        timed(x, tgt, 1)                                   # warm-up at full size
-        ts = timed(x, tgt, 2)
-        small = timed(x[:, :, :256, :512].contiguous(), tgt[:, :256, :512].contiguous(), 5)
+    base = {"unit": "images/sec", "cores": threads, "host_cpu_count": os.cpu_count(), "kind": "port"}
+    what = "KD step (teacher fwd + student fwd + hint bwd, fp32 torch CPU ops = oracle/net_ref.py)"
+    if full == "full":
+        timed(1024, 2048, 1)                               # warm-up at full size
+        ts = timed(1024, 2048, 2)
+        small = timed(256, 512, 5)
         dt = sum(ts) / len(ts)
-        return {"value": 1.0 / dt, "unit": "images/sec", "cores": threads, "host_cpu_count": os.cpu_count(), "kind": "port",
-                "sample": f"BASELINE.md section 3: 1 warm-up + 2 timed KD steps (teacher fwd + student fwd + hint bwd, fp32 torch "
-                          f"CPU ops = oracle/net_ref.py) at 1024x2048, {ts[0]:.1f} / {ts[1]:.1f} s; 5 steps at 256x512: "
-                          f"{sum(small) / len(small):.2f} s mean = {16 * sum(small) / len(small):.1f} s per full-size image equivalent",
-                "steps_s": ts, "steps_256x512_s": small}
-    net_ref.kd_step(cpu_sd, ssd, x[:, :, :64, :128].contiguous(), tgt[:, :64, :128].contiguous(), plan)  # warm-up
-    dt = timed(x, tgt, 1)[0]
-    frac = (hw[0] * hw[1]) / (1024.0 * 2048.0)
-    return {"value": frac / dt, "unit": "images/sec", "cores": threads, "host_cpu_count": os.cpu_count(), "kind": "port",
-            "sample": f"bounded sample (the bench must finish in minutes; --cpu-baseline full runs BASELINE.md section 3's 1+2 "
-                      f"full-size steps): 1 KD step (teacher fwd + student fwd + hint bwd, fp32 torch CPU ops = "
-                      f"oracle/net_ref.py) at {hw[0]}x{hw[1]} = {frac:.4f} of a 1024x2048 image, {dt:.2f} s; value = that "
-                      f"fraction / time (measured linear in pixels from this size up: 54.8 s extrapolated vs 56-58 s per full-size step, DESIGN.md section 5)"}
+        return dict(base, value=1.0 / dt, steps_s=ts, steps_256x512_s=small,
+                    sample=f"BASELINE.md section 3: 1 warm-up + 2 timed {what} at 1024x2048, {ts[0]:.1f} / {ts[1]:.1f} s; 5 steps at "
+                           f"256x512: {sum(small) / len(small):.2f} s mean")
+    timed(64, 128, 1)                                      # warm-up (thread pool, allocator)
+    half = timed(512, 1024, 1)[0]
+    if full == "sample":
+        return dict(base, value=0.25 / half,
+                    sample=f"bounded sample: 1 {what} at 512x1024 = a quarter of a 1024x2048 image, {half:.2f} s; value = 0.25 / time")
+    one = timed(1024, 2048, 1)[0]
+    return dict(base, value=1.0 / one, step_1024x2048_s=one, step_512x1024_s=half,
+                sample=f"one measured {what} at the full 1024x2048, 1 image: {one:.1f} s (after a 64x128 warm-up and one 512x1024 "
+                       f"step, {half:.2f} s = {0.25 / half:.4f} img/s pixel-scaled, reported beside it); value = 1 / that step, "
+                       f"nothing extrapolated")
 
 
-def conv_traffic(plan, batch, height, width, dtype):
-    """HBM bytes per conv_igemm launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate
-    passes, same command); None when the profiled configuration is not the one being run."""
-    path = os.path.join(ROOT, "profiles", "r02_traffic_pmc.json")
-    if not (plan == "P92" and batch == 4 and (height, width) == (1024, 2048) and dtype == "bf16" and os.path.exists(path)):
-        return None
+def _latest_profile(suffix):
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{suffix}")))
+    return c[-1] if c else None
+
+
+def conv_traffic(plan, batch, height, width, dtype, mode, arch):
+    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE in separate passes,
+    same command); None when the profiled configuration is not the one being run."""
+    path = _latest_profile("traffic_pmc.json")
+    if not (plan == "P92" and batch == 4 and (height, width) == (1024, 2048) and dtype == "bf16" and mode == "A" and arch == "deeplab" and path):
+        return None, None
     try:
         with open(path) as f:
-            return float(json.load(f)["kernels"]["conv_igemm"]["hbm_bytes_per_launch"])
+            return float(json.load(f)["kernels"]["conv_igemm"]["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
     except (KeyError, ValueError, OSError):
-        return None
+        return None, None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--plan", default="P92", choices=sorted(PLANS))
-    ap.add_argument("--arch", default="deeplab", choices=["deeplab", "gscnn"],
-                    help="deeplab: DeepLabV3+(WRN-38), the headline (BASELINE configs 2-4); gscnn: Gated-SCNN teacher/student "
-                         "(BASELINE config 5; use --plan P86, the shipped 51M_gscnn_all.json plan; mode A only)")
-    ap.add_argument("--mode", default="A", choices=["A", "B"],
-                    help="A (default, reference-faithful): loss = hint loss, only the cheap-conv blocks train; B (SURVEY 8d "
-                         "north-star mode): loss = KLDiv + hint, every student parameter trainable (37.74 TFLOP/img for P92)")
-    ap.add_argument("--batch", type=int, default=4, help="images per GPU (4 by default: +6 %% img/s over 1, +2 %% over 2 from fuller grids)")
-    ap.add_argument("--height", type=int, default=1024)
-    ap.add_argument("--width", type=int, default=2048)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full"],
-                    help="sample: one 512x1024 CPU step scaled by pixels (default, bounded); full: BASELINE.md section 3 "
-                         "(1 warm-up + 2 steps at 1024x2048 + 5 steps at 256x512; several minutes)")
-    ap.add_argument("--layer-table", default=None, help="write a per-conv-shape timing table (tsv) to this path")
-    ap.add_argument("--no-batch-sweep", action="store_true", help="skip the 1 and 2 images/GPU side measurements")
-    ap.add_argument("--no-overlap", action="store_true", help="with --teacher torch: run the teacher on the main stream")
-    ap.add_argument("--ref-logging", action="store_true",
-                    help="also do the reference's per-step host syncs (five .item() calls, layerwise_trainer.py:244-250); the "
-                         "default measures the step without them, as this trainer runs it (metrics stay on the device)")
-    ap.add_argument("--teacher-stream", default="main", choices=["main", "side"],
-                    help="with --teacher hip: run the engine teacher on a side HIP stream concurrently with the student forward")
-    ap.add_argument("--share-prefix", action="store_true",
-                    help="opt-in: compute the frozen layers the student shares bit for bit with the teacher once per step "
-                         "(stem .. the block before the first cheap conv); same numbers, ~8 %% fewer FLOPs than the reference's "
-                         "two full forwards -- NOT the headline configuration")
-    ap.add_argument("--teacher", default="hip", choices=["torch", "hip"],
-                    help="hip: frozen teacher graph through the engine's HIP kernels (default); torch: teacher as a PyTorch-ROCm "
-                         "module (MIOpen) on a side stream, the split north_star describes")
-    a = ap.parse_args()
+PEAK_HBM_GBS = 8000.0       # HBM3E, MI355X_MICROARCH.md
 
-    import kdcc_amd
+# device kernel (kernel-selection log) -> roofline class
+CONV_CLASSES = (("conv_row_persist_kernel", "conv3x3_row_persistent_256x256"), ("conv_igemm_persist_kernel", "conv1x1_persistent_256x256"),
+                ("conv_row_pp128_kernel", "conv3x3_row_512x128"))
+
+
+def _classify(rec):
+    fam, kern, label = rec[0], (rec[5] if len(rec) > 5 else ""), rec[4]
+    if fam == "conv_igemm":
+        for prefix, name in CONV_CLASSES:
+            if kern.startswith(prefix):
+                return name
+        return "conv_other_tiles"
+    if fam == "conv_wgrad":
+        return "dense_wgrad"
+    if fam == "pw_wgrad":
+        return "pointwise_wgrad"
+    if fam == "depthwise":
+        if "wgrad" in label:
+            return "depthwise_wgrad"
+        if "fan-out" in label:
+            return "depthwise_fwd_fanout"
+        if "sum of" in label:
+            return "depthwise_dgrad_sum"
+        return "depthwise_dgrad_epilogue" if "+epi" in label else "depthwise_fwd"
+    return "losses"
+
+
+def class_rooflines(prof, steps, peak_tflops):
+    """Per kernel class: live HIP-event time per step, launches per step, achieved rate and fraction of the roof that bounds
+    it (MFMA classes: algorithmic FLOP / time / dense bf16 peak; HBM classes: algorithmic bytes / time / 8 TB/s)."""
+    agg = {}
+    for rec in prof:
+        e = agg.setdefault(_classify(rec), [0, 0.0, 0.0, rec[0]])
+        e[0] += 1
+        e[1] += rec[2].elapsed_time(rec[3])
+        e[2] += rec[1]
+    out = {}
+    for name, (cnt, ms, work, fam) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        if ms <= 0:
+            continue
+        hbm = fam in ("depthwise", "loss")
+        rate = work / (ms * 1e-3) / (1e9 if hbm else 1e12)
+        out[name] = {"bound": "hbm" if hbm else "mfma", "launches_per_step": cnt / steps, "ms_per_step": ms / steps,
+                     "achieved": rate, "unit": "GB/s" if hbm else "TFLOP/s", "peak": PEAK_HBM_GBS if hbm else peak_tflops,
+                     "frac": rate / (PEAK_HBM_GBS if hbm else peak_tflops),
+                     ("algorithmic_gb_per_step" if hbm else "algorithmic_tflop_per_step"): work / steps / (1e9 if hbm else 1e12)}
+    return out
+
+
+def run_config(a, device, rank, world, plan_name=None, mode=None, arch=None, hint_loss="mse", steps=None, warmup=None,
+               batch_sweep=True):
+    """Build one configuration, run `warmup` untimed + `steps` timed KD train steps, return (record, model, cpu_sd, plan)."""
     from kdcc_amd import ops, parallel
-    rank, local, world = parallel.init_distributed()
-    if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
-    device = torch.device("cuda", local)
+    plan_name, mode, arch = plan_name or a.plan, mode or a.mode, arch or a.arch
+    steps, warmup = steps or a.steps, a.warmup if warmup is None else warmup
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    plan = PLANS[a.plan]
-    model, crit, opt, cpu_sd = build(plan, dtype, device, mode=a.mode, arch=a.arch)
+    plan = PLANS[plan_name]
+    model, crit, opt, cpu_sd = build(plan, dtype, device, mode=mode, arch=arch, hint_loss=hint_loss)
     model.overlap_teacher = not a.no_overlap
     model.teacher_backend = a.teacher
     model.hip_teacher_side_stream = a.teacher_stream == "side"
@@ -234,31 +271,31 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        kd_step(model, crit, opt, data, target, a.mode)
+    for _ in range(warmup):
+        kd_step(model, crit, opt, data, target, mode)
     sync()
     prof = []
     ops.PROFILER = prof
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss, sup, kd, tl = kd_step(model, crit, opt, data, target, a.mode)
+    for _ in range(steps):
+        loss, sup, kd, tl = kd_step(model, crit, opt, data, target, mode)
         if a.ref_logging:
             _ = (loss.item(), sup.item(), kd.item(), loss.item(), tl.item())
     sync()
     dt = time.perf_counter() - t0
     ops.PROFILER = None
-    if a.layer_table and rank == 0:
+    if a.layer_table and rank == 0 and batch_sweep:
         # per conv shape: launches per step, mean duration, TFLOP/s (live HIP events, same records as the roofline)
         agg = {}
         for p in prof:
-            if len(p) > 4:
-                e = agg.setdefault(p[4], [0, 0.0, p[1]])
+            if p[0] in ("conv_igemm", "conv_wgrad", "pw_wgrad", "depthwise"):
+                e = agg.setdefault((p[4], p[5]), [0, 0.0, p[1], p[0]])
                 e[0] += 1
                 e[1] += p[2].elapsed_time(p[3])
         with open(a.layer_table, "w") as f:
-            f.write("shape\tlaunches_per_step\tavg_ms\tTFLOP/s\tms_per_step\n")
-            for k, (cnt, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                f.write(f"{k}\t{cnt / a.steps:g}\t{ms / cnt:.4f}\t{fl * cnt / ms / 1e9:.0f}\t{ms / a.steps:.3f}\n")
+            f.write("shape\tkernel\tlaunches_per_step\tavg_ms\tTFLOP/s|GB/s\tms_per_step\n")
+            for (k, kern), (cnt, ms, work, fam) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                f.write(f"{k}\t{kern}\t{cnt / steps:g}\t{ms / cnt:.4f}\t{work * cnt / ms / (1e6 if fam == 'depthwise' else 1e9):.0f}\t{ms / steps:.3f}\n")
     replicas_identical = None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -275,17 +312,17 @@ def main():
     # SURVEY 8(d) defines the metric at 1 and 2 images per GPU; the headline uses --batch (fuller grids).  Measure both
     # side by side (short: 2 warm-up + 8 timed steps each) so one record carries all three.
     sweep = {}
-    if not a.no_batch_sweep:
+    if batch_sweep and not a.no_batch_sweep:
         for nb in (1, 2):
             if nb >= a.batch:
                 continue
             d_, t_ = data[:nb].contiguous(), target[:nb].contiguous()
             for _ in range(2):
-                kd_step(model, crit, opt, d_, t_, a.mode)
+                kd_step(model, crit, opt, d_, t_, mode)
             sync()
             t1 = time.perf_counter()
             for _ in range(8):
-                kd_step(model, crit, opt, d_, t_, a.mode)
+                kd_step(model, crit, opt, d_, t_, mode)
             sync()
             d1 = time.perf_counter() - t1
             if world > 1:
@@ -297,48 +334,136 @@ def main():
     # what actually ran: the PyTorch teacher overlaps on a side stream unless --no-overlap; the engine teacher runs in stream
     # order unless --teacher-stream side
     overlapped = bool(model.overlap_teacher) and (a.teacher == "torch" or a.teacher_stream == "side")
+    res = None
     if rank == 0:
-        # dominant kernel: the implicit-GEMM conv; live HIP-event timing of every launch on its launching stream
+        # dominant kernel family: the implicit-GEMM conv (forward + input gradient); live HIP-event timing of every launch on
+        # its launching stream
+        conv = [p for p in prof if p[0] == "conv_igemm"]
         wg = [p for p in prof if p[0] == "conv_wgrad"]
-        prof = [p for p in prof if p[0] != "conv_wgrad"]
-        flops = sum(p[1] for p in prof)
-        ms = sum(p[2].elapsed_time(p[3]) for p in prof)
+        flops = sum(p[1] for p in conv)
+        ms = sum(p[2].elapsed_time(p[3]) for p in conv)
         wg_flops, wg_ms = sum(p[1] for p in wg), sum(p[2].elapsed_time(p[3]) for p in wg)
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        traffic, traffic_src = conv_traffic(plan_name, a.batch, a.height, a.width, a.dtype, mode, arch)
+        arch_name = "Gated-SCNN (WRN-38 + shape stream, device Canny)" if arch == "gscnn" else "DeepLabV3+(WRN-38)"
+        crit_name = "WeightedHintMSELoss (filter_weight = rand(C), seed 7 + hint index)" if hint_loss == "weighted" else "MSELoss(num_classes=1000)"
         res = {
-            "metric": "images/sec KD train step, DeepLabV3+(WRN38) student 1024x2048",
-            "value": world * a.batch * a.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": ("images/sec KD train step, Gated-SCNN (WRN38) student 1024x2048" if arch == "gscnn"
+                       else "images/sec KD train step, DeepLabV3+(WRN38) student 1024x2048"),
+            "value": world * a.batch * steps / dt, "unit": "images/sec", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"KD train step (frozen teacher fwd + student fwd + CE/KD/hint criteria + "
-                                   f"{'hint-loss bwd into the cheap-conv blocks' if a.mode == 'A' else 'kd+hint bwd into every student parameter'} + "
-                                   f"RAdam), DeepLabV3+(WRN-38) student plan {a.plan} ({len(plan)} cheap-conv blocks, 9x9 d5), "
+            "config": {"workload": f"KD train step (frozen teacher fwd + student fwd + CE/KD/hint criteria, hint = {crit_name}, + "
+                                   f"{'hint-loss bwd into the cheap-conv blocks' if mode == 'A' else 'kd+hint bwd into every student parameter'} + "
+                                   f"RAdam), {arch_name} student plan {plan_name} ({len(plan)} cheap-conv blocks, 9x9 d5), "
                                    f"{a.height}x{a.width}, {a.batch} image/GPU, random-init weights",
-                       "plan": a.plan, "mode": a.mode, "per_gpu_batch": a.batch, "global_batch": world * a.batch,
-                       "parallelism": f"dp{world}", "replicas_identical_after_run": replicas_identical,
-                       "teacher_overlap": overlapped,
+                       "plan": plan_name, "mode": mode, "arch": arch, "hint_loss": hint_loss, "per_gpu_batch": a.batch,
+                       "global_batch": world * a.batch, "parallelism": f"dp{world}",
+                       "replicas_identical_after_run": replicas_identical, "teacher_overlap": overlapped,
                        "teacher_backend": a.teacher, "per_step_host_syncs": bool(a.ref_logging),
-                       "share_frozen_prefix": bool(a.share_prefix),
-                       "per_gpu_batch_sweep": sweep},
-            "roofline": {"bound": "mfma", "kernel": "kd_conv2d_fwd: conv_row_persist_kernel + conv_igemm_persist_kernel + conv_row_pp128_kernel + conv_igemm_row_kernel + conv_igemm_kernel (dense conv fwd + dgrad, student" + (" + teacher)" if a.teacher == "hip" else ")"), "achieved": ach,
-                         "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                         "traffic": conv_traffic(a.plan, a.batch, a.height, a.width, a.dtype) if a.mode == "A" else None,
-                         "traffic_note": "mean HBM bytes per conv_igemm* launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + "
-                                         "WRITE_SIZE, separate passes (profiles/r02_traffic_pmc.json); mean algorithmic "
-                                         "FLOP per launch = algorithmic_tflop_per_step / launches_per_step",
-                         "launches_per_step": len(prof) / max(a.steps, 1), "ms_per_step_in_kernel": ms / max(a.steps, 1),
-                         "algorithmic_tflop_per_step": flops / max(a.steps, 1) / 1e12},
-            "dense_wgrad": ({"kernel": "pw_wgrad_tr_kernel / pw_wgrad_kernel via kd_conv2d_wgrad", "achieved": wg_flops / (wg_ms * 1e-3) / 1e12,
-                             "unit": "TFLOP/s", "launches_per_step": len(wg) / max(a.steps, 1), "ms_per_step_in_kernel": wg_ms / max(a.steps, 1),
-                             "algorithmic_tflop_per_step": wg_flops / max(a.steps, 1) / 1e12} if wg_ms > 0 else None),
-            "losses": {("hint" if a.mode == "A" else "kd+hint"): float(loss.detach()), "supervised": float(sup), "kd": float(kd), "teacher": float(tl)},
+                       "share_frozen_prefix": bool(a.share_prefix), "per_gpu_batch_sweep": sweep},
+            "roofline": {"bound": "mfma",
+                         "kernel": "kd_conv2d_fwd: conv_row_persist_kernel + conv_igemm_persist_kernel + conv_row_pp128_kernel + conv_igemm_row_kernel "
+                                   "+ conv_igemm_kernel (dense conv fwd + dgrad, student" + (" + teacher)" if a.teacher == "hip" else ")"),
+                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                         "traffic_note": ("mean HBM bytes per conv launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate "
+                                          f"passes of this command ({traffic_src}); mean algorithmic FLOP per launch = "
+                                          "algorithmic_tflop_per_step / launches_per_step") if traffic is not None else
+                                         "no committed PMC pass for this configuration",
+                         "launches_per_step": len(conv) / max(steps, 1), "ms_per_step_in_kernel": ms / max(steps, 1),
+                         "algorithmic_tflop_per_step": flops / max(steps, 1) / 1e12,
+                         "classes": class_rooflines(prof, max(steps, 1), peak)},
+            "dense_wgrad": ({"kernel": "conv_wgrad_row_kernel / conv_wgrad_wide_kernel / pw_wgrad_tr_kernel via kd_conv2d_wgrad",
+                             "achieved": wg_flops / (wg_ms * 1e-3) / 1e12, "unit": "TFLOP/s", "peak": peak,
+                             "frac": wg_flops / (wg_ms * 1e-3) / 1e12 / peak, "launches_per_step": len(wg) / max(steps, 1),
+                             "ms_per_step_in_kernel": wg_ms / max(steps, 1),
+                             "algorithmic_tflop_per_step": wg_flops / max(steps, 1) / 1e12} if wg_ms > 0 else None),
+            "losses": {("hint" if mode == "A" else "kd+hint"): float(loss.detach()), "supervised": float(sup), "kd": float(kd), "teacher": float(tl)},
         }
-        if a.arch == "gscnn":
-            res["metric"] = "images/sec KD train step, Gated-SCNN (WRN38) student 1024x2048"
-            res["config"]["workload"] = res["config"]["workload"].replace("DeepLabV3+(WRN-38) student", "Gated-SCNN (WRN-38 + shape stream, device Canny) student")
-        if world == 1 and not a.no_cpu_baseline and a.arch == "deeplab":
-            res["cpu_baseline"] = cpu_baseline(cpu_sd, model, plan, full=a.cpu_baseline == "full")
+    return res, model, cpu_sd, plan
+
+
+# sub-records of the default run: the other BASELINE configurations, short (2 warm-up + 8 timed steps), same JSON line
+SUB_RECORDS = (
+    ("P79", dict(plan_name="P79"), "the shipped cfg/cityscapes/58M_deeplab_all.json plan (79.75 M-parameter student)"),
+    ("modeB", dict(mode="B"), "north-star mode B: loss = KLDiv + hints, all 92.1 M student parameters trainable (37.74 TFLOP/img)"),
+    ("gscnn_P86", dict(arch="gscnn", plan_name="P86"), "BASELINE config 5: Gated-SCNN student, cfg/cityscapes/51M_gscnn_all.json plan"),
+    ("weighted_hint", dict(hint_loss="weighted"), "BASELINE config 4: WeightedHintMSELoss feature-hint KD, filter_weight = rand(C) (rand:7)"),
+)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--plan", default="P92", choices=sorted(PLANS))
+    ap.add_argument("--arch", default="deeplab", choices=["deeplab", "gscnn"],
+                    help="deeplab: DeepLabV3+(WRN-38), the headline (BASELINE configs 2-4); gscnn: Gated-SCNN teacher/student "
+                         "(BASELINE config 5; use --plan P86, the shipped 51M_gscnn_all.json plan; mode A only)")
+    ap.add_argument("--mode", default="A", choices=["A", "B"],
+                    help="A (default, reference-faithful): loss = hint loss, only the cheap-conv blocks train; B (SURVEY 8d "
+                         "north-star mode): loss = KLDiv + hint, every student parameter trainable (37.74 TFLOP/img for P92)")
+    ap.add_argument("--hint-loss", default="mse", choices=["mse", "weighted"],
+                    help="mse: MSELoss(num_classes=1000) (configs 2/3); weighted: WeightedHintMSELoss with rand:7 filter weights (config 4)")
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU (4 by default: +6 %% img/s over 1, +2 %% over 2 from fuller grids)")
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="step", choices=["step", "sample", "full"],
+                    help="step (default): one measured 1024x2048 CPU step (~1 min) after a 512x1024 one; sample: the 512x1024 step only, "
+                         "pixel-scaled; full: BASELINE.md section 3 (1 warm-up + 2 steps at 1024x2048 + 5 steps at 256x512)")
+    ap.add_argument("--no-sub-records", action="store_true",
+                    help="skip the short P79 / mode B / GSCNN P86 / WeightedHintMSE side measurements of the default run")
+    ap.add_argument("--layer-table", default=None, help="write a per-conv-shape timing table (tsv) to this path")
+    ap.add_argument("--no-batch-sweep", action="store_true", help="skip the 1 and 2 images/GPU side measurements")
+    ap.add_argument("--no-overlap", action="store_true", help="with --teacher torch: run the teacher on the main stream")
+    ap.add_argument("--ref-logging", action="store_true",
+                    help="also do the reference's per-step host syncs (five .item() calls, layerwise_trainer.py:244-250); the "
+                         "default measures the step without them, as this trainer runs it (metrics stay on the device)")
+    ap.add_argument("--teacher-stream", default="main", choices=["main", "side"],
+                    help="with --teacher hip: run the engine teacher on a side HIP stream concurrently with the student forward")
+    ap.add_argument("--share-prefix", action="store_true",
+                    help="opt-in: compute the frozen layers the student shares bit for bit with the teacher once per step "
+                         "(stem .. the block before the first cheap conv); same numbers, ~8 %% fewer FLOPs than the reference's "
+                         "two full forwards -- NOT the headline configuration")
+    ap.add_argument("--teacher", default="hip", choices=["torch", "hip"],
+                    help="hip: frozen teacher graph through the engine's HIP kernels (default); torch: teacher as a PyTorch-ROCm "
+                         "module (MIOpen) on a side stream, the split north_star describes")
+    a = ap.parse_args()
+
+    import kdcc_amd
+    from kdcc_amd import parallel
+    rank, local, world = parallel.init_distributed()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    device = torch.device("cuda", local)
+
+    res, model, cpu_sd, plan = run_config(a, device, rank, world, hint_loss=a.hint_loss)
+    headline_default = (a.plan, a.mode, a.arch, a.hint_loss, a.dtype, a.teacher, (a.height, a.width)) == \
+        ("P92", "A", "deeplab", "mse", "bf16", "hip", (1024, 2048)) and not a.share_prefix
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.arch == "deeplab":
+        res["cpu_baseline"] = cpu_baseline(cpu_sd, model, plan, full=a.cpu_baseline)
+    del model
+    if world == 1 and headline_default and not a.no_sub_records:
+        import gc
+        subs = {}
+        for name, kw, what in SUB_RECORDS:
+            gc.collect()
+            torch.cuda.empty_cache()
+            print(f"[bench] sub-record {name}: {what} ...", file=sys.stderr, flush=True)
+            r, m, _, _ = run_config(a, device, rank, world, steps=8, warmup=2, batch_sweep=False, **kw)
+            del m
+            keep = {k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "dense_wgrad", "losses")}
+            keep["what"] = what
+            keep["config"] = {k: r["config"][k] for k in ("plan", "mode", "arch", "hint_loss", "per_gpu_batch")}
+            subs[name] = keep
+        res["sub_records"] = subs
+    if rank == 0:
         print(json.dumps(res))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -14,9 +14,32 @@ from ._lib import (KD_BF16, KD_F32, KD_PACK_DGRAD, KD_PACK_FWD, ConvDesc, ConvEp
                    check)
 
 
-# Optional live profiler (bench.py): a list that receives (kernel family, algorithmic flops, start event, end event)
-# for every dense-conv launch, recorded on the stream the kernel is launched on.
+# Optional live profiler (bench.py): a list that receives (family, algorithmic work, start event, end event, label, device
+# kernel the dispatcher picked) for every launch of the conv / depthwise / weight-gradient / loss entry points, the events
+# recorded on the stream the kernel is launched on.  Work is algorithmic FLOPs for the MFMA-bound families ("conv_igemm",
+# "conv_wgrad", "pw_wgrad") and algorithmic HBM bytes -- every operand read once, every result written once -- for the
+# HBM-bound ones ("depthwise", "loss").
 PROFILER = None
+
+
+def _prof_start():
+    if PROFILER is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def _prof_stop(e0, family, work, label, kernel=None):
+    if e0 is None or PROFILER is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    PROFILER.append((family, float(work), e0, e1, label, kernel if kernel is not None else _lib.last_kernel()))
+
+
+def _nbytes(*ts):
+    return sum(t.numel() * t.element_size() for t in ts if t is not None)
 
 
 def dt_of(t):
@@ -130,7 +153,7 @@ def conv2d(x, w_packed, stride=1, pad=0, dil=1, *, res_pre=None, mask=None, mask
         e1.record()
         epi = "".join(c for c, t in (("p", res_pre), ("m", mask), ("q", res_post), ("r", out_raw), ("a", out_act)) if t is not None)
         prof.append(("conv_igemm", 2.0 * N * Ho * Wo * (algo_cout or Cout) * kh * kw * (algo_cin or Cin), e0, e1,
-                     f"{kh}x{kw} s{stride} d{dil} {H}x{W} {Cin}->{Cout} [{epi}]"))
+                     f"{kh}x{kw} s{stride} d{dil} {H}x{W} {Cin}->{Cout} [{epi}]", _lib.last_kernel()))
     return out_raw, out_act
 
 
@@ -147,9 +170,11 @@ def pw_wgrad(a, dy, dw, accumulate=False, workspace=None):
     need = _lib.lib().kd_pw_wgrad_workspace(M, Cin, Cout)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=a.device)
+    e0 = _prof_start()
     check(_lib.lib().kd_pw_wgrad(dt_of(a), M, Cin, Cout, _ptr(a), nhwc_ld(a), _ptr(dy), nhwc_ld(dy), _ptr(dw),
                                  int(accumulate), _ptr(workspace), workspace.numel() * workspace.element_size(),
                                  stream_ptr()), "kd_pw_wgrad")
+    _prof_stop(e0, "pw_wgrad", 2.0 * M * Cin * Cout, f"pw wgrad {H}x{W} {Cin}->{Cout}")
     return dw
 
 
@@ -177,7 +202,7 @@ def conv2d_wgrad(x, dy, dw, stride=1, pad=0, dil=1, accumulate=False, workspace=
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         prof.append(("conv_wgrad", 2.0 * N * Ho * Wo * Cout * kh * kw * Cin, e0, e1,
-                     f"wgrad {kh}x{kw} s{stride} d{dil} {H}x{W} {Cin}->{Cout}"))
+                     f"wgrad {kh}x{kw} s{stride} d{dil} {H}x{W} {Cin}->{Cout}", _lib.last_kernel()))
     return dw
 
 
@@ -220,8 +245,10 @@ def dwconv(x, w_taps, k, pad, dil, bias=None, out=None, res_pre=None, mask=None,
         if mask_scale is not None and (mask_scale.dtype != torch.float32 or mask_scale.numel() != Cc):
             raise ValueError("dwconv: mask_scale must be fp32 (C,)")
         ep.mask_scale = _ptr(mask_scale)
+    e0 = _prof_start()
     check(_lib.lib().kd_dwconv_fwd(C.byref(d), _ptr(x), _ptr(w_taps), _ptr(bias), C.byref(ep) if ep is not None else None,
                                    _ptr(out), stream_ptr()), "kd_dwconv_fwd")
+    _prof_stop(e0, "depthwise", _nbytes(x, out, res_pre, mask, res_post), f"dw {k}x{k} d{dil} {H}x{W} C{Cc}" + (" +epi" if ep is not None else ""))
     return out
 
 
@@ -264,7 +291,9 @@ def dwconv_sum(xs, w_taps, k, pad, dil, out=None):
     n = len(xs)
     xp = (C.c_void_p * n)(*[_ptr(x) for x in xs])
     wp = (C.c_void_p * n)(*[_ptr(w) for w in w_taps])
+    e0 = _prof_start()
     check(_lib.lib().kd_dwconv_fwd_sum(C.byref(d), n, xp, wp, _ptr(out), stream_ptr()), "kd_dwconv_fwd_sum")
+    _prof_stop(e0, "depthwise", _nbytes(out, *xs), f"dw sum of {n} {k}x{k} d{dil} {H}x{W} C{Cc}")
     return out
 
 
@@ -292,7 +321,9 @@ def dwconv_fanout(x, w_taps, k, pad, dil, outs=None):
     n = len(outs)
     wp = (C.c_void_p * n)(*[_ptr(w) for w in w_taps])
     yp = (C.c_void_p * n)(*[_ptr(o) for o in outs])
+    e0 = _prof_start()
     check(_lib.lib().kd_dwconv_fwd_fanout(C.byref(d), n, _ptr(x), wp, yp, stream_ptr()), "kd_dwconv_fwd_fanout")
+    _prof_stop(e0, "depthwise", _nbytes(x, *outs), f"dw fan-out of {n} {k}x{k} d{dil} {H}x{W} C{Cc}")
     return outs
 
 
@@ -307,8 +338,10 @@ def dwconv_wgrad(x, dy, dw, k, pad, dil, accumulate=False, workspace=None):
     need = _lib.lib().kd_dwconv_wgrad_workspace(C.byref(d))
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+    e0 = _prof_start()
     check(_lib.lib().kd_dwconv_wgrad(C.byref(d), _ptr(x), _ptr(dy), nhwc_ld(dy), _ptr(dw), int(accumulate), _ptr(workspace),
                                      workspace.numel() * workspace.element_size(), stream_ptr()), "kd_dwconv_wgrad")
+    _prof_stop(e0, "depthwise", _nbytes(x, dy), f"dw wgrad {k}x{k} d{dil} {H}x{W} C{Cc}")
     return dw
 
 
@@ -720,9 +753,11 @@ def kldiv(s, t, temperature=1.0, want_grad=True, grad_scale=1.0):
     grad = torch.empty_like(s) if want_grad else None
     vg = view3(grad)[0] if want_grad else None
     ws, need = loss_workspace(N, Cc, P, s.device)
+    e0 = _prof_start()
     check(_lib.lib().kd_kldiv(C.byref(vs), C.byref(vt), C.c_float(temperature), N, Cc, P, _ptr(loss),
                               C.byref(vg) if vg is not None else None, C.c_float(grad_scale), _ptr(ws), need, stream_ptr()),
           "kd_kldiv")
+    _prof_stop(e0, "loss", _nbytes(s, t, grad), f"kldiv {N}x{Cc}x{P}", "kldiv_kernel")
     return loss, grad
 
 
@@ -732,9 +767,11 @@ def hint_mse(s, t, num_classes=19, want_grad=True, grad_scale=1.0):
     grad = torch.empty_like(s) if want_grad else None
     vg = view3(grad)[0] if want_grad else None
     ws, need = loss_workspace(N, Cc, P, s.device)
+    e0 = _prof_start()
     check(_lib.lib().kd_hint_mse(C.byref(vs), C.byref(vt), C.c_float(num_classes), N, Cc, P, _ptr(loss),
                                  C.byref(vg) if vg is not None else None, C.c_float(grad_scale), _ptr(ws), need, stream_ptr()),
           "kd_hint_mse")
+    _prof_stop(e0, "loss", _nbytes(s, t, grad), f"hint mse {N}x{Cc}x{P}", "mse_vec_kernel")
     return loss, grad
 
 
@@ -748,9 +785,11 @@ def weighted_hint_mse(s, t, w, want_grad=True, grad_scale=1.0):
     grad = torch.empty_like(s) if want_grad else None
     vg = view3(grad)[0] if want_grad else None
     ws, need = loss_workspace(N, Cc, P, s.device)
+    e0 = _prof_start()
     check(_lib.lib().kd_weighted_hint_mse(C.byref(vs), C.byref(vt), _ptr(w), int(w.dim() == 2), N, Cc, P, _ptr(loss),
                                           C.byref(vg) if vg is not None else None, C.c_float(grad_scale), _ptr(ws), need,
                                           stream_ptr()), "kd_weighted_hint_mse")
+    _prof_stop(e0, "loss", _nbytes(s, t, grad), f"weighted hint mse {N}x{Cc}x{P}", "whmse_kernel")
     return loss, grad
 
 
@@ -762,7 +801,9 @@ def ce2d(x, target, ignore_index=255):
         raise ValueError("ce2d: target must be int64 (N,H,W)")
     loss = torch.empty((), dtype=torch.float32, device=x.device)
     ws, need = loss_workspace(N, Cc, P, x.device)
+    e0 = _prof_start()
     check(_lib.lib().kd_ce2d(C.byref(vx), _ptr(tgt), ignore_index, N, Cc, P, _ptr(loss), _ptr(ws), need, stream_ptr()), "kd_ce2d")
+    _prof_stop(e0, "loss", _nbytes(x, tgt), f"ce2d {N}x{Cc}x{P}", "ce2d_kernel")
     return loss
 
 

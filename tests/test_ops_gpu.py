@@ -21,6 +21,15 @@ def K():
     return ops
 
 
+def selected(want, what=""):
+    """The dispatcher's choice for the launch just made (kd_debug_last_kernel): a case that says it covers a kernel must reach
+    it -- an edit of the selection rules (conv_igemm.hip kd_conv2d_fwd, dwconv_mfma.hip) then fails here instead of silently
+    moving the coverage."""
+    from kdcc_amd import _lib
+    got = _lib.last_kernel()
+    assert got == want, f"{what}: dispatched to {got}, this case is meant to cover {want}"
+
+
 DT = {"f32": torch.float32, "bf16": torch.bfloat16}
 RNG = np.random.default_rng(1234)
 
@@ -82,6 +91,20 @@ CONV_CASES = [
     (1, 224, 1024, 64, 256, 3, 2, 1, 1),     # stride-2 3x3 (the mod4.block1 class) on wide tiles
     (1, 120, 480, 64, 320, 3, 1, 2, 2),      # 3x3 whose rows are not tile segments: gathered im2col with border taps, ragged Cout
 ]
+# what each of the shape-selected cases above must dispatch to: index -> (bf16 kernel, f32 kernel)
+CONV_SELECTS = {
+    0: ("conv_igemm_kernel<narrow2>", "conv_igemm_kernel<f32,narrow>"),
+    6: ("conv_row_persist_kernel<pp>", "conv_igemm_row_kernel<f32,wide>"),
+    7: ("conv_row_persist_kernel<pp>", "conv_igemm_row_kernel<f32,wide>"),
+    8: ("conv_row_persist_kernel<pp>", "conv_igemm_row_kernel<f32,wide>"),
+    9: ("conv_igemm_row_kernel<x>", "conv_igemm_row_kernel<f32,x>"),
+    10: ("conv_igemm_row_kernel<narrow>", "conv_igemm_kernel<f32,narrow>"),
+    11: ("conv_igemm_row_kernel<narrow>", "conv_igemm_kernel<f32,narrow>"),
+    12: ("conv_igemm_persist_kernel<pp>", "conv_igemm_kernel<f32,wide>"),
+    13: ("conv_igemm_kernel<wide>", "conv_igemm_kernel<f32,wide>"),
+    14: ("conv_igemm_kernel<wide>", "conv_igemm_kernel<f32,wide>"),
+    15: ("conv_igemm_kernel<wide>", "conv_igemm_kernel<f32,wide>"),
+}
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
@@ -96,6 +119,9 @@ def test_conv_fwd(K, dt, case):
     Ho, Wo = ref.shape[2:]
     out = torch.empty((N, Ho, Wo, Cout), dtype=DT[dt], device="cuda")
     K.conv2d(xd, wp, s, p, d, out_raw=out)
+    idx = CONV_CASES.index(case)
+    if idx in CONV_SELECTS:
+        selected(CONV_SELECTS[idx][0 if dt == "bf16" else 1], f"conv {case} {dt}")
     assert_close(host_nchw(out), ref, dt, f"conv {case}")
 
 
@@ -213,6 +239,8 @@ def test_conv_persistent_epilogues(K, case, opnds, outs):
              res_post=dev_nhwc(post, dt, ld=Cout + 24) if "post" in opnds else None,
              out_raw=out_raw, out_act=out_act, act_scale=cu(ascale) if "act" in outs else None,
              act_shift=cu(ashift) if "act" in outs else None, act_relu="act" in outs)
+    selected("conv_igemm_persist_kernel<pp>" if k == 1 else "conv_row_pp128_kernel" if Cout == 128 else "conv_row_persist_kernel<pp>",
+             f"{case} {opnds}")
     if out_raw is not None:
         assert_close(host_nchw(out_raw), ref, dt, f"raw {case} {opnds}")
     if out_act is not None:
@@ -285,11 +313,14 @@ def test_dwconv_fwd_dgrad_wgrad(K, dt, case):
     gy = q(rnd(N, Cc, H, W), dt)
     wd = torch.from_numpy(w).cuda()
     y = K.dwconv(dev_nhwc(x, dt), K.pack_dw_weight(wd), k, p, d)
+    mfma = dt == "bf16" and k == 9 and Cc % 16 == 0    # the matrix-core kernels' domain (dwconv_mfma.hip)
+    selected("dw_mfma_fwd_kernel<1,false>" if mfma else f"dwconv_fwd_kernel<{dt}>", f"dw fwd {case} {dt}")
     assert_close(host_nchw(y), orc.conv2d_fwd(x, w, pad=p, dil=d, groups=Cc), dt, "dw fwd")
     gx = K.dwconv(dev_nhwc(gy, dt), K.pack_dw_weight(wd, flip=True), k, p, d)
     assert_close(host_nchw(gx), orc.conv2d_dgrad(gy, w, x.shape, pad=p, dil=d, groups=Cc), dt, "dw dgrad")
     dw = torch.zeros((Cc, 1, k, k), device="cuda")
     K.dwconv_wgrad(dev_nhwc(x, dt), dev_nhwc(gy, dt), dw, k, p, d)
+    selected("dw_mfma_wgrad_kernel" if mfma else f"dwconv_wgrad_kernel<{dt}>", f"dw wgrad {case} {dt}")
     assert_close(dw.cpu().numpy(), orc.conv2d_wgrad(x, gy, w.shape, pad=p, dil=d, groups=Cc), dt, "dw wgrad")
 
 
@@ -313,6 +344,8 @@ def test_dwconv_sum(K, dt, case):
     ref = sum(orc.conv2d_dgrad(g, w, g.shape, pad=p, dil=d, groups=Cc) for g, w in zip(gs, ws))
     taps = [K.pack_dw_weight(torch.from_numpy(w).cuda(), flip=True) for w in ws]
     out = K.dwconv_sum([dev_nhwc(g, dt) for g in gs], taps, k, d * (k - 1) - p, d)
+    if dt == "bf16" and k == 9 and Cc % 16 == 0 and n <= 3:
+        selected(f"dw_mfma_fwd_kernel<{n},false>", f"dw sum {case}")
     assert_close(host_nchw(out), ref, dt, f"dw sum of {n}")
     if n <= 3:   # same numbers as the chained launches up to the rounding of the running bf16 sum
         run = None
@@ -335,6 +368,8 @@ def test_dwconv_fanout(K, dt, case):
     taps = [K.pack_dw_weight(torch.from_numpy(w).cuda()) for w in ws]
     xd = dev_nhwc(x, dt)
     outs = K.dwconv_fanout(xd, taps, k, p, d)
+    if dt == "bf16" and k == 9 and Cc % 16 == 0 and n <= 3:
+        selected(f"dw_mfma_fwd_kernel<{n},true>", f"dw fan-out {case}")
     for i, (o, w) in enumerate(zip(outs, ws)):
         assert_close(host_nchw(o), orc.conv2d_fwd(x, w, pad=p, dil=d, groups=Cc), dt, f"dw fan-out {i}")
         assert torch.equal(o, K.dwconv(xd, taps[i], k, p, d)), f"fan-out output {i} differs from the single launch"
@@ -417,6 +452,7 @@ def test_stem_conv_pool_fused(K, shape):
     scale, shift = rnd(64) * 0.2 + 1.0, rnd(64) * 0.2
     xd, wd, sd, hd = (torch.from_numpy(a).cuda() for a in (x, w, scale, shift))
     raw, act = K.stem_conv_pool(xd, wd, sd, hd)
+    selected("stem_pool_kernel", "stem + pool2")
     y = K.stem_conv(xd, wd, torch.bfloat16)
     raw2, act2 = K.maxpool3x3s2(y, sd, hd)
     assert torch.equal(raw, raw2) and torch.equal(act, act2)
@@ -626,6 +662,10 @@ def test_conv_wgrad(K, dt, case):
     gyd = dev_nhwc(gy, dt, ld=ldy) if Cout % 8 else dev_nhwc(gy, dt)
     dw = torch.full((Cout, Cin, k, k), 3.0, device="cuda")
     K.conv2d_wgrad(dev_nhwc(x, dt, ld=Cin + 16), gyd, dw, s, p, d)
+    if dt == "bf16" and k == 3 and s == 1 and p == d and W % 64 == 0 and d <= 16:
+        selected("conv_wgrad_row_kernel", f"wgrad {case}")      # the row-buffer cases
+    elif dt == "bf16" and Cin >= 256 and Cout >= 256:
+        selected("conv_wgrad_wide_kernel", f"wgrad {case}")     # the 256 x 256 tile cases
     assert_close(dw.cpu().numpy(), ref, dt, f"wgrad {case}")
     K.conv2d_wgrad(dev_nhwc(x, dt), gyd, dw, s, p, d, accumulate=True)
     assert_close(dw.cpu().numpy(), 2 * ref, dt, f"wgrad accumulate {case}")
