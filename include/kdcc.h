@@ -171,6 +171,14 @@ size_t kd_dwconv_wgrad_workspace(const kd_dw_desc *d);
 int kd_dwconv_wgrad(const kd_dw_desc *d, const void *x, const void *dy, int32_t ld_dy,
                     float *dw, int32_t accumulate, void *workspace, size_t workspace_bytes,
                     kd_stream_t stream);
+/* dws[i] = the weight gradient above for x and dys[i], i < n: n depthwise convs of one geometry that read ONE input -- the
+ * replaced ASPP branches again (models/deeplabv3/deeplabv3.py:71-75; autograd of depthwise_separable_conv.py:7-8 per
+ * branch).  For n = 2, 3 bf16 9x9 branches one launch stages each tile of x once and shares its operand windows between the
+ * branches; other shapes run one kd_dwconv_wgrad per branch.  All dys share ld_dy. */
+size_t kd_dwconv_wgrad_multi_workspace(const kd_dw_desc *d, int32_t n);
+int kd_dwconv_wgrad_multi(const kd_dw_desc *d, int32_t n, const void *x, const void *const *dys, int32_t ld_dy,
+                          float *const *dws, int32_t accumulate, void *workspace, size_t workspace_bytes,
+                          kd_stream_t stream);
 
 /* ----------------------------------------------------------- trunk plumbing
  * Stem conv mod1.conv1 (wider_resnet.py:307-309): 3x3, 3 -> 64, stride 1, pad 1,

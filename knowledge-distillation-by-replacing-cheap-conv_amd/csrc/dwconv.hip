@@ -402,6 +402,8 @@ int kd_internal_dw_mfma_fwd_n(const kd_dw_desc *d, int nb, int fan, const void *
                               const float *bias, const kd_dw_epilogue *ep, hipStream_t s);
 int kd_internal_dw_mfma_wgrad_slabs(const kd_dw_desc *d);
 int kd_internal_dw_mfma_wgrad(const kd_dw_desc *d, const void *x, const void *dy, int ld_dy, float *part, hipStream_t s);
+int kd_internal_dw_mfma_wgrad_multi_slabs(const kd_dw_desc *d, int n);
+int kd_internal_dw_mfma_wgrad_multi(const kd_dw_desc *d, int n, const void *x, const void *const *dys, int ld_dy, float *part, hipStream_t s);
 
 extern "C" int kd_pack_dw_weight(const float *src, float *dst, int32_t C, int32_t k, int32_t flip, kd_stream_t stream)
 {
@@ -581,5 +583,56 @@ extern "C" int kd_dwconv_wgrad(const kd_dw_desc *d, const void *x, const void *d
     hipLaunchKernelGGL(dw_slab_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, (const float *)workspace, dw,
                        slabs, d->k * d->k, d->C, accumulate);
     KD_CHECK_LAUNCH("kd_dwconv_wgrad(reduce)");
+    return KD_OK;
+}
+
+// Weight gradients of n depthwise convs of one geometry that read ONE input (the replaced ASPP branches): fused on the matrix
+// cores for n = 2, 3 where the shape allows (x staged once, its Hankel windows shared by the branches), else one launch each.
+extern "C" size_t kd_dwconv_wgrad_multi_workspace(const kd_dw_desc *d, int32_t n)
+{
+    if (!d || d->dil < 1 || n < 1) return 0;
+    const size_t single = kd_dwconv_wgrad_workspace(d);
+    // branches are fused three (or two) at a time; the largest chunk sets the size (slabs per branch do not depend on the count)
+    const int m = n < 3 ? n : 3;
+    const size_t multi = m >= 2 ? (size_t)kd_internal_dw_mfma_wgrad_multi_slabs(d, m) * m * d->k * d->k * d->C * sizeof(float) : 0;
+    return single > multi ? single : multi;
+}
+
+extern "C" int kd_dwconv_wgrad_multi(const kd_dw_desc *d, int32_t n, const void *x, const void *const *dys, int32_t ld_dy,
+                                     float *const *dws, int32_t accumulate, void *workspace, size_t workspace_bytes,
+                                     kd_stream_t stream)
+{
+    int rc = check_desc(d, "kd_dwconv_wgrad_multi");
+    if (rc) return rc;
+    KD_REQUIRE(n >= 1 && x && dys && dws && workspace, KD_ERR_INVALID, "kd_dwconv_wgrad_multi: null argument or n < 1");
+    for (int i = 0; i < n; ++i) KD_REQUIRE(dys[i] && dws[i], KD_ERR_INVALID, "kd_dwconv_wgrad_multi: null gradient %d", i);
+    KD_REQUIRE(workspace_bytes >= kd_dwconv_wgrad_multi_workspace(d, n), KD_ERR_WORKSPACE, "kd_dwconv_wgrad_multi: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    for (int done = 0; done < n;) {
+        const int m = n - done < 3 ? n - done : 3;
+        const int slabs = kd_internal_dw_mfma_wgrad_multi_slabs(d, m);
+        int took = 0;
+        if (slabs > 0) {
+            const int es = kd_elem_size(d->dtype);
+            bool ok = ld_dy >= d->C && ld_dy % 4 == 0 && d->ldx % 4 == 0 && ((uintptr_t)x % (4 * es)) == 0;
+            for (int i = 0; i < m; ++i) ok = ok && ((uintptr_t)dys[done + i] % (4 * es)) == 0;
+            if (ok) took = kd_internal_dw_mfma_wgrad_multi(d, m, x, dys + done, ld_dy, (float *)workspace, s);
+            if (took < 0) return took;
+        }
+        if (took) {
+            const int total = d->k * d->k * d->C;
+            for (int i = 0; i < m; ++i) {
+                hipLaunchKernelGGL(dw_slab_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s,
+                                   (const float *)workspace + (size_t)i * slabs * total, dws[done + i], slabs, d->k * d->k, d->C, accumulate);
+                KD_CHECK_LAUNCH("kd_dwconv_wgrad_multi(reduce)");
+            }
+        } else {
+            for (int i = 0; i < m; ++i) {
+                rc = kd_dwconv_wgrad(d, x, dys[done + i], ld_dy, dws[done + i], accumulate, workspace, workspace_bytes, stream);
+                if (rc) return rc;
+            }
+        }
+        done += m;
+    }
     return KD_OK;
 }

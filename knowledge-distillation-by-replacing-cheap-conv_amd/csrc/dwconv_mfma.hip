@@ -580,6 +580,232 @@ __global__ __launch_bounds__(NTW, 1) void dw_mfma_wgrad_kernel(DwWgMfmaParams p)
     }
 }
 
+// ---- weight gradients of up to three depthwise convs that read ONE tensor (the replaced ASPP branches) -------------------
+// dW_b = wgrad(x, g_b), b < NG: the kernel above, restructured around what bounds it.  It is LDS-bound on the Hankel windows
+// of x (5 dword reads + 4 funnel shifts per MFMA against one 16-B read for the g operand), and the three branches multiply
+// the SAME windows: here a pair of x rows is windowed ONCE and meets the g fragments of all NG branches (per pair of rows and
+// 32-column block: 20 window dwords + NG 16-B fragments for 2 NG MFMAs, instead of NG x (20 + 4 dwords) for 2 NG), and the x
+// tile is fetched from memory once instead of NG times.  Three g tiles next to the x tile do not fit at the 26-row tile
+// (239 KiB), so work items are half-height: 13 lattice rows (x: 21 staged rows, 42.7 KiB; g: 3 x 28.5 KiB; 128 KiB in all);
+// the x rows between the two halves of a residue class are staged twice (1.31 x the x reads, against 3 x before).
+constexpr int TLY3 = 13, RY3 = TLY3 + 8, MAXG = 3;
+constexpr int X3BYTES = (RY3 * RSTR + 64 + 15) & ~15;
+constexpr int G3BYTES = ((TLY3 + 1) * RSTR + 64 + 15) & ~15;   // + one all-zero row
+constexpr int WG3_LDS = X3BYTES + MAXG * G3BYTES;
+constexpr int ITEMS3 = RY3 * 64, GUNITS3 = TLY3 * 64;
+constexpr int NIX3 = (ITEMS3 + NTW - 1) / NTW, NIG3 = (GUNITS3 + NTW - 1) / NTW;
+static_assert(NIX3 == 2 && NIG3 == 1, "interleaved fetch below is written for 2 x units + 1 g unit per branch and thread");
+static_assert(WG3_LDS <= 160 * 1024, "LDS budget");
+
+struct DwWgMultiParams {
+    const bf16_t *x;
+    const bf16_t *g[MAXG];
+    float *part;         // [branch][slab][81][C]
+    int N, H, W, C, dil, ldx, ldg;
+    int nty, ntx, ncg;
+    int nitems, nseg, nslabs;
+};
+
+__device__ __forceinline__ Item decode_item3(int H, int W, int d, int ntx, int e)
+{
+    Item it;
+    it.rx = e % d; e /= d;
+    it.ry = e % d; e /= d;
+    it.tx = e % ntx;
+    it.ty = e / ntx;
+    const int Ly = (H - it.ry + d - 1) / d, Lx = (W - it.rx + d - 1) / d;
+    it.RV = min(TLY3, Ly - it.ty * TLY3);
+    it.CV = min(TLX, Lx - it.tx * TLX);
+    return it;
+}
+
+template <int NU> struct Staged3 {
+    uint4 a[NU], b[NU];
+};
+
+template <int HALO, int NU>
+__device__ __forceinline__ void fetch_unit3(int it, __amdgpu_buffer_rsrc_t base, int ld, int H, int W, int d, const Item &w, int tid,
+                                            Staged3<NU> &s)
+{
+    constexpr int UNITS = HALO ? ITEMS3 : GUNITS3;
+    const int unit = tid + it * NTW;
+    const int h = unit & 1, lp = (unit >> 1) & 31, r = unit >> 6;
+    const int ly = w.ty * TLY3 + r - HALO, lx = w.tx * TLX + 2 * lp - HALO;
+    const int yy = w.ry + d * ly, xa = w.rx + d * lx, xb2 = xa + d;
+    bool rok = ly >= 0 && yy < H && unit < UNITS, aok = lx >= 0 && xa < W, bok = lx + 1 >= 0 && xb2 < W;
+    if (HALO) {
+        rok = rok && lp < 30;
+    } else {
+        rok = rok && r < w.RV;
+        aok = aok && 2 * lp < w.CV;
+        bok = bok && 2 * lp + 1 < w.CV;
+    }
+    const uint32_t pb = (uint32_t)ld * 2u;
+    const uint32_t oa = (uint32_t)(yy * W + xa) * pb + (uint32_t)h * 16u;
+    s.a[it] = bload16(base, rok && aok ? oa : BUF_OOB);
+    s.b[it] = bload16(base, rok && bok ? oa + (uint32_t)d * pb : BUF_OOB);
+    // (no validity mask is kept: an out-of-range buffer load has already returned zeros)
+}
+
+template <int HALO, int NU> __device__ __forceinline__ void write_item3(char *X, int tid, const Staged3<NU> &s)
+{
+    constexpr int UNITS = HALO ? ITEMS3 : GUNITS3, NR = HALO ? RY3 : TLY3;
+    for (int e = tid; e < NR * 8; e += NTW) *(uint32_t *)(X + (e >> 3) * RSTR + CG * CSTR + (e & 7) * 4) = 0u;   // row pads
+    if (HALO) {
+        for (int e = tid; e < 16; e += NTW) *(uint32_t *)(X + RY3 * RSTR + e * 4) = 0u;                           // tail
+    } else {
+        for (int e = tid; e < (RSTR + 64) / 4; e += NTW) *(uint32_t *)(X + TLY3 * RSTR + e * 4) = 0u;             // zero row + tail
+    }
+#pragma unroll
+    for (int it = 0; it < NU; ++it) {
+        const int unit = tid + it * NTW;
+        if (unit < UNITS) {
+            const int h = unit & 1, lp = (unit >> 1) & 31, r = unit >> 6;
+            char *dst = X + r * RSTR + (h * 8) * CSTR + lp * 4;
+            const uint32_t a[4] = {s.a[it].x, s.a[it].y, s.a[it].z, s.a[it].w};
+            const uint32_t b[4] = {s.b[it].x, s.b[it].y, s.b[it].z, s.b[it].w};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                *(uint32_t *)(dst + (2 * m) * CSTR) = (a[m] & 0xffffu) | (b[m] << 16);
+                *(uint32_t *)(dst + (2 * m + 1) * CSTR) = (a[m] >> 16) | (b[m] & 0xffff0000u);
+            }
+        }
+    }
+}
+
+template <int NG>
+__global__ __launch_bounds__(NTW, 1) void dw_mfma_wgrad_multi_kernel(DwWgMultiParams p)
+{
+    static_assert(NG >= 2 && NG <= MAXG, "two or three branches");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *const Xx = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // wave = channel of the group
+    int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int cgi = lin % p.ncg; lin /= p.ncg;
+    const int seg = lin % p.nseg;
+    const int n = lin / p.nseg;
+    const int c0 = cgi * CG;
+    const int ibeg = (int)((long long)p.nitems * seg / p.nseg), iend = (int)((long long)p.nitems * (seg + 1) / p.nseg);
+    const __amdgpu_buffer_rsrc_t xb = image_rsrc(p.x + (size_t)n * p.H * p.W * p.ldx + c0, p.H, p.W, p.ldx);
+    const __amdgpu_buffer_rsrc_t gb0 = image_rsrc(p.g[0] + (size_t)n * p.H * p.W * p.ldg + c0, p.H, p.W, p.ldg);
+    const __amdgpu_buffer_rsrc_t gb1 = image_rsrc(p.g[1] + (size_t)n * p.H * p.W * p.ldg + c0, p.H, p.W, p.ldg);
+    const __amdgpu_buffer_rsrc_t gb2 = image_rsrc(p.g[NG > 2 ? 2 : 1] + (size_t)n * p.H * p.W * p.ldg + c0, p.H, p.W, p.ldg);
+
+    const int fi = lane & 15, kg = lane >> 4;
+    f32x4_t acc[NG][2];   // per branch: even / odd staged x rows (the odd-row tile is shifted by one lane when written)
+#pragma unroll
+    for (int b = 0; b < NG; ++b) acc[b][0] = acc[b][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    int cur = ibeg;
+    Item wi = decode_item3(p.H, p.W, p.dil, p.ntx, cur < iend ? cur : 0);
+    while (cur < iend && (wi.RV <= 0 || wi.CV <= 0)) { ++cur; if (cur < iend) wi = decode_item3(p.H, p.W, p.dil, p.ntx, cur); }
+    if (cur < iend) {
+        Staged3<NIX3> sx;
+        Staged3<NIG3> sg0, sg1, sg2;
+        fetch_unit3<4>(0, xb, p.ldx, p.H, p.W, p.dil, wi, tid, sx);
+        fetch_unit3<4>(1, xb, p.ldx, p.H, p.W, p.dil, wi, tid, sx);
+        fetch_unit3<0>(0, gb0, p.ldg, p.H, p.W, p.dil, wi, tid, sg0);
+        fetch_unit3<0>(0, gb1, p.ldg, p.H, p.W, p.dil, wi, tid, sg1);
+        if (NG > 2) fetch_unit3<0>(0, gb2, p.ldg, p.H, p.W, p.dil, wi, tid, sg2);
+        auto publish = [&]() __attribute__((always_inline)) {
+            write_item3<4>(Xx, tid, sx);
+            write_item3<0>(smem + X3BYTES, tid, sg0);
+            write_item3<0>(smem + X3BYTES + G3BYTES, tid, sg1);
+            if (NG > 2) write_item3<0>(smem + X3BYTES + 2 * G3BYTES, tid, sg2);
+        };
+        publish();
+        __syncthreads();
+
+        const int kxl = min(fi, 8);                       // A row i = kx (rows 9..15 duplicate row 8, discarded)
+        const uint32_t sh = (kxl & 1) ? 16u : 0u;
+        const int aoff = (kg * 8 + (kxl & ~1)) * 2;       // dword-aligned start of this lane's Hankel window
+        const char *xc = Xx + wave * CSTR + aoff;
+        const char *gc = smem + X3BYTES + wave * CSTR + kg * 16;
+        while (true) {
+            int nxt = cur + 1;
+            Item wn = wi;
+            if (nxt < iend) wn = decode_item3(p.H, p.W, p.dil, p.ntx, nxt);
+            while (nxt < iend && (wn.RV <= 0 || wn.CV <= 0)) { ++nxt; if (nxt < iend) wn = decode_item3(p.H, p.W, p.dil, p.ntx, nxt); }
+            const bool more = nxt < iend;
+
+            const int RV = wi.RV;
+            const int ncb = wi.CV > 32 ? 2 : 1;
+#pragma unroll 1
+            for (int R0 = 0; R0 < RV + 8; R0 += 2) {
+                if (more && (R0 & 3) == 0) {   // next item's loads, one unit per four rows
+                    switch (R0 >> 2) {
+                    case 0: fetch_unit3<4>(0, xb, p.ldx, p.H, p.W, p.dil, wn, tid, sx); break;
+                    case 1: fetch_unit3<4>(1, xb, p.ldx, p.H, p.W, p.dil, wn, tid, sx); break;
+                    case 2: fetch_unit3<0>(0, gb0, p.ldg, p.H, p.W, p.dil, wn, tid, sg0); break;
+                    case 3: fetch_unit3<0>(0, gb1, p.ldg, p.H, p.W, p.dil, wn, tid, sg1); break;
+                    case 4: if (NG > 2) fetch_unit3<0>(0, gb2, p.ldg, p.H, p.W, p.dil, wn, tid, sg2); break;
+                    default: break;
+                    }
+                }
+                // both x rows of the pair multiply the SAME 16 rows of g (R0 - 8 + j); see dw_mfma_wgrad_kernel
+                const int ly = R0 - 8 + fi;
+                const int grow = (ly >= 0 && ly < RV ? ly : TLY3) * RSTR;
+                const char *x0 = xc + min(R0, RY3 - 1) * RSTR, *x1 = xc + min(R0 + 1, RY3 - 1) * RSTR;
+                for (int cb = 0; cb < ncb; ++cb) {
+                    const uint32_t *xw0 = (const uint32_t *)(x0 + cb * 64), *xw1 = (const uint32_t *)(x1 + cb * 64);
+                    uint32_t d0[5], d1[5];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) { d0[q] = xw0[q]; d1[q] = xw1[q]; }
+                    uint4 bv = *(const uint4 *)(gc + grow + cb * 64);
+                    const uint4 a0 = make_uint4(__builtin_amdgcn_alignbit(d0[1], d0[0], sh), __builtin_amdgcn_alignbit(d0[2], d0[1], sh),
+                                                __builtin_amdgcn_alignbit(d0[3], d0[2], sh), __builtin_amdgcn_alignbit(d0[4], d0[3], sh));
+                    const uint4 a1 = make_uint4(__builtin_amdgcn_alignbit(d1[1], d1[0], sh), __builtin_amdgcn_alignbit(d1[2], d1[1], sh),
+                                                __builtin_amdgcn_alignbit(d1[3], d1[2], sh), __builtin_amdgcn_alignbit(d1[4], d1[3], sh));
+#pragma unroll
+                    for (int b = 0; b < NG; ++b) {   // one g fragment in flight ahead of the pair of MFMAs that uses it
+                        const uint4 bc = bv;
+                        if (b + 1 < NG) bv = *(const uint4 *)(gc + (b + 1) * G3BYTES + grow + cb * 64);
+                        Mma<bf16_t>::run(a0, bc, acc[b][0]);
+                        Mma<bf16_t>::run(a1, bc, acc[b][1]);
+                    }
+                }
+            }
+            if (!more) break;
+            // short tiles: the row loop did not reach every fetch slot (slot k sits at row 4k)
+            if (0 >= RV + 8) fetch_unit3<4>(0, xb, p.ldx, p.H, p.W, p.dil, wn, tid, sx);
+            if (4 >= RV + 8) fetch_unit3<4>(1, xb, p.ldx, p.H, p.W, p.dil, wn, tid, sx);
+            if (8 >= RV + 8) fetch_unit3<0>(0, gb0, p.ldg, p.H, p.W, p.dil, wn, tid, sg0);
+            if (12 >= RV + 8) fetch_unit3<0>(0, gb1, p.ldg, p.H, p.W, p.dil, wn, tid, sg1);
+            if (NG > 2 && 16 >= RV + 8) fetch_unit3<0>(0, gb2, p.ldg, p.H, p.W, p.dil, wn, tid, sg2);
+            __syncthreads();   // every wave is done reading the tiles
+            publish();
+            __syncthreads();
+            cur = nxt;
+            wi = wn;
+        }
+    }
+    // D[kx = 4*kg + r][j = fi] -> part[b][slab][ky = 8 - fi][kx][channel]; the odd-row tile holds ky = 9 - j
+#pragma unroll
+    for (int b = 0; b < NG; ++b) {
+        float *part = p.part + ((size_t)b * p.nslabs + (size_t)(n * p.nseg + seg)) * 81 * p.C + c0 + wave;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kx = kg * 4 + r;
+            const float odd = __shfl_down(acc[b][1][r], 1, 16);
+            if (kx < 9 && fi < 9) part[(size_t)((8 - fi) * 9 + kx) * p.C] = acc[b][0][r] + odd;
+        }
+    }
+}
+
+static void dw_mfma_split3(int N, int C, int H, int W, int dil, int *nty, int *ntx, int *nitems, int *nseg)
+{
+    const int LH = (H + dil - 1) / dil, LW = (W + dil - 1) / dil;
+    *nty = (LH + TLY3 - 1) / TLY3;
+    *ntx = (LW + TLX - 1) / TLX;
+    const long long ni = (long long)*nty * *ntx * dil * dil;
+    *nitems = ni > (1 << 24) ? 0 : (int)ni;
+    const long long groups = (long long)N * (C / CG);
+    long long s = (512 + groups - 1) / groups;
+    if (s > ni / 3) s = ni / 3;
+    if (s < 1) s = 1;
+    *nseg = (int)s;
+}
+
 static void dw_mfma_split(int N, int C, int H, int W, int dil, int *nty, int *ntx, int *nitems, int *nseg)
 {
     const int LH = (H + dil - 1) / dil, LW = (W + dil - 1) / dil;
@@ -716,6 +942,53 @@ int kd_internal_dw_mfma_wgrad(const kd_dw_desc *d, const void *x, const void *dy
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
         kd_set_error("kd_dwconv_wgrad(mfma): launch failed: %s", hipGetErrorString(err));
+        return KD_ERR_HIP;
+    }
+    return 1;
+}
+
+// ---- several weight gradients over one input (kd_dwconv_wgrad_multi) -------------------------------------------------------
+// Slabs of [81][C] fp32 partial sums PER BRANCH the fused path writes (0 = not eligible: the caller runs one launch per branch).
+int kd_internal_dw_mfma_wgrad_multi_slabs(const kd_dw_desc *d, int n)
+{
+    if (n < 2 || n > MAXG || !dw_mfma_wgrad_eligible(d, nullptr, nullptr, 8)) return 0;
+    int nty, ntx, nitems, nseg;
+    dw_mfma_split3(d->N, d->C, d->H, d->W, d->dil, &nty, &ntx, &nitems, &nseg);
+    return nitems > 0 ? d->N * nseg : 0;
+}
+
+// 1 = partial sums of every branch written to `part` ([branch][slab][81][C]), 0 = not eligible, < 0 = error.
+int kd_internal_dw_mfma_wgrad_multi(const kd_dw_desc *d, int n, const void *x, const void *const *dys, int ld_dy, float *part, hipStream_t s)
+{
+    if (n < 2 || n > MAXG) return 0;
+    for (int b = 0; b < n; ++b)
+        if (!dw_mfma_wgrad_eligible(d, x, dys[b], ld_dy)) return 0;
+    DwWgMultiParams p;
+    p.x = (const bf16_t *)x;
+    for (int b = 0; b < MAXG; ++b) p.g[b] = (const bf16_t *)dys[b < n ? b : 0];
+    p.part = part;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.dil = d->dil; p.ldx = d->ldx; p.ldg = ld_dy;
+    dw_mfma_split3(d->N, d->C, d->H, d->W, d->dil, &p.nty, &p.ntx, &p.nitems, &p.nseg);
+    p.ncg = d->C / CG;
+    p.nslabs = d->N * p.nseg;
+    if (p.nitems <= 0) return 0;
+    const long long blocks = (long long)d->N * p.ncg * p.nseg;
+    if (blocks > 0x7fffffffLL) return 0;
+    typedef void (*kern_t)(DwWgMultiParams);
+    const kern_t fn = n == 2 ? dw_mfma_wgrad_multi_kernel<2> : dw_mfma_wgrad_multi_kernel<3>;
+    static bool attr_set[MAXG + 1] = {};
+    if (!attr_set[n]) {
+        if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS) != hipSuccess) {
+            kd_set_error("kd_dwconv_wgrad_multi: cannot reserve %d B of LDS", WG3_LDS);
+            return KD_ERR_HIP;
+        }
+        attr_set[n] = true;
+    }
+    KD_NOTE_KERNEL(n == 2 ? "dw_mfma_wgrad_multi_kernel<2>" : "dw_mfma_wgrad_multi_kernel<3>");
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(NTW), WG3_LDS, s, p);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        kd_set_error("kd_dwconv_wgrad_multi(mfma): launch failed: %s", hipGetErrorString(err));
         return KD_ERR_HIP;
     }
     return 1;

@@ -825,15 +825,17 @@ class StudentEngine:
         N, H, W, _ = g.shape
         g_mid = self._new(N, H, W, pw.in_channels)
         ops.conv2d(g, self._w_dgrad(pw), out_raw=g_mid)
-        if dw.weight.requires_grad:
+        if dw.weight.requires_grad and defer is None:
             gw = self._grad_like(dw.weight)
             ops.dwconv_wgrad(a_in, g_mid, gw, site.k, site.pad, site.dil)
             grads[dw.weight] = gw
             self._grad_done(dw.weight)
-        if not need_in:
-            return None
         if defer is not None:
-            defer.append((g_mid, self._w_dw(dw, True), site))
+            # the caller batches the branches that read one tensor: weight gradients in one launch (kd_dwconv_wgrad_multi),
+            # input gradients summed in one launch (kd_dwconv_fwd_sum)
+            defer.append((g_mid, self._w_dw(dw, True) if need_in else None, site, dw.weight if dw.weight.requires_grad else None))
+            return None
+        if not need_in:
             return None
         return ops.dwconv(g_mid, self._w_dw(dw, True), site.k, site.dil * (site.k - 1) - site.pad, site.dil, **ep)
 
@@ -940,9 +942,17 @@ class StudentEngine:
                 if g_in is not None:
                     g_x7 = g_in
         groups = {}
-        for g_mid, w_t, site in deferred:
-            groups.setdefault((site.k, site.pad, site.dil, tuple(g_mid.shape), g_mid.dtype), []).append((g_mid, w_t))
-        for (k, pad, dil, _, _), items in groups.items():
+        for g_mid, w_t, site, w_dw in deferred:
+            groups.setdefault((site.k, site.pad, site.dil, tuple(g_mid.shape), g_mid.dtype), []).append((g_mid, w_t, w_dw))
+        for (k, pad, dil, _, _), members in groups.items():
+            train = [(g_mid, w_dw) for g_mid, _, w_dw in members if w_dw is not None]
+            if train:   # the branches' depthwise weight gradients: x7 staged once for all of them
+                gws = [self._grad_like(w_dw) for _, w_dw in train]
+                ops.dwconv_wgrad_multi(x7, [g for g, _ in train], gws, k, pad, dil)
+                for (_, w_dw), gw in zip(train, gws):
+                    grads[w_dw] = gw
+                    self._grad_done(w_dw)
+            items = [(g_mid, w_t) for g_mid, w_t, _ in members if w_t is not None]
             for j in range(0, len(items), 3):
                 part = items[j:j + 3]
                 if g_x7 is None:

@@ -345,6 +345,33 @@ def dwconv_wgrad(x, dy, dw, k, pad, dil, accumulate=False, workspace=None):
     return dw
 
 
+def dwconv_wgrad_multi(x, dys, dws, k, pad, dil, accumulate=False):
+    """dws[i] = weight gradient of dwconv(x, .) given dys[i]: several depthwise convs of one geometry reading the same tensor
+    (deeplabv3.py:71-75, the replaced ASPP branches); one launch for two or three branches where the shape allows."""
+    dys, dws = list(dys), list(dws)
+    if not dys or len(dys) != len(dws):
+        raise ValueError("dwconv_wgrad_multi: need one gradient buffer per dy")
+    _need_cuda(x, *dys, *dws)
+    N, H, W, Cc = x.shape
+    ld = nhwc_ld(dys[0])
+    for dy, dw in zip(dys, dws):
+        if tuple(dy.shape) != (N, H, W, Cc) or dy.dtype != x.dtype or nhwc_ld(dy) != ld:
+            raise ValueError("dwconv_wgrad_multi: every dy must match x's shape / dtype and share one pixel stride")
+        if dw.dtype != torch.float32 or dw.numel() != Cc * k * k or not dw.is_contiguous():
+            raise ValueError("dwconv_wgrad_multi: dw must be contiguous fp32 (C,1,k,k)")
+    d = _dw_desc(x, k, pad, dil)
+    n = len(dys)
+    need = _lib.lib().kd_dwconv_wgrad_multi_workspace(C.byref(d), n)
+    workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+    yp = (C.c_void_p * n)(*[_ptr(t) for t in dys])
+    wp = (C.c_void_p * n)(*[_ptr(t) for t in dws])
+    e0 = _prof_start()
+    check(_lib.lib().kd_dwconv_wgrad_multi(C.byref(d), n, _ptr(x), yp, ld, wp, int(accumulate), _ptr(workspace), need, stream_ptr()),
+          "kd_dwconv_wgrad_multi")
+    _prof_stop(e0, "depthwise", _nbytes(x, *dys), f"dw wgrad of {n} {k}x{k} d{dil} {H}x{W} C{Cc}")
+    return dws
+
+
 # ------------------------------------------------------------------------------ trunk plumbing
 def stem_conv(x_nchw, w, dtype):
     """(N,3,H,W) fp32 NCHW batch + (64,3,3,3) fp32 weight -> (N,H,W,64) NHWC."""

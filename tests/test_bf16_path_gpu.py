@@ -80,7 +80,7 @@ def _step(model, backprop="hint"):
 
 SHIPPED_MODE_A = ["conv_row_persist_kernel<pp>", "conv_igemm_persist_kernel<pp>", "conv_row_pp128_kernel",
                   "dw_mfma_fwd_kernel<1,false>", "dw_mfma_fwd_kernel<3,true>", "dw_mfma_fwd_kernel<3,false>",
-                  "dw_mfma_wgrad_kernel", "stem_pool_kernel", "conv_wgrad_wide_kernel"]   # (the pointwise weight gradients take the 256x256 wgrad tile)
+                  "dw_mfma_wgrad_kernel", "dw_mfma_wgrad_multi_kernel<3>", "stem_pool_kernel", "conv_wgrad_wide_kernel"]   # (the pointwise weight gradients take the 256x256 wgrad tile)
 
 
 def test_bf16_p92_step_on_the_shipped_kernels_vs_network_oracle():

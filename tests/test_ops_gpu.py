@@ -356,6 +356,36 @@ def test_dwconv_sum(K, dt, case):
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("case", [
+    (2, 24, 32, 16, 9, 20, 5, 3),        # one half-height tile pair per residue class (the ASPP shape in small)
+    (1, 140, 270, 32, 9, 20, 5, 3),      # several tiles in both directions with real halos, ragged last tiles
+    (1, 40, 70, 16, 9, 4, 1, 2),         # two branches, dil 1: four row tiles, two column tiles
+    (2, 64, 128, 48, 9, 20, 5, 3),       # three channel groups
+    (1, 67, 33, 16, 9, 20, 5, 3),        # 14 lattice rows: a 13-row and a 1-row tile (fewer rows than fetch slots)
+    (1, 23, 37, 72, 9, 20, 5, 3),        # C % 16 != 0: one register-kernel launch per branch
+    (1, 24, 32, 16, 9, 20, 5, 4),        # four branches: three fused + one single
+    (1, 8, 8, 16, 3, 1, 1, 2),           # 3x3
+])
+def test_dwconv_wgrad_multi(K, dt, case):
+    """kd_dwconv_wgrad_multi: the depthwise weight gradients of the ASPP branches over their one input (deeplabv3.py:71-75),
+    each against the oracle; bf16 9x9 branches share one staging of x and its operand windows (dw_mfma_wgrad_multi_kernel)."""
+    N, H, W, Cc, k, p, d, n = case
+    x = q(rnd(N, Cc, H, W), dt)
+    gs = [q(rnd(N, Cc, H, W), dt) for _ in range(n)]
+    dws = [torch.full((Cc, 1, k, k), 5.0, device="cuda") for _ in range(n)]
+    xd, gd = dev_nhwc(x, dt), [dev_nhwc(g, dt) for g in gs]
+    K.dwconv_wgrad_multi(xd, gd, dws, k, p, d)
+    if dt == "bf16" and k == 9 and Cc % 16 == 0:
+        selected("dw_mfma_wgrad_kernel" if n % 3 == 1 else f"dw_mfma_wgrad_multi_kernel<{3 if n % 3 == 0 else 2}>", f"dw wgrad of {n} {case}")
+    refs = [orc.conv2d_wgrad(x, g, (Cc, 1, k, k), pad=p, dil=d, groups=Cc) for g in gs]
+    for i, (dw, ref) in enumerate(zip(dws, refs)):
+        assert_close(dw.cpu().numpy(), ref, dt, f"dw wgrad of {n}, branch {i}")
+    K.dwconv_wgrad_multi(xd, gd, dws, k, p, d, accumulate=True)
+    for i, (dw, ref) in enumerate(zip(dws, refs)):
+        assert_close(dw.cpu().numpy(), 2 * ref, dt, f"dw wgrad of {n} accumulate, branch {i}")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [
     (2, 24, 32, 16, 9, 20, 5, 3), (1, 140, 270, 32, 9, 20, 5, 3), (1, 40, 70, 16, 9, 4, 1, 2), (2, 64, 128, 48, 9, 20, 5, 3),
     (1, 23, 37, 72, 9, 20, 5, 3), (1, 24, 32, 16, 9, 20, 5, 5), (1, 8, 8, 16, 3, 1, 1, 2),
 ])

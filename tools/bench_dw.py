@@ -50,7 +50,12 @@ for C in (512, 1024, 2048, 4096):
         print(f"dw fan-out 3 (one launch) C={C:5d}: {ms:7.3f} ms")
         ms = t(lambda: [ops.dwconv(x, wt, k, p, d, out=o) for o in ys])
         print(f"dw fan-out 3 (3 launches) C={C:5d}: {ms:7.3f} ms")
-        del g2, g3, ys
+        dws = [torch.empty_like(w) for _ in range(3)]
+        ms = t(lambda: ops.dwconv_wgrad_multi(x, [g, g2, g3], dws, k, p, d))
+        print(f"dw wgrad of 3 (one launch)  C={C:5d}: {ms:7.3f} ms  {3 * fl/ms/1e9:7.1f} TFLOP/s")
+        ms = t(lambda: [ops.dwconv_wgrad(x, gg, o, k, p, d, workspace=ws) for gg, o in zip((g, g2, g3), dws)])
+        print(f"dw wgrad of 3 (3 launches)  C={C:5d}: {ms:7.3f} ms")
+        del g2, g3, ys, dws
     ms = t(lambda: ops.dwconv_wgrad(x, g, dw, k, p, d, workspace=ws))
     print(f"dw wgrad C={C:5d}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TFLOP/s")
 

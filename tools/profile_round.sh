@@ -9,7 +9,7 @@ tag=${1:-prof}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
-B="python bench.py --no-cpu-baseline --no-batch-sweep"
+B="python bench.py --no-cpu-baseline --no-batch-sweep --no-sub-records"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/profA -o modeA -- $B --steps 5 --warmup 2 > $out/a.log 2>&1 || exit 1
 echo "[profile] mode A stats done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/profB -o modeB -- $B --steps 5 --warmup 2 --mode B > $out/b.log 2>&1 || exit 1
