@@ -30,6 +30,7 @@ Design (MI355X-first, not a module-by-module translation):
 Parameters are read from the nn.Module tree (fp32 masters, reference checkpoint keys); packed
 operands are cached per parameter version, so frozen weights are packed once.
 """
+import itertools
 import os
 
 import torch
@@ -37,7 +38,7 @@ from torch import nn
 
 from . import ops
 from ._lib import KD_PACK_DGRAD, KD_PACK_FWD
-from .models.students.transform_blocks import DepthwiseSeparableBlock
+from .models.students.transform_blocks import DepthwiseSeparableBlock, GateLayer
 from .models.wider_resnet import IdentityResidualBlock
 
 _SMALL_CONV = os.environ.get("KDCC_SMALL_CONV", "1") != "0"  # A/B: 0 = GSCNN res2 / res3 zero-padded to 64 channels on the GEMM kernels
@@ -50,6 +51,9 @@ class EngineError(RuntimeError):
     pass
 
 
+_FOLD_SERIAL = itertools.count(1)   # identity of a folded (scale, shift) pair: tensor addresses are recycled by the allocator
+
+
 def _is_trainable(mod):
     return any(p.requires_grad for p in mod.parameters())
 
@@ -58,12 +62,30 @@ def _bn_of(bn_seq):
     return bn_seq[0] if isinstance(bn_seq, nn.Sequential) else bn_seq
 
 
+def _gate_split(mod):
+    """Sequential(block, GateLayer), as TaylorPruneStudent.replace builds it (models/students/taylor_prune_student.py:37-40 of
+    the reference) -> (block, gate); anything else -> (mod, None)."""
+    if isinstance(mod, nn.Sequential) and len(mod) == 2 and isinstance(mod[1], GateLayer):
+        return mod[0], mod[1]
+    return mod, None
+
+
+def _act_gate(bn_seq):
+    """The gate behind the ReLU of a bnrelu Sequential(BatchNorm2d, ReLU) -- i.e. Sequential(BN, Sequential(ReLU, GateLayer))."""
+    if isinstance(bn_seq, nn.Sequential) and len(bn_seq) > 1:
+        return _gate_split(bn_seq[1])[1]
+    return None
+
+
 class _Site:
     """One convolution site of a residual block / ASPP branch: dense nn.Conv2d or a cheap-conv block."""
 
     def __init__(self, name, mod):
+        mod, self.gate = _gate_split(mod)     # a Taylor gate behind the conv: folded into its packed weights
         self.name, self.mod = name, mod
         self.cheap = isinstance(mod, DepthwiseSeparableBlock)
+        if self.cheap and self.gate is not None:
+            raise EngineError(f"{name}: a gate behind a cheap-conv block is not supported (gates rank the TEACHER's filters)")
         if not self.cheap and not isinstance(mod, nn.Conv2d):
             raise EngineError(f"{name}: unsupported module {type(mod).__name__} in the student graph")
         conv = mod.pointwise_conv if self.cheap else mod
@@ -77,7 +99,7 @@ class _Site:
             if conv.bias is not None or conv.groups != 1:
                 raise EngineError(f"{name}: only bias-free dense convs are supported")
             self.k, self.pad, self.dil, self.stride = conv.kernel_size[0], conv.padding[0], conv.dilation[0], conv.stride[0]
-        self.trainable = _is_trainable(mod)
+        self.trainable = _is_trainable(mod) or (self.gate is not None and self.gate.weight.requires_grad)
 
 
 class StudentEngine:
@@ -130,15 +152,16 @@ class StudentEngine:
             self.reducer.grad_ready(p)
 
     # ------------------------------------------------------------------ parameter operands
-    def _packed(self, p, tag, fn):
+    def _packed(self, p, tag, fn, extra=None):
         # keyed by id(p), but the entry holds p itself: a Parameter freed by a later replace() cannot hand its id (and a
         # matching small _version) to a new one while the entry is alive, and `ent[2] is p` catches any other aliasing
         key = (id(p), tag)
         ent = self._pack.get(key)
         if ent is not None:
             first = ent[1][0] if isinstance(ent[1], tuple) else ent[1]
-        if ent is None or ent[2] is not p or ent[0] != p._version or first.device != p.device:
-            ent = (p._version, fn(), p)
+        ver = p._version if extra is None else (p._version, extra)   # extra: e.g. the version of a gate folded into the pack
+        if ent is None or ent[2] is not p or ent[0] != ver or first.device != p.device:
+            ent = (ver, fn(), p)
             self._pack[key] = ent
         return ent[1]
 
@@ -148,24 +171,29 @@ class StudentEngine:
         self._bn.clear()
         self._persist.clear()
 
-    def _w_fwd(self, conv, cin_pad=None, cin_rot=0, cout_pad=None):
+    def _w_fwd(self, conv, cin_pad=None, cin_rot=0, cout_pad=None, gate=None):
         """cin_rot = r: the conv reads its input channels rotated left by r (engine buffer order [r:], [:r]) -- the decoder keeps
         its concat as [upsampled | fine] so that the 512-B-per-pixel upsample output starts on a 128-B line.  cout_pad: zero
         filters appended up to that many outputs (bot_fine writes the concat buffer's pad channels as zeros itself)."""
         def make():
             w = conv.weight if not cin_rot else torch.cat([conv.weight.detach()[:, cin_rot:], conv.weight.detach()[:, :cin_rot]], 1).contiguous()
+            if gate is not None:   # y * g[c] == conv with the filters of output channel c scaled by g[c]
+                w = w.detach().float() * gate.weight.detach().float().view(-1, 1, 1, 1)
             if cout_pad is not None and cout_pad > w.shape[0]:
                 wp = torch.zeros((cout_pad,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
                 wp[:w.shape[0]] = w.detach()
                 w = wp
             return ops.pack_conv_weight(w, self.dtype, KD_PACK_FWD, cin_pad)
-        return self._packed(conv.weight, ("fwd", self.dtype, cin_pad, cin_rot, cout_pad), make)
+        return self._packed(conv.weight, ("fwd", self.dtype, cin_pad, cin_rot, cout_pad, id(gate) if gate is not None else None), make,
+                            extra=gate.weight._version if gate is not None else None)
 
-    def _w_dgrad(self, conv, cout_pad=None, cin_rot=0):
+    def _w_dgrad(self, conv, cout_pad=None, cin_rot=0, gate=None):
         """[Cin][flipped taps][Cout] operand of the input-gradient conv; cout_pad zero-fills the contraction axis up to the
         GEMM's K granule (the 19-class classifier, the 48-channel bot_fine)."""
         def make():
             w = conv.weight.detach()
+            if gate is not None:
+                w = w.float() * gate.weight.detach().float().view(-1, 1, 1, 1)
             if cin_rot:
                 w = torch.cat([w[:, cin_rot:], w[:, :cin_rot]], 1).contiguous()
             if cout_pad is not None and cout_pad != w.shape[0]:
@@ -173,7 +201,8 @@ class StudentEngine:
                 wp[:w.shape[0]] = w
                 w = wp
             return ops.pack_conv_weight(w, self.dtype, KD_PACK_DGRAD)
-        return self._packed(conv.weight, ("dgrad", self.dtype, cout_pad, cin_rot), make)
+        return self._packed(conv.weight, ("dgrad", self.dtype, cout_pad, cin_rot, id(gate) if gate is not None else None), make,
+                            extra=gate.weight._version if gate is not None else None)
 
     def _w_dw(self, conv, flip):
         return self._packed(conv.weight, ("dw", flip), lambda: ops.pack_dw_weight(conv.weight, flip))
@@ -189,6 +218,26 @@ class StudentEngine:
         ent = self._bn.get(key)
         if ent is None or ent[2] is not bn or ent[0] != ver:
             ent = (ver, ops.bn_fold(bn), bn)
+            ent[1][0]._kd_serial = next(_FOLD_SERIAL)
+            self._bn[key] = ent
+        return ent[1]
+
+    def _act_fold(self, bn, gate):
+        """(scale, shift) of the epilogue relu(y * scale + shift) for BN -> ReLU -> gate: relu(bn(y)) * g == relu(bn(y) * g)
+        for g > 0, so the gate multiplies the folded scale and shift.  gate None: the plain BN fold."""
+        scale, shift = self._bn_fold(bn)
+        if gate is None:
+            return scale, shift
+        key = ("gated", id(_bn_of(bn)), id(gate))
+        ver = (scale._kd_serial, gate.weight._version, gate.weight.device)
+        ent = self._bn.get(key)
+        if ent is None or ent[0] != ver or ent[2] is not gate:
+            g = gate.weight.detach().float()
+            if not bool((g > 0).all()):     # one host sync per gate update; Taylor ranking is not the measured path
+                raise EngineError("a gate behind a ReLU must stay positive to be folded into the BN+ReLU epilogue "
+                                  "(gates start at 1 and the reference's optimizer moves them by ~1e-5 per step)")
+            ent = (ver, ((scale * g).contiguous(), (shift * g).contiguous()), gate)
+            ent[1][0]._kd_serial = next(_FOLD_SERIAL)
             self._bn[key] = ent
         return ent[1]
 
@@ -370,9 +419,10 @@ class StudentEngine:
                     mids.update({i: o for (i, _), o in zip(members, outs)})
         for i, br in enumerate(aspp.features):
             site = _Site(f"aspp.features.{i}.0", br[0])
-            sc, sh = self._bn_fold(br[1])
+            act_gate = _gate_split(br[2])[1] if len(br) > 2 else None       # `aspp.features.N.2`: a gate behind the branch's ReLU
+            sc, sh = self._act_fold(br[1], act_gate)
             hinted = site.name in want
-            probed = site.name in self._probes
+            probed = site.name in self._probes or site.gate is not None
             raw = self._new(N, h8, w8, red) if (hinted or probed) else None
             out = cat[..., red * (i + lead):red * (i + lead + 1)]
             mid = None
@@ -383,12 +433,12 @@ class StudentEngine:
                 ops.conv2d(mid, self._w_fwd(site.mod.pointwise_conv), out_raw=raw, out_act=out, act_scale=sc, act_shift=sh,
                            act_relu=True)
             else:
-                ops.conv2d(x7, self._w_fwd(site.mod), 1, site.pad, site.dil, out_raw=raw, out_act=out, act_scale=sc,
+                ops.conv2d(x7, self._w_fwd(site.mod, gate=site.gate), 1, site.pad, site.dil, out_raw=raw, out_act=out, act_scale=sc,
                            act_shift=sh, act_relu=True)
             if hinted:
                 note_hint(site.name, raw, ("aspp", i))
-            arec["branches"].append({"site": site, "mid": mid, "bn": br[1], "probe_raw": raw if probed else None})
-            rg_cat = rg_cat or site.trainable or _is_trainable(br[1]) or probed
+            arec["branches"].append({"site": site, "mid": mid, "bn": br[1], "probe_raw": raw if probed else None, "act_gate": act_gate})
+            rg_cat = rg_cat or site.trainable or _is_trainable(br[1]) or probed or act_gate is not None
         if "aspp" in want:
             note_hint("aspp", cat, ("aspp_out",))
         tape["aspp"] = arec
@@ -574,7 +624,7 @@ class StudentEngine:
             # hook on either observes the tensor the in-place add turns into the block output; cfg/cityscapes/
             # 51M_deeplab_incremental.json uses 'mod4.block2.convs' and 'mod7.block1')
             hinted = site.name in want or (last and (f"{name}.convs" in want or name in want))
-            probed = site.name in self._probes
+            probed = site.name in self._probes or site.gate is not None
             kw = {}
             if last:
                 want_raw = need_raw or hinted or probed
@@ -587,7 +637,7 @@ class StudentEngine:
                 kw["out_raw"] = raw
                 x_out = raw
             else:
-                sc, sh = self._bn_fold(bns[f"bn{i + 2}"])
+                sc, sh = self._act_fold(bns[f"bn{i + 2}"], _act_gate(bns[f"bn{i + 2}"]))
                 act = self._new(N, ho, wo, site.cout)
                 raw = self._new(N, ho, wo, site.cout) if (hinted or probed) else None
                 kw.update(out_raw=raw, out_act=act, act_scale=sc, act_shift=sh, act_relu=True)
@@ -596,7 +646,7 @@ class StudentEngine:
                 ops.conv2d(mid, self._w_fwd(site.mod.pointwise_conv), **kw)
             else:
                 mid = None
-                ops.conv2d(a, self._w_fwd(site.mod), site.stride, site.pad, site.dil, **kw)
+                ops.conv2d(a, self._w_fwd(site.mod, gate=site.gate), site.stride, site.pad, site.dil, **kw)
             rec["mid"].append(mid)
             rg = rg or site.trainable or probed
             if probed:
@@ -630,20 +680,26 @@ class StudentEngine:
                     order.append(p)
 
         def add_conv(mod):
+            mod, gate = _gate_split(mod)
+            if gate is not None:
+                add_p(gate.weight)
             if isinstance(mod, DepthwiseSeparableBlock):
                 add_p(mod.pointwise_conv.weight, mod.separable_conv.weight)
             else:
                 add_p(mod.weight)
 
-        def add_bn(seq):
+        def add_bn(seq, gate=None):
             bn = _bn_of(seq)
+            gate = gate if gate is not None else _act_gate(seq)
+            if gate is not None:
+                add_p(gate.weight)
             add_p(bn.weight, bn.bias)
         f = self._final()
         add_conv(f[6]); add_bn(f[4]); add_conv(f[3]); add_bn(f[1]); add_conv(f[0])
         add_conv(net.bot_fine); add_conv(net.bot_aspp)
         add_bn(net.aspp.img_conv[1]); add_conv(net.aspp.img_conv[0])
         for br in net.aspp.features:
-            add_bn(br[1]); add_conv(br[0])
+            add_bn(br[1], _gate_split(br[2])[1] if len(br) > 2 else None); add_conv(br[0])
         for _, blk in reversed(self._flat_blocks()):
             items = list(blk.convs.named_children())
             for n, m in reversed(items):
@@ -746,17 +802,25 @@ class StudentEngine:
             g = g.contiguous()
         return g
 
-    def _probe(self, name, g, raw, shortcut):
-        """d loss / d (unit channel gate behind the conv `name`) = sum_{n,h,w} y * dL/dy with y the conv's own output: the stored
-        raw tensor, minus the shortcut the epilogue added when the conv closes a residual block."""
+    def _probe(self, name, g, raw, shortcut, gate=None, grads=None):
+        """d loss / d (channel gate behind the conv `name`) = sum_{n,h,w} y * dL/d(y g) with y the conv's own output.  The
+        stored raw tensor is the GATED output y g (the gate lives in the packed weights), plus the shortcut the epilogue added
+        when the conv closes a residual block: sum (raw - shortcut) * dL/draw = g * dL/dg."""
         _, s2 = ops.channel_sums(g, a=raw)
         if shortcut is not None:
             _, s2b = ops.channel_sums(g, a=shortcut)
             s2 = s2 - s2b
+        if gate is not None:
+            s2 = s2 / gate.weight.detach().float()
+            if gate.weight.requires_grad and grads is not None:
+                gbuf = self._grad_like(gate.weight)
+                gbuf.copy_(s2)
+                grads[gate.weight] = gbuf
+                self._grad_done(gate.weight)
         self.probe_grads[name] = s2
 
     # ---- parameter gradients ------------------------------------------------------------------------------------------
-    def _conv_wgrad(self, conv, a_in, g, grads, cin=None, cin_rot=0):
+    def _conv_wgrad(self, conv, a_in, g, grads, cin=None, cin_rot=0, gate=None):
         """Weight gradient of a dense conv (a_in = its input as stored, g = gradient of its raw output).  cin_rot: a_in holds
         the conv's input channels rotated left by that many (see _w_fwd); the gradient is rotated back."""
         w = conv.weight
@@ -773,18 +837,32 @@ class StudentEngine:
             gw[:, :cin_rot].copy_(tmp[:, k:])
         else:
             ops.conv2d_wgrad(a_in, g, gw, conv.stride[0], conv.padding[0], conv.dilation[0])
+        if gate is not None:   # g is the gradient of the gated output: d(y g)/dW = g[c] * dy/dW
+            gw.mul_(gate.weight.detach().float().view(-1, 1, 1, 1))
         grads[w] = gw
         self._grad_done(w)
 
-    def _bn_param_grads(self, bn_seq, g_x, act, grads, sub=None):
+    def _bn_param_grads(self, bn_seq, g_x, act, grads, sub=None, gate=None):
         """Eval-mode BN weight/bias gradients.  g_x: gradient w.r.t. the BN input (already through the ReLU mask and the BN
-        scale; `sub` = a tensor that was added to it afterwards, e.g. the shortcut gradient), act = relu(bn(x))."""
+        scale; `sub` = a tensor that was added to it afterwards, e.g. the shortcut gradient), act = relu(bn(x)).
+        gate: a GateLayer behind the ReLU, folded into the epilogue (act = relu(bn(x)) * g, g_x carries scale * g): with
+        S1 = sum g_x, S2 = sum g_x * act, d loss / d gate = S2 / (scale g^2), and the BN gradients take S2 / g for S2."""
         bn = _bn_of(bn_seq)
-        if not (bn.weight.requires_grad or bn.bias.requires_grad):
+        want_gate = gate is not None and gate.weight.requires_grad
+        if not (bn.weight.requires_grad or bn.bias.requires_grad or want_gate):
             return
         scale, _ = self._bn_fold(bn_seq)
         s1, s2 = ops.channel_sums(g_x, sub=sub, a=act)
-        self._bn_grads_from_sums(bn, scale, s1, s2, grads)
+        if gate is not None:
+            gv = gate.weight.detach().float()
+            if want_gate:
+                gbuf = self._grad_like(gate.weight)
+                gbuf.copy_(torch.where(scale != 0, s2 / (scale * gv * gv), torch.zeros_like(s2)))
+                grads[gate.weight] = gbuf
+                self._grad_done(gate.weight)
+            s2 = s2 / gv
+        if bn.weight.requires_grad or bn.bias.requires_grad:
+            self._bn_grads_from_sums(bn, scale, s1, s2, grads)
 
     def _bn_grads_from_sums(self, bn, scale, s1, s2, grads):
         dg, db = self._grad_like(bn.weight), self._grad_like(bn.bias)
@@ -807,7 +885,7 @@ class StudentEngine:
             g = ops.zero_insert(g, site.stride, in_hw)
             H, W = in_hw
         out = self._new(N, H, W, conv.in_channels)
-        ops.conv2d(g, self._w_dgrad(conv), 1, site.dil * (site.k - 1) - site.pad, site.dil, out_raw=out, **ep)
+        ops.conv2d(g, self._w_dgrad(conv, gate=site.gate), 1, site.dil * (site.k - 1) - site.pad, site.dil, out_raw=out, **ep)
         return out
 
     def _cheap_bwd(self, site, a_in, mid, g, grads, need_in, defer=None, **ep):
@@ -843,7 +921,7 @@ class StudentEngine:
         """Weight gradient(s) of one conv site and, when need_in, its input gradient through epilogue `ep`."""
         if site.cheap:
             return self._cheap_bwd(site, a_in, mid, g, grads, need_in, **ep)
-        self._conv_wgrad(site.mod, a_in, g, grads)
+        self._conv_wgrad(site.mod, a_in, g, grads, gate=site.gate)
         if not need_in:
             return None
         return self._dense_dgrad(site, g, in_hw=(a_in.shape[1], a_in.shape[2]), **ep)
@@ -858,10 +936,11 @@ class StudentEngine:
             site, a_in, need_in = sites[i], rec["a_in"][i], rec["rg_a"][i]
             g_in = None
             bn_seq = bns[f"bn{i + 1}"] if i > 0 else blk.bn1
+            act_gate = _act_gate(bn_seq) if i > 0 else None     # a_in = relu(bn(c_{i-1})) * gate
             if g is not None and i in rec.get("probe", {}):
-                self._probe(site.name, g, *rec["probe"][i])
+                self._probe(site.name, g, *rec["probe"][i], gate=site.gate, grads=grads)
             if g is not None and (need_in or site.trainable):
-                sc, _ = self._bn_fold(bn_seq)
+                sc, _ = self._act_fold(bn_seq, act_gate)
                 ep = dict(mask=a_in, mask_scale=sc)
                 sub = None
                 if i > 0:
@@ -879,7 +958,7 @@ class StudentEngine:
                         ep["res_post"] = g_out
                 g_in = self._site_bwd(site, a_in, rec["mid"][i], g, grads, need_in, **ep)
                 if g_in is not None:
-                    self._bn_param_grads(bn_seq, g_in, a_in, grads, sub=sub)
+                    self._bn_param_grads(bn_seq, g_in, a_in, grads, sub=sub, gate=act_gate)
             elif i == 0 and g is None and g_out is not None:
                 # only the shortcut carries gradient into this block's input
                 if rec["proj"]:
@@ -923,13 +1002,13 @@ class StudentEngine:
             g = g_aspp.get(i)
             if g_cat is not None:
                 gi = g_cat[..., sl]
-                self._bn_param_grads(br["bn"], gi, cat[..., sl], grads)
+                self._bn_param_grads(br["bn"], gi, cat[..., sl], grads, gate=br.get("act_gate"))
                 g = gi if g is None else g + gi
             if g is None:
                 continue
             site = br["site"]
             if br.get("probe_raw") is not None:
-                self._probe(site.name, g, br["probe_raw"], None)
+                self._probe(site.name, g, br["probe_raw"], None, gate=site.gate, grads=grads)
             if site.cheap and not g.is_contiguous():
                 g = g.contiguous()   # the depthwise / pointwise-wgrad kernels take dense views
             todo.append((site, br, g))
@@ -971,12 +1050,13 @@ class StudentEngine:
 
     def _cat_scale(self, aspp):
         """BN scales of [image branch, features 0..] concatenated: the mask_scale of the concat buffer."""
-        bns = [aspp.img_conv[1]] + ([aspp.edge_conv[1]] if hasattr(aspp, "edge_conv") else []) + [br[1] for br in aspp.features]
-        key = tuple(id(_bn_of(b)) for b in bns)
-        vers = tuple(self._bn_fold(b)[0].data_ptr() for b in bns)
+        bns = [(aspp.img_conv[1], None)] + ([(aspp.edge_conv[1], None)] if hasattr(aspp, "edge_conv") else []) + \
+              [(br[1], _gate_split(br[2])[1] if len(br) > 2 else None) for br in aspp.features]
+        key = tuple(id(_bn_of(b)) for b, _ in bns)
+        vers = tuple(self._act_fold(b, gt)[0]._kd_serial for b, gt in bns)
         ent = self._bn.get(("cat", key))
         if ent is None or ent[0] != vers:
-            ent = (vers, (torch.cat([self._bn_fold(b)[0] for b in bns]).contiguous(), None), None)
+            ent = (vers, (torch.cat([self._act_fold(b, gt)[0] for b, gt in bns]).contiguous(), None), None)
             self._bn[("cat", key)] = ent
         return ent[1][0]
 

@@ -247,65 +247,87 @@ class DepthwiseStudent(nn.Module):
         return pred
 
     @staticmethod
-    def sliding_windows(h, w, crop_size, overlap=1 / 3):
-        """Window boxes (x1, y1, x2, y2) of the reference's tiling (utils/tta_process.py:68-101): square crop_size tiles,
-        stride ceil(crop * (1 - overlap)), the last tile of a row / column pulled back inside the image."""
+    def sliding_windows(h, w, tile, overlap=1 / 3):
+        """Window boxes (x1, y1, x2, y2) of the reference's tiling (utils/tta_process.py:68-101), in its order (x outer, y
+        inner): square `tile`-sized windows, stride ceil(tile * (1 - overlap)), the last window of a row / column pulled back
+        inside the image, windows clipped to the image when it is smaller than the tile."""
         from math import ceil
-        stride = ceil(crop_size * (1 - overlap))
-        n_x = int(ceil((w - crop_size) / stride) + 1)
-        n_y = int(ceil((h - crop_size) / stride) + 1)
+        stride = ceil(tile * (1 - overlap))
+        n_x = max(int(ceil((w - tile) / stride) + 1), 1)
+        n_y = max(int(ceil((h - tile) / stride) + 1), 1)
         boxes = []
         for ix in range(n_x):
             for iy in range(n_y):
-                x2, y2 = min(ix * stride + crop_size, w), min(iy * stride + crop_size, h)
-                boxes.append((max(x2 - crop_size, 0), max(y2 - crop_size, 0), x2, y2))
+                x2, y2 = min(ix * stride + tile, w), min(iy * stride + tile, h)
+                boxes.append((max(x2 - tile, 0), max(y2 - tile, 0), x2, y2))
         return boxes
 
     def inference_test(self, data, args, max_windows_per_pass=8):
-        """Sliding-window + horizontal-flip test-time inference of the student (reference depthwise_student.py:187-206 with
-        utils/tta_process.py), entirely on the device: the windows of the image and of its mirror image go through the
-        student in batches, their logits are summed into full-frame maps and divided by the per-pixel window count, the
-        mirrored map is flipped back and the two are averaged.  data: normalised (N,3,H,W) batch, as the trainer feeds it.
+        """Multi-scale sliding-window + horizontal-flip test-time inference of the student (reference depthwise_student.py:187-206
+        with utils/tta_process.py), entirely on the device.  Per scale: the image and its mirror image are cut into the
+        reference's windows (tile = int(scale * crop_size)), the windows go through the student in batches, their logits are
+        summed into full-frame maps and divided by the window count, the mirrored map is flipped back, both are resized to the
+        original size and averaged; the scales are averaged.  data: normalised (N,3,H,W) batch, as the trainer feeds it.
 
-        Differences from the reference, on purpose: (1) only `scales == [1.0]` (every shipped config): other scales go
-        through PIL / cv2 resampling there, arithmetic that lives in un-vendored libraries; (2) the reference divides by a
-        window count it indexes as [class, row] instead of [row, column] (tta_process.py:41-48: `count_predictions[y1:y2,
-        x1:x2]` on a (C,h,w) array), i.e. a per-pixel positive rescaling of the logits that leaves the arg-max -- hence the
-        mIoU and the submission -- unchanged; here the count is the true per-pixel one."""
+        args: {scales, crop_size[, window_count]}.  window_count = "reference" (default) reproduces the reference's count array
+        bit for bit: it is allocated (C,h,w) and indexed `count[y1:y2, x1:x2] += 1` (tta_process.py:41-48), i.e. classes y1..y2
+        and rows x1..x2 of ALL columns -- for the shipped 1024x2048 / crop 1024 case a per-row factor that leaves the arg-max
+        alone; pinned against the reference's own reverse_mapping (tests/golden/tta.npz).  window_count = "pixel" divides by the
+        true per-pixel number of windows instead.
+
+        Resampling (scales != 1.0) is done on the normalised float tensor with bilinear interpolation at half-pixel centres
+        (anti-aliased when shrinking, like PIL's BILINEAR); the reference resamples the uint8 PIL image and cv2-resizes the
+        logits -- same geometry, not the same rounding, so scaled passes are close to, not bit-identical with, the reference.
+        Every shipped config uses scales = [1.0], which involves no resampling at all."""
+        import torch.nn.functional as F
         self.student_hidden_outputs = []
         self.teacher_hidden_outputs = []
-        scales = list(args.get('scales', [1.0]))
-        if any(abs(float(sc) - 1.0) > 1e-9 for sc in scales):
-            raise NotImplementedError("inference_test: only scales == [1.0] (resampled scales need PIL/cv2 arithmetic)")
+        scales = [float(sc) for sc in args.get('scales', [1.0])]
         crop = int(args['crop_size'])
+        mode = str(args.get('window_count', 'reference'))
+        if mode not in ('reference', 'pixel'):
+            raise ValueError("test.args.window_count must be 'reference' or 'pixel'")
         N, _, H, W = data.shape
-        crop_h, crop_w = min(crop, H), min(crop, W)
-        if crop_h != crop_w:
-            crop_h = crop_w = min(crop_h, crop_w)
-        boxes = self.sliding_windows(H, W, crop_h)
         outs = []
         with torch.no_grad():
             for n in range(N):
                 img = data[n:n + 1]
-                acc = None
-                for flipped in (False, True):
-                    src = torch.flip(img, dims=[3]) if flipped else img
-                    full = cnt = None
-                    for i in range(0, len(boxes), max_windows_per_pass):
-                        part = boxes[i:i + max_windows_per_pass]
-                        wins = torch.cat([src[:, :, y1:y2, x1:x2] for (x1, y1, x2, y2) in part], 0).contiguous()
-                        logits = self.inference(wins).float()
-                        if full is None:
-                            full = torch.zeros((logits.shape[1], H, W), dtype=torch.float32, device=data.device)
-                            cnt = torch.zeros((1, H, W), dtype=torch.float32, device=data.device)
-                        for j, (x1, y1, x2, y2) in enumerate(part):
-                            full[:, y1:y2, x1:x2] += logits[j]
-                            cnt[:, y1:y2, x1:x2] += 1
-                    full = full / cnt
-                    if flipped:
-                        full = torch.flip(full, dims=[2])
-                    acc = full if acc is None else (acc + full) / 2
-                outs.append(acc.unsqueeze(0))
+                per_scale = []
+                for scale in scales:
+                    if abs(scale - 1.0) < 1e-9:
+                        img_s = img
+                    else:
+                        img_s = F.interpolate(img.float(), size=(int(H * scale), int(W * scale)), mode='bilinear', align_corners=False,
+                                              antialias=scale < 1.0).to(img.dtype)
+                    hs, ws = img_s.shape[2:]
+                    boxes = self.sliding_windows(hs, ws, int(scale * crop))
+                    acc = None
+                    for flipped in (False, True):
+                        src = torch.flip(img_s, dims=[3]) if flipped else img_s
+                        full = cnt = None
+                        for i in range(0, len(boxes), max_windows_per_pass):
+                            part = boxes[i:i + max_windows_per_pass]
+                            wins = torch.cat([src[:, :, y1:y2, x1:x2] for (x1, y1, x2, y2) in part], 0).contiguous()
+                            logits = self.inference(wins).float()
+                            if full is None:
+                                C = logits.shape[1]
+                                full = torch.zeros((C, hs, ws), dtype=torch.float32, device=data.device)
+                                cnt = torch.zeros((C, hs, ws) if mode == 'reference' else (1, hs, ws), dtype=torch.float32,
+                                                  device=data.device)
+                            for j, (x1, y1, x2, y2) in enumerate(part):
+                                full[:, y1:y2, x1:x2] += logits[j][:, :y2 - y1, :x2 - x1]
+                                if mode == 'reference':
+                                    cnt[y1:y2, x1:x2] += 1       # the reference's indexing: [class, row] of a (C,h,w) array
+                                else:
+                                    cnt[:, y1:y2, x1:x2] += 1
+                        full = full / cnt
+                        if flipped:
+                            full = torch.flip(full, dims=[2])
+                        if (hs, ws) != (H, W):
+                            full = F.interpolate(full.unsqueeze(0), size=(H, W), mode='bilinear', align_corners=False)[0]
+                        acc = full if acc is None else (acc + full) / 2
+                    per_scale.append(acc)
+                outs.append(torch.stack(per_scale).mean(0).unsqueeze(0))
         return torch.cat(outs, 0)
 
     # ------------------------------------------------------------------ bookkeeping

@@ -1,28 +1,29 @@
-"""`TaylorPruneStudent`: first-order Taylor importance of the filters of named convs (reference
-models/students/taylor_prune_student.py:9-66, transform_blocks/gate.py:5-12): the reference wraps a copy of the teacher block
-in Sequential(block, GateLayer) -- a per-channel multiplier initialised to 1 -- and reads importance = (gate * d loss/d gate)^2
-after loss.backward() (trainer/taylor_prune_trainer.py:204-211).
+"""`TaylorPruneStudent`: first-order Taylor importance of the filters behind named blocks (reference
+models/students/taylor_prune_student.py:9-66, transform_blocks/gate.py:5-12): `replace` swaps the named student block for
+Sequential(copy of the teacher's block, GateLayer) -- a trainable per-channel multiplier initialised to 1 -- and
+`get_gate_importance` reads (gate * d loss / d gate)^2 after loss.backward() (trainer/taylor_prune_trainer.py:204-211).
 
-Here the student graph is not edited at all: a unit gate does not change the forward, and its gradient
-d loss/d gate[c] = sum_{n,h,w} y[n,c,h,w] * dL/dy[n,c,h,w] is one per-channel reduction the engine performs during backward
-for the conv sites registered as probes (engine.StudentEngine.probe_names -> kd_channel_sums).  The GateLayer objects exist
-for API / bookkeeping parity (`added_gates`, `num_features`, `.weight`, `.weight.grad`).  Deviation, on purpose: the gates
-are not handed to the optimizer, so they stay exactly 1 (the reference's optimizer nudges them every step, which perturbs the
-very network whose filters are being ranked).  Gates can be placed behind convs (block conv sites, ASPP branch convs)."""
+Same module surgery, parameters and state-dict keys as the reference (`<block>.0.*` = the copied block, `<block>.1.weight` =
+the gate), so the gates are student parameters: the trainer's optimizer holds and steps them, and `.grad` accumulates across
+backward calls exactly as autograd does there.  Execution differs: the fused engine never runs a gate as a kernel.  A gate
+behind a conv is folded into that conv's packed weights (forward and input gradient), a gate behind a BN+ReLU into the
+epilogue's scale / shift (positive gates: relu(y) * g == relu(y * g)); the gate gradients are per-channel reductions the
+engine performs during backward (sum y * dL/dy / g behind a conv; the BN-parameter channel sums behind a ReLU).
+
+Gate sites the fused graph supports -- every class cfg/taylor_importance_track.json uses: a block's conv
+(`modN.blockM.convs.convK`), the ReLU of a bnrelu inside a block (`modN.blockM.convs.bnK.1`), an ASPP branch's conv or ReLU
+(`aspp.features.N.0`, `aspp.features.N.2`).  Anything else is refused when the plan is applied."""
+import copy
+import re
+
 import torch
 from torch import nn
 
 from .depthwise_student import DepthwiseStudent
+from .transform_blocks import GateLayer  # noqa: F401  (re-exported: reference code imports it from here)
 
-
-class GateLayer(nn.Module):
-    def __init__(self, num_features):
-        super().__init__()
-        self.num_features = num_features
-        self.weight = nn.Parameter(torch.ones(num_features))
-
-    def forward(self, input):
-        return input * self.weight.view(1, -1, 1, 1)
+_CONV_SITE = re.compile(r"^(mod[2-7]\.block\d+\.convs\.conv\d+|aspp\.features\.\d+\.0)$")
+_RELU_SITE = re.compile(r"^(mod[2-7]\.block\d+\.convs\.bn\d+\.1|aspp\.features\.\d+\.2)$")
 
 
 class TaylorPruneStudent(DepthwiseStudent):
@@ -30,37 +31,46 @@ class TaylorPruneStudent(DepthwiseStudent):
         super().__init__(teacher_model, config, dtype=dtype)
         self.added_gates = dict()
 
+    def _channels_behind(self, name, block):
+        """Channel count of the tensor the gate multiplies; raises for a site the fused graph cannot fold a gate into."""
+        if self.fused:
+            if _CONV_SITE.match(name) and isinstance(block, nn.Conv2d):
+                return block.out_channels
+            if _RELU_SITE.match(name) and isinstance(block, nn.ReLU):
+                parent = self.get_block(name.rsplit('.', 1)[0], self.teacher)
+                return parent[int(name.rsplit('.', 1)[1]) - 1].num_features     # the BatchNorm2d in front of the ReLU
+            raise ValueError(f"{name}: the fused student graph folds gates behind block convs (`...convs.convK`), bnrelu ReLUs "
+                             f"(`...convs.bnK.1`) and ASPP branch convs / ReLUs (`aspp.features.N.0|2`) only")
+        return None
+
     def replace(self, blocks, **kwargs):
-        """blocks: [{"name": conv site, "epoch": e, "num_features": C}] -- registers a gate (probe) behind each named conv."""
+        """blocks: [{"name": block, "epoch": e, "num_features": C}] -- the named student block becomes
+        Sequential(copy of the teacher's block, GateLayer(C)) (reference :21-43)."""
         for block in blocks:
-            name = block['name']
-            conv = self.get_block(name, self.teacher)
-            if not isinstance(conv, nn.Conv2d) or conv.out_channels != block['num_features']:
-                raise ValueError(f"{name}: a gate needs a conv with num_features = out_channels "
-                                 f"(got {type(conv).__name__}, num_features {block['num_features']})")
+            name, num_features = block['name'], block['num_features']
+            teacher_block = self.get_block(name, self.teacher)
+            channels = self._channels_behind(name, teacher_block)
+            if channels is not None and channels != num_features:
+                raise ValueError(f"{name}: num_features {num_features} != {channels} channels behind the block")
             self.replaced_block_names.append(name)
             ref = next(self.student.parameters())
-            self.added_gates[name] = GateLayer(block['num_features']).to(ref.device)
-
-    def _student_engine(self):
-        eng = super()._student_engine()
-        eng.probe_names = list(self.added_gates)
-        return eng
+            gate = GateLayer(num_features).to(ref.device)
+            self.added_gates[name] = gate
+            # (the copied block keeps the frozen teacher's parameters: requires_grad False, like the reference)
+            self._set_block(name, nn.Sequential(copy.deepcopy(teacher_block).float().to(ref.device), gate), self.student)
+        if self._engine is not None:
+            self._engine.drop_caches()
 
     def reset(self):
-        self._remove_hooks()
-        self.hint_block_names = []
-        self.replaced_block_names = []
+        super().reset()
         self.added_gates = dict()
 
     def get_gate_importance(self):
-        """{gate name: (gate * d loss/d gate)^2 as a numpy vector} for the last backward (reference :58-66)."""
-        eng = self._student_engine()
+        """{gate name: (gate * gate.grad)^2 as a numpy vector} (reference :58-66); gate.grad is whatever autograd has
+        accumulated since the optimizer last zeroed it."""
         out = {}
         for name, gate in self.added_gates.items():
-            g = eng.probe_grads.get(name)
-            if g is None:
+            if gate.weight.grad is None:
                 raise RuntimeError(f"no gradient reached the gate behind {name}: call loss.backward() on a loss of the student logits first")
-            gate.weight.grad = g.detach().to(gate.weight.device).clone()
-            out[name] = ((gate.weight.detach() * gate.weight.grad) ** 2).cpu().numpy()
+            out[name] = ((gate.weight.detach() * gate.weight.grad) ** 2).detach().cpu().numpy()
         return out

@@ -78,3 +78,18 @@ class DepthwiseSeparableBlock(nn.Module):
             return conv2d(mid, self.pointwise_conv.weight, self.pointwise_conv.bias)
         return _DwSepFunction.apply(x, self.separable_conv.weight, self.pointwise_conv.weight, self.separable_conv.bias,
                                     self.pointwise_conv.bias, k, pad, dil)
+
+
+class GateLayer(nn.Module):
+    """Per-channel multiplier initialised to 1 (models/students/transform_blocks/gate.py:5-12): what TaylorPruneStudent puts
+    behind a block to read its filters' Taylor importance, (gate * d loss / d gate)^2.  A trainable parameter, as in the
+    reference -- its optimizer steps it.  Inside the fused student graph the engine folds it into the neighbouring kernel
+    (a conv's packed weights or a BN+ReLU epilogue's scale / shift) and produces its gradient during backward."""
+
+    def __init__(self, num_features):
+        super().__init__()
+        self.num_features = num_features
+        self.weight = nn.Parameter(torch.ones(num_features))
+
+    def forward(self, input):
+        return input * self.weight.view(1, -1, 1, 1)

@@ -347,6 +347,6 @@ class LayerwiseTrainer(BaseTrainer):
         if checkpoint['config']['optimizer']['type'] != self.config['optimizer']['type']:
             self.logger.warning("Warning: Optimizer type given in config file is different from that of checkpoint. "
                                 "Optimizer parameters not being resumed.")
-        else:
+        elif self.optimizer is not None and checkpoint.get('optimizer') is not None:
             self.optimizer.load_state_dict(checkpoint['optimizer'])
         self.logger.info("Checkpoint loaded. Resume training from epoch {}".format(self.start_epoch))

@@ -1,17 +1,24 @@
-"""`TaylorPruneTrainer`: tracks the Taylor importance of the filters behind the gated convs while running the student on
-the supervised loss (reference trainer/taylor_prune_trainer.py:181-288): per step loss = CrossEntropyLoss2d(student logits,
-target), loss.backward(), importance = (gate * d loss/d gate)^2 accumulated by ImportanceFilterTracker and dumped as
-`importance_filter_ep{E}_batch_idx{B}.pth` every `trainer.importance_log_interval` steps -- the table
-`trainer.hint_filter_weight` of LayerwiseTrainer consumes for WeightedHintMSELoss (BASELINE config 4's principled weights).
+"""`TaylorPruneTrainer`: ranks the filters behind gated blocks by their first-order Taylor importance while the student runs
+on the supervised loss (reference trainer/taylor_prune_trainer.py:18-288).  Per step: loss = CrossEntropyLoss2d(student
+logits, target); loss.backward(); importance = (gate * gate.grad)^2 goes to ImportanceFilterTracker; the optimizer -- built at
+epoch 1 from the student parameters that require grad, i.e. the gates (:152-162) -- steps and zeroes the gradients every
+`accumulation_steps` batches (:212-215; with the shipped accumulation_steps = 100000 that is batch 0 of each epoch only, so
+gate.grad keeps accumulating in between, exactly as autograd does there).  Every `importance_log_interval` steps the running
+table is dumped as `importance_filter_ep{E}_batch_idx{B}.pth` -- what `trainer.hint_filter_weight` of LayerwiseTrainer
+consumes for WeightedHintMSELoss (BASELINE config 4's principled weights).
 
-Same constructor as LayerwiseTrainer; `pruning.pruning_plan` entries carry `num_features`.  The gates are probes, not
-parameters (models/students/taylor_prune_student.py), so with a frozen student there is nothing for the optimizer to
-update and no optimizer is built; if the plan unfreezes layers they train on the supervised loss as in the reference."""
+Same constructor and config keys as the reference; cfg/taylor_importance_track.json runs as shipped: `pruning` needs only
+`args` and `pruning_plan` (`unfreeze` is optional here -- the reference indexes it unconditionally and raises KeyError at the
+second plan epoch), validation / best-model monitoring / the plateau scheduler follow LayerwiseTrainer's epoch tail, and with
+several ranks the gate gradients are averaged like every other gradient (the engine's GradReducer), so every rank accumulates
+the same importances."""
 import os
 
 import torch
 
+from ..parallel import mean_scalar
 from ..utils import ImportanceFilterTracker
+from ..utils.optim.lr_scheduler import MyOneCycleLR, MyReduceLROnPlateau
 from .layerwise_trainer import LayerwiseTrainer
 
 
@@ -27,11 +34,35 @@ class TaylorPruneTrainer(LayerwiseTrainer):
         if any(p.requires_grad for p in self.model.student.parameters()):
             super().create_new_optimizer()
         else:
-            self.optimizer = None   # importance tracking on a frozen student
+            self.optimizer = None   # nothing trainable (a plan without gates): importance tracking only
 
     def prepare_train_epoch(self, epoch, config=None):
-        super().prepare_train_epoch(epoch, config)
+        """Gate the layers scheduled for `epoch` (reference :75-131: only `pruning_plan` decides whether anything happens)."""
+        if config is None:
+            config = self.config
+        pruning = config['pruning']
+        if epoch not in [x['epoch'] for x in pruning['pruning_plan']]:
+            self.logger.info('EPOCH: ' + str(epoch))
+            self.logger.info('There is no update ...')
+            return
+        gated_layers = [x for x in pruning['pruning_plan'] if x['epoch'] == epoch]
+        self.logger.info('EPOCH: ' + str(epoch))
+        self.logger.info('Replaced layers: ' + str(gated_layers))
+        if 'args' in pruning:
+            kwargs = pruning['args']
+        else:
+            self.logger.warning('Using deprecate checkpoint...')
+            kwargs = pruning['pruner']
+        self.model.replace(gated_layers, **kwargs)
         self.importance_tracker.update_importance_list(self.model.added_gates)
+        if epoch == 1:
+            self.create_new_optimizer()
+        elif self.optimizer is not None:
+            self.update_optimizer([x for x in pruning.get('unfreeze', []) if x['epoch'] == epoch])
+        self._reducer = None              # trainable set changed: rebuild the gradient buckets lazily
+        self.logger.info(self.model.dump_trainable_params())
+        self.logger.info(self.model.dump_student_teacher_blocks_info())
+        self.reset_scheduler()
 
     def _train_epoch(self, epoch):
         self.prepare_train_epoch(epoch)
@@ -40,13 +71,15 @@ class TaylorPruneTrainer(LayerwiseTrainer):
         self.train_iou_metrics.reset()
         self.train_teacher_iou_metrics.reset()
         self._clean_cache()
+        self._attach_reducer()
         for batch_idx, (data, target) in enumerate(self.train_data_loader):
-            data, target = data.to(self.device), target.to(self.device)
+            data, target = data.to(self.device, non_blocking=True), target.to(self.device, non_blocking=True)
             output_st, output_tc = self.model(data)
-            supervised_loss = self.criterions[0](output_st, target)      # not divided: keeps the gradient's scale
+            supervised_loss = self.criterions[0](output_st, target)      # not divided: keeps the gradient's scale (:201)
             teacher_loss = self.criterions[0](output_tc, target)
-            loss = supervised_loss                                       # only the supervised loss
+            loss = supervised_loss                                       # only the supervised loss (:204-206)
             loss.backward()
+            self._reduce_unfused_grads()
             self.importance_tracker.update(self.model.get_gate_importance())
             if self.optimizer is not None and batch_idx % self.accumulation_steps == 0:
                 self.optimizer.step()
@@ -58,6 +91,16 @@ class TaylorPruneTrainer(LayerwiseTrainer):
             if self.track_miou:
                 self.train_iou_metrics.update(output_st, target)
                 self.train_teacher_iou_metrics.update(output_tc, target)
+            for met in self.metric_ftns:
+                self.train_metrics.update(met.__name__, met(output_st, target))
+            if batch_idx % self.log_step == 0:
+                self.train_metrics.flush()
+                if self.rank == 0:
+                    self.logger.info(
+                        'Train Epoch: {} [{}]/[{}] Loss: {:.6f} mIoU: {:.6f} Teacher mIoU: {:.6f} Supervised Loss: {:.6f} '
+                        'Teacher Loss: {:.6f}'.format(epoch, batch_idx, self.len_epoch, self.train_metrics.avg('loss'),
+                                                      self.train_iou_metrics.get_iou(), self.train_teacher_iou_metrics.get_iou(),
+                                                      self.train_metrics.avg('supervised_loss'), self.train_metrics.avg('teacher_loss')))
             if batch_idx % self.importance_log_interval == 0 and self.rank == 0:
                 table = self.importance_tracker.average()
                 path = os.path.join(str(self.checkpoint_dir), 'importance_filter_ep{}_batch_idx{}.pth'.format(epoch, batch_idx))
@@ -69,5 +112,16 @@ class TaylorPruneTrainer(LayerwiseTrainer):
         log = self.train_metrics.result()
         log.update({'train_teacher_mIoU': self.train_teacher_iou_metrics.get_iou(),
                     'train_student_mIoU': self.train_iou_metrics.get_iou()})
+        if self.do_validation and ((epoch % self.config["trainer"]["do_validation_interval"]) == 0):
+            val_log = self._valid_epoch(epoch)
+            log.update(**{'val_' + k: v for k, v in val_log.items()})
+            log.update(**{'val_mIoU': self.valid_iou_metrics.get_iou()})
+            self.val_iou_tracker.update(self.valid_iou_metrics.get_iou())
+        self._teacher_student_iou_gap = self.train_teacher_iou_metrics.get_iou() - self.train_iou_metrics.get_iou()
+        if (self.lr_scheduler is not None) and (not isinstance(self.lr_scheduler, MyOneCycleLR)):
+            if isinstance(self.lr_scheduler, MyReduceLROnPlateau):
+                self.lr_scheduler.step(mean_scalar(self.train_metrics.avg('loss')))
+            else:
+                self.lr_scheduler.step()
         self.weight_scheduler.step()
         return log

@@ -22,8 +22,16 @@ EPS = 1e-5
 
 
 def _bnrelu(sd, p, x, relu=True):
+    """bnrelu Sequential(BatchNorm2d, ReLU) (wider_resnet.py:43-48); `p` names the BN.  A `<relu>.gate` entry is the GateLayer
+    TaylorPruneStudent puts behind that ReLU: `<seq>.1.gate` for a block's `bnK` (p = `<seq>.0`), `aspp.features.N.2.gate` for
+    an ASPP branch (p = `aspp.features.N.1`)."""
     y = F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.0, EPS)
-    return F.relu(y) if relu else y
+    if not relu:
+        return y
+    y = F.relu(y)
+    head, idx = p.rsplit(".", 1)
+    gate = sd.get(f"{head}.{int(idx) + 1}.gate") if idx.isdigit() else None
+    return y if gate is None else y * gate.view(1, -1, 1, 1)
 
 
 def _conv(sd, name, x, stride, pad, dil, cheap_geom):
@@ -251,14 +259,15 @@ def make_student_sd(teacher_sd, plan, new_weights, trainable=None):
     return sd
 
 
-def taylor_importance(teacher_sd, x, target, gates):
-    """trainer/taylor_prune_trainer.py:196-211 for one step: unit gates behind the named convs of a copy of the teacher,
-    loss = cross entropy of the student logits, importance = (gate * d loss / d gate)^2.  gates: {conv name: channels}.
+def taylor_importance(teacher_sd, x, target, gates, values=None):
+    """trainer/taylor_prune_trainer.py:196-211 for one step: gates (unit, or `values[name]`) behind the named blocks of a copy
+    of the teacher -- convs, bnrelu ReLUs (`...bnK.1`), ASPP branch convs / ReLUs (`aspp.features.N.0|2`) -- loss = cross entropy
+    of the student logits, importance = (gate * d loss / d gate)^2.  gates: {block name: channels}.
     Returns (loss, {name: gate gradient}, {name: importance})."""
     sd = {k: v.detach().clone() for k, v in teacher_sd.items()}
     gs = {}
     for name, c in gates.items():
-        gs[name] = torch.ones(c, requires_grad=True)
+        gs[name] = (torch.ones(c) if values is None else values[name].detach().clone().float()).requires_grad_(True)
         sd[name + ".gate"] = gs[name]
     logits, _, _ = forward(sd, x)
     loss = F.cross_entropy(logits, target, ignore_index=255)

@@ -174,3 +174,41 @@ def test_weight_scheduler_and_lr_scheduler_names():
     sch.step(1.0); sch.step(1.0)
     assert sch.optimizer.param_groups[0]["lr"] == 0.0025
     sch.reset()
+
+
+def test_sliding_window_merge_matches_reference_reverse_mapping(golden):
+    """DepthwiseStudent.inference_test's tiling and merge (window boxes and order, flip restore, the reference's [class, row]
+    count indexing, mean of the plain and mirrored passes) against the reference's own utils/tta_process.py get_crops_image ->
+    reverse_mapping on a 40 x 72 frame that needs 3 x 2 overlapping 32-pixel windows (tests/golden/tta.npz).  The student is
+    replaced by seeded per-window logits on both sides; CPU only (no kernel is involved in the merge)."""
+    import numpy as np
+    import torch
+    from torch import nn
+    from _seeded import seeded_input
+    from kdcc_amd.models.students import DepthwiseStudent
+    g = golden("tta")
+    h, w, crop = int(g["hw"][0]), int(g["hw"][1]), int(g["crop"])
+    boxes = DepthwiseStudent.sliding_windows(h, w, crop)
+    assert boxes == [tuple(int(v) for v in b) for b in g["boxes"]]
+    img = seeded_input("tta.img", (3, h, w))
+    results = seeded_input("tta.logits", (2 * len(boxes), 19, crop, crop))
+    model = DepthwiseStudent(nn.Conv2d(3, 19, 1), None)
+    fed, cursor = [], [0]
+
+    def fake_inference(wins):
+        fed.append(wins.clone())
+        out = results[cursor[0]:cursor[0] + wins.shape[0]]
+        cursor[0] += wins.shape[0]
+        return out
+    model.inference = fake_inference
+    with np.errstate(all="ignore"):
+        out = model.inference_test(img.unsqueeze(0), {"scales": [1.0], "crop_size": crop}, max_windows_per_pass=4)
+    assert cursor[0] == 2 * len(boxes)
+    assert abs(float(torch.cat(fed).double().sum()) - float(g["windows_sum"])) < 1e-6 * abs(float(g["windows_sum"])) + 1e-6   # same windows
+    ref = torch.from_numpy(g["merged"])
+    assert tuple(out.shape) == (1,) + tuple(ref.shape)
+    assert torch.allclose(out[0], ref, rtol=1e-5, atol=1e-6, equal_nan=True)
+    # the count the reference builds is per (class, row): not the per-pixel window count
+    cursor[0] = 0
+    px = model.inference_test(img.unsqueeze(0), {"scales": [1.0], "crop_size": crop, "window_count": "pixel"})
+    assert not torch.allclose(px[0], ref, rtol=1e-3, atol=1e-3, equal_nan=True)

@@ -90,6 +90,31 @@ def test_taylor_importance_matches_reference(golden):
         np.testing.assert_allclose(imp[n].numpy(), g[f"imp:{n}"], rtol=2e-3, atol=1e-6 * g[f"imp:{n}"].max())
 
 
+def test_taylor_gate_sites_and_values_match_reference(golden):
+    """Gates away from 1 at every site class cfg/taylor_importance_track.json uses (block conv, bnrelu ReLUs, ASPP branch ReLU
+    and conv): the oracle's loss and gate gradients vs the reference's TaylorPruneStudent (tests/golden/taylor_steps.npz, `rnd`),
+    and -- with unit gates -- the first batch of the reference's three-step runs."""
+    g = golden("taylor_steps")
+    names = [str(s) for s in g["names"]]
+    torch.set_num_threads(8)
+    tsd = seeded_teacher_sd()
+    x = seeded_input("taylor.steps.x0", (2, 3, 64, 128))
+    tgt = torch.from_numpy(g["target0"].astype(np.int64))
+    sizes = {n: len(g[f"rnd.gate:{n}"]) for n in names}
+    vals = {n: torch.from_numpy(g[f"rnd.gate:{n}"]) for n in names}
+    loss, gg, imp = net_ref.taylor_importance(tsd, x, tgt, sizes, values=vals)
+    np.testing.assert_allclose(loss.item(), float(g["rnd.loss"]), rtol=1e-5)
+    for n in names:
+        ref = g[f"rnd.grad:{n}"].astype(np.float64)
+        assert np.abs(gg[n].numpy() - ref).max() <= 2e-4 * np.abs(ref).max(), n
+        np.testing.assert_allclose(imp[n].numpy(), g[f"rnd.imp:{n}"], rtol=2e-3, atol=1e-6 * g[f"rnd.imp:{n}"].max())
+    loss, gg, _ = net_ref.taylor_importance(tsd, x, tgt, sizes)
+    np.testing.assert_allclose(loss.item(), float(g["acc1.loss0"]), rtol=1e-5)
+    for n in names:
+        ref = g[f"acc1.grad0:{n}"].astype(np.float64)
+        assert np.abs(gg[n].numpy() - ref).max() <= 2e-4 * np.abs(ref).max(), n
+
+
 def test_gscnn_oracle_matches_reference(golden):
     """oracle/net_ref.gscnn_forward (trunk + shape stream + gated convs + edge-aware ASPP + decoder, Canny map given) vs the
     reference's GSCNN(19).forward on the same seeded weights / inputs; plus the two building blocks alone."""

@@ -47,3 +47,45 @@ def test_shipped_config_plan_applies(path):
     assert hasattr(kdcc_amd.utils.optim, cfg["optimizer"]["type"])
     assert hasattr(kdcc_amd.utils.optim.lr_scheduler, cfg["lr_scheduler"]["type"])
     assert hasattr(kdcc_amd.trainer, cfg["trainer"]["name"])
+
+
+TAYLOR_CFG = "/root/reference/cfg/taylor_importance_track.json"
+
+
+@pytest.mark.skipif(not os.path.exists(TAYLOR_CFG), reason="reference configs not present on this box")
+def test_shipped_taylor_config_plan_applies():
+    """cfg/taylor_importance_track.json -- the only Taylor config the reference ships: `pruning` has just {args, pruning_plan},
+    and the plan gates block convs, bnrelu ReLUs (`...bn2.1`, `...bn3.1`) and ASPP branch ReLUs (`aspp.features.N.2`).  Every
+    entry of every epoch must apply to the fused student and be seen by the engine as a gate at a supported site."""
+    from kdcc_amd.engine import StudentEngine, _Site, _act_gate, _gate_split
+    from kdcc_amd.models.students import TaylorPruneStudent
+    cfg = json.load(open(TAYLOR_CFG))
+    assert set(cfg["pruning"]) == {"args", "pruning_plan"} and cfg["trainer"]["name"] == "TaylorPruneTrainer"
+    with torch.device("meta"):
+        teacher = getattr(models, cfg["teacher"]["type"])(**cfg["teacher"]["args"])
+        model = TaylorPruneStudent(teacher, None)
+    plan = cfg["pruning"]["pruning_plan"]
+    for ep in sorted({e["epoch"] for e in plan}):
+        with torch.device("meta"):
+            model.replace([e for e in plan if e["epoch"] == ep], **cfg["pruning"]["args"])
+    assert sorted(model.added_gates) == sorted(e["name"] for e in plan)
+    trainable = [n for n, p in model.student.named_parameters() if p.requires_grad]
+    assert len(trainable) == len(plan) and all(n.endswith(".1.weight") for n in trainable)     # the gates, nothing else
+    # the engine finds each gate where it will fold it
+    eng = StudentEngine(model.student, torch.bfloat16)
+    seen = 0
+    for name, blk in eng._flat_blocks():
+        for n, m in blk.convs.named_children():
+            if n.startswith("conv"):
+                seen += _Site(f"{name}.convs.{n}", m).gate is not None
+            elif n.startswith("bn"):
+                seen += _act_gate(m) is not None
+    for br in model.student.aspp.features:
+        seen += _gate_split(br[0])[1] is not None
+        seen += len(br) > 2 and _gate_split(br[2])[1] is not None
+    assert seen == len(plan)
+    order = eng.grad_production_order()
+    assert len(order) == len(plan) and {id(p) for p in order} == {id(g.weight) for g in model.added_gates.values()}
+    # a site the fused graph cannot fold a gate into is refused when the plan is applied
+    with torch.device("meta"), pytest.raises(ValueError):
+        model.replace([{"name": "mod4.block2.bn1.1", "epoch": 1, "num_features": 256}])

@@ -58,6 +58,83 @@ def test_gate_importance_matches_reference(golden):
         assert np.abs(imp[n] - ri).max() < 4e-3 * ri.max(), n
 
 
+def _gate_close(got, ref, tol, what):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert np.linalg.norm(got - ref) <= tol * np.linalg.norm(ref), f"{what}: rel L2 {np.linalg.norm(got - ref) / np.linalg.norm(ref):.2e}"
+    assert np.abs(got - ref).max() <= 2 * tol * np.abs(ref).max(), what
+
+
+def test_gates_away_from_one_at_every_site_class(golden):
+    """Gates with values in 0.5 .. 1.5 behind a block conv, two bnrelu ReLUs, an ASPP branch ReLU and an ASPP branch conv --
+    every site class of cfg/taylor_importance_track.json: the folded forward (logits, loss) and every gate gradient against the
+    reference's TaylorPruneStudent (tests/golden/taylor_steps.npz, `rnd`)."""
+    from kdcc_amd import losses
+    from test_student_gpu import check_summary
+    g = golden("taylor_steps")
+    names = [str(s) for s in g["names"]]
+    model = _taylor_model(torch.float32)
+    model.replace([{"name": n, "epoch": 1, "num_features": len(g[f"rnd.gate:{n}"])} for n in names])
+    with torch.no_grad():
+        for n in names:
+            model.added_gates[n].weight.copy_(torch.from_numpy(g[f"rnd.gate:{n}"]))
+    assert {n for n, p in model.student.named_parameters() if p.requires_grad} == {f"{n}.1.weight" for n in names}   # the gates only
+    x = seeded_input("taylor.steps.x0", (2, 3, 64, 128)).cuda()
+    tgt = torch.from_numpy(g["target0"].astype(np.int64)).cuda()
+    out_st, _ = model(x)
+    loss = losses.CrossEntropyLoss2d(ignore_index=255)(out_st, tgt)
+    loss.backward()
+    check_summary(out_st, g, "rnd.logits", 1e-3, "student logits with folded gates")
+    np.testing.assert_allclose(loss.item(), float(g["rnd.loss"]), rtol=1e-3)
+    imp = model.get_gate_importance()
+    for n in names:
+        _gate_close(model.added_gates[n].weight.grad.cpu().numpy(), g[f"rnd.grad:{n}"], 1e-3, f"gate gradient {n}")
+        assert np.abs(imp[n] - g[f"rnd.imp:{n}"]).max() < 4e-3 * g[f"rnd.imp:{n}"].max(), n
+
+
+@pytest.mark.parametrize("variant,acc_steps", [("acc1", 1), ("accN", 100000)])
+def test_gate_training_three_steps_matches_reference(golden, variant, acc_steps):
+    """trainer/taylor_prune_trainer.py:196-215 for three batches: the gates are student parameters held by RAdam (lr 0.05 here);
+    acc1 steps and zeroes them after every batch, accN (the shipped accumulation_steps = 100000) at batch 0 only -- gate.grad then
+    ACCUMULATES over batches 1, 2 and the importance is (gate * running sum)^2.  Per step: loss, gate.grad, importance, gate
+    values after the step; at the end ImportanceFilterTracker.average()."""
+    from kdcc_amd import losses
+    from kdcc_amd.utils import ImportanceFilterTracker
+    from kdcc_amd.utils.optim import RAdam
+    g = golden("taylor_steps")
+    names = [str(s) for s in g["names"]]
+    model = _taylor_model(torch.float32)
+    model.replace([{"name": n, "epoch": 1, "num_features": len(g[f"rnd.gate:{n}"])} for n in names])
+    params = [p for p in model.student.parameters() if p.requires_grad]
+    assert len(params) == len(names)
+    opt = RAdam(params, lr=float(g["lr"]))
+    tr = ImportanceFilterTracker(writer=None)
+    tr.update_importance_list(model.added_gates)
+    crit = losses.CrossEntropyLoss2d(ignore_index=255)
+    for i in range(int(g["steps"])):
+        x = seeded_input(f"taylor.steps.x{i}", (2, 3, 64, 128)).cuda()
+        tgt = torch.from_numpy(g[f"target{i}"].astype(np.int64)).cuda()
+        out_st, _ = model(x)
+        loss = crit(out_st, tgt)
+        loss.backward()
+        imp = model.get_gate_importance()
+        tr.update(imp)
+        np.testing.assert_allclose(loss.item(), float(g[f"{variant}.loss{i}"]), rtol=1e-3)
+        for n in names:
+            _gate_close(model.added_gates[n].weight.grad.cpu().numpy(), g[f"{variant}.grad{i}:{n}"], 1e-3, f"{variant} step {i} grad {n}")
+            ri = g[f"{variant}.imp{i}:{n}"]
+            assert np.abs(imp[n] - ri).max() < 4e-3 * ri.max(), (variant, i, n)
+        if i % acc_steps == 0:
+            opt.step()
+            opt.zero_grad()
+        for n in names:   # what the optimizer did to the gates: compare the displacement from 1, not the value (which is 1 - 1e-5)
+            got = model.added_gates[n].weight.detach().cpu().numpy().astype(np.float64) - 1.0
+            ref = g[f"{variant}.gate{i}:{n}"].astype(np.float64) - 1.0
+            assert np.abs(got - ref).max() <= 5e-3 * np.abs(ref).max() + 3e-7, (variant, i, n)   # 3e-7: fp32 spacing at 1.0
+    avg = tr.average()
+    for n in names:
+        np.testing.assert_allclose(avg[n], g[f"{variant}.avg:{n}"], rtol=1e-2, atol=2e-3 * g[f"{variant}.avg:{n}"].max())
+
+
 def test_taylor_trainer_feeds_weighted_hint_loss(tmp_path):
     """TaylorPruneTrainer epoch (frozen student, supervised loss, importance dump) -> LayerwiseTrainer with
     WeightedHintMSELoss reading that table as filter weights."""
@@ -70,8 +147,9 @@ def test_taylor_trainer_feeds_weighted_hint_loss(tmp_path):
     gates = [("mod4.block2.convs.conv2", 512), ("aspp.features.1.0", 256)]
     cfg = trainer_config([], lr=1e-3, len_epoch=1, save_dir=str(tmp_path))
     ent = [{"name": n, "epoch": 1, "num_features": c} for n, c in gates]
-    cfg["pruning"].update(pruning_plan=ent, hint=[], unfreeze=[])
-    cfg["trainer"].update(name="TaylorPruneTrainer", importance_log_interval=1)
+    # `pruning` as cfg/taylor_importance_track.json ships it: only args + pruning_plan (no `hint`, no `unfreeze`)
+    cfg["pruning"] = {"args": cfg["pruning"]["args"], "pruning_plan": ent + [{"name": "mod4.block3.convs.bn2.1", "epoch": 2, "num_features": 512}]}
+    cfg["trainer"].update(name="TaylorPruneTrainer", importance_log_interval=1, epochs=2, save_period=1)
     config = ConfigParser(cfg, run_id="taylor")
     teacher = config.init_obj("teacher", models)
     seeded_fill_(teacher, "teacher.")
@@ -82,8 +160,10 @@ def test_taylor_trainer_feeds_weighted_hint_loss(tmp_path):
                for i in range(2)]
     opt = optim_module.RAdam([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
     tr = TaylorPruneTrainer(model, crit, [], opt, config, batches, None, None, WeightScheduler(config["weight_scheduler"]))
-    log = tr._train_epoch(1)
-    assert tr.optimizer is None and log["supervised_loss"] > 0
+    tr.train()       # two epochs across a save_period boundary: checkpoints, the second plan epoch (a ReLU-site gate, no `unfreeze`)
+    assert tr.optimizer is not None and len(tr.optimizer.param_groups[0]["params"]) == 2     # the epoch-1 gates, like the reference
+    assert (tr.checkpoint_dir / "checkpoint-epoch2.pth").exists()
+    assert sorted(model.added_gates) == sorted([n for n, _ in gates] + ["mod4.block3.convs.bn2.1"])
     path = tr.checkpoint_dir / "importance_filter_ep1_batch_idx1.pth"
     table = torch.load(str(path))
     for n, c in gates:

@@ -78,7 +78,7 @@ def test_sliding_window_test_epoch(tmp_path):
     model = DepthwiseStudent(teacher, config).cuda()
     x = seeded_input("tta.x", (1, 3, 64, 160)).cuda()
     args = cfg["test"]["args"]
-    out = model.inference_test(x, args)
+    out = model.inference_test(x, dict(args, window_count="pixel"))      # (the reference's count indexing: tests/test_host_logic.py)
     assert tuple(out.shape) == (1, 19, 64, 160)
     boxes = model.sliding_windows(64, 160, 64)
     assert boxes == [(0, 0, 64, 64), (43, 0, 107, 64), (86, 0, 150, 64), (96, 0, 160, 64)]
@@ -98,8 +98,12 @@ def test_sliding_window_test_epoch(tmp_path):
     res = tr._test_epoch(1)
     assert res["supervised_loss"] > 0 and 0.0 <= res["mIoU"] <= 1.0
     assert (tmp_path / "submission" / "frankfurt_000000.png").exists()
-    with pytest.raises(NotImplementedError):
-        model.inference_test(x, {"scales": [0.5, 1.0], "crop_size": 64})
+    # multi-scale passes (utils/tta_process.py:53-66: resampled image, tile = int(scale * crop)): the mean over scales; a scale
+    # listed twice changes nothing, a second scale does
+    ref1 = model.inference_test(x, {"scales": [1.0], "crop_size": 64})
+    assert torch.allclose(model.inference_test(x, {"scales": [1.0, 1.0], "crop_size": 64}), ref1, rtol=1e-5, atol=1e-6)
+    ms = model.inference_test(x, {"scales": [0.5, 1.0, 1.5], "crop_size": 64})
+    assert tuple(ms.shape) == (1, 19, 64, 160) and torch.isfinite(ms).all() and not torch.allclose(ms, ref1, rtol=1e-3, atol=1e-3)
 
 
 def test_gscnn_config_is_drop_in(tmp_path):

@@ -352,6 +352,112 @@ def g_taylor(hw=(64, 128), batch=2):
     save("taylor", **out)
 
 
+TAYLOR_STEP_GATES = [("mod4.block2.convs.conv2", 512),      # behind the last conv of a block (the shortcut joins after the gate)
+                     ("mod4.block3.convs.bn2.1", 512),       # behind the ReLU of a bnrelu inside a block
+                     ("mod7.block1.convs.bn3.1", 2048),      # bottleneck block, second bnrelu
+                     ("aspp.features.1.2", 256),             # behind an ASPP branch's ReLU
+                     ("aspp.features.2.0", 256)]             # behind an ASPP branch's conv
+
+
+def g_taylor_steps(hw=(64, 128), batch=2, steps=3, lr=0.05):
+    """trainer/taylor_prune_trainer.py:196-215 for THREE batches on the reference, gates trained by the reference's RAdam as
+    its trainer does (the gates are the only student parameters that require grad: create_new_optimizer, :152-162), at every gate
+    site class cfg/taylor_importance_track.json uses (conv sites, `bnK.1` ReLUs, `aspp.features.N.2`).  Two variants:
+      acc1  accumulation_steps = 1: optimizer.step() + zero_grad() after every batch;
+      accN  accumulation_steps = 100000 (the shipped config): step + zero_grad at batch 0 only, so gate.weight.grad keeps
+            ACCUMULATING over the later batches and the importance is (gate * running gradient sum)^2.
+    Stored per variant and step: loss, gate gradients as read by get_gate_importance, importances, gate values after the
+    step; and ImportanceFilterTracker.average() at the end."""
+    from models.students.taylor_prune_student import TaylorPruneStudent
+    from utils.util import ImportanceFilterTracker
+    out = dict(names=np.array([n for n, _ in TAYLOR_STEP_GATES]), lr=np.float64(lr), steps=np.int64(steps))
+    xs = [seeded_input(f"taylor.steps.x{i}", (batch, 3) + hw) for i in range(steps)]
+    tgts = []
+    for i in range(steps):
+        t = torch.randint(0, 19, (batch,) + hw, generator=torch.Generator().manual_seed(40 + i))
+        t[:, :4] = 255
+        tgts.append(t)
+        out[f"target{i}"] = t.numpy().astype(np.uint8)
+    for variant, acc_steps in (("acc1", 1), ("accN", 100000)):
+        teacher = DeepWV3Plus(num_classes=19)
+        seeded_fill_(teacher, "teacher.")
+        teacher.eval()
+        model = TaylorPruneStudent(teacher, config=None)
+        model.replace([{"name": n, "epoch": 1, "num_features": c} for n, c in TAYLOR_STEP_GATES])
+        params = [p for p in model.student.parameters() if p.requires_grad]
+        assert len(params) == len(TAYLOR_STEP_GATES)            # the gates and nothing else
+        opt = RAdam(params, lr=lr)
+        tr = ImportanceFilterTracker(writer=None)
+        tr.update_importance_list(model.added_gates)
+        crit = ref_losses.CrossEntropyLoss2d(ignore_index=255)
+        for i in range(steps):
+            out_st, _ = model(xs[i])
+            loss = crit(out_st, tgts[i])
+            loss.backward()
+            imp = model.get_gate_importance()
+            tr.update(imp)
+            out[f"{variant}.loss{i}"] = np.float64(loss.item())
+            for n, _ in TAYLOR_STEP_GATES:
+                out[f"{variant}.grad{i}:{n}"] = model.added_gates[n].weight.grad.detach().numpy().copy()
+                out[f"{variant}.imp{i}:{n}"] = np.asarray(imp[n], np.float64)
+            if i % acc_steps == 0:
+                opt.step()
+                opt.zero_grad()
+            for n, _ in TAYLOR_STEP_GATES:
+                out[f"{variant}.gate{i}:{n}"] = model.added_gates[n].weight.detach().numpy().copy()
+        avg = tr.average()
+        for n, _ in TAYLOR_STEP_GATES:
+            out[f"{variant}.avg:{n}"] = np.asarray(avg[n], np.float64)
+    # gates away from 1 (0.5 .. 1.5, seeded): one batch -- pins that a gate scales the forward and that its gradient is taken
+    # with respect to the gate, not the gated tensor (the RAdam steps above move the gates by ~1e-5 only)
+    teacher = DeepWV3Plus(num_classes=19)
+    seeded_fill_(teacher, "teacher.")
+    teacher.eval()
+    model = TaylorPruneStudent(teacher, config=None)
+    model.replace([{"name": n, "epoch": 1, "num_features": c} for n, c in TAYLOR_STEP_GATES])
+    with torch.no_grad():
+        for n, c in TAYLOR_STEP_GATES:
+            model.added_gates[n].weight.copy_(0.5 + seeded_input(f"taylor.gate.{n}", (c,)).sigmoid())
+    out_st, _ = model(xs[0])
+    loss = ref_losses.CrossEntropyLoss2d(ignore_index=255)(out_st, tgts[0])
+    loss.backward()
+    imp = model.get_gate_importance()
+    out["rnd.loss"] = np.float64(loss.item())
+    out.update({f"rnd.logits.{k}": v for k, v in summarize(out_st).items()})
+    for n, _ in TAYLOR_STEP_GATES:
+        out[f"rnd.gate:{n}"] = model.added_gates[n].weight.detach().numpy().copy()
+        out[f"rnd.grad:{n}"] = model.added_gates[n].weight.grad.detach().numpy().copy()
+        out[f"rnd.imp:{n}"] = np.asarray(imp[n], np.float64)
+    save("taylor_steps", **out)
+
+
+def g_tta(h=40, w=72, crop=32, classes=19):
+    """utils/tta_process.py on arrays (get_crops_image -> reverse_mapping, the numpy half of DepthwiseStudent.inference_test,
+    models/students/depthwise_student.py:187-206) for scales = [1.0] on an image that needs 3 x 2 overlapping windows: the
+    window boxes and order, the (reference-indexed) window count normalisation, the flip restore and the mean.  The student is
+    replaced by seeded per-window logits (stored), so only the reference's tiling / merge arithmetic is pinned.  cv2.resize is
+    only ever asked for the identity resize at scale 1.0."""
+    import cv2 as cv2_stub
+    from utils import tta_process as tta
+    np.float = float                                    # tta_process.py:48 uses the alias numpy removed
+
+    def same_size_resize(x, size, interpolation=None):
+        assert (x.shape[1], x.shape[0]) == tuple(size), "only the identity resize (scale 1.0) is pinned"
+        return x.copy()
+    cv2_stub.resize, cv2_stub.INTER_LINEAR = same_size_resize, 1
+    tta.cv2 = cv2_stub
+    img = seeded_input("tta.img", (3, h, w))
+    image_data = ((w, h), [[img, torch.flip(img, dims=[2])]])
+    ori_size, mapping, tensors = tta.get_crops_image(image_data, [1.0], crop_size=crop)
+    results = seeded_input("tta.logits", (tensors.shape[0], classes, crop, crop)).numpy()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        out = tta.reverse_mapping(mapping, results, ori_size)
+    merged = np.mean(out, axis=0)
+    # (the windows and the stand-in logits are seeded: the test regenerates them from their keys)
+    save("tta", hw=np.array([h, w]), crop=np.int64(crop), boxes=np.array(mapping[0][2], np.int64), merged=merged.astype(np.float32),
+         windows_sum=np.float64(tensors.double().sum().item()))
+
+
 def _canny_stub_map(shape, seed):
     """The edge map handed to both sides in place of cv2.Canny's output (0 / 255, like cv2): parity of the Canny operator
     itself is unpinned (opencv-python is not vendored); everything downstream of it is pinned by these goldens."""
@@ -536,7 +642,7 @@ def g_keys():
     print("wrote", path, len(inv), "entries", sum(int(np.prod(v)) for k, v in inv.items() if "num_batches" not in k and "running" not in k), "params")
 
 
-ALL = dict(keys=g_keys, gscnn=g_gscnn, confusion=g_confusion, taylor=g_taylor, student_step_full=g_student_step_full, trainer_epoch=g_trainer_epoch, classification_epoch=g_classification_epoch, losses=g_losses, dwsep=g_dwsep, resblock=g_resblock, aspp=g_aspp, ops=g_ops, radam=g_radam,
+ALL = dict(keys=g_keys, gscnn=g_gscnn, confusion=g_confusion, taylor=g_taylor, taylor_steps=g_taylor_steps, tta=g_tta, student_step_full=g_student_step_full, trainer_epoch=g_trainer_epoch, classification_epoch=g_classification_epoch, losses=g_losses, dwsep=g_dwsep, resblock=g_resblock, aspp=g_aspp, ops=g_ops, radam=g_radam,
            student_step=g_student_step)
 
 if __name__ == "__main__":
