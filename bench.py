@@ -183,11 +183,14 @@ def conv_traffic(plan, batch, height, width, dtype, mode, arch):
     """HBM bytes per conv launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE in separate passes,
     same command); None when the profiled configuration is not the one being run."""
     path = _latest_profile("traffic_pmc.json")
-    if not (plan == "P92" and batch == 4 and (height, width) == (1024, 2048) and dtype == "bf16" and mode == "A" and arch == "deeplab" and path):
+    if not (plan == "P92" and (height, width) == (1024, 2048) and dtype == "bf16" and mode == "A" and arch == "deeplab" and path):
         return None, None
     try:
         with open(path) as f:
-            return float(json.load(f)["kernels"]["conv_igemm"]["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
+            d = json.load(f)
+        if int(d.get("config", {}).get("batch", 4)) != batch:
+            return None, None
+        return float(d["kernels"]["conv_igemm"]["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
     except (KeyError, ValueError, OSError):
         return None, None
 
@@ -313,7 +316,7 @@ def run_config(a, device, rank, world, plan_name=None, mode=None, arch=None, hin
     # side by side (short: 2 warm-up + 8 timed steps each) so one record carries all three.
     sweep = {}
     if batch_sweep and not a.no_batch_sweep:
-        for nb in (1, 2):
+        for nb in (1, 2, 4):
             if nb >= a.batch:
                 continue
             d_, t_ = data[:nb].contiguous(), target[:nb].contiguous()
@@ -407,7 +410,7 @@ def main():
                          "north-star mode): loss = KLDiv + hint, every student parameter trainable (37.74 TFLOP/img for P92)")
     ap.add_argument("--hint-loss", default="mse", choices=["mse", "weighted"],
                     help="mse: MSELoss(num_classes=1000) (configs 2/3); weighted: WeightedHintMSELoss with rand:7 filter weights (config 4)")
-    ap.add_argument("--batch", type=int, default=4, help="images per GPU (4 by default: +6 %% img/s over 1, +2 %% over 2 from fuller grids)")
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU (8 by default: fuller grids, +8 %% img/s over 1, +4 %% over 2, +2 %% over 4; the record carries 1, 2 and 4 beside it)")
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])

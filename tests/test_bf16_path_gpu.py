@@ -182,7 +182,7 @@ def test_bf16_gscnn_step_vs_network_oracle():
 
 
 # ----------------------------------------------------------------------------------------------- the bench step itself
-def _bench_run(steps=2, share=False, batch=4, seed_data=1000):
+def _bench_run(steps=2, share=False, batch=8, seed_data=1000):
     """bench.py's own construction (build / kd_step, plan P92, bf16, 1024x2048) for `steps` train steps."""
     import bench
     model, crit, opt, _ = bench.build(bench.PLANS["P92"], BF, torch.device("cuda", 0))
@@ -214,11 +214,11 @@ def _bench_run(steps=2, share=False, batch=4, seed_data=1000):
 
 
 def test_fullsize_bench_step_determinism_batch_independence_and_prefix_sharing():
-    """The step bench.py times (P92, 4 x 1024 x 2048, bf16), two train steps:
+    """The step bench.py times (P92, 8 x 1024 x 2048, bf16 -- bench.py's default per-GPU batch), two train steps:
       * run-to-run: losses, gradients and updated parameters are bit-identical between two fresh runs (every reduction is
         fixed-order: DESIGN.md section 3);
-      * batch independence: image 0 alone gives bit-identical logits / hints to image 0 of the batch of four (tiles never
-        straddle images), and the batch-of-one hint gradient structure is finite;
+      * batch independence: image 0 alone gives bit-identical logits / hints to image 0 of the batch of eight (tiles never
+        straddle images);
       * share_frozen_prefix equals the two-full-forwards result bit for bit at full size;
       * the selected kernels are the shipped ones."""
     from kdcc_amd import _lib
@@ -233,7 +233,7 @@ def test_fullsize_bench_step_determinism_batch_independence_and_prefix_sharing()
         assert torch.equal(a["grads"][n], b["grads"][n]), f"gradient of {n} differs between two identical runs"
         assert torch.equal(a["params"][n], b["params"][n]), f"{n} differs after two identical runs"
     # batch independence of the forward (fresh model in the same state as run a's second step is not needed: use b's model,
-    # whose parameters equal a's after 2 steps -- compare image 0 of a 4-batch with the 1-batch forward)
+    # whose parameters equal a's after 2 steps -- compare image 0 of the 8-batch with the 1-batch forward)
     model = b["model"]
     with torch.no_grad():
         full_st, _ = model(b["data"])

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Per-kernel-family HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected separately, as
 MI355X_MICROARCH.md's HBM section prescribes) -> profiles/*_traffic_pmc.json.
-usage: summarize_pmc.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [command string]
+usage: summarize_pmc.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [command string] [images per GPU]
 FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled (gfx950 reads half the bytes a wide coalesced stream fetches)."""
 import csv, json, sys
 
-FAMILIES = {"conv_igemm": ("conv_igemm", "conv_row_persist", "conv_row_pp128"), "dw_mfma_fwd": "dw_mfma_fwd", "dw_mfma_wgrad": "dw_mfma_wgrad",
+FAMILIES = {"conv_igemm": ("conv_igemm", "conv_row_persist", "conv_row_pp128"), "dw_mfma_fwd": "dw_mfma_fwd",
+            "dw_mfma_wgrad_multi": "dw_mfma_wgrad_multi", "dw_mfma_wgrad": "dw_mfma_wgrad_kernel",
             "dwconv_fwd": "dwconv_fwd_kernel", "pw_wgrad": "pw_wgrad"}
 
 
@@ -27,7 +28,7 @@ write, nw = collect(sys.argv[2], "WRITE_SIZE")
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `%s`; FETCH_SIZE is in KiB and doubled per the "
                  "gfx950 correction of MI355X_MICROARCH.md (HBM section); WRITE_SIZE in KiB, exact" %
                  (sys.argv[4] if len(sys.argv) > 4 else "python bench.py --steps 3 --warmup 1 --no-cpu-baseline"),
-       "kernels": {}}
+       "config": {"batch": int(sys.argv[5]) if len(sys.argv) > 5 else 8}, "kernels": {}}
 for fam in FAMILIES:
     if fam in fetch and fam in write:
         f = 2.0 * 1024.0 * fetch[fam] / nf[fam]
