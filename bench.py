@@ -54,6 +54,7 @@ def build(plan, dtype, device, seed=123, mode="A", arch="deeplab", hint_loss="ms
     if mode == "B":   # SURVEY 8(d) mode B: every student parameter trainable (dense convs, eval-mode BN affine, stem)
         for p in model.student.parameters():
             p.requires_grad = True
+        model.logits_need_grad = True     # the KD term reaches the logits (Gated-SCNN: the shape stream keeps its intermediates)
     crit = [losses.CrossEntropyLoss2d(ignore_index=255), losses.KLDivergenceLoss(1),
             losses.WeightedHintMSELoss() if hint_loss == "weighted" else losses.MSELoss(num_classes=1000)]
     opt = RAdam([p for p in model.student.parameters() if p.requires_grad], lr=0.005)
@@ -404,7 +405,7 @@ def main():
     ap.add_argument("--plan", default="P92", choices=sorted(PLANS))
     ap.add_argument("--arch", default="deeplab", choices=["deeplab", "gscnn"],
                     help="deeplab: DeepLabV3+(WRN-38), the headline (BASELINE configs 2-4); gscnn: Gated-SCNN teacher/student "
-                         "(BASELINE config 5; use --plan P86, the shipped 51M_gscnn_all.json plan; mode A only)")
+                         "(BASELINE config 5; use --plan P86, the shipped 51M_gscnn_all.json plan)")
     ap.add_argument("--mode", default="A", choices=["A", "B"],
                     help="A (default, reference-faithful): loss = hint loss, only the cheap-conv blocks train; B (SURVEY 8d "
                          "north-star mode): loss = KLDiv + hint, every student parameter trainable (37.74 TFLOP/img for P92)")

@@ -255,6 +255,10 @@ size_t kd_upsample_bilinear_ac_bwd_workspace(int32_t N, int32_t H, int32_t W, in
 int kd_upsample_bilinear_ac_bwd(const void *gy, int32_t gy_dtype, int32_t ldgy, void *gx, int32_t gx_dtype, int32_t ldgx,
                                 int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
                                 void *workspace, size_t workspace_bytes, kd_stream_t stream);
+/* The same transpose for either corner convention (align_corners = 0: the last upsample of GSCNN, models/gscnn/gscnn.py:323). */
+int kd_upsample_bilinear_bwd(const void *gy, int32_t gy_dtype, int32_t ldgy, void *gx, int32_t gx_dtype, int32_t ldgx,
+                             int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, int32_t align_corners,
+                             void *workspace, size_t workspace_bytes, kd_stream_t stream);
 int kd_zero_insert(int32_t dtype, const void *x, int32_t ldx, void *y, int32_t ldy, int32_t N, int32_t H, int32_t W,
                    int32_t C, int32_t stride, int32_t Hy, int32_t Wy, kd_stream_t stream);
 int kd_relu_bn_bwd(int32_t dtype, const void *g, int32_t ldg, const void *mask, int32_t ldm, const float *scale,
@@ -418,6 +422,34 @@ typedef struct kd_radam_tensor {
     float lr, beta1, beta2, eps, weight_decay;
 } kd_radam_tensor;
 int kd_radam_step_multi(const kd_radam_tensor *ts, int32_t count, kd_stream_t stream);
+
+/* ------------------------------------------------- Gated-SCNN shape stream, backward (models/gscnn/gscnn.py:269-314 under autograd)
+ * The forward kernels (kd_gated_conv, kd_pointwise_small, kd_edge_attention, kd_edge_aspp) fuse per-pixel algebra; loss.backward()
+ * (trainer/layerwise_trainer.py:235) through them -- `aspp` hints, loss terms on the logits, trainable shape-stream parameters --
+ * is built from these general pieces (fp32 arithmetic, either storage type, deterministic reductions):
+ *
+ * kd_small_linear: y[p][co] (+)= bias[co] + sum_ci w[co*Cin + ci] * x[p][ci], optional ReLU; 1 <= Cin, Cout <= 72.  The forward of any
+ *   1x1 map of the stream (nn.Conv2d(C, C', 1): d1..d3, gscnn.py:232-236; the two 1x1 convs inside GatedSpatialConv2d._gate_conv,
+ *   gate_spatial_conv.py:36-43) and, given the transposed matrix, its input gradient.
+ * kd_small_wgrad: dw[cb*Ca + ca] = sum_p b[p][cb] * a[p][ca], db[cb] = sum_p b[p][cb] (db may be NULL): weight / bias gradient of the
+ *   same maps with a = the map's input, b = the gradient of its output.
+ * kd_gate_mix_bwd: GatedSpatialConv2d's tail `input_features * (alphas + 1)` (gate_spatial_conv.py:58-59) with alphas = sigmoid(a):
+ *   v = feat * (sigmoid(a) + 1) (if v), gfeat = gv * (sigmoid(a) + 1) (if gfeat), ga = (sum_c gv * feat) * sigmoid'(a) (if ga).
+ * kd_edge_attention_bwd: backward of kd_edge_attention (gscnn.py:308-314): g_t = dL/d(cw pre-activation), g_s = dL/d(fuse
+ *   pre-activation), eo_canny[p] = (sigmoid(fuse . cs), canny) -- the cw conv's input, for its weight gradient.
+ * kd_rank1_add: y[p][c] (+)= g[p] * w[c]: input gradient of a C -> 1 1x1 conv (the dsn3 / dsn4 / dsn7 side outputs, gscnn.py:272-277). */
+int kd_small_linear(const void *x, int32_t x_dtype, int32_t ldx, int32_t Cin, const float *w, const float *bias, void *y,
+                    int32_t y_dtype, int32_t ldy, int32_t Cout, int64_t npix, int32_t accumulate, int32_t relu,
+                    const float *mask /* fp32 (npix, ldm) or NULL: y = mask > 0 ? y : 0 */, int32_t ldm, kd_stream_t stream);
+size_t kd_small_wgrad_workspace(int32_t Ca, int32_t Cb, int64_t npix);
+int kd_small_wgrad(const void *a, int32_t a_dtype, int32_t lda, int32_t Ca, const void *b, int32_t b_dtype, int32_t ldb, int32_t Cb,
+                   int64_t npix, float *dw, float *db, int32_t accumulate, void *workspace, size_t workspace_bytes, kd_stream_t stream);
+int kd_gate_mix_bwd(const void *feat, int32_t feat_dtype, int32_t ldf, const float *a, const float *gv, int32_t ldgv, float *gfeat,
+                    int32_t ldgf, float *ga, float *v, int32_t ldv, int32_t C, int64_t npix, kd_stream_t stream);
+int kd_edge_attention_bwd(int32_t dtype, const void *cs, int32_t ldc, const float *canny, const float *weights, const float *g_acts,
+                          float *g_t, float *g_s, float *eo_canny, int64_t npix, kd_stream_t stream);
+int kd_rank1_add(int32_t dtype, void *y, int32_t ldy, const float *g, const float *w, int32_t C, int64_t npix, int32_t accumulate,
+                 kd_stream_t stream);
 
 /* ----------------------------------------------------------------- diagnostics (host side only; no launch changes)
  * Kernel-selection log: the dispatchers behind kd_conv2d_fwd / kd_conv2d_wgrad / kd_pw_wgrad / kd_dwconv_* /

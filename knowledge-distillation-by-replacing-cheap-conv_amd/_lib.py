@@ -127,6 +127,14 @@ _SIGS = {
     "kd_confusion": (c_int, [_P(View3), c_vp, c_int, c_int, c_i64, c_vp, c_int, c_vp]),
     "kd_radam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f, c_f, c_f, c_f, c_f, c_vp]),
     "kd_radam_step_multi": (c_int, [_P(RadamTensor), c_int, c_vp]),
+    "kd_small_linear": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_i64, c_int, c_int, c_vp, c_int, c_vp]),
+    "kd_upsample_bilinear_bwd": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp,
+                                         c_sz, c_vp]),
+    "kd_small_wgrad_workspace": (c_sz, [c_int, c_int, c_i64]),
+    "kd_small_wgrad": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_i64, c_vp, c_vp, c_int, c_vp, c_sz, c_vp]),
+    "kd_gate_mix_bwd": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_i64, c_vp]),
+    "kd_edge_attention_bwd": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "kd_rank1_add": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_int, c_i64, c_int, c_vp]),
     "kd_debug_kernel_log_enable": (c_int, [c_int]),
     "kd_debug_kernel_log_read": (c_i64, [C.c_char_p, c_sz]),
     "kd_debug_last_kernel": (C.c_char_p, []),

@@ -290,9 +290,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_gather_kernel(const uint2 *__
 // forward: src = o * (I - 1) / (O - 1); i0 = floor(src), i1 = min(i0 + 1, I - 1), f = src - i0; y[o] = (1-f) x[i0] + f x[i1].
 // backward along one axis: gx[i] = sum_o [i0(o) == i] (1 - f(o)) gy[o] + [i1(o) == i] f(o) gy[o]; the candidate range of o is
 // bracketed generously and every candidate re-evaluates the forward's own (i0, i1, f), so the two sides cannot disagree.
-__device__ __forceinline__ void up_src(int o, float sc, int I, int &i0, int &i1, float &f)
+__device__ __forceinline__ void up_src(int o, float sc, float off, int I, int &i0, int &i1, float &f)
 {
-    const float src = o * sc;
+    // align_corners=True: off = 0, sc = (I-1)/(O-1); align_corners=False: sc = I/O, off = 0.5 sc - 0.5, clamped at 0 (the
+    // forward kernel's own expression, trunk_ops.hip upsample_kernel)
+    const float src = fmaxf(o * sc + off, 0.f);
     i0 = min((int)src, I - 1);
     i1 = min(i0 + 1, I - 1);
     f = src - (float)i0;
@@ -302,7 +304,7 @@ __device__ __forceinline__ void up_src(int o, float sc, int I, int &i0, int &i1,
 // decoder gradient took 1.33 ms one element per thread), VEC = 1: any C (the 19-class logits).
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void upsample_bwd_w_kernel(const T *__restrict__ gy, int ldgy, float *__restrict__ tmp, int N,
-                                                             int Ho, int Wo, int W, int C, float sw)
+                                                             int Ho, int Wo, int W, int C, float sw, float ow)
 {
     const int CV = C / VEC;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_w_kernel(const T *__restrict
     const int w = i / CV, c = (i - w * CV) * VEC;
     const int ho = blockIdx.y, n = blockIdx.z;
     const float inv = sw > 0.f ? 1.f / sw : 0.f;
-    int lo = sw > 0.f ? (int)((w - 1) * inv) - 1 : 0, hi = sw > 0.f ? (int)((w + 1) * inv) + 2 : Wo - 1;
+    int lo = sw > 0.f ? (int)((w - 1 - ow) * inv) - 1 : 0, hi = sw > 0.f ? (int)((w + 1 - ow) * inv) + 2 : Wo - 1;
     lo = max(lo, 0); hi = min(hi, Wo - 1);
     const T *row = gy + (((size_t)n * Ho + ho) * Wo) * ldgy + c;
     float acc[VEC];
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_w_kernel(const T *__restrict
     for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
     for (int o = lo; o <= hi; ++o) {
         int i0, i1; float f;
-        up_src(o, sw, W, i0, i1, f);
+        up_src(o, sw, ow, W, i0, i1, f);
         float wgt = 0.f;
         if (i0 == w) wgt += 1.f - f;
         if (i1 == w) wgt += f;
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_w_kernel(const T *__restrict
 // pass 2: along H.  tmp (N, Ho, W, C) float -> gx (N, H, W, C)
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void upsample_bwd_h_kernel(const float *__restrict__ tmp, T *__restrict__ gx, int ldgx, int N, int Ho,
-                                                             int H, int W, int C, float sh)
+                                                             int H, int W, int C, float sh, float oh)
 {
     const int CV = C / VEC;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -349,14 +351,14 @@ __global__ __launch_bounds__(256) void upsample_bwd_h_kernel(const float *__rest
     const int w = i / CV, c = (i - w * CV) * VEC;
     const int h = blockIdx.y, n = blockIdx.z;
     const float inv = sh > 0.f ? 1.f / sh : 0.f;
-    int lo = sh > 0.f ? (int)((h - 1) * inv) - 1 : 0, hi = sh > 0.f ? (int)((h + 1) * inv) + 2 : Ho - 1;
+    int lo = sh > 0.f ? (int)((h - 1 - oh) * inv) - 1 : 0, hi = sh > 0.f ? (int)((h + 1 - oh) * inv) + 2 : Ho - 1;
     lo = max(lo, 0); hi = min(hi, Ho - 1);
     float acc[VEC];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
     for (int o = lo; o <= hi; ++o) {
         int i0, i1; float f;
-        up_src(o, sh, H, i0, i1, f);
+        up_src(o, sh, oh, H, i0, i1, f);
         float wgt = 0.f;
         if (i0 == h) wgt += 1.f - f;
         if (i1 == h) wgt += f;
@@ -610,37 +612,53 @@ extern "C" size_t kd_upsample_bilinear_ac_bwd_workspace(int32_t N, int32_t H, in
     return (size_t)N * Ho * W * C * sizeof(float);
 }
 
+extern "C" int kd_upsample_bilinear_bwd(const void *gy, int32_t gy_dtype, int32_t ldgy, void *gx, int32_t gx_dtype, int32_t ldgx,
+                                        int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, int32_t align_corners,
+                                        void *workspace, size_t workspace_bytes, kd_stream_t stream);
+
 extern "C" int kd_upsample_bilinear_ac_bwd(const void *gy, int32_t gy_dtype, int32_t ldgy, void *gx, int32_t gx_dtype, int32_t ldgx,
                                            int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, void *workspace,
                                            size_t workspace_bytes, kd_stream_t stream)
+{
+    return kd_upsample_bilinear_bwd(gy, gy_dtype, ldgy, gx, gx_dtype, ldgx, N, H, W, C, Ho, Wo, 1, workspace, workspace_bytes, stream);
+}
+
+extern "C" int kd_upsample_bilinear_bwd(const void *gy, int32_t gy_dtype, int32_t ldgy, void *gx, int32_t gx_dtype, int32_t ldgx,
+                                        int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, int32_t align_corners,
+                                        void *workspace, size_t workspace_bytes, kd_stream_t stream)
 {
     KD_REQUIRE(gy && gx && workspace && N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0, KD_ERR_INVALID,
                "kd_upsample_bilinear_ac_bwd: bad argument");
     KD_REQUIRE(ok_dt(gy_dtype) && ok_dt(gx_dtype), KD_ERR_INVALID, "kd_upsample_bilinear_ac_bwd: bad dtype");
     KD_REQUIRE(workspace_bytes >= kd_upsample_bilinear_ac_bwd_workspace(N, H, W, C, Ho, Wo), KD_ERR_WORKSPACE,
                "kd_upsample_bilinear_ac_bwd: workspace too small");
-    const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;   // the forward kernel's scales (kd_upsample_bilinear_ac)
-    const float sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;   // the forward kernel's scales and offsets (kd_upsample_bilinear)
+    float sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    float oh = 0.f, ow = 0.f;
+    if (!align_corners) {
+        sh = (float)H / (float)Ho; sw = (float)W / (float)Wo;
+        oh = 0.5f * sh - 0.5f; ow = 0.5f * sw - 0.5f;
+    }
     hipStream_t s = (hipStream_t)stream;
     float *tmp = (float *)workspace;
     const bool vec = C % 8 == 0 && vec_ok(gy, ldgy, kd_elem_size(gy_dtype)) && vec_ok(gx, ldgx, kd_elem_size(gx_dtype)) && kd_aligned16(tmp);
     const int cv = vec ? C / 8 : C;
     const dim3 g1((unsigned)((W * cv + 255) / 256), (unsigned)Ho, (unsigned)N);
     if (vec) {
-        if (gy_dtype == KD_BF16) hipLaunchKernelGGL((upsample_bwd_w_kernel<bf16_t, 8>), g1, dim3(256), 0, s, (const bf16_t *)gy, ldgy, tmp, N, Ho, Wo, W, C, sw);
-        else hipLaunchKernelGGL((upsample_bwd_w_kernel<float, 8>), g1, dim3(256), 0, s, (const float *)gy, ldgy, tmp, N, Ho, Wo, W, C, sw);
+        if (gy_dtype == KD_BF16) hipLaunchKernelGGL((upsample_bwd_w_kernel<bf16_t, 8>), g1, dim3(256), 0, s, (const bf16_t *)gy, ldgy, tmp, N, Ho, Wo, W, C, sw, ow);
+        else hipLaunchKernelGGL((upsample_bwd_w_kernel<float, 8>), g1, dim3(256), 0, s, (const float *)gy, ldgy, tmp, N, Ho, Wo, W, C, sw, ow);
     } else {
-        if (gy_dtype == KD_BF16) hipLaunchKernelGGL((upsample_bwd_w_kernel<bf16_t, 1>), g1, dim3(256), 0, s, (const bf16_t *)gy, ldgy, tmp, N, Ho, Wo, W, C, sw);
-        else hipLaunchKernelGGL((upsample_bwd_w_kernel<float, 1>), g1, dim3(256), 0, s, (const float *)gy, ldgy, tmp, N, Ho, Wo, W, C, sw);
+        if (gy_dtype == KD_BF16) hipLaunchKernelGGL((upsample_bwd_w_kernel<bf16_t, 1>), g1, dim3(256), 0, s, (const bf16_t *)gy, ldgy, tmp, N, Ho, Wo, W, C, sw, ow);
+        else hipLaunchKernelGGL((upsample_bwd_w_kernel<float, 1>), g1, dim3(256), 0, s, (const float *)gy, ldgy, tmp, N, Ho, Wo, W, C, sw, ow);
     }
     KD_CHECK_LAUNCH("kd_upsample_bilinear_ac_bwd(w)");
     const dim3 g2((unsigned)((W * cv + 255) / 256), (unsigned)H, (unsigned)N);
     if (vec) {
-        if (gx_dtype == KD_BF16) hipLaunchKernelGGL((upsample_bwd_h_kernel<bf16_t, 8>), g2, dim3(256), 0, s, (const float *)tmp, (bf16_t *)gx, ldgx, N, Ho, H, W, C, sh);
-        else hipLaunchKernelGGL((upsample_bwd_h_kernel<float, 8>), g2, dim3(256), 0, s, (const float *)tmp, (float *)gx, ldgx, N, Ho, H, W, C, sh);
+        if (gx_dtype == KD_BF16) hipLaunchKernelGGL((upsample_bwd_h_kernel<bf16_t, 8>), g2, dim3(256), 0, s, (const float *)tmp, (bf16_t *)gx, ldgx, N, Ho, H, W, C, sh, oh);
+        else hipLaunchKernelGGL((upsample_bwd_h_kernel<float, 8>), g2, dim3(256), 0, s, (const float *)tmp, (float *)gx, ldgx, N, Ho, H, W, C, sh, oh);
     } else {
-        if (gx_dtype == KD_BF16) hipLaunchKernelGGL((upsample_bwd_h_kernel<bf16_t, 1>), g2, dim3(256), 0, s, (const float *)tmp, (bf16_t *)gx, ldgx, N, Ho, H, W, C, sh);
-        else hipLaunchKernelGGL((upsample_bwd_h_kernel<float, 1>), g2, dim3(256), 0, s, (const float *)tmp, (float *)gx, ldgx, N, Ho, H, W, C, sh);
+        if (gx_dtype == KD_BF16) hipLaunchKernelGGL((upsample_bwd_h_kernel<bf16_t, 1>), g2, dim3(256), 0, s, (const float *)tmp, (bf16_t *)gx, ldgx, N, Ho, H, W, C, sh, oh);
+        else hipLaunchKernelGGL((upsample_bwd_h_kernel<float, 1>), g2, dim3(256), 0, s, (const float *)tmp, (float *)gx, ldgx, N, Ho, H, W, C, sh, oh);
     }
     KD_CHECK_LAUNCH("kd_upsample_bilinear_ac_bwd(h)");
     return KD_OK;

@@ -126,6 +126,11 @@ class StudentEngine:
         self.edge_prior = None   # (N,H,W) fp32 Canny map handed in by the caller (teacher and student share one per batch)
         self.exported = None     # inputs of block k kept for the student (forward(export_at=k))
         self._next_prefix = None
+        # Gated-SCNN: gradients enter the shape stream only through the logits (a loss term on them) or an `aspp` hint -- never
+        # under the shipped plan's hint losses.  The owner says which it is (DepthwiseStudent.logits_need_grad, set by trainers
+        # that back-propagate a logit loss): the stream then runs on the general kernels and keeps its intermediates.
+        self.logits_need_grad = False
+        self._differentiable = False
 
     def compute_edge_prior(self, x_nchw):
         """The Canny prior of the batch: the device kernel, or the model's `canny_fn` plug point (tests feed the goldens' map)."""
@@ -251,8 +256,7 @@ class StudentEngine:
         graph can capture: a conv site `modN.blockM.convs.convK`, a block's `modN.blockM.convs` or `modN.blockM` (both the
         block output), an ASPP branch conv `aspp.features.N.0`, or `aspp` (the module output)."""
         ok = {f"aspp.features.{i}.0" for i in range(len(self.net.aspp.features))}
-        if not self.is_gscnn:
-            ok.add("aspp")   # (GSCNN's `aspp` output carries the edge branch, whose gradient re-enters the trunk: not built)
+        ok.add("aspp")   # (GSCNN: the edge branch's gradient re-enters the trunk through the shape stream, _shape_stream_bwd)
         for name, blk in self._flat_blocks():
             ok.add(name)
             ok.add(f"{name}.convs")
@@ -372,6 +376,7 @@ class StudentEngine:
             tape["blocks"].append(rec)
             if self.is_gscnn and mod_end:
                 tape.setdefault("mods", {})[name.split(".")[0]] = x_raw
+                tape.setdefault("mod_end", {})[name.split(".")[0]] = (bi, rg)
             if last_of_mod2:
                 m2 = x_raw
                 sc, sh = self._bn_fold(flat[bi + 1][1].bn1)
@@ -381,7 +386,9 @@ class StudentEngine:
         x7, rg7 = x_raw, rg
 
         if self.is_gscnn:
-            tape["acts"] = self._shape_stream(xin, s, tape["mods"]["mod3"], tape["mods"]["mod4"], x7)
+            train_shape = self._differentiable and (self.logits_need_grad or "aspp" in want)
+            tape["shape"] = {} if train_shape else None
+            tape["acts"] = self._shape_stream(xin, s, tape["mods"]["mod3"], tape["mods"]["mod4"], x7, rec=tape["shape"])
         cat, rg_cat = self._aspp_fwd(net.aspp, x7, rg7, want, note_hint, tape)
         logits = self._decoder_fwd(cat, rg_cat, m2, tape["pools"]["pool3"]["rg"], (H, W), tape)
 
@@ -456,19 +463,25 @@ class StudentEngine:
             sp = torch.zeros(cpad, dtype=torch.float32, device=w.device)
             sp[:shift.numel()] = shift
             return (ops.pack_conv_weight(wp, self.dtype, KD_PACK_FWD), sp)
-        return self._packed(conv.weight, ("bnfold", self.dtype, cpad, id(bn)), make)
+        bnm = _bn_of(bn)
+        return self._packed(conv.weight, ("bnfold", self.dtype, cpad, id(bn)), make,
+                            extra=(bnm.weight._version, bnm.bias._version, bnm.running_mean._version, bnm.running_var._version))
 
-    def _basic_block(self, blk, x, cpad=64):
+    def _basic_block(self, blk, x, cpad=64, rec=None):
         """Resnet.BasicBlock (encoders/Resnet.py:64-99) on a cpad-channel buffer: two row-buffer 3x3 convs, BN folded into the
         weights, bias + ReLU (+ identity shortcut) in the epilogues.  bf16 blocks of 16 / 32 / 64 channels (res3, res2, res1) run
         on kd_conv3x3_small instead: dense C-channel input and intermediate, the result in the first C channels of a 64-channel
-        buffer whose pad channels were zeroed once (its reader is a 1x1 conv padded to the 64-channel GEMM granule)."""
-        for p in blk.parameters():
-            if p.requires_grad:
-                raise EngineError("trainable shape-stream parameters are not supported (the GSCNN plan keeps them frozen)")
+        buffer whose pad channels were zeroed once (its reader is a 1x1 conv padded to the 64-channel GEMM granule).
+        rec (a list): the stream is being differentiated -- general kernels only, nothing in persistent buffers, and
+        (blk, x, t, y) is appended for _basic_block_bwd."""
+        if rec is None:
+            for p in blk.parameters():
+                if p.requires_grad:
+                    raise EngineError("trainable shape-stream parameters need the differentiable shape stream: set "
+                                      "DepthwiseStudent.logits_need_grad = True (trainers that back-propagate a logit loss do)")
         N, H, W, cx = x.shape
         planes = blk.conv1.out_channels
-        if _SMALL_CONV and self.dtype == torch.bfloat16 and planes in (16, 32, 64) and blk.conv1.in_channels == planes:
+        if rec is None and _SMALL_CONV and self.dtype == torch.bfloat16 and planes in (16, 32, 64) and blk.conv1.in_channels == planes:
             w1, s1 = self._w_bn_folded(blk.conv1, blk.bn1, planes)
             w2, s2 = self._w_bn_folded(blk.conv2, blk.bn2, planes)
             xin = x if cx == planes else x[..., :planes]
@@ -483,6 +496,8 @@ class StudentEngine:
         ops.conv2d(x, w1, 1, 1, 1, out_act=t, act_shift=s1, act_relu=True)
         y = self._new(N, H, W, cpad)
         ops.conv2d(t, w2, 1, 1, 1, res_pre=x, out_act=y, act_shift=s2, act_relu=True)
+        if rec is not None:
+            rec.append((blk, x, t, y))
         return y
 
     def _zero_padded(self, tag, N, H, W, C):
@@ -499,7 +514,8 @@ class StudentEngine:
     def _gate_params(self, gate):
         """GatedSpatialConv2d -> the packed fp32 vector kd_gated_conv takes (both eval-mode BNs folded)."""
         ent = self._gate_prm.get(id(gate))
-        if ent is not None and ent[0] is gate:
+        ver = tuple(t._version for t in list(gate.parameters()) + list(gate.buffers()))     # trainable gates change every step
+        if ent is not None and ent[0] is gate and ent[2] == ver:
             return ent[1]
         bn0, c1, _, c2, bn4, _ = gate._gate_conv
         hdim = c1.in_channels
@@ -509,21 +525,41 @@ class StudentEngine:
         prm = torch.cat([(w1 * s0.view(1, -1)).reshape(-1), c1.bias.detach().float() + w1 @ t0,
                          c2.weight.detach().float().view(hdim) * s4, c2.bias.detach().float() * s4 + t4,
                          gate.weight.detach().float().reshape(-1)]).contiguous()
-        self._gate_prm[id(gate)] = (gate, prm)
+        self._gate_prm[id(gate)] = (gate, prm, ver)
         return prm
 
-    def _shape_stream(self, x_nchw, m1, m3, m4, m7):
+    def _w_bn_folded_dgrad(self, conv, bn, cpad):
+        """Input-gradient operand of a BN-folded 3x3 conv (see _w_bn_folded): [Cin][flipped taps][Cout] of w * scale[co], padded."""
+        def make():
+            scale, _ = self._bn_fold(bn)
+            w = conv.weight.detach().float() * scale.view(-1, 1, 1, 1)
+            wp = torch.zeros((cpad, cpad) + tuple(w.shape[2:]), dtype=torch.float32, device=w.device)
+            wp[:w.shape[0], :w.shape[1]] = w
+            return ops.pack_conv_weight(wp, self.dtype, KD_PACK_DGRAD)
+        bnm = _bn_of(bn)
+        return self._packed(conv.weight, ("bnfold_dgrad", self.dtype, cpad, id(bn)), make,
+                            extra=(bnm.weight._version, bnm.bias._version, bnm.running_var._version))
+
+    def _shape_stream(self, x_nchw, m1, m3, m4, m7, rec=None):
         """gscnn.py:269-314: edge attention `acts` (N,H,W) fp32 from the stem output, the three side outputs and the Canny
-        prior.  The reference's interpolations of full-resolution tensors to the full resolution are identities."""
+        prior.  The reference's interpolations of full-resolution tensors to the full resolution are identities.
+        rec (a dict): the stream is being differentiated (see forward); every layer's operands are recorded for
+        _shape_stream_bwd and the bf16-only small-channel kernels / persistent buffers are not used."""
         net = self.net
         N, H, W, _ = m1.shape
+        train = rec is not None
+        if train:
+            rec.update(sides=[], blocks=[], squeezes=[], gates=[], m1=m1)
 
         def side(conv, t):   # dsnK: 1x1 (C -> 1) + bias, then bilinear (align_corners) to the input size
             o = self._new(N, t.shape[1], t.shape[2], 1)
             ops.conv2d(t, self._w_fwd(conv), out_act=o, act_shift=conv.bias.detach().float().contiguous())
-            return ops.upsample_bilinear_ac(o, (H, W))
+            smap = ops.upsample_bilinear_ac(o, (H, W))
+            if train:
+                rec["sides"].append((conv, t))
+            return smap
 
-        small = _SMALL_CONV and self.dtype == torch.bfloat16
+        small = _SMALL_CONV and self.dtype == torch.bfloat16 and not train
 
         def squeeze(conv, x, cout):   # dK: 1x1 + bias -> `cout` dense channels (its only reader is the gated conv)
             if small and (conv.in_channels, cout) in ((64, 32), (32, 16), (16, 8)) and x.shape[3] == conv.in_channels:
@@ -532,6 +568,8 @@ class StudentEngine:
             buf = self._new(N, H, W, cout)
             ops.conv2d(x, self._w_fwd(conv, cin_pad=64 if conv.in_channels < 64 else None), out_act=buf,
                        act_shift=conv.bias.detach().float().contiguous())
+            if train:
+                rec["squeezes"].append((conv, x, buf))
             return buf
 
         def gated(gate, buf, side_map, c):
@@ -539,18 +577,173 @@ class StudentEngine:
             # with zero pad channels (the GEMM kernels read all 64)
             if small:
                 return ops.gated_conv(buf, side_map, self._gate_params(gate), c, out=self._new(N, H, W, c))
-            out = self._zero_padded(("gated", id(gate)), N, H, W, 64)
+            out = self._new(N, H, W, 64, zero=True) if train else self._zero_padded(("gated", id(gate)), N, H, W, 64)
             ops.gated_conv(buf, side_map, self._gate_params(gate), c, out=out[..., :c])
+            if train:
+                rec["gates"].append((gate, buf, side_map, c))
             return out
 
+        blocks = rec["blocks"] if train else None
         s3, s4, s7 = side(net.dsn3, m3), side(net.dsn4, m4), side(net.dsn7, m7)
         # (small: the BasicBlocks hand dense C-channel tensors to kd_pointwise_small; else 64-channel buffers to the GEMM kernels)
-        cs = gated(net.gate1, squeeze(net.d1, self._basic_block(net.res1, m1), 32), s3, 32)
-        cs = gated(net.gate2, squeeze(net.d2, self._basic_block(net.res2, cs, 32 if small else 64), 16), s4, 16)
-        cs = gated(net.gate3, squeeze(net.d3, self._basic_block(net.res3, cs, 16 if small else 64), 8), s7, 8)
+        cs = gated(net.gate1, squeeze(net.d1, self._basic_block(net.res1, m1, rec=blocks), 32), s3, 32)
+        cs = gated(net.gate2, squeeze(net.d2, self._basic_block(net.res2, cs, 32 if small else 64, rec=blocks), 16), s4, 16)
+        cs = gated(net.gate3, squeeze(net.d3, self._basic_block(net.res3, cs, 16 if small else 64, rec=blocks), 8), s7, 8)
         canny = self.edge_prior if self.edge_prior is not None else self.compute_edge_prior(x_nchw)
         w = torch.cat([net.fuse.weight.detach().float().reshape(-1), net.cw.weight.detach().float().reshape(-1)]).contiguous()
+        if train:
+            rec["edge"] = (cs, canny, w)
         return ops.edge_attention(cs, canny, w)
+
+    # ---- Gated-SCNN shape stream, backward (gscnn.py:269-314 under autograd) ---------------------------------------------------
+    def _give(self, p, g, grads):
+        """Hand the gradient `g` of parameter p (any shape with p's element count) to autograd / the reducer."""
+        if p is None or not p.requires_grad:
+            return
+        buf = self._grad_like(p)
+        buf.copy_(g.reshape(buf.shape))
+        grads[p] = buf
+        self._grad_done(p)
+
+    def _bn_raw(self, bn):
+        """(gamma, beta, mean, sigma) of an eval-mode BatchNorm as fp32 vectors."""
+        return (bn.weight.detach().float(), bn.bias.detach().float(), bn.running_mean.float(),
+                torch.sqrt(bn.running_var.float() + bn.eps))
+
+    def _basic_block_bwd(self, blk, x, t, y, g_y, grads, need_in):
+        """Backward of _basic_block's general path on 64-channel padded buffers.  y = relu(z2 + x), z2 = bn2(conv2(t)),
+        t = relu(bn1(conv1(x))), both BNs folded into the convs in the forward.  g_y: (N,H,W,64) gradient (pad channels zero)."""
+        C = blk.conv1.out_channels
+        ones = self._ones(y.shape[3])
+        g_z2 = ops.relu_bn_bwd(g_y, y, ones)                                                  # through the last ReLU
+        g_z1 = self._new(*t.shape)
+        ops.conv2d(g_z2, self._w_bn_folded_dgrad(blk.conv2, blk.bn2, y.shape[3]), 1, 1, 1, out_raw=g_z1, mask=t)   # dgrad2, then ReLU of t
+        for conv, bn, a_in, g_z, act, sub in ((blk.conv2, blk.bn2, t, g_z2, y, x), (blk.conv1, blk.bn1, x, g_z1, t, None)):
+            scale, _ = self._bn_fold(bn)
+            if conv.weight.requires_grad:
+                gw = torch.empty((a_in.shape[3], a_in.shape[3], 3, 3), dtype=torch.float32, device=a_in.device)
+                ops.conv2d_wgrad(a_in, g_z, gw, 1, 1, 1)
+                self._give(conv.weight, gw[:C, :C] * scale.view(-1, 1, 1, 1), grads)           # the conv ran with w * scale[co]
+            if bn.weight.requires_grad or bn.bias.requires_grad:
+                # z = bn(c): dbeta = sum g_z, dgamma = sum g_z (z - beta) / gamma, with z = act (- shortcut) where the ReLU passed
+                s1, s2 = ops.channel_sums(g_z, a=act)
+                if sub is not None:
+                    _, s2b = ops.channel_sums(g_z, a=sub)
+                    s2 = s2 - s2b
+                gamma, beta, _, _ = self._bn_raw(bn)
+                self._give(bn.bias, s1[:C], grads)
+                self._give(bn.weight, (s2[:C] - beta * s1[:C]) / gamma, grads)
+        if not need_in:
+            return None
+        g_x = self._new(*x.shape)
+        ops.conv2d(g_z1, self._w_bn_folded_dgrad(blk.conv1, blk.bn1, x.shape[3]), 1, 1, 1, out_raw=g_x, res_post=g_z2)
+        return g_x
+
+    def _ones(self, n):
+        key = ("ones", n)
+        if key not in self._persist or self._persist[key].device != self.device:
+            self._persist[key] = torch.ones(n, dtype=torch.float32, device=self.device)
+        return self._persist[key]
+
+    def _gated_conv_bwd(self, gate, feat, side_map, C, g_out, grads):
+        """Backward of GatedSpatialConv2d (gate_spatial_conv.py:50-60): returns (g_feat (N,H,W,C) fp32, g_gate (N,H,W) fp32).
+        The hidden activations are recomputed from feat / the side map with the folded parameters the forward used."""
+        bn0, c1, _, c2, bn4, _ = gate._gate_conv
+        Hd = C + 1
+        s0, t0 = self._bn_fold(bn0)
+        s4, t4 = self._bn_fold(bn4)
+        W1 = c1.weight.detach().float().view(Hd, Hd)
+        b1 = c1.bias.detach().float()
+        w2 = c2.weight.detach().float().view(1, Hd)
+        b2 = c2.bias.detach().float()
+        W1f, b1f = W1 * s0.view(1, -1), b1 + W1 @ t0
+        w2f, b2f = w2 * s4, b2 * s4 + t4
+        Wg = gate.weight.detach().float().view(C, C)
+        f = feat[..., :C]
+        U = torch.cat([f.float(), side_map.float().reshape(f.shape[:3] + (1,))], dim=3)     # [feat; gate] (a copy, no arithmetic)
+        Z = ops.small_linear(U, W1f, b1f, relu=True)
+        A = ops.small_linear(Z, w2f, b2f).reshape(f.shape[:3])
+        g_v = ops.small_linear(g_out[..., :C], Wg.t().contiguous(), out_dtype=torch.float32)
+        g_feat, g_a, v = ops.gate_mix_bwd(f, A, gv=g_v, want_v=gate.weight.requires_grad)
+        if gate.weight.requires_grad:
+            dWg, _ = ops.small_wgrad(v, g_out[..., :C])
+            self._give(gate.weight, dWg, grads)
+        g_a1 = g_a.unsqueeze(3)
+        train_gate = any(p.requires_grad for p in gate._gate_conv.parameters())
+        g_H = ops.small_linear(g_a1, w2f.t().contiguous(), mask=Z)                          # through c2, then the ReLU of Z
+        if train_gate:
+            dw2f, db2f = ops.small_wgrad(Z, g_a1, want_bias=True)                             # (1, Hd), (1,)
+            dW1f, db1f = ops.small_wgrad(U, g_H, want_bias=True)                              # (Hd, Hd), (Hd,)
+            # folded -> raw parameters: W1f = W1 diag(s0), b1f = b1 + W1 t0; w2f = w2 s4, b2f = b2 s4 + t4;  s = gamma / sigma,
+            # t = beta - mean s
+            self._give(c1.weight, dW1f * s0.view(1, -1) + db1f.view(-1, 1) * t0.view(1, -1), grads)
+            self._give(c1.bias, db1f, grads)
+            ds0, dt0 = (dW1f * W1).sum(0), (db1f.view(-1, 1) * W1).sum(0)
+            _, _, mu0, sig0 = self._bn_raw(bn0)
+            self._give(bn0.weight, (ds0 - mu0 * dt0) / sig0, grads)
+            self._give(bn0.bias, dt0, grads)
+            self._give(c2.weight, dw2f * s4, grads)
+            self._give(c2.bias, db2f * s4, grads)
+            ds4, dt4 = (dw2f * w2).sum().view(1) + db2f * b2, db2f
+            _, _, mu4, sig4 = self._bn_raw(bn4)
+            self._give(bn4.weight, (ds4 - mu4 * dt4) / sig4, grads)
+            self._give(bn4.bias, dt4, grads)
+        W1ft = W1f.t().contiguous()                                                          # (Hd in, Hd out) -> rows = inputs
+        ops.small_linear(g_H, W1ft[:C], out=g_feat, accumulate=True)                         # g_feat += (W1f^T g_H)[:C]
+        g_gate = ops.small_linear(g_H, W1ft[C:C + 1]).reshape(f.shape[:3])
+        return g_feat, g_gate
+
+    def _shape_stream_bwd(self, g_acts, grads, need):
+        """g_acts: (N,H,W) fp32 gradient of the edge attention.  need: {'m1','m3','m4','m7'} -> bool, which trunk tensors have
+        trainable parameters upstream.  Returns {name: gradient tensor in the engine dtype | None}."""
+        rec = self._tape["shape"]
+        net = self.net
+        cs, canny, w = rec["edge"]
+        N, H, W = g_acts.shape
+        g_t, g_s, eo_canny = ops.edge_attention_bwd(cs, canny, w, g_acts.contiguous())
+        if net.fuse.weight.requires_grad:
+            self._give(net.fuse.weight, ops.small_wgrad(cs[..., :8], g_s.unsqueeze(3))[0], grads)
+        if net.cw.weight.requires_grad:
+            self._give(net.cw.weight, ops.small_wgrad(eo_canny, g_t.unsqueeze(3))[0], grads)
+        g = ops.small_linear(g_s.unsqueeze(3), net.fuse.weight.detach().float().view(1, 8).t().contiguous())   # (N,H,W,8) fp32
+        out = {"m1": None, "m3": None, "m4": None, "m7": None}
+        side_names = ["m3", "m4", "m7"]
+        for k in (2, 1, 0):                                      # gate3/d3/res3 ... gate1/d1/res1
+            gate, feat, side_map, C = rec["gates"][k]
+            g_feat, g_gate = self._gated_conv_bwd(gate, feat, side_map, C, g, grads)
+            # side output: s = upsample(conv1x1(m) + b)
+            conv, m = rec["sides"][k]
+            nm = side_names[k]
+            if need[nm] or conv.weight.requires_grad or conv.bias.requires_grad:
+                g_o = ops.upsample_bilinear_ac_bwd(g_gate.unsqueeze(3), (m.shape[1], m.shape[2]))              # (N,h,w,1) fp32
+                if conv.weight.requires_grad or conv.bias.requires_grad:
+                    pad8 = torch.zeros(g_o.shape[:3] + (8,), dtype=m.dtype, device=m.device)
+                    pad8[..., 0:1] = g_o.to(m.dtype)
+                    dw8 = torch.empty((8, m.shape[3], 1, 1), dtype=torch.float32, device=m.device)
+                    ops.pw_wgrad(m, pad8, dw8)
+                    self._give(conv.weight, dw8[0], grads)
+                    self._give(conv.bias, ops.channel_sums(pad8)[0][0:1], grads)
+                if need[nm]:
+                    gm = self._new(*m.shape)
+                    ops.rank1_add(gm, g_o.reshape(-1), conv.weight.detach().float().reshape(-1), accumulate=False)
+                    out[nm] = gm
+            # squeeze dK: 1x1 + bias on the BasicBlock's (64-channel padded) output
+            sq, x_sq, _ = rec["squeezes"][k]
+            cin = sq.in_channels
+            if sq.weight.requires_grad or sq.bias.requires_grad:
+                dW, db = ops.small_wgrad(x_sq[..., :cin], g_feat, want_bias=True)
+                self._give(sq.weight, dW, grads)
+                self._give(sq.bias, db, grads)
+            g_y = self._new(N, H, W, x_sq.shape[3], zero=x_sq.shape[3] != cin)
+            ops.small_linear(g_feat, sq.weight.detach().float().view(sq.out_channels, cin).t().contiguous(), out=g_y[..., :cin])
+            blk, x, t, y = rec["blocks"][k]
+            first = k == 0
+            g_x = self._basic_block_bwd(blk, x, t, y, g_y, grads, need_in=(not first) or need["m1"])
+            if first:
+                out["m1"] = g_x
+            else:
+                g = g_x                                           # gradient of the previous gated conv's (padded) output
+        return out
 
     def _decoder_fwd(self, cat, rg_cat, m2, rg_m2, size, tape):
         """bot_aspp / bot_fine / upsample x4 / final / upsample to the input size (deeplabv3.py:141-162)."""
@@ -698,6 +891,12 @@ class StudentEngine:
         add_conv(f[6]); add_bn(f[4]); add_conv(f[3]); add_bn(f[1]); add_conv(f[0])
         add_conv(net.bot_fine); add_conv(net.bot_aspp)
         add_bn(net.aspp.img_conv[1]); add_conv(net.aspp.img_conv[0])
+        if self.is_gscnn:   # edge branch, then the shape stream from its end (fuse / cw) back to res1, the side outputs with their gate
+            add_bn(net.aspp.edge_conv[1]); add_conv(net.aspp.edge_conv[0])
+            add_p(net.fuse.weight, net.cw.weight)
+            for gate, dsn, d, res in ((net.gate3, net.dsn7, net.d3, net.res3), (net.gate2, net.dsn4, net.d2, net.res2),
+                                      (net.gate1, net.dsn3, net.d1, net.res1)):
+                add_p(*gate.parameters()); add_p(*dsn.parameters()); add_p(*d.parameters()); add_p(*res.parameters())
         for br in net.aspp.features:
             add_bn(br[1], _gate_split(br[2])[1] if len(br) > 2 else None); add_conv(br[0])
         for _, blk in reversed(self._flat_blocks()):
@@ -752,6 +951,14 @@ class StudentEngine:
         g_x7 = self._aspp_bwd(g_cat, g_cat_hint, g_aspp, grads)
         if g_x7 is not None:
             g_block_out[nb - 1] = g_x7 if (nb - 1) not in g_block_out else g_block_out[nb - 1].add_(g_x7)
+        g_m1 = None
+        sg = getattr(self, "_shape_grads", None)
+        if sg is not None:     # Gated-SCNN: what the shape stream sends back into the trunk (side outputs dsn3/4/7, the stem output)
+            self._shape_grads = None
+            for nm, bi_ in (("m7", nb - 1), ("m4", tape["mod_end"]["mod4"][0]), ("m3", tape["mod_end"]["mod3"][0])):
+                if sg[nm] is not None:
+                    g_block_out[bi_] = sg[nm] if bi_ not in g_block_out else g_block_out[bi_].add_(sg[nm])
+            g_m1 = sg["m1"]
 
         pool3 = tape["pools"]["pool3"]
         for bi in range(nb - 1, -1, -1):
@@ -771,6 +978,9 @@ class StudentEngine:
             elif bi == 0:
                 st = tape["stem"]                                     # pool2, then the stem conv's weight gradient
                 g_s = ops.maxpool3x3s2_bwd(st["s"], g_xin)
+                if g_m1 is not None:                                  # + the shape stream's share (res1 reads the stem output)
+                    g_s.add_(g_m1[..., :g_s.shape[3]])
+                    g_m1 = None
                 w = self.net.mod1.conv1.weight
                 gw = self._grad_like(w)
                 ops.stem_wgrad(st["x"], g_s, gw)
@@ -778,6 +988,12 @@ class StudentEngine:
                 self._grad_done(w)
             else:
                 g_block_out[bi - 1] = g_xin if (bi - 1) not in g_block_out else g_block_out[bi - 1].add_(g_xin)
+        if g_m1 is not None and self.net.mod1.conv1.weight.requires_grad:   # only the shape stream reached the stem
+            w = self.net.mod1.conv1.weight
+            gw = self._grad_like(w)
+            ops.stem_wgrad(tape["stem"]["x"], g_m1[..., :64].contiguous(), gw)
+            grads[w] = gw
+            self._grad_done(w)
         self._tape = None
         if self.reducer is not None:
             for p in self.reducer.params:      # trainable parameters this loss does not reach: zero gradient, bucket complete
@@ -996,6 +1212,9 @@ class StudentEngine:
         # (registers instead of a read-modify-write of the running 4096-channel sum per branch) -- then the dense branches
         # chain onto that sum through their dgrad epilogue.
         g_x7 = None
+        self._shape_grads = None
+        if lead == 2 and g_cat is not None:
+            self._edge_branch_bwd(arec, g_cat[..., red:2 * red], grads)
         todo = []
         for i, br in enumerate(arec["branches"]):
             sl = slice(red * (i + lead), red * (i + lead + 1))
@@ -1048,6 +1267,44 @@ class StudentEngine:
             g_x7 = self._image_pool_bwd(arec, g_cat[..., 0:red], grads, g_x7)
         return g_x7
 
+    def _edge_branch_bwd(self, arec, gi, grads):
+        """Edge branch of the GSCNN ASPP (gscnn.py:168-171: resampled edge attention -> 1x1 (1 -> red) -> BN -> ReLU) and, behind
+        it, the whole shape stream.  gi: gradient w.r.t. the branch's conv output (already through BN + ReLU), a channel slice of
+        the concat-shaped gradient.  Leaves {m1, m3, m4, m7: gradient | None} in self._shape_grads."""
+        tape = self._tape
+        if tape.get("shape") is None:
+            raise EngineError("a gradient reached the GSCNN edge branch, but the shape stream was run without keeping its "
+                              "intermediates (DepthwiseStudent.logits_need_grad / an `aspp` hint switch that on)")
+        aspp, cat, red = arec["mod"], arec["cat"], arec["red"]
+        conv, bn = aspp.edge_conv[0], aspp.edge_conv[1]
+        acts = tape["acts"]
+        N, H, W = acts.shape
+        h8, w8 = cat.shape[1], cat.shape[2]
+        self._bn_param_grads(bn, gi, cat[..., red:2 * red], grads)
+        if conv.weight.requires_grad:
+            e = ops.upsample_bilinear_ac(acts.unsqueeze(3), (h8, w8))                          # the branch's input (N,h8,w8,1) fp32
+            pad8 = torch.zeros((N, h8, w8, 8), dtype=gi.dtype, device=gi.device)
+            pad8[..., 0:1] = e.to(gi.dtype)
+            dw8 = torch.empty((red, 8, 1, 1), dtype=torch.float32, device=gi.device)
+            ops.pw_wgrad(pad8, gi, dw8)
+            self._give(conv.weight, dw8[:, 0], grads)
+        need = {"m7": arec["rg7"], "m1": self.net.mod1.conv1.weight.requires_grad}
+        for nm in ("mod3", "mod4"):
+            need["m" + nm[-1]] = bool(tape["mod_end"][nm][1])
+        if not (any(need.values()) or any(p.requires_grad for m in self._shape_modules() for p in m.parameters())):
+            return
+        g_e = torch.empty((N, h8, w8, 1), dtype=gi.dtype, device=gi.device)
+        ops.conv2d(gi, self._packed(conv.weight, ("edge_t", self.dtype),
+                                    lambda: ops.pack_conv_weight(conv.weight.detach().float().view(1, red, 1, 1), self.dtype, KD_PACK_FWD)),
+                   out_raw=g_e)
+        g_acts = ops.upsample_bilinear_ac_bwd(g_e, (H, W), out_dtype=torch.float32).reshape(N, H, W)   # adjoint of the resample
+        self._shape_grads = self._shape_stream_bwd(g_acts, grads, need)
+
+    def _shape_modules(self):
+        net = self.net
+        return [net.dsn3, net.dsn4, net.dsn7, net.res1, net.res2, net.res3, net.d1, net.d2, net.d3, net.gate1, net.gate2, net.gate3,
+                net.fuse, net.cw]
+
     def _cat_scale(self, aspp):
         """BN scales of [image branch, features 0..] concatenated: the mask_scale of the concat buffer."""
         bns = [(aspp.img_conv[1], None)] + ([(aspp.edge_conv[1], None)] if hasattr(aspp, "edge_conv") else []) + \
@@ -1098,10 +1355,12 @@ class StudentEngine:
         w.r.t. the raw ASPP branch outputs (concat-shaped, through BN+ReLU) and w.r.t. mod2's output -- None where nothing
         upstream is trainable."""
         net, dec = self.net, self._tape["dec"]
-        if self.is_gscnn:
-            raise EngineError("gradients w.r.t. the GSCNN logits are not built (mode B through the shape stream); the shipped "
-                              "GSCNN plan back-propagates hint losses only (cfg/cityscapes/51M_gscnn_all.json)")
-        f = net.final
+        if self.is_gscnn and self._tape.get("shape") is None:
+            raise EngineError("a gradient reached the GSCNN logits, but the shape stream was run without keeping its intermediates: "
+                              "set DepthwiseStudent.logits_need_grad = True before the forward (LayerwiseTrainer does for "
+                              "trainer.backprop = 'kd+hint', TaylorPruneTrainer always); the shipped GSCNN plan back-propagates hint "
+                              "losses only (cfg/cityscapes/51M_gscnn_all.json)")
+        f = self._final()
         N, h2, w2, _ = dec["d2"].shape
         cdec, nf = dec["cdec"], dec["nf"]
         rg_dec0 = dec["rg_cat"] or dec["rg_m2"] or _is_trainable(net.bot_aspp) or _is_trainable(net.bot_fine)
@@ -1112,7 +1371,7 @@ class StudentEngine:
         ncls = f[6].out_channels
         kpad = ((ncls + 63) // 64) * 64
         g_d3 = self._new(N, h2, w2, kpad, zero=True)               # classes padded to the GEMM K granule
-        ops.upsample_bilinear_ac_bwd(g_logits, (h2, w2), out=g_d3[..., :ncls])
+        ops.upsample_bilinear_ac_bwd(g_logits, (h2, w2), out=g_d3[..., :ncls], align_corners=not self.is_gscnn)   # gscnn.py:323
         self._conv_wgrad(f[6], dec["d2"], g_d3[..., :ncls], grads)
         if not rg_d2:
             return None, None
@@ -1194,10 +1453,12 @@ def _run_student(engine, x, prefix):
         if not params:   # probes only: autograd still needs one differentiable input to build the node
             x = x.detach().requires_grad_(True)
         engine._probe_active = bool(engine.probe_names)
+        engine._differentiable = True
         try:
             outs = _StudentFunction.apply(engine, x, *params)
         finally:
             engine._probe_active = False
+            engine._differentiable = False
     else:
         logits, hints = engine.forward(x, prefix=prefix)
         engine._tape = None

@@ -67,6 +67,10 @@ class DepthwiseStudent(nn.Module):
         # reference's two full forwards (which is why it is not the default and not what bench.py's headline measures).
         self.share_frozen_prefix = False
         self._teacher_engine = None
+        # Gated-SCNN only: a loss term will be back-propagated into the student LOGITS (KD / supervised terms; the shipped plan's
+        # hint losses never reach them).  The shape stream then keeps its intermediates and runs on the differentiable kernels.
+        # Trainers set it from their loss (LayerwiseTrainer: trainer.backprop = 'kd+hint'; TaylorPruneTrainer: always).
+        self.logits_need_grad = False
 
     # ------------------------------------------------------------------ model surgery (host side)
     def register_hint_layers(self, block_names):
@@ -155,6 +159,7 @@ class DepthwiseStudent(nn.Module):
         if self._engine is None or self._engine.net is not self.student or self._engine.dtype != self.dtype:
             self._engine = StudentEngine(self.student, self.dtype)
         self._engine.hint_names = list(self.hint_block_names) if self.save_hidden else []
+        self._engine.logits_need_grad = bool(getattr(self, "logits_need_grad", False))
         return self._engine
 
     def _prepare_teacher(self, device):

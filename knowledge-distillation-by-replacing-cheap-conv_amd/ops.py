@@ -476,8 +476,8 @@ def maxpool3x3s2_bwd(x, gy, out=None):
     return out
 
 
-def upsample_bilinear_ac_bwd(gy, size, out=None, out_dtype=None):
-    """gy (N,Ho,Wo,C) -> gradient w.r.t. the (N,H,W,C) input of upsample_bilinear_ac, size = (H, W)."""
+def upsample_bilinear_ac_bwd(gy, size, out=None, out_dtype=None, align_corners=True):
+    """gy (N,Ho,Wo,C) -> gradient w.r.t. the (N,H,W,C) input of upsample_bilinear_ac (same corner convention), size = (H, W)."""
     _need_cuda(gy, out)
     N, Ho, Wo, Cc = gy.shape
     H, W = size
@@ -487,8 +487,8 @@ def upsample_bilinear_ac_bwd(gy, size, out=None, out_dtype=None):
         raise ValueError("upsample_bilinear_ac_bwd: bad output view")
     need = _lib.lib().kd_upsample_bilinear_ac_bwd_workspace(N, H, W, Cc, Ho, Wo)
     ws = _ws(need, gy.device)
-    check(_lib.lib().kd_upsample_bilinear_ac_bwd(_ptr(gy), dt_of(gy), nhwc_ld(gy), _ptr(out), dt_of(out), nhwc_ld(out), N, H, W, Cc,
-                                                 Ho, Wo, _ptr(ws), need, stream_ptr()), "kd_upsample_bilinear_ac_bwd")
+    check(_lib.lib().kd_upsample_bilinear_bwd(_ptr(gy), dt_of(gy), nhwc_ld(gy), _ptr(out), dt_of(out), nhwc_ld(out), N, H, W, Cc,
+                                              Ho, Wo, int(bool(align_corners)), _ptr(ws), need, stream_ptr()), "kd_upsample_bilinear_bwd")
     return out
 
 
@@ -735,6 +735,118 @@ def canny(x_nchw, low=10, high=100, sweeps=8, max_rounds=64):
             break
         check(_lib.lib().kd_canny_continue(N, H, W, sweeps, _ptr(out), _ptr(changed), _ptr(ws), need, stream_ptr()), "kd_canny_continue")
     return out
+
+
+# ------------------------------------------------------------------------- Gated-SCNN shape stream, backward pieces
+def _rows(t):
+    """(..., C) tensor with dense channels and uniformly strided pixels -> (pixel stride, pixels, channels)."""
+    if t.stride(-1) != 1:
+        raise ValueError("expected dense channels")
+    Cc = t.shape[-1]
+    npix = t.numel() // Cc
+    ld = t.stride(-2) if t.dim() > 1 else Cc
+    lead = t.shape[:-1]
+    exp = ld
+    for n, st in zip(reversed(lead), reversed(t.stride()[:-1])):   # every leading dimension must continue the pixel stride
+        if n > 1 and st != exp:
+            raise ValueError(f"not a pixel-strided view: shape {tuple(t.shape)} stride {t.stride()}")
+        exp *= n
+    return ld, npix, Cc
+
+
+def small_linear(x, w, bias=None, out=None, out_dtype=None, accumulate=False, relu=False, mask=None):
+    """out[p][co] (+)= bias[co] + sum_ci w[co][ci] x[p][ci]; x (..., Cin), w fp32 (Cout, Cin), <= 72 channels on either side.
+    mask: fp32 (..., Cout), the result is zeroed where mask <= 0 (backward through the ReLU that produced `mask`)."""
+    _need_cuda(x, w, bias, out, mask)
+    ldx, npix, Cin = _rows(x)
+    w = w.detach().float().contiguous()
+    Cout = w.shape[0]
+    if w.dim() != 2 or w.shape[1] != Cin:
+        raise ValueError(f"small_linear: w {tuple(w.shape)} does not match {Cin} input channels")
+    if bias is not None:
+        bias = bias.detach().float().contiguous()
+    if out is None:
+        out = torch.empty(tuple(x.shape[:-1]) + (Cout,), dtype=out_dtype or x.dtype, device=x.device)
+    ldy, npo, Co = _rows(out)
+    if npo != npix or Co != Cout:
+        raise ValueError("small_linear: bad output view")
+    ldm = 0
+    if mask is not None:
+        ldm, npm, Cm = _rows(mask)
+        if mask.dtype != torch.float32 or npm != npix or Cm != Cout:
+            raise ValueError("small_linear: mask must be fp32 and match the output")
+    check(_lib.lib().kd_small_linear(_ptr(x), dt_of(x), ldx, Cin, _ptr(w), _ptr(bias), _ptr(out), dt_of(out), ldy, Cout, npix, int(accumulate),
+                                     int(relu), _ptr(mask), ldm, stream_ptr()), "kd_small_linear")
+    return out
+
+
+def small_wgrad(a, b, want_bias=False, dw=None, db=None, accumulate=False):
+    """dw[cb][ca] = sum_p b[p][cb] a[p][ca] (fp32 (Cb, Ca)), db[cb] = sum_p b[p][cb]; a (..., Ca), b (..., Cb), <= 72 channels."""
+    _need_cuda(a, b, dw, db)
+    lda, npix, Ca = _rows(a)
+    ldb, npb, Cb = _rows(b)
+    if npb != npix:
+        raise ValueError("small_wgrad: a and b must cover the same pixels")
+    if dw is None:
+        dw = torch.empty((Cb, Ca), dtype=torch.float32, device=a.device)
+    if want_bias and db is None:
+        db = torch.empty((Cb,), dtype=torch.float32, device=a.device)
+    need = _lib.lib().kd_small_wgrad_workspace(Ca, Cb, npix)
+    ws = _ws(need, a.device)
+    check(_lib.lib().kd_small_wgrad(_ptr(a), dt_of(a), lda, Ca, _ptr(b), dt_of(b), ldb, Cb, npix, _ptr(dw), _ptr(db), int(accumulate), _ptr(ws),
+                                    need, stream_ptr()), "kd_small_wgrad")
+    return dw, db
+
+
+def gate_mix_bwd(feat, a, gv=None, want_v=False):
+    """GatedSpatialConv2d's tail: returns (gfeat, ga, v) -- gfeat = gv (sigmoid(a) + 1), ga = (sum_c gv feat) sigmoid'(a) (both None
+    without gv), v = feat (sigmoid(a) + 1) (if want_v); fp32 outputs."""
+    _need_cuda(feat, a, gv)
+    ldf, npix, Cc = _rows(feat)
+    if a.dtype != torch.float32 or a.numel() != npix or not a.is_contiguous():
+        raise ValueError("gate_mix_bwd: a must be a contiguous fp32 tensor with one value per pixel")
+    gfeat = ga = v = None
+    ldgv = 0
+    if gv is not None:
+        if gv.dtype != torch.float32:
+            raise ValueError("gate_mix_bwd: gv must be fp32")
+        ldgv, npg, Cg = _rows(gv)
+        if npg != npix or Cg != Cc:
+            raise ValueError("gate_mix_bwd: gv must match feat")
+        gfeat = torch.empty(tuple(feat.shape), dtype=torch.float32, device=feat.device)
+        ga = torch.empty(tuple(feat.shape[:-1]), dtype=torch.float32, device=feat.device)
+    if want_v:
+        v = torch.empty(tuple(feat.shape), dtype=torch.float32, device=feat.device)
+    check(_lib.lib().kd_gate_mix_bwd(_ptr(feat), dt_of(feat), ldf, _ptr(a), _ptr(gv), ldgv, _ptr(gfeat), Cc, _ptr(ga), _ptr(v), Cc, Cc, npix,
+                                     stream_ptr()), "kd_gate_mix_bwd")
+    return gfeat, ga, v
+
+
+def edge_attention_bwd(cs, canny, weights, g_acts):
+    """Backward of edge_attention: returns (g_t, g_s, eo_canny) -- gradients w.r.t. the cw and fuse pre-activations (N,H,W) fp32 and the
+    cw conv's input [sigmoid(fuse . cs), canny] (N,H,W,2) fp32."""
+    _need_cuda(cs, canny, weights, g_acts)
+    c8 = cs[..., :8]
+    ldc, npix, _ = _rows(c8)
+    for t in (canny, g_acts):
+        if t.dtype != torch.float32 or t.numel() != npix or not t.is_contiguous():
+            raise ValueError("edge_attention_bwd: canny / g_acts must be contiguous fp32 (N,H,W)")
+    g_t, g_s = torch.empty_like(g_acts), torch.empty_like(g_acts)
+    eo_canny = torch.empty(tuple(g_acts.shape) + (2,), dtype=torch.float32, device=cs.device)
+    check(_lib.lib().kd_edge_attention_bwd(dt_of(cs), _ptr(c8), ldc, _ptr(canny), _ptr(weights), _ptr(g_acts), _ptr(g_t), _ptr(g_s), _ptr(eo_canny),
+                                           npix, stream_ptr()), "kd_edge_attention_bwd")
+    return g_t, g_s, eo_canny
+
+
+def rank1_add(y, g, w, accumulate=True):
+    """y[p][c] (+)= g[p] * w[c]; y (..., C) view, g fp32 one value per pixel, w fp32 (C,)."""
+    _need_cuda(y, g, w)
+    ldy, npix, Cc = _rows(y)
+    w = w.detach().float().contiguous()
+    if g.dtype != torch.float32 or g.numel() != npix or not g.is_contiguous() or w.numel() != Cc:
+        raise ValueError("rank1_add: g must be contiguous fp32 with one value per pixel, w (C,)")
+    check(_lib.lib().kd_rank1_add(dt_of(y), _ptr(y), ldy, _ptr(g), _ptr(w), Cc, npix, int(accumulate), stream_ptr()), "kd_rank1_add")
+    return y
 
 
 # ------------------------------------------------------------------------------------- losses

@@ -59,6 +59,8 @@ class LayerwiseTrainer(BaseTrainer):
         self.backprop = str(self.config['trainer'].get('backprop', 'hint'))
         if self.backprop not in ('hint', 'kd+hint'):
             raise ValueError("trainer.backprop must be 'hint' (reference behaviour) or 'kd+hint'")
+        if self.backprop == 'kd+hint':
+            self.model.logits_need_grad = True    # (Gated-SCNN: the shape stream must keep its intermediates, engine.py)
         self._reducer = None
         if 'resume_path' in self.config['trainer']:
             self.resume(self.config['trainer']['resume_path'])

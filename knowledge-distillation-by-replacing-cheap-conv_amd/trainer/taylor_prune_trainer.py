@@ -28,6 +28,7 @@ class TaylorPruneTrainer(LayerwiseTrainer):
         super().__init__(model, criterions, metric_ftns, optimizer, config, train_data_loader, valid_data_loader, lr_scheduler,
                          weight_scheduler)
         self.importance_log_interval = self.config['trainer']['importance_log_interval']
+        self.model.logits_need_grad = True        # the supervised loss is back-propagated through the logits
         self.importance_tracker = ImportanceFilterTracker(writer=self.writer)
 
     def create_new_optimizer(self):

@@ -50,7 +50,7 @@ def seeded_input(key, shape, scale=1.0):
 def sample_idx(numel, k=4096):
     if numel <= k:
         return torch.arange(numel)
-    return torch.linspace(0, numel - 1, k).long()
+    return torch.linspace(0, numel - 1, k).long().clamp_(max=numel - 1)   # (fp32 linspace: numel - 1 > 2^24 can round up to numel)
 
 
 def summarize(t, k=4096):

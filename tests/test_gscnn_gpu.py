@@ -9,7 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from _netutil import canny_stub_map, gscnn_key_inventory, seeded_cheap_weights, seeded_gscnn_sd  # noqa: E402
-from _seeded import seeded_fill_, seeded_input, seeded_value  # noqa: E402
+from _seeded import sample_idx, seeded_fill_, seeded_input, seeded_value  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 from test_modeb_gpu import _check  # noqa: E402
 
@@ -258,7 +258,129 @@ def test_gscnn_kd_step_vs_network_oracle():
             ref = r["grads"][n].numpy().astype(np.float64)
             got = p.grad.cpu().numpy().astype(np.float64)
             assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-3, n
-    # mode B / `aspp` hints are refused loudly for GSCNN rather than silently dropping the edge-branch gradient
+
+
+def test_gscnn_mode_b_through_the_shape_stream_matches_reference(golden):
+    """Mode B on Gated-SCNN: every student parameter trainable -- trunk, ASPP with the edge branch, decoder and the whole shape
+    stream (dsn3/4/7, res1-3, d1-3, gate1-3, fuse, cw) -- with hints on a block conv, an ASPP branch conv and the `aspp` module,
+    loss = KLDivergenceLoss(1) + hint MSEs: every one of the 203 gradients against the reference's own DepthwiseStudent(GSCNN) run
+    (tests/golden/gscnn_step_full.npz; cv2.Canny replaced by the same seeded maps on both sides), fp32."""
+    from kdcc_amd import losses
+    from kdcc_amd.models.students import DepthwiseStudent
+    from test_student_gpu import check_summary
+    g = golden("gscnn_step_full")
+    plan, hints = [str(s) for s in g["plan"]], [str(s) for s in g["hints"]]
+    teacher = _gscnn()
+    model = DepthwiseStudent(teacher, None, dtype=torch.float32)
+    model.replace([{"name": n, "epoch": 1} for n in plan], kernel_size=9, padding=20, dilation=5)
+    for n in plan:
+        seeded_fill_(model.get_block(n, model.student), f"student.{n}.")
+    model.register_hint_layers(hints)
+    for p in model.student.parameters():
+        p.requires_grad = True
+    model.logits_need_grad = True
+    model = model.cuda()
+    maps = torch.stack([canny_stub_map((64, 128), int(s)) for s in g["canny_seeds"]]).cuda()
+    for net in (model.teacher, model.student):
+        net.canny_fn = lambda x: maps
+    x = seeded_input(str(g["x_key"]), (2, 3, 64, 128), scale=float(g["x_scale"])).cuda()
+    out_st, out_tc = model(x)
+    kd = losses.KLDivergenceLoss(1)(out_st, out_tc)
+    crit = losses.MSELoss(num_classes=1000)
+    hint, per = 0, []
+    for s_, t_ in zip(model.student_hidden_outputs, model.teacher_hidden_outputs):
+        l = crit(s_, t_)
+        per.append(l.item())
+        hint = hint + l
+    (kd + hint).backward()
+    torch.cuda.synchronize()
+    assert model.student_hint_names == hints
+    _check(out_st, g, "student_logits", 1024, 1e-3, "GSCNN student logits")
+    np.testing.assert_allclose(kd.item(), float(g["kd_loss"]), rtol=1e-3)
+    np.testing.assert_allclose(per, g["per_hint"], rtol=1e-3)
+    names = [str(s) for s in g["trainable"]]
+    got = {n: p for n, p in model.student.named_parameters() if p.grad is not None}
+    assert sorted(got) == sorted(names) and len(names) == 203           # everything but the unused dsn1 (gscnn.py:269-314)
+    bad = []
+    for n in names:
+        ref, gr = g[f"grad:{n}.sample"].astype(np.float64), got[n].grad.detach().float().reshape(-1).cpu()
+        smp = gr[sample_idx(gr.numel(), 256)].numpy().astype(np.float64)
+        err = np.linalg.norm(smp - ref) / max(np.linalg.norm(ref), 1e-30)
+        ssq = float((gr.double() ** 2).sum())
+        if err >= 2e-3 or abs(ssq - float(g[f"grad:{n}.sumsq"][0])) > 8e-3 * float(g[f"grad:{n}.sumsq"][0]) + 1e-30:
+            bad.append((n, err, ssq, float(g[f"grad:{n}.sumsq"][0])))
+    assert not bad, bad[:12]
+    # a logit loss on a model that was not told to keep the shape stream's intermediates is refused, not silently wrong
     from kdcc_amd.engine import EngineError
-    with pytest.raises(EngineError):
-        model.register_hint_layers(["aspp"])
+    model.logits_need_grad = False
+    model.register_hint_layers(plan)
+    with pytest.raises(EngineError):                      # trainable shape-stream parameters: refused at the forward
+        model(x)
+    for name in ("dsn3", "dsn4", "dsn7", "res1", "res2", "res3", "d1", "d2", "d3", "gate1", "gate2", "gate3", "fuse", "cw"):
+        for p in getattr(model.student, name).parameters():
+            p.requires_grad = False
+    out_st, out_tc = model(x)
+    with pytest.raises(EngineError):                      # frozen stream, but a loss on the logits: refused at the backward
+        losses.KLDivergenceLoss(1)(out_st, out_tc).backward()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_shape_stream_backward_pieces_vs_autograd(dt):
+    """kd_small_linear / kd_small_wgrad / kd_gate_mix_bwd / kd_edge_attention_bwd / kd_rank1_add and the non-aligned bilinear
+    transpose against torch autograd of the reference's own expressions (gate_spatial_conv.py:50-60, gscnn.py:308-314, :323)."""
+    import torch.nn.functional as F
+    from kdcc_amd import ops
+    g0 = torch.Generator().manual_seed(5)
+    tol = 2e-5 if dt == torch.float32 else 2e-2
+    rnd = lambda *s: torch.randn(*s, generator=g0)
+
+    def close(got, ref, what, t=tol):
+        got, ref = got.detach().float().cpu().double(), ref.detach().double()
+        assert float((got - ref).norm() / ref.norm().clamp_min(1e-30)) < t, what
+    # a 1x1 map with odd channel counts, bias, ReLU, a channel-sliced input view and accumulation
+    x, w, b = rnd(2, 5, 7, 40), rnd(33, 33) * 0.2, rnd(33) * 0.1
+    xd = x.to(dt).cuda()
+    xin = xd[..., 3:36]
+    ref = F.relu(xin.float().cpu() @ w.t() + b)
+    close(ops.small_linear(xin, w.cuda(), b.cuda(), relu=True, out_dtype=torch.float32), ref, "small_linear")
+    base = rnd(2, 5, 7, 33)
+    acc = base.clone().cuda()
+    mask = rnd(2, 5, 7, 33)
+    ops.small_linear(xin, w.cuda(), None, out=acc, accumulate=True, mask=mask.cuda())
+    close(acc, base + torch.where(mask > 0, xin.float().cpu() @ w.t(), torch.zeros(())), "small_linear accumulate + mask")
+    # weight / bias gradient over a pixel count that is not a multiple of the staging chunk
+    a, bb = rnd(3, 17, 29, 24).to(dt), rnd(3, 17, 29, 9).to(dt)
+    dw, db = ops.small_wgrad(a.cuda(), bb.cuda(), want_bias=True)
+    close(dw, torch.einsum("nhwb,nhwa->ba", bb.float(), a.float()), "small_wgrad", 1e-4 if dt == torch.float32 else tol)
+    close(db, bb.float().sum((0, 1, 2)), "small_wgrad bias", 1e-4 if dt == torch.float32 else tol)
+    # the gate's tail
+    feat, al, gv = rnd(2, 6, 5, 16).to(dt), rnd(2, 6, 5), rnd(2, 6, 5, 16)
+    fr, ar = feat.float().clone().requires_grad_(True), al.clone().requires_grad_(True)
+    v_ref = fr * (torch.sigmoid(ar).unsqueeze(3) + 1)
+    (v_ref * gv).sum().backward()
+    gfeat, ga, v = ops.gate_mix_bwd(feat.cuda(), al.cuda(), gv=gv.cuda(), want_v=True)
+    close(v, v_ref, "gate mix v"); close(gfeat, fr.grad, "gate mix d feat"); close(ga, ar.grad, "gate mix d a")
+    # edge attention
+    cs, canny, wts, g = rnd(2, 9, 11, 8).to(dt), (torch.rand(2, 9, 11, generator=g0) < 0.2).float() * 255, rnd(10) * 0.3, rnd(2, 9, 11)
+    wts[9] *= 0.01
+    cr, wr = cs.float().clone().requires_grad_(True), wts.clone().requires_grad_(True)
+    eo = torch.sigmoid((cr * wr[:8]).sum(3))
+    acts = torch.sigmoid(wr[8] * eo + wr[9] * canny)
+    (acts * g).sum().backward()
+    g_t, g_s, eoc = ops.edge_attention_bwd(cs.cuda(), canny.cuda(), wts.cuda(), g.cuda())
+    close(ops.small_linear(g_s.unsqueeze(3), wts[:8].view(8, 1).cuda()), cr.grad, "edge attention d cs")
+    close(ops.small_wgrad(cs.cuda(), g_s.unsqueeze(3))[0].reshape(-1), wr.grad[:8], "d fuse")
+    close(ops.small_wgrad(eoc, g_t.unsqueeze(3))[0].reshape(-1), wr.grad[8:], "d cw")
+    # rank-1 update and the non-aligned bilinear transpose
+    y, gp, wv = rnd(2, 4, 6, 32).to(dt), rnd(2, 4, 6), rnd(32)
+    yd = y.clone().cuda()
+    ops.rank1_add(yd, gp.cuda().reshape(-1), wv.cuda())
+    close(yd, y.float() + gp.unsqueeze(3) * wv, "rank1_add")
+    for align in (False, True):
+        for (hin, win, ho, wo) in ((6, 10, 12, 20), (16, 24, 5, 7)):      # enlarging (the logits) and shrinking (the edge map)
+            src = rnd(2, 3, hin, win).requires_grad_(True)
+            gy = rnd(2, 3, ho, wo)
+            (F.interpolate(src, size=(ho, wo), mode="bilinear", align_corners=align) * gy).sum().backward()
+            got = ops.upsample_bilinear_ac_bwd(gy.permute(0, 2, 3, 1).contiguous().cuda(), (hin, win), out_dtype=torch.float32,
+                                               align_corners=align)
+            close(got.permute(0, 3, 1, 2), src.grad, f"bilinear transpose align={align} {hin}x{win}->{ho}x{wo}", 2e-5)

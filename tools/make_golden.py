@@ -512,6 +512,57 @@ def g_gscnn(hw=(64, 128), batch=2):
     save("gscnn", **out)
 
 
+GSCNN_FULL_PLAN = ["mod4.block2.convs.conv2", "aspp.features.1.0"]
+GSCNN_FULL_HINTS = ["mod4.block2.convs.conv2", "aspp.features.1.0", "aspp"]
+
+
+def g_gscnn_step_full(hw=(64, 128), batch=2):
+    """Mode B on the reference's Gated-SCNN: DepthwiseStudent(GSCNN) with two cheap-conv blocks, EVERY student parameter
+    trainable -- trunk, ASPP incl. the edge branch, decoder and the whole shape stream (dsn3/4/7, res1-3, d1-3, gate1-3, fuse, cw) --
+    hints on a block conv, an ASPP branch conv and the `aspp` module (whose gradient re-enters the trunk through the edge branch
+    and the side outputs), loss = KLDivergenceLoss(1)(student, teacher logits) + sum of hint MSEs, loss.backward()
+    (models/gscnn/gscnn.py:269-325 under autograd).  cv2.Canny is replaced by seeded 0/255 maps on both networks, as in g_gscnn.
+    Stores the losses, logits and a summary of every parameter's gradient."""
+    import cv2 as cv2_stub
+    from models.gscnn.gscnn import GSCNN
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    teacher = GSCNN(num_classes=19)
+    seeded_fill_(teacher, "gscnn.")
+    teacher.eval()
+    model = DepthwiseStudent(teacher, config=None)
+    model.replace([{"name": n, "epoch": 1} for n in GSCNN_FULL_PLAN], kernel_size=9, padding=20, dilation=5)
+    for n in GSCNN_FULL_PLAN:
+        seeded_fill_(model.get_block(n, model.student), f"student.{n}.")
+    model.register_hint_layers(GSCNN_FULL_HINTS)
+    for p in model.student.parameters():
+        p.requires_grad = True
+    calls = []
+
+    def fake_canny(img, lo, hi):      # teacher forward first, then student: image i of either network gets map 900 + i
+        calls.append(1)
+        return _canny_stub_map(hw, 900 + (len(calls) - 1) % batch)
+    cv2_stub.Canny = fake_canny
+    x = seeded_input("gscnn.full.x", (batch, 3) + hw, scale=30.0)
+    out_st, out_tc = model(x)
+    kd = ref_losses.KLDivergenceLoss(1)(out_st, out_tc)
+    crit = ref_losses.MSELoss(num_classes=1000)
+    hint, per = 0, []
+    for s_, t_ in zip(model.student_hidden_outputs, model.teacher_hidden_outputs):
+        l = crit(s_, t_); per.append(l.item()); hint = hint + l
+    (kd + hint).backward()
+    out = dict(plan=np.array(GSCNN_FULL_PLAN), hints=np.array(GSCNN_FULL_HINTS), x_key="gscnn.full.x", x_scale=np.float64(30.0),
+               canny_seeds=np.array([900 + i for i in range(batch)]), kd_loss=np.float64(kd.item()), hint_loss=np.float64(hint.item()),
+               per_hint=np.array(per), student_logits=summarize(out_st, 1024))
+    names = []
+    for n, p in model.student.named_parameters():
+        if p.grad is None:
+            assert n.startswith("dsn1."), n        # dsn1 is declared but never used by GSCNN.forward (gscnn.py:269-314)
+            continue
+        names.append(n); out[f"grad:{n}"] = summarize(p.grad, 256)
+    out["trainable"] = np.array(names)
+    save("gscnn_step_full", **out)
+
+
 def trainer_config(plan, lr, len_epoch, save_dir):
     """A config dict in the reference's JSON schema (cfg/cityscapes/*.json) for a tiny synthetic run."""
     ent = [{"name": n, "epoch": 1} for n in plan]
@@ -642,7 +693,7 @@ def g_keys():
     print("wrote", path, len(inv), "entries", sum(int(np.prod(v)) for k, v in inv.items() if "num_batches" not in k and "running" not in k), "params")
 
 
-ALL = dict(keys=g_keys, gscnn=g_gscnn, confusion=g_confusion, taylor=g_taylor, taylor_steps=g_taylor_steps, tta=g_tta, student_step_full=g_student_step_full, trainer_epoch=g_trainer_epoch, classification_epoch=g_classification_epoch, losses=g_losses, dwsep=g_dwsep, resblock=g_resblock, aspp=g_aspp, ops=g_ops, radam=g_radam,
+ALL = dict(keys=g_keys, gscnn=g_gscnn, confusion=g_confusion, taylor=g_taylor, taylor_steps=g_taylor_steps, tta=g_tta, gscnn_step_full=g_gscnn_step_full, student_step_full=g_student_step_full, trainer_epoch=g_trainer_epoch, classification_epoch=g_classification_epoch, losses=g_losses, dwsep=g_dwsep, resblock=g_resblock, aspp=g_aspp, ops=g_ops, radam=g_radam,
            student_step=g_student_step)
 
 if __name__ == "__main__":
