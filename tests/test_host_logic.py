@@ -132,8 +132,10 @@ def test_gscnn_checkpoint_contract_and_plan():
     assert m.fused and nparams(m.student) == 86135022          # 51M_gscnn_all.json -> 86 135 022
     m.register_hint_layers(plan)
     from kdcc_amd.engine import EngineError
+    m.register_hint_layers(plan + ["aspp"])                     # the `aspp` module output is a valid hint on GSCNN too (edge-branch
+    assert m.hint_block_names[-1] == "aspp"                     # gradient: engine._edge_branch_bwd, tests/test_gscnn_gpu.py)
     with pytest.raises(EngineError):
-        m.register_hint_layers(["aspp"])                        # GSCNN: the edge branch's gradient path is not built
+        m.register_hint_layers(["aspp.edge_conv"])              # not a tensor the fused graph materialises
     with pytest.raises(RuntimeError):
         net.forward(torch.zeros(1, 3, 8, 8, device="meta") if False else torch.zeros(1, 3, 8, 8))   # host tensors need canny_fn
 
