@@ -677,6 +677,10 @@ WGRAD_CASES = [
     (1, 12, 64, 304, 256, 3, 1, 1, 1),    # 304 input channels: ragged third Cin tile, two Cout tiles
     (1, 40, 64, 72, 40, 3, 1, 16, 16),    # largest dilation the row buffer holds, ragged channels
     (1, 6, 64, 64, 64, 3, 1, 1, 1),       # fewer stages than the ring holds
+    # several Cout and Cin tiles, ragged channel tiles at the dilations the trunk uses
+    (1, 16, 128, 256, 512, 3, 1, 2, 2),   # four Cout tiles, two Cin tiles, 32 stages: ring fill / steady state / drain
+    (2, 8, 64, 128, 320, 3, 1, 4, 4),     # ragged third Cout tile, dilation 4
+    (1, 3, 64, 64, 256, 3, 1, 1, 1),      # three stages per split: shorter than the ring
 ]
 
 
