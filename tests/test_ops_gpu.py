@@ -594,6 +594,26 @@ def test_losses_bf16_large_vs_oracle(K):
     assert_close(grad.float().cpu().numpy(), rg, "bf16", "kld grad")
 
 
+@pytest.mark.parametrize("Cc", [32, 33, 64, 100])
+def test_logit_losses_channels_last_any_class_count(K, Cc):
+    """KLDiv / CE / confusion on channels-last fp32 logits with class counts on both sides of what the NHWC fast paths stage in
+    the default 64 KiB of dynamic LDS (KLDiv: 2 x 256 x C floats, C <= 32; CE: C <= 64; confusion: C <= 51): larger counts -- the
+    100-class CIFAR heads -- must take the strided kernels, not fail at launch."""
+    N, H, W = 2, 9, 13
+    s, t = rnd(N, Cc, H, W), rnd(N, Cc, H, W)
+    tgt = RNG.integers(0, Cc, size=(N, H, W)).astype(np.int64)
+    tgt[:, :2] = 255
+    sd, td = dev_nhwc(s, "f32").permute(0, 3, 1, 2), dev_nhwc(t, "f32").permute(0, 3, 1, 2)
+    loss, grad = K.kldiv(sd, td, 2.0)
+    rl, rg = orc.kldiv(s, t, 2.0)
+    np.testing.assert_allclose(loss.item(), rl, rtol=1e-4)
+    assert_close(grad.cpu().numpy(), rg, "f32", f"kld grad C={Cc}")
+    np.testing.assert_allclose(K.ce2d(sd, torch.from_numpy(tgt).cuda()).item(), orc.ce2d(s, tgt), rtol=1e-4)
+    if Cc <= 64:
+        conf = K.confusion(sd, torch.from_numpy(tgt).cuda()).cpu().numpy()
+        assert np.array_equal(conf, orc.confusion(s, tgt)), f"confusion C={Cc}"
+
+
 def test_radam_golden(K, golden):
     g = golden("radam")
     p = torch.from_numpy(g["p"][0].copy()).cuda()
