@@ -574,15 +574,17 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row_kernel(const WgradParam
 }
 
 // plan of the row-buffer kernel: ~2.5 one-per-CU workgroups per CU, >= 8 stages per split
+int fill_splits(int per, int max_splits);   // below, next to wide_plan
 void row_plan(long long M, int Cin, int Cout, int &tiles, int &tiles_ci, int &splits, int &rps)
 {
     tiles_ci = (Cin + 127) / 128;
     tiles = tiles_ci * ((Cout + 127) / 128);
     const int stages = (int)(M / 64);
-    int want = (640 + tiles * 3 - 1) / (tiles * 3);
-    const int max_splits = (stages + 7) / 8;
-    splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
-    if (splits < 1) splits = 1;
+    static int target = -1;
+    if (target < 0) { const char *e = getenv("KDCC_WGRAD_TARGET"); target = e ? atoi(e) : 0; }   // A/B: floor(n / workgroups per split)
+    const int per = tiles * 3, max_splits = (stages + 7) / 8;
+    splits = target > 0 ? target / per : fill_splits(per, max_splits);
+    splits = splits < 1 ? 1 : (splits > max_splits ? max_splits : splits);
     rps = ((stages + splits - 1) / splits) * 64;
     splits = (int)((M + rps - 1) / rps);
 }
@@ -664,13 +666,37 @@ bool wide_tile_pays(int dtype, int Cin, int Cout)
     if (const char *e = getenv("KDCC_WGRAD_WIDE")) wide = wide && e[0] != '0';
     return wide;
 }
+// Split-K factor for kernels that run ONE workgroup per CU, all of equal length (the 256 x 256 and the row-buffer weight-gradient
+// tiles): the launch takes ceil(W / 256) rounds of the 256 CUs with W = splits * per workgroups, so W should sit just BELOW a
+// multiple of 256, and the fewest rounds that fill the chip win (fewer partial slabs to write and reduce, fewer pipeline fills).
+// Returns the first floor(256 k / per), k = 1..4, that fills >= 95 % of its k rounds, else the best fill.  Round 2 aimed at "about
+// 640 / 768 workgroups" rounded UP: 2.5 rounds with the last half empty, or one workgroup into a fourth round.  Measured
+// (tools/bench_wgrad.py, 4 images): 3x3 128->128 at 512x1024 1.01 -> 0.85 ms, 256->256 at 512x1024 2.99 -> 2.50, 512->512 0.78 -> 0.73,
+// 1024->512 1.44 -> 1.27, 304->256 4.45 -> 3.87; 1x1 512->512 0.220 -> 0.114, 4096->256 0.371 -> 0.313; mode B 24.5 -> 25.8 img/s.
+int fill_splits(int per, int max_splits)
+{
+    int splits = 1;
+    double best = -1.0;
+    for (int k = 1; k <= 4; ++k) {
+        int sp = (256 * k) / per;
+        sp = sp < 1 ? 1 : (sp > max_splits ? max_splits : sp);
+        const long long w = (long long)sp * per;
+        const double fill = (double)w / (double)(((w + 255) / 256) * 256);
+        if (fill >= 0.95) return sp;
+        if (fill > best) { best = fill; splits = sp; }
+    }
+    return splits;
+}
+
 void wide_plan(long long M, int Cin, int Cout, int taps, int &tiles, int &tiles_ci, int &splits, int &rps)
 {
     tiles_ci = (Cin + 255) / 256;
     tiles = tiles_ci * ((Cout + 255) / 256);
     const int stages = (int)((M + 63) / 64);
-    int want = (768 + tiles * taps - 1) / (tiles * taps);
+    static int target = -1;
+    if (target < 0) { const char *e = getenv("KDCC_WGRAD_WIDE_TARGET"); target = e ? atoi(e) : 0; }   // A/B: floor(n / workgroups per split)
     const int max_splits = (stages + 7) / 8;
+    const int want = target > 0 ? target / (tiles * taps) : fill_splits(tiles * taps, max_splits);
     splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
     if (splits < 1) splits = 1;
     rps = ((stages + splits - 1) / splits) * 64;
