@@ -946,7 +946,9 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_row_persist_kernel(
         const int row_off = ((u_ky - 1) * d * p.W) * p.ldx + u_cb * BK;
         static_assert(GAR2 == 5 && GB2 == 4, "piece groups below");
         if constexpr (PP) {
-            const int pbase = wv < 4 ? wv * 6 : 24 + (wv - 4) * 4, np = wv < 4 ? 6 : 4;
+            // (pieces that lie wholly behind the BM + 2 dil rows the fragments read are not issued: 7 of the 40 at dil = 1)
+            const int pbase = wv < 4 ? wv * 6 : 24 + (wv - 4) * 4,
+                      np = (p.tune & 4096) ? (wv < 4 ? 6 : 4) : min(wv < 4 ? 6 : 4, (CF::BM + 2 * d + PR - 1) / PR - pbase);   // 4096: A/B, all 40
             char *la = lds + (u_idx & 1) * CF::ABUF + pbase * 1024;
 #pragma unroll
             for (int j = 0; j < 6; ++j)
@@ -1419,7 +1421,8 @@ __global__ __launch_bounds__(512, 2) void conv_row_pp128_kernel(const ConvParams
     const int srow = lane >> 2;
     const int chunk = (lane & 3) ^ ((srow >> 1) & 3);
     const int frow = lane & 15, fq = lane >> 4;
-    const int pbase = wv < 4 ? wv * 5 : 20 + (wv - 4) * 4, np = wv < 4 ? 5 : 4;   // row-buffer pieces of this wave
+    // row-buffer pieces of this wave (16 rows each); those wholly behind the BM + 2 dil rows that are read are not issued
+    const int pbase = wv < 4 ? wv * 5 : 20 + (wv - 4) * 4, np = (p.tune & 4096) ? (wv < 4 ? 5 : 4) : min(wv < 4 ? 5 : 4, (BM + 2 * d + 15) / 16 - pbase);
 
     int m0 = 0, n0 = 0, ky_lo = 0, ky_hi = 0, nu = 0, ns = 0, a_off0 = 0, b_off0 = 0;
     uint32_t a_ok = 0;

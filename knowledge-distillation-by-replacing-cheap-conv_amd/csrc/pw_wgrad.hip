@@ -424,10 +424,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide_kernel(const WgradPara
 // row, so the shifted reads stay conflict-free.  Bytes staged per MAC: (64*128 + 96*128) * 2 B per 128 x 384 x 64 MACs = 1/77
 // against 1/32 for the 128 x 128 kernel and 1/64 for the 256 x 256 one.  8 waves (2 x 4 of 64 x 96), grid.z = ky; a
 // four-stage ring of 40 KiB stages (160 KiB, one workgroup per CU): three stages in flight behind a counted vmcnt.
+// s_waitcnt immediate (gfx9 layout): vmcnt(vm) lgkmcnt(0), expcnt untouched
+constexpr int waitcnt_vm_lgkm0(int vm) { return (vm & 15) | (7 << 4) | ((vm >> 4) << 14); }
 constexpr int WR_XROWS = 96;                        // row-buffer rows: 64 + 2 * dil <= 96
 constexpr int WR_STAGE = 16384 + WR_XROWS * 256;    // dy image + row buffer
 constexpr int WR_NST = 4;
 __device__ unsigned long long kd_wgrad_tlog[256 * 8 * 8];   // KDCC_WGRAD_DBG=1: per-wave phase clocks of conv_wgrad_row_kernel (debug)
+// ABL (tuning build only, KDCC_WGRAD_DBG bits; timing ablations, results wrong): 2 = no MFMAs, 4 = no fragment reads, 8 = no DMA
+template <bool ABL, int MODE>   // MODE 0 / 1: half-stage software pipeline, fragment reads in front of / dealt between the MFMAs; 2: ping-pong
 __global__ __launch_bounds__(512, 2) void conv_wgrad_row_kernel(const WgradParams p)
 {
     __shared__ __attribute__((aligned(16))) char lds[WR_NST * WR_STAGE];
@@ -463,14 +467,18 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row_kernel(const WgradParam
         voy[j] = r * p.ldy + co0 + c;
         vy |= co0 + c < p.Cout ? (1u << j) : 0u;
     }
+    // row buffer: up to 24 pieces, row r = pixel x0 - dil + r; wave w stages pieces w, 8 + w, 16 + w -- only those that hold
+    // one of the 64 + 2 dil rows the fragments read (dil = 1: 17 pieces, two per wave and a third for wave 0)
+    const int nxp = __builtin_amdgcn_readfirstlane(min(3, (64 + 2 * d - 4 * wv + 31) / 32));
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {                           // row buffer: 24 pieces; row r = pixel x0 - dil + r
-        const int r = (wv * 3 + j) * 4 + prow;
+    for (int j = 0; j < 3; ++j) {
+        const int r = (j * 8 + wv) * 4 + prow;
         const int c = (slot ^ (tr_f(r) << 1)) * 8;
         vox[j] = r * p.lda + ci0 + c;
         vx |= (r < 64 + 2 * d && ci0 + c < p.Cin) ? (1u << j) : 0u;
     }
     auto stage = [&](int st) {
+        if (ABL && (p.dbg & 8)) return;
         char *base = lds + (st % WR_NST) * WR_STAGE;
         const int m0 = m_begin + st * 64;
         const uint32_t n = fastdiv((uint32_t)m0, p.mg_howo, p.sh_howo);
@@ -485,9 +493,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row_kernel(const WgradParam
         for (int j = 0; j < 2; ++j) glds16(((vy >> j) & 1u) ? yb + voy[j] : zero, base + (wv * 2 + j) * 1024);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int x = x0 - d + (wv * 3 + j) * 4 + prow;
-            const bool ok = rowok && ((vx >> j) & 1u) && x >= 0 && x < p.W;
-            glds16(ok ? xb + vox[j] : zero, base + 16384 + (wv * 3 + j) * 1024);
+            if (j < nxp) {
+                const int x = x0 - d + (j * 8 + wv) * 4 + prow;
+                const bool ok = rowok && ((vx >> j) & 1u) && x >= 0 && x < p.W;
+                glds16(ok ? xb + vox[j] : zero, base + 16384 + (j * 8 + wv) * 1024);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -515,47 +525,164 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row_kernel(const WgradParam
     for (int j = 0; j < 6; ++j) { const int jt = wn * 6 + j; jkx[j] = jt >> 3; jct[j] = jt & 7; }
 
     constexpr int G = 5;   // pieces per wave per stage
-    unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0;
-    const bool dbg = p.dbg != 0;
-    for (int st = 0; st < WR_NST - 1 && st < nst; ++st) stage(st);
-    for (int st = 0; st < nst; ++st) {
-        unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-        if (dbg) c0 = clock64();
-        // stage st has landed once at most the stages issued after it are outstanding
-        const int ahead = min(nst - 1 - st, WR_NST - 2);
-        if (dbg) {
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            c1 = clock64();
-            __builtin_amdgcn_s_barrier();
-            c2 = clock64();
-        } else {
-        if (ahead >= 2) wait_vm_barrier<2 * G>();
-        else if (ahead == 1) wait_vm_barrier<G>();
-        else wait_vm_barrier<0>();
-        }
-        if (st + WR_NST - 1 < nst) stage(st + WR_NST - 1);   // into the buffer every wave left before this barrier
-        if (dbg) c3 = clock64();
+    // Software pipeline over HALF stages (k = 32 pixels each): the fragments of the next half are in flight while the 24 MFMAs
+    // of this one run.  With the reads of a whole stage in front of its MFMAs every wave of the workgroup read at the same
+    // time and multiplied at the same time -- LDS port (1600 cycles per stage) and matrix pipe (1536) took turns: 3600 cycles
+    // per stage.  One barrier per stage, between the halves: it publishes stage st + 1 (whose first half is read right after
+    // it) and retires stage st - 1, whose buffer the DMA of stage st + 3 then overwrites; two stages stay in flight behind it.
+    // (fragments live in integer vectors: a bf16 vector that is live across a branch is taken apart element by element)
+    typedef int v2i32_t __attribute__((ext_vector_type(2)));
+    uint4 fa0[4], fb0[6], fa1[4], fb1[6];
+    if (ABL) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa0[i] = fa1[i] = make_uint4(tid, 1, 2, 3);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) fb0[j] = fb1[j] = make_uint4(tid, 1, 2, 3);
+    }
+    auto frag4 = [&](const char *img, int mrow, int t) __attribute__((always_inline)) {
+        const int m0 = mrow + 8 * q + (li >> 2);
+        const int m1 = m0 + 4;
+        const v2i32_t lo = __builtin_bit_cast(v2i32_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4i16_t *)(img + m0 * 256 + ((t ^ tr_f(m0)) << 5) + (li & 3) * 8)));
+        const v2i32_t hi = __builtin_bit_cast(v2i32_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4i16_t *)(img + m1 * 256 + ((t ^ tr_f(m1)) << 5) + (li & 3) * 8)));
+        return make_uint4((uint32_t)lo.x, (uint32_t)lo.y, (uint32_t)hi.x, (uint32_t)hi.y);
+    };
+    auto read_frags = [&](int st, int ks, uint4 (&fa)[4], uint4 (&fb)[6]) __attribute__((always_inline)) {
+        if (ABL && (p.dbg & 4)) return;
         const char *imgY = lds + (st % WR_NST) * WR_STAGE, *imgX = imgY + 16384;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8_t fa[4], fb[6];
+        for (int i = 0; i < 4; ++i) fa[i] = frag4(imgY, ks * 32, wm * 4 + i);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = frag(imgY, ks * 32, wm * 4 + i);
+        for (int j = 0; j < 6; ++j) fb[j] = frag4(imgX, ks * 32 + jkx[j] * d, jct[j]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mfmas = [&](const uint4 (&fa)[4], const uint4 (&fb)[6]) __attribute__((always_inline)) {
+        if (ABL && (p.dbg & 2)) return;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) fb[j] = frag(imgX, ks * 32 + jkx[j] * d, jct[j]);
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 6; ++j) Mma<bf16_t>::run(fa[i], fb[j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // one half stage: the 24 MFMAs on (faM, fbM) with the 20 reads of the NEXT half's fragments (faR, fbR) dealt between them,
+    // five per row of six MFMAs -- a burst of 8 x 20 reads in front of the MFMAs keeps the LDS port busy for 640 cycles while the
+    // matrix pipe waits for the first fragments, then the pipe runs with the port idle
+    auto half = [&](int st, int ks, uint4 (&faR)[4], uint4 (&fbR)[6], const uint4 (&faM)[4], const uint4 (&fbM)[6]) __attribute__((always_inline)) {
+        const char *imgY = lds + (st % WR_NST) * WR_STAGE, *imgX = imgY + 16384;
 #pragma unroll
-                for (int j = 0; j < 6; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+            if (!(ABL && (p.dbg & 4))) {
+#pragma unroll
+                for (int k = 5 * i; k < 5 * i + 5; ++k) {
+                    const int hf = k & 1, f = (k < 8 ? k : k - 8) >> 1;
+                    const char *img = k < 8 ? imgY : imgX;
+                    const int m = ks * 32 + (k < 8 ? 0 : jkx[f] * d) + 8 * q + (li >> 2) + 4 * hf;
+                    const int t = k < 8 ? wm * 4 + f : jct[f];
+                    const v2i32_t v = __builtin_bit_cast(v2i32_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) v4i16_t *)(img + m * 256 + ((t ^ tr_f(m)) << 5) + (li & 3) * 8)));
+                    uint4 &dst = k < 8 ? faR[f] : fbR[f];
+                    if (hf == 0) { dst.x = (uint32_t)v.x; dst.y = (uint32_t)v.y; }
+                    else { dst.z = (uint32_t)v.x; dst.w = (uint32_t)v.y; }
+                }
+            }
+            if (!(ABL && (p.dbg & 2))) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) Mma<bf16_t>::run(faM[i], fbM[j], acc[i][j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (dbg) { const unsigned long long c4 = clock64(); ph0 += c1 - c0; ph1 += c2 - c1; ph2 += c3 - c2; ph3 += c4 - c3; }
+    };
+    const bool dbg = ABL && p.dbg != 0;
+    unsigned long long c0 = 0;
+    if (dbg) c0 = clock64();
+    // vmcnt(n) lgkmcnt(0) for a wave-uniform n: this wave issues gw = 2 + nxp pieces per stage (an s_waitcnt immediate per case)
+    const int gw = 2 + nxp;
+    auto wait_pieces = [&](int n) __attribute__((always_inline)) {
+        switch (n) {
+        case 0: __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(0)); break;
+        case 2: __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(2)); break;
+        case 3: __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(3)); break;
+        case 4: __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(4)); break;
+        case 5: __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(5)); break;
+        case 6: __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(6)); break;
+        case 8: __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(8)); break;
+        case 9: __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(9)); break;
+        case 10: __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(10)); break;
+        case 12: __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(12)); break;
+        default: __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(15)); break;
+        }
+    };
+    if constexpr (MODE == 2) {
+        // Ping-pong (the schedule of conv_row_persist_kernel<.., PP>): waves 0-3 (group 0, one per SIMD) multiply stage st while
+        // waves 4-7 (group 1) issue their DMA pieces and read their fragments of stage st, then the groups swap -- the matrix
+        // pipe of every SIMD always has one wave that does nothing but MFMAs.  Two barriers per stage (the half-periods); a wave
+        // holds the fragments of a whole stage (both k halves).  All four stage buffers are in flight: stage st + 4 goes into
+        // the buffer of stage st once both groups have read it (behind barrier 2 st + 1).
+        for (int st = 0; st < WR_NST && st < nst; ++st) stage(st);
+        wait_pieces(min(nst - 1, WR_NST - 1) * gw);
+        __builtin_amdgcn_s_barrier();    // stage 0 has landed for every wave
+        auto landed = [&](int st) __attribute__((always_inline)) {   // before barrier 2 st + 1: this wave's pieces of stage st + 1
+            wait_pieces(max(min(st + WR_NST - 1, nst - 1) - (st + 1), 0) * gw);
+        };
+        if (wv < 4) {
+#pragma unroll 1
+            for (int st = 0; st < nst; ++st) {
+                read_frags(st, 0, fa0, fb0);
+                read_frags(st, 1, fa1, fb1);
+                __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(63));   // lgkmcnt(0) only
+                __builtin_amdgcn_s_barrier();          // half-period 2 st: group 1 reads stage st
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(fa0, fb0);
+                mfmas(fa1, fb1);
+                landed(st);
+                __builtin_amdgcn_s_barrier();          // half-period 2 st + 1: group 1 has read stage st
+                if (st + WR_NST < nst) stage(st + WR_NST);
+            }
+        } else {
+#pragma unroll 1
+            for (int st = 0; st < nst; ++st) {
+                __builtin_amdgcn_s_barrier();          // half-period 2 st
+                if (st > 0 && st - 1 + WR_NST < nst) stage(st - 1 + WR_NST);   // into the buffer of stage st - 1
+                read_frags(st, 0, fa0, fb0);
+                read_frags(st, 1, fa1, fb1);
+                landed(st);
+                __builtin_amdgcn_s_barrier();          // half-period 2 st + 1
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(fa0, fb0);
+                mfmas(fa1, fb1);
+            }
+        }
+    } else {
+    constexpr bool IL = MODE == 1;
+    for (int st = 0; st < WR_NST - 1 && st < nst; ++st) stage(st);
+    wait_pieces(min(nst - 1, WR_NST - 2) * gw);   // stage 0 has landed once at most the stages issued after it are outstanding
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, 0, fa0, fb0);
+    // The two waves of a SIMD (w, w + 4) issue their pieces at different points of the stage: while the vector-memory queue
+    // holds one of them in its five global_load_lds (1670 cycles per stage for the whole workgroup when nothing else runs),
+    // the other has MFMAs to issue.  "late" waves issue stage st + 3 after the second half's MFMAs instead of before them.
+    const bool early = wv < 4;
+#pragma unroll 1
+    for (int st = 0; st + 1 < nst; ++st) {
+        if (IL) half(st, 1, fa1, fb1, fa0, fb0);
+        else { read_frags(st, 1, fa1, fb1); mfmas(fa0, fb0); }
+        // the waits are the BUILTIN, which hipcc's wait-count pass sees: it knows the second half's fragments have arrived and
+        // puts no lgkmcnt wait between the reads below and the MFMAs that do not use them
+        wait_pieces(st + 2 < nst ? gw : 0);   // stage st + 1 has landed; st + 2 may be outstanding
+        __builtin_amdgcn_s_barrier();
+        if (early && st + WR_NST - 1 < nst) stage(st + WR_NST - 1);   // into the buffer of stage st - 1
+        if (IL) half(st + 1, 0, fa0, fb0, fa1, fb1);
+        else { read_frags(st + 1, 0, fa0, fb0); mfmas(fa1, fb1); }
+        if (!early && st + WR_NST - 1 < nst) stage(st + WR_NST - 1);
+    }
+    if (IL) half(nst - 1, 1, fa1, fb1, fa0, fb0);
+    else { read_frags(nst - 1, 1, fa1, fb1); mfmas(fa0, fb0); }
+    mfmas(fa1, fb1);
     }
     if (dbg && lane == 0 && blockIdx.x < 256) {
         unsigned long long *o = kd_wgrad_tlog + (blockIdx.x * 8 + wv) * 8;
-        o[0] = ph0; o[1] = ph1; o[2] = ph2; o[3] = ph3; o[4] = nst;
+        o[0] = clock64() - c0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = nst;
     }
 
     const int frow = lane & 15, fq = lane >> 4;
@@ -844,7 +971,18 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
         fastdiv_magic((uint32_t)d->W, p.mg_wo, p.sh_wo);
         p.tiles = tiles;
         KD_NOTE_KERNEL("conv_wgrad_row_kernel");
-        hipLaunchKernelGGL(conv_wgrad_row_kernel, dim3((unsigned)(tiles * splits * 3)), dim3(512), 0, s, p);
+#ifdef KDCC_TUNING
+        static int il = -1;
+        if (il < 0) il = KD_TUNING_ENV_INT("KDCC_WGRAD_IL");   // A/B: 0 = reads in front of the MFMAs, 1 = interleaved, 2 = ping-pong
+        const dim3 grid((unsigned)(tiles * splits * 3));
+        if (p.dbg && il == 2) hipLaunchKernelGGL((conv_wgrad_row_kernel<true, 2>), grid, dim3(512), 0, s, p);
+        else if (p.dbg && il == 1) hipLaunchKernelGGL((conv_wgrad_row_kernel<true, 1>), grid, dim3(512), 0, s, p);
+        else if (p.dbg) hipLaunchKernelGGL((conv_wgrad_row_kernel<true, 0>), grid, dim3(512), 0, s, p);
+        else if (il == 2) hipLaunchKernelGGL((conv_wgrad_row_kernel<false, 2>), grid, dim3(512), 0, s, p);
+        else if (il == 0) hipLaunchKernelGGL((conv_wgrad_row_kernel<false, 0>), grid, dim3(512), 0, s, p);
+        else
+#endif
+        hipLaunchKernelGGL((conv_wgrad_row_kernel<false, 1>), dim3((unsigned)(tiles * splits * 3)), dim3(512), 0, s, p);
     } else if (wide) { KD_NOTE_KERNEL("conv_wgrad_wide_kernel"); hipLaunchKernelGGL(conv_wgrad_wide_kernel, grid, dim3(512), 0, s, p); }
     else if (d->dtype == KD_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0) launch_tr(grid, s, p);
     else if (d->dtype == KD_BF16) { KD_NOTE_KERNEL("pw_wgrad_kernel<bf16>"); hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, p); }

@@ -8,6 +8,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import kdcc_amd  # noqa: E402
+if os.environ.get("KDCC_LIB") == "tuning":   # A/B switches that exist only in the diagnostics build (e.g. KDCC_WGRAD_IL=1)
+    kdcc_amd._lib.build_tuning()
 from kdcc_amd import ops  # noqa: E402
 
 SHAPES = [  # N, H, W, Cin, Cout, k, dil   (P92 mode-B layer classes at 4 images)
