@@ -222,6 +222,8 @@ def _classify(rec):
         if "sum of" in label:
             return "depthwise_dgrad_sum"
         return "depthwise_dgrad_epilogue" if "+epi" in label else "depthwise_fwd"
+    if fam == "channel_sums":
+        return "bn_param_sums"
     return "losses"
 
 
@@ -238,7 +240,7 @@ def class_rooflines(prof, steps, peak_tflops):
     for name, (cnt, ms, work, fam) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         if ms <= 0:
             continue
-        hbm = fam in ("depthwise", "loss")
+        hbm = fam in ("depthwise", "loss", "channel_sums")
         rate = work / (ms * 1e-3) / (1e9 if hbm else 1e12)
         out[name] = {"bound": "hbm" if hbm else "mfma", "launches_per_step": cnt / steps, "ms_per_step": ms / steps,
                      "achieved": rate, "unit": "GB/s" if hbm else "TFLOP/s", "peak": PEAK_HBM_GBS if hbm else peak_tflops,
@@ -292,14 +294,14 @@ def run_config(a, device, rank, world, plan_name=None, mode=None, arch=None, hin
         # per conv shape: launches per step, mean duration, TFLOP/s (live HIP events, same records as the roofline)
         agg = {}
         for p in prof:
-            if p[0] in ("conv_igemm", "conv_wgrad", "pw_wgrad", "depthwise"):
+            if p[0] in ("conv_igemm", "conv_wgrad", "pw_wgrad", "depthwise", "channel_sums"):
                 e = agg.setdefault((p[4], p[5]), [0, 0.0, p[1], p[0]])
                 e[0] += 1
                 e[1] += p[2].elapsed_time(p[3])
         with open(a.layer_table, "w") as f:
             f.write("shape\tkernel\tlaunches_per_step\tavg_ms\tTFLOP/s|GB/s\tms_per_step\n")
             for (k, kern), (cnt, ms, work, fam) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                f.write(f"{k}\t{kern}\t{cnt / steps:g}\t{ms / cnt:.4f}\t{work * cnt / ms / (1e6 if fam == 'depthwise' else 1e9):.0f}\t{ms / steps:.3f}\n")
+                f.write(f"{k}\t{kern}\t{cnt / steps:g}\t{ms / cnt:.4f}\t{work * cnt / ms / (1e6 if fam in ('depthwise', 'channel_sums') else 1e9):.0f}\t{ms / steps:.3f}\n")
     replicas_identical = None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)

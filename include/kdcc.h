@@ -90,10 +90,25 @@ typedef struct kd_conv_epilogue {
     const void *res_post; int32_t ld_res_post;
     void *out_raw;        int32_t ld_raw;      int32_t raw_f32;
     void *out_act;        int32_t ld_act;      const float *act_scale; const float *act_shift; int32_t act_relu;
+    float *bn_sums;       /* optional, with `mask`: [M/128][2][Cout] fp32 partial sums over blocks of 128 output pixels of
+                             g = (mask > 0 ? v * mask_scale : 0) and of g * mask -- the eval-mode BN parameter gradients'
+                             reductions, taken where the input gradient is produced instead of by kd_channel_sums reading it
+                             back.  Only the kernels kd_conv2d_bn_sums_rows() reports write it; finish with kd_bn_sums_finish */
 } kd_conv_epilogue;
 
 int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w_packed,
                   const kd_conv_epilogue *ep, kd_stream_t stream);
+/* Rows of `bn_sums` partials (one per 128 output pixels) the kernel kd_conv2d_fwd selects for (d, ep) writes, or 0 when that
+ * kernel does not produce them -- the caller then leaves ep->bn_sums NULL (kd_conv2d_fwd refuses it otherwise) and takes the
+ * sums with kd_channel_sums from the stored gradient.  The reference gets these reductions from autograd of
+ * bn -> relu in IdentityResidualBlock (models/encoders/wider_resnet.py:124-167, reached from loss.backward(),
+ * trainer/layerwise_trainer.py:235).
+ * kd_bn_sums_finish: s1[c] = sum_r part[r][0][c], s2[c] = sum_r part[r][1][c] in a fixed order (fp64 accumulators; more than
+ *   2048 rows go through a first stage of 256-row chunks in `workspace`). */
+int32_t kd_conv2d_bn_sums_rows(const kd_conv_desc *d, const kd_conv_epilogue *ep);
+size_t kd_bn_sums_finish_workspace(int32_t rows, int32_t C);
+int kd_bn_sums_finish(const float *part, int32_t rows, int32_t C, float *s1, float *s2, void *workspace, size_t workspace_bytes,
+                      kd_stream_t stream);
 
 /* Weight packing (runs on device, on `stream`).  src: the reference's
  * nn.Conv2d.weight, fp32 (Cout, Cin, kh, kw) contiguous.

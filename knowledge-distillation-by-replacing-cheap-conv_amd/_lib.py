@@ -37,7 +37,8 @@ class ConvEpilogue(C.Structure):
                 ("mask", c_vp), ("ld_mask", c_int), ("mask_scale", c_vp),
                 ("res_post", c_vp), ("ld_res_post", c_int),
                 ("out_raw", c_vp), ("ld_raw", c_int), ("raw_f32", c_int),
-                ("out_act", c_vp), ("ld_act", c_int), ("act_scale", c_vp), ("act_shift", c_vp), ("act_relu", c_int)]
+                ("out_act", c_vp), ("ld_act", c_int), ("act_scale", c_vp), ("act_shift", c_vp), ("act_relu", c_int),
+                ("bn_sums", c_vp)]
 
 
 class DwDesc(C.Structure):
@@ -67,6 +68,9 @@ _SIGS = {
     "kd_version": (c_int, []),
     "kd_last_error": (C.c_char_p, []),
     "kd_conv2d_fwd": (c_int, [_P(ConvDesc), c_vp, c_vp, _P(ConvEpilogue), c_vp]),
+    "kd_conv2d_bn_sums_rows": (c_int, [_P(ConvDesc), _P(ConvEpilogue)]),
+    "kd_bn_sums_finish_workspace": (c_sz, [c_int, c_int]),
+    "kd_bn_sums_finish": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "kd_pack_conv_weight": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "kd_pw_wgrad_workspace": (c_sz, [c_int, c_int, c_int]),
     "kd_pw_wgrad": (c_int, [c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_sz, c_vp]),

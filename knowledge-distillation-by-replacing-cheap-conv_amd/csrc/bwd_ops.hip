@@ -556,6 +556,62 @@ extern "C" int kd_channel_sums(int32_t dtype, const void *g, int32_t ldg, const 
     return KD_OK;
 }
 
+namespace {
+// rows [chunk * per, ...) of part[R][2][C] -> out[chunk][2][C] (fp64 accumulators, fixed order): first stage of
+// kd_bn_sums_finish for the full-resolution layers (32768 partial rows and more)
+__global__ __launch_bounds__(256) void bn_sums_stage_kernel(const float *__restrict__ part, int R, int C, int per, float *__restrict__ out)
+{
+    __shared__ double sh[2][16][16];
+    const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl, chunk = blockIdx.y;
+    const int r0 = chunk * per, r1 = min(R, r0 + per);
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int k = r0 + lane; k < r1; k += 16) {
+            const float *o = part + (size_t)k * 2 * C;
+            a += o[c];
+            b += o[C + c];
+        }
+    sh[0][lane][cl] = a;
+    sh[1][lane][cl] = b;
+    __syncthreads();
+    for (int w = 8; w >= 1; w >>= 1) {
+        if (lane < w) {
+            sh[0][lane][cl] += sh[0][lane + w][cl];
+            sh[1][lane][cl] += sh[1][lane + w][cl];
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && c < C) {
+        out[(size_t)chunk * 2 * C + c] = (float)sh[0][0][cl];
+        out[(size_t)chunk * 2 * C + C + c] = (float)sh[1][0][cl];
+    }
+}
+}  // namespace
+
+extern "C" size_t kd_bn_sums_finish_workspace(int32_t rows, int32_t C)
+{
+    return rows > 2048 ? (size_t)((rows + 255) / 256) * 2 * (size_t)C * sizeof(float) : 0;
+}
+
+extern "C" int kd_bn_sums_finish(const float *part, int32_t rows, int32_t C, float *s1, float *s2, void *workspace, size_t workspace_bytes,
+                                 kd_stream_t stream)
+{
+    KD_REQUIRE(part && s1 && s2 && rows > 0 && C > 0, KD_ERR_INVALID, "kd_bn_sums_finish: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (rows > 2048) {
+        KD_REQUIRE(workspace && workspace_bytes >= kd_bn_sums_finish_workspace(rows, C), KD_ERR_WORKSPACE, "kd_bn_sums_finish: workspace too small");
+        const int chunks = (rows + 255) / 256;
+        hipLaunchKernelGGL(bn_sums_stage_kernel, dim3((unsigned)((C + 15) / 16), (unsigned)chunks), dim3(256), 0, s, part, rows, C, 256, (float *)workspace);
+        KD_CHECK_LAUNCH("kd_bn_sums_finish(stage)");
+        part = (const float *)workspace;
+        rows = chunks;
+    }
+    hipLaunchKernelGGL(channel_sums_finish_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, s, part, 1, rows, C, s1, s2);
+    KD_CHECK_LAUNCH("kd_bn_sums_finish");
+    return KD_OK;
+}
+
 extern "C" int kd_bn_eval_param_grads(const float *s1, const float *s2, const float *scale, const float *gamma, const float *beta,
                                       float *dgamma, float *dbeta, int32_t C, int32_t accumulate, kd_stream_t stream)
 {

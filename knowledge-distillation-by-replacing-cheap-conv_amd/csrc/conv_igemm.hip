@@ -701,6 +701,8 @@ __device__ __forceinline__ void wait_vm_stores(int nst)
     if (nst == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
     else if (nst == 32) asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
     else if (nst == 48) asm volatile("s_waitcnt vmcnt(48) lgkmcnt(0)" ::: "memory");
+    else if (nst == 20) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");   // + the four stores of the eval-BN sums
+    else if (nst == 36) asm volatile("s_waitcnt vmcnt(36) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 }
@@ -711,6 +713,8 @@ __device__ __forceinline__ void wait_vm_only(int nst)
     if (nst == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if (nst == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
     else if (nst == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+    else if (nst == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if (nst == 36) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -726,12 +730,14 @@ __device__ __forceinline__ void wait_vm_only(int nst)
 // front, two operands for 64 rows at a time (one store -> load hand-over instead of three).  Issues exactly 16 stores per
 // output and lane.
 // PT: row tiles (2 KiB each) per LDS round trip -- the patch is PT * 2 KiB per wave where the stage buffers leave room
-template <int MI, int NOPS, int PT = 1>
+template <int MI, int NOPS_, int PT = 1>   // NOPS_ = operands | 4 when the eval-BN sums are taken (kernels' NOPS parameter)
 __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *patch, f32x4_t (&acc)[MI][4], int mw, int nw,
                                                    int lane)
 {
     typedef bf16_t T;
-    static_assert(MI == 8 && NOPS >= 0 && NOPS <= 3, "128-row wave sub-tiles");
+    constexpr int NOPS = NOPS_ & 3;
+    constexpr bool SUMS = (NOPS_ & 4) != 0;
+    static_assert(MI == 8 && NOPS_ >= 0 && NOPS_ <= 7 && NOPS_ != 4, "128-row wave sub-tiles; sums need the mask operand");
     const kd_conv_epilogue &e = p.ep;
     // every per-lane address below derives from this copy: the compiler cannot hoist them out of the tile loop into
     // registers that would stay live through the main loop (which runs at the 256-VGPR limit)
@@ -764,6 +770,12 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) r[ps] = *(const uint4 *)(src + rowof(hb * 8 + ps) * ld + c0);
     };
+    // eval-BN parameter sums of the masked gradient (backward: v = gradient w.r.t. the BN output where the activation is on):
+    // S1[c] = sum_m v * mask_scale, S2[c] = sum_m v * mask_scale * act -- what kd_channel_sums would read back from memory
+    float bs1[8], bs2[8];
+    constexpr bool sums = SUMS;   // (host: only with a mask, and never without the pointer)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { bs1[q] = 0.f; bs2[q] = 0.f; }
     // pack first (frees half the accumulator registers), then the loads: no spills
     uint2 pk[MI][4];
 #pragma unroll
@@ -827,6 +839,10 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
                     ld8((const T *)&om, t);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) v[q] = t[q] > 0.f ? v[q] * mscale[q] : 0.f;
+                    if constexpr (SUMS) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { bs1[q] += v[q]; bs2[q] = fmaf(v[q], t[q], bs2[q]); }
+                    }
                 }
                 if (has_q) {
                     const uint4 oq = NOPS == 3 ? rc[NOPS == 3 ? ps : 0] : (q_in1 ? o1 : o0);
@@ -850,6 +866,25 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    if constexpr (SUMS) {
+        // lanes l, l + 8, .., l + 56 hold the same 8 channels (rows lrow + 8 k): butterfly over lane bits 3-5 in a fixed order,
+        // then lane l < 8 writes partial row mw / 128 of [M / 128][2][Cout] (summed in row order by kd_bn_sums_finish)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int sft = 8; sft < 64; sft <<= 1) {
+                bs1[q] += __shfl_xor(bs1[q], sft, 64);
+                bs2[q] += __shfl_xor(bs2[q], sft, 64);
+            }
+        }
+        if (lane < 8) {
+            float *dst = e.bn_sums + (size_t)(mw >> 7) * 2 * p.Cout + c0;
+            *(float4 *)dst = make_float4(bs1[0], bs1[1], bs1[2], bs1[3]);
+            *(float4 *)(dst + 4) = make_float4(bs1[4], bs1[5], bs1[6], bs1[7]);
+            *(float4 *)(dst + p.Cout) = make_float4(bs2[0], bs2[1], bs2[2], bs2[3]);
+            *(float4 *)(dst + p.Cout + 4) = make_float4(bs2[4], bs2[5], bs2[6], bs2[7]);
         }
     }
 }
@@ -1019,7 +1054,7 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_row_persist_kernel(
             for (int j = 0; j < NJ; ++j) Mma<T>::run(b[j], a[i], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
     };
-    const int nst_epi = 2 * MI * ((p.ep.out_raw ? 1 : 0) + (p.ep.out_act ? 1 : 0));
+    const int nst_epi = 2 * MI * ((p.ep.out_raw ? 1 : 0) + (p.ep.out_act ? 1 : 0)) + ((NOPS & 4) ? 4 : 0);
     int nst = 0;   // stores issued after the pending prologue
     int tcount = 0;
     setup(walk.t);
@@ -1247,7 +1282,7 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_persist_kerne
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    const int nst_epi = 2 * MI * ((p.ep.out_raw ? 1 : 0) + (p.ep.out_act ? 1 : 0));
+    const int nst_epi = 2 * MI * ((p.ep.out_raw ? 1 : 0) + (p.ep.out_act ? 1 : 0)) + ((NOPS & 4) ? 4 : 0);
     if constexpr (PP) {
         // Ping-pong with seamless tile transitions: the staging runs ahead of the compute ACROSS tiles -- group 0 always issues
         // the stage two ahead of the one it computes, group 1 its rows of the stage one ahead, whichever tile that stage
@@ -1501,7 +1536,7 @@ __global__ __launch_bounds__(512, 2) void conv_row_pp128_kernel(const ConvParams
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    const int nst_epi = 2 * MI * ((p.ep.out_raw ? 1 : 0) + (p.ep.out_act ? 1 : 0));
+    const int nst_epi = 2 * MI * ((p.ep.out_raw ? 1 : 0) + (p.ep.out_act ? 1 : 0)) + ((NOPS & 4) ? 4 : 0);
     int nst = 0, tcount = 0;
     setup(walk.t);
     prologue();
@@ -1605,6 +1640,73 @@ static bool pp_row()
     return pp != 0;
 }
 
+// Which kernel kd_conv2d_fwd runs for a problem (shared with kd_conv2d_bn_sums_rows, which must predict it).
+struct ConvSel {
+    int cfg;   // 0 narrow2, 1 wide, 2 deep, 3 narrow (one workgroup per CU)
+    bool norow, half, row_wide, row_x, row_narrow, vec_ok;
+    int nops, ncu;
+    bool use_row_persist, use_igemm_persist, use_pp128;
+};
+static ConvSel conv_select(const kd_conv_desc *d, const kd_conv_epilogue *ep, int tune)
+{
+    ConvSel c;
+    const int es = kd_elem_size(d->dtype);
+    const int M = d->N * d->Ho * d->Wo;
+    auto ok = [&](const void *ptr, int ld, int esz) { return !ptr || (kd_aligned16(ptr) && (ld * esz) % 16 == 0); };
+    c.vec_ok = ok(ep->res_pre, ep->ld_res_pre, es) && ok(ep->mask, ep->ld_mask, es) &&
+               ok(ep->res_post, ep->ld_res_post, es) && ok(ep->out_raw, ep->ld_raw, ep->raw_f32 ? 4 : es) &&
+               ok(ep->out_act, ep->ld_act, es);
+    // wide tiles only when they still fill the chip (one workgroup per CU, 256 CUs); e.g. the ASPP 4096->256 1x1 at
+    // 128x256 pixels would give 128 wide tiles, so it runs on the narrow config (256 tiles)
+    const long long wide_tiles = (long long)((M + CfgWide::BM - 1) / CfgWide::BM) * ((d->Cout + CfgWide::BN - 1) / CfgWide::BN);
+    c.norow = false; c.half = false;
+    c.cfg = (d->Cout > 128 && wide_tiles >= 224) ? 1 : 0;
+    if (const char *e = getenv("KDCC_CONV_CFG")) {              // tuning hook
+        if (!strcmp(e, "narrow")) c.cfg = 0;
+        else if (!strcmp(e, "norow")) c.norow = true;
+        else if (!strcmp(e, "half")) c.half = true;
+        else if (!strcmp(e, "deep") && c.cfg == 1) c.cfg = 2;
+        else if (!strcmp(e, "narrow1") && c.cfg == 0) c.cfg = 3;
+    }
+    // 256-pixel tiles that are segments of one image row, 3x3 / stride 1 / 'same': row-buffer kernels (the narrow one is
+    // compiled for <= 128 VGPRs, which the fp32 parity path's blocked accumulation does not fit)
+    const bool row_geom = !c.norow && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == d->dil && d->W % 256 == 0;
+    c.row_wide = row_geom && c.cfg == 1 && d->dil <= CfgRowX::MAXDIL;
+    c.row_x = c.row_wide && d->dil > CfgRow::MAXDIL;
+    c.row_narrow = row_geom && c.cfg == 0 && d->dtype == KD_BF16 && d->dil <= CfgRowN::MAXDIL;
+    // persistent kernels (bf16 wide tiles, whole tiles, vector-friendly epilogue): one workgroup per CU walks the tiles
+    static int persist = -1, ncu = 0;
+    if (persist < 0) {
+        const char *v = getenv("KDCC_CONV_PERSIST");
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+            ncu = 256;
+        persist = !(v && v[0] == '0');
+    }
+    c.ncu = ncu;
+    c.nops = (ep->res_pre ? 1 : 0) + (ep->mask ? 1 : 0) + (ep->res_post ? 1 : 0);
+    const bool persist_ok = persist && !c.half && d->dtype == KD_BF16 && c.cfg == 1 && c.vec_ok && !ep->raw_f32 && M % 256 == 0 && d->Cout % 256 == 0 &&
+                            (c.nops <= 2 || (pp_row() && !(tune & 512)));   // three operands: the default (ping-pong) instantiations only
+    c.use_row_persist = persist_ok && c.row_wide && !c.row_x;
+    c.use_igemm_persist = !c.use_row_persist && persist_ok && d->kh == 1 && d->stride == 1 && d->pad == 0;
+    c.use_pp128 = !c.use_row_persist && !c.use_igemm_persist && !(c.row_wide && c.half && d->dtype == KD_BF16) && c.row_narrow && pp_row() && persist &&
+                  c.vec_ok && !ep->raw_f32 && c.nops <= 2 && d->Cout % 128 == 0 && d->W % 512 == 0 && d->dil <= 16 && d->Cin % 32 == 0;
+    return c;
+}
+
+/* Rows of per-channel partial sums the kernel selected for (d, ep) writes to ep->bn_sums (one per 128 output pixels), or 0 when
+ * that kernel does not produce them (the caller then runs kd_channel_sums on the result). */
+extern "C" int32_t kd_conv2d_bn_sums_rows(const kd_conv_desc *d, const kd_conv_epilogue *ep)
+{
+    if (!d || !ep || !ep->mask || d->dtype != KD_BF16 || d->N <= 0 || d->Ho <= 0 || d->Wo <= 0) return 0;
+    static int tn = -1;
+    if (tn < 0) tn = KD_TUNING_ENV_INT("KDCC_CONV_TUNE");
+    const ConvSel c = conv_select(d, ep, tn);
+    // (the ping-pong instantiations with one or two epilogue operands; with three the sums' registers spill 150 values)
+    if (!(c.use_row_persist || c.use_igemm_persist || c.use_pp128) || (tn & 512) || !pp_row() || (c.use_row_persist && d->dil > 32) || c.nops > 2) return 0;
+    return (int32_t)((long long)d->N * d->Ho * d->Wo / 128);
+}
+
 extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w_packed, const kd_conv_epilogue *ep,
                              kd_stream_t stream)
 {
@@ -1638,10 +1740,6 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
     p.HoWo = d->Ho * d->Wo;
     p.Ktot = d->kh * d->kw * d->Cin;
     p.ep = *ep;
-    auto ok = [&](const void *ptr, int ld, int esz) { return !ptr || (kd_aligned16(ptr) && (ld * esz) % 16 == 0); };
-    p.vec_ok = ok(ep->res_pre, ep->ld_res_pre, es) && ok(ep->mask, ep->ld_mask, es) &&
-               ok(ep->res_post, ep->ld_res_post, es) && ok(ep->out_raw, ep->ld_raw, ep->raw_f32 ? 4 : es) &&
-               ok(ep->out_act, ep->ld_act, es);
     {
         static int eb = -1;
         if (eb < 0) { const char *v = getenv("KDCC_EPI_BATCH"); eb = !(v && v[0] == '0'); }
@@ -1650,18 +1748,12 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         if (tn < 0) tn = KD_TUNING_ENV_INT("KDCC_CONV_TUNE");   // timing ablations / timestamps: tuning build only (kd_common.h)
         p.tune = tn;
     }
-    // wide tiles only when they still fill the chip (one workgroup per CU, 256 CUs); e.g. the ASPP 4096->256 1x1 at
-    // 128x256 pixels would give 128 wide tiles, so it runs on the narrow config (256 tiles)
-    const long long wide_tiles = (long long)((p.M + CfgWide::BM - 1) / CfgWide::BM) * ((d->Cout + CfgWide::BN - 1) / CfgWide::BN);
-    bool norow = false, half = false;
-    int cfg = (d->Cout > 128 && wide_tiles >= 224) ? 1 : 0;   // 0 narrow2, 1 wide, 2 deep, 3 narrow (one workgroup per CU)
-    if (const char *e = getenv("KDCC_CONV_CFG")) {              // tuning hook
-        if (!strcmp(e, "narrow")) cfg = 0;
-        else if (!strcmp(e, "norow")) norow = true;
-        else if (!strcmp(e, "half")) half = true;
-        else if (!strcmp(e, "deep") && cfg == 1) cfg = 2;
-        else if (!strcmp(e, "narrow1") && cfg == 0) cfg = 3;
-    }
+    const ConvSel sel = conv_select(d, ep, p.tune);
+    p.vec_ok = sel.vec_ok;
+    const int cfg = sel.cfg, nops = sel.nops, ncu = sel.ncu;
+    const bool half = sel.half, row_wide = sel.row_wide, row_x = sel.row_x, row_narrow = sel.row_narrow;
+    KD_REQUIRE(!ep->bn_sums || kd_conv2d_bn_sums_rows(d, ep) > 0, KD_ERR_UNSUPPORTED,
+               "kd_conv2d_fwd: bn_sums is not produced by the kernel this problem selects (ask kd_conv2d_bn_sums_rows first)");
     hipStream_t s = (hipStream_t)stream;
     auto launch = [&](auto cf, auto tag) {
         using CF = decltype(cf);
@@ -1674,24 +1766,6 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         hipLaunchKernelGGL((conv_igemm_kernel<T, CF>), dim3((unsigned)(tiles_m * p.tiles_n)), dim3(64 * CF::NW), 0, s, p);
     };
     const bool f32 = d->dtype == KD_F32;
-    // 256-pixel tiles that are segments of one image row, 3x3 / stride 1 / 'same': row-buffer kernels (the narrow one is
-    // compiled for <= 128 VGPRs, which the fp32 parity path's blocked accumulation does not fit)
-    const bool row_geom = !norow && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == d->dil && d->W % 256 == 0;
-    const bool row_wide = row_geom && cfg == 1 && d->dil <= CfgRowX::MAXDIL;
-    const bool row_x = row_wide && d->dil > CfgRow::MAXDIL;
-    const bool row_narrow = row_geom && cfg == 0 && d->dtype == KD_BF16 && d->dil <= CfgRowN::MAXDIL;
-    // persistent kernels (bf16 wide tiles, whole tiles, vector-friendly epilogue): one workgroup per CU walks the tiles
-    static int persist = -1, ncu = 0;
-    if (persist < 0) {
-        const char *v = getenv("KDCC_CONV_PERSIST");
-        persist = !(v && v[0] == '0');
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
-            ncu = 256;
-    }
-    const int nops = (ep->res_pre ? 1 : 0) + (ep->mask ? 1 : 0) + (ep->res_post ? 1 : 0);
-    const bool persist_ok = persist && !half && d->dtype == KD_BF16 && cfg == 1 && p.vec_ok && !ep->raw_f32 && p.M % 256 == 0 && d->Cout % 256 == 0 &&
-                            (nops <= 2 || (pp_row() && !(p.tune & 512)));   // three operands: the default (ping-pong) instantiations only
     auto persist_grid = [&]() {
         p.tiles_n = d->Cout / 256;
         p.tiles_m = p.M / 256;
@@ -1704,7 +1778,7 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         const int nwg = p.ntiles < ncu ? p.ntiles : ncu;
         return dim3((unsigned)((nwg + 7) / 8 * 8));
     };
-    if (persist_ok && row_wide && !row_x) {
+    if (sel.use_row_persist) {
         p.nkc = d->Cin / (CfgRow::RB / es);
         p.nk = 9 * p.nkc;
         const dim3 grid = persist_grid();
@@ -1715,19 +1789,23 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
             else hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 2, true, true>), grid, dim3(512), 0, s, p);
         } else if (pp_row() && d->dil <= 32) {
             if (nops == 0) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 0, false, true>), grid, dim3(512), 0, s, p);
+            else if (ep->bn_sums && nops == 1) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 5, false, true>), grid, dim3(512), 0, s, p);
+            else if (ep->bn_sums && nops == 2) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 6, false, true>), grid, dim3(512), 0, s, p);
             else if (nops == 1) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 1, false, true>), grid, dim3(512), 0, s, p);
             else if (nops == 2) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 2, false, true>), grid, dim3(512), 0, s, p);
             else hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 3, false, true>), grid, dim3(512), 0, s, p);
         } else if (nops == 0) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 0>), grid, dim3(512), 0, s, p);
         else if (nops == 1) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 1>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 2>), grid, dim3(512), 0, s, p);
-    } else if (persist_ok && d->kh == 1 && d->stride == 1 && d->pad == 0) {
+    } else if (sel.use_igemm_persist) {
         p.nkc = d->Cin / (CfgWide::RB / es);
         p.nk = d->kh * d->kw * p.nkc;
         const dim3 grid = persist_grid();
         KD_NOTE_KERNEL(pp_row() ? "conv_igemm_persist_kernel<pp>" : "conv_igemm_persist_kernel<lockstep>");
         if (pp_row()) {
             if (nops == 0) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 0, true>), grid, dim3(512), 0, s, p);
+            else if (ep->bn_sums && nops == 1) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 5, true>), grid, dim3(512), 0, s, p);
+            else if (ep->bn_sums && nops == 2) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 6, true>), grid, dim3(512), 0, s, p);
             else if (nops == 1) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 1, true>), grid, dim3(512), 0, s, p);
             else if (nops == 2) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 2, true>), grid, dim3(512), 0, s, p);
             else hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 3, true>), grid, dim3(512), 0, s, p);
@@ -1742,8 +1820,7 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         KD_NOTE_KERNEL("conv_igemm_row_kernel<half>");
         if (row_x) hipLaunchKernelGGL((conv_igemm_row_kernel<bf16_t, CfgRowHX>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((conv_igemm_row_kernel<bf16_t, CfgRowH>), grid, dim3(256), 0, s, p);
-    } else if (row_narrow && pp_row() && persist && p.vec_ok && !ep->raw_f32 && nops <= 2 && d->Cout % 128 == 0 && d->W % 512 == 0 &&
-               d->dil <= 16 && d->Cin % 32 == 0) {
+    } else if (sel.use_pp128) {
         // Cout = 128 layers: 512 x 128 ping-pong tiles
         p.nkc = d->Cin / 32;
         p.nk = 9 * p.nkc;
@@ -1756,6 +1833,8 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         KD_NOTE_KERNEL("conv_row_pp128_kernel");
         if (p.tune & 512) hipLaunchKernelGGL((conv_row_pp128_kernel<0, true>), grid, dim3(512), 0, s, p);   // phase clocks (no-operand form only)
         else if (nops == 0) hipLaunchKernelGGL((conv_row_pp128_kernel<0>), grid, dim3(512), 0, s, p);
+        else if (ep->bn_sums && nops == 1) hipLaunchKernelGGL((conv_row_pp128_kernel<5>), grid, dim3(512), 0, s, p);
+        else if (ep->bn_sums) hipLaunchKernelGGL((conv_row_pp128_kernel<6>), grid, dim3(512), 0, s, p);
         else if (nops == 1) hipLaunchKernelGGL((conv_row_pp128_kernel<1>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv_row_pp128_kernel<2>), grid, dim3(512), 0, s, p);
     } else if (row_wide || row_narrow) {

@@ -45,6 +45,7 @@ _SMALL_CONV = os.environ.get("KDCC_SMALL_CONV", "1") != "0"  # A/B: 0 = GSCNN re
 _SPLIT_DEC_DGRAD = os.environ.get("KDCC_SPLIT_DEC_DGRAD", "1") != "0"   # A/B: 0 = the decoder's 304-channel input gradient in one launch
 _STEM_POOL = os.environ.get("KDCC_STEM_POOL", "1") != "0"   # A/B: 0 = stem conv and pool2 as two kernels
 _DW_SUM = os.environ.get("KDCC_DW_SUM", "1") != "0"   # A/B: 0 = one depthwise input-gradient launch per ASPP branch
+_FUSE_BN_SUMS = os.environ.get("KDCC_FUSE_BN_SUMS", "1") != "0"   # A/B: 0 = eval-BN parameter sums by kd_channel_sums only
 
 
 class EngineError(RuntimeError):
@@ -1058,7 +1059,11 @@ class StudentEngine:
         grads[w] = gw
         self._grad_done(w)
 
-    def _bn_param_grads(self, bn_seq, g_x, act, grads, sub=None, gate=None):
+    def _wants_bn_sums(self, bn_seq, gate=None):
+        bn = _bn_of(bn_seq)
+        return bn.weight.requires_grad or bn.bias.requires_grad or (gate is not None and gate.weight.requires_grad)
+
+    def _bn_param_grads(self, bn_seq, g_x, act, grads, sub=None, gate=None, sums=None):
         """Eval-mode BN weight/bias gradients.  g_x: gradient w.r.t. the BN input (already through the ReLU mask and the BN
         scale; `sub` = a tensor that was added to it afterwards, e.g. the shortcut gradient), act = relu(bn(x)).
         gate: a GateLayer behind the ReLU, folded into the epilogue (act = relu(bn(x)) * g, g_x carries scale * g): with
@@ -1068,7 +1073,8 @@ class StudentEngine:
         if not (bn.weight.requires_grad or bn.bias.requires_grad or want_gate):
             return
         scale, _ = self._bn_fold(bn_seq)
-        s1, s2 = ops.channel_sums(g_x, sub=sub, a=act)
+        # sums: (S1, S2) already taken by the conv epilogue that produced g_x (ops.conv2d(bn_sums=...)) -- no second pass over it
+        s1, s2 = sums if sums is not None else ops.channel_sums(g_x, sub=sub, a=act)
         if gate is not None:
             gv = gate.weight.detach().float()
             if want_gate:
@@ -1172,9 +1178,12 @@ class StudentEngine:
                     elif rec["rg_in"]:
                         sub = g_out
                         ep["res_post"] = g_out
+                fused = []
+                if _FUSE_BN_SUMS and need_in and not site.cheap and self._wants_bn_sums(bn_seq, act_gate):
+                    ep["bn_sums"] = fused       # the dense input gradient's epilogue takes the BN parameter sums where it can
                 g_in = self._site_bwd(site, a_in, rec["mid"][i], g, grads, need_in, **ep)
                 if g_in is not None:
-                    self._bn_param_grads(bn_seq, g_in, a_in, grads, sub=sub, gate=act_gate)
+                    self._bn_param_grads(bn_seq, g_in, a_in, grads, sub=sub, gate=act_gate, sums=fused[0] if fused else None)
             elif i == 0 and g is None and g_out is not None:
                 # only the shortcut carries gradient into this block's input
                 if rec["proj"]:
@@ -1204,9 +1213,11 @@ class StudentEngine:
         arec = self._tape["aspp"]
         aspp, cat, red, x7, rg7 = arec["mod"], arec["cat"], arec["red"], arec["x7"], arec["rg7"]
         lead = arec.get("lead", 1)
+        cat_sums = arec.pop("cat_sums", None)     # (S1, S2) over the concat's channels from the bot_aspp input-gradient epilogue
         if g_cat_hint is not None:
             scale = self._cat_scale(aspp)
             g_cat = ops.relu_bn_bwd(g_cat_hint, cat, scale, res=g_cat)
+            cat_sums = None                        # an `aspp` hint's gradient joined in: the sums no longer describe g_cat
         # x7 feeds every branch: its gradient is the sum of the branches' input gradients.  The replaced (cheap) branches go
         # first -- weight gradients per branch, their depthwise input gradients summed inside ONE launch per geometry
         # (registers instead of a read-modify-write of the running 4096-channel sum per branch) -- then the dense branches
@@ -1221,7 +1232,8 @@ class StudentEngine:
             g = g_aspp.get(i)
             if g_cat is not None:
                 gi = g_cat[..., sl]
-                self._bn_param_grads(br["bn"], gi, cat[..., sl], grads, gate=br.get("act_gate"))
+                self._bn_param_grads(br["bn"], gi, cat[..., sl], grads, gate=br.get("act_gate"),
+                                     sums=(cat_sums[0][sl], cat_sums[1][sl]) if cat_sums is not None else None)
                 g = gi if g is None else g + gi
             if g is None:
                 continue
@@ -1377,14 +1389,16 @@ class StudentEngine:
             return None, None
         sc, _ = self._bn_fold(f[4])
         g_c2 = self._new(N, h2, w2, f[3].out_channels)
-        ops.conv2d(g_d3, self._w_dgrad(f[6], cout_pad=kpad), out_raw=g_c2, mask=dec["d2"], mask_scale=sc)
-        self._bn_param_grads(f[4], g_c2, dec["d2"], grads)
+        fused = [] if _FUSE_BN_SUMS and self._wants_bn_sums(f[4]) else None
+        ops.conv2d(g_d3, self._w_dgrad(f[6], cout_pad=kpad), out_raw=g_c2, mask=dec["d2"], mask_scale=sc, bn_sums=fused)
+        self._bn_param_grads(f[4], g_c2, dec["d2"], grads, sums=fused[0] if fused else None)
         self._conv_wgrad(f[3], dec["d1"], g_c2, grads)
         if not rg_d1:
             return None, None
         sc, _ = self._bn_fold(f[1])
-        g_c1 = self._dense_dgrad(_Site("final.3", f[3]), g_c2, mask=dec["d1"], mask_scale=sc)
-        self._bn_param_grads(f[1], g_c1, dec["d1"], grads)
+        fused = [] if _FUSE_BN_SUMS and self._wants_bn_sums(f[1]) else None
+        g_c1 = self._dense_dgrad(_Site("final.3", f[3]), g_c2, mask=dec["d1"], mask_scale=sc, bn_sums=fused)
+        self._bn_param_grads(f[1], g_c1, dec["d1"], grads, sums=fused[0] if fused else None)
         self._conv_wgrad(f[0], dec["dec0"], g_c1, grads, cin=cdec, cin_rot=nf)
         if not rg_dec0:
             return None, None
@@ -1416,7 +1430,10 @@ class StudentEngine:
             if dec["rg_cat"]:
                 cat = dec["cat"]
                 g_cat = self._new(N, cat.shape[1], cat.shape[2], cat.shape[3])
-                ops.conv2d(g_up, self._w_dgrad(net.bot_aspp), out_raw=g_cat, mask=cat, mask_scale=self._cat_scale(net.aspp))
+                # the branches' BN parameter sums are channel slices of this epilogue's sums (kept for _aspp_bwd)
+                fused = [] if _FUSE_BN_SUMS else None
+                ops.conv2d(g_up, self._w_dgrad(net.bot_aspp), out_raw=g_cat, mask=cat, mask_scale=self._cat_scale(net.aspp), bn_sums=fused)
+                self._tape["aspp"]["cat_sums"] = fused[0] if fused else None
         return g_cat, g_m2
 
 

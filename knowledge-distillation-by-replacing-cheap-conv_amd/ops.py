@@ -106,8 +106,11 @@ def pack_conv_weight(w, dtype, mode=KD_PACK_FWD, cin_pad=None):
 
 
 def conv2d(x, w_packed, stride=1, pad=0, dil=1, *, res_pre=None, mask=None, mask_scale=None, res_post=None,
-           out_raw=None, out_act=None, act_scale=None, act_shift=None, act_relu=False, algo_cin=None, algo_cout=None):
-    """Implicit-GEMM conv; w_packed is (Cout,kh,kw,Cin). Outputs are caller-provided NHWC views."""
+           out_raw=None, out_act=None, act_scale=None, act_shift=None, act_relu=False, algo_cin=None, algo_cout=None, bn_sums=None):
+    """Implicit-GEMM conv; w_packed is (Cout,kh,kw,Cin). Outputs are caller-provided NHWC views.
+    bn_sums: an empty list (backward, with `mask`): when the kernel this problem selects can take the eval-BN parameter sums in
+    its epilogue, (s1, s2) = per-channel sums of the masked gradient and of it times `mask` are appended -- what
+    channel_sums(out_raw, sub=res_post, a=mask) would return from another pass over the tensors; otherwise it stays empty."""
     _need_cuda(x, w_packed)
     N, H, W, Cin = x.shape
     Cout, kh, kw, Cin_w = w_packed.shape
@@ -143,6 +146,13 @@ def conv2d(x, w_packed, stride=1, pad=0, dil=1, *, res_pre=None, mask=None, mask
     ep.out_act, ep.ld_act = _ptr(out_act), chk(out_act, "out_act")
     chk_vec(act_scale, "act_scale"); chk_vec(act_shift, "act_shift")
     ep.act_scale, ep.act_shift, ep.act_relu = _ptr(act_scale), _ptr(act_shift), int(act_relu)
+    ep.bn_sums = None
+    sums_rows = 0
+    if bn_sums is not None and mask is not None:
+        sums_rows = int(_lib.lib().kd_conv2d_bn_sums_rows(C.byref(d), C.byref(ep)))
+        if sums_rows > 0:
+            part = torch.empty((sums_rows, 2, Cout), dtype=torch.float32, device=x.device)
+            ep.bn_sums = _ptr(part)
     prof = PROFILER
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
@@ -153,7 +163,14 @@ def conv2d(x, w_packed, stride=1, pad=0, dil=1, *, res_pre=None, mask=None, mask
         e1.record()
         epi = "".join(c for c, t in (("p", res_pre), ("m", mask), ("q", res_post), ("r", out_raw), ("a", out_act)) if t is not None)
         prof.append(("conv_igemm", 2.0 * N * Ho * Wo * (algo_cout or Cout) * kh * kw * (algo_cin or Cin), e0, e1,
-                     f"{kh}x{kw} s{stride} d{dil} {H}x{W} {Cin}->{Cout} [{epi}]", _lib.last_kernel()))
+                     f"{kh}x{kw} s{stride} d{dil} {H}x{W} {Cin}->{Cout} [{epi}{'s' if sums_rows else ''}]", _lib.last_kernel()))
+    if sums_rows > 0:
+        s12 = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
+        need = _lib.lib().kd_bn_sums_finish_workspace(sums_rows, Cout)
+        ws = _ws(need, x.device) if need else None
+        check(_lib.lib().kd_bn_sums_finish(_ptr(part), sums_rows, Cout, _ptr(s12[0]), _ptr(s12[1]), _ptr(ws), need, stream_ptr()),
+              "kd_bn_sums_finish")
+        bn_sums.append((s12[0], s12[1]))
     return out_raw, out_act
 
 
@@ -530,8 +547,11 @@ def channel_sums(g, sub=None, a=None, per_image=False):
     for t in (sub, a):
         if t is not None and (tuple(t.shape) != (N, H, W, Cc) or t.dtype != g.dtype):
             raise ValueError("channel_sums: operand mismatch")
+    e0 = _prof_start()
     check(_lib.lib().kd_channel_sums(dt_of(g), _ptr(g), ld(g), _ptr(sub), ld(sub), _ptr(a), ld(a), groups, rows, Cc, _ptr(s1), _ptr(s2),
                                      _ptr(ws), need, stream_ptr()), "kd_channel_sums")
+    _prof_stop(e0, "channel_sums", float(_nbytes(g, sub, a)), f"channel sums {H}x{W} C{Cc}{' -sub' if sub is not None else ''}{' *a' if a is not None else ''}",
+               "channel_sums_partial_kernel")
     if not per_image:
         s1 = s1[0]
         s2 = s2[0] if s2 is not None else None

@@ -147,6 +147,63 @@ def test_conv_epilogue_forward(K, dt):
     assert float(wide[..., :Cout].abs().max()) == 0 and float(wide[..., 2 * Cout:].abs().max()) == 0
 
 
+BN_SUMS_CASES = [
+    # N, H, W, Cin, Cout, k, dil, operands, kernel -- the backward of conv -> BN -> ReLU at shapes that select each kernel whose
+    # epilogue can take the eval-BN parameter sums (mask alone, mask + res_post, res_pre + mask), and one that selects none
+    (1, 128, 512, 256, 256, 3, 1, "m", "conv_row_persist_kernel<pp>"),
+    (2, 96, 256, 256, 512, 3, 2, "mq", "conv_row_persist_kernel<pp>"),
+    (1, 128, 512, 128, 256, 1, 1, "pm", "conv_igemm_persist_kernel<pp>"),
+    (1, 128, 512, 256, 256, 1, 1, "mq", "conv_igemm_persist_kernel<pp>"),
+    (1, 256, 512, 128, 128, 3, 1, "m", "conv_row_pp128_kernel"),
+    (1, 256, 512, 64, 128, 3, 1, "mq", "conv_row_pp128_kernel"),
+    (1, 64, 256, 128, 64, 3, 1, "m", None),
+]
+
+
+@pytest.mark.parametrize("case", BN_SUMS_CASES)
+def test_conv_epilogue_bn_sums(K, case):
+    """kd_conv2d_fwd(bn_sums): the sums eval-mode BN's weight / bias gradients need (autograd of bn -> relu in
+    IdentityResidualBlock, wider_resnet.py:124-167), taken in the epilogue of the input-gradient conv, against kd_channel_sums
+    of the stored result and against fp64 sums of the same expression."""
+    N, H, W, Cin, Cout, k, d, opnds, kernel = case
+    dt = "bf16"
+    x = dev_nhwc(q(rnd(N, Cin, H, W), dt), dt)
+    wp = K.pack_conv_weight(torch.from_numpy(q(rnd(Cout, Cin, k, k, scale=(2.0 / (Cin * k * k)) ** 0.5), dt)).cuda(), DT[dt])
+    act = dev_nhwc(q(np.maximum(rnd(N, Cout, H, W), 0), dt), dt)         # relu(bn(x)): zero where the unit is off
+    scale = torch.from_numpy(rnd(Cout) * 0.2 + 1.0).cuda()
+    res_pre = dev_nhwc(q(rnd(N, Cout, H, W), dt), dt) if "p" in opnds else None
+    res_post = dev_nhwc(q(rnd(N, Cout, H, W), dt), dt) if "q" in opnds else None
+    pad = d if k == 3 else 0
+    out = torch.empty((N, H, W, Cout), dtype=DT[dt], device="cuda")
+    got = []
+    K.conv2d(x, wp, 1, pad, d, res_pre=res_pre, mask=act, mask_scale=scale, res_post=res_post, out_raw=out, bn_sums=got)
+    if kernel is None:
+        assert got == [], "a kernel without the fused sums reported them"
+        return
+    selected(kernel, f"bn_sums {case}")
+    assert len(got) == 1
+    s1, s2 = got[0]
+    # the same launch without the sums: the stored gradient must not change
+    out2 = torch.empty_like(out)
+    K.conv2d(x, wp, 1, pad, d, res_pre=res_pre, mask=act, mask_scale=scale, res_post=res_post, out_raw=out2)
+    assert torch.equal(out, out2)
+    c1, c2 = K.channel_sums(out, sub=res_post, a=act)
+    # fp64 restatement from the unmasked conv: g = (act > 0) * (conv + res_pre) * scale
+    raw = torch.empty_like(out)
+    K.conv2d(x, wp, 1, pad, d, res_pre=res_pre, out_raw=raw)
+    g = torch.where(act > 0, raw.double() * scale.double(), torch.zeros((), dtype=torch.float64, device="cuda"))
+    r1, r2 = g.sum((0, 1, 2)), (g * act.double()).sum((0, 1, 2))
+    for name, a, b, ref in (("s1", s1, c1, r1), ("s2", s2, c2, r2)):
+        norm = float(ref.abs().max()) + 1e-6
+        # the stored gradient is rounded to bf16 before kd_channel_sums reads it; the fused sums see fp32 values of bf16 `raw`
+        assert float((a.double() - ref).abs().max()) / norm < 4e-3, f"{name} fused vs fp64 {case}"
+        assert float((a.double() - b.double()).abs().max()) / norm < 8e-3, f"{name} fused vs kd_channel_sums {case}"
+    # run to run
+    again = []
+    K.conv2d(x, wp, 1, pad, d, res_pre=res_pre, mask=act, mask_scale=scale, res_post=res_post, out_raw=out2, bn_sums=again)
+    assert torch.equal(again[0][0], s1) and torch.equal(again[0][1], s2)
+
+
 WIDE_EPI_CASES = [
     # N, H, W, Cin, Cout, k, pad, dil -- every one selects a 256 x 256 tile config (>= 224 wide tiles, Cout > 128)
     (1, 112, 512, 64, 256, 1, 0, 1),      # gathered 1x1 (CfgWide, pipelined loop in bf16)
