@@ -576,6 +576,8 @@ def test_stem_pool_upsample_imagepool(K, dt):
     lgd2 = torch.from_numpy(np.ascontiguousarray(lg2.transpose(0, 2, 3, 1))).cuda()
     o2 = K.upsample_bilinear_ac(lgd2, (42, 666), out_dtype=torch.float32)
     assert_close(host_nchw(o2), orc.upsample_bilinear_ac(lg2, (42, 666)), "f32", "logit upsample (segments)")
+    o2b = K.upsample_bilinear_ac(lgd2, (42, 668), out_dtype=torch.float32)   # 668 * 19 % 4 == 0: the 16-B-store kernel, ragged last block
+    assert_close(host_nchw(o2b), orc.upsample_bilinear_ac(lg2, (42, 668)), "f32", "logit upsample (flat rows)")
     # odd channel count (the 19-class logits), both corner modes
     import torch.nn.functional as F
     lg3 = rnd(2, 19, 9, 10)
