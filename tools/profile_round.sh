@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profile passes of one round on the GPU box (run from the repo root through gpurun):
-#   tools/profile_round.sh <tag>      -> gpurun_out/<tag>/{profA,profB,profG,fetch,write,mfma}
+#   tools/profile_round.sh <tag>      -> gpurun_out/<tag>/{profA,profB,profG,fetch,write,fetchB,writeB,mfma}
 # Kernel stats (mode A headline, mode B, GSCNN) and the three counter passes, each its own rocprofv3 run with
 # --kernel-trace only (no other trace domain next to --pmc).  Summaries for profiles/ are made afterwards with
 # tools/summarize_profile.py / summarize_pmc.py / summarize_mfma.py.
@@ -20,6 +20,10 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f
 echo "[profile] FETCH_SIZE pass done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- $B --steps 3 --warmup 1 > $out/w.log 2>&1 || exit 1
 echo "[profile] WRITE_SIZE pass done"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetchB -o f -- $B --steps 2 --warmup 1 --mode B > $out/fb.log 2>&1 || exit 1
+echo "[profile] FETCH_SIZE pass (mode B) done"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/writeB -o w -- $B --steps 2 --warmup 1 --mode B > $out/wb.log 2>&1 || exit 1
+echo "[profile] WRITE_SIZE pass (mode B) done"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/mfma -o m -- $B --steps 3 --warmup 1 > $out/m.log 2>&1 || exit 1
 echo "[profile] MFMA pass done"
 # keep only what the summarizers read (the traces are tens of MB)

@@ -7,7 +7,8 @@ import csv, json, sys
 
 FAMILIES = {"conv_igemm": ("conv_igemm", "conv_row_persist", "conv_row_pp128"), "dw_mfma_fwd": "dw_mfma_fwd",
             "dw_mfma_wgrad_multi": "dw_mfma_wgrad_multi", "dw_mfma_wgrad": "dw_mfma_wgrad_kernel",
-            "dwconv_fwd": "dwconv_fwd_kernel", "pw_wgrad": "pw_wgrad"}
+            "dwconv_fwd": "dwconv_fwd_kernel", "pw_wgrad": "pw_wgrad", "conv_wgrad_row": "conv_wgrad_row_kernel",
+            "conv_wgrad_wide": "conv_wgrad_wide_kernel"}
 
 
 def collect(path, counter):
