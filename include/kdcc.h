@@ -104,7 +104,7 @@ int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w_packed,
  * bn -> relu in IdentityResidualBlock (models/encoders/wider_resnet.py:124-167, reached from loss.backward(),
  * trainer/layerwise_trainer.py:235).
  * kd_bn_sums_finish: s1[c] = sum_r part[r][0][c], s2[c] = sum_r part[r][1][c] in a fixed order (fp64 accumulators; more than
- *   2048 rows go through a first stage of 256-row chunks in `workspace`). */
+ *   256 rows go through a first stage of 64- or 256-row chunks in `workspace`). */
 int32_t kd_conv2d_bn_sums_rows(const kd_conv_desc *d, const kd_conv_epilogue *ep);
 size_t kd_bn_sums_finish_workspace(int32_t rows, int32_t C);
 int kd_bn_sums_finish(const float *part, int32_t rows, int32_t C, float *s1, float *s2, void *workspace, size_t workspace_bytes,

@@ -589,9 +589,11 @@ __global__ __launch_bounds__(256) void bn_sums_stage_kernel(const float *__restr
 }
 }  // namespace
 
+static int bn_sums_chunk(int rows) { return rows > 16384 ? 256 : 64; }   // rows per first-stage block
+
 extern "C" size_t kd_bn_sums_finish_workspace(int32_t rows, int32_t C)
 {
-    return rows > 2048 ? (size_t)((rows + 255) / 256) * 2 * (size_t)C * sizeof(float) : 0;
+    return rows > 256 ? (size_t)((rows + bn_sums_chunk(rows) - 1) / bn_sums_chunk(rows)) * 2 * (size_t)C * sizeof(float) : 0;
 }
 
 extern "C" int kd_bn_sums_finish(const float *part, int32_t rows, int32_t C, float *s1, float *s2, void *workspace, size_t workspace_bytes,
@@ -599,10 +601,11 @@ extern "C" int kd_bn_sums_finish(const float *part, int32_t rows, int32_t C, flo
 {
     KD_REQUIRE(part && s1 && s2 && rows > 0 && C > 0, KD_ERR_INVALID, "kd_bn_sums_finish: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    if (rows > 2048) {
+    if (rows > 256) {
+        // (C / 16 blocks walking 2048 rows each took 36 us per call, 41 calls per mode-B step: the rows are split first)
         KD_REQUIRE(workspace && workspace_bytes >= kd_bn_sums_finish_workspace(rows, C), KD_ERR_WORKSPACE, "kd_bn_sums_finish: workspace too small");
-        const int chunks = (rows + 255) / 256;
-        hipLaunchKernelGGL(bn_sums_stage_kernel, dim3((unsigned)((C + 15) / 16), (unsigned)chunks), dim3(256), 0, s, part, rows, C, 256, (float *)workspace);
+        const int per = bn_sums_chunk(rows), chunks = (rows + per - 1) / per;
+        hipLaunchKernelGGL(bn_sums_stage_kernel, dim3((unsigned)((C + 15) / 16), (unsigned)chunks), dim3(256), 0, s, part, rows, C, per, (float *)workspace);
         KD_CHECK_LAUNCH("kd_bn_sums_finish(stage)");
         part = (const float *)workspace;
         rows = chunks;
