@@ -1754,6 +1754,7 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
     const bool half = sel.half, row_wide = sel.row_wide, row_x = sel.row_x, row_narrow = sel.row_narrow;
     KD_REQUIRE(!ep->bn_sums || kd_conv2d_bn_sums_rows(d, ep) > 0, KD_ERR_UNSUPPORTED,
                "kd_conv2d_fwd: bn_sums is not produced by the kernel this problem selects (ask kd_conv2d_bn_sums_rows first)");
+    if (ep->bn_sums) KD_NOTE_KERNEL("bn_sums_epilogue");   // (kernel-selection log: counted next to the kernel that carries it)
     hipStream_t s = (hipStream_t)stream;
     auto launch = [&](auto cf, auto tag) {
         using CF = decltype(cf);

@@ -135,8 +135,11 @@ def test_bf16_mode_b_step_on_the_shipped_kernels_vs_network_oracle():
     with _lib.kernel_log() as log:
         out_st, out_tc, hint, kd, loss = _step(model, "kd+hint")
     for k in ("conv_wgrad_row_kernel", "conv_wgrad_wide_kernel", "conv_row_persist_kernel<pp>", "conv_igemm_persist_kernel<pp>",
-              "dw_mfma_wgrad_kernel", "dw_mfma_fwd_kernel<3,false>"):
+              "dw_mfma_wgrad_kernel", "dw_mfma_fwd_kernel<3,false>", "bn_sums_epilogue"):
         assert log.counts.get(k, 0) > 0, (k, log.counts)
+    # the eval-BN parameter sums ride in the input-gradient epilogues: only the sites those kernels do not cover still read the
+    # gradient back (depthwise sites, three-operand epilogues, narrow tiles)
+    print("bf16 mode B: fused BN-sums launches", log.counts["bn_sums_epilogue"])
     tsd = seeded_teacher_sd()
     ssd = net_ref.make_student_sd(tsd, P92, seeded_cheap_weights(tsd, P92), trainable="all")
     _threads()
