@@ -475,6 +475,95 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float *__restrict
         part[(size_t)blockIdx.x * 64 * 27 + e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
+// The same reduction on the matrix cores (bf16 dy): the VALU kernel above streams 2.1 GB of dy at 8 images in 2.4 ms -- 27 FMAs
+// and as many broadcast LDS reads per pixel and thread -- where 58 GFLOP are nothing for the fp32 MFMA.  Per work item (256
+// pixels of one image row): dy goes to LDS as [pixel][64 ch] bf16 (coalesced 16-B loads), the 3 x 3 x 3 input patch as fp32
+// rows like above; wave w owns output channels 16 w .. 16 w + 15 and two 16 x 16 accumulators over the 27 (+5 zero) columns
+// (ci, ky, kx).  One v_mfma_f32_16x16x4_f32 step contracts FOUR pixels: A[i][k] = dy[p0 + k][16 w + i] (a 2-B LDS read,
+// widened), B[k][j] = x[ci_j][h - 1 + ky_j][w0 + p0 + k - 1 + kx_j] (a 4-B LDS read at a per-lane offset): x stays fp32,
+// products and sums are fp32 as in the kernel above.  Same partial layout and finish kernel.
+typedef float stem_f32x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float *__restrict__ x, const bf16_t *__restrict__ dy, int lddy, int N,
+                                                              int H, int W, float *__restrict__ part)
+{
+    constexpr int PROW = SW_SEG + 4;
+    __shared__ __attribute__((aligned(16))) float patch[9][PROW];          // [(ci, ky)][col], zero outside the image
+    __shared__ __attribute__((aligned(16))) bf16_t dys[SW_SEG][64];        // [pixel][channel], zero behind the row's end
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i = lane & 15, k = lane >> 4;
+    // this lane's two B columns: col = (ci * 3 + ky) * 3 + kx; columns 27..31 read a zeroed LDS word
+    int boff[2];
+    bool bok[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int col = t * 16 + i;
+        bok[t] = col < 27;
+        const int rk = bok[t] ? col / 3 : 0, kx = bok[t] ? col - rk * 3 : 0;
+        boff[t] = rk * PROW + k + kx;
+    }
+    const int nseg = (W + SW_SEG - 1) / SW_SEG;
+    const long long nitems = (long long)N * H * nseg;
+    stem_f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // an item's loads are all issued together and land in registers under the PREVIOUS item's MFMAs (one memory latency per
+    // item exposed otherwise -- nine with a load in front of each LDS store: 1.9 ms)
+    constexpr int NPF = (9 * PROW + 255) / 256;
+    float pv[NPF];
+    uint4 dv[8];
+    auto fetch = [&](long long it) __attribute__((always_inline)) {
+        const int seg = (int)(it % nseg);
+        const long long r = it / nseg;
+        const int h = (int)(r % H), n = (int)(r / H);
+        const int w0 = seg * SW_SEG, cols = min(SW_SEG, W - w0);
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int e = tid + q * 256;
+            const int rk = e / PROW, col = e - rk * PROW;
+            const int ci = rk / 3, ky = rk - ci * 3;
+            const int hh = h - 1 + ky, ww = w0 - 1 + col;
+            pv[q] = (e < 9 * PROW && hh >= 0 && hh < H && ww >= 0 && ww < W && col < cols + 2) ? x[(((size_t)n * 3 + ci) * H + hh) * W + ww] : 0.f;
+        }
+        // dy: 256 pixels x 128 B, eight 16-B pieces per thread (pixel = piece / 8)
+        const bf16_t *src = dy + (((size_t)n * H + h) * W + w0) * lddy;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int pc = tid + q * 256, px = pc >> 3, ch = (pc & 7) * 8;
+            dv[q] = make_uint4(0u, 0u, 0u, 0u);
+            if (px < cols) dv[q] = *(const uint4 *)(src + (size_t)px * lddy + ch);
+        }
+    };
+    if ((long long)blockIdx.x < nitems) fetch(blockIdx.x);
+    for (long long it = blockIdx.x; it < nitems; it += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NPF; ++q)
+            if (tid + q * 256 < 9 * PROW) (&patch[0][0])[tid + q * 256] = pv[q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int pc = tid + q * 256;
+            *(uint4 *)&dys[pc >> 3][(pc & 7) * 8] = dv[q];
+        }
+        __syncthreads();
+        if (it + gridDim.x < nitems) fetch(it + gridDim.x);
+        const float *pf = &patch[0][0];
+        const bf16_t *da = &dys[k][wv * 16 + i];
+#pragma unroll 8
+        for (int p0 = 0; p0 < SW_SEG; p0 += 4) {
+            const float a = Elem<bf16_t>::ld(da + (size_t)p0 * 64);
+            const float b0 = pf[boff[0] + p0], b1 = bok[1] ? pf[boff[1] + p0] : 0.f;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc1, 0, 0, 0);
+        }
+    }
+    // D[row = channel][col]: lane (j = lane & 15, q = lane >> 4) holds rows 4 q .. 4 q + 3 of column j
+    float *out = part + (size_t)blockIdx.x * 64 * 27;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int co = wv * 16 + k * 4 + rr;
+        out[co * 27 + i] = acc0[rr];
+        if (16 + i < 27) out[co * 27 + 16 + i] = acc1[rr];
+    }
+}
+
 __global__ void stem_wgrad_finish_kernel(const float *__restrict__ part, int nblocks, float *__restrict__ dw, int accumulate)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -757,7 +846,7 @@ extern "C" int kd_broadcast_add(int32_t dtype, const float *v, void *y, int32_t 
 static int stem_blocks(int N, int H, int W)
 {
     const long long items = (long long)N * H * ((W + SW_SEG - 1) / SW_SEG);
-    return (int)(items < 1024 ? items : 1024);
+    return (int)(items < 768 ? items : 768);   // three 256-thread blocks per CU (41 KiB of LDS each): one round
 }
 
 extern "C" size_t kd_stem_wgrad_workspace(int32_t N, int32_t H, int32_t W)
@@ -773,7 +862,10 @@ extern "C" int kd_stem_wgrad(int32_t dtype, const float *x_nchw, const void *dy,
     KD_REQUIRE(workspace_bytes >= kd_stem_wgrad_workspace(N, H, W), KD_ERR_WORKSPACE, "kd_stem_wgrad: workspace too small");
     const int nb = stem_blocks(N, H, W);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == KD_BF16) hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, x_nchw, (const bf16_t *)dy, ld_dy, N, H, W, (float *)workspace);
+    if (dtype == KD_BF16 && ld_dy % 8 == 0 && kd_aligned16(dy)) {
+        KD_NOTE_KERNEL("stem_wgrad_mfma_kernel");
+        hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(nb), dim3(256), 0, s, x_nchw, (const bf16_t *)dy, ld_dy, N, H, W, (float *)workspace);
+    } else if (dtype == KD_BF16) hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, x_nchw, (const bf16_t *)dy, ld_dy, N, H, W, (float *)workspace);
     else hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(nb), dim3(256), 0, s, x_nchw, (const float *)dy, ld_dy, N, H, W, (float *)workspace);
     KD_CHECK_LAUNCH("kd_stem_wgrad");
     hipLaunchKernelGGL(stem_wgrad_finish_kernel, dim3((64 * 27 + 255) / 256), dim3(256), 0, s, (const float *)workspace, nb, dw, accumulate);
