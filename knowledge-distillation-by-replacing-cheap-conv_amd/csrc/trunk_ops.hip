@@ -450,9 +450,10 @@ __global__ __launch_bounds__(256) void upsample_kernel(const TI *__restrict__ x,
     }
 }
 
-// Dense output rows whose channel count is not a multiple of 8 (the 19-class logits, fp32: 1.27 GB per 8 images written with 4-B
-// stores at 2.4 TB/s by the kernel above): a thread owns FOUR consecutive floats of the flattened (wo, c) row -- up to two pixels --
-// and stores them as one 16-B vector; same expression tree per element, same row reuse over UP_RO output rows.
+// Dense output rows whose channel count is not a multiple of 8 (the 19-class logits, fp32: 1.27 GB per 8 images): a thread owns
+// FOUR consecutive floats of the flattened (wo, c) row -- up to two pixels -- and stores them as one 16-B vector; same expression
+// tree per element, same row reuse over UP_RO output rows.  (Measured: 520 us against 532 us for the 4-B-store kernel above at
+// 8 images -- the store width is not what holds this kernel at 2.4 TB/s; kept for the quarter of the store instructions.)
 template <typename TI>
 __global__ __launch_bounds__(256) void upsample_flat4_kernel(const TI *__restrict__ x, int ldx, float *__restrict__ y, int N, int H, int W,
                                                              int C, int Ho, int Wo, float sh, float sw, float oh, float ow)
