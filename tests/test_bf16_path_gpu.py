@@ -154,6 +154,36 @@ def test_bf16_mode_b_step_on_the_shipped_kernels_vs_network_oracle():
     assert not bad, bad
 
 
+def test_bf16_mode_b_bn_gradients_fused_sums_equal_the_read_back_path(monkeypatch):
+    """The eval-BN weight / bias gradients with their sums taken in the input-gradient epilogues (kd_conv_epilogue.bn_sums)
+    against the same step with kd_channel_sums reading every gradient tensor back (KDCC_FUSE_BN_SUMS=0), at a size where the
+    persistent kernels carry the sums: every other gradient bit-identical (the stored tensors do not change), the BN ones equal
+    to the rounding of the stored bf16 gradient."""
+    from kdcc_amd import _lib, engine
+    x = seeded_input("bf16.modeb.x", (1, 3, 256, 2048)).cuda()
+    grads = {}
+    for fused in (True, False):
+        monkeypatch.setattr(engine, "_FUSE_BN_SUMS", fused)
+        model = _build(P92, BF)
+        for p in model.student.parameters():
+            p.requires_grad = True
+        model._x = x
+        with _lib.kernel_log() as log:
+            _step(model, "kd+hint")
+        assert (log.counts.get("bn_sums_epilogue", 0) > 0) == fused, log.counts
+        grads[fused] = {n: p.grad.detach().clone() for n, p in model.student.named_parameters()}
+    worst = 0.0
+    for n, g in grads[True].items():
+        r = grads[False][n]
+        if g.dim() == 1:      # BN weights / biases (and the classifier bias, which does not depend on the sums)
+            err = float((g.double() - r.double()).norm() / r.double().norm().clamp_min(1e-30))
+            worst = max(worst, err)
+            assert err < 5e-3, (n, err)
+        else:
+            assert torch.equal(g, r), n
+    print("fused vs read-back BN parameter gradients: worst relative L2", worst)
+
+
 def test_bf16_gscnn_step_vs_network_oracle():
     """Gated-SCNN student (BASELINE config 5; cheap convs in mod4 / mod7 / ASPP, hint MSE) in bf16 at 1 x 256 x 2048: the
     shape stream's small-channel kernels (conv3x3_small, pointwise_small, matrix-core gated conv) and the 512x128 kernel at
