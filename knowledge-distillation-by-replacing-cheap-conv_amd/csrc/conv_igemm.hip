@@ -773,7 +773,7 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
     // eval-BN parameter sums of the masked gradient (backward: v = gradient w.r.t. the BN output where the activation is on):
     // S1[c] = sum_m v * mask_scale, S2[c] = sum_m v * mask_scale * act -- what kd_channel_sums would read back from memory
     float bs1[8], bs2[8];
-    constexpr bool sums = SUMS;   // (host: only with a mask, and never without the pointer)
+    // (SUMS -- host: only with a mask, and never without the pointer)
 #pragma unroll
     for (int q = 0; q < 8; ++q) { bs1[q] = 0.f; bs2[q] = 0.f; }
     // pack first (frees half the accumulator registers), then the loads: no spills

@@ -511,22 +511,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row_kernel(const WgradParam
         for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     const int q = lane >> 4, li = lane & 15;
-    auto frag = [&](const char *img, int mrow, int t) {
-        const int m0 = mrow + 8 * q + (li >> 2);
-        const int m1 = m0 + 4;
-        const v4i16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) v4i16_t *)(img + m0 * 256 + ((t ^ tr_f(m0)) << 5) + (li & 3) * 8));
-        const v4i16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) v4i16_t *)(img + m1 * 256 + ((t ^ tr_f(m1)) << 5) + (li & 3) * 8));
-        return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    };
-
     // this wave's six 16-column tiles of the 3 x 128 (kx, ci) columns
     int jkx[6], jct[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) { const int jt = wn * 6 + j; jkx[j] = jt >> 3; jct[j] = jt & 7; }
 
-    constexpr int G = 5;   // pieces per wave per stage
     // Software pipeline over HALF stages (k = 32 pixels each): the fragments of the next half are in flight while the 24 MFMAs
     // of this one run.  With the reads of a whole stage in front of its MFMAs every wave of the workgroup read at the same
     // time and multiplied at the same time -- LDS port (1600 cycles per stage) and matrix pipe (1536) took turns: 3600 cycles
