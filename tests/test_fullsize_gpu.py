@@ -130,3 +130,54 @@ def test_student_equals_teacher_when_nothing_is_replaced_fullsize():
     assert losses.KLDivergenceLoss(1)(out_st, out_tc).item() == 0.0
     # not degenerate: logits vary across pixels and classes
     assert float(out_st.std()) > 1e-3
+
+
+def test_stem_wgrad_mfma_equals_the_valu_kernel_fullsize(K):
+    """mod1.conv1's weight gradient at 2 x 1024 x 2048: the fp32-MFMA kernel (bf16 dy) against the VALU kernel fed the same values
+    as fp32 -- same products, different summation order -- and the adjoint identity <conv(x; w), dy> == <w, dW> with the stem
+    forward (wider_resnet.py:307-309)."""
+    from kdcc_amd import _lib
+    g0 = torch.Generator(device="cuda").manual_seed(5)
+    N, H, W = 2, 1024, 2048
+    x = torch.randn((N, 3, H, W), device="cuda", generator=g0)
+    dy = torch.randn((N, H, W, 64), device="cuda", generator=g0).to(BF)
+    dw, dw32 = torch.empty((64, 3, 3, 3), device="cuda"), torch.empty((64, 3, 3, 3), device="cuda")
+    K.stem_wgrad(x, dy, dw)
+    assert _lib.last_kernel() == "stem_wgrad_mfma_kernel"
+    K.stem_wgrad(x, dy.float(), dw32)
+    err = float((dw.double() - dw32.double()).norm() / dw32.double().norm())
+    assert err < 1e-5, err
+    dw2 = torch.empty_like(dw)
+    K.stem_wgrad(x, dy, dw2)
+    assert torch.equal(dw, dw2)                                   # run to run
+    # adjoint with the stem forward: the forward rounds x and w to bf16 (MFMA operands), the gradient keeps x in fp32
+    w = torch.randn((64, 3, 3, 3), device="cuda", generator=g0) * 0.2
+    y = K.stem_conv(x, w, BF)
+    dwy = torch.empty_like(dw)
+    K.stem_wgrad(x, y, dwy)
+    assert rel(dot(y, y), dot(w, dwy)) < 5e-3
+
+
+def test_bn_sums_in_the_dgrad_epilogue_fullsize(K):
+    """The eval-BN parameter sums of a mod5-shaped input gradient (3x3 dil 2, 1024 -> 512 at 4 x 128 x 256, mask + shortcut
+    gradient: the bench's [mq] launches) taken in the epilogue against kd_channel_sums of the stored tensor, and
+    S1 == column sums of the stored gradient minus the shortcut's."""
+    from kdcc_amd._lib import KD_PACK_DGRAD
+    g0 = torch.Generator(device="cuda").manual_seed(6)
+    N, H, W, Cin, Cout, d = 4, 128, 256, 1024, 512, 2
+    g = torch.randn((N, H, W, Cin), device="cuda", generator=g0).to(BF)
+    w = torch.randn((Cin, Cout, 3, 3), device="cuda", generator=g0) * 0.02       # the forward conv's weight (Cout_fwd = Cin here)
+    wd = K.pack_conv_weight(w, BF, KD_PACK_DGRAD)
+    act = torch.relu(torch.randn((N, H, W, Cout), device="cuda", generator=g0)).to(BF)
+    sub = torch.randn((N, H, W, Cout), device="cuda", generator=g0).to(BF)
+    scale = torch.rand(Cout, device="cuda", generator=g0) + 0.5
+    out = torch.empty((N, H, W, Cout), device="cuda", dtype=BF)
+    got = []
+    K.conv2d(g, wd, 1, d, d, mask=act, mask_scale=scale, res_post=sub, out_raw=out, bn_sums=got)
+    assert len(got) == 1, "the persistent row kernel carries the sums at this shape"
+    s1, s2 = got[0]
+    c1, c2 = K.channel_sums(out, sub=sub, a=act)
+    for a, b in ((s1, c1), (s2, c2)):
+        assert float((a.double() - b.double()).abs().max()) / float(b.double().abs().max()) < 5e-3
+    ref1 = (out.double() - sub.double()).sum((0, 1, 2))
+    assert float((s1.double() - ref1).abs().max()) / float(ref1.abs().max()) < 5e-3
