@@ -320,6 +320,7 @@ __global__ void slab_reduce_taps_cc_kernel(const float *__restrict__ part, float
 // same bytes in flight feed twice the matrix work -- the trade the forward kernel's 256 x 256 configs make.  Stage = 64 pixels
 // x (256 + 256) channels = four 16-KiB images in the [pixel][128 channels] layout of pw_wgrad_tr_kernel (same source-side
 // swizzle, same transposing fragment reads); double-buffered: 128 KiB.
+template <bool PW>   // PW: 1x1 / stride 1 / no padding (GEMM row m IS input pixel m): staging addresses are per-lane constants
 __global__ __launch_bounds__(512, 2) void conv_wgrad_wide_kernel(const WgradParams p)
 {
     __shared__ __attribute__((aligned(16))) char lds[2 * 65536];
@@ -340,8 +341,41 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide_kernel(const WgradPara
     // staging: a piece = 4 pixel rows x 256 B of one image; image q of a stage: 0/1 = dy channels 0-127 / 128-255, 2/3 = a.
     // 16 pieces per image, 64 per stage, 8 per wave: wave w stages pieces w*2, w*2+1 of every image (rows (w*2+j)*4 ..)
     const int prow = lane >> 4, slot = lane & 15;
+    // pointwise form: element offsets of this lane's eight pieces relative to the stage's first pixel, and which of them exist
+    // (the general form below spends ~200 scalar + vector instructions per stage on pixel maps, bounds and 64-bit addresses --
+    // as many issue cycles as the stage's 64 MFMAs)
+    int poy[4], pox[4];
+    uint32_t pvy = 0, pvx = 0;
+    if (PW) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = (wv * 2 + j) * 4 + prow;
+            const int c = (slot ^ (tr_f(r) << 1)) * 8;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int cc = h * 128 + c;
+                poy[j * 2 + h] = r * p.ldy + co0 + cc;
+                pox[j * 2 + h] = r * p.lda + ci0 + cc;
+                pvy |= co0 + cc < p.Cout ? (1u << (j * 2 + h)) : 0u;
+                pvx |= ci0 + cc < p.Cin ? (1u << (j * 2 + h)) : 0u;
+            }
+        }
+    }
     auto stage = [&](int st, int buf) {
         char *base = lds + buf * 65536;
+        if (PW && m_begin + (st + 1) * 64 <= m_end) {   // whole stage inside the split (always, when M % 64 == 0)
+            const bf16_t *yb = dy + (size_t)(m_begin + st * 64) * p.ldy, *xb = a + (size_t)(m_begin + st * 64) * p.lda;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int q = j * 2 + h, pc = wv * 2 + j;
+                    glds16(((pvy >> q) & 1u) ? yb + poy[q] : zero, base + h * 16384 + pc * 1024);
+                    glds16(((pvx >> q) & 1u) ? xb + pox[q] : zero, base + (2 + h) * 16384 + pc * 1024);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int pc = wv * 2 + j;
@@ -862,7 +896,7 @@ extern "C" int kd_pw_wgrad(int32_t dtype, int32_t M, int32_t Cin, int32_t Cout, 
     p.mg_howo = p.sh_howo = p.mg_wo = p.sh_wo = 0;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)tiles, (unsigned)splits);
-    if (wide) { KD_NOTE_KERNEL("conv_wgrad_wide_kernel"); hipLaunchKernelGGL(conv_wgrad_wide_kernel, grid, dim3(512), 0, s, p); }
+    if (wide) { KD_NOTE_KERNEL("conv_wgrad_wide_kernel"); hipLaunchKernelGGL(conv_wgrad_wide_kernel<true>, grid, dim3(512), 0, s, p); }
     else if (dtype == KD_BF16 && Cin % 8 == 0 && Cout % 8 == 0) launch_tr(grid, s, p);
     else if (dtype == KD_BF16) { KD_NOTE_KERNEL("pw_wgrad_kernel<bf16>"); hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, p); }
     else { KD_NOTE_KERNEL("pw_wgrad_kernel<f32>"); hipLaunchKernelGGL(pw_wgrad_kernel<float>, grid, dim3(256), 0, s, p); }
@@ -952,6 +986,8 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
     p.tiles_ci = tiles_ci; p.rows_per_split = rps; p.splits = splits; p.tiles = tiles;
     { static int wd = -1; if (wd < 0) wd = KD_TUNING_ENV_INT("KDCC_WGRAD_DBG"); p.dbg = wd; }   // phase clocks: tuning build only
     p.geom = !(taps == 1 && d->stride == 1 && d->pad == 0);
+    static int wide_general = -1;
+    if (wide_general < 0) { const char *e = getenv("KDCC_WGRAD_WIDE_GENERAL"); wide_general = e && e[0] == '1'; }   // A/B: the general staging on 1x1 too
     p.H = d->H; p.W = d->W; p.Ho = d->Ho; p.Wo = d->Wo; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     fastdiv_magic((uint32_t)(d->Ho * d->Wo), p.mg_howo, p.sh_howo);
     fastdiv_magic((uint32_t)d->Wo, p.mg_wo, p.sh_wo);
@@ -974,7 +1010,11 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
         else
 #endif
         hipLaunchKernelGGL((conv_wgrad_row_kernel<false, 1>), dim3((unsigned)(tiles * splits * 3)), dim3(512), 0, s, p);
-    } else if (wide) { KD_NOTE_KERNEL("conv_wgrad_wide_kernel"); hipLaunchKernelGGL(conv_wgrad_wide_kernel, grid, dim3(512), 0, s, p); }
+    } else if (wide) {
+        KD_NOTE_KERNEL("conv_wgrad_wide_kernel");
+        if (!p.geom && !wide_general) hipLaunchKernelGGL(conv_wgrad_wide_kernel<true>, grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL(conv_wgrad_wide_kernel<false>, grid, dim3(512), 0, s, p);
+    }
     else if (d->dtype == KD_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0) launch_tr(grid, s, p);
     else if (d->dtype == KD_BF16) { KD_NOTE_KERNEL("pw_wgrad_kernel<bf16>"); hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, p); }
     else { KD_NOTE_KERNEL("pw_wgrad_kernel<f32>"); hipLaunchKernelGGL(pw_wgrad_kernel<float>, grid, dim3(256), 0, s, p); }
