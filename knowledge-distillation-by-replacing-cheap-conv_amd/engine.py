@@ -1384,7 +1384,17 @@ class StudentEngine:
         kpad = ((ncls + 63) // 64) * 64
         g_d3 = self._new(N, h2, w2, kpad, zero=True)               # classes padded to the GEMM K granule
         ops.upsample_bilinear_ac_bwd(g_logits, (h2, w2), out=g_d3[..., :ncls], align_corners=not self.is_gscnn)   # gscnn.py:323
-        self._conv_wgrad(f[6], dec["d2"], g_d3[..., :ncls], grads)
+        if f[6].weight.requires_grad and self.dtype == torch.bfloat16 and kpad != ncls:
+            # the classifier's weight gradient over the zero-padded class channels: 64 outputs take the LDS-DMA + transposing-read
+            # kernel (19 do not: Cout % 8), the 45 extra rows are zeros
+            tmp = torch.empty((kpad, f[6].weight.shape[1], 1, 1), dtype=torch.float32, device=g_d3.device)
+            ops.conv2d_wgrad(dec["d2"], g_d3, tmp, 1, 0, 1)
+            gw = self._grad_like(f[6].weight)
+            gw.copy_(tmp[:ncls])
+            grads[f[6].weight] = gw
+            self._grad_done(f[6].weight)
+        else:
+            self._conv_wgrad(f[6], dec["d2"], g_d3[..., :ncls], grads)
         if not rg_d2:
             return None, None
         sc, _ = self._bn_fold(f[4])
