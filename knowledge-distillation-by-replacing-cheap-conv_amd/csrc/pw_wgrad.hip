@@ -1000,7 +1000,7 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
         KD_NOTE_KERNEL("conv_wgrad_row_kernel");
 #ifdef KDCC_TUNING
         static int il = -1;
-        if (il < 0) il = KD_TUNING_ENV_INT("KDCC_WGRAD_IL");   // A/B: 0 = reads in front of the MFMAs, 1 = interleaved, 2 = ping-pong
+        if (il < 0) { const char *e = getenv("KDCC_WGRAD_IL"); il = e ? atoi(e) : 1; }   // A/B: 0 = reads in front of the MFMAs, 1 = interleaved (shipped), 2 = ping-pong
         const dim3 grid((unsigned)(tiles * splits * 3));
         if (p.dbg && il == 2) hipLaunchKernelGGL((conv_wgrad_row_kernel<true, 2>), grid, dim3(512), 0, s, p);
         else if (p.dbg && il == 1) hipLaunchKernelGGL((conv_wgrad_row_kernel<true, 1>), grid, dim3(512), 0, s, p);
