@@ -1535,12 +1535,10 @@ __global__ __launch_bounds__(512, 2) void conv_row_pp128_kernel(const ConvParams
         __builtin_amdgcn_sched_barrier(0);
     };
     auto mfmas = [&]() __attribute__((always_inline)) {
-        if (!(p.tune & 8192)) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) Mma<T>::run(b0[j], a0[i], acc[i][j]);   // transposed tile: see ig_epilogue
-        if (!(p.tune & 8192)) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
 
