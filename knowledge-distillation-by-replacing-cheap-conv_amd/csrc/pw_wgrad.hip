@@ -612,12 +612,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row_kernel(const WgradParam
                 }
             }
             if (!(ABL && (p.dbg & 2))) {
-                // the wave that multiplies issues ahead of its SIMD partner (which may be staging or reading): -3 % on every layer
-                // (KDCC_WGRAD_DBG bit 32 in the tuning build leaves the priority alone)
-                if (!(ABL && (p.dbg & 32))) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
                 for (int j = 0; j < 6; ++j) Mma<bf16_t>::run(faM[i], fbM[j], acc[i][j]);
-                if (!(ABL && (p.dbg & 32))) __builtin_amdgcn_s_setprio(0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
