@@ -183,8 +183,10 @@ def _latest_profile(suffix):
 def conv_traffic(plan, batch, height, width, dtype, mode, arch):
     """HBM bytes per conv launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE in separate passes,
     same command); None when the profiled configuration is not the one being run."""
-    path = _latest_profile("traffic_pmc.json")
-    if not (plan == "P92" and (height, width) == (1024, 2048) and dtype == "bf16" and mode == "A" and arch == "deeplab" and path):
+    want = {("A", "deeplab", "P92"): "traffic_pmc.json", ("B", "deeplab", "P92"): "traffic_modeB_pmc.json",
+            ("A", "gscnn", "P86"): "traffic_gscnn_pmc.json"}.get((mode, arch, plan))
+    path = _latest_profile(want) if want else None
+    if not ((height, width) == (1024, 2048) and dtype == "bf16" and path):
         return None, None
     try:
         with open(path) as f:
@@ -281,7 +283,7 @@ def run_config(a, device, rank, world, plan_name=None, mode=None, arch=None, hin
         kd_step(model, crit, opt, data, target, mode)
     sync()
     prof = []
-    ops.PROFILER = prof
+    ops.PROFILER = None if a.no_profiler else prof      # two HIP events per kernel launch inside the timed region (--no-profiler: none)
     t0 = time.perf_counter()
     for _ in range(steps):
         loss, sup, kd, tl = kd_step(model, crit, opt, data, target, mode)
@@ -290,6 +292,19 @@ def run_config(a, device, rank, world, plan_name=None, mode=None, arch=None, hin
     sync()
     dt = time.perf_counter() - t0
     ops.PROFILER = None
+    # what the per-launch events cost: the same step, un-instrumented, right behind the timed region (same device, same clocks)
+    ab_steps = 0 if (a.no_profiler or a.no_profiler_ab or not batch_sweep) else min(8, steps)
+    dt_plain = None
+    if ab_steps:
+        t1 = time.perf_counter()
+        for _ in range(ab_steps):
+            kd_step(model, crit, opt, data, target, mode)
+        sync()
+        dt_plain = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([dt_plain], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dt_plain = float(tt.item())
     if a.layer_table and rank == 0 and batch_sweep:
         # per conv shape: launches per step, mean duration, TFLOP/s (live HIP events, same records as the roofline)
         agg = {}
@@ -359,10 +374,13 @@ def run_config(a, device, rank, world, plan_name=None, mode=None, arch=None, hin
                        else "images/sec KD train step, DeepLabV3+(WRN38) student 1024x2048"),
             "value": world * a.batch * steps / dt, "unit": "images/sec", "n_gpus": world, "steps": steps,
             "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "profiler": {"events_in_timed_region": not a.no_profiler,
+                         "ms_per_step_without_events": (dt_plain / ab_steps * 1e3 if ab_steps else None), "ab_steps": ab_steps},
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"KD train step (frozen teacher fwd + student fwd + CE/KD/hint criteria, hint = {crit_name}, + "
                                    f"{'hint-loss bwd into the cheap-conv blocks' if mode == 'A' else 'kd+hint bwd into every student parameter'} + "
-                                   f"RAdam), {arch_name} student plan {plan_name} ({len(plan)} cheap-conv blocks, 9x9 d5), "
+                                   f"RAdam), frozen teacher through {'the HIP engine (teacher_backend hip), stream order' if a.teacher == 'hip' else 'PyTorch-ROCm on a side stream (teacher_backend torch)'}, "
+                                   f"{arch_name} student plan {plan_name} ({len(plan)} cheap-conv blocks, 9x9 d5), "
                                    f"{a.height}x{a.width}, {a.batch} image/GPU, random-init weights",
                        "plan": plan_name, "mode": mode, "arch": arch, "hint_loss": hint_loss, "per_gpu_batch": a.batch,
                        "global_batch": world * a.batch, "parallelism": f"dp{world}",
@@ -388,6 +406,54 @@ def run_config(a, device, rank, world, plan_name=None, mode=None, arch=None, hin
             "losses": {("hint" if mode == "A" else "kd+hint"): float(loss.detach()), "supervised": float(sup), "kd": float(kd), "teacher": float(tl)},
         }
     return res, model, cpu_sd, plan
+
+
+def _r(x, nd=4):
+    """floats to nd significant digits (the compact line is read by a driver that keeps only a few KB of stdout)"""
+    if isinstance(x, float):
+        return float(f"{x:.{nd}g}")
+    return x
+
+
+def compact_record(res, full_path=None):
+    """The ONE stdout line: contract keys + roofline + cpu_baseline + one number per side measurement, < 4 KB.  Everything
+    else (per-class detail, layer notes, sub-record rooflines) is in the full record file / on stderr."""
+    cfg, rf = res["config"], res["roofline"]
+    out = {k: _r(res[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                   "scaling", "vs_baseline", "dtype", "data")}
+    out["config"] = {"workload": (f"KD train step (teacher fwd + student fwd + CE/KD/hint criteria + "
+                                  f"{'hint bwd' if cfg['mode'] == 'A' else 'kd+hint bwd, all params'} + RAdam), "
+                                  f"{'Gated-SCNN' if cfg['arch'] == 'gscnn' else 'DeepLabV3+'}(WRN-38) student {cfg['plan']}, "
+                                  f"{res.get('_hw', '1024x2048')}, {cfg['per_gpu_batch']} img/GPU, random init, teacher through the "
+                                  f"{'HIP engine' if cfg['teacher_backend'] == 'hip' else 'PyTorch-ROCm side stream'}"),
+                     **{k: cfg[k] for k in ("plan", "mode", "arch", "hint_loss", "per_gpu_batch", "global_batch", "parallelism",
+                                            "teacher_backend", "share_frozen_prefix", "replicas_identical_after_run")}}
+    out["roofline"] = {"bound": rf["bound"], "kernel": "kd_conv2d_fwd (dense conv fwd + dgrad: conv_row_persist / conv_igemm_persist / "
+                                                       "conv_row_pp128 / one-tile kernels)",
+                       **{k: _r(rf[k]) for k in ("achieved", "peak", "unit", "frac", "traffic", "launches_per_step",
+                                                 "ms_per_step_in_kernel", "algorithmic_tflop_per_step")},
+                       "classes": {n: [_r(c["ms_per_step"], 3), _r(c["frac"], 3)] for n, c in rf["classes"].items()},
+                       "classes_fmt": "[ms_per_step, frac of its roof (mfma 2500 TFLOP/s | hbm 8000 GB/s)]"}
+    if res.get("profiler"):
+        out["profiler"] = {k: _r(v) for k, v in res["profiler"].items()}
+    cb = res.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {k: _r(cb[k]) for k in ("value", "unit", "cores", "host_cpu_count", "kind", "step_1024x2048_s",
+                                                      "step_512x1024_s") if k in cb}
+        out["cpu_baseline"]["sample"] = ("one measured 1024x2048 KD step of oracle/net_ref.py (fp32 torch CPU ops), 1 image"
+                                         if "step_1024x2048_s" in cb else cb.get("sample", "")[:160])
+    if res.get("sub_records"):
+        out["sub_records"] = {n: {"value": _r(r["value"]), "ms_per_step": _r(r["ms_per_step"]), "frac": _r(r["roofline"]["frac"], 3),
+                                  "traffic": _r(r["roofline"].get("traffic")),
+                                  "wgrad_frac": _r(r["dense_wgrad"]["frac"], 3) if r.get("dense_wgrad") else None}
+                              for n, r in res["sub_records"].items()}
+    sw = cfg.get("per_gpu_batch_sweep") or {}
+    if sw:
+        out["batch_sweep"] = {n: _r(v["images_per_sec"]) for n, v in sw.items()}
+    out["losses"] = {k: _r(v, 6) for k, v in res.get("losses", {}).items()}
+    if full_path:
+        out["full_record"] = full_path
+    return out
 
 
 # sub-records of the default run: the other BASELINE configurations, short (2 warm-up + 8 timed steps), same JSON line
@@ -425,6 +491,12 @@ def main():
                     help="skip the short P79 / mode B / GSCNN P86 / WeightedHintMSE side measurements of the default run")
     ap.add_argument("--layer-table", default=None, help="write a per-conv-shape timing table (tsv) to this path")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the 1 and 2 images/GPU side measurements")
+    ap.add_argument("--no-profiler", action="store_true",
+                    help="time the steps without the two HIP events per kernel launch (no roofline in the record); the default run "
+                         "measures the same un-instrumented step right behind the timed region and reports both")
+    ap.add_argument("--no-profiler-ab", action="store_true", help="skip that un-instrumented A/B measurement")
+    ap.add_argument("--full-record", default=None,
+                    help="where the full record goes (default gpurun_out/bench_full.json); stdout carries the compact line only")
     ap.add_argument("--no-overlap", action="store_true", help="with --teacher torch: run the teacher on the main stream")
     ap.add_argument("--ref-logging", action="store_true",
                     help="also do the reference's per-step host syncs (five .item() calls, layerwise_trainer.py:244-250); the "
@@ -470,7 +542,21 @@ def main():
             subs[name] = keep
         res["sub_records"] = subs
     if rank == 0:
-        print(json.dumps(res))
+        res["_hw"] = f"{a.height}x{a.width}"
+        # the full record (per-class rooflines with their notes, sub-record rooflines, the batch sweep) goes to a file and to
+        # stderr; stdout carries ONE compact line (the driver keeps a few KB of it)
+        full = a.full_record or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+        try:
+            os.makedirs(os.path.dirname(full), exist_ok=True)
+            with open(full, "w") as f:
+                json.dump(res, f)
+            shown = os.path.relpath(full, ROOT)
+        except OSError:
+            shown = None
+        print("[bench] full record: " + json.dumps(res), file=sys.stderr, flush=True)
+        line = json.dumps(compact_record(res, shown))
+        assert len(line) < 4096, len(line)
+        print(line, flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 

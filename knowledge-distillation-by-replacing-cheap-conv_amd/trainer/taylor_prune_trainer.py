@@ -9,7 +9,8 @@ consumes for WeightedHintMSELoss (BASELINE config 4's principled weights).
 
 Same constructor and config keys as the reference; cfg/taylor_importance_track.json runs as shipped: `pruning` needs only
 `args` and `pruning_plan` (`unfreeze` is optional here -- the reference indexes it unconditionally and raises KeyError at the
-second plan epoch), validation / best-model monitoring / the plateau scheduler follow LayerwiseTrainer's epoch tail, and with
+second plan epoch; gates added at a later plan epoch join the optimizer as a new param group, so every gate is stepped and
+zeroed on the same schedule), validation / best-model monitoring / the plateau scheduler follow LayerwiseTrainer's epoch tail, and with
 several ranks the gate gradients are averaged like every other gradient (the engine's GradReducer), so every rank accumulates
 the same importances."""
 import os
@@ -56,10 +57,21 @@ class TaylorPruneTrainer(LayerwiseTrainer):
             kwargs = pruning['pruner']
         self.model.replace(gated_layers, **kwargs)
         self.importance_tracker.update_importance_list(self.model.added_gates)
-        if epoch == 1:
+        if epoch == 1 or self.optimizer is None:
             self.create_new_optimizer()
-        elif self.optimizer is not None:
-            self.update_optimizer([x for x in pruning.get('unfreeze', []) if x['epoch'] == epoch])
+        else:
+            # The gates added at this plan epoch join the optimizer as a new group: they are stepped and -- what the importances
+            # depend on -- ZEROED with the earlier ones (the optimizer was built at epoch 1 from the gates that existed then;
+            # a gate outside it would keep accumulating .grad over every batch of every later epoch).  The reference defines
+            # nothing here: it raises KeyError at its second plan epoch (:101).
+            known = {id(p) for g in self.optimizer.param_groups for p in g['params']}
+            fresh = [p for p in self.model.student.parameters() if p.requires_grad and id(p) not in known]
+            if fresh:
+                self.logger.debug('Add {} new gate tensors to the optimizer'.format(len(fresh)))
+                self.optimizer.add_param_group({'params': fresh, **self.config['optimizer']['args']})
+            self.update_optimizer([x for x in pruning.get('unfreeze', []) if x['epoch'] == epoch
+                                   and not any(id(q) in {id(f) for f in fresh}
+                                               for q in self.model.get_block(x['name'], self.model.student).parameters())])
         self._reducer = None              # trainable set changed: rebuild the gradient buckets lazily
         self.logger.info(self.model.dump_trainable_params())
         self.logger.info(self.model.dump_student_teacher_blocks_info())

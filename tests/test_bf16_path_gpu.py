@@ -291,19 +291,25 @@ def test_bench_two_ranks_child_process(tmp_path):
     device buckets (RCCL refuses two ranks per device).  Each rank trains on its own data shard, so bit-identical replicas
     after the run prove that every gradient bucket was exchanged before the optimizer read it."""
     import json
+    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:                   # a free rendezvous port, not a fixed one
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
     env = dict(os.environ, KDCC_DIST_SHARE_GPU="1", KDCC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29611", os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "1", "--steps", "3", "--warmup", "1",
-           "--height", "512", "--width", "1024", "--no-batch-sweep", "--no-sub-records"]
+           "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "1", "--steps", "3", "--warmup", "1",
+           "--height", "512", "--width", "1024", "--no-batch-sweep", "--no-sub-records", "--full-record", str(tmp_path / "full.json")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]      # rank 0 prints ONE JSON line
+    assert len(lines[0]) < 4096                   # ... short enough for the driver's stdout window
     rec = json.loads(lines[0])
+    assert rec["roofline"]["frac"] > 0 and json.load(open(tmp_path / "full.json"))["value"] == pytest.approx(rec["value"], rel=1e-3)
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 2 and rec["scaling"] == "weak"
     assert rec["config"]["replicas_identical_after_run"] is True
     assert rec["value"] > 0 and rec["steps"] == 3

@@ -161,7 +161,16 @@ def test_taylor_trainer_feeds_weighted_hint_loss(tmp_path):
     opt = optim_module.RAdam([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
     tr = TaylorPruneTrainer(model, crit, [], opt, config, batches, None, None, WeightScheduler(config["weight_scheduler"]))
     tr.train()       # two epochs across a save_period boundary: checkpoints, the second plan epoch (a ReLU-site gate, no `unfreeze`)
-    assert tr.optimizer is not None and len(tr.optimizer.param_groups[0]["params"]) == 2     # the epoch-1 gates, like the reference
+    # the epoch-1 gates are the optimizer the reference builds; the gate added at plan epoch 2 joins it as a second group, so it
+    # is stepped and zeroed on the same schedule (outside the optimizer its .grad would accumulate over every later batch)
+    groups = tr.optimizer.param_groups
+    late = model.added_gates["mod4.block3.convs.bn2.1"].weight
+    assert len(groups) == 2 and len(groups[0]["params"]) == 2 and len(groups[1]["params"]) == 1 and groups[1]["params"][0] is late
+    assert late in tr.optimizer.state and int(tr.optimizer.state[late]["step"]) == 1          # stepped at batch 0 of epoch 2
+    assert not torch.equal(late.detach(), torch.ones_like(late))
+    # ... and zeroed there: what is left is batch 1's gradient alone, i.e. importance == (gate * grad)^2 of ONE batch
+    imp = model.get_gate_importance()["mod4.block3.convs.bn2.1"]
+    np.testing.assert_allclose(imp, ((late.detach() * late.grad) ** 2).cpu().numpy().reshape(imp.shape), rtol=1e-5)
     assert (tr.checkpoint_dir / "checkpoint-epoch2.pth").exists()
     assert sorted(model.added_gates) == sorted([n for n, _ in gates] + ["mod4.block3.convs.bn2.1"])
     path = tr.checkpoint_dir / "importance_filter_ep1_batch_idx1.pth"
