@@ -201,7 +201,7 @@ def conv_traffic(plan, batch, height, width, dtype, mode, arch):
 PEAK_HBM_GBS = 8000.0       # HBM3E, MI355X_MICROARCH.md
 
 # device kernel (kernel-selection log) -> roofline class
-CONV_CLASSES = (("conv_row_persist_kernel", "conv3x3_row_persistent_256x256"), ("conv_igemm_persist_kernel", "conv1x1_persistent_256x256"),
+CONV_CLASSES = (("conv_row_lw_kernel", "conv3x3_row_lone_wave_256x256"), ("conv_row_persist_kernel", "conv3x3_row_persistent_256x256"), ("conv_igemm_persist_kernel", "conv1x1_persistent_256x256"),
                 ("conv_row_pp128_kernel", "conv3x3_row_512x128"))
 
 
@@ -388,7 +388,7 @@ def run_config(a, device, rank, world, plan_name=None, mode=None, arch=None, hin
                        "teacher_backend": a.teacher, "per_step_host_syncs": bool(a.ref_logging),
                        "share_frozen_prefix": bool(a.share_prefix), "per_gpu_batch_sweep": sweep},
             "roofline": {"bound": "mfma",
-                         "kernel": "kd_conv2d_fwd: conv_row_persist_kernel + conv_igemm_persist_kernel + conv_row_pp128_kernel + conv_igemm_row_kernel "
+                         "kernel": "kd_conv2d_fwd: conv_row_lw_kernel + conv_igemm_persist_kernel + conv_row_pp128_kernel + conv_igemm_row_kernel "
                                    "+ conv_igemm_kernel (dense conv fwd + dgrad, student" + (" + teacher)" if a.teacher == "hip" else ")"),
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                          "traffic_note": ("mean HBM bytes per conv launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate "
@@ -428,7 +428,7 @@ def compact_record(res, full_path=None):
                                   f"{'HIP engine' if cfg['teacher_backend'] == 'hip' else 'PyTorch-ROCm side stream'}"),
                      **{k: cfg[k] for k in ("plan", "mode", "arch", "hint_loss", "per_gpu_batch", "global_batch", "parallelism",
                                             "teacher_backend", "share_frozen_prefix", "replicas_identical_after_run")}}
-    out["roofline"] = {"bound": rf["bound"], "kernel": "kd_conv2d_fwd (dense conv fwd + dgrad: conv_row_persist / conv_igemm_persist / "
+    out["roofline"] = {"bound": rf["bound"], "kernel": "kd_conv2d_fwd (dense conv fwd + dgrad: conv_row_lw / conv_igemm_persist / "
                                                        "conv_row_pp128 / one-tile kernels)",
                        **{k: _r(rf[k]) for k in ("achieved", "peak", "unit", "frac", "traffic", "launches_per_step",
                                                  "ms_per_step_in_kernel", "algorithmic_tflop_per_step")},

@@ -1,0 +1,237 @@
+// Pieces shared by the dense-conv translation units (conv_igemm.hip, conv_lw.hip): launch parameters, the persistent kernels'
+// epilogue (accumulators -> wave-private LDS patch -> 16-B rows) and the per-XCD tile walk.
+#pragma once
+#include "igemm_core.h"
+
+namespace kdconv {
+struct ConvParams {
+    const void *x;
+    const void *w;
+    int M, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil, ldx;
+    int HoWo, nkc, nk, Ktot, tiles_n, ntiles, tiles_m, tn_group;
+    int vec_ok;  // every epilogue pointer/stride is 16-B friendly
+    int epi_batch;  // A/B hook: 0 = one pass at a time (KDCC_EPI_BATCH=0)
+    int tune;       // A/B hook (KDCC_CONV_TUNE)
+    kd_conv_epilogue ep;
+};
+}  // namespace kdconv
+using kdconv::ConvParams;
+
+namespace {
+
+__device__ __forceinline__ void wait_vm_stores(int nst)
+{
+    // at most nst (= 16 * outputs) younger stores may stay outstanding; everything older -- the prologue DMAs -- has landed
+    if (nst == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+    else if (nst == 32) asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
+    else if (nst == 48) asm volatile("s_waitcnt vmcnt(48) lgkmcnt(0)" ::: "memory");
+    else if (nst == 20) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");   // + the four stores of the eval-BN sums
+    else if (nst == 36) asm volatile("s_waitcnt vmcnt(36) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+// the same without the barrier
+__device__ __forceinline__ void wait_vm_only(int nst)
+{
+    if (nst == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (nst == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if (nst == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+    else if (nst == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if (nst == 36) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// Accumulators -> memory through a wave-private 2-KiB LDS patch OUTSIDE the stage buffers (which the next tile's prologue is
+// already filling): one 16-pixel x 64-channel row tile at a time is written as bf16 (8-B chunk c of row r at c ^ r), then
+// read back as two passes of 8 rows x 128 B, 16 B per lane -- whole 128-B lines per pixel for the operand loads and the
+// stores (8-B accumulator-layout accesses straight to memory, 32-B pieces of 32 lines per instruction, measured 7-40 %
+// slower per layer).  Arithmetic and rounding are those of ig_epilogue's bf16 fast path.
+// Operand loads (residuals, mask): vmcnt retires in issue order, so a load issued after a batch of stores returns only once
+// those stores are acknowledged -- with load -> store -> load per 32 rows the [res_pre, raw, act] epilogue of a 512-channel
+// 3x3 tile took 21 us against 5.6 us without operands (tools/conv_timeline.py).  The host passes at most two operands
+// (slot 0 / slot 1 in the order res_pre, mask, res_post): a single operand is loaded for the whole 128-row sub-tile up
+// front, two operands for 64 rows at a time (one store -> load hand-over instead of three).  Issues exactly 16 stores per
+// output and lane.
+// PT: row tiles (2 KiB each) per LDS round trip -- the patch is PT * 2 KiB per wave where the stage buffers leave room
+__device__ __forceinline__ uint2 ig_pack_acc(const f32x4_t &v) { return make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])); }
+__device__ __forceinline__ uint2 ig_pack_acc(const uint2 &v) { return v; }   // (conv_lw.hip hands over packed accumulators)
+
+template <int MI, int NOPS_, int PT = 1, typename ACC = f32x4_t>   // NOPS_ = operands | 4 when the eval-BN sums are taken (kernels' NOPS parameter)
+__device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *patch, ACC (&acc)[MI][4], int mw, int nw,
+                                                   int lane)
+{
+    typedef bf16_t T;
+    constexpr int NOPS = NOPS_ & 3;
+    constexpr bool SUMS = (NOPS_ & 4) != 0;
+    static_assert(MI == 8 && NOPS_ >= 0 && NOPS_ <= 7 && NOPS_ != 4, "128-row wave sub-tiles; sums need the mask operand");
+    const kd_conv_epilogue &e = p.ep;
+    // every per-lane address below derives from this copy: the compiler cannot hoist them out of the tile loop into
+    // registers that would stay live through the main loop (which runs at the 256-VGPR limit)
+    asm volatile("" : "+v"(lane));
+    const int frow = lane & 15, fq = lane >> 4;
+    const int c0 = nw + (lane & 7) * 8, lrow = lane >> 3, c2 = (lane & 7) * 2;
+    float mscale[8], ascale[8], ashift[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { mscale[q] = 1.f; ascale[q] = 1.f; ashift[q] = 0.f; }
+    // operand slots
+    // (NOPS == 0: compile-time false -- as run-time flags the three blocks below become 24 selects per row)
+    const bool has_p = NOPS == 3 || (NOPS > 0 && e.res_pre != nullptr), has_m = NOPS == 3 || (NOPS > 0 && e.mask != nullptr),
+               has_q = NOPS == 3 || (NOPS > 0 && e.res_post != nullptr);   // (three operands: all of them, compile-time)
+    const float relu_lo = e.act_relu ? 0.f : -INFINITY;   // max(a, -inf) = a: no select per element
+    if (has_m && e.mask_scale) ld8(e.mask_scale + c0, mscale);
+    if (e.act_scale) ld8(e.act_scale + c0, ascale);
+    if (e.act_shift) ld8(e.act_shift + c0, ashift);
+    const T *s0 = (const T *)(has_p ? e.res_pre : has_m ? e.mask : e.res_post);
+    const int ld0 = has_p ? e.ld_res_pre : has_m ? e.ld_mask : e.ld_res_post;
+    const T *s1 = (const T *)(has_p && has_m ? e.mask : e.res_post);
+    const int ld1 = has_p && has_m ? e.ld_mask : e.ld_res_post;
+    constexpr int nops = NOPS;   // == operands present (host)
+    const bool m_in1 = has_p && has_m, q_in1 = has_q && nops == 2;
+    // 64 rows (8 passes) of up to two operands in flight: one operand -> ra = rows 0..63, rb = rows 64..127, both loaded up
+    // front; two operands -> ra / rb = slot 0 / slot 1 of the current 64 rows.  The accumulators are rounded to packed bf16
+    // in place right after the first loads are issued (the patch holds bf16 anyway), which halves their registers.
+    uint4 ra[8], rb[8], rc[NOPS == 3 ? 8 : 1];   // three operands: 64 rows of res_pre / mask / res_post
+    auto rowof = [&](int pass) { return (size_t)(mw + pass * 8 + lrow); };
+    auto load64 = [&](const T *src, int ld, int hb, uint4 (&r)[8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) r[ps] = *(const uint4 *)(src + rowof(hb * 8 + ps) * ld + c0);
+    };
+    // eval-BN parameter sums of the masked gradient (backward: v = gradient w.r.t. the BN output where the activation is on):
+    // S1[c] = sum_m v * mask_scale, S2[c] = sum_m v * mask_scale * act -- what kd_channel_sums would read back from memory
+    float bs1[8], bs2[8];
+    // (SUMS -- host: only with a mask, and never without the pointer)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { bs1[q] = 0.f; bs2[q] = 0.f; }
+    // pack first (frees half the accumulator registers), then the loads: no spills
+    uint2 pk[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pk[i][j] = ig_pack_acc(acc[i][j]);
+    if (nops >= 1) load64(s0, ld0, 0, ra);
+    if (nops >= 2) load64(s1, ld1, 0, rb);
+    if (nops == 1) load64(s0, ld0, 1, rb);
+    if constexpr (NOPS == 3) load64((const T *)e.res_post, e.ld_res_post, 0, rc);
+    // hipcc's wait-count insertion is path-insensitive: a load whose uses sit under run-time conditions counts as pending on
+    // the paths that skip them, and the wait it then needs lands in front of the main loop's first ds_read (which reuses the
+    // registers) -- inside the hand-scheduled loop, draining the LDS-DMA every stage (tools/check_loop_waits.py).  The empty
+    // asm statements below and in the row loop are unconditional uses: the waits are inserted here, where the first row's
+    // arithmetic would have waited anyway.
+    asm volatile("" ::"v"(ascale[0]), "v"(ascale[1]), "v"(ascale[2]), "v"(ascale[3]), "v"(ascale[4]), "v"(ascale[5]), "v"(ascale[6]),
+                 "v"(ascale[7]), "v"(ashift[0]), "v"(ashift[1]), "v"(ashift[2]), "v"(ashift[3]), "v"(ashift[4]), "v"(ashift[5]),
+                 "v"(ashift[6]), "v"(ashift[7]));
+    if (NOPS > 0)
+        asm volatile("" ::"v"(mscale[0]), "v"(mscale[1]), "v"(mscale[2]), "v"(mscale[3]), "v"(mscale[4]), "v"(mscale[5]), "v"(mscale[6]),
+                     "v"(mscale[7]));
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {   // 64 rows each
+        if (nops >= 2 && hb == 1) { load64(s0, ld0, 1, ra); load64(s1, ld1, 1, rb); }
+        if constexpr (NOPS == 3) { if (hb == 1) load64((const T *)e.res_post, e.ld_res_post, 1, rc); }
+#pragma unroll
+        for (int ig = 0; ig < 4; ig += PT) {
+#pragma unroll
+            for (int it = 0; it < PT; ++it) {
+                const int i = 4 * hb + ig + it;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *(uint2 *)(patch + it * 2048 + frow * 128 + (((j * 4 + fq) ^ frow) << 3)) = pk[i][j];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int it = 0; it < PT; ++it) {
+            const int ii = ig + it;
+            const char *pt = patch + it * 2048;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = h * 8 + lrow, ps = 2 * ii + h;       // ps: 8-row group inside the 64 rows
+                const size_t m = rowof(hb * 8 + ps);
+                const uint2 lo = *(const uint2 *)(pt + row * 128 + ((c2 ^ row) << 3));
+                const uint2 hi = *(const uint2 *)(pt + row * 128 + (((c2 + 1) ^ row) << 3));
+                const uint4 rawv = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                float v[8], t[8];
+                ld8((const bf16_t *)&rawv, v);
+                const uint4 o0 = (hb == 1 && nops == 1) ? rb[ps] : ra[ps], o1 = rb[ps];
+                if (NOPS >= 1) asm volatile("" ::"v"(o0.x), "v"(o0.y), "v"(o0.z), "v"(o0.w));
+                if (NOPS >= 2) asm volatile("" ::"v"(o1.x), "v"(o1.y), "v"(o1.z), "v"(o1.w));
+                if constexpr (NOPS == 3) asm volatile("" ::"v"(rc[ps].x), "v"(rc[ps].y), "v"(rc[ps].z), "v"(rc[ps].w));
+                if (has_p) {
+                    ld8((const T *)&o0, t);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] += t[q];
+                }
+                if (has_m) {
+                    const uint4 om = m_in1 ? o1 : o0;
+                    ld8((const T *)&om, t);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = t[q] > 0.f ? v[q] * mscale[q] : 0.f;
+                    if constexpr (SUMS) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { bs1[q] += v[q]; bs2[q] = fmaf(v[q], t[q], bs2[q]); }
+                    }
+                }
+                if (has_q) {
+                    const uint4 oq = NOPS == 3 ? rc[NOPS == 3 ? ps : 0] : (q_in1 ? o1 : o0);
+                    ld8((const T *)&oq, t);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] += t[q];
+                }
+                if (e.out_raw) {
+                    if (nops == 0) *(uint4 *)((T *)e.out_raw + m * e.ld_raw + c0) = rawv;
+                    else st8((T *)e.out_raw + m * e.ld_raw + c0, v);
+                }
+                if (e.out_act) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        t[q] = fmaxf(v[q] * ascale[q] + ashift[q], relu_lo);
+                    }
+                    st8((T *)e.out_act + m * e.ld_act + c0, t);
+                }
+            }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    if constexpr (SUMS) {
+        // lanes l, l + 8, .., l + 56 hold the same 8 channels (rows lrow + 8 k): butterfly over lane bits 3-5 in a fixed order,
+        // then lane l < 8 writes partial row mw / 128 of [M / 128][2][Cout] (summed in row order by kd_bn_sums_finish)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int sft = 8; sft < 64; sft <<= 1) {
+                bs1[q] += __shfl_xor(bs1[q], sft, 64);
+                bs2[q] += __shfl_xor(bs2[q], sft, 64);
+            }
+        }
+        if (lane < 8) {
+            float *dst = e.bn_sums + (size_t)(mw >> 7) * 2 * p.Cout + c0;
+            *(float4 *)dst = make_float4(bs1[0], bs1[1], bs1[2], bs1[3]);
+            *(float4 *)(dst + 4) = make_float4(bs1[4], bs1[5], bs1[6], bs1[7]);
+            *(float4 *)(dst + p.Cout) = make_float4(bs2[0], bs2[1], bs2[2], bs2[3]);
+            *(float4 *)(dst + p.Cout + 4) = make_float4(bs2[4], bs2[5], bs2[6], bs2[7]);
+        }
+    }
+}
+
+// the tiles of this workgroup: XCD x owns a contiguous range of tile ids (as xcd_remap deals them), its workgroups take
+// them round-robin, so the tiles in flight on one XCD at any time are neighbours (shared image rows / weight slabs in L2)
+struct TileWalk {
+    int t, t_end, step;
+    __device__ __forceinline__ TileWalk(int nt)
+    {
+        const int xcd = blockIdx.x & 7, q = nt >> 3, r = nt & 7;
+        t = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        t_end = t + q + (xcd < r ? 1 : 0);
+        t += blockIdx.x >> 3;
+        step = gridDim.x >> 3;
+    }
+};
+
+}  // namespace
+
+// conv_lw.hip: the one-wave-per-SIMD row kernel (128 x 128 wave tiles, hand-scheduled main loop).  nops_sums = NOPS | 4 when the
+// eval-BN sums are taken.  Returns false when the instantiation does not exist.
+bool kd_launch_conv_row_lw(const ConvParams &p, int nops_sums, unsigned grid, hipStream_t s);

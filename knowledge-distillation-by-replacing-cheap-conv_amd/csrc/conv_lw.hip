@@ -1,0 +1,220 @@
+// conv_row_lw_kernel: the 3x3 / stride 1 / 'same' row-buffer convolution (kd_conv2d_fwd; forward and input gradient of
+// reference models/encoders/wider_resnet.py:124-167) with ONE wave per SIMD and a hand-scheduled main loop.
+//
+// Why: conv_row_persist_kernel<pp> (8 waves of 128 x 64, two per SIMD) reads 0.0234 B of LDS fragments per FLOP, spends one of
+// its two waves per SIMD in the hand-over (LDS-DMA issue, fragment reads) while the other multiplies, and ends at 0.65 MFMA-busy.
+// A 128 x 128 wave tile reads a third less per FLOP but needs 256 accumulator registers, i.e. the 512-register file of a lone
+// wave -- and a lone wave has nobody to hide its reads and its DMA issue behind, which hipcc's schedule never overlaps with the
+// MFMAs (r03: 430 TFLOP/s).  Here the loop is written by hand (tools/gen_conv_lw.py -> conv_lw_body.inc): accumulators in
+// a[0:255] for the whole kernel, fragments in v[128:255], every ds_read and every 1-KiB LDS-DMA piece dealt into the shadow of
+// the MFMAs (tools/ubench/lone_wave: 1128 cycles per 64-MFMA k-step against 1117 for the bare MFMAs; the ping-pong kernel's
+// stage is 2430 cycles per 128), ONE barrier per k-step, B in four 16-KiB slots of 32 channels of K so that a slot has >= 2
+// k-steps to land, the row buffer of period P + 1 issued under period P.  The staging runs ahead ACROSS tiles (persistent
+// workgroups, conv_common.h TileWalk), so a tile boundary is the epilogue between two periods and nothing else.  All periods of a
+// tile are ONE asm statement (LW_TILE_ASM: the fragment registers never live across compiler-generated code; the accumulators
+// do, tools/check_lw_asm.py audits that hipcc never touches them).
+//
+// Work split: tile 256 pixels (a segment of one image row) x 256 output channels; wave (wm, wn) = (wv >> 1, wv & 1) owns pixels
+// wm * 128 .. + 127, channels wn * 128 .. + 127.  A "period" = one (64-channel block, kernel row inside the image) = three taps =
+// six k-steps.  LDS: two row buffers of 320 rows x 128 B (pixel x0 - dil + r, swizzled 16-B chunks; dil <= 32), four B slots of
+// 256 rows x 64 B, four 2-KiB epilogue patches = 152 KiB.
+// Results are bit-identical to conv_row_persist_kernel: the same k order into the same fp32 accumulation chains, the same epilogue.
+#include "conv_common.h"
+#include "conv_lw_body.inc"
+
+namespace {
+
+__device__ __attribute__((aligned(256))) uint32_t lw_zero_page[64];   // zero-initialised
+
+constexpr int LW_ABUF = 320 * 128, LW_BSLOT = 256 * 64, LW_NEED = 2 * LW_ABUF + 4 * LW_BSLOT;
+
+template <int NOPS_>
+__global__ __launch_bounds__(256, 1) void conv_row_lw_kernel(const ConvParams p)
+{
+    typedef bf16_t T;
+    typedef unsigned long long u64;
+    __shared__ __attribute__((aligned(1024))) char lds[LW_NEED + 4 * 2048];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const int d = p.dil;
+    TileWalk walk(p.ntiles);
+    if (walk.t >= walk.t_end) return;
+    const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
+    // ---- per-lane addresses handed to the asm statements.  They are loop-invariant, but 27 registers that stay live through the
+    // epilogue push it into spills (and hipcc then parks values in the accumulator file: tools/check_lw_asm.py): they are
+    // recomputed per tile from a laundered copy of the lane id instead.
+    // fragment reads: A row (wm * 128 + 16 i + frow + kx * dil) of the row buffer, 16-B chunk (fq + 4 ks) at slot chunk ^ (row & 7);
+    // B row (wn * 128 + 16 j + frow) of a slot, chunk fq at slot fq ^ ((row >> 1) & 3); i / j / buffer / slot are instruction offsets.
+    // LDS-DMA sources (byte offsets from a wave-uniform base; the swizzle is applied on the source side): this wave's ten 8-row
+    // pieces of a row buffer, its four 16-row pieces of a B slot.
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    uint32_t va[6], vb, voa[10], vob[4], vz0, vz1, vr0;
+    u32x4_t vzero;
+    auto lane_addresses = [&]() __attribute__((always_inline)) {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int frow = l & 15, fq = l >> 4;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int rsh = frow + kx * d;
+                va[kx * 2 + ks] = lbase + (wm * 128 + rsh) * 128 + (((fq + 4 * ks) ^ (rsh & 7)) << 4);
+            }
+        vb = lbase + 2 * LW_ABUF + (wn * 128 + frow) * 64 + ((fq ^ ((frow >> 1) & 3)) << 4);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) voa[j] = (uint32_t)(((wv * 10 + j) * 8 + (l >> 3)) * (p.ldx * 2) + (((l & 7) ^ (l >> 3)) << 4));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vob[j] = (uint32_t)(((wv * 4 + j) * 16 + (l >> 2)) * (p.Ktot * 2) + (((l & 3) ^ ((l >> 3) & 3)) << 4));
+        vz0 = lbase + wv * 10240 + l * 16;
+        vz1 = vz0 + LW_ABUF;
+        vr0 = (uint32_t)(wv * 80 + (l >> 3));   // buffer row of this lane in piece 0 (piece j: + 8 j)
+        vzero = (u32x4_t){0u, 0u, 0u, 0u};
+    };
+    lane_addresses();
+    const uint32_t sldsA = __builtin_amdgcn_readfirstlane(lbase + wv * 10240);
+    const uint32_t sldsB = __builtin_amdgcn_readfirstlane(lbase + 2 * LW_ABUF + wv * 4096);
+    const uint32_t s2c = (uint32_t)(2 * p.Cin - 64);
+    const long long dWl2 = 2ll * d * p.W * p.ldx;   // bytes from one kernel row's image row to the next
+
+    // ---- tiles -----------------------------------------------------------------------------------------------------------------
+    struct Tile {
+        int m0, n0, kylo, nky;
+        uint32_t lo, span;   // buffer rows [lo, lo + span) hold pixels of the image row (and are read)
+        u64 abase, bbase;    // (n, ho, x0 - dil) of the input / the tile's first weight row
+    };
+    auto decode = [&](int tile, Tile &t) {
+        int tn, tm;
+        if (p.tn_group > 0) {
+            const int per = p.tiles_m * p.tn_group, blk = tile / per, r = tile - blk * per;
+            tm = r / p.tn_group;
+            tn = blk * p.tn_group + (r - tm * p.tn_group);
+        } else {
+            tn = tile % p.tiles_n;
+            tm = tile / p.tiles_n;
+        }
+        t.m0 = tm * 256;
+        t.n0 = tn * 256;
+        const int n = t.m0 / p.HoWo, rem = t.m0 - n * p.HoWo;
+        const int ho = rem / p.W, x0 = rem - ho * p.W;
+        t.kylo = ho - d < 0 ? 1 : 0;
+        t.nky = (ho + d >= p.H ? 1 : 2) - t.kylo + 1;
+        // pixel x0 - d + r: outside the row for r < d in the row's first tile and for r >= 256 + d in its last
+        t.lo = x0 == 0 ? (uint32_t)d : 0u;
+        t.span = (x0 + 256 == p.W ? 256u + d : 320u) - t.lo;
+        t.abase = (u64)p.x + (u64)(2ll * ((long long)((n * p.H + ho) * p.W + (x0 - d)) * p.ldx));
+        t.bbase = (u64)p.w + (u64)(2ll * (long long)t.n0 * p.Ktot);
+    };
+    // period q of a tile = (channel block q / nky, kernel row kylo + q % nky)
+    auto a_of = [&](const Tile &t, int cb, int kyi) { return t.abase + (u64)((long long)(t.kylo + kyi - 1) * dWl2 + cb * 128); };
+    auto b_of = [&](const Tile &t, int cb, int kyi) { return t.bbase + (u64)(2ll * ((long long)(t.kylo + kyi) * 3 * p.Cin + cb * 64)); };
+
+    Tile cur, nxt;
+    int c_tile = walk.t;
+    decode(c_tile, cur);
+
+    // ---- prologue: row buffer of period 0 and the B slots of its k-steps 0 .. 3 (generic pieces: 64-bit lane addresses, lanes
+    // outside the image read the zero page) ---------------------------------------------------------------------------------------
+    {
+        const char *ab = (const char *)a_of(cur, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const uint32_t r = vr0 + 8 * j - cur.lo;
+            glds16(r < cur.span ? (const void *)(ab + voa[j]) : (const void *)lw_zero_page, lds + (wv * 10 + j) * 1024);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const char *bb = (const char *)b_of(cur, 0, 0) + 2ll * (q >> 1) * p.Cin + (q & 1) * 64;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) glds16(bb + vob[j], lds + 2 * LW_ABUF + q * LW_BSLOT + (wv * 4 + j) * 1024);
+        }
+    }
+    u64 sBp = b_of(cur, 0, 0) + (u64)(4ll * p.Cin);   // k-step 4 of period 0 = tap kx 2, first k-half
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // The accumulator file belongs to the asm statements (they name a[0:255] literally).  hipcc must know it is occupied, or it
+    // parks its own values there under register pressure (seen in the three-operand instantiation: v_accvgpr_write a0 .. a21 in
+    // the epilogue = silent corruption): eight 32-register values constrained to AGPRs are outputs of the zeroing statement and
+    // read-write operands of every statement that touches an accumulator, so all 256 registers are live for the whole kernel.
+    typedef __attribute__((ext_vector_type(32))) float f32x32_t;
+    f32x32_t A0, A1, A2, A3, A4, A5, A6, A7;
+    asm volatile(LW_ZERO_ACC_ASM : "=a"(A0), "=a"(A1), "=a"(A2), "=a"(A3), "=a"(A4), "=a"(A5), "=a"(A6), "=a"(A7));
+#define LW_ACC_RW "+a"(A0), "+a"(A1), "+a"(A2), "+a"(A3), "+a"(A4), "+a"(A5), "+a"(A6), "+a"(A7)
+
+    uint32_t flag = 0, par = 0;
+#pragma unroll 1
+    for (;;) {
+        // the first k-step's fragments (the epilogue below runs in the fragment registers), then every period of the tile
+        lane_addresses();
+        asm volatile(LW_REFILL_ASM : : [vaf] "v"(va[0] + par * LW_ABUF), [vbf] "v"(vb + par * 2 * LW_BSLOT) : "memory", LW_CLOBBER_FRAG);
+        const int n_tile = c_tile + walk.step;
+        const bool more = n_tile < walk.t_end;
+        if (more) decode(n_tile, nxt);
+        else nxt = cur;                       // nothing left to stage: the last body re-stages this tile's period 0 (valid memory, unread)
+        const uint32_t nper = (uint32_t)(p.nkc * cur.nky);
+        const u64 sAn = a_of(cur, 0, 1), sBn = b_of(cur, 0, 1), sAnT = a_of(nxt, 0, 0), sBnT = b_of(nxt, 0, 0);
+        const int dAs = (int)dWl2, dAw = (int)(128 - (cur.nky - 1) * dWl2), dBs = 6 * p.Cin, dBw = 128 - (cur.nky - 1) * 6 * p.Cin;
+        asm volatile(LW_TILE_ASM
+                     : [sBp] "+s"(sBp), LW_ACC_RW
+                     : [va0] "v"(va[0]), [va1] "v"(va[1]), [va2] "v"(va[2]), [va3] "v"(va[3]), [va4] "v"(va[4]), [va5] "v"(va[5]), [vb] "v"(vb),
+                       [voa0] "v"(voa[0]), [voa1] "v"(voa[1]), [voa2] "v"(voa[2]), [voa3] "v"(voa[3]), [voa4] "v"(voa[4]), [voa5] "v"(voa[5]),
+                       [voa6] "v"(voa[6]), [voa7] "v"(voa[7]), [voa8] "v"(voa[8]), [voa9] "v"(voa[9]), [vob0] "v"(vob[0]), [vob1] "v"(vob[1]),
+                       [vob2] "v"(vob[2]), [vob3] "v"(vob[3]), [vz0] "v"(vz0), [vz1] "v"(vz1), [vzero] "v"(vzero), [vr0] "v"(vr0),
+                       [sAn] "s"(sAn), [sBn] "s"(sBn), [sAnT] "s"(sAnT), [sBnT] "s"(sBnT), [slo] "s"(cur.lo), [ssp] "s"(cur.span),
+                       [sloT] "s"(nxt.lo), [sspT] "s"(nxt.span), [sdAs] "s"(dAs), [sdAw] "s"(dAw), [sdBs] "s"(dBs), [sdBw] "s"(dBw),
+                       [snky] "s"((uint32_t)cur.nky), [snper] "s"(nper), [s2c] "s"(s2c), [sflag] "s"(flag), [spar] "s"(par),
+                       [sldsA] "s"(sldsA), [sldsB] "s"(sldsB)
+                     : "memory", "scc", "vcc", LW_CLOBBER_S, LW_CLOBBER_FRAG);
+        par = (par + nper) & 1u;
+        // ---- the tile is complete: accumulators -> memory (conv_common.h ig_epilogue_rows16, 128 x 64 at a time) ----------------
+        asm volatile("s_nop 15\n\ts_nop 15" : LW_ACC_RW : : "memory");   // the last MFMAs' results have reached the accumulator file
+        const int mw = cur.m0 + wm * 128, nw = cur.n0 + wn * 128;
+        char *patch = lds + LW_NEED + wv * 2048;
+#define LW_RD(I, JG)                                                                                                                  \
+    {                                                                                                                                 \
+        float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14, t15;                                                   \
+        asm volatile(LW_READ_ACC_##I##_##JG##_ASM                                                                                     \
+                     : "=v"(t0), "=v"(t1), "=v"(t2), "=v"(t3), "=v"(t4), "=v"(t5), "=v"(t6), "=v"(t7), "=v"(t8), "=v"(t9), "=v"(t10), \
+                       "=v"(t11), "=v"(t12), "=v"(t13), "=v"(t14), "=v"(t15), LW_ACC_RW);                                             \
+        acc[I][0] = make_uint2(pack_bf16x2(t0, t1), pack_bf16x2(t2, t3));      /* rounded to the stored type at once: half the registers */ \
+        acc[I][1] = make_uint2(pack_bf16x2(t4, t5), pack_bf16x2(t6, t7));                                                             \
+        acc[I][2] = make_uint2(pack_bf16x2(t8, t9), pack_bf16x2(t10, t11));                                                           \
+        acc[I][3] = make_uint2(pack_bf16x2(t12, t13), pack_bf16x2(t14, t15));                                                         \
+    }
+        {
+            uint2 acc[8][4];
+            LW_RD(0, 0) LW_RD(1, 0) LW_RD(2, 0) LW_RD(3, 0) LW_RD(4, 0) LW_RD(5, 0) LW_RD(6, 0) LW_RD(7, 0)
+            ig_epilogue_rows16<8, NOPS_, 1>(p, patch, acc, mw, nw, lane);
+        }
+        {
+            uint2 acc[8][4];
+            LW_RD(0, 1) LW_RD(1, 1) LW_RD(2, 1) LW_RD(3, 1) LW_RD(4, 1) LW_RD(5, 1) LW_RD(6, 1) LW_RD(7, 1)
+            ig_epilogue_rows16<8, NOPS_, 1>(p, patch, acc, mw, nw + 64, lane);
+        }
+#undef LW_RD
+        if (!more) break;
+        c_tile = n_tile;
+        cur = nxt;
+        flag = 1;
+    }
+#undef LW_ACC_RW
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the staging ran ahead of the last tile: nothing may land after the wave ends
+}
+
+}  // namespace
+
+bool kd_launch_conv_row_lw(const ConvParams &p, int nops_sums, unsigned grid, hipStream_t s)
+{
+    const dim3 g(grid), b(256);
+    switch (nops_sums) {
+    case 0: hipLaunchKernelGGL((conv_row_lw_kernel<0>), g, b, 0, s, p); return true;
+    case 1: hipLaunchKernelGGL((conv_row_lw_kernel<1>), g, b, 0, s, p); return true;
+    case 2: hipLaunchKernelGGL((conv_row_lw_kernel<2>), g, b, 0, s, p); return true;
+    case 3: hipLaunchKernelGGL((conv_row_lw_kernel<3>), g, b, 0, s, p); return true;
+    case 5: hipLaunchKernelGGL((conv_row_lw_kernel<5>), g, b, 0, s, p); return true;
+    case 6: hipLaunchKernelGGL((conv_row_lw_kernel<6>), g, b, 0, s, p); return true;
+    default: return false;
+    }
+}

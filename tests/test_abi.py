@@ -104,3 +104,18 @@ def test_no_compiler_waits_inside_the_conv_main_loops():
         pytest.skip("no hipcc")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_loop_waits.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
+
+
+def test_hand_scheduled_conv_loop_is_generated_and_audited():
+    """csrc/conv_lw_body.inc is the output of tools/gen_conv_lw.py (the hand-scheduled main loop of conv_row_lw_kernel), and
+    the compiled kernel passes tools/check_lw_asm.py: hipcc never touches the accumulator file the asm statements own, every
+    MFMA sits in the one tile statement, no scratch in the no-operand instantiation."""
+    import shutil
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_conv_lw.py"), "--check"])
+    assert r.returncode == 0, "csrc/conv_lw_body.inc is stale: run python tools/gen_conv_lw.py"
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_lw_asm.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]

@@ -1,5 +1,5 @@
 """The MEASURED path (bf16, the kernels bench.py times) under the network-level oracle at shapes where the dispatchers pick
-the shipped kernels -- persistent row / 1x1 ping-pong kernels, the 512x128 mod2 kernel, the matrix-core depthwise forward /
+the shipped kernels -- the one-wave-per-SIMD row kernel (hand-scheduled loop), the persistent 1x1 ping-pong kernel, the 512x128 mod2 kernel, the matrix-core depthwise forward /
 fan-out / summed input gradient / weight gradient, the fused stem + pool -- with the selection asserted through the kernel log
 (kd_debug_kernel_log_*).  The per-kernel bf16 oracle tests live in test_ops_gpu.py; this file checks the ENGINE WIRING of those
 kernels (trainer/layerwise_trainer.py:220-239 of the reference: forward, criteria, backward) against oracle/net_ref.py.
@@ -78,7 +78,7 @@ def _step(model, backprop="hint"):
     return out_st, out_tc, hint, kd, loss
 
 
-SHIPPED_MODE_A = ["conv_row_persist_kernel<pp>", "conv_igemm_persist_kernel<pp>", "conv_row_pp128_kernel",
+SHIPPED_MODE_A = ["conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>", "conv_row_pp128_kernel",
                   "dw_mfma_fwd_kernel<1,false>", "dw_mfma_fwd_kernel<3,true>", "dw_mfma_fwd_kernel<3,false>",
                   "dw_mfma_wgrad_kernel", "dw_mfma_wgrad_multi_kernel<3>", "stem_pool_kernel", "conv_wgrad_wide_kernel"]   # (the pointwise weight gradients take the 256x256 wgrad tile)
 
@@ -96,7 +96,7 @@ def test_bf16_p92_step_on_the_shipped_kernels_vs_network_oracle():
     missing = [k for k in SHIPPED_MODE_A if log.counts.get(k, 0) == 0]
     assert not missing, f"kernels the bench step runs but this step did not select: {missing}; selected: {log.counts}"
     # the 3x3 / 1x1 layers of mod3..mod7 and the decoder must be on the persistent kernels, not on the one-tile fallbacks
-    persistent = log.counts["conv_row_persist_kernel<pp>"] + log.counts["conv_igemm_persist_kernel<pp>"] + log.counts["conv_row_pp128_kernel"]
+    persistent = log.counts["conv_row_lw_kernel"] + log.counts["conv_igemm_persist_kernel<pp>"] + log.counts["conv_row_pp128_kernel"]
     total_conv = sum(v for k, v in log.counts.items() if k.startswith(("conv_row_", "conv_igemm_")))
     assert persistent >= 0.75 * total_conv, log.counts
 
@@ -134,7 +134,7 @@ def test_bf16_mode_b_step_on_the_shipped_kernels_vs_network_oracle():
     model._x = x.cuda()
     with _lib.kernel_log() as log:
         out_st, out_tc, hint, kd, loss = _step(model, "kd+hint")
-    for k in ("conv_wgrad_row_kernel", "conv_wgrad_wide_kernel", "conv_row_persist_kernel<pp>", "conv_igemm_persist_kernel<pp>",
+    for k in ("conv_wgrad_row_kernel", "conv_wgrad_wide_kernel", "conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>",
               "dw_mfma_wgrad_kernel", "dw_mfma_fwd_kernel<3,false>", "bn_sums_epilogue"):
         assert log.counts.get(k, 0) > 0, (k, log.counts)
     # the eval-BN parameter sums ride in the input-gradient epilogues: only the sites those kernels do not cover still read the
@@ -199,7 +199,7 @@ def test_bf16_gscnn_step_vs_network_oracle():
     model._x = x.cuda()
     with _lib.kernel_log() as log:
         out_st, out_tc, hint, kd, _ = _step(model)
-    for k in ("conv3x3_small_kernel<64>", "gated_conv_mfma_kernel", "conv_row_persist_kernel<pp>", "conv_igemm_persist_kernel<pp>"):
+    for k in ("conv3x3_small_kernel<64>", "gated_conv_mfma_kernel", "conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>"):
         assert log.counts.get(k, 0) > 0, (k, log.counts)
     tsd = seeded_gscnn_sd()
     ssd = net_ref.make_student_sd(tsd, plan, seeded_cheap_weights(tsd, plan))

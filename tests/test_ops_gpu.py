@@ -94,9 +94,9 @@ CONV_CASES = [
 # what each of the shape-selected cases above must dispatch to: index -> (bf16 kernel, f32 kernel)
 CONV_SELECTS = {
     0: ("conv_igemm_kernel<narrow2>", "conv_igemm_kernel<f32,narrow>"),
-    6: ("conv_row_persist_kernel<pp>", "conv_igemm_row_kernel<f32,wide>"),
-    7: ("conv_row_persist_kernel<pp>", "conv_igemm_row_kernel<f32,wide>"),
-    8: ("conv_row_persist_kernel<pp>", "conv_igemm_row_kernel<f32,wide>"),
+    6: ("conv_row_lw_kernel", "conv_igemm_row_kernel<f32,wide>"),
+    7: ("conv_row_lw_kernel", "conv_igemm_row_kernel<f32,wide>"),
+    8: ("conv_row_lw_kernel", "conv_igemm_row_kernel<f32,wide>"),
     9: ("conv_igemm_row_kernel<x>", "conv_igemm_row_kernel<f32,x>"),
     10: ("conv_igemm_row_kernel<narrow>", "conv_igemm_kernel<f32,narrow>"),
     11: ("conv_igemm_row_kernel<narrow>", "conv_igemm_kernel<f32,narrow>"),
@@ -150,8 +150,8 @@ def test_conv_epilogue_forward(K, dt):
 BN_SUMS_CASES = [
     # N, H, W, Cin, Cout, k, dil, operands, kernel -- the backward of conv -> BN -> ReLU at shapes that select each kernel whose
     # epilogue can take the eval-BN parameter sums (mask alone, mask + res_post, res_pre + mask), and one that selects none
-    (1, 128, 512, 256, 256, 3, 1, "m", "conv_row_persist_kernel<pp>"),
-    (2, 96, 256, 256, 512, 3, 2, "mq", "conv_row_persist_kernel<pp>"),
+    (1, 128, 512, 256, 256, 3, 1, "m", "conv_row_lw_kernel"),
+    (2, 96, 256, 256, 512, 3, 2, "mq", "conv_row_lw_kernel"),
     (1, 128, 512, 128, 256, 1, 1, "pm", "conv_igemm_persist_kernel<pp>"),
     (1, 128, 512, 256, 256, 1, 1, "mq", "conv_igemm_persist_kernel<pp>"),
     (1, 256, 512, 128, 128, 3, 1, "m", "conv_row_pp128_kernel"),
@@ -296,7 +296,7 @@ def test_conv_persistent_epilogues(K, case, opnds, outs):
              res_post=dev_nhwc(post, dt, ld=Cout + 24) if "post" in opnds else None,
              out_raw=out_raw, out_act=out_act, act_scale=cu(ascale) if "act" in outs else None,
              act_shift=cu(ashift) if "act" in outs else None, act_relu="act" in outs)
-    selected("conv_igemm_persist_kernel<pp>" if k == 1 else "conv_row_pp128_kernel" if Cout == 128 else "conv_row_persist_kernel<pp>",
+    selected("conv_igemm_persist_kernel<pp>" if k == 1 else "conv_row_pp128_kernel" if Cout == 128 else "conv_row_lw_kernel",
              f"{case} {opnds}")
     if out_raw is not None:
         assert_close(host_nchw(out_raw), ref, dt, f"raw {case} {opnds}")

@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Generator of csrc/conv_lw_body.inc: the hand-scheduled main loop of conv_row_lw_kernel (csrc/conv_lw.hip).
+
+One wave per SIMD (4 waves per workgroup, 512 registers per lane): a wave owns 128 pixels x 128 output channels of the
+256 x 256 tile, its 256 accumulator registers live in a[0:255] for the whole kernel, the MFMA operand fragments in
+v[128:255] (two sets of 8 A + 8 B fragments, one per k-step parity).  hipcc would schedule none of this the way the matrix
+pipe wants it: a lone wave has no partner that hides its LDS reads and LDS-DMA issue, so every
+one of them is DEALT into the shadow of the MFMAs by hand -- tools/ubench/lone_wave measures that stream at 1128 cycles per
+k-step against 1117 for the bare MFMAs.
+
+LW_TILE_ASM is ONE asm statement that runs every period of a tile (the fragments never live across compiler code).  A period P
+= the three kx taps of one (64-channel block, kernel row) = 6 k-steps of 32 channels = 384 MFMAs per wave.  Per k-step p
+(global k-step h = 6 P + p):
+  * 64 v_mfma_f32_16x16x32_bf16 on fragment set p & 1;
+  * 16 ds_read_b128: the fragments of k-step h + 1 into the other set (A from the row buffer of its period at the tap's row
+    shift, B from slot (h + 1) & 3);
+  * LDS-DMA, 1-KiB pieces (global_load_lds_dwordx4, source = SGPR base + per-lane offset VGPR, M0 written per piece):
+      B of k-step h + 4 into slot h & 3 (4 pieces per wave; that slot's fragments were read during k-step h - 1),
+      at p = 0, 1, 2 this wave's 4 + 3 + 3 pieces of the NEXT period's row buffer (EXEC = the lanes whose pixel lies inside
+      the image row, from a compare of the lane's buffer row against two scalars; the other lanes' bytes are zero-filled by
+      a ds_write under the complementary mask);
+  * s_waitcnt vmcnt(N_p) lgkmcnt(0): everything issued up to k-step h - 2 has landed (N_p = pieces issued in h - 1 and h;
+    in the first period after an epilogue the first two waits also leave that epilogue's stores outstanding); s_barrier.
+So a B slot has two to three k-steps (>= 2048 cycles) to land and a row buffer two, and ONE barrier per k-step both publishes
+what landed and frees what was read.  Two body copies (P even / odd: row buffer P & 1, B slot phase 2 (P & 1)) form the loop;
+behind each, a few SALU instructions step the staging iterator (next kernel row / channel block, or the next TILE's first
+period: the staging runs ahead across tiles).
+
+usage: python tools/gen_conv_lw.py   (rewrites csrc/conv_lw_body.inc; `--check` exits 1 when the file is stale: tests/test_abi.py)"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "knowledge-distillation-by-replacing-cheap-conv_amd", "csrc", "conv_lw_body.inc")
+
+ABUF = 320 * 128          # one row buffer (320 rows x 128 B)
+BSLOT = 256 * 64          # one B slot (256 output channels x 32 channels of K)
+A_PIECES = ((0, 1, 2, 3), (4, 5, 6), (7, 8, 9), (), (), ())     # row-buffer pieces issued at k-step p
+ISSUED = [4 + len(a) for a in A_PIECES]                         # VMEM operations per k-step and wave
+# scalar registers owned by the statement (clobbered)
+SB = "s[88:89]"           # running B source pointer (k-step h + 4)
+SAN, SBN = "s[76:77]", "s[78:79]"     # the period being staged: row-buffer source base, weight base
+SLO, SSPAN = "s80", "s81"             # ... its valid buffer rows [lo, lo + span)
+SKY, SIN, SCNT, SFLAG = "s82", "s83", "s84", "s85"   # kernel-row position of the staged period, in-tile periods left to stage, periods left to compute, stores-outstanding flag
+ST0, ST1, ST2 = "s86", "s87", "s91"
+CLOBBER_S = ["s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91"]
+VT = "v127"               # lane temporary (clobbered)
+
+
+def frag_regs(s):
+    base = 128 + 64 * s
+    return [base + 4 * i for i in range(8)], [base + 32 + 4 * j for j in range(8)]
+
+
+def kstep(par, p):
+    cur = p & 1
+    areg, breg = frag_regs(cur)
+    nareg, nbreg = frag_regs(1 - cur)
+    slots = [[] for _ in range(64)]
+    # ---- fragment reads of the next k-step
+    q = p + 1
+    if q < 6:
+        kx, ks, buf = q >> 1, q & 1, par
+    else:
+        kx, ks, buf = 0, 0, par ^ 1
+    slot_next = (2 * par + p + 1) & 3
+    reads = [f"ds_read_b128 v[{nareg[i]}:{nareg[i] + 3}], %[va{kx * 2 + ks}] offset:{i * 2048 + buf * ABUF}" for i in range(8)]
+    reads += [f"ds_read_b128 v[{nbreg[j]}:{nbreg[j] + 3}], %[vb] offset:{slot_next * BSLOT + j * 1024}" for j in range(8)]
+    for r, ins in enumerate(reads):
+        slots[1 + 3 * r].append(ins)
+    # ---- B pieces of k-step h + 4 into slot h & 3
+    slot_cur = (2 * par + p) & 3
+    if p == 2:
+        slots[2].append(f"s_mov_b64 {SB}, {SBN}")          # positions 0 .. 3 of the period being staged
+    for j, k in enumerate((4, 20, 36, 52)):
+        slots[k] += [f"s_add_u32 m0, %[sldsB], {slot_cur * BSLOT + j * 1024}", "s_nop 0",
+                     f"global_load_lds_dwordx4 %[vob{j}], {SB}"]
+    # advance the B pointer: +64 B to the second k-half, then on to the next tap
+    if p & 1:
+        slots[54] += ["s_add_u32 s88, s88, %[s2c]", "s_addc_u32 s89, s89, 0"]
+    else:
+        slots[54] += ["s_add_u32 s88, s88, 64", "s_addc_u32 s89, s89, 0"]
+    # ---- row-buffer pieces of the period being staged
+    at = (12, 28, 44, 60)
+    for n, j in enumerate(A_PIECES[p]):
+        nb = par ^ 1
+        slots[at[n]] += [f"s_add_u32 m0, %[sldsA], {nb * ABUF + j * 1024}",
+                         f"v_add_u32 {VT}, {8 * j}, %[vr0]", f"v_subrev_u32 {VT}, {SLO}, {VT}",     # buffer row of the lane - lo
+                         f"v_cmpx_gt_u32 vcc, {SSPAN}, {VT}",                                       # EXEC: lo <= row < lo + span
+                         f"global_load_lds_dwordx4 %[voa{j}], {SAN}", "s_not_b64 exec, exec",
+                         f"ds_write_b128 %[vz{nb}], %[vzero] offset:{j * 1024}", "s_mov_b64 exec, -1"]
+    L = []
+    k = 0
+    for i in range(8):
+        for j in range(8):
+            acc = 4 * (8 * i + j)
+            L.append(f"v_mfma_f32_16x16x32_bf16 a[{acc}:{acc + 3}], v[{breg[j]}:{breg[j] + 3}], v[{areg[i]}:{areg[i] + 3}], a[{acc}:{acc + 3}]")
+            L += slots[k]
+            k += 1
+    n = ISSUED[p] + ISSUED[p - 1]          # (p = 0: the previous period's last k-step)
+    if p < 2:
+        # right after an epilogue its stores are younger than the pieces this wait is for and older than this period's: leave
+        # them outstanding (the counter saturates at 63)
+        L += [f"s_cmp_eq_u32 {SFLAG}, 0", f"s_cbranch_scc1 LWN{par}{p}_%=", "s_waitcnt vmcnt(63) lgkmcnt(0)", f"s_branch LWD{par}{p}_%=",
+              f"LWN{par}{p}_%=:", f"s_waitcnt vmcnt({n}) lgkmcnt(0)", f"LWD{par}{p}_%=:"]
+        if p == 1:
+            L.append(f"s_mov_b32 {SFLAG}, 0")
+    else:
+        L.append(f"s_waitcnt vmcnt({n}) lgkmcnt(0)")
+    L.append("s_barrier")
+    return L
+
+
+def step_iterator(par):
+    """the staging iterator moves on by one period: next kernel row / channel block of this tile, or the next tile's first period"""
+    return [f"s_sub_u32 {SIN}, {SIN}, 1", f"s_cmp_gt_i32 {SIN}, 0", f"s_cbranch_scc0 LWT{par}_%=",
+            f"s_add_u32 {SKY}, {SKY}, 1", f"s_cmp_eq_u32 {SKY}, %[snky]",
+            f"s_cselect_b32 {ST0}, %[sdAw], %[sdAs]", f"s_cselect_b32 {ST1}, %[sdBw], %[sdBs]", f"s_cselect_b32 {SKY}, 0, {SKY}",
+            f"s_ashr_i32 {ST2}, {ST0}, 31", f"s_add_u32 s76, s76, {ST0}", f"s_addc_u32 s77, s77, {ST2}",
+            f"s_ashr_i32 {ST2}, {ST1}, 31", f"s_add_u32 s78, s78, {ST1}", f"s_addc_u32 s79, s79, {ST2}",
+            f"s_branch LWU{par}_%=", f"LWT{par}_%=:",
+            f"s_mov_b64 {SAN}, %[sAnT]", f"s_mov_b64 {SBN}, %[sBnT]", f"s_mov_b32 {SLO}, %[sloT]", f"s_mov_b32 {SSPAN}, %[sspT]",
+            f"LWU{par}_%=:"]
+
+
+def tile():
+    L = ["s_mov_b32 s90, m0", f"s_mov_b64 {SB}, %[sBp]", f"s_mov_b64 {SAN}, %[sAn]", f"s_mov_b64 {SBN}, %[sBn]",
+         f"s_mov_b32 {SLO}, %[slo]", f"s_mov_b32 {SSPAN}, %[ssp]", f"s_mov_b32 {SKY}, 1", f"s_sub_u32 {SIN}, %[snper], 1",
+         f"s_mov_b32 {SCNT}, %[snper]", f"s_mov_b32 {SFLAG}, %[sflag]", "s_cmp_eq_u32 %[spar], 0", "s_cbranch_scc0 LWODD_%=",
+         "LWEVEN_%=:"]
+    for p in range(6):
+        L += kstep(0, p)
+    L += step_iterator(0) + [f"s_sub_u32 {SCNT}, {SCNT}, 1", f"s_cmp_eq_u32 {SCNT}, 0", "s_cbranch_scc1 LWEND_%=", "LWODD_%=:"]
+    for p in range(6):
+        L += kstep(1, p)
+    L += step_iterator(1) + [f"s_sub_u32 {SCNT}, {SCNT}, 1", f"s_cmp_lg_u32 {SCNT}, 0", "s_cbranch_scc1 LWEVEN_%=", "LWEND_%=:",
+                             f"s_mov_b64 %[sBp], {SB}", "s_mov_b32 m0, s90"]
+    return L
+
+
+def refill():
+    """the first k-step's fragments of a period: A from %[vaf] (row-buffer address of tap 0 / k-half 0), B from %[vbf] (its slot)"""
+    areg, breg = frag_regs(0)
+    L = [f"ds_read_b128 v[{areg[i]}:{areg[i] + 3}], %[vaf] offset:{i * 2048}" for i in range(8)]
+    L += [f"ds_read_b128 v[{breg[j]}:{breg[j] + 3}], %[vbf] offset:{j * 1024}" for j in range(8)]
+    L += ["s_waitcnt lgkmcnt(0)", "s_barrier"]      # (no wave stages into that slot before every wave has read it)
+    return L
+
+
+def read_acc(i, jg):
+    regs = [4 * (8 * i + 4 * jg + jj) + r for jj in range(4) for r in range(4)]
+    L = [f"v_accvgpr_read_b32 %{n}, a{a}" for n, a in enumerate(regs)]
+    L += [f"v_accvgpr_write_b32 a{a}, 0" for a in regs]
+    return L
+
+
+def cstr(lines):
+    return " \\\n".join('    "' + l + '\\n\\t"' for l in lines)
+
+
+def main():
+    o = ["// GENERATED by tools/gen_conv_lw.py -- do not edit (python tools/gen_conv_lw.py rewrites it).",
+         "// The hand-scheduled main loop of conv_row_lw_kernel; see the generator for the schedule.", ""]
+    o += ["#define LW_TILE_ASM \\", cstr(tile()), ""]
+    o += ["#define LW_REFILL_ASM \\", cstr(refill()), ""]
+    for i in range(8):
+        for jg in range(2):
+            o += [f"#define LW_READ_ACC_{i}_{jg}_ASM \\", cstr(read_acc(i, jg)), ""]
+    o += ["#define LW_ZERO_ACC_ASM \\", cstr([f"v_accvgpr_write_b32 a{n}, 0" for n in range(256)]), ""]
+    o += ["#define LW_CLOBBER_ACC " + ", ".join(f'"a{n}"' for n in range(256)),
+          "#define LW_CLOBBER_FRAG " + ", ".join(f'"v{n}"' for n in range(127, 256)),
+          "#define LW_CLOBBER_S " + ", ".join(f'"{s}"' for s in CLOBBER_S), ""]
+    text = "\n".join(o)
+    if len(sys.argv) > 1 and sys.argv[1] == "--check":
+        sys.exit(0 if open(OUT).read() == text else 1)
+    with open(OUT, "w") as f:
+        f.write(text)
+
+
+if __name__ == "__main__":
+    main()

@@ -12,7 +12,7 @@ import csv
 import json
 import sys
 
-FAMILIES = [("conv_igemm_row_persist<CfgRow 256x256>", ("conv_row_persist_kernel",)),
+FAMILIES = [("conv_row_lw<256x256, one wave per SIMD>", ("conv_row_lw_kernel",)), ("conv_igemm_row_persist<CfgRow 256x256>", ("conv_row_persist_kernel",)),
             ("conv_igemm_row_pp128<512x128>", ("conv_row_pp128_kernel",)),
             ("conv_igemm_persist<CfgWide 256x256 1x1>", ("conv_igemm_persist_kernel",)),
             ("conv_igemm_row<CfgRow 256x256>", ("conv_igemm_row_kernel", "CfgRowT<8, 2, 4, 128, 320")),
