@@ -12,6 +12,7 @@ struct ConvParams {
     int vec_ok;  // every epilogue pointer/stride is 16-B friendly
     int epi_batch;  // A/B hook: 0 = one pass at a time (KDCC_EPI_BATCH=0)
     int tune;       // A/B hook (KDCC_CONV_TUNE)
+    int stagger_us; // A/B hook (KDCC_CONV_STAGGER, with tune & 16384)
     kd_conv_epilogue ep;
 };
 }  // namespace kdconv
@@ -57,7 +58,22 @@ __device__ __forceinline__ void wait_vm_only(int nst)
 __device__ __forceinline__ uint2 ig_pack_acc(const f32x4_t &v) { return make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])); }
 __device__ __forceinline__ uint2 ig_pack_acc(const uint2 &v) { return v; }   // (conv_lw.hip hands over packed accumulators)
 
-template <int MI, int NOPS_, int PT = 1, typename ACC = f32x4_t>   // NOPS_ = operands | 4 when the eval-BN sums are taken (kernels' NOPS parameter)
+// one v_cvt_pk_bf16_f32 per pair (a vector cast; pack_bf16x2's two scalar casts cost three instructions -- kept in the
+// ping-pong kernels, where the vector form once moved a compiler wait into a main loop: DESIGN.md section 5)
+__device__ __forceinline__ uint32_t pack_bf16x2_v(float lo, float hi)
+{
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t));
+}
+__device__ __forceinline__ void st8_v(bf16_t *p, const float (&v)[8])
+{
+    *(uint4 *)p = make_uint4(pack_bf16x2_v(v[0], v[1]), pack_bf16x2_v(v[2], v[3]), pack_bf16x2_v(v[4], v[5]), pack_bf16x2_v(v[6], v[7]));
+}
+
+// OUTS: 0 = which outputs exist is read from the epilogue descriptor per row (the ping-pong kernels); 1 raw, 2 act, 3 both at
+// compile time + single-instruction packing (conv_lw.hip: a lone wave's epilogue is bound by its own instruction count)
+template <int MI, int NOPS_, int PT = 1, typename ACC = f32x4_t, int OUTS = 0>   // NOPS_ = operands | 4 when the eval-BN sums are taken (kernels' NOPS parameter)
 __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *patch, ACC (&acc)[MI][4], int mw, int nw,
                                                    int lane)
 {
@@ -177,16 +193,24 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
 #pragma unroll
                     for (int q = 0; q < 8; ++q) v[q] += t[q];
                 }
-                if (e.out_raw) {
+                if (OUTS ? (OUTS & 1) != 0 : e.out_raw != nullptr) {
                     if (nops == 0) *(uint4 *)((T *)e.out_raw + m * e.ld_raw + c0) = rawv;
+                    else if (OUTS) st8_v((T *)e.out_raw + m * e.ld_raw + c0, v);
                     else st8((T *)e.out_raw + m * e.ld_raw + c0, v);
                 }
-                if (e.out_act) {
+                if (OUTS ? (OUTS & 2) != 0 : e.out_act != nullptr) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         t[q] = fmaxf(v[q] * ascale[q] + ashift[q], relu_lo);
                     }
-                    st8((T *)e.out_act + m * e.ld_act + c0, t);
+#ifdef KDCC_TUNING
+                    // timing ablations (tuning build): 128 = everything but the store itself; 256 = the store lands in a 16-KiB
+                    // window per wave (same instruction stream, the bytes stay in L2)
+                    if (p.tune & 128) { asm volatile("" ::"v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6]), "v"(t[7])); continue; }
+                    if (p.tune & 256) { st8((T *)e.out_act + (size_t)(((m & 15) + 16 * (blockIdx.x * 8 + (threadIdx.x >> 6))) % 4096) * e.ld_act + c0, t); continue; }
+#endif
+                    if (OUTS) st8_v((T *)e.out_act + m * e.ld_act + c0, t);
+                    else st8((T *)e.out_act + m * e.ld_act + c0, t);
                 }
             }
             }
@@ -218,6 +242,16 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
 
 // the tiles of this workgroup: XCD x owns a contiguous range of tile ids (as xcd_remap deals them), its workgroups take
 // them round-robin, so the tiles in flight on one XCD at any time are neighbours (shared image rows / weight slabs in L2)
+// A/B experiment (tuning build, KDCC_CONV_TUNE & 16384): every second workgroup of an XCD starts p.stagger_us microseconds late, so
+// that the store phases (epilogues) of one half of the chip fall into the main loops of the other half.
+__device__ __forceinline__ void stagger_start(const ConvParams &p)
+{
+    if ((p.tune & 16384) && ((blockIdx.x >> 3) & 1)) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)p.stagger_us * 100ull) __builtin_amdgcn_s_sleep(8);
+    }
+}
+
 struct TileWalk {
     int t, t_end, step;
     __device__ __forceinline__ TileWalk(int nt)
@@ -235,3 +269,4 @@ struct TileWalk {
 // conv_lw.hip: the one-wave-per-SIMD row kernel (128 x 128 wave tiles, hand-scheduled main loop).  nops_sums = NOPS | 4 when the
 // eval-BN sums are taken.  Returns false when the instantiation does not exist.
 bool kd_launch_conv_row_lw(const ConvParams &p, int nops_sums, unsigned grid, hipStream_t s);
+bool kd_launch_conv_pw_lw(const ConvParams &p, int nops_sums, unsigned grid, hipStream_t s);   // 1x1 / stride 1, Cin % 128 == 0

@@ -706,6 +706,7 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_row_persist_kernel(
     const int d = p.dil;
     TileWalk walk(p.ntiles);
     if (walk.t >= walk.t_end) return;
+    stagger_start(p);
 
     const int srow = lane / CPR;
     const int chunk = (lane & 7) ^ srow;
@@ -989,6 +990,7 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_persist_kerne
     const T *__restrict__ wg = (const T *)p.w;
     TileWalk walk(p.ntiles);
     if (walk.t >= walk.t_end) return;
+    stagger_start(p);
 
     const int srow = lane / CPR;
     const int chunk = (lane & 7) ^ srow;
@@ -1240,6 +1242,7 @@ __global__ __launch_bounds__(512, 2) void conv_row_pp128_kernel(const ConvParams
     const int d = p.dil;
     TileWalk walk(p.ntiles);
     if (walk.t >= walk.t_end) return;
+    stagger_start(p);
 
     // 64-B rows: LDS slot s of row r holds chunk s ^ ((r >> 1) & 3); a piece = 16 rows, lane -> (row lane / 4, slot lane & 3)
     const int srow = lane >> 2;
@@ -1544,6 +1547,9 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         static int tn = -1;
         if (tn < 0) tn = KD_TUNING_ENV_INT("KDCC_CONV_TUNE");   // timing ablations / timestamps: tuning build only (kd_common.h)
         p.tune = tn;
+        static int sg = -1;
+        if (sg < 0) sg = KD_TUNING_ENV_INT("KDCC_CONV_STAGGER");
+        p.stagger_us = sg;
     }
     const ConvSel sel = conv_select(d, ep, p.tune);
     p.vec_ok = sel.vec_ok;
@@ -1580,7 +1586,7 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         p.nkc = d->Cin / (CfgRow::RB / es);
         p.nk = 9 * p.nkc;
         const dim3 grid = persist_grid();
-        const bool lw = lw_row() && pp_row() && d->dil <= 32 && !(p.tune & (512 | 64));
+        const bool lw = lw_row() && pp_row() && d->dil <= 32 && !(p.tune & 512);
         KD_NOTE_KERNEL((p.tune & 512) ? "conv_row_persist_kernel<dbg>" : lw ? "conv_row_lw_kernel" : (pp_row() && d->dil <= 32) ? "conv_row_persist_kernel<pp>" : "conv_row_persist_kernel<lockstep>");
         if (lw) {
             KD_REQUIRE(kd_launch_conv_row_lw(p, nops | (ep->bn_sums ? 4 : 0), grid.x, s), KD_ERR_UNSUPPORTED, "kd_conv2d_fwd: no conv_row_lw_kernel instantiation for %d epilogue operands", nops);
@@ -1602,8 +1608,17 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         p.nkc = d->Cin / (CfgWide::RB / es);
         p.nk = d->kh * d->kw * p.nkc;
         const dim3 grid = persist_grid();
-        KD_NOTE_KERNEL(pp_row() ? "conv_igemm_persist_kernel<pp>" : "conv_igemm_persist_kernel<lockstep>");
-        if (pp_row()) {
+        // conv_pw_lw_kernel (the lone-wave loop for 1x1 layers) is bit-identical but NOT faster here: its main loop ties the
+        // ping-pong kernel's (8 DMA pieces per k-step keep both near the staging rate) and its serial epilogue -- four waves with
+        // twice the instructions each, nothing to overlap them -- costs 10-60 % more on these short-K layers (tools/lw_ablate.sh).
+        // Opt-in for A/B: KDCC_CONV_LW_PW=1.
+        static int lw_pw = -1;
+        if (lw_pw < 0) { const char *v = getenv("KDCC_CONV_LW_PW"); lw_pw = (v && v[0] == '1') ? 1 : 0; }
+        const bool lw = lw_pw && lw_row() && pp_row() && d->Cin % 128 == 0 && !(p.tune & 512);
+        KD_NOTE_KERNEL(lw ? "conv_pw_lw_kernel" : pp_row() ? "conv_igemm_persist_kernel<pp>" : "conv_igemm_persist_kernel<lockstep>");
+        if (lw) {
+            KD_REQUIRE(kd_launch_conv_pw_lw(p, nops | (ep->bn_sums ? 4 : 0), grid.x, s), KD_ERR_UNSUPPORTED, "kd_conv2d_fwd: no conv_pw_lw_kernel instantiation for %d epilogue operands", nops);
+        } else if (pp_row()) {
             if (nops == 0) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 0, true>), grid, dim3(512), 0, s, p);
             else if (ep->bn_sums && nops == 1) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 5, true>), grid, dim3(512), 0, s, p);
             else if (ep->bn_sums && nops == 2) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 6, true>), grid, dim3(512), 0, s, p);

@@ -17,7 +17,7 @@
 // Work split: tile 256 pixels (a segment of one image row) x 256 output channels; wave (wm, wn) = (wv >> 1, wv & 1) owns pixels
 // wm * 128 .. + 127, channels wn * 128 .. + 127.  A "period" = one (64-channel block, kernel row inside the image) = three taps =
 // six k-steps.  LDS: two row buffers of 320 rows x 128 B (pixel x0 - dil + r, swizzled 16-B chunks; dil <= 32), four B slots of
-// 256 rows x 64 B, four 2-KiB epilogue patches = 152 KiB.
+// 256 rows x 64 B, four 4-KiB epilogue patches = 160 KiB.
 // Results are bit-identical to conv_row_persist_kernel: the same k order into the same fp32 accumulation chains, the same epilogue.
 #include "conv_common.h"
 #include "conv_lw_body.inc"
@@ -33,13 +33,14 @@ __global__ __launch_bounds__(256, 1) void conv_row_lw_kernel(const ConvParams p)
 {
     typedef bf16_t T;
     typedef unsigned long long u64;
-    __shared__ __attribute__((aligned(1024))) char lds[LW_NEED + 4 * 2048];
+    __shared__ __attribute__((aligned(1024))) char lds[LW_NEED + 4 * 4096];   // 160 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1;
     const int d = p.dil;
     TileWalk walk(p.ntiles);
     if (walk.t >= walk.t_end) return;
+    stagger_start(p);
     const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
     // ---- per-lane addresses handed to the asm statements.  They are loop-invariant, but 27 registers that stay live through the
     // epilogue push it into spills (and hipcc then parks values in the accumulator file: tools/check_lw_asm.py): they are
@@ -170,30 +171,36 @@ __global__ __launch_bounds__(256, 1) void conv_row_lw_kernel(const ConvParams p)
         par = (par + nper) & 1u;
         // ---- the tile is complete: accumulators -> memory (conv_common.h ig_epilogue_rows16, 128 x 64 at a time) ----------------
         asm volatile("s_nop 15\n\ts_nop 15" : LW_ACC_RW : : "memory");   // the last MFMAs' results have reached the accumulator file
+        if (!(p.tune & 64)) {   // (64: timing ablation without the epilogue, tuning build only)
         const int mw = cur.m0 + wm * 128, nw = cur.n0 + wn * 128;
-        char *patch = lds + LW_NEED + wv * 2048;
+        char *patch = lds + LW_NEED + wv * 4096;
 #define LW_RD(I, JG)                                                                                                                  \
     {                                                                                                                                 \
         float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14, t15;                                                   \
         asm volatile(LW_READ_ACC_##I##_##JG##_ASM                                                                                     \
                      : "=v"(t0), "=v"(t1), "=v"(t2), "=v"(t3), "=v"(t4), "=v"(t5), "=v"(t6), "=v"(t7), "=v"(t8), "=v"(t9), "=v"(t10), \
                        "=v"(t11), "=v"(t12), "=v"(t13), "=v"(t14), "=v"(t15), LW_ACC_RW);                                             \
-        acc[I][0] = make_uint2(pack_bf16x2(t0, t1), pack_bf16x2(t2, t3));      /* rounded to the stored type at once: half the registers */ \
-        acc[I][1] = make_uint2(pack_bf16x2(t4, t5), pack_bf16x2(t6, t7));                                                             \
-        acc[I][2] = make_uint2(pack_bf16x2(t8, t9), pack_bf16x2(t10, t11));                                                           \
-        acc[I][3] = make_uint2(pack_bf16x2(t12, t13), pack_bf16x2(t14, t15));                                                         \
+        acc[I][0] = make_uint2(pack_bf16x2_v(t0, t1), pack_bf16x2_v(t2, t3));      /* rounded to the stored type at once: half the registers */ \
+        acc[I][1] = make_uint2(pack_bf16x2_v(t4, t5), pack_bf16x2_v(t6, t7));                                                             \
+        acc[I][2] = make_uint2(pack_bf16x2_v(t8, t9), pack_bf16x2_v(t10, t11));                                                           \
+        acc[I][3] = make_uint2(pack_bf16x2_v(t12, t13), pack_bf16x2_v(t14, t15));                                                         \
     }
         {
             uint2 acc[8][4];
             LW_RD(0, 0) LW_RD(1, 0) LW_RD(2, 0) LW_RD(3, 0) LW_RD(4, 0) LW_RD(5, 0) LW_RD(6, 0) LW_RD(7, 0)
-            ig_epilogue_rows16<8, NOPS_, 1>(p, patch, acc, mw, nw, lane);
+            if (p.ep.out_raw && p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 2, uint2, 3>(p, patch, acc, mw, nw, lane);
+            else if (p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 2, uint2, 2>(p, patch, acc, mw, nw, lane);
+            else ig_epilogue_rows16<8, NOPS_, 2, uint2, 1>(p, patch, acc, mw, nw, lane);
         }
         {
             uint2 acc[8][4];
             LW_RD(0, 1) LW_RD(1, 1) LW_RD(2, 1) LW_RD(3, 1) LW_RD(4, 1) LW_RD(5, 1) LW_RD(6, 1) LW_RD(7, 1)
-            ig_epilogue_rows16<8, NOPS_, 1>(p, patch, acc, mw, nw + 64, lane);
+            if (p.ep.out_raw && p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 2, uint2, 3>(p, patch, acc, mw, nw + 64, lane);
+            else if (p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 2, uint2, 2>(p, patch, acc, mw, nw + 64, lane);
+            else ig_epilogue_rows16<8, NOPS_, 2, uint2, 1>(p, patch, acc, mw, nw + 64, lane);
         }
 #undef LW_RD
+        }
         if (!more) break;
         c_tile = n_tile;
         cur = nxt;
@@ -201,6 +208,130 @@ __global__ __launch_bounds__(256, 1) void conv_row_lw_kernel(const ConvParams p)
     }
 #undef LW_ACC_RW
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the staging ran ahead of the last tile: nothing may land after the wave ends
+}
+
+
+// ---- the same loop for 1x1 / stride 1 convolutions (kd_conv2d_fwd: the pointwise layers and their input gradients) -----------------
+// No row buffer: the A operand (256 pixels x 32 channels per k-step) is staged per k-step like B, four 16-KiB slots each, 8 DMA
+// pieces per wave and k-step (conv_igemm_persist_kernel<pp> stages 64 pieces per 64-deep stage through waves that also have to
+// multiply; it sits at 0.48 of peak).  Cin % 128 == 0 (whole passes over the four slots).
+template <int NOPS_>
+__global__ __launch_bounds__(256, 1) void conv_pw_lw_kernel(const ConvParams p)
+{
+    typedef unsigned long long u64;
+    constexpr int SLOT = LW_BSLOT, NEED = 8 * SLOT;
+    __shared__ __attribute__((aligned(1024))) char lds[NEED + 4 * 8192];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    TileWalk walk(p.ntiles);
+    if (walk.t >= walk.t_end) return;
+    stagger_start(p);
+    const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
+    uint32_t va, vb, voa[4], vob[4];
+    auto lane_addresses = [&]() __attribute__((always_inline)) {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int frow = l & 15, fq = l >> 4, sw = (fq ^ ((frow >> 1) & 3)) << 4;
+        va = lbase + (wm * 128 + frow) * 64 + sw;
+        vb = lbase + 4 * SLOT + (wn * 128 + frow) * 64 + sw;
+        const int srow = l >> 2, chunk = ((l & 3) ^ ((l >> 3) & 3)) << 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            voa[j] = (uint32_t)(((wv * 4 + j) * 16 + srow) * (p.ldx * 2) + chunk);
+            vob[j] = (uint32_t)(((wv * 4 + j) * 16 + srow) * (p.Ktot * 2) + chunk);
+        }
+    };
+    lane_addresses();
+    const uint32_t sldsA = __builtin_amdgcn_readfirstlane(lbase + wv * 4096);
+    const uint32_t sldsB = __builtin_amdgcn_readfirstlane(lbase + 4 * SLOT + wv * 4096);
+    auto bases = [&](int tile, int &m0, int &n0, u64 &ab, u64 &bb) {
+        int tn, tm;
+        if (p.tn_group > 0) {
+            const int per = p.tiles_m * p.tn_group, blk = tile / per, r = tile - blk * per;
+            tm = r / p.tn_group;
+            tn = blk * p.tn_group + (r - tm * p.tn_group);
+        } else {
+            tn = tile % p.tiles_n;
+            tm = tile / p.tiles_n;
+        }
+        m0 = tm * 256;
+        n0 = tn * 256;
+        ab = (u64)p.x + (u64)(2ll * (long long)m0 * p.ldx);
+        bb = (u64)p.w + (u64)(2ll * (long long)n0 * p.Ktot);
+    };
+    int c_tile = walk.t, m0, n0, m0n, n0n;
+    u64 ab, bb, abn, bbn;
+    bases(c_tile, m0, n0, ab, bb);
+    // prologue: k-steps 0 .. 3 of the first tile
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16((const char *)ab + q * 64 + voa[j], lds + q * SLOT + (wv * 4 + j) * 1024);
+            glds16((const char *)bb + q * 64 + vob[j], lds + (4 + q) * SLOT + (wv * 4 + j) * 1024);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    typedef __attribute__((ext_vector_type(32))) float f32x32_t;
+    f32x32_t A0, A1, A2, A3, A4, A5, A6, A7;   // the accumulator file is occupied (see conv_row_lw_kernel)
+    asm volatile(LW_ZERO_ACC_ASM : "=a"(A0), "=a"(A1), "=a"(A2), "=a"(A3), "=a"(A4), "=a"(A5), "=a"(A6), "=a"(A7));
+#define LW_ACC_RW "+a"(A0), "+a"(A1), "+a"(A2), "+a"(A3), "+a"(A4), "+a"(A5), "+a"(A6), "+a"(A7)
+    const uint32_t nit = (uint32_t)(p.nk / 2);   // passes of four 32-channel k-steps (p.nk counts 64-channel stages)
+    uint32_t flag = 0;
+#pragma unroll 1
+    for (;;) {
+        lane_addresses();
+        asm volatile(LW1_REFILL_ASM : : [va] "v"(va), [vb] "v"(vb) : "memory", LW_CLOBBER_FRAG);
+        const int n_tile = c_tile + walk.step;
+        const bool more = n_tile < walk.t_end;
+        if (more) bases(n_tile, m0n, n0n, abn, bbn);
+        else { abn = ab; bbn = bb; }             // nothing left to stage: re-stage this tile's first k-steps (valid memory, unread)
+        const u64 sA = ab + 256, sB = bb + 256;
+        asm volatile(LW1_TILE_ASM
+                     : LW_ACC_RW
+                     : [va] "v"(va), [vb] "v"(vb), [voa0] "v"(voa[0]), [voa1] "v"(voa[1]), [voa2] "v"(voa[2]), [voa3] "v"(voa[3]),
+                       [vob0] "v"(vob[0]), [vob1] "v"(vob[1]), [vob2] "v"(vob[2]), [vob3] "v"(vob[3]), [sA] "s"(sA), [sB] "s"(sB),
+                       [sAT] "s"(abn), [sBT] "s"(bbn), [snit] "s"(nit), [sflag] "s"(flag), [sldsA] "s"(sldsA), [sldsB] "s"(sldsB)
+                     : "memory", "scc", LW_CLOBBER_S, LW_CLOBBER_FRAG);
+        asm volatile("s_nop 15\n\ts_nop 15" : LW_ACC_RW : : "memory");
+        if (!(p.tune & 64)) {
+        const int mw = m0 + wm * 128, nw = n0 + wn * 128;
+        char *patch = lds + NEED + wv * 8192;
+#define LW_RD(I, JG)                                                                                                                  \
+    {                                                                                                                                 \
+        float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14, t15;                                                   \
+        asm volatile(LW_READ_ACC_##I##_##JG##_ASM                                                                                     \
+                     : "=v"(t0), "=v"(t1), "=v"(t2), "=v"(t3), "=v"(t4), "=v"(t5), "=v"(t6), "=v"(t7), "=v"(t8), "=v"(t9), "=v"(t10), \
+                       "=v"(t11), "=v"(t12), "=v"(t13), "=v"(t14), "=v"(t15), LW_ACC_RW);                                             \
+        acc[I][0] = make_uint2(pack_bf16x2_v(t0, t1), pack_bf16x2_v(t2, t3));                                                             \
+        acc[I][1] = make_uint2(pack_bf16x2_v(t4, t5), pack_bf16x2_v(t6, t7));                                                             \
+        acc[I][2] = make_uint2(pack_bf16x2_v(t8, t9), pack_bf16x2_v(t10, t11));                                                           \
+        acc[I][3] = make_uint2(pack_bf16x2_v(t12, t13), pack_bf16x2_v(t14, t15));                                                         \
+    }
+        {
+            uint2 acc[8][4];
+            LW_RD(0, 0) LW_RD(1, 0) LW_RD(2, 0) LW_RD(3, 0) LW_RD(4, 0) LW_RD(5, 0) LW_RD(6, 0) LW_RD(7, 0)
+            if (p.ep.out_raw && p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 4, uint2, 3>(p, patch, acc, mw, nw, lane);
+            else if (p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 4, uint2, 2>(p, patch, acc, mw, nw, lane);
+            else ig_epilogue_rows16<8, NOPS_, 4, uint2, 1>(p, patch, acc, mw, nw, lane);
+        }
+        {
+            uint2 acc[8][4];
+            LW_RD(0, 1) LW_RD(1, 1) LW_RD(2, 1) LW_RD(3, 1) LW_RD(4, 1) LW_RD(5, 1) LW_RD(6, 1) LW_RD(7, 1)
+            if (p.ep.out_raw && p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 4, uint2, 3>(p, patch, acc, mw, nw + 64, lane);
+            else if (p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 4, uint2, 2>(p, patch, acc, mw, nw + 64, lane);
+            else ig_epilogue_rows16<8, NOPS_, 4, uint2, 1>(p, patch, acc, mw, nw + 64, lane);
+        }
+#undef LW_RD
+        }
+        if (!more) break;
+        c_tile = n_tile;
+        m0 = m0n; n0 = n0n; ab = abn; bb = bbn;
+        flag = 1;
+    }
+#undef LW_ACC_RW
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 }  // namespace
@@ -215,6 +346,20 @@ bool kd_launch_conv_row_lw(const ConvParams &p, int nops_sums, unsigned grid, hi
     case 3: hipLaunchKernelGGL((conv_row_lw_kernel<3>), g, b, 0, s, p); return true;
     case 5: hipLaunchKernelGGL((conv_row_lw_kernel<5>), g, b, 0, s, p); return true;
     case 6: hipLaunchKernelGGL((conv_row_lw_kernel<6>), g, b, 0, s, p); return true;
+    default: return false;
+    }
+}
+
+bool kd_launch_conv_pw_lw(const ConvParams &p, int nops_sums, unsigned grid, hipStream_t s)
+{
+    const dim3 g(grid), b(256);
+    switch (nops_sums) {
+    case 0: hipLaunchKernelGGL((conv_pw_lw_kernel<0>), g, b, 0, s, p); return true;
+    case 1: hipLaunchKernelGGL((conv_pw_lw_kernel<1>), g, b, 0, s, p); return true;
+    case 2: hipLaunchKernelGGL((conv_pw_lw_kernel<2>), g, b, 0, s, p); return true;
+    case 3: hipLaunchKernelGGL((conv_pw_lw_kernel<3>), g, b, 0, s, p); return true;
+    case 5: hipLaunchKernelGGL((conv_pw_lw_kernel<5>), g, b, 0, s, p); return true;
+    case 6: hipLaunchKernelGGL((conv_pw_lw_kernel<6>), g, b, 0, s, p); return true;
     default: return false;
     }
 }

@@ -4,7 +4,7 @@ in a[0:255] across compiler-generated code (the epilogue reads them back with v_
   * no compiler-generated instruction anywhere in the kernel may touch an accumulator register -- a spill into that range
     would be silent corruption;
   * every MFMA of a kernel sits in ONE inline-asm statement (all periods of a tile: the fragment registers v[128:255] never
-    live across compiler code), 768 of them (two period bodies);
+    live across compiler code): 896 in the 3x3 kernel (two period bodies + two zero-C first k-steps), 320 in the 1x1 kernel;
   * no scratch (private segment) in the instantiation without epilogue operands.
 usage: check_lw_asm.py [conv_lw.s]   (without an argument compiles csrc/conv_lw.hip to assembly first); exit 1 on a finding."""
 import os
@@ -23,7 +23,7 @@ LABEL = re.compile(r"^(\.?[A-Za-z_][\w.$]*):")
 
 def audit(text):
     findings = []
-    bodies = re.split(r"^(_ZN\S*conv_row_lw_kernel\S*):\s*;[^\n]*\n", text, flags=re.M)
+    bodies = re.split(r"^(_ZN\S*conv_(?:row|pw)_lw_kernel\S*):\s*;[^\n]*\n", text, flags=re.M)
     n_kernels = 0
     for k in range(1, len(bodies), 2):
         name, code = bodies[k], bodies[k + 1].split(".Lfunc_end")[0]
@@ -56,8 +56,9 @@ def audit(text):
                 findings.append(f"{name}: compiler instruction touches an accumulator register: {it[1].strip()}")
         # 2. all MFMAs in one statement
         mf = [it[2].count("v_mfma") for it in items if it[0] == "asm" and "v_mfma" in it[2]]
-        if mf != [768]:
-            findings.append(f"{name}: expected one inline-asm statement with the 768 MFMAs of the two period bodies, found {mf}")
+        want = [320] if "conv_pw_lw" in name else [896]      # 1x1: one pass over the four slots; 3x3: two period bodies; + the zero-C first k-step(s)
+        if mf != want:
+            findings.append(f"{name}: expected one inline-asm statement with {want[0]} MFMAs, found {mf}")
         if any(it[0] == "ins" and "v_mfma" in it[1] for it in items):
             findings.append(f"{name}: compiler-generated MFMA")
         if "ILi0E" in name:
@@ -65,7 +66,7 @@ def audit(text):
             if m and int(m.group(1)) != 0:
                 findings.append(f"{name}: scratch in the no-operand instantiation ({m.group(1)} B)")
     if n_kernels == 0:
-        findings.append("no conv_row_lw_kernel found in the assembly")
+        findings.append("no conv_row_lw_kernel / conv_pw_lw_kernel found in the assembly")
     return findings, n_kernels
 
 

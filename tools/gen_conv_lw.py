@@ -52,7 +52,8 @@ def frag_regs(s):
     return [base + 4 * i for i in range(8)], [base + 32 + 4 * j for j in range(8)]
 
 
-def kstep(par, p):
+def kstep(par, p, zero=False):
+    """zero: the tile's first k-step -- the MFMAs take 0 as their C operand (the accumulators still hold the previous tile)"""
     cur = p & 1
     areg, breg = frag_regs(cur)
     nareg, nbreg = frag_regs(1 - cur)
@@ -94,15 +95,16 @@ def kstep(par, p):
     for i in range(8):
         for j in range(8):
             acc = 4 * (8 * i + j)
-            L.append(f"v_mfma_f32_16x16x32_bf16 a[{acc}:{acc + 3}], v[{breg[j]}:{breg[j] + 3}], v[{areg[i]}:{areg[i] + 3}], a[{acc}:{acc + 3}]")
+            L.append(f"v_mfma_f32_16x16x32_bf16 a[{acc}:{acc + 3}], v[{breg[j]}:{breg[j] + 3}], v[{areg[i]}:{areg[i] + 3}], " + ("0" if zero else f"a[{acc}:{acc + 3}]"))
             L += slots[k]
             k += 1
     n = ISSUED[p] + ISSUED[p - 1]          # (p = 0: the previous period's last k-step)
+    tag = f"{par}{p}z" if zero else f"{par}{p}"
     if p < 2:
         # right after an epilogue its stores are younger than the pieces this wait is for and older than this period's: leave
         # them outstanding (the counter saturates at 63)
-        L += [f"s_cmp_eq_u32 {SFLAG}, 0", f"s_cbranch_scc1 LWN{par}{p}_%=", "s_waitcnt vmcnt(63) lgkmcnt(0)", f"s_branch LWD{par}{p}_%=",
-              f"LWN{par}{p}_%=:", f"s_waitcnt vmcnt({n}) lgkmcnt(0)", f"LWD{par}{p}_%=:"]
+        L += [f"s_cmp_eq_u32 {SFLAG}, 0", f"s_cbranch_scc1 LWN{tag}_%=", "s_waitcnt vmcnt(63) lgkmcnt(0)", f"s_branch LWD{tag}_%=",
+              f"LWN{tag}_%=:", f"s_waitcnt vmcnt({n}) lgkmcnt(0)", f"LWD{tag}_%=:"]
         if p == 1:
             L.append(f"s_mov_b32 {SFLAG}, 0")
     else:
@@ -126,13 +128,19 @@ def step_iterator(par):
 def tile():
     L = ["s_mov_b32 s90, m0", f"s_mov_b64 {SB}, %[sBp]", f"s_mov_b64 {SAN}, %[sAn]", f"s_mov_b64 {SBN}, %[sBn]",
          f"s_mov_b32 {SLO}, %[slo]", f"s_mov_b32 {SSPAN}, %[ssp]", f"s_mov_b32 {SKY}, 1", f"s_sub_u32 {SIN}, %[snper], 1",
-         f"s_mov_b32 {SCNT}, %[snper]", f"s_mov_b32 {SFLAG}, %[sflag]", "s_cmp_eq_u32 %[spar], 0", "s_cbranch_scc0 LWODD_%=",
+         f"s_mov_b32 {SCNT}, %[snper]", f"s_mov_b32 {SFLAG}, %[sflag]", "s_cmp_eq_u32 %[spar], 0", "s_cbranch_scc0 LWODDZ_%=",
+         # the tile's first k-step multiplies into zero, then joins the period body behind its first k-step
+         ] + kstep(0, 0, True) + ["s_branch LWEVEN1_%=", "LWODDZ_%=:"] + kstep(1, 0, True) + ["s_branch LWODD1_%=",
          "LWEVEN_%=:"]
     for p in range(6):
         L += kstep(0, p)
+        if p == 0:
+            L.append("LWEVEN1_%=:")
     L += step_iterator(0) + [f"s_sub_u32 {SCNT}, {SCNT}, 1", f"s_cmp_eq_u32 {SCNT}, 0", "s_cbranch_scc1 LWEND_%=", "LWODD_%=:"]
     for p in range(6):
         L += kstep(1, p)
+        if p == 0:
+            L.append("LWODD1_%=:")
     L += step_iterator(1) + [f"s_sub_u32 {SCNT}, {SCNT}, 1", f"s_cmp_lg_u32 {SCNT}, 0", "s_cbranch_scc1 LWEVEN_%=", "LWEND_%=:",
                              f"s_mov_b64 %[sBp], {SB}", "s_mov_b32 m0, s90"]
     return L
@@ -149,8 +157,72 @@ def refill():
 
 def read_acc(i, jg):
     regs = [4 * (8 * i + 4 * jg + jj) + r for jj in range(4) for r in range(4)]
-    L = [f"v_accvgpr_read_b32 %{n}, a{a}" for n, a in enumerate(regs)]
-    L += [f"v_accvgpr_write_b32 a{a}, 0" for a in regs]
+    return [f"v_accvgpr_read_b32 %{n}, a{a}" for n, a in enumerate(regs)]      # (the next tile's first k-step multiplies into zero)
+
+
+# ---- 1x1 / stride 1 (conv_pw_lw_kernel): no row buffer, the A operand is staged per k-step like B ------------------------------------
+# LDS: four A slots of 256 pixels x 64 B, then four B slots of 256 channels x 64 B.  Per k-step h: 64 MFMAs, the 16 fragment reads of
+# k-step h + 1 (slots (h + 1) & 3), 4 + 4 DMA pieces of k-step h + 4 into slots h & 3, vmcnt(16) + barrier.  The loop body is four
+# k-steps (one pass over the slots); the staging pointers run 4 k-steps ahead and move to the NEXT tile's operands before the last pass.
+SPA, SPB = "s[76:77]", "s[78:79]"     # running A / B source pointers (k-step h + 4)
+
+
+def kstep_1x1(p, zero=False):
+    cur = p & 1
+    areg, breg = frag_regs(cur)
+    nareg, nbreg = frag_regs(1 - cur)
+    slots = [[] for _ in range(64)]
+    sn, sc = (p + 1) & 3, p & 3
+    reads = [f"ds_read_b128 v[{nareg[i]}:{nareg[i] + 3}], %[va] offset:{sn * BSLOT + i * 1024}" for i in range(8)]
+    reads += [f"ds_read_b128 v[{nbreg[j]}:{nbreg[j] + 3}], %[vb] offset:{sn * BSLOT + j * 1024}" for j in range(8)]
+    for r, ins in enumerate(reads):
+        slots[1 + 3 * r].append(ins)
+    for j, k in enumerate((3, 17, 31, 45)):
+        slots[k] += [f"s_add_u32 m0, %[sldsA], {sc * BSLOT + j * 1024}", "s_nop 0", f"global_load_lds_dwordx4 %[voa{j}], {SPA}"]
+    for j, k in enumerate((10, 24, 38, 52)):
+        slots[k] += [f"s_add_u32 m0, %[sldsB], {sc * BSLOT + j * 1024}", "s_nop 0", f"global_load_lds_dwordx4 %[vob{j}], {SPB}"]
+    slots[54] += ["s_add_u32 s76, s76, 64", "s_addc_u32 s77, s77, 0", "s_add_u32 s78, s78, 64", "s_addc_u32 s79, s79, 0"]
+    L = []
+    k = 0
+    for i in range(8):
+        for j in range(8):
+            acc = 4 * (8 * i + j)
+            L.append(f"v_mfma_f32_16x16x32_bf16 a[{acc}:{acc + 3}], v[{breg[j]}:{breg[j] + 3}], v[{areg[i]}:{areg[i] + 3}], " + ("0" if zero else f"a[{acc}:{acc + 3}]"))
+            L += slots[k]
+            k += 1
+    tag = f"{p}z" if zero else f"{p}"
+    if p < 2:
+        L += [f"s_cmp_eq_u32 {SFLAG}, 0", f"s_cbranch_scc1 LPN{tag}_%=", "s_waitcnt vmcnt(63) lgkmcnt(0)", f"s_branch LPD{tag}_%=",
+              f"LPN{tag}_%=:", "s_waitcnt vmcnt(16) lgkmcnt(0)", f"LPD{tag}_%=:"]
+        if p == 1:
+            L.append(f"s_mov_b32 {SFLAG}, 0")
+    else:
+        L.append("s_waitcnt vmcnt(16) lgkmcnt(0)")
+    L.append("s_barrier")
+    return L
+
+
+def tile_1x1():
+    L = ["s_mov_b32 s90, m0", f"s_mov_b64 {SPA}, %[sA]", f"s_mov_b64 {SPB}, %[sB]", f"s_mov_b32 {SCNT}, %[snit]", f"s_mov_b32 {SFLAG}, %[sflag]",
+         "s_cmp_lg_u32 %[snit], 1", "s_cbranch_scc1 LPSAMEZ_%=", f"s_mov_b64 {SPA}, %[sAT]", f"s_mov_b64 {SPB}, %[sBT]", "LPSAMEZ_%=:",
+         # the tile's first k-step multiplies into zero, then joins the loop body behind its first k-step
+         ] + kstep_1x1(0, True) + ["s_branch LPLOOP1_%=",
+         "LPLOOP_%=:",
+         # the last pass stages the next tile's first four k-steps
+         f"s_cmp_lg_u32 {SCNT}, 1", "s_cbranch_scc1 LPSAME_%=", f"s_mov_b64 {SPA}, %[sAT]", f"s_mov_b64 {SPB}, %[sBT]", "LPSAME_%=:"]
+    for p in range(4):
+        L += kstep_1x1(p)
+        if p == 0:
+            L.append("LPLOOP1_%=:")
+    L += [f"s_sub_u32 {SCNT}, {SCNT}, 1", f"s_cmp_lg_u32 {SCNT}, 0", "s_cbranch_scc1 LPLOOP_%=", "s_mov_b32 m0, s90"]
+    return L
+
+
+def refill_1x1():
+    areg, breg = frag_regs(0)
+    L = [f"ds_read_b128 v[{areg[i]}:{areg[i] + 3}], %[va] offset:{i * 1024}" for i in range(8)]
+    L += [f"ds_read_b128 v[{breg[j]}:{breg[j] + 3}], %[vb] offset:{j * 1024}" for j in range(8)]
+    L += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
     return L
 
 
@@ -163,6 +235,8 @@ def main():
          "// The hand-scheduled main loop of conv_row_lw_kernel; see the generator for the schedule.", ""]
     o += ["#define LW_TILE_ASM \\", cstr(tile()), ""]
     o += ["#define LW_REFILL_ASM \\", cstr(refill()), ""]
+    o += ["#define LW1_TILE_ASM \\", cstr(tile_1x1()), ""]
+    o += ["#define LW1_REFILL_ASM \\", cstr(refill_1x1()), ""]
     for i in range(8):
         for jg in range(2):
             o += [f"#define LW_READ_ACC_{i}_{jg}_ASM \\", cstr(read_acc(i, jg)), ""]

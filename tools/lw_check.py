@@ -28,6 +28,15 @@ CASES = [
     ("final 320->256", 512, 1024, 320, 256, 1, (), ("act",)),
     ("final 256->256", 512, 1024, 256, 256, 1, ("pre", "mask", "post"), ("raw", "act")),
     ("small 64->512 d2", 80, 512, 64, 512, 2, ("pre", "post"), ("act",)),
+    # 1x1 (dil 0 marks them): conv_pw_lw_kernel against conv_igemm_persist_kernel<pp>
+    ("pw 512->512", 128, 256, 512, 512, 0, (), ("act",)),
+    ("pw 1024->2048", 128, 256, 1024, 2048, 0, (), ("raw", "act")),
+    ("pw 2048->4096", 128, 256, 2048, 4096, 0, ("pre",), ("raw", "act")),
+    ("pw 4096->2048", 128, 256, 4096, 2048, 0, ("mask", "post"), ("raw",)),
+    ("pw 2048->1024", 128, 256, 2048, 1024, 0, ("mask",), ("raw",)),
+    ("pw 256->4096", 128, 256, 256, 4096, 0, (), ("act",)),
+    ("pw 1280->256", 128, 256, 1280, 256, 0, (), ("act",)),
+    ("pw 128->256 x3", 256, 512, 128, 256, 0, ("pre", "mask", "post"), ("raw", "act")),
 ]
 
 
@@ -42,7 +51,8 @@ def child(a):
         g = torch.Generator(device="cuda").manual_seed(zlib.crc32(name.encode()) & 0xffff)
         rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
         x = rn(a.batch, H, W, Cin).relu().bfloat16()
-        w = (rn(Cout, 3, 3, Cin) * (2.0 / (9 * Cin)) ** 0.5).bfloat16()
+        k = 3 if d else 1
+        w = (rn(Cout, k, k, Cin) * (2.0 / (k * k * Cin)) ** 0.5).bfloat16()
         kw = {}
         if "pre" in opnds:
             kw["res_pre"] = rn(a.batch, H, W, Cout).bfloat16()
@@ -56,18 +66,18 @@ def child(a):
         if act is not None:
             kw.update(act_scale=torch.rand(Cout, device="cuda", generator=g) + 0.5, act_shift=rn(Cout) * 0.1, act_relu=True)
         with _lib.kernel_log() as log:
-            ops.conv2d(x, w, 1, d, d, out_raw=raw, out_act=act, **kw)
+            ops.conv2d(x, w, 1, d, max(d, 1), out_raw=raw, out_act=act, **kw)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(a.iters):
-            ops.conv2d(x, w, 1, d, d, out_raw=raw, out_act=act, **kw)
+            ops.conv2d(x, w, 1, d, max(d, 1), out_raw=raw, out_act=act, **kw)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
         dig = [hashlib.sha256(t.cpu().view(torch.int16).numpy().tobytes()).hexdigest()[:16] for t in (raw, act) if t is not None]
         fin = all(bool(torch.isfinite(t.float()).all()) for t in (raw, act) if t is not None)
-        res[name] = {"ms": ms, "tflops": 2.0 * a.batch * H * W * Cout * 9 * Cin / ms / 1e9, "digest": dig, "finite": fin,
+        res[name] = {"ms": ms, "tflops": 2.0 * a.batch * H * W * Cout * k * k * Cin / ms / 1e9, "digest": dig, "finite": fin,
                      "kernel": [k for k, v in log.counts.items() if v], "absmean": float((act if act is not None else raw).float().abs().mean())}
     print("RESULT " + json.dumps(res))
 
@@ -83,7 +93,7 @@ def main():
         return child(a)
     out = {}
     for lw in ("1", "0"):
-        env = dict(os.environ, KDCC_CONV_LW=lw)
+        env = dict(os.environ, KDCC_CONV_LW=lw, KDCC_CONV_LW_PW="1")
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--batch", str(a.batch), "--iters", str(a.iters),
                             "--only", a.only], env=env, capture_output=True, text=True, timeout=900)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
