@@ -1559,6 +1559,20 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
                "kd_conv2d_fwd: bn_sums is not produced by the kernel this problem selects (ask kd_conv2d_bn_sums_rows first)");
     if (ep->bn_sums) KD_NOTE_KERNEL("bn_sums_epilogue");   // (kernel-selection log: counted next to the kernel that carries it)
     hipStream_t s = (hipStream_t)stream;
+    // Workgroups of the persistent kernels (one per CU, each walks tiles for 1-6 ms).  KDCC_PERSIST_CUS=n (a multiple of 8,
+    // e.g. 248) leaves CUs free for a concurrent kernel -- the RCCL all-reduce the gradient reducer launches on its side stream
+    // from inside backward -- which otherwise only gets a CU between two conv launches.  Results do not depend on it: a tile's
+    // arithmetic is the same whichever workgroup computes it (tests/test_ddp_gpu.py).
+    auto persist_cus = [&]() {
+        static int n = -1;
+        if (n < 0) {
+            const char *v = getenv("KDCC_PERSIST_CUS");
+            n = v ? atoi(v) : 0;
+            if (n < 8 || n > ncu) n = ncu;
+            n -= n % 8;
+        }
+        return n;
+    };
     auto launch = [&](auto cf, auto tag) {
         using CF = decltype(cf);
         using T = decltype(tag);
@@ -1579,7 +1593,7 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         // the whole launch instead of cycling all 8-16 of them per round of tiles; +3-4 % on the 4096-wide 1x1 layers
         if (tng < 0) { const char *v = getenv("KDCC_CONV_TNGROUP"); tng = v ? atoi(v) : 4; }
         p.tn_group = (tng > 0 && p.tiles_n > tng && p.tiles_n % tng == 0) ? tng : 0;
-        const int nwg = p.ntiles < ncu ? p.ntiles : ncu;
+        const int nwg = p.ntiles < persist_cus() ? p.ntiles : persist_cus();
         return dim3((unsigned)((nwg + 7) / 8 * 8));
     };
     if (sel.use_row_persist) {
@@ -1644,7 +1658,7 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         p.tiles_m = p.M / 512;
         p.ntiles = p.tiles_m * p.tiles_n;
         p.tn_group = 0;
-        const int nwg = p.ntiles < ncu ? p.ntiles : ncu;
+        const int nwg = p.ntiles < persist_cus() ? p.ntiles : persist_cus();
         const dim3 grid((unsigned)((nwg + 7) / 8 * 8));
         KD_NOTE_KERNEL("conv_row_pp128_kernel");
         if (p.tune & 512) hipLaunchKernelGGL((conv_row_pp128_kernel<0, true>), grid, dim3(512), 0, s, p);   // phase clocks (no-operand form only)

@@ -184,7 +184,12 @@ class StudentEngine:
         def make():
             w = conv.weight if not cin_rot else torch.cat([conv.weight.detach()[:, cin_rot:], conv.weight.detach()[:, :cin_rot]], 1).contiguous()
             if gate is not None:   # y * g[c] == conv with the filters of output channel c scaled by g[c]
-                w = w.detach().float() * gate.weight.detach().float().view(-1, 1, 1, 1)
+                gv = gate.weight.detach().float()
+                if not bool((gv != 0).all()):   # one host sync per gate update (the pack is cached on the gate's version)
+                    raise EngineError("a gate folded into a conv's weights has a zero entry: d loss / d gate is recovered from the "
+                                      "gated output by a division (_probe), which a zero gate makes undefined (gates start at 1 and "
+                                      "the reference's optimizer moves them by ~1e-5 per step)")
+                w = w.detach().float() * gv.view(-1, 1, 1, 1)
             if cout_pad is not None and cout_pad > w.shape[0]:
                 wp = torch.zeros((cout_pad,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
                 wp[:w.shape[0]] = w.detach()

@@ -379,7 +379,7 @@ def dwconv_wgrad_multi(x, dys, dws, k, pad, dil, accumulate=False):
     d = _dw_desc(x, k, pad, dil)
     n = len(dys)
     need = _lib.lib().kd_dwconv_wgrad_multi_workspace(C.byref(d), n)
-    workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+    workspace = _ws(need, x.device)
     yp = (C.c_void_p * n)(*[_ptr(t) for t in dys])
     wp = (C.c_void_p * n)(*[_ptr(t) for t in dws])
     e0 = _prof_start()

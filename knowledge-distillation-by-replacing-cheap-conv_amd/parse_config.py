@@ -58,11 +58,19 @@ class ConfigParser:
         # directory: it creates both directories and writes config.json FIRST, the other ranks wait at the barrier and only
         # then make sure the directories exist (without that order a non-zero rank's mkdir could win the race and rank 0's
         # exist_ok=False would kill the job)
+        # ... and if rank 0 fails there (run-id collision, permissions, a full disk) every rank raises the SAME error instead of
+        # sitting in a barrier until the process-group timeout: rank 0 broadcasts what happened
+        err = None
         if rank == 0:
-            for d in (self._save_dir, self._log_dir):
-                d.mkdir(parents=True, exist_ok=not fresh and run_id == '')
-            write_json(config, self._save_dir / 'config.json')
-        parallel.barrier()
+            try:
+                for d in (self._save_dir, self._log_dir):
+                    d.mkdir(parents=True, exist_ok=not fresh and run_id == '')
+                write_json(config, self._save_dir / 'config.json')
+            except OSError as e:
+                err = f'{type(e).__name__}: {e}'
+        err = parallel.broadcast_object(err)
+        if err is not None:
+            raise RuntimeError(f'rank 0 could not create the run directory {self._save_dir}: {err}')
         if rank != 0:
             for d in (self._save_dir, self._log_dir):
                 d.mkdir(parents=True, exist_ok=True)

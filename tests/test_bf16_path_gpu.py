@@ -122,6 +122,76 @@ def test_bf16_p92_step_on_the_shipped_kernels_vs_network_oracle():
     assert not bad, bad
 
 
+P79 = ["mod4.block2.convs.conv2", "mod4.block3.convs.conv1", "mod4.block3.convs.conv2", "mod4.block4.convs.conv2",
+       "mod4.block5.convs.conv2", "mod4.block6.convs.conv2", "mod5.block2.convs.conv2", "mod7.block1.convs.conv2",
+       "aspp.features.1.0", "aspp.features.2.0", "aspp.features.3.0"]      # cfg/cityscapes/58M_deeplab_all.json:123-168
+
+
+def _check_step(model, r, hint, kd, out_st, out_tc, n_grads, what):
+    errs = {"student logits": _rel_l2(out_st, r["student_logits"]), "teacher logits": _rel_l2(out_tc, r["teacher_logits"])}
+    for i, (s, t) in enumerate(zip(model.student_hidden_outputs, model.teacher_hidden_outputs)):
+        errs[f"student hint {i}"] = _rel_l2(s, r["student_hints"][i])
+        errs[f"teacher hint {i}"] = _rel_l2(t, r["teacher_hints"][i])
+    rows = _grad_report(model, r["grads"])
+    print(what, {k: f"{v:.2e}" for k, v in errs.items()}, "hint", hint.item(), r["hint_loss"].item(),
+          "worst gradients", sorted(rows, key=lambda t: t[1])[:3])
+    # the bars of the P92 test: logits 1e-2, hints 2e-2 relative L2, hint loss 5e-3, gradient cosine 0.9995, norm within 1 %
+    assert errs["student logits"] < 1e-2 and errs["teacher logits"] < 1e-2 and max(errs.values()) < 2e-2, errs
+    assert abs(hint.item() - r["hint_loss"].item()) <= 5e-3 * abs(r["hint_loss"].item())
+    assert abs(kd.item() - r["kd_loss"].item()) <= 5e-2 * abs(r["kd_loss"].item()) + 1e-6
+    assert len(rows) == n_grads
+    bad = [(n, c, q) for n, c, q in rows if c < 0.9995 or abs(q - 1) > 0.01]
+    assert not bad, bad
+
+
+def test_bf16_weighted_hint_step_vs_network_oracle():
+    """BASELINE config 4 on the measured path: WeightedHintMSELoss (losses/WeightedHintMSELoss.py:12-16 of the reference) with
+    filter_weight = rand(C), generator seed 7 + hint index (what trainer.hint_filter_weight = 'rand:7' gives), plan P92, bf16,
+    1 x 256 x 2048 (the persistent kernels are selected), against oracle/net_ref.kd_step(hint_weights=...)."""
+    from kdcc_amd import _lib, losses
+    from oracle import net_ref
+    model = _build(P92, BF)
+    x = seeded_input("bf16.whint.x", (1, 3, 256, 2048))
+    with _lib.kernel_log() as log:
+        out_st, out_tc = model(x.cuda())
+        crit = losses.WeightedHintMSELoss()
+        ws = [torch.rand(s.shape[1], generator=torch.Generator().manual_seed(7 + i)) for i, s in enumerate(model.student_hidden_outputs)]
+        hint = 0
+        for i, (s, t) in enumerate(zip(model.student_hidden_outputs, model.teacher_hidden_outputs)):
+            hint = hint + crit(s, t, ws[i].cuda())
+        kd = losses.KLDivergenceLoss(1)(out_st, out_tc)
+        hint.backward()
+        torch.cuda.synchronize()
+    for k in ("conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>", "dw_mfma_fwd_kernel<3,true>", "dw_mfma_wgrad_multi_kernel<3>"):
+        assert log.counts.get(k, 0) > 0, (k, log.counts)
+    tsd = seeded_teacher_sd()
+    ssd = net_ref.make_student_sd(tsd, P92, seeded_cheap_weights(tsd, P92))
+    _threads()
+    r = net_ref.kd_step(tsd, ssd, x, None, P92, hint_weights=ws)
+    _check_step(model, r, hint, kd, out_st, out_tc, 12, "bf16 weighted hints 1x256x2048 vs net_ref:")
+
+
+def test_bf16_p79_step_vs_network_oracle():
+    """The shipped 58M plan (cfg/cityscapes/58M_deeplab_all.json: eleven cheap-conv blocks incl. mod5.block2's dw-512 -> pw-1024
+    and five more mod4 blocks) in bf16 at 1 x 256 x 2048, hint MSE, against oracle/net_ref.py: all 22 gradients."""
+    from kdcc_amd import _lib
+    from oracle import net_ref
+    model = _build(P79, BF)
+    x = seeded_input("bf16.p79.x", (1, 3, 256, 2048))
+    model._x = x.cuda()
+    with _lib.kernel_log() as log:
+        out_st, out_tc, hint, kd, _ = _step(model)
+    for k in ("conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>", "dw_mfma_fwd_kernel<1,false>", "dw_mfma_wgrad_kernel"):
+        assert log.counts.get(k, 0) > 0, (k, log.counts)
+    assert log.counts["dw_mfma_fwd_kernel<1,false>"] >= 8          # the eight trunk blocks' depthwise forwards
+    tsd = seeded_teacher_sd()
+    ssd = net_ref.make_student_sd(tsd, P79, seeded_cheap_weights(tsd, P79))
+    _threads()
+    r = net_ref.kd_step(tsd, ssd, x, None, P79)
+    assert model.student_hint_names == r["hint_names"]
+    _check_step(model, r, hint, kd, out_st, out_tc, 22, "bf16 P79 1x256x2048 vs net_ref:")
+
+
 def test_bf16_mode_b_step_on_the_shipped_kernels_vs_network_oracle():
     """Mode B (loss = KLDiv + hints, every student parameter trainable) in bf16 at 1 x 256 x 2048: the row-buffer / wide dense
     weight-gradient kernels, the strided dgrad, pools / upsamples / stem backward as wired by the engine, vs net_ref."""
@@ -215,10 +285,10 @@ def test_bf16_gscnn_step_vs_network_oracle():
 
 
 # ----------------------------------------------------------------------------------------------- the bench step itself
-def _bench_run(steps=2, share=False, batch=8, seed_data=1000):
-    """bench.py's own construction (build / kd_step, plan P92, bf16, 1024x2048) for `steps` train steps."""
+def _bench_run(steps=2, share=False, batch=8, seed_data=1000, plan="P92", mode="A", arch="deeplab"):
+    """bench.py's own construction (build / kd_step, bf16, 1024x2048) for `steps` train steps."""
     import bench
-    model, crit, opt, _ = bench.build(bench.PLANS["P92"], BF, torch.device("cuda", 0))
+    model, crit, opt, _ = bench.build(bench.PLANS[plan], BF, torch.device("cuda", 0), mode=mode, arch=arch)
     model.share_frozen_prefix = share
     g = torch.Generator().manual_seed(seed_data)
     data = torch.randn((batch, 3, 1024, 2048), generator=g).cuda()
@@ -232,7 +302,7 @@ def _bench_run(steps=2, share=False, batch=8, seed_data=1000):
         hint = 0
         for s, t in zip(model.student_hidden_outputs, model.teacher_hidden_outputs):
             hint = hint + crit[2](s, t)
-        hint.backward()
+        (kd + hint if mode == "B" else hint).backward()      # bench.kd_step: mode B back-propagates the KD term too
         if i == steps - 1:
             grads = {n: p.grad.clone() for n, p in model.student.named_parameters() if p.requires_grad}
             logits = out_st.detach().clone()
@@ -283,6 +353,36 @@ def test_fullsize_bench_step_determinism_batch_independence_and_prefix_sharing()
     for n in a["grads"]:
         assert torch.equal(a["grads"][n], c["grads"][n]), f"share_frozen_prefix changed the gradient of {n}"
     assert torch.equal(a["logits"], c["logits"])
+
+
+@pytest.mark.parametrize("name,kw,must", [
+    ("modeB", dict(mode="B"), ("conv_wgrad_row_kernel", "conv_wgrad_wide_kernel", "conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>",
+                              "conv_row_pp128_kernel", "dw_mfma_wgrad_multi_kernel<3>", "bn_sums_epilogue", "stem_wgrad_mfma_kernel")),
+    ("gscnn_P86", dict(arch="gscnn", plan="P86"), ("conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>", "conv_row_pp128_kernel",
+                                                   "conv3x3_small_kernel<64>", "gated_conv_mfma_kernel", "dw_mfma_fwd_kernel<3,true>")),
+])
+def test_fullsize_bench_subrecords_are_deterministic(name, kw, must):
+    """The other two steps bench.py times as sub-records -- mode B (loss = KLDiv + hints, every student parameter trainable) and
+    the Gated-SCNN student of BASELINE config 5 (plan P86) -- at the bench's own size, 8 x 1024 x 2048, two train steps: the
+    kernels the record's rooflines name are the ones selected, and losses, every gradient and every updated parameter are
+    bit-identical between two fresh runs."""
+    from kdcc_amd import _lib
+    with _lib.kernel_log() as log:
+        a = _bench_run(**kw)
+    missing = [k for k in must if log.counts.get(k, 0) == 0]
+    assert not missing, (name, missing, log.counts)
+    la = a["losses"]
+    assert torch.isfinite(la).all() and float(la[0, 0]) > 0 and float(la[1, 0]) != float(la[0, 0])      # the parameters moved
+    grads_a = {n: g.cpu() for n, g in a["grads"].items()}
+    params_a = {n: g.cpu() for n, g in a["params"].items()}
+    del a
+    torch.cuda.empty_cache()
+    b = _bench_run(**kw)
+    print(name, "losses (hint, supervised, kd, teacher) per step:", la.tolist())
+    assert torch.equal(la, b["losses"]), (la, b["losses"])
+    for n in grads_a:
+        assert torch.equal(grads_a[n], b["grads"][n].cpu()), f"{name}: gradient of {n} differs between two identical runs"
+        assert torch.equal(params_a[n], b["params"][n].cpu()), f"{name}: {n} differs after two identical runs"
 
 
 def test_bench_two_ranks_child_process(tmp_path):

@@ -1,5 +1,5 @@
-import sys, torch
-sys.path.insert(0, '/root/repo')
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import kdcc_amd
 from kdcc_amd import ops
 x = torch.randn(8, 3, 1024, 2048, device='cuda')
