@@ -403,6 +403,19 @@ int kd_weighted_hint_mse(const kd_view3 *s, const kd_view3 *t, const float *w, i
 int kd_ce2d(const kd_view3 *x, const int64_t *target, int32_t ignore_index, int32_t N, int32_t C, int64_t P,
             float *loss, void *workspace, size_t workspace_bytes, kd_stream_t stream);
 
+/* The two logged logit losses straight from the LOW-RESOLUTION logits: x_lo / s_lo / t_lo are the classifier's dense fp32
+ * (N,h,w,C) NHWC outputs; the value equals kd_ce2d / kd_kldiv on F.interpolate(x, (H,W), mode='bilinear', align_corners)
+ * (models/deeplabv3/deeplabv3.py:160-162 followed by losses/CrossEntropy.py:10-14 / losses/KLDiv.py:19-23), but the two
+ * full-resolution fp32 tensors are never written or read: a pixel's C logits are interpolated in registers (same expression
+ * tree as kd_upsample_bilinear).  Forward only (the logged metrics of trainer/layerwise_trainer.py:222-227); C <= 48 / C <= 24;
+ * KD_ERR_UNSUPPORTED when the resampling ratio puts more than 160 source columns under 256 output pixels (materialise then).
+ * target int64 (N,H,W); workspace as kd_loss_workspace(N, C, H*W). */
+int kd_ce2d_up(const float *x_lo, const int64_t *target, int32_t ignore_index, int32_t N, int32_t h, int32_t w, int32_t C,
+               int32_t H, int32_t W, int32_t align_corners, float *loss, void *workspace, size_t workspace_bytes,
+               kd_stream_t stream);
+int kd_kldiv_up(const float *s_lo, const float *t_lo, float temperature, int32_t N, int32_t h, int32_t w, int32_t C, int32_t H,
+                int32_t W, int32_t align_corners, float *loss, void *workspace, size_t workspace_bytes, kd_stream_t stream);
+
 /* gradient of kd_ce2d w.r.t. x (needed when the supervised loss is back-propagated: trainer/taylor_prune_trainer.py:204-206,
  * or any loss = supervised + kd + hint mix): grad[n,c,p] = grad_scale * (softmax_c(x[n,:,p]) - [c == target[n,p]]) / #valid,
  * zero for ignored pixels. */

@@ -242,6 +242,154 @@ __global__ __launch_bounds__(256) void ce2d_nhwc_kernel(const TX *__restrict__ x
     if (threadIdx.x == 0) { partial[blockIdx.x] = w1[0] + w1[1] + w1[2] + w1[3]; count[blockIdx.x] = w2[0] + w2[1] + w2[2] + w2[3]; }
 }
 
+// ---- logit losses straight from the LOW-RESOLUTION logits ---------------------------------------------------------------------------
+// The decoder's classifier produces (N,h,w,C) fp32 logits; the reference up-samples them bilinearly to the input size
+// (models/deeplabv3/deeplabv3.py:160-162) and the trainer logs CE(student), CE(teacher) and KLDiv on the full-resolution tensors
+// (trainer/layerwise_trainer.py:222-227).  Materialised, that is two 1.27-GB fp32 tensors per 8 images written once and read back by
+// three kernels (2.3 ms per step).  Here a pixel's C logits are interpolated in registers -- the expression tree of
+// upsample_flat4_kernel: horizontal blend of each source row, then the vertical blend -- from a low-resolution patch staged in LDS: a
+// workgroup takes 256 consecutive output pixels of one output row, i.e. <= UP_NW source columns of two source rows.
+constexpr int UP_NW = 160;
+
+struct UpGeom { int N, h, w, C, H, W; float sh, sw, oh, ow; };
+
+// stage rows h0 / h1, columns [wlo, wlo + nw) of image n: 2 * nw * C contiguous floats per row
+__device__ __forceinline__ void up_stage(float *sm, const float *__restrict__ x, const UpGeom &g, int n, int h0, int h1, int wlo, int nw)
+{
+    const int nel = nw * g.C;
+    const float *r0 = x + (((size_t)n * g.h + h0) * g.w + wlo) * g.C, *r1 = x + (((size_t)n * g.h + h1) * g.w + wlo) * g.C;
+    for (int i = threadIdx.x; i < nel; i += 256) { sm[i] = r0[i]; sm[nel + i] = r1[i]; }
+}
+__device__ __forceinline__ float up_val(const float *sm, int nelrow, int o0, int o1, int c, float aw, float ah)
+{
+    const float l0 = (1.f - aw) * sm[o0 + c] + aw * sm[o1 + c];
+    const float l1 = (1.f - aw) * sm[nelrow + o0 + c] + aw * sm[nelrow + o1 + c];
+    return (1.f - ah) * l0 + ah * l1;
+}
+// chunk -> (n, ho, first output column); source rows / columns of the chunk
+struct UpChunk { int n, ho, wo0, h0, h1, wlo, nw; float ah; };
+__device__ __forceinline__ UpChunk up_chunk(const UpGeom &g, long long chunk, int cpr)
+{
+    UpChunk k;
+    const long long row = chunk / cpr;
+    k.wo0 = (int)(chunk - row * cpr) * 256;
+    k.n = (int)(row / g.H);
+    k.ho = (int)(row - (long long)k.n * g.H);
+    const float fh = fmaxf(k.ho * g.sh + g.oh, 0.f);
+    int h0 = (int)fh; h0 = h0 > g.h - 1 ? g.h - 1 : h0;
+    k.h0 = h0; k.h1 = h0 + 1 < g.h ? h0 + 1 : g.h - 1; k.ah = fh - h0;
+    const int wlast = min(k.wo0 + 255, g.W - 1);
+    int a = (int)fmaxf(k.wo0 * g.sw + g.ow, 0.f); a = a > g.w - 1 ? g.w - 1 : a;
+    int b = (int)fmaxf(wlast * g.sw + g.ow, 0.f); b = b > g.w - 1 ? g.w - 1 : b;
+    b = b + 1 < g.w ? b + 1 : g.w - 1;
+    k.wlo = a; k.nw = b - a + 1;
+    return k;
+}
+
+// CT: the class count at compile time (19: a pixel's logits are interpolated ONCE into registers) or 0 (any C: re-interpolated per pass)
+template <int CT>
+__global__ __launch_bounds__(256) void ce2d_up_kernel(const float *__restrict__ x, const int64_t *__restrict__ target, int ignore_index,
+                                                      UpGeom g, long long nchunks, int cpr, double *partial, double *count)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    double acc = 0.0, cnt = 0.0;
+    for (long long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const UpChunk k = up_chunk(g, chunk, cpr);
+        up_stage(sm, x, g, k.n, k.h0, k.h1, k.wlo, k.nw);
+        __syncthreads();
+        const int wo = k.wo0 + threadIdx.x;
+        if (wo < g.W) {
+            const int64_t y = target[((size_t)k.n * g.H + k.ho) * g.W + wo];
+            if (!(y == ignore_index || y < 0 || y >= g.C)) {
+                const float fw = fmaxf(wo * g.sw + g.ow, 0.f);
+                int w0 = (int)fw; w0 = w0 > g.w - 1 ? g.w - 1 : w0;
+                const int w1 = w0 + 1 < g.w ? w0 + 1 : g.w - 1;
+                const float aw = fw - w0;
+                const int o0 = (w0 - k.wlo) * g.C, o1 = (w1 - k.wlo) * g.C, nr = k.nw * g.C;
+                float m = -INFINITY, z = 0.f, vy = 0.f;
+                if constexpr (CT > 0) {
+                    float v[CT];
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) { v[c] = up_val(sm, nr, o0, o1, c, aw, k.ah); m = fmaxf(m, v[c]); }
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) { z += __expf(v[c] - m); vy = c == (int)y ? v[c] : vy; }
+                } else {
+                    for (int c = 0; c < g.C; ++c) m = fmaxf(m, up_val(sm, nr, o0, o1, c, aw, k.ah));
+                    for (int c = 0; c < g.C; ++c) z += __expf(up_val(sm, nr, o0, o1, c, aw, k.ah) - m);
+                    vy = up_val(sm, nr, o0, o1, (int)y, aw, k.ah);
+                }
+                acc += (double)(-(vy - m - __logf(z)));
+                cnt += 1.0;
+            }
+        }
+        __syncthreads();
+    }
+    __shared__ double w1s[4], w2s[4];
+    acc = wave_sum_d(acc); cnt = wave_sum_d(cnt);
+    if ((threadIdx.x & 63) == 0) { w1s[threadIdx.x >> 6] = acc; w2s[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) { partial[blockIdx.x] = w1s[0] + w1s[1] + w1s[2] + w1s[3]; count[blockIdx.x] = w2s[0] + w2s[1] + w2s[2] + w2s[3]; }
+}
+
+template <int CT>
+__global__ __launch_bounds__(256) void kldiv_up_kernel(const float *__restrict__ s, const float *__restrict__ t, UpGeom g, float invT,
+                                                       long long nchunks, int cpr, double *partial)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *ss = sm, *st = sm + 2 * UP_NW * g.C;
+    double acc = 0.0;
+    for (long long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const UpChunk k = up_chunk(g, chunk, cpr);
+        up_stage(ss, s, g, k.n, k.h0, k.h1, k.wlo, k.nw);
+        up_stage(st, t, g, k.n, k.h0, k.h1, k.wlo, k.nw);
+        __syncthreads();
+        const int wo = k.wo0 + threadIdx.x;
+        if (wo < g.W) {
+            const float fw = fmaxf(wo * g.sw + g.ow, 0.f);
+            int w0 = (int)fw; w0 = w0 > g.w - 1 ? g.w - 1 : w0;
+            const int w1 = w0 + 1 < g.w ? w0 + 1 : g.w - 1;
+            const float aw = fw - w0;
+            const int o0 = (w0 - k.wlo) * g.C, o1 = (w1 - k.wlo) * g.C, nr = k.nw * g.C;
+            float ms = -INFINITY, mt = -INFINITY, zs = 0.f, zt = 0.f, kl = 0.f;
+            if constexpr (CT > 0) {
+                float a[CT], b[CT];
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    a[c] = up_val(ss, nr, o0, o1, c, aw, k.ah) * invT;
+                    b[c] = up_val(st, nr, o0, o1, c, aw, k.ah) * invT;
+                    ms = fmaxf(ms, a[c]); mt = fmaxf(mt, b[c]);
+                }
+#pragma unroll
+                for (int c = 0; c < CT; ++c) { zs += __expf(a[c] - ms); zt += __expf(b[c] - mt); }
+                const float lzs = __logf(zs) + ms, lzt = __logf(zt) + mt;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const float lps = a[c] - lzs, lpt = b[c] - lzt, pt = __expf(lpt);
+                    kl += pt > 0.f ? pt * (lpt - lps) : 0.f;
+                }
+            } else {
+                for (int c = 0; c < g.C; ++c) {
+                    ms = fmaxf(ms, up_val(ss, nr, o0, o1, c, aw, k.ah) * invT);
+                    mt = fmaxf(mt, up_val(st, nr, o0, o1, c, aw, k.ah) * invT);
+                }
+                for (int c = 0; c < g.C; ++c) {
+                    zs += __expf(up_val(ss, nr, o0, o1, c, aw, k.ah) * invT - ms);
+                    zt += __expf(up_val(st, nr, o0, o1, c, aw, k.ah) * invT - mt);
+                }
+                const float lzs = __logf(zs) + ms, lzt = __logf(zt) + mt;
+                for (int c = 0; c < g.C; ++c) {
+                    const float lps = up_val(ss, nr, o0, o1, c, aw, k.ah) * invT - lzs, lpt = up_val(st, nr, o0, o1, c, aw, k.ah) * invT - lzt;
+                    const float pt = __expf(lpt);
+                    kl += pt > 0.f ? pt * (lpt - lps) : 0.f;
+                }
+            }
+            acc += (double)kl;
+        }
+        __syncthreads();
+    }
+    block_partial(acc, partial);
+}
+
 // ---- hint MSE -----------------------------------------------------------------------------
 // contiguous fast path: s, t, g share one dense layout -> 8 elements per thread per step
 template <typename T>
@@ -642,6 +790,70 @@ extern "C" int kd_ce2d(const kd_view3 *x, const int64_t *target, int32_t ignore_
     KD_CHECK_LAUNCH("kd_ce2d");
     hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, (const double *)partial, nb, 1.0, (const double *)count, loss);
     KD_CHECK_LAUNCH("kd_ce2d(finish)");
+    return KD_OK;
+}
+
+// ---- kd_ce2d_up / kd_kldiv_up: the logged logit losses from the low-resolution logits (see ce2d_up_kernel) ---------------------------
+static bool up_geom(UpGeom &g, int32_t N, int32_t h, int32_t w, int32_t C, int32_t H, int32_t W, int32_t align_corners)
+{
+    g.N = N; g.h = h; g.w = w; g.C = C; g.H = H; g.W = W;
+    g.sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    g.sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    g.oh = 0.f; g.ow = 0.f;
+    if (!align_corners) {
+        g.sh = (float)h / (float)H; g.sw = (float)w / (float)W;
+        g.oh = 0.5f * g.sh - 0.5f; g.ow = 0.5f * g.sw - 0.5f;
+    }
+    // source columns one 256-pixel chunk can touch (the kernels stage them in LDS)
+    return (int)(255.f * g.sw) + 3 <= UP_NW;
+}
+
+extern "C" int kd_ce2d_up(const float *x_lo, const int64_t *target, int32_t ignore_index, int32_t N, int32_t h, int32_t w, int32_t C,
+                          int32_t H, int32_t W, int32_t align_corners, float *loss, void *workspace, size_t workspace_bytes,
+                          kd_stream_t stream)
+{
+    KD_REQUIRE(x_lo && target && loss && workspace, KD_ERR_INVALID, "kd_ce2d_up: null argument");
+    KD_REQUIRE(N > 0 && h > 0 && w > 0 && C > 0 && C <= 48 && H > 0 && W > 0, KD_ERR_INVALID, "kd_ce2d_up: bad argument (C <= 48: the staged patch fits 64 KiB of LDS)");
+    KD_REQUIRE(workspace_bytes >= kd_loss_workspace(N, C, (int64_t)H * W), KD_ERR_WORKSPACE, "kd_ce2d_up: workspace too small");
+    UpGeom g;
+    KD_REQUIRE(up_geom(g, N, h, w, C, H, W, align_corners), KD_ERR_UNSUPPORTED,
+               "kd_ce2d_up: a 256-pixel chunk spans more than %d source columns (scale %dx%d -> %dx%d): materialise the logits", UP_NW, h, w, H, W);
+    double *partial = (double *)workspace, *count = partial + MAX_BLOCKS;
+    const int cpr = (W + 255) / 256;
+    const long long nchunks = (long long)N * H * cpr;
+    const int nb = (int)(nchunks < MAX_BLOCKS ? nchunks : MAX_BLOCKS);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)2 * UP_NW * C * sizeof(float);
+    if (C == 19) hipLaunchKernelGGL(ce2d_up_kernel<19>, dim3(nb), dim3(256), lds, st, x_lo, target, ignore_index, g, nchunks, cpr, partial, count);
+    else hipLaunchKernelGGL(ce2d_up_kernel<0>, dim3(nb), dim3(256), lds, st, x_lo, target, ignore_index, g, nchunks, cpr, partial, count);
+    KD_CHECK_LAUNCH("kd_ce2d_up");
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, (const double *)partial, nb, 1.0, (const double *)count, loss);
+    KD_CHECK_LAUNCH("kd_ce2d_up(finish)");
+    return KD_OK;
+}
+
+extern "C" int kd_kldiv_up(const float *s_lo, const float *t_lo, float temperature, int32_t N, int32_t h, int32_t w, int32_t C, int32_t H,
+                           int32_t W, int32_t align_corners, float *loss, void *workspace, size_t workspace_bytes, kd_stream_t stream)
+{
+    KD_REQUIRE(s_lo && t_lo && loss && workspace, KD_ERR_INVALID, "kd_kldiv_up: null argument");
+    KD_REQUIRE(N > 0 && h > 0 && w > 0 && C > 0 && C <= 24 && H > 0 && W > 0 && temperature > 0.f, KD_ERR_INVALID, "kd_kldiv_up: bad argument (C <= 24: two staged patches fit 64 KiB of LDS)");
+    KD_REQUIRE(workspace_bytes >= kd_loss_workspace(N, C, (int64_t)H * W), KD_ERR_WORKSPACE, "kd_kldiv_up: workspace too small");
+    UpGeom g;
+    KD_REQUIRE(up_geom(g, N, h, w, C, H, W, align_corners), KD_ERR_UNSUPPORTED,
+               "kd_kldiv_up: a 256-pixel chunk spans more than %d source columns: materialise the logits", UP_NW);
+    double *partial = (double *)workspace;
+    const int cpr = (W + 255) / 256;
+    const long long nchunks = (long long)N * H * cpr;
+    const int nb = (int)(nchunks < MAX_BLOCKS ? nchunks : MAX_BLOCKS);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)4 * UP_NW * C * sizeof(float);
+    if (C == 19) hipLaunchKernelGGL(kldiv_up_kernel<19>, dim3(nb), dim3(256), lds, st, s_lo, t_lo, g, 1.f / temperature, nchunks, cpr, partial);
+    else hipLaunchKernelGGL(kldiv_up_kernel<0>, dim3(nb), dim3(256), lds, st, s_lo, t_lo, g, 1.f / temperature, nchunks, cpr, partial);
+    KD_CHECK_LAUNCH("kd_kldiv_up");
+    // 'mean' over N*C*P elements, then * T^2 * C  ==  T^2 / (N*P) * sum  (kd_kldiv)
+    const double scale = (double)temperature * temperature / ((double)N * (double)H * (double)W);
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, (const double *)partial, nb, scale, (const double *)nullptr, loss);
+    KD_CHECK_LAUNCH("kd_kldiv_up(finish)");
     return KD_OK;
 }
 

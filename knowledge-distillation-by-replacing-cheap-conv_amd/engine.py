@@ -38,6 +38,7 @@ from torch import nn
 
 from . import ops
 from ._lib import KD_PACK_DGRAD, KD_PACK_FWD
+from .lazy import LazyLogits
 from .models.students.transform_blocks import DepthwiseSeparableBlock, GateLayer
 from .models.wider_resnet import IdentityResidualBlock
 
@@ -131,6 +132,10 @@ class StudentEngine:
         # under the shipped plan's hint losses.  The owner says which it is (DepthwiseStudent.logits_need_grad, set by trainers
         # that back-propagate a logit loss): the stream then runs on the general kernels and keeps its intermediates.
         self.logits_need_grad = False
+        # full-resolution logits materialised on demand (lazy.py); A/B: KDCC_LAZY_LOGITS=0
+        self.lazy_logits = os.environ.get("KDCC_LAZY_LOGITS", "1") != "0"
+        self._lazy_call = False    # set by the callers that hand the logits to a trainer (run_student, the frozen-teacher call):
+                                   # StudentEngine.forward itself keeps returning the materialised (N,H,W,C) tensor
         self._differentiable = False
 
     def compute_edge_prior(self, x_nchw):
@@ -780,7 +785,12 @@ class StudentEngine:
         ncls = f[6].out_channels
         d3 = self._new(N, h2, w2, ncls, dtype=torch.float32)
         ops.conv2d(d2, self._w_fwd(f[6]), out_raw=d3)
-        logits = ops.upsample_bilinear_ac(d3, size, out_dtype=torch.float32, align_corners=not self.is_gscnn)
+        if self.lazy_logits and self._lazy_call and not self.logits_need_grad:
+            # nothing differentiates through the logits: hand out the half-resolution tensor behind the full-resolution
+            # signature (lazy.LazyLogits); the logged criteria interpolate in registers, anything else materialises it
+            logits = LazyLogits(d3, size, align_corners=not self.is_gscnn)
+        else:
+            logits = ops.upsample_bilinear_ac(d3, size, out_dtype=torch.float32, align_corners=not self.is_gscnn)
         tape["dec"] = dict(cat=cat, rg_cat=rg_cat, m2=m2, rg_m2=rg_m2, dec0=dec0, d1=d1, d2=d2, cdec=cdec, nf=nf, nu=nu, size=size,
                            small=(h8, w8))
         return logits
@@ -1460,11 +1470,23 @@ class _StudentFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         logits, hints = engine.forward(x, prefix=engine._next_prefix)
         ctx.engine, ctx.params = engine, params
-        outs = (logits.permute(0, 3, 1, 2),) + tuple(h.permute(0, 3, 1, 2) for h in hints)
+        lazy = isinstance(logits, LazyLogits)
+        outs = (logits if lazy else logits.permute(0, 3, 1, 2),) + tuple(h.permute(0, 3, 1, 2) for h in hints)
+        ctx.nh = len(hints)
+        if lazy:
+            # the logits output carries no gradient of its own; a 0-dim differentiable output anchors loss values computed from
+            # the half-resolution logits to this node (lazy.deferred: if one is back-propagated, its gradient arrives through it)
+            ctx.mark_non_differentiable(outs[0])
+            outs = outs + (x.new_zeros(()),)
+        ctx.lazy = outs[0] if lazy else None
         return outs
 
     @staticmethod
-    def backward(ctx, g_logits, *g_hints):
+    def backward(ctx, g_logits, *g_rest):
+        g_hints = g_rest[:ctx.nh]
+        if ctx.lazy is not None:      # a loss on the lazy logits was back-propagated after all: lazy._DeferredLogitLoss left its gradient
+            g_logits, ctx.lazy.pending_grad = ctx.lazy.pending_grad, None
+            ctx.lazy = None
         grads = ctx.engine.backward(list(g_hints), g_logits)
         return (None, None) + tuple(grads.get(p) for p in ctx.params)
 
@@ -1473,10 +1495,12 @@ def run_student(engine, x, prefix=None):
     """Differentiable student call: returns (logits NCHW-logical fp32, [hints NCHW-logical]).  prefix: the teacher engine's
     export of the shared frozen prefix (StudentEngine.shareable_prefix), or None."""
     engine._next_prefix = prefix
+    engine._lazy_call = True
     try:
         return _run_student(engine, x, prefix)
     finally:
         engine._next_prefix = None
+        engine._lazy_call = False
 
 
 def _run_student(engine, x, prefix):
@@ -1488,11 +1512,14 @@ def _run_student(engine, x, prefix):
         engine._differentiable = True
         try:
             outs = _StudentFunction.apply(engine, x, *params)
+            if isinstance(outs[0], LazyLogits):
+                outs[0].anchor = outs[-1]
+                outs = outs[:-1]
         finally:
             engine._probe_active = False
             engine._differentiable = False
     else:
         logits, hints = engine.forward(x, prefix=prefix)
         engine._tape = None
-        outs = (logits.permute(0, 3, 1, 2),) + tuple(h.permute(0, 3, 1, 2) for h in hints)
+        outs = (logits if isinstance(logits, LazyLogits) else logits.permute(0, 3, 1, 2),) + tuple(h.permute(0, 3, 1, 2) for h in hints)
     return outs[0], list(outs[1:])

@@ -5,6 +5,8 @@ import torch
 from torch import nn
 
 from .. import ops
+from .._lib import KdccError
+from ..lazy import LazyLogits, deferred
 
 
 class _FusedLoss(torch.autograd.Function):
@@ -50,6 +52,14 @@ class KLDivergenceLoss(nn.Module):
         self.temperature = temperature
 
     def forward(self, inputs, targets):
+        if isinstance(inputs, LazyLogits) and isinstance(targets, LazyLogits) and inputs.pending and targets.pending and \
+                inputs.size_hw == targets.size_hw and inputs.align_corners == targets.align_corners:
+            # both sides are the classifier's half-resolution logits: interpolate in registers (kd_kldiv_up)
+            try:
+                return deferred(ops.kldiv_up(inputs.low, targets.low, inputs.size_hw, float(self.temperature), inputs.align_corners),
+                                "kld", inputs, targets, float(self.temperature))
+            except KdccError:
+                pass      # resampling ratio / class count outside the kernel's range: materialise
         return _FusedLoss.apply("kld", inputs, _same_device_dtype(inputs, targets), float(self.temperature), None)
 
 
@@ -104,6 +114,12 @@ class CrossEntropyLoss2d(nn.Module):
         self.ignore_index = ignore_index
 
     def forward(self, inputs, targets):
+        if isinstance(inputs, LazyLogits) and inputs.pending:
+            try:
+                return deferred(ops.ce2d_up(inputs.low, targets, inputs.size_hw, self.ignore_index, inputs.align_corners),
+                                "ce", inputs, targets, self.ignore_index)
+            except KdccError:
+                pass
         if inputs.requires_grad and torch.is_grad_enabled():
             return _CEFunction.apply(inputs, targets, self.ignore_index)
         return ops.ce2d(inputs, targets, self.ignore_index)

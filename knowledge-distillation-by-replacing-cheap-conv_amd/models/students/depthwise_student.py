@@ -181,14 +181,18 @@ class DepthwiseStudent(nn.Module):
             k = 0
             if self.share_frozen_prefix and self.fused and not self.hip_teacher_side_stream:
                 k = self._student_engine().shareable_prefix(eng)
-            with torch.no_grad():
-                logits, hints = eng.forward(x, export_at=k if k > 0 else None)
+            eng._lazy_call = True          # the trainer's criteria read the half-resolution logits (lazy.LazyLogits)
+            try:
+                with torch.no_grad():
+                    logits, hints = eng.forward(x, export_at=k if k > 0 else None)
+            finally:
+                eng._lazy_call = False
             self._prefix = eng.exported if k > 0 else None
             eng.exported = None
             eng._tape = None
             if self.save_hidden:
                 self.teacher_hidden_outputs = [h.permute(0, 3, 1, 2) for h in hints]
-            return logits.permute(0, 3, 1, 2)
+            return logits if hasattr(logits, "materialize") else logits.permute(0, 3, 1, 2)     # (lazy.LazyLogits is NCHW-logical already)
         self._prepare_teacher(x.device)
         xt = x.to(dtype=self.dtype, memory_format=torch.channels_last)
         with torch.no_grad():

@@ -30,6 +30,9 @@ class TaylorPruneStudent(DepthwiseStudent):
     def __init__(self, teacher_model, config=None, dtype=None):
         super().__init__(teacher_model, config, dtype=dtype)
         self.added_gates = dict()
+        # this student exists to back-propagate the supervised loss through the logits (trainer/taylor_prune_trainer.py:204-206):
+        # the engine hands out real (not lazy) logits
+        self.logits_need_grad = True
 
     def _channels_behind(self, name, block):
         """Channel count of the tensor the gate multiplies; raises for a site the fused graph cannot fold a gate into."""

@@ -55,7 +55,11 @@ def stream_ptr():
 
 
 def _ptr(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    if t is None:
+        return None
+    if type(t) is not torch.Tensor and hasattr(t, "materialize"):   # lazy.LazyLogits has no storage of its own
+        t = t.materialize()
+    return C.c_void_p(t.data_ptr())
 
 
 def _need_cuda(*ts):
@@ -872,6 +876,9 @@ def rank1_add(y, g, w, accumulate=True):
 # ------------------------------------------------------------------------------------- losses
 def view3(t):
     """(N,C,*spatial) logical tensor (any of NCHW / channels_last / (N,C)) -> kd_view3 + (N,C,P)."""
+    mat = getattr(t, "materialize", None)     # lazy.LazyLogits: a raw pointer is wanted, so the tensor has to exist
+    if mat is not None:
+        t = mat()
     if t.dim() == 2:
         N, Cc = t.shape
         return View3(t.data_ptr(), dt_of(t), t.stride(0), t.stride(1), 0), (N, Cc, 1)
@@ -963,6 +970,47 @@ def ce2d(x, target, ignore_index=255):
     e0 = _prof_start()
     check(_lib.lib().kd_ce2d(C.byref(vx), _ptr(tgt), ignore_index, N, Cc, P, _ptr(loss), _ptr(ws), need, stream_ptr()), "kd_ce2d")
     _prof_stop(e0, "loss", _nbytes(x, tgt), f"ce2d {N}x{Cc}x{P}", "ce2d_kernel")
+    return loss
+
+
+def _lowres_ok(*lows):
+    for t in lows:
+        if t.dim() != 4 or t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("low-resolution logits must be dense fp32 (N,h,w,C)")
+
+
+def ce2d_up(x_lo, target, size, ignore_index=255, align_corners=True):
+    """ce2d(upsample_bilinear(x_lo, size), target) without the full-resolution tensor (kd_ce2d_up)."""
+    _need_cuda(x_lo, target)
+    _lowres_ok(x_lo)
+    N, h, w, Cc = x_lo.shape
+    H, W = size
+    tgt = target.contiguous()
+    if tgt.dtype != torch.int64 or tgt.numel() != N * H * W:
+        raise ValueError("ce2d_up: target must be int64 (N,H,W)")
+    loss = torch.empty((), dtype=torch.float32, device=x_lo.device)
+    ws, need = loss_workspace(N, Cc, H * W, x_lo.device)
+    e0 = _prof_start()
+    check(_lib.lib().kd_ce2d_up(_ptr(x_lo), _ptr(tgt), ignore_index, N, h, w, Cc, H, W, int(bool(align_corners)), _ptr(loss), _ptr(ws),
+                                need, stream_ptr()), "kd_ce2d_up")
+    _prof_stop(e0, "loss", _nbytes(x_lo, tgt), f"ce2d from {h}x{w} logits at {H}x{W}", "ce2d_up_kernel")
+    return loss
+
+
+def kldiv_up(s_lo, t_lo, size, temperature=1.0, align_corners=True):
+    """kldiv(upsample_bilinear(s_lo, size), upsample_bilinear(t_lo, size)) forward, without the full-resolution tensors."""
+    _need_cuda(s_lo, t_lo)
+    _lowres_ok(s_lo, t_lo)
+    if s_lo.shape != t_lo.shape:
+        raise ValueError("kldiv_up: shape mismatch")
+    N, h, w, Cc = s_lo.shape
+    H, W = size
+    loss = torch.empty((), dtype=torch.float32, device=s_lo.device)
+    ws, need = loss_workspace(N, Cc, H * W, s_lo.device)
+    e0 = _prof_start()
+    check(_lib.lib().kd_kldiv_up(_ptr(s_lo), _ptr(t_lo), C.c_float(temperature), N, h, w, Cc, H, W, int(bool(align_corners)), _ptr(loss),
+                                 _ptr(ws), need, stream_ptr()), "kd_kldiv_up")
+    _prof_stop(e0, "loss", _nbytes(s_lo, t_lo), f"kldiv from {h}x{w} logits at {H}x{W}", "kldiv_up_kernel")
     return loss
 
 
