@@ -80,7 +80,8 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
     typedef bf16_t T;
     constexpr int NOPS = NOPS_ & 3;
     constexpr bool SUMS = (NOPS_ & 4) != 0;
-    static_assert(MI == 8 && NOPS_ >= 0 && NOPS_ <= 7 && NOPS_ != 4, "128-row wave sub-tiles; sums need the mask operand");
+    static_assert((MI == 8 || (MI == 4 && !(NOPS_ & 4))) && NOPS_ >= 0 && NOPS_ <= 7 && NOPS_ != 4,
+                  "128-row wave sub-tiles (64 rows at a time: conv_row_duo_kernel, no sums); sums need the mask operand");
     const kd_conv_epilogue &e = p.ep;
     // every per-lane address below derives from this copy: the compiler cannot hoist them out of the tile loop into
     // registers that would stay live through the main loop (which runs at the 256-VGPR limit)
@@ -127,7 +128,7 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
         for (int j = 0; j < 4; ++j) pk[i][j] = ig_pack_acc(acc[i][j]);
     if (nops >= 1) load64(s0, ld0, 0, ra);
     if (nops >= 2) load64(s1, ld1, 0, rb);
-    if (nops == 1) load64(s0, ld0, 1, rb);
+    if (nops == 1 && MI == 8) load64(s0, ld0, 1, rb);
     if constexpr (NOPS == 3) load64((const T *)e.res_post, e.ld_res_post, 0, rc);
     // hipcc's wait-count insertion is path-insensitive: a load whose uses sit under run-time conditions counts as pending on
     // the paths that skip them, and the wait it then needs lands in front of the main loop's first ds_read (which reuses the
@@ -141,7 +142,7 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
         asm volatile("" ::"v"(mscale[0]), "v"(mscale[1]), "v"(mscale[2]), "v"(mscale[3]), "v"(mscale[4]), "v"(mscale[5]), "v"(mscale[6]),
                      "v"(mscale[7]));
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {   // 64 rows each
+    for (int hb = 0; hb < MI / 4; ++hb) {   // 64 rows each
         if (nops >= 2 && hb == 1) { load64(s0, ld0, 1, ra); load64(s1, ld1, 1, rb); }
         if constexpr (NOPS == 3) { if (hb == 1) load64((const T *)e.res_post, e.ld_res_post, 1, rc); }
 #pragma unroll
@@ -269,4 +270,5 @@ struct TileWalk {
 // conv_lw.hip: the one-wave-per-SIMD row kernel (128 x 128 wave tiles, hand-scheduled main loop).  nops_sums = NOPS | 4 when the
 // eval-BN sums are taken.  Returns false when the instantiation does not exist.
 bool kd_launch_conv_row_lw(const ConvParams &p, int nops_sums, unsigned grid, hipStream_t s);
+bool kd_launch_conv_row_duo(const ConvParams &p, int nops_sums, unsigned grid, hipStream_t s);   // 256 x 128 tiles, two workgroups per CU
 bool kd_launch_conv_pw_lw(const ConvParams &p, int nops_sums, unsigned grid, hipStream_t s);   // 1x1 / stride 1, Cin % 128 == 0

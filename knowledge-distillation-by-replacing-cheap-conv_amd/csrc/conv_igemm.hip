@@ -1596,7 +1596,30 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         const int nwg = p.ntiles < persist_cus() ? p.ntiles : persist_cus();
         return dim3((unsigned)((nwg + 7) / 8 * 8));
     };
-    if (sel.use_row_persist) {
+    // conv_row_duo_kernel (conv_lw.hip): 256 x 128 tiles, two workgroups per CU -- one's epilogue under the other's main loop.
+    // KDCC_CONV_DUO: 0 off, 1 the Cout = 128 layers (instead of the 512 x 128 ping-pong kernel), 2 every row-buffer layer it fits
+    static int duo = -1;
+    if (duo < 0) { const char *v = getenv("KDCC_CONV_DUO"); duo = v ? atoi(v) : 0; }
+    const bool duo_ok = duo > 0 && lw_row() && d->dtype == KD_BF16 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == d->dil && d->dil <= 32 &&
+                        d->W % 256 == 0 && p.M % 256 == 0 && d->Cout % 128 == 0 && d->Cin % 64 == 0 && sel.vec_ok && !ep->raw_f32 && nops <= 1 &&
+                        !ep->bn_sums && !(p.tune & 512) && (long long)(p.M / 256) * (d->Cout / 128) >= 2 * ncu &&
+                        (duo >= 2 || d->Cout == 128);
+    if (duo_ok) {
+        p.tiles_n = d->Cout / 128;
+        p.tiles_m = p.M / 256;
+        p.ntiles = p.tiles_m * p.tiles_n;
+        {   // N tiles walked in groups over all M tiles for wide layers (see persist_grid): 8 tiles of 128 channels = 4 of 256
+            static int tng = -1;
+            if (tng < 0) { const char *v = getenv("KDCC_CONV_TNGROUP"); tng = v ? atoi(v) : 4; }
+            p.tn_group = (tng > 0 && p.tiles_n > 2 * tng && p.tiles_n % (2 * tng) == 0) ? 2 * tng : 0;
+        }
+        p.nkc = d->Cin / 32;
+        p.nk = 9 * p.nkc;
+        const int cap = 2 * persist_cus();
+        const int nwg = p.ntiles < cap ? p.ntiles : cap;
+        KD_NOTE_KERNEL("conv_row_duo_kernel");
+        KD_REQUIRE(kd_launch_conv_row_duo(p, nops, (unsigned)((nwg + 7) / 8 * 8), s), KD_ERR_UNSUPPORTED, "kd_conv2d_fwd: no conv_row_duo_kernel instantiation");
+    } else if (sel.use_row_persist) {
         p.nkc = d->Cin / (CfgRow::RB / es);
         p.nk = 9 * p.nkc;
         const dim3 grid = persist_grid();

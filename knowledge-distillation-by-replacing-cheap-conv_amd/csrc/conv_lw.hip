@@ -334,6 +334,184 @@ __global__ __launch_bounds__(256, 1) void conv_pw_lw_kernel(const ConvParams p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+
+// ---- two workgroups per CU: the epilogue of one under the main loop of the other ---------------------------------------------------------
+// conv_row_duo_kernel: the same hand-dealt stream on a 256 x 128 tile -- 4 waves of 128 x 64, 128 accumulators in a[0:127], 256 registers
+// per wave, 72 KiB of LDS -- so that two independent workgroups are resident per CU (tools/gen_conv_lw.py, "duo").  K is staged in
+// 32-channel periods (64-B row buffers / B slots, one slot per tap): the k order is (32-channel block, kernel row, tap) where the other
+// row kernels walk (64-channel block, kernel row, tap, k-half), so results agree to fp32 summation order, not bit for bit.
+// Cout % 128 == 0, Cin % 64 == 0.
+constexpr int DUO_ABUF = 320 * 64, DUO_BSLOT = 128 * 64, DUO_NEED = 2 * DUO_ABUF + 3 * DUO_BSLOT;
+
+template <int NOPS_>
+__global__ __launch_bounds__(256, 2) void conv_row_duo_kernel(const ConvParams p)
+{
+    typedef unsigned long long u64;
+    __shared__ __attribute__((aligned(1024))) char lds[DUO_NEED + 4 * 2048];   // 72 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const int d = p.dil;
+    TileWalk walk(p.ntiles);
+    if (walk.t >= walk.t_end) return;
+    const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    uint32_t va[3], vb, voa[5], vob[2], vz0, vz1, vr0;
+    u32x4_t vzero;
+    auto lane_addresses = [&]() __attribute__((always_inline)) {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int frow = l & 15, fq = l >> 4;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int rsh = frow + kx * d;
+            va[kx] = lbase + (wm * 128 + rsh) * 64 + ((fq ^ ((rsh >> 1) & 3)) << 4);
+        }
+        vb = lbase + 2 * DUO_ABUF + (wn * 64 + frow) * 64 + ((fq ^ ((frow >> 1) & 3)) << 4);
+        const int srow = l >> 2, chunk = ((l & 3) ^ ((l >> 3) & 3)) << 4;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) voa[j] = (uint32_t)(((wv * 5 + j) * 16 + srow) * (p.ldx * 2) + chunk);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) vob[j] = (uint32_t)(((wv * 2 + j) * 16 + srow) * (p.Ktot * 2) + chunk);
+        vz0 = lbase + wv * 5120 + l * 16;
+        vz1 = vz0 + DUO_ABUF;
+        vr0 = (uint32_t)(wv * 80 + srow);      // buffer row of this lane in piece 0 (piece j: + 16 j)
+        vzero = (u32x4_t){0u, 0u, 0u, 0u};
+    };
+    lane_addresses();
+    const uint32_t sldsA = __builtin_amdgcn_readfirstlane(lbase + wv * 5120);
+    const uint32_t sldsB = __builtin_amdgcn_readfirstlane(lbase + 2 * DUO_ABUF + wv * 2048);
+    const uint32_t s2cin = (uint32_t)(2 * p.Cin);
+    const long long dWl2 = 2ll * d * p.W * p.ldx;
+    const int nkc = p.Cin / 32;
+
+    struct Tile {
+        int m0, n0, kylo, nky;
+        uint32_t lo, span;
+        u64 abase, bbase;
+    };
+    auto decode = [&](int tile, Tile &t) {
+        int tn, tm;
+        if (p.tn_group > 0) {
+            const int per = p.tiles_m * p.tn_group, blk = tile / per, r = tile - blk * per;
+            tm = r / p.tn_group;
+            tn = blk * p.tn_group + (r - tm * p.tn_group);
+        } else {
+            tn = tile % p.tiles_n;
+            tm = tile / p.tiles_n;
+        }
+        t.m0 = tm * 256;
+        t.n0 = tn * 128;
+        const int n = t.m0 / p.HoWo, rem = t.m0 - n * p.HoWo;
+        const int ho = rem / p.W, x0 = rem - ho * p.W;
+        t.kylo = ho - d < 0 ? 1 : 0;
+        t.nky = (ho + d >= p.H ? 1 : 2) - t.kylo + 1;
+        t.lo = x0 == 0 ? (uint32_t)d : 0u;
+        t.span = (x0 + 256 == p.W ? 256u + d : 320u) - t.lo;
+        t.abase = (u64)p.x + (u64)(2ll * ((long long)((n * p.H + ho) * p.W + (x0 - d)) * p.ldx));
+        t.bbase = (u64)p.w + (u64)(2ll * (long long)t.n0 * p.Ktot);
+    };
+    // period q of a tile = (32-channel block q / nky, kernel row kylo + q % nky)
+    auto a_of = [&](const Tile &t, int q) { return t.abase + (u64)((long long)(t.kylo + q % t.nky - 1) * dWl2 + (q / t.nky) * 64); };
+    auto b_of = [&](const Tile &t, int q) { return t.bbase + (u64)(2ll * ((long long)(t.kylo + q % t.nky) * 3 * p.Cin + (q / t.nky) * 32)); };
+
+    Tile cur, nxt;
+    int c_tile = walk.t;
+    decode(c_tile, cur);
+    // prologue (generic pieces): row buffer of period 0, pieces 0-2 of period 1, B of period 0's three taps
+    {
+        const char *a0 = (const char *)a_of(cur, 0), *a1 = (const char *)a_of(cur, 1);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const bool ok = vr0 + 16 * j - cur.lo < cur.span;
+            glds16(ok ? (const void *)(a0 + voa[j]) : (const void *)lw_zero_page, lds + (wv * 5 + j) * 1024);
+            if (j < 3) glds16(ok ? (const void *)(a1 + voa[j]) : (const void *)lw_zero_page, lds + DUO_ABUF + (wv * 5 + j) * 1024);
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                glds16((const char *)b_of(cur, 0) + 2ll * kx * p.Cin + vob[j], lds + 2 * DUO_ABUF + kx * DUO_BSLOT + (wv * 2 + j) * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // The two workgroups of a CU do identical work: started together they would reach their epilogues together.  The second half
+    // of the grid (dealt to the CUs' second slots) starts half a tile late -- a tile takes about 2 x nper x 3 k-steps x 1117 cycles
+    // while both workgroups share the matrix pipes -- once per launch; the offset then persists (equal tiles).
+    if (blockIdx.x * 2 >= gridDim.x && !(p.tune & 16384)) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+        const unsigned long long ticks = (unsigned long long)(nkc * cur.nky) * (unsigned long long)(p.stagger_us > 0 ? p.stagger_us : 160);
+        while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+    }
+    __builtin_amdgcn_s_barrier();
+    typedef __attribute__((ext_vector_type(32))) float f32x32_t;
+    f32x32_t A0, A1, A2, A3;      // the accumulator file is occupied (see conv_row_lw_kernel)
+    asm volatile(DUO_ZERO_ACC_ASM : "=a"(A0), "=a"(A1), "=a"(A2), "=a"(A3));
+#define DUO_ACC_RW "+a"(A0), "+a"(A1), "+a"(A2), "+a"(A3)
+    uint32_t flag = 0;
+#pragma unroll 1
+    for (;;) {
+        lane_addresses();
+        asm volatile(DUO_REFILL_ASM : : [va0] "v"(va[0]), [vb] "v"(vb) : "memory", DUO_CLOBBER_FRAG);
+        const int n_tile = c_tile + walk.step;
+        const bool more = n_tile < walk.t_end;
+        if (more) decode(n_tile, nxt);
+        else nxt = cur;                       // nothing left to stage: re-stage this tile's first periods (valid memory, unread)
+        const uint32_t nper = (uint32_t)(nkc * cur.nky);
+        const u64 sAn1 = a_of(cur, 1), sBn1 = b_of(cur, 1), sAn2 = a_of(cur, 2), sBn2 = b_of(cur, 2);
+        const u64 sAnT0 = a_of(nxt, 0), sBnT0 = b_of(nxt, 0), sAnT1 = a_of(nxt, 1), sBnT1 = b_of(nxt, 1);
+        const int dAs = (int)dWl2, dAw = (int)(64 - (cur.nky - 1) * dWl2), dBs = 6 * p.Cin, dBw = 64 - (cur.nky - 1) * 6 * p.Cin;
+        asm volatile(DUO_TILE_ASM
+                     : DUO_ACC_RW
+                     : [va0] "v"(va[0]), [va1] "v"(va[1]), [va2] "v"(va[2]), [vb] "v"(vb), [voa0] "v"(voa[0]), [voa1] "v"(voa[1]),
+                       [voa2] "v"(voa[2]), [voa3] "v"(voa[3]), [voa4] "v"(voa[4]), [vob0] "v"(vob[0]), [vob1] "v"(vob[1]), [vz0] "v"(vz0),
+                       [vz1] "v"(vz1), [vzero] "v"(vzero), [vr0] "v"(vr0), [sAn1] "s"(sAn1), [sBn1] "s"(sBn1), [sAn2] "s"(sAn2),
+                       [sBn2] "s"(sBn2), [sAnT0] "s"(sAnT0), [sBnT0] "s"(sBnT0), [sAnT1] "s"(sAnT1), [sBnT1] "s"(sBnT1), [slo] "s"(cur.lo),
+                       [ssp] "s"(cur.span), [sloT] "s"(nxt.lo), [sspT] "s"(nxt.span), [sdAs] "s"(dAs), [sdAw] "s"(dAw), [sdBs] "s"(dBs),
+                       [sdBw] "s"(dBw), [snky] "s"((uint32_t)cur.nky), [sky2] "s"((uint32_t)(2 % cur.nky)), [snper] "s"(nper),
+                       [s2cin] "s"(s2cin), [sflag] "s"(flag), [sldsA] "s"(sldsA), [sldsB] "s"(sldsB)
+                     : "memory", "scc", "vcc", DUO_CLOBBER_S, DUO_CLOBBER_FRAG);
+        asm volatile("s_nop 15\n\ts_nop 15" : DUO_ACC_RW : : "memory");
+        if (!(p.tune & 64)) {
+            const int mw = cur.m0 + wm * 128, nw = cur.n0 + wn * 64;
+            char *patch = lds + DUO_NEED + wv * 2048;
+#define DUO_RD(I, K)                                                                                                                  \
+    {                                                                                                                                 \
+        float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14, t15;                                                   \
+        asm volatile(DUO_READ_ACC_##I##_ASM                                                                                           \
+                     : "=v"(t0), "=v"(t1), "=v"(t2), "=v"(t3), "=v"(t4), "=v"(t5), "=v"(t6), "=v"(t7), "=v"(t8), "=v"(t9), "=v"(t10), \
+                       "=v"(t11), "=v"(t12), "=v"(t13), "=v"(t14), "=v"(t15), DUO_ACC_RW);                                            \
+        acc[K][0] = make_uint2(pack_bf16x2_v(t0, t1), pack_bf16x2_v(t2, t3));                                                         \
+        acc[K][1] = make_uint2(pack_bf16x2_v(t4, t5), pack_bf16x2_v(t6, t7));                                                         \
+        acc[K][2] = make_uint2(pack_bf16x2_v(t8, t9), pack_bf16x2_v(t10, t11));                                                       \
+        acc[K][3] = make_uint2(pack_bf16x2_v(t12, t13), pack_bf16x2_v(t14, t15));                                                     \
+    }
+#define DUO_EPI(MW)                                                                                                                   \
+    if (p.ep.out_raw && p.ep.out_act) ig_epilogue_rows16<4, NOPS_, 1, uint2, 3>(p, patch, acc, MW, nw, lane);                         \
+    else if (p.ep.out_act) ig_epilogue_rows16<4, NOPS_, 1, uint2, 2>(p, patch, acc, MW, nw, lane);                                    \
+    else ig_epilogue_rows16<4, NOPS_, 1, uint2, 1>(p, patch, acc, MW, nw, lane);
+            // 64 rows at a time: the epilogue has 128 registers (the other 128 are the accumulator file)
+            {
+                uint2 acc[4][4];
+                DUO_RD(0, 0) DUO_RD(1, 1) DUO_RD(2, 2) DUO_RD(3, 3)
+                DUO_EPI(mw)
+            }
+            {
+                uint2 acc[4][4];
+                DUO_RD(4, 0) DUO_RD(5, 1) DUO_RD(6, 2) DUO_RD(7, 3)
+                DUO_EPI(mw + 64)
+            }
+#undef DUO_RD
+#undef DUO_EPI
+        }
+        if (!more) break;
+        c_tile = n_tile;
+        cur = nxt;
+        flag = 1;
+    }
+#undef DUO_ACC_RW
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace
 
 bool kd_launch_conv_row_lw(const ConvParams &p, int nops_sums, unsigned grid, hipStream_t s)
@@ -361,5 +539,16 @@ bool kd_launch_conv_pw_lw(const ConvParams &p, int nops_sums, unsigned grid, hip
     case 5: hipLaunchKernelGGL((conv_pw_lw_kernel<5>), g, b, 0, s, p); return true;
     case 6: hipLaunchKernelGGL((conv_pw_lw_kernel<6>), g, b, 0, s, p); return true;
     default: return false;
+    }
+}
+
+bool kd_launch_conv_row_duo(const ConvParams &p, int nops_sums, unsigned grid, hipStream_t s)
+{
+    const dim3 g(grid), b(256);
+    switch (nops_sums) {
+    case 0: hipLaunchKernelGGL((conv_row_duo_kernel<0>), g, b, 0, s, p); return true;
+    case 1: hipLaunchKernelGGL((conv_row_duo_kernel<1>), g, b, 0, s, p); return true;
+    default: return false;      // two operands: the epilogue does not fit the 128 registers beside the accumulator file (hipcc then moves
+                                // accumulators around: tools/check_lw_asm.py); eval-BN sums: one partial row per 128 pixels in one pass
     }
 }

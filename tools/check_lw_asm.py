@@ -23,7 +23,7 @@ LABEL = re.compile(r"^(\.?[A-Za-z_][\w.$]*):")
 
 def audit(text):
     findings = []
-    bodies = re.split(r"^(_ZN\S*conv_(?:row|pw)_lw_kernel\S*):\s*;[^\n]*\n", text, flags=re.M)
+    bodies = re.split(r"^(_ZN\S*conv_(?:row_lw|pw_lw|row_duo)_kernel\S*):\s*;[^\n]*\n", text, flags=re.M)
     n_kernels = 0
     for k in range(1, len(bodies), 2):
         name, code = bodies[k], bodies[k + 1].split(".Lfunc_end")[0]
@@ -56,12 +56,12 @@ def audit(text):
                 findings.append(f"{name}: compiler instruction touches an accumulator register: {it[1].strip()}")
         # 2. all MFMAs in one statement
         mf = [it[2].count("v_mfma") for it in items if it[0] == "asm" and "v_mfma" in it[2]]
-        want = [320] if "conv_pw_lw" in name else [896]      # 1x1: one pass over the four slots; 3x3: two period bodies; + the zero-C first k-step(s)
+        want = [320] if "conv_pw_lw" in name else [224] if "conv_row_duo" in name else [896]      # 1x1: one pass over the four slots; 3x3: two period bodies; + the zero-C first k-step(s)
         if mf != want:
             findings.append(f"{name}: expected one inline-asm statement with {want[0]} MFMAs, found {mf}")
         if any(it[0] == "ins" and "v_mfma" in it[1] for it in items):
             findings.append(f"{name}: compiler-generated MFMA")
-        if "ILi0E" in name:
+        if "ILi0E" in name and "conv_row_duo" not in name:
             m = re.search(re.escape(name) + r"\.private_seg_size, (\d+)", text)
             if m and int(m.group(1)) != 0:
                 findings.append(f"{name}: scratch in the no-operand instantiation ({m.group(1)} B)")

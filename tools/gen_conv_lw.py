@@ -226,6 +226,117 @@ def refill_1x1():
     return L
 
 
+# ---- "duo": TWO workgroups per CU (conv_row_duo_kernel) -------------------------------------------------------------------------------
+# What the lone-wave kernel cannot hide is its epilogue: one wave per SIMD converts, transposes and stores its 128 x 128 outputs with
+# the matrix pipe idle (8-13 % of a 3x3 layer, a third of the 128-channel layers: tools/lw_ablate.sh).  Here a workgroup is 4 waves of
+# 128 x 64 (128 accumulators in a[0:127], 256 registers per wave) on a 256 x 128 tile and 72 KiB of LDS, so that two INDEPENDENT
+# workgroups share a CU: each SIMD holds one wave of either, both run this same hand-dealt stream, and while one workgroup is in its
+# epilogue the other one's MFMAs have the pipe to themselves.
+# K is staged in 32-channel periods: row buffers of 320 rows x 64 B (two), B in three 8-KiB slots (one per tap of a period).  A period
+# P = the three kx taps of one (32-channel block, kernel row) = 3 k-steps; per k-step (P, kx): 32 MFMAs, the 12 fragment reads of the
+# next k-step, the two B pieces of (P + 1, kx) into slot kx, and of the row buffers pieces 3, 4 of period P + 1 at kx = 0 and pieces
+# 0, 1, 2 of period P + 2 at kx = 2 (that buffer was last read during (P, 1)); s_waitcnt vmcnt(pieces issued in this k-step) -- everything
+# older has landed -- and one barrier.  The loop body is two periods (fragment set parity); tiles have an even number of periods.
+DUO_ABUF, DUO_BSLOT, DUO_B0 = 320 * 64, 128 * 64, 2 * 320 * 64
+D_SAN1, D_SBN1, D_LO1, D_SP1 = "s[76:77]", "s[78:79]", "s80", "s81"       # period P + 1
+D_SAN2, D_SBN2, D_LO2, D_SP2 = "s[92:93]", "s[94:95]", "s96", "s97"       # period P + 2
+DUO_CLOBBER_S = CLOBBER_S + ["s92", "s93", "s94", "s95", "s96", "s97"]
+D_VT = "v31"
+
+
+def duo_frags(sset):
+    base = 32 + 48 * sset
+    return [base + 4 * i for i in range(8)], [base + 32 + 4 * j for j in range(4)]
+
+
+def duo_a_piece(j, buf, san, lo, span):
+    return [f"s_add_u32 m0, %[sldsA], {buf * DUO_ABUF + j * 1024}", f"v_add_u32 {D_VT}, {16 * j}, %[vr0]", f"v_subrev_u32 {D_VT}, {lo}, {D_VT}",
+            f"v_cmpx_gt_u32 vcc, {span}, {D_VT}", f"global_load_lds_dwordx4 %[voa{j}], {san}", "s_not_b64 exec, exec",
+            f"ds_write_b128 %[vz{buf}], %[vzero] offset:{j * 1024}", "s_mov_b64 exec, -1"]
+
+
+def duo_shift(tag):
+    """period end: the period being staged moves on by one (P + 1 := P + 2; P + 2 := next kernel row / channel block of the tile, then
+    the next tile's periods 0 and 1)"""
+    return [f"s_mov_b64 {D_SAN1}, {D_SAN2}", f"s_mov_b64 {D_SBN1}, {D_SBN2}", f"s_mov_b32 {D_LO1}, {D_LO2}", f"s_mov_b32 {D_SP1}, {D_SP2}",
+            f"s_sub_u32 {SIN}, {SIN}, 1", f"s_cmp_gt_i32 {SIN}, 0", f"s_cbranch_scc0 LDT{tag}_%=",
+            f"s_add_u32 {SKY}, {SKY}, 1", f"s_cmp_eq_u32 {SKY}, %[snky]",
+            f"s_cselect_b32 {ST0}, %[sdAw], %[sdAs]", f"s_cselect_b32 {ST1}, %[sdBw], %[sdBs]", f"s_cselect_b32 {SKY}, 0, {SKY}",
+            f"s_ashr_i32 {ST2}, {ST0}, 31", f"s_add_u32 s92, s92, {ST0}", f"s_addc_u32 s93, s93, {ST2}",
+            f"s_ashr_i32 {ST2}, {ST1}, 31", f"s_add_u32 s94, s94, {ST1}", f"s_addc_u32 s95, s95, {ST2}",
+            f"s_branch LDU{tag}_%=", f"LDT{tag}_%=:",
+            f"s_mov_b32 {D_LO2}, %[sloT]", f"s_mov_b32 {D_SP2}, %[sspT]", f"s_cmp_eq_u32 {SIN}, 0", f"s_cbranch_scc0 LDV{tag}_%=",
+            f"s_mov_b64 {D_SAN2}, %[sAnT0]", f"s_mov_b64 {D_SBN2}, %[sBnT0]", f"s_branch LDU{tag}_%=", f"LDV{tag}_%=:",
+            f"s_mov_b64 {D_SAN2}, %[sAnT1]", f"s_mov_b64 {D_SBN2}, %[sBnT1]", f"LDU{tag}_%=:"]
+
+
+def duo_kstep(pp, zero=False):
+    """pp = 0 .. 5: k-step of the two-period body (period pp // 3, tap pp % 3)"""
+    per, kx, cur = pp // 3, pp % 3, pp & 1
+    areg, breg = duo_frags(cur)
+    nareg, nbreg = duo_frags(1 - cur)
+    slots = [[] for _ in range(32)]
+    nkx = (kx + 1) % 3
+    nbuf = per if kx < 2 else 1 - per
+    reads = [f"ds_read_b128 v[{nareg[i]}:{nareg[i] + 3}], %[va{nkx}] offset:{nbuf * DUO_ABUF + i * 1024}" for i in range(8)]
+    reads += [f"ds_read_b128 v[{nbreg[j]}:{nbreg[j] + 3}], %[vb] offset:{nkx * DUO_BSLOT + j * 1024}" for j in range(4)]
+    for r, ins in enumerate(reads):
+        slots[1 + 2 * r].append(ins)
+    # B of (P + 1, kx) into slot kx
+    if kx == 0:
+        slots[2].append(f"s_mov_b64 {SB}, {D_SBN1}")
+    for j, k in enumerate((4, 20)):
+        slots[k] += [f"s_add_u32 m0, %[sldsB], {kx * DUO_BSLOT + j * 1024}", "s_nop 0", f"global_load_lds_dwordx4 %[vob{j}], {SB}"]
+    slots[22] += ["s_add_u32 s88, s88, %[s2cin]", "s_addc_u32 s89, s89, 0"]
+    if kx == 0:
+        for n, j in enumerate((3, 4)):
+            slots[(12, 28)[n]] += duo_a_piece(j, 1 - per, D_SAN1, D_LO1, D_SP1)
+    if kx == 2:
+        for n, j in enumerate((0, 1, 2)):
+            slots[(10, 16, 26)[n]] += duo_a_piece(j, per, D_SAN2, D_LO2, D_SP2)
+    L = []
+    k = 0
+    for i in range(8):
+        for j in range(4):
+            acc = 4 * (4 * i + j)
+            L.append(f"v_mfma_f32_16x16x32_bf16 a[{acc}:{acc + 3}], v[{breg[j]}:{breg[j] + 3}], v[{areg[i]}:{areg[i] + 3}], " + ("0" if zero else f"a[{acc}:{acc + 3}]"))
+            L += slots[k]
+            k += 1
+    if kx == 2:
+        L += duo_shift(f"{pp}z" if zero else f"{pp}")
+    n = (4, 2, 5)[kx]
+    tag = f"{pp}z" if zero else f"{pp}"
+    if pp == 0:
+        L += [f"s_cmp_eq_u32 {SFLAG}, 0", f"s_cbranch_scc1 LDN{tag}_%=", "s_waitcnt vmcnt(63) lgkmcnt(0)", f"s_branch LDD{tag}_%=",
+              f"LDN{tag}_%=:", f"s_waitcnt vmcnt({n}) lgkmcnt(0)", f"LDD{tag}_%=:", f"s_mov_b32 {SFLAG}, 0"]
+    else:
+        L.append(f"s_waitcnt vmcnt({n}) lgkmcnt(0)")
+    L.append("s_barrier")
+    return L
+
+
+def tile_duo():
+    # the multiplying workgroup outranks its CU partner (which may be in its VALU-heavy epilogue) at the instruction arbiter
+    L = ["s_setprio 3", "s_mov_b32 s90, m0", f"s_mov_b64 {D_SAN1}, %[sAn1]", f"s_mov_b64 {D_SBN1}, %[sBn1]", f"s_mov_b32 {D_LO1}, %[slo]", f"s_mov_b32 {D_SP1}, %[ssp]",
+         f"s_mov_b64 {D_SAN2}, %[sAn2]", f"s_mov_b64 {D_SBN2}, %[sBn2]", f"s_mov_b32 {D_LO2}, %[slo]", f"s_mov_b32 {D_SP2}, %[ssp]",
+         f"s_mov_b32 {SKY}, %[sky2]", f"s_sub_u32 {SIN}, %[snper], 2", f"s_lshr_b32 {SCNT}, %[snper], 1", f"s_mov_b32 {SFLAG}, %[sflag]"]
+    L += duo_kstep(0, True) + ["s_branch LDLOOP1_%=", "LDLOOP_%=:"]
+    for pp in range(6):
+        L += duo_kstep(pp)
+        if pp == 0:
+            L.append("LDLOOP1_%=:")
+    L += [f"s_sub_u32 {SCNT}, {SCNT}, 1", f"s_cmp_lg_u32 {SCNT}, 0", "s_cbranch_scc1 LDLOOP_%=", "s_mov_b32 m0, s90", "s_setprio 0"]
+    return L
+
+
+def refill_duo():
+    areg, breg = duo_frags(0)
+    L = [f"ds_read_b128 v[{areg[i]}:{areg[i] + 3}], %[va0] offset:{i * 1024}" for i in range(8)]
+    L += [f"ds_read_b128 v[{breg[j]}:{breg[j] + 3}], %[vb] offset:{j * 1024}" for j in range(4)]
+    L += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
+    return L
+
+
 def cstr(lines):
     return " \\\n".join('    "' + l + '\\n\\t"' for l in lines)
 
@@ -235,6 +346,13 @@ def main():
          "// The hand-scheduled main loop of conv_row_lw_kernel; see the generator for the schedule.", ""]
     o += ["#define LW_TILE_ASM \\", cstr(tile()), ""]
     o += ["#define LW_REFILL_ASM \\", cstr(refill()), ""]
+    o += ["#define DUO_TILE_ASM \\", cstr(tile_duo()), ""]
+    o += ["#define DUO_REFILL_ASM \\", cstr(refill_duo()), ""]
+    for i in range(8):
+        o += [f"#define DUO_READ_ACC_{i}_ASM \\", cstr([f"v_accvgpr_read_b32 %{n}, a{16 * i + n}" for n in range(16)]), ""]
+    o += ["#define DUO_ZERO_ACC_ASM \\", cstr([f"v_accvgpr_write_b32 a{n}, 0" for n in range(128)]), ""]
+    o += ["#define DUO_CLOBBER_FRAG " + ", ".join(f'"v{n}"' for n in range(31, 128)),
+          "#define DUO_CLOBBER_S " + ", ".join(f'"{x}"' for x in DUO_CLOBBER_S), ""]
     o += ["#define LW1_TILE_ASM \\", cstr(tile_1x1()), ""]
     o += ["#define LW1_REFILL_ASM \\", cstr(refill_1x1()), ""]
     for i in range(8):
