@@ -258,7 +258,22 @@ __device__ __forceinline__ void up_stage(float *sm, const float *__restrict__ x,
 {
     const int nel = nw * g.C;
     const float *r0 = x + (((size_t)n * g.h + h0) * g.w + wlo) * g.C, *r1 = x + (((size_t)n * g.h + h1) * g.w + wlo) * g.C;
-    for (int i = threadIdx.x; i < nel; i += 256) { sm[i] = r0[i]; sm[nel + i] = r1[i]; }
+    // loads in batches of 8 per row, all in flight together (one load -> one LDS store per iteration waits a memory latency per
+    // iteration: 10+ us per chunk)
+    for (int base = threadIdx.x; base < nel; base += 8 * 256) {
+        float a[8], b[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = base + k * 256;
+            a[k] = i < nel ? r0[i] : 0.f;
+            b[k] = i < nel ? r1[i] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = base + k * 256;
+            if (i < nel) { sm[i] = a[k]; sm[nel + i] = b[k]; }
+        }
+    }
 }
 __device__ __forceinline__ float up_val(const float *sm, int nelrow, int o0, int o1, int c, float aw, float ah)
 {
