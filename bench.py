@@ -202,7 +202,7 @@ PEAK_HBM_GBS = 8000.0       # HBM3E, MI355X_MICROARCH.md
 
 # device kernel (kernel-selection log) -> roofline class
 CONV_CLASSES = (("conv_row_lw_kernel", "conv3x3_row_lone_wave_256x256"), ("conv_row_persist_kernel", "conv3x3_row_persistent_256x256"), ("conv_igemm_persist_kernel", "conv1x1_persistent_256x256"),
-                ("conv_row_pp128_kernel", "conv3x3_row_512x128"))
+                ("conv_row_tall_kernel", "conv3x3_row_lone_wave_512x128"), ("conv_row_pp128_kernel", "conv3x3_row_512x128"))
 
 
 def _classify(rec):
@@ -388,7 +388,7 @@ def run_config(a, device, rank, world, plan_name=None, mode=None, arch=None, hin
                        "teacher_backend": a.teacher, "per_step_host_syncs": bool(a.ref_logging),
                        "share_frozen_prefix": bool(a.share_prefix), "per_gpu_batch_sweep": sweep},
             "roofline": {"bound": "mfma",
-                         "kernel": "kd_conv2d_fwd: conv_row_lw_kernel + conv_igemm_persist_kernel + conv_row_pp128_kernel + conv_igemm_row_kernel "
+                         "kernel": "kd_conv2d_fwd: conv_row_lw_kernel + conv_igemm_persist_kernel + conv_row_tall_kernel + conv_igemm_row_kernel "
                                    "+ conv_igemm_kernel (dense conv fwd + dgrad, student" + (" + teacher)" if a.teacher == "hip" else ")"),
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                          "traffic_note": ("mean HBM bytes per conv launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate "
@@ -429,7 +429,7 @@ def compact_record(res, full_path=None):
                      **{k: cfg[k] for k in ("plan", "mode", "arch", "hint_loss", "per_gpu_batch", "global_batch", "parallelism",
                                             "teacher_backend", "share_frozen_prefix", "replicas_identical_after_run")}}
     out["roofline"] = {"bound": rf["bound"], "kernel": "kd_conv2d_fwd (dense conv fwd + dgrad: conv_row_lw / conv_igemm_persist / "
-                                                       "conv_row_pp128 / one-tile kernels)",
+                                                       "conv_row_tall / one-tile kernels)",
                        **{k: _r(rf[k]) for k in ("achieved", "peak", "unit", "frac", "traffic", "launches_per_step",
                                                  "ms_per_step_in_kernel", "algorithmic_tflop_per_step")},
                        "classes": {n: [_r(c["ms_per_step"], 3), _r(c["frac"], 3)] for n, c in rf["classes"].items()},

@@ -71,6 +71,32 @@ __device__ __forceinline__ void st8_v(bf16_t *p, const float (&v)[8])
     *(uint4 *)p = make_uint4(pack_bf16x2_v(v[0], v[1]), pack_bf16x2_v(v[2], v[3]), pack_bf16x2_v(v[4], v[5]), pack_bf16x2_v(v[6], v[7]));
 }
 
+// The lone-wave kernels' epilogue (OUTS != 0) is bound by its own instruction count -- one wave per SIMD, 4+ cycles per VALU
+// instruction, ~1700 of them per 128 x 128 wave tile (tools/duo_timeline.py --tall: 6.5 us of a 40-us 512 x 128 tile with the stores
+// removed).  Three things take instructions out without changing a bit of the result:
+//   * rows are addressed through a buffer resource based at the wave's first row: per-lane byte offset computed once, the row
+//     step is a scalar (the generic path spends ~6 VALU instructions of 64-bit address arithmetic per 16-B access).  Loads take
+//     it as the instruction's scalar offset; STORES add it to the lane offset (one VALU add) and leave the scalar-offset field 0:
+//     with an SGPR there, hipcc assumes (as the gfx9 hazard table says) that the store's four data registers may be rewritten by
+//     the very next VALU instruction -- on gfx950 the second data dword of raw stores then came out corrupted in 0.4 % of the
+//     elements whenever arithmetic on the same registers followed (the raw + act epilogues; tools/lw_check.py);
+//   * act = v * scale + shift on pairs (v_pk_fma_f32: the same fused arithmetic per element);
+//   * ReLU after the rounding, on the packed bf16 pair as v_pk_max_i16(x, 0) -- rounding is monotonic and keeps the sign, a negative
+//     bf16 is a negative int16 (-0 included: max(-32768, 0) = +0 as fmaxf(-0, 0)); without ReLU the bound is -32768 (identity).
+typedef float f32x2_v __attribute__((ext_vector_type(2)));
+typedef short i16x2_v __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const void *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7fffffff, 0x00020000);   // raw buffer, offsets stay far below 2 GiB
+}
+__device__ __forceinline__ uint32_t act_pair(float lo, float hi, f32x2_v sc, f32x2_v sh, i16x2_v relu_lo)
+{
+    const f32x2_v r = __builtin_elementwise_fma((f32x2_v){lo, hi}, sc, sh);
+    const i16x2_v q = __builtin_bit_cast(i16x2_v, pack_bf16x2_v(r[0], r[1]));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(q, relu_lo));
+}
+
 // OUTS: 0 = which outputs exist is read from the epilogue descriptor per row (the ping-pong kernels); 1 raw, 2 act, 3 both at
 // compile time + single-instruction packing (conv_lw.hip: a lone wave's epilogue is bound by its own instruction count)
 template <int MI, int NOPS_, int PT = 1, typename ACC = f32x4_t, int OUTS = 0>   // NOPS_ = operands | 4 when the eval-BN sums are taken (kernels' NOPS parameter)
@@ -99,6 +125,13 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
     if (has_m && e.mask_scale) ld8(e.mask_scale + c0, mscale);
     if (e.act_scale) ld8(e.act_scale + c0, ascale);
     if (e.act_shift) ld8(e.act_shift + c0, ashift);
+    // lone-wave path: the outputs' rows through buffer resources (see above)
+    const int mwu = __builtin_amdgcn_readfirstlane(mw);
+    const __amdgpu_buffer_rsrc_t rs_raw = rows_rsrc((OUTS & 1) ? (const T *)e.out_raw + (size_t)mwu * e.ld_raw : nullptr);
+    const __amdgpu_buffer_rsrc_t rs_act = rows_rsrc((OUTS & 2) ? (const T *)e.out_act + (size_t)mwu * e.ld_act : nullptr);
+    const uint32_t vo_raw = (uint32_t)(lrow * e.ld_raw + c0) * 2u, vo_act = (uint32_t)(lrow * e.ld_act + c0) * 2u;
+    const short relu_w = e.act_relu ? (short)0 : (short)-32768;
+    const i16x2_v relu_i16 = {relu_w, relu_w};
     const T *s0 = (const T *)(has_p ? e.res_pre : has_m ? e.mask : e.res_post);
     const int ld0 = has_p ? e.ld_res_pre : has_m ? e.ld_mask : e.ld_res_post;
     const T *s1 = (const T *)(has_p && has_m ? e.mask : e.res_post);
@@ -111,8 +144,19 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
     uint4 ra[8], rb[8], rc[NOPS == 3 ? 8 : 1];   // three operands: 64 rows of res_pre / mask / res_post
     auto rowof = [&](int pass) { return (size_t)(mw + pass * 8 + lrow); };
     auto load64 = [&](const T *src, int ld, int hb, uint4 (&r)[8]) __attribute__((always_inline)) {
+        if constexpr (OUTS != 0) {
+            // (mw is wave-uniform: the resource and the row step live in SGPRs)
+            const __amdgpu_buffer_rsrc_t rs = rows_rsrc(src + (size_t)__builtin_amdgcn_readfirstlane(mw) * ld);
+            const uint32_t vo = (uint32_t)(lrow * ld + c0) * 2u;
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps) r[ps] = *(const uint4 *)(src + rowof(hb * 8 + ps) * ld + c0);
+            for (int ps = 0; ps < 8; ++ps) {
+                const u32x4_v q = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (hb * 8 + ps) * 16 * ld, 0);
+                r[ps] = make_uint4(q[0], q[1], q[2], q[3]);
+            }
+        } else {
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) r[ps] = *(const uint4 *)(src + rowof(hb * 8 + ps) * ld + c0);
+        }
     };
     // eval-BN parameter sums of the masked gradient (backward: v = gradient w.r.t. the BN output where the activation is on):
     // S1[c] = sum_m v * mask_scale, S2[c] = sum_m v * mask_scale * act -- what kd_channel_sums would read back from memory
@@ -141,6 +185,8 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
     if (NOPS > 0)
         asm volatile("" ::"v"(mscale[0]), "v"(mscale[1]), "v"(mscale[2]), "v"(mscale[3]), "v"(mscale[4]), "v"(mscale[5]), "v"(mscale[6]),
                      "v"(mscale[7]));
+    const f32x2_v asc2[4] = {{ascale[0], ascale[1]}, {ascale[2], ascale[3]}, {ascale[4], ascale[5]}, {ascale[6], ascale[7]}};
+    const f32x2_v ash2[4] = {{ashift[0], ashift[1]}, {ashift[2], ashift[3]}, {ashift[4], ashift[5]}, {ashift[6], ashift[7]}};
 #pragma unroll
     for (int hb = 0; hb < MI / 4; ++hb) {   // 64 rows each
         if (nops >= 2 && hb == 1) { load64(s0, ld0, 1, ra); load64(s1, ld1, 1, rb); }
@@ -193,6 +239,24 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
                     ld8((const T *)&oq, t);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) v[q] += t[q];
+                }
+                if constexpr (OUTS != 0) {
+                    const int srow = (hb * 8 + ps) * 16;       // bytes per ld: row (hb * 8 + ps) * 8 of the wave's 128
+                    if constexpr ((OUTS & 1) != 0) {
+                        const u32x4_v o = nops == 0 ? (u32x4_v){rawv.x, rawv.y, rawv.z, rawv.w}
+                                                    : (u32x4_v){pack_bf16x2_v(v[0], v[1]), pack_bf16x2_v(v[2], v[3]), pack_bf16x2_v(v[4], v[5]), pack_bf16x2_v(v[6], v[7])};
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_raw, vo_raw + (uint32_t)(srow * e.ld_raw), 0, 0);
+                    }
+                    if constexpr ((OUTS & 2) != 0) {
+                        const u32x4_v o = {act_pair(v[0], v[1], asc2[0], ash2[0], relu_i16), act_pair(v[2], v[3], asc2[1], ash2[1], relu_i16),
+                                           act_pair(v[4], v[5], asc2[2], ash2[2], relu_i16), act_pair(v[6], v[7], asc2[3], ash2[3], relu_i16)};
+#ifdef KDCC_TUNING
+                        if (p.tune & 128) { asm volatile("" ::"v"(o)); continue; }      // timing ablation: everything but the store itself
+                        if (p.tune & 256) { *(u32x4_v *)((T *)e.out_act + (size_t)(((m & 15) + 16 * (blockIdx.x * 8 + (threadIdx.x >> 6))) % 4096) * e.ld_act + c0) = o; continue; }
+#endif
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_act, vo_act + (uint32_t)(srow * e.ld_act), 0, 0);
+                    }
+                    continue;
                 }
                 if (OUTS ? (OUTS & 1) != 0 : e.out_raw != nullptr) {
                     if (nops == 0) *(uint4 *)((T *)e.out_raw + m * e.ld_raw + c0) = rawv;
@@ -270,5 +334,7 @@ struct TileWalk {
 // conv_lw.hip: the one-wave-per-SIMD row kernel (128 x 128 wave tiles, hand-scheduled main loop).  nops_sums = NOPS | 4 when the
 // eval-BN sums are taken.  Returns false when the instantiation does not exist.
 bool kd_launch_conv_row_lw(const ConvParams &p, int nops_sums, unsigned grid, hipStream_t s);
+bool kd_launch_conv_row_tall(const ConvParams &p, int nops_sums, unsigned grid, hipStream_t s);   // 512 x 128 tiles (Cout % 128 == 0, Cin % 64 == 0, W % 512 == 0)
+int kd_lw_tlog_copy(unsigned long long *dst, size_t bytes);   // conv_row_duo_kernel's per-tile stamps (KDCC_CONV_TUNE & 1024)
 bool kd_launch_conv_row_duo(const ConvParams &p, int nops_sums, unsigned grid, hipStream_t s);   // 256 x 128 tiles, two workgroups per CU
 bool kd_launch_conv_pw_lw(const ConvParams &p, int nops_sums, unsigned grid, hipStream_t s);   // 1x1 / stride 1, Cin % 128 == 0

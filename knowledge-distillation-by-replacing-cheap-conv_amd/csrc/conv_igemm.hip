@@ -1683,7 +1683,12 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         p.tn_group = 0;
         const int nwg = p.ntiles < persist_cus() ? p.ntiles : persist_cus();
         const dim3 grid((unsigned)((nwg + 7) / 8 * 8));
-        KD_NOTE_KERNEL("conv_row_pp128_kernel");
+        // conv_row_tall_kernel (conv_lw.hip): the same tiles with one wave per SIMD and the hand-scheduled loop; A/B: KDCC_CONV_LW=0
+        const bool tall = lw_row() && d->Cin % 64 == 0 && d->H > d->dil && !(p.tune & 512) && !(ep->bn_sums && nops == 0);
+        KD_NOTE_KERNEL(tall ? "conv_row_tall_kernel" : "conv_row_pp128_kernel");
+        if (tall) {
+            KD_REQUIRE(kd_launch_conv_row_tall(p, nops | (ep->bn_sums ? 4 : 0), grid.x, s), KD_ERR_UNSUPPORTED, "kd_conv2d_fwd: no conv_row_tall_kernel instantiation for %d epilogue operands", nops);
+        } else
         if (p.tune & 512) hipLaunchKernelGGL((conv_row_pp128_kernel<0, true>), grid, dim3(512), 0, s, p);   // phase clocks (no-operand form only)
         else if (nops == 0) hipLaunchKernelGGL((conv_row_pp128_kernel<0>), grid, dim3(512), 0, s, p);
         else if (ep->bn_sums && nops == 1) hipLaunchKernelGGL((conv_row_pp128_kernel<5>), grid, dim3(512), 0, s, p);
@@ -1723,6 +1728,7 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
 
 extern "C" int kd_debug_conv_tlog(unsigned long long *dst, size_t bytes)
 {
+    if (KD_TUNING_ENV_INT("KDCC_CONV_TUNE") & 1024) return kd_lw_tlog_copy(dst, bytes) == 0 ? KD_OK : KD_ERR_HIP;   // conv_lw.hip's log
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(kd_conv_tlog), bytes < sizeof(kd_conv_tlog) ? bytes : sizeof(kd_conv_tlog), 0,
                                hipMemcpyDeviceToHost) == hipSuccess ? KD_OK : KD_ERR_HIP;
 }

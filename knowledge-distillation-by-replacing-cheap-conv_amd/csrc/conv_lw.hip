@@ -25,6 +25,7 @@
 namespace {
 
 __device__ __attribute__((aligned(256))) uint32_t lw_zero_page[64];   // zero-initialised
+__device__ unsigned long long lw_tlog[512 * 32 * 4];   // KDCC_CONV_TUNE & 1024 (tuning build): per workgroup and tile, 100-MHz stamps: tile start / main loop end / epilogue end
 
 constexpr int LW_ABUF = 320 * 128, LW_BSLOT = 256 * 64, LW_NEED = 2 * LW_ABUF + 4 * LW_BSLOT;
 
@@ -448,8 +449,12 @@ __global__ __launch_bounds__(256, 2) void conv_row_duo_kernel(const ConvParams p
     asm volatile(DUO_ZERO_ACC_ASM : "=a"(A0), "=a"(A1), "=a"(A2), "=a"(A3));
 #define DUO_ACC_RW "+a"(A0), "+a"(A1), "+a"(A2), "+a"(A3)
     uint32_t flag = 0;
+    int tcount = 0;
 #pragma unroll 1
     for (;;) {
+        const bool tl = (p.tune & 1024) && tid == 0 && tcount < 32 && blockIdx.x < 512;
+        unsigned long long *tlp = lw_tlog + ((size_t)blockIdx.x * 32 + (tcount & 31)) * 4;
+        if (tl) tlp[0] = __builtin_amdgcn_s_memrealtime();
         lane_addresses();
         asm volatile(DUO_REFILL_ASM : : [va0] "v"(va[0]), [vb] "v"(vb) : "memory", DUO_CLOBBER_FRAG);
         const int n_tile = c_tile + walk.step;
@@ -471,6 +476,7 @@ __global__ __launch_bounds__(256, 2) void conv_row_duo_kernel(const ConvParams p
                        [s2cin] "s"(s2cin), [sflag] "s"(flag), [sldsA] "s"(sldsA), [sldsB] "s"(sldsB)
                      : "memory", "scc", "vcc", DUO_CLOBBER_S, DUO_CLOBBER_FRAG);
         asm volatile("s_nop 15\n\ts_nop 15" : DUO_ACC_RW : : "memory");
+        if (tl) tlp[1] = __builtin_amdgcn_s_memrealtime();
         if (!(p.tune & 64)) {
             const int mw = cur.m0 + wm * 128, nw = cur.n0 + wn * 64;
             char *patch = lds + DUO_NEED + wv * 2048;
@@ -503,12 +509,187 @@ __global__ __launch_bounds__(256, 2) void conv_row_duo_kernel(const ConvParams p
 #undef DUO_RD
 #undef DUO_EPI
         }
+        if (tl) { tlp[2] = __builtin_amdgcn_s_memrealtime(); tlp[3] = (unsigned long long)c_tile; }
+        ++tcount;
         if (!more) break;
         c_tile = n_tile;
         cur = nxt;
         flag = 1;
     }
 #undef DUO_ACC_RW
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---- the lone-wave loop for the 128-output-channel layers (mod2, the GSCNN shape stream) --------------------------------------------------
+// conv_row_tall_kernel: tile 512 pixels x 128 channels, wave w = pixels 128 w .. + 127 x all 128 channels, i.e. conv_row_lw_kernel's wave
+// tile, accumulator layout and epilogue; K staged in 32-channel periods (tools/gen_conv_lw.py, "tall": two row buffers of 576 rows x 64 B,
+// four 8-KiB B slots, 16-KiB epilogue patches = 120 KiB).  Replaces conv_row_pp128_kernel (8 waves of 128 x 64, hipcc-scheduled ping-pong:
+// 0.38-0.40 of peak) where Cin % 64 == 0; same k order (32-channel block, kernel row, tap), same epilogue: bit-identical results.
+constexpr int TALL_ABUF = 576 * 64, TALL_BSLOT = 128 * 64, TALL_NEED = 2 * TALL_ABUF + 4 * TALL_BSLOT;
+
+template <int NOPS_>
+__global__ __launch_bounds__(256, 1) void conv_row_tall_kernel(const ConvParams p)
+{
+    typedef unsigned long long u64;
+    __shared__ __attribute__((aligned(1024))) char lds[TALL_NEED + 4 * 4096];   // 120 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int d = p.dil;
+    TileWalk walk(p.ntiles);
+    if (walk.t >= walk.t_end) return;
+    stagger_start(p);
+    const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    uint32_t va[3], vb, voa[9], vob[2], vz0, vz1, vr0;
+    u32x4_t vzero;
+    auto lane_addresses = [&]() __attribute__((always_inline)) {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int frow = l & 15, fq = l >> 4;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int rsh = frow + kx * d;
+            va[kx] = lbase + (wv * 128 + rsh) * 64 + ((fq ^ ((rsh >> 1) & 3)) << 4);
+        }
+        vb = lbase + 2 * TALL_ABUF + frow * 64 + ((fq ^ ((frow >> 1) & 3)) << 4);
+        const int srow = l >> 2, chunk = ((l & 3) ^ ((l >> 3) & 3)) << 4;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) voa[j] = (uint32_t)(((wv * 9 + j) * 16 + srow) * (p.ldx * 2) + chunk);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) vob[j] = (uint32_t)(((wv * 2 + j) * 16 + srow) * (p.Ktot * 2) + chunk);
+        vz0 = lbase + wv * 9216 + l * 16;
+        vz1 = vz0 + TALL_ABUF;
+        vr0 = (uint32_t)(wv * 144 + srow);     // buffer row of this lane in piece 0 (piece j: + 16 j)
+        vzero = (u32x4_t){0u, 0u, 0u, 0u};
+    };
+    lane_addresses();
+    const uint32_t sldsA = __builtin_amdgcn_readfirstlane(lbase + wv * 9216);
+    const uint32_t sldsB = __builtin_amdgcn_readfirstlane(lbase + 2 * TALL_ABUF + wv * 2048);
+    const uint32_t s2cin = (uint32_t)(2 * p.Cin);
+    const long long dWl2 = 2ll * d * p.W * p.ldx;
+    const int nkc = p.Cin / 32;
+
+    struct Tile {
+        int m0, n0, kylo, nky;
+        uint32_t lo, span;
+        u64 abase, bbase;
+    };
+    auto decode = [&](int tile, Tile &t) {
+        const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+        t.m0 = tm * 512;
+        t.n0 = tn * 128;
+        const int n = t.m0 / p.HoWo, rem = t.m0 - n * p.HoWo;
+        const int ho = rem / p.W, x0 = rem - ho * p.W;
+        t.kylo = ho - d < 0 ? 1 : 0;
+        t.nky = (ho + d >= p.H ? 1 : 2) - t.kylo + 1;
+        // pixel x0 - d + r: outside the row for r < d in the row's first tile and for r >= 512 + d in its last
+        t.lo = x0 == 0 ? (uint32_t)d : 0u;
+        t.span = (x0 + 512 == p.W ? 512u + d : 576u) - t.lo;
+        t.abase = (u64)p.x + (u64)(2ll * ((long long)((n * p.H + ho) * p.W + (x0 - d)) * p.ldx));
+        if (p.tune & 2048) t.abase = (u64)p.x + (u64)(2ll * ((long long)((d + (tile & 7)) * p.W + (x0 - d)) * p.ldx));   // timing ablation (tuning build): every tile reads the same few rows (L2-resident input)
+        t.bbase = (u64)p.w + (u64)(2ll * (long long)t.n0 * p.Ktot);
+    };
+    // period q of a tile = (32-channel block q / nky, kernel row kylo + q % nky)
+    auto a_of = [&](const Tile &t, int q) { return t.abase + (u64)((long long)(t.kylo + q % t.nky - 1) * dWl2 + (q / t.nky) * 64); };
+    auto b_of = [&](const Tile &t, int q) { return t.bbase + (u64)(2ll * ((long long)(t.kylo + q % t.nky) * 3 * p.Cin + (q / t.nky) * 32)); };
+
+    Tile cur, nxt;
+    int c_tile = walk.t;
+    decode(c_tile, cur);
+    // prologue (generic pieces): the row buffers of periods 0 and 1, B of k-steps 0 .. 3 = period 0's three taps and period 1's first
+    {
+        const char *a0 = (const char *)a_of(cur, 0), *a1 = (const char *)a_of(cur, 1);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const bool ok = vr0 + 16 * j - cur.lo < cur.span;
+            glds16(ok ? (const void *)(a0 + voa[j]) : (const void *)lw_zero_page, lds + (wv * 9 + j) * 1024);
+            glds16(ok ? (const void *)(a1 + voa[j]) : (const void *)lw_zero_page, lds + TALL_ABUF + (wv * 9 + j) * 1024);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const char *bb = q < 3 ? (const char *)b_of(cur, 0) + 2ll * q * p.Cin : (const char *)b_of(cur, 1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16(bb + vob[j], lds + 2 * TALL_ABUF + q * TALL_BSLOT + (wv * 2 + j) * 1024);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    typedef __attribute__((ext_vector_type(32))) float f32x32_t;
+    f32x32_t A0, A1, A2, A3, A4, A5, A6, A7;   // the accumulator file is occupied (see conv_row_lw_kernel)
+    asm volatile(LW_ZERO_ACC_ASM : "=a"(A0), "=a"(A1), "=a"(A2), "=a"(A3), "=a"(A4), "=a"(A5), "=a"(A6), "=a"(A7));
+#define LW_ACC_RW "+a"(A0), "+a"(A1), "+a"(A2), "+a"(A3), "+a"(A4), "+a"(A5), "+a"(A6), "+a"(A7)
+    uint32_t flag = 0, par = 0;
+    int tcount = 0;
+#pragma unroll 1
+    for (;;) {
+        const bool tl = (p.tune & 1024) && tid == 0 && tcount < 32 && blockIdx.x < 512;     // tools/duo_timeline.py --tall
+        unsigned long long *tlp = lw_tlog + ((size_t)blockIdx.x * 32 + (tcount & 31)) * 4;
+        if (tl) tlp[0] = __builtin_amdgcn_s_memrealtime();
+        lane_addresses();
+        asm volatile(TALL_REFILL_ASM : : [va0] "v"(va[0]), [vbf] "v"(vb + par * 2 * TALL_BSLOT) : "memory", LW_CLOBBER_FRAG);
+        const int n_tile = c_tile + walk.step;
+        const bool more = n_tile < walk.t_end;
+        if (more) decode(n_tile, nxt);
+        else nxt = cur;                       // nothing left to stage: re-stage this tile's first periods (valid memory, unread)
+        const uint32_t nper = (uint32_t)(nkc * cur.nky);
+        const u64 sBn1 = b_of(cur, 1), sAn2 = a_of(cur, 2), sBn2 = b_of(cur, 2);
+        const u64 sAnT0 = a_of(nxt, 0), sBnT0 = b_of(nxt, 0), sAnT1 = a_of(nxt, 1), sBnT1 = b_of(nxt, 1);
+        const int dAs = (int)dWl2, dAw = (int)(64 - (cur.nky - 1) * dWl2), dBs = 6 * p.Cin, dBw = 64 - (cur.nky - 1) * 6 * p.Cin;
+        asm volatile(TALL_TILE_ASM
+                     : LW_ACC_RW
+                     : [va0] "v"(va[0]), [va1] "v"(va[1]), [va2] "v"(va[2]), [vb] "v"(vb), [voa0] "v"(voa[0]), [voa1] "v"(voa[1]),
+                       [voa2] "v"(voa[2]), [voa3] "v"(voa[3]), [voa4] "v"(voa[4]), [voa5] "v"(voa[5]), [voa6] "v"(voa[6]), [voa7] "v"(voa[7]),
+                       [voa8] "v"(voa[8]), [vob0] "v"(vob[0]), [vob1] "v"(vob[1]), [vz0] "v"(vz0), [vz1] "v"(vz1), [vzero] "v"(vzero),
+                       [vr0] "v"(vr0), [sBn1] "s"(sBn1), [sAn2] "s"(sAn2), [sBn2] "s"(sBn2), [sAnT0] "s"(sAnT0), [sBnT0] "s"(sBnT0),
+                       [sAnT1] "s"(sAnT1), [sBnT1] "s"(sBnT1), [slo] "s"(cur.lo), [ssp] "s"(cur.span), [sloT] "s"(nxt.lo), [sspT] "s"(nxt.span),
+                       [sdAs] "s"(dAs), [sdAw] "s"(dAw), [sdBs] "s"(dBs), [sdBw] "s"(dBw), [snky] "s"((uint32_t)cur.nky),
+                       [sky2] "s"((uint32_t)(2 % cur.nky)), [snper] "s"(nper), [s2cin] "s"(s2cin), [sflag] "s"(flag), [spar] "s"(par),
+                       [sldsA] "s"(sldsA), [sldsB] "s"(sldsB)
+                     : "memory", "scc", "vcc", DUO_CLOBBER_S, LW_CLOBBER_FRAG);
+        par = (par + (nper >> 1)) & 1u;
+        asm volatile("s_nop 15\n\ts_nop 15" : LW_ACC_RW : : "memory");
+        if (tl) tlp[1] = __builtin_amdgcn_s_memrealtime();
+        if (!(p.tune & 64)) {
+        const int mw = cur.m0 + wv * 128, nw = cur.n0;
+        char *patch = lds + TALL_NEED + wv * 4096;
+#define LW_RD(I, JG)                                                                                                                  \
+    {                                                                                                                                 \
+        float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14, t15;                                                   \
+        asm volatile(LW_READ_ACC_##I##_##JG##_ASM                                                                                     \
+                     : "=v"(t0), "=v"(t1), "=v"(t2), "=v"(t3), "=v"(t4), "=v"(t5), "=v"(t6), "=v"(t7), "=v"(t8), "=v"(t9), "=v"(t10), \
+                       "=v"(t11), "=v"(t12), "=v"(t13), "=v"(t14), "=v"(t15), LW_ACC_RW);                                             \
+        acc[I][0] = make_uint2(pack_bf16x2_v(t0, t1), pack_bf16x2_v(t2, t3));                                                         \
+        acc[I][1] = make_uint2(pack_bf16x2_v(t4, t5), pack_bf16x2_v(t6, t7));                                                         \
+        acc[I][2] = make_uint2(pack_bf16x2_v(t8, t9), pack_bf16x2_v(t10, t11));                                                       \
+        acc[I][3] = make_uint2(pack_bf16x2_v(t12, t13), pack_bf16x2_v(t14, t15));                                                     \
+    }
+        {
+            uint2 acc[8][4];
+            LW_RD(0, 0) LW_RD(1, 0) LW_RD(2, 0) LW_RD(3, 0) LW_RD(4, 0) LW_RD(5, 0) LW_RD(6, 0) LW_RD(7, 0)
+            // what ran ahead into the next tile's buffers has landed before the first store: the first two waits of that tile may then
+            // leave every store outstanding
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (p.ep.out_raw && p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 2, uint2, 3>(p, patch, acc, mw, nw, lane);
+            else if (p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 2, uint2, 2>(p, patch, acc, mw, nw, lane);
+            else ig_epilogue_rows16<8, NOPS_, 2, uint2, 1>(p, patch, acc, mw, nw, lane);
+        }
+        {
+            uint2 acc[8][4];
+            LW_RD(0, 1) LW_RD(1, 1) LW_RD(2, 1) LW_RD(3, 1) LW_RD(4, 1) LW_RD(5, 1) LW_RD(6, 1) LW_RD(7, 1)
+            if (p.ep.out_raw && p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 2, uint2, 3>(p, patch, acc, mw, nw + 64, lane);
+            else if (p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 2, uint2, 2>(p, patch, acc, mw, nw + 64, lane);
+            else ig_epilogue_rows16<8, NOPS_, 2, uint2, 1>(p, patch, acc, mw, nw + 64, lane);
+        }
+#undef LW_RD
+        }
+        if (tl) { tlp[2] = __builtin_amdgcn_s_memrealtime(); tlp[3] = (unsigned long long)c_tile; }
+        ++tcount;
+        if (!more) break;
+        c_tile = n_tile;
+        cur = nxt;
+        flag = 1;
+    }
+#undef LW_ACC_RW
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -551,4 +732,22 @@ bool kd_launch_conv_row_duo(const ConvParams &p, int nops_sums, unsigned grid, h
     default: return false;      // two operands: the epilogue does not fit the 128 registers beside the accumulator file (hipcc then moves
                                 // accumulators around: tools/check_lw_asm.py); eval-BN sums: one partial row per 128 pixels in one pass
     }
+}
+
+bool kd_launch_conv_row_tall(const ConvParams &p, int nops_sums, unsigned grid, hipStream_t s)
+{
+    const dim3 g(grid), b(256);
+    switch (nops_sums) {
+    case 0: hipLaunchKernelGGL((conv_row_tall_kernel<0>), g, b, 0, s, p); return true;
+    case 1: hipLaunchKernelGGL((conv_row_tall_kernel<1>), g, b, 0, s, p); return true;
+    case 2: hipLaunchKernelGGL((conv_row_tall_kernel<2>), g, b, 0, s, p); return true;
+    case 5: hipLaunchKernelGGL((conv_row_tall_kernel<5>), g, b, 0, s, p); return true;
+    case 6: hipLaunchKernelGGL((conv_row_tall_kernel<6>), g, b, 0, s, p); return true;
+    default: return false;
+    }
+}
+
+int kd_lw_tlog_copy(unsigned long long *dst, size_t bytes)
+{
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(lw_tlog), bytes < sizeof(lw_tlog) ? bytes : sizeof(lw_tlog), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }

@@ -78,7 +78,7 @@ def _step(model, backprop="hint"):
     return out_st, out_tc, hint, kd, loss
 
 
-SHIPPED_MODE_A = ["conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>", "conv_row_pp128_kernel",
+SHIPPED_MODE_A = ["conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>", "conv_row_tall_kernel",
                   "dw_mfma_fwd_kernel<1,false>", "dw_mfma_fwd_kernel<3,true>", "dw_mfma_fwd_kernel<3,false>",
                   "dw_mfma_wgrad_kernel", "dw_mfma_wgrad_multi_kernel<3>", "stem_pool_kernel", "conv_wgrad_wide_kernel"]   # (the pointwise weight gradients take the 256x256 wgrad tile)
 
@@ -96,7 +96,7 @@ def test_bf16_p92_step_on_the_shipped_kernels_vs_network_oracle():
     missing = [k for k in SHIPPED_MODE_A if log.counts.get(k, 0) == 0]
     assert not missing, f"kernels the bench step runs but this step did not select: {missing}; selected: {log.counts}"
     # the 3x3 / 1x1 layers of mod3..mod7 and the decoder must be on the persistent kernels, not on the one-tile fallbacks
-    persistent = log.counts["conv_row_lw_kernel"] + log.counts["conv_igemm_persist_kernel<pp>"] + log.counts["conv_row_pp128_kernel"]
+    persistent = log.counts["conv_row_lw_kernel"] + log.counts["conv_igemm_persist_kernel<pp>"] + log.counts["conv_row_tall_kernel"]
     total_conv = sum(v for k, v in log.counts.items() if k.startswith(("conv_row_", "conv_igemm_")))
     assert persistent >= 0.75 * total_conv, log.counts
 
@@ -357,8 +357,8 @@ def test_fullsize_bench_step_determinism_batch_independence_and_prefix_sharing()
 
 @pytest.mark.parametrize("name,kw,must", [
     ("modeB", dict(mode="B"), ("conv_wgrad_row_kernel", "conv_wgrad_wide_kernel", "conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>",
-                              "conv_row_pp128_kernel", "dw_mfma_wgrad_multi_kernel<3>", "bn_sums_epilogue", "stem_wgrad_mfma_kernel")),
-    ("gscnn_P86", dict(arch="gscnn", plan="P86"), ("conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>", "conv_row_pp128_kernel",
+                              "conv_row_tall_kernel", "dw_mfma_wgrad_multi_kernel<3>", "bn_sums_epilogue", "stem_wgrad_mfma_kernel")),
+    ("gscnn_P86", dict(arch="gscnn", plan="P86"), ("conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>", "conv_row_tall_kernel",
                                                    "conv3x3_small_kernel<64>", "gated_conv_mfma_kernel", "dw_mfma_fwd_kernel<3,true>")),
 ])
 def test_fullsize_bench_subrecords_are_deterministic(name, kw, must):

@@ -136,7 +136,7 @@ def test_reducer_mode_b_buckets_complete_before_the_optimizer_single_rank_nccl()
 def test_persistent_conv_kernels_on_fewer_cus_are_bit_identical():
     """KDCC_PERSIST_CUS=248 (the persistent conv kernels leave 8 CUs to a concurrent RCCL kernel): a tile's arithmetic does not
     depend on which workgroup computes it -- the outputs of the 3x3 lone-wave kernel, the 1x1 ping-pong kernel and the 512 x 128
-    kernel are bit-identical to the 256-workgroup launch (child processes: the switch is read once)."""
+    lone-wave kernel are bit-identical to the 256-workgroup launch (child processes: the switch is read once)."""
     import json
     import subprocess
     import sys
@@ -166,5 +166,5 @@ print("RESULT " + json.dumps(out))
         assert r.returncode == 0 and line, (r.stdout[-1000:], r.stderr[-2000:])
         res[cus] = json.loads(line[0][7:])
     assert res["256"]["row"][1] == ["conv_row_lw_kernel"] and res["256"]["pw"][1] == ["conv_igemm_persist_kernel<pp>"] and \
-        res["256"]["pp128"][1] == ["conv_row_pp128_kernel"], res["256"]
+        res["256"]["pp128"][1] == ["conv_row_tall_kernel"], res["256"]
     assert res["248"] == res["256"]

@@ -154,8 +154,8 @@ BN_SUMS_CASES = [
     (2, 96, 256, 256, 512, 3, 2, "mq", "conv_row_lw_kernel"),
     (1, 128, 512, 128, 256, 1, 1, "pm", "conv_igemm_persist_kernel<pp>"),
     (1, 128, 512, 256, 256, 1, 1, "mq", "conv_igemm_persist_kernel<pp>"),
-    (1, 256, 512, 128, 128, 3, 1, "m", "conv_row_pp128_kernel"),
-    (1, 256, 512, 64, 128, 3, 1, "mq", "conv_row_pp128_kernel"),
+    (1, 256, 512, 128, 128, 3, 1, "m", "conv_row_tall_kernel"),
+    (1, 256, 512, 64, 128, 3, 1, "mq", "conv_row_tall_kernel"),
     (1, 64, 256, 128, 64, 3, 1, "m", None),
 ]
 
@@ -259,7 +259,8 @@ PERSIST_CASES = [
     ((1, 20, 512, 64, 2048, 1, 0, 1), (), ("act",)),
     ((1, 160, 512, 64, 256, 1, 0, 1), ("pre", "mask", "post"), ("raw",)),          # three operands (dgrad: mask + both residuals)
     ((1, 80, 512, 64, 512, 3, 2, 2), ("pre", "mask", "post"), ("raw", "act")),
-    # Cout = 128, W % 512 == 0: the 512 x 128 ping-pong kernel (64-B K stages)
+    # Cout = 128, W % 512 == 0: 512 x 128 tiles, conv_row_tall_kernel (64-B K stages; KDCC_CONV_LW=0: conv_row_pp128_kernel, tools/lw_check.py)
+    ((1, 40, 1024, 192, 128, 3, 3, 3), ("pre", "mask"), ("raw", "act")),     # 18 / 12 periods per tile: both entry phases of the loop body
     ((1, 24, 512, 64, 128, 3, 1, 1), ("pre",), ("raw", "act")),
     ((1, 20, 1024, 128, 128, 3, 2, 2), (), ("act",)),
     ((2, 150, 512, 64, 128, 3, 1, 1), ("mask", "post"), ("raw",)),      # 300 tiles: two per workgroup on part of the chip
@@ -296,7 +297,7 @@ def test_conv_persistent_epilogues(K, case, opnds, outs):
              res_post=dev_nhwc(post, dt, ld=Cout + 24) if "post" in opnds else None,
              out_raw=out_raw, out_act=out_act, act_scale=cu(ascale) if "act" in outs else None,
              act_shift=cu(ashift) if "act" in outs else None, act_relu="act" in outs)
-    selected("conv_igemm_persist_kernel<pp>" if k == 1 else "conv_row_pp128_kernel" if Cout == 128 else "conv_row_lw_kernel",
+    selected("conv_igemm_persist_kernel<pp>" if k == 1 else "conv_row_tall_kernel" if Cout == 128 else "conv_row_lw_kernel",
              f"{case} {opnds}")
     if out_raw is not None:
         assert_close(host_nchw(out_raw), ref, dt, f"raw {case} {opnds}")

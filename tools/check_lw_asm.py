@@ -23,7 +23,7 @@ LABEL = re.compile(r"^(\.?[A-Za-z_][\w.$]*):")
 
 def audit(text):
     findings = []
-    bodies = re.split(r"^(_ZN\S*conv_(?:row_lw|pw_lw|row_duo)_kernel\S*):\s*;[^\n]*\n", text, flags=re.M)
+    bodies = re.split(r"^(_ZN\S*conv_(?:row_lw|pw_lw|row_duo|row_tall)_kernel\S*):\s*;[^\n]*\n", text, flags=re.M)
     n_kernels = 0
     for k in range(1, len(bodies), 2):
         name, code = bodies[k], bodies[k + 1].split(".Lfunc_end")[0]

@@ -337,6 +337,120 @@ def refill_duo():
     return L
 
 
+# ---- "tall": the lone-wave loop for 128-output-channel layers (conv_row_tall_kernel) ---------------------------------------------------
+# Tile 512 pixels x 128 channels: wave w owns pixels 128 w .. + 127 and all 128 channels -- the 128 x 128 wave tile, accumulator layout,
+# fragment registers and epilogue of conv_row_lw_kernel.  (256 x 128 with 128 x 64 wave tiles, the duo kernel above, reads 1.5 x the LDS
+# fragment bytes per MFMA and sits on the LDS port: 0.39 of peak in its main loop.)  Two 256 x 256 row buffers would not fit for 512
+# pixels, so K is staged in 32-channel periods like the duo kernel: two row buffers of 576 rows x 64 B (dil <= 32), B in FOUR 8-KiB slots.
+# A period P = the three taps of one (32-channel block, kernel row) = 3 k-steps of 64 MFMAs.  Body k-step b = 0 .. 11 (four periods: the
+# slot cycle of 4 and the period length of 3 close after 12; fragment set b & 1, row buffer (b / 3) & 1, B slot b & 3):
+#   * the 16 fragment reads of k-step b + 1;
+#   * B of k-step b + 4 into slot b & 3 (its fragments were read during b - 1): 2 pieces per wave, source = period P + 1 tap kx + 1
+#     (kx = 0, 1) or period P + 2 tap 0 (kx = 2);
+#   * at kx = 2 all 9 pieces of this wave of the row buffer of period P + 2 (the buffer of period P, last read during (P, 1));
+#   * s_waitcnt vmcnt(13, 4, 13)[kx]: what k-step b + 2 reads has landed (B: issued at b - 2; row buffer: at the previous period's
+#     tap 2), then the barrier.  After an epilogue the first two waits leave its stores outstanding (everything they are for was issued
+#     before the epilogue, and the kernel waits vmcnt(0) before the first store), the third one is the first that needs them acknowledged.
+# Tiles have an even number of periods (Cin % 64 == 0), so a tile starts at b = 0 or b = 6 (operand spar): fragment set 0, row buffer 0,
+# B slot 0 or 2.
+TALL_ABUF, TALL_BSLOT = 576 * 64, 128 * 64
+TALL_WAIT = (13, 4, 13)
+
+
+def tall_a_piece(j, buf):
+    return [f"s_add_u32 m0, %[sldsA], {buf * TALL_ABUF + j * 1024}", f"v_add_u32 {VT}, {16 * j}, %[vr0]", f"v_subrev_u32 {VT}, {D_LO2}, {VT}",
+            f"v_cmpx_gt_u32 vcc, {D_SP2}, {VT}", f"global_load_lds_dwordx4 %[voa{j}], {D_SAN2}", "s_not_b64 exec, exec",
+            f"ds_write_b128 %[vz{buf}], %[vzero] offset:{j * 1024}", "s_mov_b64 exec, -1"]
+
+
+def tall_shift(tag):
+    """period end: B's period P + 1 := P + 2; the (A, B) period P + 2 moves on: next kernel row / channel block of the tile, then the
+    next tile's periods 0 and 1"""
+    return [f"s_mov_b64 {D_SBN1}, {D_SBN2}",
+            f"s_sub_u32 {SIN}, {SIN}, 1", f"s_cmp_gt_i32 {SIN}, 0", f"s_cbranch_scc0 LTT{tag}_%=",
+            f"s_add_u32 {SKY}, {SKY}, 1", f"s_cmp_eq_u32 {SKY}, %[snky]",
+            f"s_cselect_b32 {ST0}, %[sdAw], %[sdAs]", f"s_cselect_b32 {ST1}, %[sdBw], %[sdBs]", f"s_cselect_b32 {SKY}, 0, {SKY}",
+            f"s_ashr_i32 {ST2}, {ST0}, 31", f"s_add_u32 s92, s92, {ST0}", f"s_addc_u32 s93, s93, {ST2}",
+            f"s_ashr_i32 {ST2}, {ST1}, 31", f"s_add_u32 s94, s94, {ST1}", f"s_addc_u32 s95, s95, {ST2}",
+            f"s_branch LTU{tag}_%=", f"LTT{tag}_%=:",
+            f"s_mov_b32 {D_LO2}, %[sloT]", f"s_mov_b32 {D_SP2}, %[sspT]", f"s_cmp_eq_u32 {SIN}, 0", f"s_cbranch_scc0 LTV{tag}_%=",
+            f"s_mov_b64 {D_SAN2}, %[sAnT0]", f"s_mov_b64 {D_SBN2}, %[sBnT0]", f"s_branch LTU{tag}_%=", f"LTV{tag}_%=:",
+            f"s_mov_b64 {D_SAN2}, %[sAnT1]", f"s_mov_b64 {D_SBN2}, %[sBnT1]", f"LTU{tag}_%=:"]
+
+
+def tall_kstep(b, zero=False):
+    pb, kx, cur = b // 3, b % 3, b & 1
+    per = pb & 1
+    areg, breg = frag_regs(cur)
+    nareg, nbreg = frag_regs(1 - cur)
+    slots = [[] for _ in range(64)]
+    nkx = (kx + 1) % 3
+    nbuf = per if kx < 2 else 1 - per
+    nslot = (b + 1) & 3
+    reads = [f"ds_read_b128 v[{nareg[i]}:{nareg[i] + 3}], %[va{nkx}] offset:{nbuf * TALL_ABUF + i * 1024}" for i in range(8)]
+    reads += [f"ds_read_b128 v[{nbreg[j]}:{nbreg[j] + 3}], %[vb] offset:{nslot * TALL_BSLOT + j * 1024}" for j in range(8)]
+    for r, ins in enumerate(reads):
+        slots[1 + 3 * r].append(ins)
+    # B of k-step b + 4 into slot b & 3
+    if kx == 0:
+        slots[2] += ["s_add_u32 s88, s78, %[s2cin]", "s_addc_u32 s89, s79, 0"]        # (P + 1, tap 1)
+    elif kx == 1:
+        slots[2] += ["s_add_u32 s88, s88, %[s2cin]", "s_addc_u32 s89, s89, 0"]        # (P + 1, tap 2)
+    else:
+        slots[2].append(f"s_mov_b64 {SB}, {D_SBN2}")                                  # (P + 2, tap 0)
+    for j, k in enumerate((5, 20)):
+        slots[k] += [f"s_add_u32 m0, %[sldsB], {(b & 3) * TALL_BSLOT + j * 1024}", "s_nop 0", f"global_load_lds_dwordx4 %[vob{j}], {SB}"]
+    if kx == 2:
+        for n, j in enumerate(range(9)):
+            slots[(8, 14, 23, 29, 35, 41, 48, 54, 60)[n]] += tall_a_piece(j, per)
+    L = []
+    k = 0
+    for i in range(8):
+        for j in range(8):
+            acc = 4 * (8 * i + j)
+            L.append(f"v_mfma_f32_16x16x32_bf16 a[{acc}:{acc + 3}], v[{breg[j]}:{breg[j] + 3}], v[{areg[i]}:{areg[i] + 3}], " + ("0" if zero else f"a[{acc}:{acc + 3}]"))
+            L += slots[k]
+            k += 1
+    tag = f"{b}z" if zero else f"{b}"
+    if kx == 2:
+        L += tall_shift(tag)
+    n = TALL_WAIT[kx]
+    if b % 6 < 2:
+        L += [f"s_cmp_eq_u32 {SFLAG}, 0", f"s_cbranch_scc1 LTN{tag}_%=", "s_waitcnt vmcnt(63) lgkmcnt(0)", f"s_branch LTD{tag}_%=",
+              f"LTN{tag}_%=:", f"s_waitcnt vmcnt({n}) lgkmcnt(0)", f"LTD{tag}_%=:"]
+        if b % 6 == 1:
+            L.append(f"s_mov_b32 {SFLAG}, 0")
+    else:
+        L.append(f"s_waitcnt vmcnt({n}) lgkmcnt(0)")
+    L.append("s_barrier")
+    return L
+
+
+def tile_tall():
+    L = ["s_mov_b32 s90, m0", f"s_mov_b64 {D_SBN1}, %[sBn1]", f"s_mov_b64 {D_SAN2}, %[sAn2]", f"s_mov_b64 {D_SBN2}, %[sBn2]",
+         f"s_mov_b32 {D_LO2}, %[slo]", f"s_mov_b32 {D_SP2}, %[ssp]", f"s_mov_b32 {SKY}, %[sky2]", f"s_sub_u32 {SIN}, %[snper], 2",
+         f"s_lshr_b32 {SCNT}, %[snper], 1", f"s_mov_b32 {SFLAG}, %[sflag]", "s_cmp_eq_u32 %[spar], 0", "s_cbranch_scc0 LTODDZ_%="]
+    L += tall_kstep(0, True) + ["s_branch LTA1_%=", "LTODDZ_%=:"] + tall_kstep(6, True) + ["s_branch LTB1_%=", "LTLOOP_%=:"]
+    for b in range(12):
+        L += tall_kstep(b)
+        if b == 0:
+            L.append("LTA1_%=:")
+        if b == 6:
+            L.append("LTB1_%=:")
+        if b == 5:
+            L += [f"s_sub_u32 {SCNT}, {SCNT}, 1", f"s_cmp_eq_u32 {SCNT}, 0", "s_cbranch_scc1 LTEND_%="]
+    L += [f"s_sub_u32 {SCNT}, {SCNT}, 1", f"s_cmp_lg_u32 {SCNT}, 0", "s_cbranch_scc1 LTLOOP_%=", "LTEND_%=:", "s_mov_b32 m0, s90"]
+    return L
+
+
+def refill_tall():
+    areg, breg = frag_regs(0)
+    L = [f"ds_read_b128 v[{areg[i]}:{areg[i] + 3}], %[va0] offset:{i * 1024}" for i in range(8)]
+    L += [f"ds_read_b128 v[{breg[j]}:{breg[j] + 3}], %[vbf] offset:{j * 1024}" for j in range(8)]
+    L += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
+    return L
+
+
 def cstr(lines):
     return " \\\n".join('    "' + l + '\\n\\t"' for l in lines)
 
@@ -353,6 +467,8 @@ def main():
     o += ["#define DUO_ZERO_ACC_ASM \\", cstr([f"v_accvgpr_write_b32 a{n}, 0" for n in range(128)]), ""]
     o += ["#define DUO_CLOBBER_FRAG " + ", ".join(f'"v{n}"' for n in range(31, 128)),
           "#define DUO_CLOBBER_S " + ", ".join(f'"{x}"' for x in DUO_CLOBBER_S), ""]
+    o += ["#define TALL_TILE_ASM \\", cstr(tile_tall()), ""]
+    o += ["#define TALL_REFILL_ASM \\", cstr(refill_tall()), ""]
     o += ["#define LW1_TILE_ASM \\", cstr(tile_1x1()), ""]
     o += ["#define LW1_REFILL_ASM \\", cstr(refill_1x1()), ""]
     for i in range(8):

@@ -31,6 +31,8 @@ CASES = [
     ("mod2 64->128", 512, 1024, 64, 128, 1, (), ("act",)),
     ("mod2 128->128", 512, 1024, 128, 128, 1, (), ("act",)),
     ("mod2 128->128 +res", 512, 1024, 128, 128, 1, ("pre",), ("raw", "act")),
+    ("mod2 128->128 d3 W512", 96, 512, 128, 128, 3, ("mask", "post"), ("raw",)),
+    ("mod2 192->256 d32 H40", 40, 512, 192, 128, 32, ("pre",), ("act",)),
     # 1x1 (dil 0 marks them): conv_pw_lw_kernel against conv_igemm_persist_kernel<pp>
     ("pw 512->512", 128, 256, 512, 512, 0, (), ("act",)),
     ("pw 1024->2048", 128, 256, 1024, 2048, 0, (), ("raw", "act")),
@@ -122,6 +124,12 @@ def main():
         rel = max(float((x.float() - y.float()).norm() / y.float().norm().clamp_min(1e-30)) for x, y in zip(ta, tb))
         mx = max(float((x.float() - y.float()).abs().max() / y.float().abs().max()) for x, y in zip(ta, tb))
         ok = l["finite"] and (same or (rel < 2e-3 and mx < 2e-2))        # (another k order: one-ulp bf16 flips)
+        if not ok:
+            for k, (x, y) in enumerate(zip(ta, tb)):
+                ne = (x.view(torch.int16) != y.view(torch.int16))
+                idx = ne.nonzero()
+                print(f"    output {k}: {int(ne.sum())} of {ne.numel()} differ; non-finite lw {int((~torch.isfinite(x.float())).sum())} pp {int((~torch.isfinite(y.float())).sum())}; "
+                      f"first {idx[:3].tolist()} last {idx[-2:].tolist()}; lw {x[tuple(idx[0])].item() if len(idx) else None} pp {y[tuple(idx[0])].item() if len(idx) else None}")
         bad += not ok
         tl += l["ms"]; tp += p["ms"]
         print(f"{name:26s} {l['ms']:8.3f} {p['ms']:8.3f} {l['tflops']:8.0f} {p['tflops']:8.0f}  {'identical' if same else ('rel L2 %.1e max %.1e' % (rel, mx)) + ('' if ok else ' DIFFERENT')}"

@@ -13,7 +13,7 @@ import json
 import sys
 
 FAMILIES = [("conv_row_lw<256x256, one wave per SIMD>", ("conv_row_lw_kernel",)), ("conv_igemm_row_persist<CfgRow 256x256>", ("conv_row_persist_kernel",)),
-            ("conv_igemm_row_pp128<512x128>", ("conv_row_pp128_kernel",)),
+            ("conv_row_tall<512x128, one wave per SIMD>", ("conv_row_tall_kernel",)), ("conv_igemm_row_pp128<512x128>", ("conv_row_pp128_kernel",)),
             ("conv_igemm_persist<CfgWide 256x256 1x1>", ("conv_igemm_persist_kernel",)),
             ("conv_igemm_row<CfgRow 256x256>", ("conv_igemm_row_kernel", "CfgRowT<8, 2, 4, 128, 320")),
             ("conv_igemm_row<CfgRowX 256x256 rate-36>", ("conv_igemm_row_kernel", "CfgRowT<8, 2, 4, 128, 384")),
