@@ -305,6 +305,183 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
     }
 }
 
+// ---- the lone-wave kernels' epilogue (conv_lw.hip: 128-row x 64-channel halves of a 128 x 128 wave tile, packed accumulators) ----------
+// Same values, same arithmetic and rounding as ig_epilogue_rows16<8, NOPS_, 2, uint2, OUTS> (bit-identical outputs), rearranged for a
+// wave that has the SIMD to itself and therefore nobody to hide its latencies behind (tools/duo_timeline.py --tall: of the 2.6 us a
+// half took without its stores, more than half was waiting -- for the per-channel constants' loads and for four serial LDS round trips):
+//   * the per-channel constants are loaded by lw_epilogue_consts() ahead of time (the caller issues half 0's before it reads the
+//     accumulators out of the AGPRs and half 1's before half 0's epilogue);
+//   * the LDS transposes are software-pipelined over the two 2-KiB halves of the wave's patch, one 16-row tile each: while tile i is
+//     unpacked, combined with its operands and stored, tile i + 1's read and tile i + 2's write are already in the LDS queue
+//     (in-order per wave: a write issued behind a read of the same patch cannot overtake it).
+struct LwEpiConsts {
+    float mscale[8], ascale[8], ashift[8];
+};
+template <int NOPS_>
+__device__ __forceinline__ void lw_epilogue_consts(const ConvParams &p, int nw, int lane, LwEpiConsts &k)
+{
+    constexpr int NOPS = NOPS_ & 3;
+    const kd_conv_epilogue &e = p.ep;
+    asm volatile("" : "+v"(lane));
+    const int c0 = nw + (lane & 7) * 8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { k.mscale[q] = 1.f; k.ascale[q] = 1.f; k.ashift[q] = 0.f; }
+    const bool has_m = NOPS == 3 || (NOPS > 0 && e.mask != nullptr);
+    if (has_m && e.mask_scale) ld8(e.mask_scale + c0, k.mscale);
+    if (e.act_scale) ld8(e.act_scale + c0, k.ascale);
+    if (e.act_shift) ld8(e.act_shift + c0, k.ashift);
+}
+
+template <int NOPS_, int OUTS>
+__device__ __forceinline__ void lw_epilogue_rows16(const ConvParams &p, char *patch, uint2 (&acc)[8][4], int mw, int nw, int lane, const LwEpiConsts &kc)
+{
+    typedef bf16_t T;
+    constexpr int NOPS = NOPS_ & 3;
+    constexpr bool SUMS = (NOPS_ & 4) != 0;
+    static_assert(NOPS_ >= 0 && NOPS_ <= 7 && NOPS_ != 4 && OUTS >= 1 && OUTS <= 3, "operands | 4 (eval-BN sums, with the mask operand); raw / act / both");
+    const kd_conv_epilogue &e = p.ep;
+    asm volatile("" : "+v"(lane));
+    const int frow = lane & 15, fq = lane >> 4;
+    const int c0 = nw + (lane & 7) * 8, lrow = lane >> 3, c2 = (lane & 7) * 2;
+    const bool has_p = NOPS == 3 || (NOPS > 0 && e.res_pre != nullptr), has_m = NOPS == 3 || (NOPS > 0 && e.mask != nullptr),
+               has_q = NOPS == 3 || (NOPS > 0 && e.res_post != nullptr);
+    const int mwu = __builtin_amdgcn_readfirstlane(mw);
+    const __amdgpu_buffer_rsrc_t rs_raw = rows_rsrc((OUTS & 1) ? (const T *)e.out_raw + (size_t)mwu * e.ld_raw : nullptr);
+    const __amdgpu_buffer_rsrc_t rs_act = rows_rsrc((OUTS & 2) ? (const T *)e.out_act + (size_t)mwu * e.ld_act : nullptr);
+    const uint32_t vo_raw = (uint32_t)(lrow * e.ld_raw + c0) * 2u, vo_act = (uint32_t)(lrow * e.ld_act + c0) * 2u;
+    const short relu_w = e.act_relu ? (short)0 : (short)-32768;
+    const i16x2_v relu_i16 = {relu_w, relu_w};
+    const T *s0 = (const T *)(has_p ? e.res_pre : has_m ? e.mask : e.res_post);
+    const int ld0 = has_p ? e.ld_res_pre : has_m ? e.ld_mask : e.ld_res_post;
+    const T *s1 = (const T *)(has_p && has_m ? e.mask : e.res_post);
+    const int ld1 = has_p && has_m ? e.ld_mask : e.ld_res_post;
+    constexpr int nops = NOPS;
+    const bool m_in1 = has_p && has_m, q_in1 = has_q && nops == 2;
+    // operands: one -> ra = rows 0..63, rb = rows 64..127, both up front; two / three -> slots of the current 64 rows
+    uint4 ra[8], rb[8], rc[NOPS == 3 ? 8 : 1];
+    auto load64 = [&](const T *src, int ld, int hb, uint4 (&r)[8]) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rs = rows_rsrc(src + (size_t)mwu * ld);
+        const uint32_t vo = (uint32_t)(lrow * ld + c0) * 2u;
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const u32x4_v q = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (hb * 8 + ps) * 16 * ld, 0);
+            r[ps] = make_uint4(q[0], q[1], q[2], q[3]);
+        }
+    };
+    float bs1[8], bs2[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { bs1[q] = 0.f; bs2[q] = 0.f; }
+    if (nops >= 1) load64(s0, ld0, 0, ra);
+    if (nops >= 2) load64(s1, ld1, 0, rb);
+    if (nops == 1) load64(s0, ld0, 1, rb);
+    if constexpr (NOPS == 3) load64((const T *)e.res_post, e.ld_res_post, 0, rc);
+    const f32x2_v asc2[4] = {{kc.ascale[0], kc.ascale[1]}, {kc.ascale[2], kc.ascale[3]}, {kc.ascale[4], kc.ascale[5]}, {kc.ascale[6], kc.ascale[7]}};
+    const f32x2_v ash2[4] = {{kc.ashift[0], kc.ashift[1]}, {kc.ashift[2], kc.ashift[3]}, {kc.ashift[4], kc.ashift[5]}, {kc.ashift[6], kc.ashift[7]}};
+
+    auto write_tile = [&](int i) __attribute__((always_inline)) {        // 16 rows x 64 channels, 8-B chunk c of row r at c ^ r
+        char *pt = patch + (i & 1) * 2048;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(uint2 *)(pt + frow * 128 + (((j * 4 + fq) ^ frow) << 3)) = acc[i][j];
+    };
+    auto read_tile = [&](int i, uint4 (&r)[2]) __attribute__((always_inline)) {   // two passes of 8 rows x 128 B, 16 B per lane
+        const char *pt = patch + (i & 1) * 2048;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = h * 8 + lrow;
+            const uint2 lo = *(const uint2 *)(pt + row * 128 + ((c2 ^ row) << 3));
+            const uint2 hi = *(const uint2 *)(pt + row * 128 + (((c2 + 1) ^ row) << 3));
+            r[h] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+    };
+    auto lds_order = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    uint4 cur[2], nxt[2];
+    write_tile(0);
+    write_tile(1);
+    lds_order();
+    read_tile(0, cur);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int hb = i >> 2;
+        if ((i & 3) == 0 && hb == 1) {
+            if (nops >= 2) { load64(s0, ld0, 1, ra); load64(s1, ld1, 1, rb); }
+            if constexpr (NOPS == 3) load64((const T *)e.res_post, e.ld_res_post, 1, rc);
+        }
+        lds_order();
+        if (i + 2 < 8) write_tile(i + 2);      // into the patch half tile i was read from (queued behind that read)
+        lds_order();
+        if (i + 1 < 8) read_tile(i + 1, nxt);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ps = 2 * (i & 3) + h;    // 8-row group inside the 64 rows
+            const uint4 rawv = cur[h];
+            float v[8], t[8];
+            ld8((const bf16_t *)&rawv, v);
+            const uint4 o0 = (hb == 1 && nops == 1) ? rb[ps] : ra[ps], o1 = rb[ps];
+            if (has_p) {
+                ld8((const T *)&o0, t);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += t[q];
+            }
+            if (has_m) {
+                const uint4 om = m_in1 ? o1 : o0;
+                ld8((const T *)&om, t);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = t[q] > 0.f ? v[q] * kc.mscale[q] : 0.f;
+                if constexpr (SUMS) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { bs1[q] += v[q]; bs2[q] = fmaf(v[q], t[q], bs2[q]); }
+                }
+            }
+            if (has_q) {
+                const uint4 oq = NOPS == 3 ? rc[NOPS == 3 ? ps : 0] : (q_in1 ? o1 : o0);
+                ld8((const T *)&oq, t);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += t[q];
+            }
+            const int srow = (hb * 8 + ps) * 16;       // x ld = byte offset of row (hb * 8 + ps) * 8 of the wave's 128
+            if constexpr ((OUTS & 1) != 0) {
+                const u32x4_v o = nops == 0 ? (u32x4_v){rawv.x, rawv.y, rawv.z, rawv.w}
+                                            : (u32x4_v){pack_bf16x2_v(v[0], v[1]), pack_bf16x2_v(v[2], v[3]), pack_bf16x2_v(v[4], v[5]), pack_bf16x2_v(v[6], v[7])};
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_raw, vo_raw + (uint32_t)(srow * e.ld_raw), 0, 0);
+            }
+            if constexpr ((OUTS & 2) != 0) {
+                const u32x4_v o = {act_pair(v[0], v[1], asc2[0], ash2[0], relu_i16), act_pair(v[2], v[3], asc2[1], ash2[1], relu_i16),
+                                   act_pair(v[4], v[5], asc2[2], ash2[2], relu_i16), act_pair(v[6], v[7], asc2[3], ash2[3], relu_i16)};
+#ifdef KDCC_TUNING
+                if (p.tune & 128) { asm volatile("" ::"v"(o)); continue; }      // timing ablation: everything but the store itself
+                if (p.tune & 256) { *(u32x4_v *)((T *)e.out_act + (size_t)((((mw + (hb * 8 + ps) * 8 + lrow) & 15) + 16 * (blockIdx.x * 8 + (threadIdx.x >> 6))) % 4096) * e.ld_act + c0) = o; continue; }
+#endif
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_act, vo_act + (uint32_t)(srow * e.ld_act), 0, 0);
+            }
+        }
+        cur[0] = nxt[0];
+        cur[1] = nxt[1];
+    }
+    lds_order();
+    if constexpr (SUMS) {
+        // (ig_epilogue_rows16: lanes l, l + 8, .., l + 56 hold the same 8 channels; fixed butterfly order; partial row mw / 128)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int sft = 8; sft < 64; sft <<= 1) {
+                bs1[q] += __shfl_xor(bs1[q], sft, 64);
+                bs2[q] += __shfl_xor(bs2[q], sft, 64);
+            }
+        }
+        if (lane < 8) {
+            float *dst = e.bn_sums + (size_t)(mw >> 7) * 2 * p.Cout + c0;
+            *(float4 *)dst = make_float4(bs1[0], bs1[1], bs1[2], bs1[3]);
+            *(float4 *)(dst + 4) = make_float4(bs1[4], bs1[5], bs1[6], bs1[7]);
+            *(float4 *)(dst + p.Cout) = make_float4(bs2[0], bs2[1], bs2[2], bs2[3]);
+            *(float4 *)(dst + p.Cout + 4) = make_float4(bs2[4], bs2[5], bs2[6], bs2[7]);
+        }
+    }
+}
+
 // the tiles of this workgroup: XCD x owns a contiguous range of tile ids (as xcd_remap deals them), its workgroups take
 // them round-robin, so the tiles in flight on one XCD at any time are neighbours (shared image rows / weight slabs in L2)
 // A/B experiment (tuning build, KDCC_CONV_TUNE & 16384): every second workgroup of an XCD starts p.stagger_us microseconds late, so

@@ -25,7 +25,7 @@
 namespace {
 
 __device__ __attribute__((aligned(256))) uint32_t lw_zero_page[64];   // zero-initialised
-__device__ unsigned long long lw_tlog[512 * 32 * 4];   // KDCC_CONV_TUNE & 1024 (tuning build): per workgroup and tile, 100-MHz stamps: tile start / main loop end / epilogue end
+__device__ unsigned long long lw_tlog[512 * 32 * 8];   // KDCC_CONV_TUNE & 1024 (tuning build): per workgroup and tile, 100-MHz stamps: tile start / main loop end / epilogue end / tile id; conv_row_tall_kernel also [4..7]: accumulators read (half 0) / staged loads landed / half 0 stored / accumulators read (half 1)
 
 constexpr int LW_ABUF = 320 * 128, LW_BSLOT = 256 * 64, LW_NEED = 2 * LW_ABUF + 4 * LW_BSLOT;
 
@@ -186,19 +186,22 @@ __global__ __launch_bounds__(256, 1) void conv_row_lw_kernel(const ConvParams p)
         acc[I][2] = make_uint2(pack_bf16x2_v(t8, t9), pack_bf16x2_v(t10, t11));                                                           \
         acc[I][3] = make_uint2(pack_bf16x2_v(t12, t13), pack_bf16x2_v(t14, t15));                                                         \
     }
+        LwEpiConsts k0, k1;
+        lw_epilogue_consts<NOPS_>(p, nw, lane, k0);      // (their latency passes under the accumulator read-out)
         {
             uint2 acc[8][4];
             LW_RD(0, 0) LW_RD(1, 0) LW_RD(2, 0) LW_RD(3, 0) LW_RD(4, 0) LW_RD(5, 0) LW_RD(6, 0) LW_RD(7, 0)
-            if (p.ep.out_raw && p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 2, uint2, 3>(p, patch, acc, mw, nw, lane);
-            else if (p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 2, uint2, 2>(p, patch, acc, mw, nw, lane);
-            else ig_epilogue_rows16<8, NOPS_, 2, uint2, 1>(p, patch, acc, mw, nw, lane);
+            lw_epilogue_consts<NOPS_>(p, nw + 64, lane, k1);
+            if (p.ep.out_raw && p.ep.out_act) lw_epilogue_rows16<NOPS_, 3>(p, patch, acc, mw, nw, lane, k0);
+            else if (p.ep.out_act) lw_epilogue_rows16<NOPS_, 2>(p, patch, acc, mw, nw, lane, k0);
+            else lw_epilogue_rows16<NOPS_, 1>(p, patch, acc, mw, nw, lane, k0);
         }
         {
             uint2 acc[8][4];
             LW_RD(0, 1) LW_RD(1, 1) LW_RD(2, 1) LW_RD(3, 1) LW_RD(4, 1) LW_RD(5, 1) LW_RD(6, 1) LW_RD(7, 1)
-            if (p.ep.out_raw && p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 2, uint2, 3>(p, patch, acc, mw, nw + 64, lane);
-            else if (p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 2, uint2, 2>(p, patch, acc, mw, nw + 64, lane);
-            else ig_epilogue_rows16<8, NOPS_, 2, uint2, 1>(p, patch, acc, mw, nw + 64, lane);
+            if (p.ep.out_raw && p.ep.out_act) lw_epilogue_rows16<NOPS_, 3>(p, patch, acc, mw, nw + 64, lane, k1);
+            else if (p.ep.out_act) lw_epilogue_rows16<NOPS_, 2>(p, patch, acc, mw, nw + 64, lane, k1);
+            else lw_epilogue_rows16<NOPS_, 1>(p, patch, acc, mw, nw + 64, lane, k1);
         }
 #undef LW_RD
         }
@@ -310,19 +313,22 @@ __global__ __launch_bounds__(256, 1) void conv_pw_lw_kernel(const ConvParams p)
         acc[I][2] = make_uint2(pack_bf16x2_v(t8, t9), pack_bf16x2_v(t10, t11));                                                           \
         acc[I][3] = make_uint2(pack_bf16x2_v(t12, t13), pack_bf16x2_v(t14, t15));                                                         \
     }
+        LwEpiConsts k0, k1;
+        lw_epilogue_consts<NOPS_>(p, nw, lane, k0);      // (their latency passes under the accumulator read-out)
         {
             uint2 acc[8][4];
             LW_RD(0, 0) LW_RD(1, 0) LW_RD(2, 0) LW_RD(3, 0) LW_RD(4, 0) LW_RD(5, 0) LW_RD(6, 0) LW_RD(7, 0)
-            if (p.ep.out_raw && p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 4, uint2, 3>(p, patch, acc, mw, nw, lane);
-            else if (p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 4, uint2, 2>(p, patch, acc, mw, nw, lane);
-            else ig_epilogue_rows16<8, NOPS_, 4, uint2, 1>(p, patch, acc, mw, nw, lane);
+            lw_epilogue_consts<NOPS_>(p, nw + 64, lane, k1);
+            if (p.ep.out_raw && p.ep.out_act) lw_epilogue_rows16<NOPS_, 3>(p, patch, acc, mw, nw, lane, k0);
+            else if (p.ep.out_act) lw_epilogue_rows16<NOPS_, 2>(p, patch, acc, mw, nw, lane, k0);
+            else lw_epilogue_rows16<NOPS_, 1>(p, patch, acc, mw, nw, lane, k0);
         }
         {
             uint2 acc[8][4];
             LW_RD(0, 1) LW_RD(1, 1) LW_RD(2, 1) LW_RD(3, 1) LW_RD(4, 1) LW_RD(5, 1) LW_RD(6, 1) LW_RD(7, 1)
-            if (p.ep.out_raw && p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 4, uint2, 3>(p, patch, acc, mw, nw + 64, lane);
-            else if (p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 4, uint2, 2>(p, patch, acc, mw, nw + 64, lane);
-            else ig_epilogue_rows16<8, NOPS_, 4, uint2, 1>(p, patch, acc, mw, nw + 64, lane);
+            if (p.ep.out_raw && p.ep.out_act) lw_epilogue_rows16<NOPS_, 3>(p, patch, acc, mw, nw + 64, lane, k1);
+            else if (p.ep.out_act) lw_epilogue_rows16<NOPS_, 2>(p, patch, acc, mw, nw + 64, lane, k1);
+            else lw_epilogue_rows16<NOPS_, 1>(p, patch, acc, mw, nw + 64, lane, k1);
         }
 #undef LW_RD
         }
@@ -453,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void conv_row_duo_kernel(const ConvParams p
 #pragma unroll 1
     for (;;) {
         const bool tl = (p.tune & 1024) && tid == 0 && tcount < 32 && blockIdx.x < 512;
-        unsigned long long *tlp = lw_tlog + ((size_t)blockIdx.x * 32 + (tcount & 31)) * 4;
+        unsigned long long *tlp = lw_tlog + ((size_t)blockIdx.x * 32 + (tcount & 31)) * 8;
         if (tl) tlp[0] = __builtin_amdgcn_s_memrealtime();
         lane_addresses();
         asm volatile(DUO_REFILL_ASM : : [va0] "v"(va[0]), [vb] "v"(vb) : "memory", DUO_CLOBBER_FRAG);
@@ -623,7 +629,7 @@ __global__ __launch_bounds__(256, 1) void conv_row_tall_kernel(const ConvParams 
 #pragma unroll 1
     for (;;) {
         const bool tl = (p.tune & 1024) && tid == 0 && tcount < 32 && blockIdx.x < 512;     // tools/duo_timeline.py --tall
-        unsigned long long *tlp = lw_tlog + ((size_t)blockIdx.x * 32 + (tcount & 31)) * 4;
+        unsigned long long *tlp = lw_tlog + ((size_t)blockIdx.x * 32 + (tcount & 31)) * 8;
         if (tl) tlp[0] = __builtin_amdgcn_s_memrealtime();
         lane_addresses();
         asm volatile(TALL_REFILL_ASM : : [va0] "v"(va[0]), [vbf] "v"(vb + par * 2 * TALL_BSLOT) : "memory", LW_CLOBBER_FRAG);
@@ -663,22 +669,29 @@ __global__ __launch_bounds__(256, 1) void conv_row_tall_kernel(const ConvParams 
         acc[I][2] = make_uint2(pack_bf16x2_v(t8, t9), pack_bf16x2_v(t10, t11));                                                       \
         acc[I][3] = make_uint2(pack_bf16x2_v(t12, t13), pack_bf16x2_v(t14, t15));                                                     \
     }
+        LwEpiConsts k0, k1;
+        lw_epilogue_consts<NOPS_>(p, nw, lane, k0);      // (their latency passes under the accumulator read-out)
         {
             uint2 acc[8][4];
             LW_RD(0, 0) LW_RD(1, 0) LW_RD(2, 0) LW_RD(3, 0) LW_RD(4, 0) LW_RD(5, 0) LW_RD(6, 0) LW_RD(7, 0)
+            if (tl) tlp[4] = __builtin_amdgcn_s_memrealtime();
             // what ran ahead into the next tile's buffers has landed before the first store: the first two waits of that tile may then
             // leave every store outstanding
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (p.ep.out_raw && p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 2, uint2, 3>(p, patch, acc, mw, nw, lane);
-            else if (p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 2, uint2, 2>(p, patch, acc, mw, nw, lane);
-            else ig_epilogue_rows16<8, NOPS_, 2, uint2, 1>(p, patch, acc, mw, nw, lane);
+            if (tl) tlp[5] = __builtin_amdgcn_s_memrealtime();
+            lw_epilogue_consts<NOPS_>(p, nw + 64, lane, k1);
+            if (p.ep.out_raw && p.ep.out_act) lw_epilogue_rows16<NOPS_, 3>(p, patch, acc, mw, nw, lane, k0);
+            else if (p.ep.out_act) lw_epilogue_rows16<NOPS_, 2>(p, patch, acc, mw, nw, lane, k0);
+            else lw_epilogue_rows16<NOPS_, 1>(p, patch, acc, mw, nw, lane, k0);
+            if (tl) tlp[6] = __builtin_amdgcn_s_memrealtime();
         }
         {
             uint2 acc[8][4];
             LW_RD(0, 1) LW_RD(1, 1) LW_RD(2, 1) LW_RD(3, 1) LW_RD(4, 1) LW_RD(5, 1) LW_RD(6, 1) LW_RD(7, 1)
-            if (p.ep.out_raw && p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 2, uint2, 3>(p, patch, acc, mw, nw + 64, lane);
-            else if (p.ep.out_act) ig_epilogue_rows16<8, NOPS_, 2, uint2, 2>(p, patch, acc, mw, nw + 64, lane);
-            else ig_epilogue_rows16<8, NOPS_, 2, uint2, 1>(p, patch, acc, mw, nw + 64, lane);
+            if (tl) tlp[7] = __builtin_amdgcn_s_memrealtime();
+            if (p.ep.out_raw && p.ep.out_act) lw_epilogue_rows16<NOPS_, 3>(p, patch, acc, mw, nw + 64, lane, k1);
+            else if (p.ep.out_act) lw_epilogue_rows16<NOPS_, 2>(p, patch, acc, mw, nw + 64, lane, k1);
+            else lw_epilogue_rows16<NOPS_, 1>(p, patch, acc, mw, nw + 64, lane, k1);
         }
 #undef LW_RD
         }

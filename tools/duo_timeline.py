@@ -25,11 +25,11 @@ for _ in range(3):
         ops.conv2d(x, w, 1, 1, 1, out_act=out, act_scale=sc, act_shift=sh, act_relu=True)
 torch.cuda.synchronize()
 print("kernel:", dict(log.counts))
-buf = np.zeros(512 * 32 * 4, dtype=np.uint64)
+buf = np.zeros(512 * 32 * 8, dtype=np.uint64)
 lib = _lib.lib()
 lib.kd_debug_conv_tlog.argtypes = [C.c_void_p, C.c_size_t]
 lib.kd_debug_conv_tlog(buf.ctypes.data, buf.nbytes)
-t = buf.reshape(512, 32, 4).astype(np.int64)
+t = buf.reshape(512, 32, 8).astype(np.int64)
 t0 = t[:, 0, 0].min()
 us = lambda v: (v - t0) / 100.0
 if "--tall" in sys.argv:
@@ -41,6 +41,9 @@ if "--tall" in sys.argv:
     ml = (t[:256, 1:30, 1] - t[:256, 1:30, 0]) / 100.0
     bd = (t[:256, 2:30, 0] - t[:256, 1:29, 1]) / 100.0
     print(f"main loop per tile {ml.mean():.2f} us (sd {ml.std():.2f}; min {ml.min():.2f}, max {ml.max():.2f}), boundary {bd.mean():.2f} us (sd {bd.std():.2f})")
+    seg = lambda a, b: ((t[:256, 1:30, a] - t[:256, 1:30, b]) / 100.0).mean()
+    print(f"epilogue phases [us]: accumulators read + packed (half 0) {seg(4, 1):.2f}, staged loads landed {seg(5, 4):.2f}, half 0 transposed + stored {seg(6, 5):.2f}, "
+          f"accumulators (half 1) {seg(7, 6):.2f}, half 1 {seg(2, 7):.2f}")
     sys.exit(0)
 hidden = []
 for b in (0, 1, 9, 100, 255):
