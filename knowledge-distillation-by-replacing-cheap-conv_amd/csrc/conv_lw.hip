@@ -191,6 +191,9 @@ __global__ __launch_bounds__(256, 1) void conv_row_lw_kernel(const ConvParams p)
         {
             uint2 acc[8][4];
             LW_RD(0, 0) LW_RD(1, 0) LW_RD(2, 0) LW_RD(3, 0) LW_RD(4, 0) LW_RD(5, 0) LW_RD(6, 0) LW_RD(7, 0)
+            // what ran ahead into the next tile's buffers has landed before the first store is issued: the next tile's first two
+            // waits leave every store outstanding (vmcnt is one in-order counter), which is only sound if nothing older is pending
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             lw_epilogue_consts<NOPS_>(p, nw + 64, lane, k1);
             if (p.ep.out_raw && p.ep.out_act) lw_epilogue_rows16<NOPS_, 3>(p, patch, acc, mw, nw, lane, k0);
             else if (p.ep.out_act) lw_epilogue_rows16<NOPS_, 2>(p, patch, acc, mw, nw, lane, k0);
@@ -318,6 +321,9 @@ __global__ __launch_bounds__(256, 1) void conv_pw_lw_kernel(const ConvParams p)
         {
             uint2 acc[8][4];
             LW_RD(0, 0) LW_RD(1, 0) LW_RD(2, 0) LW_RD(3, 0) LW_RD(4, 0) LW_RD(5, 0) LW_RD(6, 0) LW_RD(7, 0)
+            // what ran ahead into the next tile's buffers has landed before the first store is issued: the next tile's first two
+            // waits leave every store outstanding (vmcnt is one in-order counter), which is only sound if nothing older is pending
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             lw_epilogue_consts<NOPS_>(p, nw + 64, lane, k1);
             if (p.ep.out_raw && p.ep.out_act) lw_epilogue_rows16<NOPS_, 3>(p, patch, acc, mw, nw, lane, k0);
             else if (p.ep.out_act) lw_epilogue_rows16<NOPS_, 2>(p, patch, acc, mw, nw, lane, k0);
@@ -505,6 +511,7 @@ __global__ __launch_bounds__(256, 2) void conv_row_duo_kernel(const ConvParams p
             {
                 uint2 acc[4][4];
                 DUO_RD(0, 0) DUO_RD(1, 1) DUO_RD(2, 2) DUO_RD(3, 3)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (see conv_row_lw_kernel)
                 DUO_EPI(mw)
             }
             {
