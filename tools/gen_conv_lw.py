@@ -355,6 +355,7 @@ def refill_duo():
 # B slot 0 or 2.
 TALL_ABUF, TALL_BSLOT = 576 * 64, 128 * 64
 TALL_WAIT = (13, 4, 13)
+TALL_FLAGWIN = int(os.environ.get("KDCC_GEN_TALL_FLAGWIN", "2"))   # experiment (timing only, wrong results above 2): k-steps after an epilogue whose waits ignore vmcnt
 
 
 def tall_a_piece(j, buf):
@@ -415,10 +416,10 @@ def tall_kstep(b, zero=False):
     if kx == 2:
         L += tall_shift(tag)
     n = TALL_WAIT[kx]
-    if b % 6 < 2:
+    if b % 6 < TALL_FLAGWIN:
         L += [f"s_cmp_eq_u32 {SFLAG}, 0", f"s_cbranch_scc1 LTN{tag}_%=", "s_waitcnt vmcnt(63) lgkmcnt(0)", f"s_branch LTD{tag}_%=",
               f"LTN{tag}_%=:", f"s_waitcnt vmcnt({n}) lgkmcnt(0)", f"LTD{tag}_%=:"]
-        if b % 6 == 1:
+        if b % 6 == TALL_FLAGWIN - 1:
             L.append(f"s_mov_b32 {SFLAG}, 0")
     else:
         L.append(f"s_waitcnt vmcnt({n}) lgkmcnt(0)")
