@@ -261,6 +261,8 @@ PERSIST_CASES = [
     ((1, 80, 512, 64, 512, 3, 2, 2), ("pre", "mask", "post"), ("raw", "act")),
     # Cout = 128, W % 512 == 0: 512 x 128 tiles, conv_row_tall_kernel (64-B K stages; KDCC_CONV_LW=0: conv_row_pp128_kernel, tools/lw_check.py)
     ((1, 40, 1024, 192, 128, 3, 3, 3), ("pre", "mask"), ("raw", "act")),     # 18 / 12 periods per tile: both entry phases of the loop body
+    ((3, 9, 1536, 64, 128, 3, 4, 4), ("pre",), ("raw", "act")),              # three tiles per image row (first / inner / last), image boundaries, 81 tiles
+    ((1, 17, 512, 128, 128, 3, 16, 16), (), ("act",)),                       # H = dil + 1: no image row has all three kernel rows inside the image (8-period tiles only)
     ((1, 24, 512, 64, 128, 3, 1, 1), ("pre",), ("raw", "act")),
     ((1, 20, 1024, 128, 128, 3, 2, 2), (), ("act",)),
     ((2, 150, 512, 64, 128, 3, 1, 1), ("mask", "post"), ("raw",)),      # 300 tiles: two per workgroup on part of the chip
