@@ -119,3 +119,30 @@ def test_hand_scheduled_conv_loop_is_generated_and_audited():
         pytest.skip("no hipcc")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_lw_asm.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
+
+
+def test_hand_scheduled_loops_pass_the_schedule_interpreter():
+    """tools/check_lw_schedule.py interprets the generated instruction streams of conv_row_lw_kernel / conv_row_tall_kernel for a few
+    consecutive tiles (scalar registers, branches, M0, the in-order vmcnt counter, barriers) and checks every fragment read: the
+    pieces it finds were fetched from the address the convolution needs there, each of them was covered by a vmcnt wait and a
+    barrier before the read, and nothing is staged into a buffer before a barrier behind its last read.  The checker itself is
+    held to account with three mutated schedules it has to reject."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_lw_schedule as C
+    import gen_conv_lw as G
+    lw = lambda: sum((C.check_lw(c, n, stores=s) for c, n in ((64, [3, 2, 3]), (128, [3, 3, 2, 2, 3]), (320, [3, 2, 3, 3])) for s in (32, 64, 96)), [])
+    tall = lambda: sum((C.check_tall(c, n, stores=s) for c, n in ((64, [3, 2, 3, 3]), (128, [3, 2, 2, 3]), (192, [3, 3, 2, 3])) for s in (32, 64)), [])
+    assert lw() == [] and tall() == []
+    issued, waits, shift = G.ISSUED, G.TALL_WAIT, G.tall_shift
+    try:
+        G.ISSUED = [x + 1 for x in issued]              # every wait of the 3x3 loop two operations too lax
+        assert any("in flight" in f for f in lw())
+        G.ISSUED = issued
+        G.TALL_WAIT = (13, 5, 13)                        # the 512 x 128 loop's row-buffer wait one piece too lax
+        assert any("in flight" in f for f in tall())
+        G.TALL_WAIT = waits
+        G.tall_shift = lambda tag: [l for l in shift(tag) if not l.startswith("s_mov_b64 " + G.D_SBN1)]      # B's staging iterator not advanced
+        assert any("holds data from" in f for f in tall())
+    finally:
+        G.ISSUED, G.TALL_WAIT, G.tall_shift = issued, waits, shift
