@@ -64,16 +64,19 @@ class KLDivergenceLoss(nn.Module):
 
 
 class MSELoss(nn.Module):
-    """nn.MSELoss('mean')(inputs, targets) * num_classes  (losses/MSELoss.py:9-16)."""
+    """nn.MSELoss(reduction)(inputs, targets) * num_classes  (losses/MSELoss.py:9-16); reduction 'mean' (every shipped config) or 'sum'
+    (the same kernel: the mean and its gradient scaled by the element count)."""
 
     def __init__(self, reduction='mean', num_classes=19):
         super().__init__()
-        if reduction != 'mean':
-            raise NotImplementedError("only reduction='mean' (every shipped config) is implemented")
+        if reduction not in ('mean', 'sum'):
+            raise NotImplementedError("reduction='none' returns a tensor no KD trainer consumes: 'mean' or 'sum'")
+        self.reduction = reduction
         self.num_classes = num_classes
 
     def forward(self, inputs, targets):
-        return _FusedLoss.apply("mse", inputs, _same_device_dtype(inputs, targets), float(self.num_classes), None)
+        scale = float(self.num_classes) * (inputs.numel() if self.reduction == 'sum' else 1)
+        return _FusedLoss.apply("mse", inputs, _same_device_dtype(inputs, targets), scale, None)
 
 
 class WeightedHintMSELoss(nn.Module):

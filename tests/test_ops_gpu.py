@@ -640,6 +640,22 @@ def test_losses_vs_golden_and_oracle(K, golden):
     np.testing.assert_allclose(ce.item(), g["ce.loss"], rtol=1e-5)
 
 
+def test_mse_sum_reduction_matches_torch():
+    """MSELoss(reduction='sum') (reference losses/MSELoss.py:9-16 passes `reduction` to nn.MSELoss): value and gradient against
+    torch's own on the device, fp32."""
+    from kdcc_amd import losses
+    g = torch.Generator(device="cuda").manual_seed(3)
+    s = torch.randn(2, 24, 9, 13, device="cuda", generator=g, requires_grad=True)
+    t = torch.randn(2, 24, 9, 13, device="cuda", generator=g)
+    loss = losses.MSELoss(reduction='sum', num_classes=19)(s, t)
+    loss.backward()
+    s2 = s.detach().clone().requires_grad_(True)
+    ref = torch.nn.MSELoss(reduction='sum')(s2, t) * 19
+    ref.backward()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-6)
+    np.testing.assert_allclose(s.grad.cpu().numpy(), s2.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
 def test_losses_bf16_large_vs_oracle(K):
     """bf16 NHWC operands at a hint-like size: vector path, compared with the oracle on the rounded inputs."""
     N, Cc, H, W = 2, 64, 24, 40
