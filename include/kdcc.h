@@ -422,6 +422,16 @@ int kd_kldiv_up(const float *s_lo, const float *t_lo, float temperature, int32_t
 int kd_ce2d_grad(const kd_view3 *x, const int64_t *target, int32_t ignore_index, int32_t N, int32_t C, int64_t P,
                  const kd_mview3 *grad, float grad_scale, void *workspace, size_t workspace_bytes, kd_stream_t stream);
 
+/* CrossEntropyLoss2d(weight, size_average) (losses/CrossEntropy.py:5-14: nn.NLLLoss(weight, size_average, ignore_index) on
+ * log_softmax): class_weight fp32 (C) on the device or NULL; the mean is weighted, sum_i w[y_i] nll_i / sum_i w[y_i]
+ * (sum_reduction == 0, size_average=True) or the plain weighted sum (sum_reduction != 0, size_average=False); ignored
+ * pixels contribute to neither.  kd_ce2d / kd_ce2d_grad are these with class_weight == NULL, sum_reduction == 0. */
+int kd_ce2d_weighted(const kd_view3 *x, const int64_t *target, const float *class_weight, int32_t sum_reduction, int32_t ignore_index,
+                     int32_t N, int32_t C, int64_t P, float *loss, void *workspace, size_t workspace_bytes, kd_stream_t stream);
+int kd_ce2d_weighted_grad(const kd_view3 *x, const int64_t *target, const float *class_weight, int32_t sum_reduction, int32_t ignore_index,
+                          int32_t N, int32_t C, int64_t P, const kd_mview3 *grad, float grad_scale, void *workspace,
+                          size_t workspace_bytes, kd_stream_t stream);
+
 /* CityscapesMetricTracker.update / confusion_for_batch (utils/util.py:108-128), the logged train mIoU, without the
  * reference's two full-logit D2H copies per step (trainer/layerwise_trainer.py:249-250):
  *   for every pixel with 0 <= target < C:  conf[target][argmax_c x(n,c,p)] += 1

@@ -130,6 +130,8 @@ _SIGS = {
     "kd_ce2d_up": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_sz, c_vp]),
     "kd_kldiv_up": (c_int, [c_vp, c_vp, c_f, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_sz, c_vp]),
     "kd_ce2d_grad": (c_int, [_P(View3), c_vp, c_int, c_int, c_int, c_i64, _P(View3), c_f, c_vp, c_sz, c_vp]),
+    "kd_ce2d_weighted": (c_int, [_P(View3), c_vp, c_vp, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp, c_sz, c_vp]),
+    "kd_ce2d_weighted_grad": (c_int, [_P(View3), c_vp, c_vp, c_int, c_int, c_int, c_int, c_i64, _P(View3), c_f, c_vp, c_sz, c_vp]),
     "kd_confusion": (c_int, [_P(View3), c_vp, c_int, c_int, c_i64, c_vp, c_int, c_vp]),
     "kd_radam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f, c_f, c_f, c_f, c_f, c_vp]),
     "kd_radam_step_multi": (c_int, [_P(RadamTensor), c_int, c_vp]),

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void kldiv_nhwc_kernel(const TS *__restrict__ 
 
 template <typename TX>
 __global__ __launch_bounds__(256) void ce2d_nhwc_kernel(const TX *__restrict__ x, const int64_t *__restrict__ target, int ignore_index,
-                                                        int C, long long npix, double *partial, double *count)
+                                                        int C, long long npix, double *partial, double *count, const float *__restrict__ cw)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     double acc = 0.0, cnt = 0.0;
@@ -229,8 +229,9 @@ __global__ __launch_bounds__(256) void ce2d_nhwc_kernel(const TX *__restrict__ x
                 for (int c = 0; c < C; ++c) m = fmaxf(m, a[c]);
                 float z = 0.f;
                 for (int c = 0; c < C; ++c) z += __expf(a[c] - m);
-                acc += (double)(-(a[y] - m - __logf(z)));
-                cnt += 1.0;
+                const float wy = cw ? cw[y] : 1.f;      // (class weights: nn.NLLLoss(weight): sum_i w[y_i] * nll_i / sum_i w[y_i])
+                acc += (double)(wy * -(a[y] - m - __logf(z)));
+                cnt += (double)wy;
             }
         }
         __syncthreads();
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(256) void whmse_kernel(V3 s, V3 t, M3 g, const floa
 
 // ---- cross entropy (logged metric) ----------------------------------------------------------
 __global__ __launch_bounds__(256) void ce2d_kernel(V3 x, const int64_t *target, int ignore_index, int N, int C, long long P,
-                                                   double *partial, double *count)
+                                                   double *partial, double *count, const float *cw)
 {
     double acc = 0.0, cnt = 0.0;
     const long long total = (long long)N * P;
@@ -500,8 +501,9 @@ __global__ __launch_bounds__(256) void ce2d_kernel(V3 x, const int64_t *target, 
         for (int c = 0; c < C; ++c) m = fmaxf(m, kd_ld(x.p, x.dt, b + c * x.sC));
         float z = 0.f;
         for (int c = 0; c < C; ++c) z += __expf(kd_ld(x.p, x.dt, b + c * x.sC) - m);
-        acc += (double)(-(kd_ld(x.p, x.dt, b + y * x.sC) - m - __logf(z)));
-        cnt += 1.0;
+        const float wy = cw ? cw[y] : 1.f;
+        acc += (double)(wy * -(kd_ld(x.p, x.dt, b + y * x.sC) - m - __logf(z)));
+        cnt += (double)wy;
     }
     __shared__ double w1[4], w2[4];
     acc = wave_sum_d(acc); cnt = wave_sum_d(cnt);
@@ -512,12 +514,12 @@ __global__ __launch_bounds__(256) void ce2d_kernel(V3 x, const int64_t *target, 
 
 // gradient of the cross entropy above: (softmax - onehot) / #valid, zero rows for ignored pixels.  count[] holds the forward's
 // per-block valid-pixel counts (any block count nb); every block sums them in the same order.
-__global__ __launch_bounds__(256) void ce2d_count_kernel(const int64_t *target, int ignore_index, int C, long long total, double *count)
+__global__ __launch_bounds__(256) void ce2d_count_kernel(const int64_t *target, int ignore_index, int C, long long total, double *count, const float *cw)
 {
     double cnt = 0.0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int64_t y = target[i];
-        if (!(y == ignore_index || y < 0 || y >= C)) cnt += 1.0;
+        if (!(y == ignore_index || y < 0 || y >= C)) cnt += cw ? (double)cw[y] : 1.0;
     }
     __shared__ double w2[4];
     cnt = wave_sum_d(cnt);
@@ -527,7 +529,7 @@ __global__ __launch_bounds__(256) void ce2d_count_kernel(const int64_t *target, 
 }
 
 __global__ __launch_bounds__(256) void ce2d_grad_kernel(V3 x, const int64_t *target, int ignore_index, int N, int C, long long P, M3 g,
-                                                        float gscale, const double *count, int ncount)
+                                                        float gscale, const double *count, int ncount, const float *cw, int sum_reduction)
 {
     __shared__ double tot;
     if (threadIdx.x == 0) {
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(256) void ce2d_grad_kernel(V3 x, const int64_t *tar
         tot = c;
     }
     __syncthreads();
-    const float k = tot > 0.0 ? gscale / (float)tot : 0.f;
+    const float k = sum_reduction ? gscale : (tot > 0.0 ? gscale / (float)tot : 0.f);
     const long long total = (long long)N * P;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int64_t y = target[i];
@@ -550,10 +552,10 @@ __global__ __launch_bounds__(256) void ce2d_grad_kernel(V3 x, const int64_t *tar
         for (int c = 0; c < C; ++c) m = fmaxf(m, kd_ld(x.p, x.dt, b + c * x.sC));
         float z = 0.f;
         for (int c = 0; c < C; ++c) z += __expf(kd_ld(x.p, x.dt, b + c * x.sC) - m);
-        const float iz = 1.f / z;
+        const float iz = 1.f / z, kw = cw ? k * cw[y] : k;
         for (int c = 0; c < C; ++c) {
             const float pr = __expf(kd_ld(x.p, x.dt, b + c * x.sC) - m) * iz;
-            kd_st(g.p, g.dt, gb + c * g.sC, k * (pr - (c == (int)y ? 1.f : 0.f)));
+            kd_st(g.p, g.dt, gb + c * g.sC, kw * (pr - (c == (int)y ? 1.f : 0.f)));
         }
     }
 }
@@ -782,12 +784,12 @@ extern "C" int kd_weighted_hint_mse(const kd_view3 *s, const kd_view3 *t, const 
     return KD_OK;
 }
 
-extern "C" int kd_ce2d(const kd_view3 *x, const int64_t *target, int32_t ignore_index, int32_t N, int32_t C, int64_t P,
-                       float *loss, void *workspace, size_t workspace_bytes, kd_stream_t stream)
+static int ce2d_impl(const char *who, const kd_view3 *x, const int64_t *target, const float *class_weight, int32_t sum_reduction, int32_t ignore_index,
+                     int32_t N, int32_t C, int64_t P, float *loss, void *workspace, size_t workspace_bytes, kd_stream_t stream)
 {
-    KD_REQUIRE(x && x->ptr && target && loss && workspace, KD_ERR_INVALID, "kd_ce2d: null argument");
-    KD_REQUIRE(ok_dt(x->dtype) && N > 0 && C > 0 && P > 0, KD_ERR_INVALID, "kd_ce2d: bad argument");
-    KD_REQUIRE(workspace_bytes >= kd_loss_workspace(N, C, P), KD_ERR_WORKSPACE, "kd_ce2d: workspace too small");
+    KD_REQUIRE(x && x->ptr && target && loss && workspace, KD_ERR_INVALID, "%s: null argument", who);
+    KD_REQUIRE(ok_dt(x->dtype) && N > 0 && C > 0 && P > 0, KD_ERR_INVALID, "%s: bad argument", who);
+    KD_REQUIRE(workspace_bytes >= kd_loss_workspace(N, C, P), KD_ERR_WORKSPACE, "%s: workspace too small", who);
     double *partial = (double *)workspace, *count = partial + MAX_BLOCKS;
     const int nb = blocks_for((long long)N * P);
     hipStream_t st = (hipStream_t)stream;
@@ -795,17 +797,29 @@ extern "C" int kd_ce2d(const kd_view3 *x, const int64_t *target, int32_t ignore_
         const size_t lds = (size_t)256 * C * sizeof(float);   // <= the 64-KiB default dynamic-LDS limit, else the strided kernel
         if (x->dtype == KD_F32)
             hipLaunchKernelGGL(ce2d_nhwc_kernel<float>, dim3(nb), dim3(256), lds, st, (const float *)x->ptr, target, ignore_index, C,
-                               (long long)N * P, partial, count);
+                               (long long)N * P, partial, count, class_weight);
         else
             hipLaunchKernelGGL(ce2d_nhwc_kernel<bf16_t>, dim3(nb), dim3(256), lds, st, (const bf16_t *)x->ptr, target, ignore_index,
-                               C, (long long)N * P, partial, count);
+                               C, (long long)N * P, partial, count, class_weight);
     } else {
-        hipLaunchKernelGGL(ce2d_kernel, dim3(nb), dim3(256), 0, st, v3(x), target, ignore_index, N, C, (long long)P, partial, count);
+        hipLaunchKernelGGL(ce2d_kernel, dim3(nb), dim3(256), 0, st, v3(x), target, ignore_index, N, C, (long long)P, partial, count, class_weight);
     }
-    KD_CHECK_LAUNCH("kd_ce2d");
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, (const double *)partial, nb, 1.0, (const double *)count, loss);
-    KD_CHECK_LAUNCH("kd_ce2d(finish)");
+    KD_CHECK_LAUNCH(who);
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, (const double *)partial, nb, 1.0, sum_reduction ? (const double *)nullptr : (const double *)count, loss);
+    KD_CHECK_LAUNCH(who);
     return KD_OK;
+}
+
+extern "C" int kd_ce2d(const kd_view3 *x, const int64_t *target, int32_t ignore_index, int32_t N, int32_t C, int64_t P,
+                       float *loss, void *workspace, size_t workspace_bytes, kd_stream_t stream)
+{
+    return ce2d_impl("kd_ce2d", x, target, nullptr, 0, ignore_index, N, C, P, loss, workspace, workspace_bytes, stream);
+}
+
+extern "C" int kd_ce2d_weighted(const kd_view3 *x, const int64_t *target, const float *class_weight, int32_t sum_reduction, int32_t ignore_index,
+                                int32_t N, int32_t C, int64_t P, float *loss, void *workspace, size_t workspace_bytes, kd_stream_t stream)
+{
+    return ce2d_impl("kd_ce2d_weighted", x, target, class_weight, sum_reduction, ignore_index, N, C, P, loss, workspace, workspace_bytes, stream);
 }
 
 // ---- kd_ce2d_up / kd_kldiv_up: the logged logit losses from the low-resolution logits (see ce2d_up_kernel) ---------------------------
@@ -872,21 +886,36 @@ extern "C" int kd_kldiv_up(const float *s_lo, const float *t_lo, float temperatu
     return KD_OK;
 }
 
-extern "C" int kd_ce2d_grad(const kd_view3 *x, const int64_t *target, int32_t ignore_index, int32_t N, int32_t C, int64_t P,
-                            const kd_mview3 *grad, float grad_scale, void *workspace, size_t workspace_bytes, kd_stream_t stream)
+static int ce2d_grad_impl(const char *who, const kd_view3 *x, const int64_t *target, const float *class_weight, int32_t sum_reduction, int32_t ignore_index,
+                          int32_t N, int32_t C, int64_t P, const kd_mview3 *grad, float grad_scale, void *workspace, size_t workspace_bytes,
+                          kd_stream_t stream)
 {
-    KD_REQUIRE(x && x->ptr && target && grad && grad->ptr && workspace, KD_ERR_INVALID, "kd_ce2d_grad: null argument");
-    KD_REQUIRE(ok_dt(x->dtype) && ok_dt(grad->dtype) && N > 0 && C > 0 && P > 0, KD_ERR_INVALID, "kd_ce2d_grad: bad argument");
-    KD_REQUIRE(workspace_bytes >= kd_loss_workspace(N, C, P), KD_ERR_WORKSPACE, "kd_ce2d_grad: workspace too small");
+    KD_REQUIRE(x && x->ptr && target && grad && grad->ptr && workspace, KD_ERR_INVALID, "%s: null argument", who);
+    KD_REQUIRE(ok_dt(x->dtype) && ok_dt(grad->dtype) && N > 0 && C > 0 && P > 0, KD_ERR_INVALID, "%s: bad argument", who);
+    KD_REQUIRE(workspace_bytes >= kd_loss_workspace(N, C, P), KD_ERR_WORKSPACE, "%s: workspace too small", who);
     double *count = (double *)workspace;
     const int nb = blocks_for((long long)N * P);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(ce2d_count_kernel, dim3(nb), dim3(256), 0, st, target, ignore_index, C, (long long)N * P, count);
-    KD_CHECK_LAUNCH("kd_ce2d_grad(count)");
+    hipLaunchKernelGGL(ce2d_count_kernel, dim3(nb), dim3(256), 0, st, target, ignore_index, C, (long long)N * P, count, class_weight);
+    KD_CHECK_LAUNCH(who);
     hipLaunchKernelGGL(ce2d_grad_kernel, dim3(nb), dim3(256), 0, st, v3(x), target, ignore_index, N, C, (long long)P, m3(grad), grad_scale,
-                       (const double *)count, nb);
-    KD_CHECK_LAUNCH("kd_ce2d_grad");
+                       (const double *)count, nb, class_weight, (int)sum_reduction);
+    KD_CHECK_LAUNCH(who);
     return KD_OK;
+}
+
+extern "C" int kd_ce2d_grad(const kd_view3 *x, const int64_t *target, int32_t ignore_index, int32_t N, int32_t C, int64_t P,
+                            const kd_mview3 *grad, float grad_scale, void *workspace, size_t workspace_bytes, kd_stream_t stream)
+{
+    return ce2d_grad_impl("kd_ce2d_grad", x, target, nullptr, 0, ignore_index, N, C, P, grad, grad_scale, workspace, workspace_bytes, stream);
+}
+
+extern "C" int kd_ce2d_weighted_grad(const kd_view3 *x, const int64_t *target, const float *class_weight, int32_t sum_reduction, int32_t ignore_index,
+                                     int32_t N, int32_t C, int64_t P, const kd_mview3 *grad, float grad_scale, void *workspace,
+                                     size_t workspace_bytes, kd_stream_t stream)
+{
+    return ce2d_grad_impl("kd_ce2d_weighted_grad", x, target, class_weight, sum_reduction, ignore_index, N, C, P, grad, grad_scale, workspace,
+                          workspace_bytes, stream);
 }
 
 extern "C" int kd_confusion(const kd_view3 *x, const int64_t *target, int32_t N, int32_t C, int64_t P, int64_t *conf,

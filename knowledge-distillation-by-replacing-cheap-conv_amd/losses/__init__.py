@@ -93,16 +93,16 @@ class WeightedHintMSELoss(nn.Module):
 
 class _CEFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, inputs, targets, ignore_index):
+    def forward(ctx, inputs, targets, ignore_index, weight=None, size_average=True):
         ctx.save_for_backward(inputs.detach(), targets)
-        ctx.ignore_index = ignore_index
-        return ops.ce2d(inputs.detach(), targets, ignore_index)
+        ctx.ignore_index, ctx.weight, ctx.size_average = ignore_index, weight, size_average
+        return ops.ce2d(inputs.detach(), targets, ignore_index, weight, size_average)
 
     @staticmethod
     def backward(ctx, g):
         x, tgt = ctx.saved_tensors
-        grad = ops.ce2d_grad(x, tgt, ctx.ignore_index)
-        return grad * g.to(grad.dtype), None, None
+        grad = ops.ce2d_grad(x, tgt, ctx.ignore_index, 1.0, ctx.weight, ctx.size_average)
+        return grad * g.to(grad.dtype), None, None, None, None
 
 
 class CrossEntropyLoss2d(nn.Module):
@@ -112,11 +112,15 @@ class CrossEntropyLoss2d(nn.Module):
 
     def __init__(self, weight=None, size_average=True, ignore_index=255):
         super().__init__()
-        if weight is not None or not size_average:
-            raise NotImplementedError("class weights / sum reduction are not used by any KD config")
+        self.weight = None if weight is None else torch.as_tensor(weight, dtype=torch.float32)
+        self.size_average = bool(size_average)
         self.ignore_index = ignore_index
 
     def forward(self, inputs, targets):
+        if self.weight is not None or not self.size_average:       # (kd_ce2d_weighted; no shipped KD config: full-resolution logits)
+            if inputs.requires_grad and torch.is_grad_enabled():
+                return _CEFunction.apply(inputs, targets, self.ignore_index, self.weight, self.size_average)
+            return ops.ce2d(inputs, targets, self.ignore_index, self.weight, self.size_average)
         if isinstance(inputs, LazyLogits) and inputs.pending:
             try:
                 return deferred(ops.ce2d_up(inputs.low, targets, inputs.size_hw, self.ignore_index, inputs.align_corners),

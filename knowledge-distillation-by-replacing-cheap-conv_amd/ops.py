@@ -959,7 +959,14 @@ def weighted_hint_mse(s, t, w, want_grad=True, grad_scale=1.0):
     return loss, grad
 
 
-def ce2d(x, target, ignore_index=255):
+def _class_weight(weight, Cc, device):
+    w = weight.detach().to(device=device, dtype=torch.float32).contiguous()
+    if w.numel() != Cc:
+        raise ValueError("class weights: one per class")
+    return w
+
+
+def ce2d(x, target, ignore_index=255, weight=None, size_average=True):
     _need_cuda(x, target)
     vx, (N, Cc, P) = view3(x)
     tgt = target.contiguous()
@@ -968,7 +975,12 @@ def ce2d(x, target, ignore_index=255):
     loss = torch.empty((), dtype=torch.float32, device=x.device)
     ws, need = loss_workspace(N, Cc, P, x.device)
     e0 = _prof_start()
-    check(_lib.lib().kd_ce2d(C.byref(vx), _ptr(tgt), ignore_index, N, Cc, P, _ptr(loss), _ptr(ws), need, stream_ptr()), "kd_ce2d")
+    if weight is not None or not size_average:
+        w = _class_weight(weight, Cc, x.device) if weight is not None else None
+        check(_lib.lib().kd_ce2d_weighted(C.byref(vx), _ptr(tgt), _ptr(w) if w is not None else None, int(not size_average), ignore_index, N, Cc, P,
+                                          _ptr(loss), _ptr(ws), need, stream_ptr()), "kd_ce2d_weighted")
+    else:
+        check(_lib.lib().kd_ce2d(C.byref(vx), _ptr(tgt), ignore_index, N, Cc, P, _ptr(loss), _ptr(ws), need, stream_ptr()), "kd_ce2d")
     _prof_stop(e0, "loss", _nbytes(x, tgt), f"ce2d {N}x{Cc}x{P}", "ce2d_kernel")
     return loss
 
@@ -1014,7 +1026,7 @@ def kldiv_up(s_lo, t_lo, size, temperature=1.0, align_corners=True):
     return loss
 
 
-def ce2d_grad(x, target, ignore_index=255, grad_scale=1.0):
+def ce2d_grad(x, target, ignore_index=255, grad_scale=1.0, weight=None, size_average=True):
     """d ce2d / d x, same layout as x."""
     _need_cuda(x, target)
     vx, (N, Cc, P) = view3(x)
@@ -1024,6 +1036,11 @@ def ce2d_grad(x, target, ignore_index=255, grad_scale=1.0):
     grad = torch.empty_like(x)
     vg, _ = view3(grad)
     ws, need = loss_workspace(N, Cc, P, x.device)
+    if weight is not None or not size_average:
+        w = _class_weight(weight, Cc, x.device) if weight is not None else None
+        check(_lib.lib().kd_ce2d_weighted_grad(C.byref(vx), _ptr(tgt), _ptr(w) if w is not None else None, int(not size_average), ignore_index, N, Cc, P,
+                                               C.byref(vg), C.c_float(grad_scale), _ptr(ws), need, stream_ptr()), "kd_ce2d_weighted_grad")
+        return grad
     check(_lib.lib().kd_ce2d_grad(C.byref(vx), _ptr(tgt), ignore_index, N, Cc, P, C.byref(vg), C.c_float(grad_scale), _ptr(ws), need,
                                   stream_ptr()), "kd_ce2d_grad")
     return grad

@@ -656,6 +656,36 @@ def test_mse_sum_reduction_matches_torch():
     np.testing.assert_allclose(s.grad.cpu().numpy(), s2.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("size_average", [True, False])
+@pytest.mark.parametrize("fmt", ["nchw", "nhwc", "bf16_nhwc"])
+def test_cross_entropy_class_weights_and_sum_match_torch(size_average, fmt):
+    """CrossEntropyLoss2d(weight, size_average) (reference losses/CrossEntropy.py:5-14 = nn.NLLLoss(weight, size_average, ignore_index)
+    on log_softmax): value and gradient against torch's own cross_entropy on the device, through the strided and the NHWC kernels."""
+    from kdcc_amd import losses
+    g = torch.Generator(device="cuda").manual_seed(5)
+    N, Cc, H, W = 2, 19, 11, 17
+    x = torch.randn(N, Cc, H, W, device="cuda", generator=g) * 2
+    if fmt != "nchw":
+        x = x.contiguous(memory_format=torch.channels_last)
+    if fmt == "bf16_nhwc":
+        x = x.bfloat16()
+    x.requires_grad_(True)
+    t = torch.randint(0, Cc, (N, H, W), device="cuda", generator=g)
+    t[0, :2] = 255
+    w = torch.rand(Cc, device="cuda", generator=g) + 0.25
+    loss = losses.CrossEntropyLoss2d(weight=w, size_average=size_average, ignore_index=255)(x, t)
+    loss.backward()
+    x2 = x.detach().float().clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(x2, t, weight=w, ignore_index=255, reduction="mean" if size_average else "sum")
+    ref.backward()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-5)
+    tol = dict(rtol=2e-2, atol=2e-3) if fmt == "bf16_nhwc" else dict(rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(x.grad.float().cpu().numpy(), x2.grad.cpu().numpy(), **tol)
+    # and without weights, sum reduction alone
+    plain = losses.CrossEntropyLoss2d(size_average=False)(x.detach(), t)
+    np.testing.assert_allclose(plain.item(), torch.nn.functional.cross_entropy(x2.detach(), t, ignore_index=255, reduction="sum").item(), rtol=2e-5)
+
+
 def test_losses_bf16_large_vs_oracle(K):
     """bf16 NHWC operands at a hint-like size: vector path, compared with the oracle on the rounded inputs."""
     N, Cc, H, W = 2, 64, 24, 40
