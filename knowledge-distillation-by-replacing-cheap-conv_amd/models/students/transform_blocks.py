@@ -13,8 +13,8 @@ from ... import ops
 
 
 def _small_shape(x, pw):
-    """The MFMA pointwise kernel needs the channel count to be a multiple of its K granule (32 in fp32) and has no bias
-    operand; fp32 blocks outside that (the CIFAR configs' 16-channel blocks, biased blocks) take the direct NCHW kernels."""
+    """The MFMA pointwise kernel needs the channel count to be a multiple of its K granule (32 in fp32); fp32 blocks outside that
+    (the CIFAR configs' 16-channel blocks) and biased fp32 blocks take the direct NCHW kernels."""
     return x.dtype == torch.float32 and (x.shape[1] % 32 != 0 or pw.bias is not None)
 
 
@@ -23,23 +23,24 @@ class _DwSepFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_dw, w_pw, b_dw, b_pw, k, pad, dil):
-        if b_pw is not None:
-            raise NotImplementedError("pointwise bias is not supported by the fused epilogue (never set for WRN-38 targets)")
         xh = x.permute(0, 2, 3, 1).contiguous()
         mid = ops.dwconv(xh, ops.pack_dw_weight(w_dw), k, pad, dil, bias=b_dw)
         wp = ops.pack_conv_weight(w_pw, xh.dtype)
         N, H, W, _ = xh.shape
         y = torch.empty((N, H, W, w_pw.shape[0]), dtype=xh.dtype, device=xh.device)
-        ops.conv2d(mid, wp, out_raw=y)
+        if b_pw is not None:      # the conv epilogue's per-channel shift (scale 1, no ReLU) is the bias
+            ops.conv2d(mid, wp, out_act=y, act_shift=b_pw.detach().float().contiguous(), act_relu=False)
+        else:
+            ops.conv2d(mid, wp, out_raw=y)
         ctx.save_for_backward(xh, mid, w_dw, w_pw)
-        ctx.geom = (k, pad, dil, b_dw is not None)
+        ctx.geom = (k, pad, dil, b_dw is not None, b_pw is not None)
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, gy):
         from ..._lib import KD_PACK_DGRAD
         xh, mid, w_dw, w_pw = ctx.saved_tensors
-        k, pad, dil, has_bias = ctx.geom
+        k, pad, dil, has_bias, has_pw_bias = ctx.geom
         g = gy.permute(0, 2, 3, 1).contiguous()
         gw_pw = torch.empty_like(w_pw, dtype=torch.float32)
         ops.pw_wgrad(mid, g, gw_pw)
@@ -51,7 +52,8 @@ class _DwSepFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = ops.dwconv(gmid, ops.pack_dw_weight(w_dw, flip=True), k, pad, dil).permute(0, 3, 1, 2)
         gb = gmid.float().sum(dim=(0, 1, 2)) if has_bias else None
-        return gx, gw_dw, gw_pw, gb, None, None, None, None
+        gb_pw = g.float().sum(dim=(0, 1, 2)) if has_pw_bias else None
+        return gx, gw_dw, gw_pw, gb, gb_pw, None, None, None
 
 
 class DepthwiseSeparableBlock(nn.Module):

@@ -247,6 +247,8 @@ def _dw_desc(x, k, pad, dil, y=None):
 
 def dwconv(x, w_taps, k, pad, dil, bias=None, out=None, res_pre=None, mask=None, mask_scale=None, res_post=None):
     _need_cuda(x, w_taps, bias, out, res_pre, mask, mask_scale, res_post)
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
+        bias = bias.detach().float().contiguous()      # the kernel reads fp32 (C) (a bf16 module's parameter is not)
     N, H, W, Cc = x.shape
     if tuple(w_taps.shape) != (k * k, Cc) or w_taps.dtype != torch.float32 or not w_taps.is_contiguous():
         raise ValueError("dwconv: w_taps must be contiguous fp32 [k*k][C]")

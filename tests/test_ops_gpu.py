@@ -656,6 +656,31 @@ def test_mse_sum_reduction_matches_torch():
     np.testing.assert_allclose(s.grad.cpu().numpy(), s2.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
 
 
+def test_biased_cheap_conv_block_bf16_matches_torch():
+    """DepthwiseSeparableBlock(bias=True) (reference depthwise_separable_conv.py:7-9 passes `bias` to both convs) on the bf16 MFMA
+    path: forward and every gradient against torch's own convs on the same bf16-rounded parameters."""
+    from kdcc_amd.models.students import DepthwiseSeparableBlock
+    torch.manual_seed(4)
+    Cc, Co, k, p, d = 64, 128, 3, 2, 2
+    blk = DepthwiseSeparableBlock(Cc, Co, k, p, d, Cc, True).cuda().bfloat16()
+    x = torch.randn(2, Cc, 20, 24, device="cuda").bfloat16().requires_grad_(True)
+    y = blk(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    got = [y, x.grad] + [q.grad for q in blk.parameters()]
+    ref_blk = torch.nn.Sequential(torch.nn.Conv2d(Cc, Cc, k, padding=p, dilation=d, groups=Cc), torch.nn.Conv2d(Cc, Co, 1)).cuda().float()
+    with torch.no_grad():
+        ref_blk[0].weight.copy_(blk.separable_conv.weight.float()); ref_blk[0].bias.copy_(blk.separable_conv.bias.float())
+        ref_blk[1].weight.copy_(blk.pointwise_conv.weight.float()); ref_blk[1].bias.copy_(blk.pointwise_conv.bias.float())
+    x2 = x.detach().float().requires_grad_(True)
+    y2 = ref_blk(x2)
+    y2.backward(gy.float())
+    want = [y2, x2.grad, ref_blk[0].weight.grad, ref_blk[0].bias.grad, ref_blk[1].weight.grad, ref_blk[1].bias.grad]
+    for name, a, b in zip(("y", "dx", "dw_dw", "db_dw", "dw_pw", "db_pw"), got, want):
+        err = float((a.float() - b).norm() / b.norm().clamp_min(1e-12))
+        assert err < 2e-2, (name, err)
+
+
 @pytest.mark.parametrize("size_average", [True, False])
 @pytest.mark.parametrize("fmt", ["nchw", "nhwc", "bf16_nhwc"])
 def test_cross_entropy_class_weights_and_sum_match_torch(size_average, fmt):
