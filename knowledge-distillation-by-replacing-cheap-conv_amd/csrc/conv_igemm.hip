@@ -1601,7 +1601,7 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
     static int duo = -1;
     if (duo < 0) { const char *v = getenv("KDCC_CONV_DUO"); duo = v ? atoi(v) : 0; }
     const bool duo_ok = duo > 0 && lw_row() && d->dtype == KD_BF16 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == d->dil && d->dil <= 32 &&
-                        d->W % 256 == 0 && p.M % 256 == 0 && d->H > d->dil && d->Cout % 128 == 0 && d->Cin % 64 == 0 && sel.vec_ok && !ep->raw_f32 && nops <= 1 &&
+                        d->W % 256 == 0 && p.M % 256 == 0 && d->H >= 2 * d->dil && d->Cout % 128 == 0 && d->Cin % 64 == 0 && sel.vec_ok && !ep->raw_f32 && nops <= 1 &&
                         !ep->bn_sums && !(p.tune & 512) && (long long)(p.M / 256) * (d->Cout / 128) >= 2 * ncu &&
                         (duo >= 2 || d->Cout == 128);
     if (duo_ok) {
@@ -1623,7 +1623,9 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         p.nkc = d->Cin / (CfgRow::RB / es);
         p.nk = 9 * p.nkc;
         const dim3 grid = persist_grid();
-        const bool lw = lw_row() && pp_row() && d->dil <= 32 && d->H > d->dil && !(p.tune & 512);   // (H > dil: every tile has >= 2 kernel rows, i.e. >= 2 periods)
+        // H >= 2 dil: every output row has >= 2 kernel rows inside the image, which the loop's period hand-over assumes (with dil < H < 2 dil the
+        // rows H - dil <= ho < dil have one; they go to the ping-pong kernel, which counts kernel rows per tile)
+        const bool lw = lw_row() && pp_row() && d->dil <= 32 && d->H >= 2 * d->dil && !(p.tune & 512);
         KD_NOTE_KERNEL((p.tune & 512) ? "conv_row_persist_kernel<dbg>" : lw ? "conv_row_lw_kernel" : (pp_row() && d->dil <= 32) ? "conv_row_persist_kernel<pp>" : "conv_row_persist_kernel<lockstep>");
         if (lw) {
             KD_REQUIRE(kd_launch_conv_row_lw(p, nops | (ep->bn_sums ? 4 : 0), grid.x, s), KD_ERR_UNSUPPORTED, "kd_conv2d_fwd: no conv_row_lw_kernel instantiation for %d epilogue operands", nops);

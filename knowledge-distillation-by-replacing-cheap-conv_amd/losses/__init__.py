@@ -112,11 +112,14 @@ class CrossEntropyLoss2d(nn.Module):
 
     def __init__(self, weight=None, size_average=True, ignore_index=255):
         super().__init__()
-        self.weight = None if weight is None else torch.as_tensor(weight, dtype=torch.float32)
+        # a buffer like nn.NLLLoss(weight)'s: follows .to(device) / state_dict and is uploaded once
+        self.register_buffer('weight', None if weight is None else torch.as_tensor(weight, dtype=torch.float32))
         self.size_average = bool(size_average)
         self.ignore_index = ignore_index
 
     def forward(self, inputs, targets):
+        if self.weight is not None and self.weight.device != inputs.device:
+            self.weight = self.weight.to(inputs.device)             # once (a criterion that was never moved with .to())
         if self.weight is not None or not self.size_average:       # (kd_ce2d_weighted; no shipped KD config: full-resolution logits)
             if inputs.requires_grad and torch.is_grad_enabled():
                 return _CEFunction.apply(inputs, targets, self.ignore_index, self.weight, self.size_average)

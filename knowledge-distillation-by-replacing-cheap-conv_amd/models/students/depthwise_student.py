@@ -18,6 +18,7 @@ from torch import nn
 
 from ..deeplabv3 import DeepWV3Plus
 from ..gscnn import GSCNN
+from ...lazy import LazyLogits
 from .transform_blocks import DepthwiseSeparableBlock
 
 BLOCKS_LEVEL_SPLIT_CHAR = '.'
@@ -228,7 +229,10 @@ class DepthwiseStudent(nn.Module):
             student_pred, hints = run_student(engine, x)
             main.wait_stream(self._side_stream)
             for t in [teacher_pred] + list(self.teacher_hidden_outputs):
-                t.record_stream(main)
+                if isinstance(t, LazyLogits) and t.pending:     # (record_stream on the wrapper would materialise the full-resolution tensor)
+                    t.low.record_stream(main)
+                else:
+                    t.record_stream(main)
         else:
             self._prefix = None
             teacher_pred = self._teacher_forward(x)

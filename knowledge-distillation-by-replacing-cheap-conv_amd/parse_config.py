@@ -66,7 +66,7 @@ class ConfigParser:
                 for d in (self._save_dir, self._log_dir):
                     d.mkdir(parents=True, exist_ok=not fresh and run_id == '')
                 write_json(config, self._save_dir / 'config.json')
-            except OSError as e:
+            except Exception as e:      # anything (a non-serialisable config value too): every rank must learn of it
                 err = f'{type(e).__name__}: {e}'
         err = parallel.broadcast_object(err)
         if err is not None:

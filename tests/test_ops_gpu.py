@@ -259,6 +259,10 @@ PERSIST_CASES = [
     ((1, 20, 512, 64, 2048, 1, 0, 1), (), ("act",)),
     ((1, 160, 512, 64, 256, 1, 0, 1), ("pre", "mask", "post"), ("raw",)),          # three operands (dgrad: mask + both residuals)
     ((1, 80, 512, 64, 512, 3, 2, 2), ("pre", "mask", "post"), ("raw", "act")),
+    # dil < H < 2 dil (ASPP rate 24 on a 256 x 2048 crop): output rows H - dil <= ho < dil see ONE kernel row, which the lone-wave loop's
+    # period hand-over does not model -> the ping-pong kernel must take the launch (round-4 advisor finding); H = 2 dil is the first lone-wave size
+    ((8, 32, 256, 64, 256, 3, 24, 24), ("pre",), ("raw", "act")),
+    ((8, 48, 256, 64, 256, 3, 24, 24), ("mask",), ("raw", "act")),
     # Cout = 128, W % 512 == 0: 512 x 128 tiles, conv_row_tall_kernel (64-B K stages; KDCC_CONV_LW=0: conv_row_pp128_kernel, tools/lw_check.py)
     ((1, 40, 1024, 192, 128, 3, 3, 3), ("pre", "mask"), ("raw", "act")),     # 18 / 12 periods per tile: both entry phases of the loop body
     ((3, 9, 1536, 64, 128, 3, 4, 4), ("pre",), ("raw", "act")),              # three tiles per image row (first / inner / last), image boundaries, 81 tiles
@@ -299,8 +303,8 @@ def test_conv_persistent_epilogues(K, case, opnds, outs):
              res_post=dev_nhwc(post, dt, ld=Cout + 24) if "post" in opnds else None,
              out_raw=out_raw, out_act=out_act, act_scale=cu(ascale) if "act" in outs else None,
              act_shift=cu(ashift) if "act" in outs else None, act_relu="act" in outs)
-    selected("conv_igemm_persist_kernel<pp>" if k == 1 else "conv_row_tall_kernel" if Cout == 128 else "conv_row_lw_kernel",
-             f"{case} {opnds}")
+    selected("conv_igemm_persist_kernel<pp>" if k == 1 else "conv_row_tall_kernel" if Cout == 128 else
+             "conv_row_persist_kernel<pp>" if H < 2 * d else "conv_row_lw_kernel", f"{case} {opnds}")
     if out_raw is not None:
         assert_close(host_nchw(out_raw), ref, dt, f"raw {case} {opnds}")
     if out_act is not None:

@@ -47,7 +47,7 @@ for fam, _ in FAMILIES:
     tf = a["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512.0 / (a["ns"] * 1e-9) / 1e12
     out["kernels"][fam] = {"launches_profiled": n[fam], "avg_us": a["ns"] / n[fam] / 1e3, "mfma_util": a["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0),
                            "counter_tflops": tf, "frac_of_2500": tf / 2500.0, "clock_ghz_from_grbm": cyc / a["ns"]}
-    if fam.startswith("conv_igemm"):
+    if fam.startswith("conv_") and not fam.startswith("conv_wgrad"):      # every forward / input-gradient conv family (lone-wave kernels included)
         for k, v in a.items():
             tot[k] += v
 if tot["ns"]:
