@@ -195,6 +195,38 @@ int kd_dwconv_wgrad_multi(const kd_dw_desc *d, int32_t n, const void *x, const v
                           float *const *dws, int32_t accumulate, void *workspace, size_t workspace_bytes,
                           kd_stream_t stream);
 
+/* ------------------------------------------------ lattice-planar intermediates of the replaced ASPP branches
+ * The depthwise outputs of the replaced branches and their gradients (models/students/transform_blocks/
+ * depthwise_separable_conv.py:11-13, `x = self.separable_conv(x); x = self.pointwise_conv(x)`, under
+ * models/deeplabv3/deeplabv3.py:64-75) are 4096-channel tensors that nothing but the depthwise kernels and the 1x1 convs next
+ * to them ever reads.  In NHWC a depthwise workgroup (16 channels) moves them as 32-B pieces 40 KiB apart; in the
+ * LATTICE-PLANAR layout of a dilation d
+ *     [C/16 planes][rows][16 channels],   row(n, ry, rx, ly, lx) = ((n*d*d + ry*d + rx)*Ly + ly)*Lx + lx,
+ *     Ly = ceil(H/d), Lx = ceil(W/d),  pixel (y, x) = (ry + d*ly, rx + d*lx),  rows = kd_lattice_rows() (a multiple of 256)
+ * the pixels of one residue class of one image are consecutive rows, so the same tile is one contiguous run per lattice row.
+ * Cells whose pixel is outside the image and the tail rows of a plane hold zeros (writers keep them zero).  1x1 convs take
+ * such a tensor as a GEMM operand over `rows` rows (kd_conv1x1_rows, kd_pw_wgrad_rows); their 256-channel side is a dense
+ * [rows][C] matrix in the same row order, moved from / to image order by kd_lattice_rows_move. */
+int64_t kd_lattice_rows(int32_t N, int32_t H, int32_t W, int32_t dil);
+/* 1 when the fan-out / sum / multi-gradient launches of n (2 or 3) branches of geometry d can run on lattice-planar
+ * intermediates (bf16, 9x9, C % 16 == 0, 32-bit plane offsets); otherwise the caller keeps NHWC intermediates. */
+int32_t kd_dwconv_lattice_ok(const kd_dw_desc *d, int32_t n);
+/* to_rows != 0: rows[r][c] = img[n, y, x, c] for the pixel of lattice row r (zero rows for padded cells and the tail);
+ * to_rows == 0: img[n, y, x, c] = rows[r][c] for every pixel.  img: (N,H,W,C) view with pixel stride ld_img; rows:
+ * kd_lattice_rows() x C with row stride ld_rows.  C and both strides multiples of 16 B. */
+int kd_lattice_rows_move(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dil, void *img, int32_t ld_img,
+                         void *rows, int32_t ld_rows, int32_t to_rows, kd_stream_t stream);
+/* kd_dwconv_fwd_fanout / kd_dwconv_fwd_sum / kd_dwconv_wgrad_multi with the n-side tensors lattice-planar: the fan-out's
+ * outputs ys[] (x stays NHWC), the sum's inputs xs[] (y stays NHWC, stride d->ldy), the gradients dys[] (x stays NHWC).
+ * n = 2 or 3; KD_ERR_UNSUPPORTED unless kd_dwconv_lattice_ok(d, n).  Same values as the NHWC entry points. */
+int kd_dwconv_fwd_fanout_lattice(const kd_dw_desc *d, int32_t n, const void *x, const float *const *w_taps, void *const *ys,
+                                 kd_stream_t stream);
+int kd_dwconv_fwd_sum_lattice(const kd_dw_desc *d, int32_t n, const void *const *xs, const float *const *w_taps, void *y,
+                              kd_stream_t stream);
+int kd_dwconv_wgrad_multi_lattice(const kd_dw_desc *d, int32_t n, const void *x, const void *const *dys, float *const *dws,
+                                  int32_t accumulate, void *workspace, size_t workspace_bytes /* kd_dwconv_wgrad_multi_workspace */,
+                                  kd_stream_t stream);
+
 /* ----------------------------------------------------------- trunk plumbing
  * Stem conv mod1.conv1 (wider_resnet.py:307-309): 3x3, 3 -> 64, stride 1, pad 1,
  * reading the trainer's NCHW fp32 batch directly (layerwise_trainer.py:221).

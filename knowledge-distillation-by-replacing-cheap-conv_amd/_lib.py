@@ -102,6 +102,12 @@ _SIGS = {
     "kd_dwconv_wgrad": (c_int, [_P(DwDesc), c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_sz, c_vp]),
     "kd_dwconv_wgrad_multi_workspace": (c_sz, [_P(DwDesc), c_int]),
     "kd_dwconv_wgrad_multi": (c_int, [_P(DwDesc), c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_sz, c_vp]),
+    "kd_lattice_rows": (c_i64, [c_int, c_int, c_int, c_int]),
+    "kd_dwconv_lattice_ok": (c_int, [_P(DwDesc), c_int]),
+    "kd_lattice_rows_move": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_int, c_vp]),
+    "kd_dwconv_fwd_fanout_lattice": (c_int, [_P(DwDesc), c_int, c_vp, c_vp, c_vp, c_vp]),
+    "kd_dwconv_fwd_sum_lattice": (c_int, [_P(DwDesc), c_int, c_vp, c_vp, c_vp, c_vp]),
+    "kd_dwconv_wgrad_multi_lattice": (c_int, [_P(DwDesc), c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_sz, c_vp]),
     "kd_stem_conv": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "kd_scale_by_device_scalar": (c_int, [c_vp, c_int, c_i64, c_vp, c_vp]),
     "kd_pointwise_small": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_vp]),

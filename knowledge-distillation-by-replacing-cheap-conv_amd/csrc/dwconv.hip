@@ -398,12 +398,14 @@ int check_desc(const kd_dw_desc *d, const char *who)
 int kd_internal_dw_mfma_fwd(const kd_dw_desc *d, const void *x, const float *w_taps, const float *bias,
                             const kd_dw_epilogue *ep, void *y, hipStream_t s);
 
+long long kd_internal_lattice_rows(int N, int H, int W, int dil);
+int kd_internal_dw_lattice_ok(const kd_dw_desc *d, int nb);
 int kd_internal_dw_mfma_fwd_n(const kd_dw_desc *d, int nb, int fan, const void *const *xs, const float *const *ws, void *const *ys,
-                              const float *bias, const kd_dw_epilogue *ep, hipStream_t s);
+                              const float *bias, const kd_dw_epilogue *ep, hipStream_t s, int lp = 0);
 int kd_internal_dw_mfma_wgrad_slabs(const kd_dw_desc *d);
 int kd_internal_dw_mfma_wgrad(const kd_dw_desc *d, const void *x, const void *dy, int ld_dy, float *part, hipStream_t s);
 int kd_internal_dw_mfma_wgrad_multi_slabs(const kd_dw_desc *d, int n);
-int kd_internal_dw_mfma_wgrad_multi(const kd_dw_desc *d, int n, const void *x, const void *const *dys, int ld_dy, float *part, hipStream_t s);
+int kd_internal_dw_mfma_wgrad_multi(const kd_dw_desc *d, int n, const void *x, const void *const *dys, int ld_dy, float *part, hipStream_t s, int lp = 0);
 
 extern "C" int kd_pack_dw_weight(const float *src, float *dst, int32_t C, int32_t k, int32_t flip, kd_stream_t stream)
 {
@@ -633,6 +635,123 @@ extern "C" int kd_dwconv_wgrad_multi(const kd_dw_desc *d, int32_t n, const void 
             }
         }
         done += m;
+    }
+    return KD_OK;
+}
+
+
+// ---- lattice-planar intermediates (include/kdcc.h "lattice-planar layout"; kernels in dwconv_mfma.hip) ----------------------
+namespace {
+// rows of an NHWC tensor <-> rows in lattice order (dense [rows][C] with stride ld_rows): the 1x1 convs next to the depthwise
+// kernels run over rows in lattice order, their other operand / result (the branch's 256-channel output, hint gradient) lives
+// in image order.  A thread moves 16 B; gather zero-fills the rows of padded cells and of the plane's tail.
+template <bool GATHER>
+__global__ void lattice_rows_kernel(const uint4 *__restrict__ img, uint4 *__restrict__ rows, long long nrows, int N, int H, int W, int d,
+                                    int Ly, int Lx, int c16, int ld_img16, int ld_rows16)
+{
+    const long long total = nrows * c16;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long row = e / c16;
+        const int c = (int)(e - row * c16);
+        long long r = row;
+        const int lx = (int)(r % Lx); r /= Lx;
+        const int ly = (int)(r % Ly); r /= Ly;
+        const int cls = (int)(r % (d * d)); r /= d * d;
+        const int yy = cls / d + d * ly, xx = cls % d + d * lx;
+        const bool in = r < N && yy < H && xx < W;
+        if (GATHER) rows[row * ld_rows16 + c] = in ? img[((r * H + yy) * W + xx) * ld_img16 + c] : make_uint4(0u, 0u, 0u, 0u);
+        else if (in) const_cast<uint4 *>(img)[((r * H + yy) * W + xx) * ld_img16 + c] = rows[row * ld_rows16 + c];
+    }
+}
+}  // namespace
+
+extern "C" int64_t kd_lattice_rows(int32_t N, int32_t H, int32_t W, int32_t dil)
+{
+    return (int64_t)kd_internal_lattice_rows(N, H, W, dil);
+}
+
+extern "C" int32_t kd_dwconv_lattice_ok(const kd_dw_desc *d, int32_t n)
+{
+    if (!d || check_desc(d, "kd_dwconv_lattice_ok")) return 0;
+    return kd_internal_dw_lattice_ok(d, n);
+}
+
+extern "C" int kd_lattice_rows_move(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dil, void *img, int32_t ld_img,
+                                    void *rows, int32_t ld_rows, int32_t to_rows, kd_stream_t stream)
+{
+    KD_REQUIRE(img && rows && N > 0 && H > 0 && W > 0 && C > 0 && dil >= 1, KD_ERR_INVALID, "kd_lattice_rows_move: bad argument");
+    KD_REQUIRE(dtype == KD_F32 || dtype == KD_BF16, KD_ERR_INVALID, "kd_lattice_rows_move: bad dtype");
+    const int es = kd_elem_size(dtype), v = 16 / es;
+    KD_REQUIRE(C % v == 0 && ld_img % v == 0 && ld_rows % v == 0 && ld_img >= C && ld_rows >= C && kd_aligned16(img) && kd_aligned16(rows),
+               KD_ERR_INVALID, "kd_lattice_rows_move: channels / strides must be multiples of 16 B and the tensors 16-B aligned");
+    const long long nrows = kd_internal_lattice_rows(N, H, W, dil);
+    const int Ly = (H + dil - 1) / dil, Lx = (W + dil - 1) / dil;
+    const long long total = nrows * (C / v);
+    const unsigned grid = (unsigned)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+    if (to_rows)
+        hipLaunchKernelGGL(lattice_rows_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4 *)img, (uint4 *)rows, nrows, N, H, W,
+                           dil, Ly, Lx, C / v, ld_img / v, ld_rows / v);
+    else
+        hipLaunchKernelGGL(lattice_rows_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4 *)img, (uint4 *)rows, nrows, N, H, W,
+                           dil, Ly, Lx, C / v, ld_img / v, ld_rows / v);
+    KD_CHECK_LAUNCH("kd_lattice_rows_move");
+    return KD_OK;
+}
+
+extern "C" int kd_dwconv_fwd_fanout_lattice(const kd_dw_desc *d, int32_t n, const void *x, const float *const *w_taps, void *const *ys,
+                                            kd_stream_t stream)
+{
+    int rc = check_desc(d, "kd_dwconv_fwd_fanout_lattice");
+    if (rc) return rc;
+    KD_REQUIRE(n >= 2 && n <= 3 && x && w_taps && ys, KD_ERR_INVALID, "kd_dwconv_fwd_fanout_lattice: null argument or n not 2, 3");
+    for (int i = 0; i < n; ++i) {
+        KD_REQUIRE(ys[i] && w_taps[i] && ys[i] != x, KD_ERR_INVALID, "kd_dwconv_fwd_fanout_lattice: null / aliasing output %d", i);
+        for (int j = 0; j < i; ++j) KD_REQUIRE(ys[i] != ys[j], KD_ERR_INVALID, "kd_dwconv_fwd_fanout_lattice: outputs %d and %d alias", j, i);
+    }
+    KD_REQUIRE(kd_internal_dw_lattice_ok(d, n), KD_ERR_UNSUPPORTED, "kd_dwconv_fwd_fanout_lattice: shape not eligible (kd_dwconv_lattice_ok)");
+    kd_dw_desc dd = *d;
+    dd.ldy = d->C;   // (unused by the lattice kernels; the eligibility test of the shared launcher reads it)
+    const int took = kd_internal_dw_mfma_fwd_n(&dd, n, 1, &x, w_taps, ys, nullptr, nullptr, (hipStream_t)stream, 1);
+    if (took < 0) return took;
+    KD_REQUIRE(took, KD_ERR_UNSUPPORTED, "kd_dwconv_fwd_fanout_lattice: the matrix-core kernel refused the call");
+    return KD_OK;
+}
+
+extern "C" int kd_dwconv_fwd_sum_lattice(const kd_dw_desc *d, int32_t n, const void *const *xs, const float *const *w_taps, void *y,
+                                         kd_stream_t stream)
+{
+    int rc = check_desc(d, "kd_dwconv_fwd_sum_lattice");
+    if (rc) return rc;
+    KD_REQUIRE(n >= 2 && n <= 3 && xs && w_taps && y, KD_ERR_INVALID, "kd_dwconv_fwd_sum_lattice: null argument or n not 2, 3");
+    for (int i = 0; i < n; ++i) KD_REQUIRE(xs[i] && w_taps[i] && xs[i] != y, KD_ERR_INVALID, "kd_dwconv_fwd_sum_lattice: null / aliasing input %d", i);
+    KD_REQUIRE(d->ldy >= d->C && d->ldy % 8 == 0, KD_ERR_INVALID, "kd_dwconv_fwd_sum_lattice: bad ldy");
+    KD_REQUIRE(kd_internal_dw_lattice_ok(d, n), KD_ERR_UNSUPPORTED, "kd_dwconv_fwd_sum_lattice: shape not eligible (kd_dwconv_lattice_ok)");
+    const int took = kd_internal_dw_mfma_fwd_n(d, n, 0, xs, w_taps, &y, nullptr, nullptr, (hipStream_t)stream, 1);
+    if (took < 0) return took;
+    KD_REQUIRE(took, KD_ERR_UNSUPPORTED, "kd_dwconv_fwd_sum_lattice: the matrix-core kernel refused the call");
+    return KD_OK;
+}
+
+extern "C" int kd_dwconv_wgrad_multi_lattice(const kd_dw_desc *d, int32_t n, const void *x, const void *const *dys, float *const *dws,
+                                             int32_t accumulate, void *workspace, size_t workspace_bytes, kd_stream_t stream)
+{
+    int rc = check_desc(d, "kd_dwconv_wgrad_multi_lattice");
+    if (rc) return rc;
+    KD_REQUIRE(n >= 2 && n <= 3 && x && dys && dws && workspace, KD_ERR_INVALID, "kd_dwconv_wgrad_multi_lattice: null argument or n not 2, 3");
+    for (int i = 0; i < n; ++i) KD_REQUIRE(dys[i] && dws[i], KD_ERR_INVALID, "kd_dwconv_wgrad_multi_lattice: null gradient %d", i);
+    KD_REQUIRE(workspace_bytes >= kd_dwconv_wgrad_multi_workspace(d, n), KD_ERR_WORKSPACE, "kd_dwconv_wgrad_multi_lattice: workspace too small");
+    KD_REQUIRE(kd_internal_dw_lattice_ok(d, n), KD_ERR_UNSUPPORTED, "kd_dwconv_wgrad_multi_lattice: shape not eligible (kd_dwconv_lattice_ok)");
+    hipStream_t s = (hipStream_t)stream;
+    const int slabs = kd_internal_dw_mfma_wgrad_multi_slabs(d, n);
+    KD_REQUIRE(slabs > 0, KD_ERR_UNSUPPORTED, "kd_dwconv_wgrad_multi_lattice: shape not eligible");
+    const int took = kd_internal_dw_mfma_wgrad_multi(d, n, x, dys, d->C, (float *)workspace, s, 1);
+    if (took < 0) return took;
+    KD_REQUIRE(took, KD_ERR_UNSUPPORTED, "kd_dwconv_wgrad_multi_lattice: the matrix-core kernel refused the call");
+    const int total = d->k * d->k * d->C;
+    for (int i = 0; i < n; ++i) {
+        hipLaunchKernelGGL(dw_slab_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, (const float *)workspace + (size_t)i * slabs * total,
+                           dws[i], slabs, d->k * d->k, d->C, accumulate);
+        KD_CHECK_LAUNCH("kd_dwconv_wgrad_multi_lattice(reduce)");
     }
     return KD_OK;
 }

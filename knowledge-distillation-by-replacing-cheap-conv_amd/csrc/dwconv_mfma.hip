@@ -26,6 +26,8 @@
 
 #include "igemm_core.h"
 
+long long kd_internal_lattice_rows(int N, int H, int W, int dil);
+
 namespace {
 
 constexpr int CG = 16;                      // channels per block
@@ -47,6 +49,19 @@ static_assert(TLY * OPX * OSTR <= RY * RSTR, "output staging must fit in the inp
 static_assert(TLY <= 28 && TLX <= 64 && NT == 512, "store phase: thread = (half, 64 columns, row mod 4), 7 rows each");
 static_assert(LDS_BYTES + 2 * WTBYTES <= 160 * 1024, "LDS budget (three summed inputs)");
 
+// Lattice-planar layout ("LP") of an (N,H,W,C) bf16 tensor for dilation d -- the private layout of the tensors only these kernels
+// and the 1x1 convs next to them touch (the replaced ASPP branches' depthwise outputs and their gradients):
+//   [C/16 planes][rows][16 channels],  row(n, ry, rx, ly, lx) = ((n*d*d + ry*d + rx)*Ly + ly)*Lx + lx,  Ly = ceil(H/d), Lx = ceil(W/d)
+// i.e. the pixels of one residue class (ry, rx) of one image are CONSECUTIVE rows in lattice order, so a work item's tile of a
+// 16-channel group is one contiguous run of 32-B cells per lattice row (26 x 52 x 32 B = 42 KiB in one piece when a class is one
+// tile) instead of 32-B pieces 40 KiB apart in NHWC (tools/ubench/piece_bw.hip: those copy at a third of the rate).  Cells whose
+// pixel lies outside the image (yy >= H or xx >= W: classes one row / column shorter) and the rows that pad a plane to a
+// multiple of 256 hold zeros; `plane` = rows per plane * 16 elements.
+struct LpGeom {
+    int Ly, Lx, rpi;     // lattice extent of a class (padded), rows per image = d*d*Ly*Lx
+    long long plane;     // elements per plane
+};
+
 constexpr int MAXB = 3;                     // inputs one launch can sum (the three ASPP branches)
 struct DwMfmaParams {
     const bf16_t *x;     // input 0
@@ -58,7 +73,8 @@ struct DwMfmaParams {
     int N, H, W, C, dil, ldx, ldy;
     int nty, ntx, ncg;
     int nitems, nseg;    // work items per (image, channel group); segments they are split into
-    int dbg;             // timing-only ablation hook (KDCC_DW_DBG): 1 = no MFMA phase, 2 = no output phase, 4 = no LDS fill of the next tile
+    int dbg;             // timing-only ablation hook (KDCC_DW_DBG): 1 = no MFMA phase, 2 = no output phase, 4 = no LDS fill of the next tile, 8 = no load requests, 16 = no output stores
+    LpGeom lp;           // lattice-planar operands (LP kernels: the fan-out's outputs, the summing kernel's inputs)
 };
 
 struct Item {
@@ -102,7 +118,11 @@ struct Staged {
     uint32_t ok[NIT];
 };
 
-// global -> registers: unit (row r, column pair lp, half h) = two pixels of the residue lattice, 8 channels each
+// global -> registers: unit (row r, column pair lp, half h) = two pixels of the residue lattice, 8 channels each.
+// XLP: the input is lattice-planar and `xr` spans this (image, channel group)'s rows of its plane -- the two pixels of a unit are
+// neighbouring 32-B cells, a lattice row of the tile one contiguous run (cells outside the image are still masked here: the
+// halo of a tile must read zeros, not the neighbouring lattice row's end)
+template <bool XLP = false>
 __device__ __forceinline__ void fetch_unit(int it, const DwMfmaParams &p, __amdgpu_buffer_rsrc_t xr, const Item &w, int tid, Staged &s)
 {
     const int d = p.dil;
@@ -113,17 +133,24 @@ __device__ __forceinline__ void fetch_unit(int it, const DwMfmaParams &p, __amdg
         const int yy = w.ry + d * ly, xa = w.rx + d * lx, xb2 = xa + d;
         const bool rok = ly >= 0 && yy < p.H && lp < 30 && unit < ITEMS;
         const bool aok = rok && lx >= 0 && xa < p.W, bok = rok && lx + 1 >= 0 && xb2 < p.W;
-        const uint32_t pb = (uint32_t)p.ldx * 2u;
-        const uint32_t oa = (uint32_t)(yy * p.W + xa) * pb + (uint32_t)h * 16u;
-        s.a[it] = bload16(xr, aok ? oa : BUF_OOB);
-        s.b[it] = bload16(xr, bok ? oa + (uint32_t)d * pb : BUF_OOB);
+        const uint32_t pb = XLP ? 32u : (uint32_t)p.ldx * 2u;
+        const uint32_t oa = (XLP ? (uint32_t)(((w.ry * d + w.rx) * p.lp.Ly + ly) * p.lp.Lx + lx) : (uint32_t)(yy * p.W + xa)) * pb + (uint32_t)h * 16u;
+        const bool req = !(p.dbg & 8);   // (timing ablation, tuning build: no memory requests at all)
+        s.a[it] = bload16(xr, aok && req ? oa : BUF_OOB);
+        s.b[it] = bload16(xr, bok && req ? oa + (XLP ? 1u : (uint32_t)d) * pb : BUF_OOB);
         s.ok[it] = (aok ? 0x0000ffffu : 0u) | (bok ? 0xffff0000u : 0u);
     }
 }
+template <bool XLP = false>
 __device__ __forceinline__ void fetch_item(const DwMfmaParams &p, __amdgpu_buffer_rsrc_t xb, const Item &w, int tid, Staged &s)
 {
-    fetch_unit(0, p, xb, w, tid, s); fetch_unit(1, p, xb, w, tid, s); fetch_unit(2, p, xb, w, tid, s);
-    fetch_unit(3, p, xb, w, tid, s); fetch_unit(4, p, xb, w, tid, s);
+    fetch_unit<XLP>(0, p, xb, w, tid, s); fetch_unit<XLP>(1, p, xb, w, tid, s); fetch_unit<XLP>(2, p, xb, w, tid, s);
+    fetch_unit<XLP>(3, p, xb, w, tid, s); fetch_unit<XLP>(4, p, xb, w, tid, s);
+}
+// this (image, channel group)'s rows of a lattice-planar tensor: rpi rows of 32 B
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t lattice_rsrc(const bf16_t *base, const LpGeom &g, int n, int cgi)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(base + (size_t)cgi * g.plane + (size_t)n * g.rpi * CG), 0, g.rpi * CG * 2, 0x00020000);
 }
 static_assert(NIT == 5, "fetch_item / the interleaved fetch below are written for 5 units per thread");
 
@@ -183,10 +210,13 @@ __device__ __forceinline__ void build_toeplitz(const char *smem, int b, int wave
 // NB = 2, 3, FAN = true: y_b = dwconv(x, w_b) -- the forward of those NB convs: the tile of x is staged ONCE per item and
 // stays in its buffer while the NB outputs are computed one after the other (operands rebuilt per output, the output staging
 // uses the idle second buffer); the next item's loads go out under the first output's MFMAs.  One read of x instead of NB.
-template <int NB, bool FAN>
+// LP: the tensors on the NB side are lattice-planar -- the fan-out's outputs (x stays NHWC), the summing kernel's inputs (y stays
+// NHWC): the 4096-channel intermediates of the replaced ASPP branches, which only these kernels and 1x1 convs touch.
+template <int NB, bool FAN, bool LP = false>
 __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
 {
     static_assert(NB >= 1 && NB <= MAXB && (NB > 1 || !FAN), "one to three inputs (sum) or outputs (fan-out)");
+    constexpr bool XLP = LP && !FAN, YLP = LP && FAN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int lin = xcd_remap(blockIdx.x, gridDim.x);
@@ -196,9 +226,9 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
     const int c0 = cgi * CG;
     const int ibeg = (int)((long long)p.nitems * seg / p.nseg), iend = (int)((long long)p.nitems * (seg + 1) / p.nseg);
     const size_t img = (size_t)n * p.H * p.W * p.ldx + c0;
-    const __amdgpu_buffer_rsrc_t xb0 = image_rsrc(p.x + img, p.H, p.W, p.ldx);
-    const __amdgpu_buffer_rsrc_t xb1 = image_rsrc((NB > 1 && !FAN ? p.xs[0] : p.x) + img, p.H, p.W, p.ldx);
-    const __amdgpu_buffer_rsrc_t xb2 = image_rsrc((NB > 2 && !FAN ? p.xs[1] : p.x) + img, p.H, p.W, p.ldx);
+    const __amdgpu_buffer_rsrc_t xb0 = XLP ? lattice_rsrc(p.x, p.lp, n, cgi) : image_rsrc(p.x + img, p.H, p.W, p.ldx);
+    const __amdgpu_buffer_rsrc_t xb1 = XLP ? lattice_rsrc(NB > 1 ? p.xs[0] : p.x, p.lp, n, cgi) : image_rsrc((NB > 1 && !FAN ? p.xs[0] : p.x) + img, p.H, p.W, p.ldx);
+    const __amdgpu_buffer_rsrc_t xb2 = XLP ? lattice_rsrc(NB > 2 ? p.xs[1] : p.x, p.lp, n, cgi) : image_rsrc((NB > 2 && !FAN ? p.xs[1] : p.x) + img, p.H, p.W, p.ldx);
     auto rsrc_of = [&](int b) { return NB > 2 && b == 2 ? xb2 : (NB > 1 && b == 1 ? xb1 : xb0); };
     const int d = p.dil;
 
@@ -208,7 +238,7 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
     while (cur < iend && (wi.RV <= 0 || wi.CV <= 0)) { ++cur; if (cur < iend) wi = decode_item(p, cur); }
     if (cur >= iend) return;   // block-uniform
     Staged st;
-    fetch_item(p, xb0, wi, tid, st);
+    fetch_item<XLP>(p, xb0, wi, tid, st);
 
     // taps -> bf16 tables (loads issued together, then converted)
     {
@@ -285,11 +315,11 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
                     // memory pipeline under the MFMAs instead of stalling the wave's issue in one burst
                     const int step = cc * 8 + mt * 4 + jt;
                     if (fetch) {
-                        if (step == 0) fetch_unit(0, p, xn, wn, tid, st);
-                        if (step == 3) fetch_unit(1, p, xn, wn, tid, st);
-                        if (step == 6) fetch_unit(2, p, xn, wn, tid, st);
-                        if (step == 9) fetch_unit(3, p, xn, wn, tid, st);
-                        if (step == 12) fetch_unit(4, p, xn, wn, tid, st);
+                        if (step == 0) fetch_unit<XLP>(0, p, xn, wn, tid, st);
+                        if (step == 3) fetch_unit<XLP>(1, p, xn, wn, tid, st);
+                        if (step == 6) fetch_unit<XLP>(2, p, xn, wn, tid, st);
+                        if (step == 9) fetch_unit<XLP>(3, p, xn, wn, tid, st);
+                        if (step == 12) fetch_unit<XLP>(4, p, xn, wn, tid, st);
                     }
                     if (mt < nmt && jt < njt && !(p.dbg & 1)) {
                         const char *xa = xc + ((mt ? m1 : 0) + fi) * RSTR + min(jt * 16, jlast) * 2;
@@ -333,6 +363,30 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
             if (!(p.dbg & 2)) {
                 // thread = (8-channel half, column, row mod 4): no divisions, 16-B loads/stores
                 const int h = tid & 1, col = (tid >> 1) & 63, rq = tid >> 7;
+                if constexpr (YLP) {
+                    // lattice-planar output: the tile is a run of 32-B cells per lattice row -- a wave stores 1 KiB in one piece.
+                    // Cells of the class's padded extent whose pixel is outside the image (at most one row / column) get zeros.
+                    const int RVp = min(TLY, p.lp.Ly - wi.ty * TLY), CVp = min(TLX, p.lp.Lx - wi.tx * TLX);
+                    if (col < CVp) {
+                        const char *osrc = S + col * OSTR + ((h ^ ((col >> 2) & 1)) << 4);
+                        const bool s1 = col & 1, s2 = col & 2;
+                        // (buffer stores: the plane's base in SGPRs, one 32-bit cell offset per lane)
+                        const __amdgpu_buffer_rsrc_t yr = lattice_rsrc(NB > 2 && b == 2 ? p.ys[1] : (b == 1 ? p.ys[0] : p.y), p.lp, n, cgi);
+                        const uint32_t ocol = (uint32_t)(((wi.ry * d + wi.rx) * p.lp.Ly + wi.ty * TLY) * p.lp.Lx + wi.tx * TLX + col) * 32u + (uint32_t)h * 16u;
+                        const uint32_t rstep = (uint32_t)p.lp.Lx * 32u;
+#pragma unroll
+                        for (int k = 0; k < (TLY + 3) / 4; ++k) {
+                            const int row = rq + 4 * k;
+                            if (row < RVp) {
+                                const uint4 o = *(const uint4 *)(osrc + min(row, RV - 1) * OPX * OSTR);
+                                const uint32_t a0 = s1 ? o.y : o.x, a1 = s1 ? o.x : o.y, a2 = s1 ? o.w : o.z, a3 = s1 ? o.z : o.w;
+                                const bool in = row < RV && col < CV;
+                                const u32x4_t v = in ? (u32x4_t){s2 ? a2 : a0, s2 ? a3 : a1, s2 ? a0 : a2, s2 ? a1 : a3} : (u32x4_t){0u, 0u, 0u, 0u};
+                                if (!(p.dbg & 16)) __builtin_amdgcn_raw_buffer_store_b128(v, yr, ocol + (uint32_t)row * rstep, 0, 0);
+                            }
+                        }
+                    }
+                } else
                 if (col < CV) {
                     const int xx = wi.rx + d * (wi.tx * TLX + col);
                     const char *osrc = S + col * OSTR + ((h ^ ((col >> 2) & 1)) << 4);
@@ -347,7 +401,7 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
                             const uint4 o = *(const uint4 *)(osrc + row * OPX * OSTR);
                             const uint32_t a0 = s1 ? o.y : o.x, a1 = s1 ? o.x : o.y, a2 = s1 ? o.w : o.z, a3 = s1 ? o.z : o.w;
                             const int yy = wi.ry + d * (wi.ty * TLY + row);
-                            *(uint4 *)(ycol + (size_t)yy * p.W * p.ldy) = make_uint4(s2 ? a2 : a0, s2 ? a3 : a1, s2 ? a0 : a2, s2 ? a1 : a3);
+                            if (!(p.dbg & 16)) *(uint4 *)(ycol + (size_t)yy * p.W * p.ldy) = make_uint4(s2 ? a2 : a0, s2 ? a3 : a1, s2 ? a0 : a2, s2 ? a1 : a3);
                         }
                     }
                 }
@@ -604,6 +658,7 @@ struct DwWgMultiParams {
     int N, H, W, C, dil, ldx, ldg;
     int nty, ntx, ncg;
     int nitems, nseg, nslabs;
+    LpGeom lp;           // GLP: the gradients g[] are lattice-planar (x stays NHWC)
 };
 
 __device__ __forceinline__ Item decode_item3(int H, int W, int d, int ntx, int e)
@@ -623,9 +678,9 @@ template <int NU> struct Staged3 {
     uint4 a[NU], b[NU];
 };
 
-template <int HALO, int NU>
+template <int HALO, int NU, bool LPT = false>   // LPT: `base` spans this (image, channel group)'s rows of a lattice-planar tensor (ld = its Lx, lpLy its Ly)
 __device__ __forceinline__ void fetch_unit3(int it, __amdgpu_buffer_rsrc_t base, int ld, int H, int W, int d, const Item &w, int tid,
-                                            Staged3<NU> &s)
+                                            Staged3<NU> &s, int lpLy = 0)
 {
     constexpr int UNITS = HALO ? ITEMS3 : GUNITS3;
     const int unit = tid + it * NTW;
@@ -640,10 +695,10 @@ __device__ __forceinline__ void fetch_unit3(int it, __amdgpu_buffer_rsrc_t base,
         aok = aok && 2 * lp < w.CV;
         bok = bok && 2 * lp + 1 < w.CV;
     }
-    const uint32_t pb = (uint32_t)ld * 2u;
-    const uint32_t oa = (uint32_t)(yy * W + xa) * pb + (uint32_t)h * 16u;
+    const uint32_t pb = LPT ? 32u : (uint32_t)ld * 2u;
+    const uint32_t oa = (LPT ? (uint32_t)(((w.ry * d + w.rx) * lpLy + ly) * ld + lx) : (uint32_t)(yy * W + xa)) * pb + (uint32_t)h * 16u;
     s.a[it] = bload16(base, rok && aok ? oa : BUF_OOB);
-    s.b[it] = bload16(base, rok && bok ? oa + (uint32_t)d * pb : BUF_OOB);
+    s.b[it] = bload16(base, rok && bok ? oa + (LPT ? 1u : (uint32_t)d) * pb : BUF_OOB);
     // (no validity mask is kept: an out-of-range buffer load has already returned zeros)
 }
 
@@ -673,7 +728,7 @@ template <int HALO, int NU> __device__ __forceinline__ void write_item3(char *X,
     }
 }
 
-template <int NG>
+template <int NG, bool GLP = false>
 __global__ __launch_bounds__(NTW, 1) void dw_mfma_wgrad_multi_kernel(DwWgMultiParams p)
 {
     static_assert(NG >= 2 && NG <= MAXG, "two or three branches");
@@ -687,9 +742,11 @@ __global__ __launch_bounds__(NTW, 1) void dw_mfma_wgrad_multi_kernel(DwWgMultiPa
     const int c0 = cgi * CG;
     const int ibeg = (int)((long long)p.nitems * seg / p.nseg), iend = (int)((long long)p.nitems * (seg + 1) / p.nseg);
     const __amdgpu_buffer_rsrc_t xb = image_rsrc(p.x + (size_t)n * p.H * p.W * p.ldx + c0, p.H, p.W, p.ldx);
-    const __amdgpu_buffer_rsrc_t gb0 = image_rsrc(p.g[0] + (size_t)n * p.H * p.W * p.ldg + c0, p.H, p.W, p.ldg);
-    const __amdgpu_buffer_rsrc_t gb1 = image_rsrc(p.g[1] + (size_t)n * p.H * p.W * p.ldg + c0, p.H, p.W, p.ldg);
-    const __amdgpu_buffer_rsrc_t gb2 = image_rsrc(p.g[NG > 2 ? 2 : 1] + (size_t)n * p.H * p.W * p.ldg + c0, p.H, p.W, p.ldg);
+    const __amdgpu_buffer_rsrc_t gb0 = GLP ? lattice_rsrc(p.g[0], p.lp, n, cgi) : image_rsrc(p.g[0] + (size_t)n * p.H * p.W * p.ldg + c0, p.H, p.W, p.ldg);
+    const __amdgpu_buffer_rsrc_t gb1 = GLP ? lattice_rsrc(p.g[1], p.lp, n, cgi) : image_rsrc(p.g[1] + (size_t)n * p.H * p.W * p.ldg + c0, p.H, p.W, p.ldg);
+    const __amdgpu_buffer_rsrc_t gb2 = GLP ? lattice_rsrc(p.g[NG > 2 ? 2 : 1], p.lp, n, cgi)
+                                           : image_rsrc(p.g[NG > 2 ? 2 : 1] + (size_t)n * p.H * p.W * p.ldg + c0, p.H, p.W, p.ldg);
+    const int gld = GLP ? p.lp.Lx : p.ldg, gly = GLP ? p.lp.Ly : 0;
 
     const int fi = lane & 15, kg = lane >> 4;
     f32x4_t acc[NG][2];   // per branch: even / odd staged x rows (the odd-row tile is shifted by one lane when written)
@@ -704,9 +761,9 @@ __global__ __launch_bounds__(NTW, 1) void dw_mfma_wgrad_multi_kernel(DwWgMultiPa
         Staged3<NIG3> sg0, sg1, sg2;
         fetch_unit3<4>(0, xb, p.ldx, p.H, p.W, p.dil, wi, tid, sx);
         fetch_unit3<4>(1, xb, p.ldx, p.H, p.W, p.dil, wi, tid, sx);
-        fetch_unit3<0>(0, gb0, p.ldg, p.H, p.W, p.dil, wi, tid, sg0);
-        fetch_unit3<0>(0, gb1, p.ldg, p.H, p.W, p.dil, wi, tid, sg1);
-        if (NG > 2) fetch_unit3<0>(0, gb2, p.ldg, p.H, p.W, p.dil, wi, tid, sg2);
+        fetch_unit3<0, NIG3, GLP>(0, gb0, gld, p.H, p.W, p.dil, wi, tid, sg0, gly);
+        fetch_unit3<0, NIG3, GLP>(0, gb1, gld, p.H, p.W, p.dil, wi, tid, sg1, gly);
+        if (NG > 2) fetch_unit3<0, NIG3, GLP>(0, gb2, gld, p.H, p.W, p.dil, wi, tid, sg2, gly);
         auto publish = [&]() __attribute__((always_inline)) {
             write_item3<4>(Xx, tid, sx);
             write_item3<0>(smem + X3BYTES, tid, sg0);
@@ -736,9 +793,9 @@ __global__ __launch_bounds__(NTW, 1) void dw_mfma_wgrad_multi_kernel(DwWgMultiPa
                     switch (R0 >> 2) {
                     case 0: fetch_unit3<4>(0, xb, p.ldx, p.H, p.W, p.dil, wn, tid, sx); break;
                     case 1: fetch_unit3<4>(1, xb, p.ldx, p.H, p.W, p.dil, wn, tid, sx); break;
-                    case 2: fetch_unit3<0>(0, gb0, p.ldg, p.H, p.W, p.dil, wn, tid, sg0); break;
-                    case 3: fetch_unit3<0>(0, gb1, p.ldg, p.H, p.W, p.dil, wn, tid, sg1); break;
-                    case 4: if (NG > 2) fetch_unit3<0>(0, gb2, p.ldg, p.H, p.W, p.dil, wn, tid, sg2); break;
+                    case 2: fetch_unit3<0, NIG3, GLP>(0, gb0, gld, p.H, p.W, p.dil, wn, tid, sg0, gly); break;
+                    case 3: fetch_unit3<0, NIG3, GLP>(0, gb1, gld, p.H, p.W, p.dil, wn, tid, sg1, gly); break;
+                    case 4: if (NG > 2) fetch_unit3<0, NIG3, GLP>(0, gb2, gld, p.H, p.W, p.dil, wn, tid, sg2, gly); break;
                     default: break;
                     }
                 }
@@ -769,9 +826,9 @@ __global__ __launch_bounds__(NTW, 1) void dw_mfma_wgrad_multi_kernel(DwWgMultiPa
             // short tiles: the row loop did not reach every fetch slot (slot k sits at row 4k)
             if (0 >= RV + 8) fetch_unit3<4>(0, xb, p.ldx, p.H, p.W, p.dil, wn, tid, sx);
             if (4 >= RV + 8) fetch_unit3<4>(1, xb, p.ldx, p.H, p.W, p.dil, wn, tid, sx);
-            if (8 >= RV + 8) fetch_unit3<0>(0, gb0, p.ldg, p.H, p.W, p.dil, wn, tid, sg0);
-            if (12 >= RV + 8) fetch_unit3<0>(0, gb1, p.ldg, p.H, p.W, p.dil, wn, tid, sg1);
-            if (NG > 2 && 16 >= RV + 8) fetch_unit3<0>(0, gb2, p.ldg, p.H, p.W, p.dil, wn, tid, sg2);
+            if (8 >= RV + 8) fetch_unit3<0, NIG3, GLP>(0, gb0, gld, p.H, p.W, p.dil, wn, tid, sg0, gly);
+            if (12 >= RV + 8) fetch_unit3<0, NIG3, GLP>(0, gb1, gld, p.H, p.W, p.dil, wn, tid, sg1, gly);
+            if (NG > 2 && 16 >= RV + 8) fetch_unit3<0, NIG3, GLP>(0, gb2, gld, p.H, p.W, p.dil, wn, tid, sg2, gly);
             __syncthreads();   // every wave is done reading the tiles
             publish();
             __syncthreads();
@@ -822,15 +879,57 @@ static void dw_mfma_split(int N, int C, int H, int W, int dil, int *nty, int *nt
     *nseg = (int)s;
 }
 
+static LpGeom lp_geom(const kd_dw_desc *d)
+{
+    LpGeom g;
+    g.Ly = (d->H + d->dil - 1) / d->dil;
+    g.Lx = (d->W + d->dil - 1) / d->dil;
+    g.rpi = d->dil * d->dil * g.Ly * g.Lx;
+    g.plane = (long long)kd_internal_lattice_rows(d->N, d->H, d->W, d->dil) * CG;
+    return g;
+}
+
 }  // namespace
+
+// Rows per plane of the lattice-planar layout (a multiple of 256: the 1x1 convs' M tile), 0 if the shape has none.
+long long kd_internal_lattice_rows(int N, int H, int W, int dil)
+{
+    if (N < 1 || H < 1 || W < 1 || dil < 1) return 0;
+    const long long Ly = (H + dil - 1) / dil, Lx = (W + dil - 1) / dil;
+    const long long rows = (long long)N * dil * dil * Ly * Lx;
+    return (rows + 255) / 256 * 256;
+}
+
+// Can the fan-out / summing / multi-gradient launches of `nb` branches run on lattice-planar intermediates?  (The matrix-core
+// kernels' own conditions, plus: no work item of the fan-out may be empty while its padded cells exist -- they are zeroed by the
+// item that owns them -- and a plane's rows must stay inside 32-bit buffer offsets.)
+int kd_internal_dw_lattice_ok(const kd_dw_desc *d, int nb)
+{
+    if (nb < 2 || nb > MAXB || d->dtype != KD_BF16 || d->k != 9 || d->C % CG != 0 || d->ldx % 8 != 0) return 0;
+    static int enabled = -1;
+    if (enabled < 0) {
+        const char *e = getenv("KDCC_DW_MFMA"), *l = getenv("KDCC_DW_LATTICE");   // A/B hooks: 0 = NHWC intermediates
+        enabled = !(e && e[0] == '0') && !(l && l[0] == '0');
+    }
+    if (!enabled) return 0;
+    const LpGeom g = lp_geom(d);
+    if ((long long)g.rpi * CG * 2 >= (long long)BUF_OOB || g.plane * (d->C / CG) > 0x7fffffffLL) return 0;
+    if ((long long)d->H * d->W * d->ldx * 2 >= (long long)BUF_OOB) return 0;
+    const int ry_last = g.Ly - (g.Ly - 1) / TLY * TLY, rx_last = g.Lx - (g.Lx - 1) / TLX * TLX;   // padded extent of the last tile row / column
+    const bool short_y = (d->H % d->dil) != 0, short_x = (d->W % d->dil) != 0;                     // some classes are one row / column shorter
+    if ((short_y && ry_last < 2) || (short_x && rx_last < 2)) return 0;
+    return 1;
+}
 
 // fan == 0: ys[0] = sum_{b < nb} dwconv(xs[b], ws[b]);  fan != 0: ys[b] = dwconv(xs[0], ws[b]) for b < nb -- on the matrix
 // cores.  Returns 1 if the MFMA path took the call, 0 if the shape is not eligible (caller falls back to the register kernel,
 // one launch per term), < 0 on a launch error.
+// lp != 0 (nb >= 2, kd_internal_dw_lattice_ok): the nb-side tensors -- the fan-out's outputs, the sum's inputs -- are lattice-planar.
 int kd_internal_dw_mfma_fwd_n(const kd_dw_desc *d, int nb, int fan, const void *const *xs, const float *const *ws, void *const *ys,
-                              const float *bias, const kd_dw_epilogue *ep, hipStream_t s)
+                              const float *bias, const kd_dw_epilogue *ep, hipStream_t s, int lp)
 {
     if (nb < 1 || nb > MAXB) return 0;
+    if (lp && !kd_internal_dw_lattice_ok(d, nb)) return 0;
     if (nb == 1) fan = 0;
     if (d->dtype != KD_BF16 || d->k != 9 || d->C % CG != 0 || d->ldx % 8 != 0 || d->ldy % 8 != 0) return 0;
     for (int b = 0; b < nb; ++b) {
@@ -858,6 +957,7 @@ int kd_internal_dw_mfma_fwd_n(const kd_dw_desc *d, int nb, int fan, const void *
     }
     { static int dbg = -1; if (dbg < 0) dbg = KD_TUNING_ENV_INT("KDCC_DW_DBG"); p.dbg = dbg; }   // phase ablations: tuning build only
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.dil = d->dil; p.ldx = d->ldx; p.ldy = d->ldy;
+    p.lp = lp_geom(d);
     dw_mfma_split(d->N, d->C, d->H, d->W, d->dil, &p.nty, &p.ntx, &p.nitems, &p.nseg);
     p.ncg = d->C / CG;
     if (p.nitems <= 0) return 0;
@@ -866,18 +966,23 @@ int kd_internal_dw_mfma_fwd_n(const kd_dw_desc *d, int nb, int fan, const void *
     const int lds = LDS_BYTES + (nb - 1) * WTBYTES;
     typedef void (*kern_t)(DwMfmaParams);
     const kern_t fn = nb == 1 ? dw_mfma_fwd_kernel<1, false>
+                    : lp ? (nb == 2 ? (fan ? dw_mfma_fwd_kernel<2, true, true> : dw_mfma_fwd_kernel<2, false, true>)
+                                    : (fan ? dw_mfma_fwd_kernel<3, true, true> : dw_mfma_fwd_kernel<3, false, true>))
                     : nb == 2 ? (fan ? dw_mfma_fwd_kernel<2, true> : dw_mfma_fwd_kernel<2, false>)
                               : (fan ? dw_mfma_fwd_kernel<3, true> : dw_mfma_fwd_kernel<3, false>);
-    static bool attr_set[2][MAXB + 1] = {};
-    if (!attr_set[fan ? 1 : 0][nb]) {
+    static bool attr_set[2][2][MAXB + 1] = {};
+    if (!attr_set[lp ? 1 : 0][fan ? 1 : 0][nb]) {
         if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             kd_set_error("kd_dwconv_fwd: cannot reserve %d B of LDS", lds);
             return KD_ERR_HIP;
         }
-        attr_set[fan ? 1 : 0][nb] = true;
+        attr_set[lp ? 1 : 0][fan ? 1 : 0][nb] = true;
     }
-    KD_NOTE_KERNEL(nb == 1 ? "dw_mfma_fwd_kernel<1,false>" : nb == 2 ? (fan ? "dw_mfma_fwd_kernel<2,true>" : "dw_mfma_fwd_kernel<2,false>")
-                           : (fan ? "dw_mfma_fwd_kernel<3,true>" : "dw_mfma_fwd_kernel<3,false>"));
+    KD_NOTE_KERNEL(nb == 1 ? "dw_mfma_fwd_kernel<1,false>"
+                   : lp ? (nb == 2 ? (fan ? "dw_mfma_fwd_kernel<2,true,lattice>" : "dw_mfma_fwd_kernel<2,false,lattice>")
+                                   : (fan ? "dw_mfma_fwd_kernel<3,true,lattice>" : "dw_mfma_fwd_kernel<3,false,lattice>"))
+                   : nb == 2 ? (fan ? "dw_mfma_fwd_kernel<2,true>" : "dw_mfma_fwd_kernel<2,false>")
+                             : (fan ? "dw_mfma_fwd_kernel<3,true>" : "dw_mfma_fwd_kernel<3,false>"));
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(NT), lds, s, p);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
@@ -890,7 +995,7 @@ int kd_internal_dw_mfma_fwd_n(const kd_dw_desc *d, int nb, int fan, const void *
 int kd_internal_dw_mfma_fwd(const kd_dw_desc *d, const void *x, const float *w_taps, const float *bias,
                             const kd_dw_epilogue *ep, void *y, hipStream_t s)
 {
-    return kd_internal_dw_mfma_fwd_n(d, 1, 0, &x, &w_taps, &y, bias, ep, s);
+    return kd_internal_dw_mfma_fwd_n(d, 1, 0, &x, &w_taps, &y, bias, ep, s, 0);
 }
 
 static bool dw_mfma_wgrad_eligible(const kd_dw_desc *d, const void *x, const void *dy, int ld_dy)
@@ -958,9 +1063,11 @@ int kd_internal_dw_mfma_wgrad_multi_slabs(const kd_dw_desc *d, int n)
 }
 
 // 1 = partial sums of every branch written to `part` ([branch][slab][81][C]), 0 = not eligible, < 0 = error.
-int kd_internal_dw_mfma_wgrad_multi(const kd_dw_desc *d, int n, const void *x, const void *const *dys, int ld_dy, float *part, hipStream_t s)
+// lp != 0: the gradients dys[] are lattice-planar (ld_dy is ignored)
+int kd_internal_dw_mfma_wgrad_multi(const kd_dw_desc *d, int n, const void *x, const void *const *dys, int ld_dy, float *part, hipStream_t s, int lp)
 {
     if (n < 2 || n > MAXG) return 0;
+    if (lp) { if (!kd_internal_dw_lattice_ok(d, n)) return 0; ld_dy = d->C; }
     for (int b = 0; b < n; ++b)
         if (!dw_mfma_wgrad_eligible(d, x, dys[b], ld_dy)) return 0;
     DwWgMultiParams p;
@@ -968,6 +1075,7 @@ int kd_internal_dw_mfma_wgrad_multi(const kd_dw_desc *d, int n, const void *x, c
     for (int b = 0; b < MAXG; ++b) p.g[b] = (const bf16_t *)dys[b < n ? b : 0];
     p.part = part;
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.dil = d->dil; p.ldx = d->ldx; p.ldg = ld_dy;
+    p.lp = lp_geom(d);
     dw_mfma_split3(d->N, d->C, d->H, d->W, d->dil, &p.nty, &p.ntx, &p.nitems, &p.nseg);
     p.ncg = d->C / CG;
     p.nslabs = d->N * p.nseg;
@@ -975,16 +1083,18 @@ int kd_internal_dw_mfma_wgrad_multi(const kd_dw_desc *d, int n, const void *x, c
     const long long blocks = (long long)d->N * p.ncg * p.nseg;
     if (blocks > 0x7fffffffLL) return 0;
     typedef void (*kern_t)(DwWgMultiParams);
-    const kern_t fn = n == 2 ? dw_mfma_wgrad_multi_kernel<2> : dw_mfma_wgrad_multi_kernel<3>;
-    static bool attr_set[MAXG + 1] = {};
-    if (!attr_set[n]) {
+    const kern_t fn = lp ? (n == 2 ? dw_mfma_wgrad_multi_kernel<2, true> : dw_mfma_wgrad_multi_kernel<3, true>)
+                         : (n == 2 ? dw_mfma_wgrad_multi_kernel<2> : dw_mfma_wgrad_multi_kernel<3>);
+    static bool attr_set[2][MAXG + 1] = {};
+    if (!attr_set[lp ? 1 : 0][n]) {
         if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS) != hipSuccess) {
             kd_set_error("kd_dwconv_wgrad_multi: cannot reserve %d B of LDS", WG3_LDS);
             return KD_ERR_HIP;
         }
-        attr_set[n] = true;
+        attr_set[lp ? 1 : 0][n] = true;
     }
-    KD_NOTE_KERNEL(n == 2 ? "dw_mfma_wgrad_multi_kernel<2>" : "dw_mfma_wgrad_multi_kernel<3>");
+    KD_NOTE_KERNEL(lp ? (n == 2 ? "dw_mfma_wgrad_multi_kernel<2,lattice>" : "dw_mfma_wgrad_multi_kernel<3,lattice>")
+                      : (n == 2 ? "dw_mfma_wgrad_multi_kernel<2>" : "dw_mfma_wgrad_multi_kernel<3>"));
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(NTW), WG3_LDS, s, p);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) {

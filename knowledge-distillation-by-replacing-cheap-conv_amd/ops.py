@@ -395,6 +395,149 @@ def dwconv_wgrad_multi(x, dys, dws, k, pad, dil, accumulate=False):
     return dws
 
 
+# ------------------------------------------------------------------ lattice-planar intermediates (include/kdcc.h)
+class Lattice:
+    """An (N,H,W,C) bf16 tensor in the lattice-planar layout of dilation `dil`: `t` is (C/16, rows, 16) -- the depthwise outputs of
+    the replaced ASPP branches and their gradients, which only the depthwise kernels and the 1x1 convs next to them read
+    (depthwise_separable_conv.py:11-13 under deeplabv3.py:64-75).  Not an image any more: `to_nhwc()` is for tests."""
+
+    def __init__(self, N, H, W, Cc, dil, dtype=torch.bfloat16, device="cuda", t=None):
+        self.N, self.H, self.W, self.C, self.dil = N, H, W, Cc, dil
+        self.rows = lattice_rows(N, H, W, dil)
+        if Cc % 16:
+            raise ValueError("Lattice: channels must be a multiple of 16")
+        self.t = t if t is not None else torch.empty((Cc // 16, self.rows, 16), dtype=dtype, device=device)
+        if tuple(self.t.shape) != (Cc // 16, self.rows, 16) or not self.t.is_contiguous():
+            raise ValueError("Lattice: bad storage")
+        used = N * dil * dil * (-(-H // dil)) * (-(-W // dil))
+        if t is None and used < self.rows:
+            self.t[:, used:].zero_()          # the tail rows of every plane hold zeros (nobody else writes them)
+
+    dtype = property(lambda self: self.t.dtype)
+    device = property(lambda self: self.t.device)
+    shape = property(lambda self: (self.N, self.H, self.W, self.C))
+    plane = property(lambda self: self.rows * 16)
+
+    def same_geometry(self, o):
+        return (self.N, self.H, self.W, self.C, self.dil, self.dtype) == (o.N, o.H, o.W, o.C, o.dil, o.dtype)
+
+    def to_nhwc(self):
+        """Image-order copy (tests / debugging): plain torch indexing, not a kernel."""
+        rows = self.t.permute(1, 0, 2).reshape(self.rows, self.C)
+        out = torch.empty((self.N, self.H, self.W, self.C), dtype=self.dtype, device=self.device)
+        return lattice_to_image(rows, out, self.dil)
+
+
+def lattice_rows(N, H, W, dil):
+    return int(_lib.lib().kd_lattice_rows(N, H, W, dil))
+
+
+def dwconv_lattice_ok(x, n, k, pad, dil):
+    """Can n (2, 3) depthwise convs of this geometry reading / summing into x-shaped tensors keep lattice-planar intermediates?"""
+    if not x.is_cuda or x.dtype != torch.bfloat16:
+        return False
+    return bool(_lib.lib().kd_dwconv_lattice_ok(C.byref(_dw_desc(x, k, pad, dil)), n))
+
+
+def image_to_lattice(img, dil, out=None):
+    """(N,H,W,C) view -> dense [rows][C] in lattice row order (zero rows where a lattice cell has no pixel)."""
+    _need_cuda(img, out)
+    N, H, W, Cc = img.shape
+    rows = lattice_rows(N, H, W, dil)
+    if out is None:
+        out = torch.empty((rows, Cc), dtype=img.dtype, device=img.device)
+    if tuple(out.shape) != (rows, Cc) or out.dtype != img.dtype or out.stride(1) != 1:
+        raise ValueError("image_to_lattice: bad output")
+    e0 = _prof_start()
+    check(_lib.lib().kd_lattice_rows_move(dt_of(img), N, H, W, Cc, dil, _ptr(img), nhwc_ld(img), _ptr(out), out.stride(0), 1, stream_ptr()),
+          "kd_lattice_rows_move")
+    _prof_stop(e0, "plumbing", _nbytes(img, out), f"rows to lattice order {H}x{W} C{Cc}")
+    return out
+
+
+def lattice_to_image(rows, img, dil):
+    """Dense [rows][C] in lattice row order -> the (N,H,W,C) view `img`."""
+    _need_cuda(img, rows)
+    N, H, W, Cc = img.shape
+    if tuple(rows.shape) != (lattice_rows(N, H, W, dil), Cc) or rows.dtype != img.dtype or rows.stride(1) != 1:
+        raise ValueError("lattice_to_image: bad input")
+    e0 = _prof_start()
+    check(_lib.lib().kd_lattice_rows_move(dt_of(img), N, H, W, Cc, dil, _ptr(img), nhwc_ld(img), _ptr(rows), rows.stride(0), 0, stream_ptr()),
+          "kd_lattice_rows_move")
+    _prof_stop(e0, "plumbing", _nbytes(img, rows), f"rows to image order {H}x{W} C{Cc}")
+    return img
+
+
+def dwconv_fanout_lattice(x, w_taps, k, pad, dil, outs=None):
+    """dwconv_fanout with lattice-planar outputs (n = 2, 3; dwconv_lattice_ok)."""
+    w_taps = list(w_taps)
+    _need_cuda(x, *w_taps)
+    N, H, W, Cc = x.shape
+    for w in w_taps:
+        if tuple(w.shape) != (k * k, Cc) or w.dtype != torch.float32 or not w.is_contiguous():
+            raise ValueError("dwconv_fanout_lattice: w_taps must be contiguous fp32 [k*k][C]")
+    if outs is None:
+        outs = [Lattice(N, H, W, Cc, dil, x.dtype, x.device) for _ in w_taps]
+    outs = list(outs)
+    if len(outs) != len(w_taps) or any(o.shape != (N, H, W, Cc) or o.dil != dil or o.dtype != x.dtype for o in outs):
+        raise ValueError("dwconv_fanout_lattice: need one matching Lattice per tap table")
+    d = _dw_desc(x, k, pad, dil)
+    n = len(outs)
+    wp = (C.c_void_p * n)(*[_ptr(w) for w in w_taps])
+    yp = (C.c_void_p * n)(*[_ptr(o.t) for o in outs])
+    e0 = _prof_start()
+    check(_lib.lib().kd_dwconv_fwd_fanout_lattice(C.byref(d), n, _ptr(x), wp, yp, stream_ptr()), "kd_dwconv_fwd_fanout_lattice")
+    _prof_stop(e0, "depthwise", x.numel() * x.element_size() * (1 + n), f"dw fan-out of {n} {k}x{k} d{dil} {H}x{W} C{Cc} [lattice]")
+    return outs
+
+
+def dwconv_sum_lattice(xs, w_taps, k, pad, dil, out=None):
+    """dwconv_sum over lattice-planar inputs (n = 2, 3); the sum is an NHWC tensor."""
+    xs, w_taps = list(xs), list(w_taps)
+    if len(xs) != len(w_taps) or not xs or any(not xs[0].same_geometry(x) for x in xs) or xs[0].dil != dil:
+        raise ValueError("dwconv_sum_lattice: need matching Lattice inputs, one tap table each")
+    N, H, W, Cc = xs[0].shape
+    _need_cuda(*[x.t for x in xs], *w_taps, out)
+    for w in w_taps:
+        if tuple(w.shape) != (k * k, Cc) or w.dtype != torch.float32 or not w.is_contiguous():
+            raise ValueError("dwconv_sum_lattice: w_taps must be contiguous fp32 [k*k][C]")
+    if out is None:
+        out = torch.empty((N, H, W, Cc), dtype=xs[0].dtype, device=xs[0].device)
+    if tuple(out.shape) != (N, H, W, Cc) or out.dtype != xs[0].dtype:
+        raise ValueError("dwconv_sum_lattice: bad output view")
+    d = DwDesc(dt_of(out), N, H, W, Cc, k, pad, dil, Cc, nhwc_ld(out))
+    n = len(xs)
+    xp = (C.c_void_p * n)(*[_ptr(x.t) for x in xs])
+    wp = (C.c_void_p * n)(*[_ptr(w) for w in w_taps])
+    e0 = _prof_start()
+    check(_lib.lib().kd_dwconv_fwd_sum_lattice(C.byref(d), n, xp, wp, _ptr(out), stream_ptr()), "kd_dwconv_fwd_sum_lattice")
+    _prof_stop(e0, "depthwise", out.numel() * out.element_size() * (1 + n), f"dw sum of {n} {k}x{k} d{dil} {H}x{W} C{Cc} [lattice]")
+    return out
+
+
+def dwconv_wgrad_multi_lattice(x, dys, dws, k, pad, dil, accumulate=False):
+    """dwconv_wgrad_multi with lattice-planar gradients dys (n = 2, 3)."""
+    dys, dws = list(dys), list(dws)
+    N, H, W, Cc = x.shape
+    if len(dys) != len(dws) or not dys or any(dy.shape != (N, H, W, Cc) or dy.dil != dil or dy.dtype != x.dtype for dy in dys):
+        raise ValueError("dwconv_wgrad_multi_lattice: need one matching Lattice gradient per weight gradient")
+    _need_cuda(x, *[dy.t for dy in dys], *dws)
+    for dw in dws:
+        if dw.dtype != torch.float32 or dw.numel() != Cc * k * k or not dw.is_contiguous():
+            raise ValueError("dwconv_wgrad_multi_lattice: dw must be contiguous fp32 (C,1,k,k)")
+    d = _dw_desc(x, k, pad, dil)
+    n = len(dys)
+    need = _lib.lib().kd_dwconv_wgrad_multi_workspace(C.byref(d), n)
+    workspace = _ws(need, x.device)
+    yp = (C.c_void_p * n)(*[_ptr(t.t) for t in dys])
+    wp = (C.c_void_p * n)(*[_ptr(t) for t in dws])
+    e0 = _prof_start()
+    check(_lib.lib().kd_dwconv_wgrad_multi_lattice(C.byref(d), n, _ptr(x), yp, wp, int(accumulate), _ptr(workspace), need, stream_ptr()),
+          "kd_dwconv_wgrad_multi_lattice")
+    _prof_stop(e0, "depthwise", x.numel() * x.element_size() * (1 + n), f"dw wgrad of {n} {k}x{k} d{dil} {H}x{W} C{Cc} [lattice]")
+    return dws
+
+
 # ------------------------------------------------------------------------------ trunk plumbing
 def stem_conv(x_nchw, w, dtype):
     """(N,3,H,W) fp32 NCHW batch + (64,3,3,3) fp32 weight -> (N,H,W,64) NHWC."""

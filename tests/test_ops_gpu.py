@@ -469,6 +469,114 @@ def test_dwconv_fanout(K, dt, case):
         assert torch.equal(o, K.dwconv(xd, taps[i], k, p, d)), f"fan-out output {i} differs from the single launch"
 
 
+LATTICE_CASES = [
+    # N, H, W, C, k, pad, dil, branches -- bf16 only (the lattice-planar intermediates of the replaced ASPP branches)
+    (2, 24, 32, 16, 9, 20, 5, 3),        # H, W not multiples of dil: classes one row / column shorter, padded cells
+    (1, 128, 256, 32, 9, 20, 5, 3),      # the ASPP map itself: 26 x 52 lattice, one tile per class (last row / column padded)
+    (1, 140, 270, 32, 9, 20, 5, 3),      # several tiles per class with real halos, ragged last tiles
+    (2, 40, 70, 16, 9, 4, 1, 2),         # two branches, dil 1: one class, many tiles, nothing padded
+    (2, 64, 128, 48, 9, 20, 5, 2),       # three channel groups (three planes), two branches
+    (3, 65, 130, 16, 9, 20, 5, 3),       # H, W multiples of dil: no padded cells; tail rows of the plane only
+]
+
+
+def _lattice_of(K, a, dil):
+    """NCHW numpy -> ops.Lattice through the row-move kernel (image order -> lattice order), plane by plane."""
+    t = dev_nhwc(a, "bf16")
+    N, H, W, Cc = t.shape
+    rows = K.image_to_lattice(t, dil)
+    return K.Lattice(N, H, W, Cc, dil, t=rows.reshape(rows.shape[0], Cc // 16, 16).permute(1, 0, 2).contiguous())
+
+
+@pytest.mark.parametrize("case", LATTICE_CASES)
+def test_lattice_rows_round_trip(K, case):
+    """kd_lattice_rows_move: image order -> lattice order -> image order is the identity; rows of cells without a pixel are zero;
+    the row of pixel (n, y, x) is the one include/kdcc.h states."""
+    N, H, W, Cc, k, p, d, n = case
+    x = q(rnd(N, Cc, H, W), "bf16")
+    xd = dev_nhwc(x, "bf16")
+    rows = K.image_to_lattice(xd, d)
+    assert rows.shape[0] == K.lattice_rows(N, H, W, d) and rows.shape[0] % 256 == 0
+    Ly, Lx = -(-H // d), -(-W // d)
+    r = rows.cpu().float().numpy()
+    expect = np.zeros_like(r)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    for i in range(N):
+        idx = ((i * d * d + (yy % d) * d + (xx % d)) * Ly + yy // d) * Lx + xx // d
+        expect[idx.reshape(-1)] = x[i].reshape(Cc, -1).T
+    assert np.array_equal(r, expect), "lattice row order / zero padding"
+    back = torch.full_like(xd, 7.0)
+    K.lattice_to_image(rows, back, d)
+    assert torch.equal(back, xd)
+
+
+@pytest.mark.parametrize("case", LATTICE_CASES)
+def test_dwconv_fanout_lattice(K, case):
+    """kd_dwconv_fwd_fanout_lattice: the same values as kd_dwconv_fwd_fanout, bit for bit, in the lattice-planar layout -- padded
+    cells and tail rows zero -- and each output against the oracle."""
+    N, H, W, Cc, k, p, d, n = case
+    dt = "bf16"
+    x = q(rnd(N, Cc, H, W), dt)
+    ws = [rnd(Cc, 1, k, k, scale=1.0 / k) for _ in range(n)]
+    taps = [K.pack_dw_weight(torch.from_numpy(w).cuda()) for w in ws]
+    xd = dev_nhwc(x, dt)
+    assert K.dwconv_lattice_ok(xd, n, k, p, d)
+    outs = [K.Lattice(N, H, W, Cc, d) for _ in range(n)]
+    for o in outs:
+        o.t.fill_(3.0)                 # stale data everywhere: the kernel must zero the padded cells itself
+        used = N * d * d * (-(-H // d)) * (-(-W // d))
+        o.t[:, used:].zero_()
+    K.dwconv_fanout_lattice(xd, taps, k, p, d, outs=outs)
+    selected(f"dw_mfma_fwd_kernel<{n},true,lattice>", f"dw fan-out lattice {case}")
+    plain = K.dwconv_fanout(xd, taps, k, p, d)
+    for i, (o, w) in enumerate(zip(outs, ws)):
+        assert torch.equal(o.to_nhwc(), plain[i]), f"lattice fan-out output {i} differs from the NHWC launch"
+        want = K.image_to_lattice(plain[i], d)
+        got = o.t.permute(1, 0, 2).reshape(o.rows, Cc)
+        assert torch.equal(got, want), f"lattice fan-out output {i}: padded cells / tail rows must be zero"
+        assert_close(host_nchw(o.to_nhwc()), orc.conv2d_fwd(x, w, pad=p, dil=d, groups=Cc), dt, f"dw fan-out lattice {i}")
+
+
+@pytest.mark.parametrize("case", LATTICE_CASES)
+def test_dwconv_sum_lattice(K, case):
+    """kd_dwconv_fwd_sum_lattice: bit-identical to kd_dwconv_fwd_sum on the same values, and against the oracle's summed dgrads."""
+    N, H, W, Cc, k, p, d, n = case
+    dt = "bf16"
+    gs = [q(rnd(N, Cc, H, W), dt) for _ in range(n)]
+    ws = [rnd(Cc, 1, k, k, scale=1.0 / k) for _ in range(n)]
+    taps = [K.pack_dw_weight(torch.from_numpy(w).cuda(), flip=True) for w in ws]
+    lat = [_lattice_of(K, g, d) for g in gs]
+    out = K.dwconv_sum_lattice(lat, taps, k, d * (k - 1) - p, d)
+    selected(f"dw_mfma_fwd_kernel<{n},false,lattice>", f"dw sum lattice {case}")
+    plain = K.dwconv_sum([dev_nhwc(g, dt) for g in gs], taps, k, d * (k - 1) - p, d)
+    assert torch.equal(out, plain), "lattice sum differs from the NHWC launch"
+    ref = sum(orc.conv2d_dgrad(g, w, g.shape, pad=p, dil=d, groups=Cc) for g, w in zip(gs, ws))
+    assert_close(host_nchw(out), ref, dt, f"dw sum lattice of {n}")
+
+
+@pytest.mark.parametrize("case", LATTICE_CASES)
+def test_dwconv_wgrad_multi_lattice(K, case):
+    """kd_dwconv_wgrad_multi_lattice: bit-identical to kd_dwconv_wgrad_multi, each branch against the oracle, accumulate too."""
+    N, H, W, Cc, k, p, d, n = case
+    dt = "bf16"
+    x = q(rnd(N, Cc, H, W), dt)
+    gs = [q(rnd(N, Cc, H, W), dt) for _ in range(n)]
+    xd = dev_nhwc(x, dt)
+    lat = [_lattice_of(K, g, d) for g in gs]
+    dws = [torch.full((Cc, 1, k, k), 5.0, device="cuda") for _ in range(n)]
+    K.dwconv_wgrad_multi_lattice(xd, lat, dws, k, p, d)
+    selected(f"dw_mfma_wgrad_multi_kernel<{n},lattice>", f"dw wgrad lattice {case}")
+    plain = [torch.empty((Cc, 1, k, k), device="cuda") for _ in range(n)]
+    K.dwconv_wgrad_multi(xd, [dev_nhwc(g, dt) for g in gs], plain, k, p, d)
+    refs = [orc.conv2d_wgrad(x, g, (Cc, 1, k, k), pad=p, dil=d, groups=Cc) for g in gs]
+    for i in range(n):
+        assert torch.equal(dws[i], plain[i]), f"lattice weight gradient {i} differs from the NHWC launch"
+        assert_close(dws[i].cpu().numpy(), refs[i], dt, f"dw wgrad lattice, branch {i}")
+    K.dwconv_wgrad_multi_lattice(xd, lat, dws, k, p, d, accumulate=True)
+    for i in range(n):
+        assert_close(dws[i].cpu().numpy(), 2 * refs[i], dt, f"dw wgrad lattice accumulate, branch {i}")
+
+
 @pytest.mark.parametrize("case", [(2, 24, 32, 16, 5), (1, 131, 261, 32, 5), (1, 30, 60, 16, 2)])
 def test_dwconv_epilogue_bf16(K, case):
     """bias + res_pre + BN/ReLU mask + res_post through the depthwise epilogue, multi-tile shapes included."""
