@@ -252,11 +252,13 @@ def class_rooflines(prof, steps, peak_tflops):
 
 
 def run_config(a, device, rank, world, plan_name=None, mode=None, arch=None, hint_loss="mse", steps=None, warmup=None,
-               batch_sweep=True):
+               batch_sweep=True, dtype_name=None, batch=None):
     """Build one configuration, run `warmup` untimed + `steps` timed KD train steps, return (record, model, cpu_sd, plan)."""
     from kdcc_amd import ops, parallel
     plan_name, mode, arch = plan_name or a.plan, mode or a.mode, arch or a.arch
     steps, warmup = steps or a.steps, a.warmup if warmup is None else warmup
+    if dtype_name is not None or batch is not None:       # a sub-record in another storage type / batch (the fp32 parity path)
+        a = argparse.Namespace(**{**vars(a), "dtype": dtype_name or a.dtype, "batch": batch or a.batch})
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     plan = PLANS[plan_name]
     model, crit, opt, cpu_sd = build(plan, dtype, device, mode=mode, arch=arch, hint_loss=hint_loss)
@@ -390,7 +392,7 @@ def run_config(a, device, rank, world, plan_name=None, mode=None, arch=None, hin
             "roofline": {"bound": "mfma",
                          "kernel": "kd_conv2d_fwd: conv_row_lw_kernel + conv_igemm_persist_kernel + conv_row_tall_kernel + conv_igemm_row_kernel "
                                    "+ conv_igemm_kernel (dense conv fwd + dgrad, student" + (" + teacher)" if a.teacher == "hip" else ")"),
-                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_src": traffic_src,
                          "traffic_note": ("mean HBM bytes per conv launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate "
                                           f"passes of this command ({traffic_src}); mean algorithmic FLOP per launch = "
                                           "algorithmic_tflop_per_step / launches_per_step") if traffic is not None else
@@ -430,7 +432,7 @@ def compact_record(res, full_path=None):
                                             "teacher_backend", "share_frozen_prefix", "replicas_identical_after_run")}}
     out["roofline"] = {"bound": rf["bound"], "kernel": "kd_conv2d_fwd (dense conv fwd + dgrad: conv_row_lw / conv_igemm_persist / "
                                                        "conv_row_tall / one-tile kernels)",
-                       **{k: _r(rf[k]) for k in ("achieved", "peak", "unit", "frac", "traffic", "launches_per_step",
+                       **{k: _r(rf.get(k)) for k in ("achieved", "peak", "unit", "frac", "traffic", "traffic_src", "launches_per_step",
                                                  "ms_per_step_in_kernel", "algorithmic_tflop_per_step")},
                        "classes": {n: [_r(c["ms_per_step"], 3), _r(c["frac"], 3)] for n, c in rf["classes"].items()},
                        "classes_fmt": "[ms_per_step, frac of its roof (mfma 2500 TFLOP/s | hbm 8000 GB/s)]"}
@@ -443,7 +445,7 @@ def compact_record(res, full_path=None):
         out["cpu_baseline"]["sample"] = ("one measured 1024x2048 KD step of oracle/net_ref.py (fp32 torch CPU ops), 1 image"
                                          if "step_1024x2048_s" in cb else cb.get("sample", "")[:160])
     if res.get("sub_records"):
-        out["sub_records"] = {n: {"value": _r(r["value"]), "ms_per_step": _r(r["ms_per_step"]), "frac": _r(r["roofline"]["frac"], 3),
+        out["sub_records"] = {n: {"value": _r(r["value"]), "ms_per_step": _r(r["ms_per_step"]), "dtype": r.get("dtype"), "frac": _r(r["roofline"]["frac"], 3),
                                   "traffic": _r(r["roofline"].get("traffic")),
                                   "wgrad_frac": _r(r["dense_wgrad"]["frac"], 3) if r.get("dense_wgrad") else None}
                               for n, r in res["sub_records"].items()}
@@ -462,6 +464,9 @@ SUB_RECORDS = (
     ("modeB", dict(mode="B"), "north-star mode B: loss = KLDiv + hints, all 92.1 M student parameters trainable (37.74 TFLOP/img)"),
     ("gscnn_P86", dict(arch="gscnn", plan_name="P86"), "BASELINE config 5: Gated-SCNN student, cfg/cityscapes/51M_gscnn_all.json plan"),
     ("weighted_hint", dict(hint_loss="weighted"), "BASELINE config 4: WeightedHintMSELoss feature-hint KD, filter_weight = rand(C) (rand:7)"),
+    ("f32_parity", dict(dtype_name="f32", batch=2, steps=2, warmup=1),
+     "BASELINE.md section 4 'fp32 parity mode separately': the same P92 step with fp32 storage and fp32 MFMA (the path the 1e-3 parity tests run), "
+     "2 images, 1 warm-up + 2 timed steps; frac against the 157.3 TFLOP/s fp32 matrix peak"),
 )
 
 
@@ -534,11 +539,12 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             print(f"[bench] sub-record {name}: {what} ...", file=sys.stderr, flush=True)
-            r, m, _, _ = run_config(a, device, rank, world, steps=8, warmup=2, batch_sweep=False, **kw)
+            r, m, _, _ = run_config(a, device, rank, world, **{"steps": 8, "warmup": 2, "batch_sweep": False, **kw})
             del m
             keep = {k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "dense_wgrad", "losses")}
             keep["what"] = what
             keep["config"] = {k: r["config"][k] for k in ("plan", "mode", "arch", "hint_loss", "per_gpu_batch")}
+            keep["roofline"]["peak_tflops"] = r["roofline"]["peak"]
             subs[name] = keep
         res["sub_records"] = subs
     if rank == 0:

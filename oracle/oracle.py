@@ -33,6 +33,8 @@ def lib():
         _lib.orc_mse.restype = ctypes.c_double
         _lib.orc_whmse.restype = ctypes.c_double
         _lib.orc_ce2d.restype = ctypes.c_double
+        _lib.orc_mse_sum.restype = ctypes.c_double
+        _lib.orc_ce2d_w.restype = ctypes.c_double
     return _lib
 
 
@@ -161,6 +163,14 @@ def mse(s, t, num_classes=19, want_grad=True):
     return loss, g
 
 
+def mse_sum(s, t, num_classes=19, want_grad=True):
+    """MSELoss(reduction='sum', num_classes)."""
+    s, t = _c(s), _c(t)
+    g = np.empty_like(s) if want_grad else None
+    loss = lib().orc_mse_sum(_p(s), _p(t), _p(g), ctypes.c_double(num_classes), ctypes.c_size_t(s.size))
+    return loss, g
+
+
 def whmse(s, t, w, want_grad=True):
     s, N, C, HW = _nchw3(s)
     t, w = _c(t), _c(w)
@@ -173,6 +183,16 @@ def ce2d(x, target, ignore_index=255):
     x, N, C, HW = _nchw3(x)
     tgt = np.ascontiguousarray(target, dtype=np.int64)
     return lib().orc_ce2d(_p(x), tgt.ctypes.data_as(_i64), ignore_index, N, C, HW)
+
+
+def ce2d_weighted(x, target, weight=None, size_average=True, ignore_index=255, want_grad=True):
+    """CrossEntropyLoss2d(weight, size_average, ignore_index): (loss, grad_x)."""
+    x, N, C, HW = _nchw3(x)
+    tgt = np.ascontiguousarray(target, dtype=np.int64)
+    w = None if weight is None else _c(weight)
+    g = np.empty_like(x) if want_grad else None
+    loss = lib().orc_ce2d_w(_p(x), tgt.ctypes.data_as(_i64), _p(w), int(bool(size_average)), ignore_index, N, C, HW, _p(g))
+    return loss, g
 
 
 def confusion(x, target, ignore_index=255, conf=None):

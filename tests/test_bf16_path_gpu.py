@@ -51,6 +51,21 @@ def _rel_l2(got, ref):
     return float((got - ref).norm() / ref.norm().clamp_min(1e-30))
 
 
+def _worst_tile(got, ref, px=256, ch=256):
+    """Worst relative L2 error over the conv kernels' output tiles of an NCHW-logical tensor: blocks of `px` consecutive pixels of one
+    image row x `ch` channels (256 x 256 = the workgroup tile of the persistent kernels; a narrower tensor is one channel block).  A
+    global norm averages one wrong tile away (1 of ~2000 at these sizes moves the global relative L2 by 2 %); here it is the maximum.
+    The denominator is the tile's own reference norm, floored at a quarter of the mean tile norm (near-empty tiles)."""
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    N, Cc, H, W = ref.shape
+    px, ch = min(px, W), min(ch, Cc)
+    Wt, Ct = W // px * px, Cc // ch * ch
+    e = ((got - ref)[:, :Ct, :, :Wt].double() ** 2).reshape(N, Ct // ch, ch, H, Wt // px, px).sum(dim=(2, 5))
+    r = (ref[:, :Ct, :, :Wt].double() ** 2).reshape(N, Ct // ch, ch, H, Wt // px, px).sum(dim=(2, 5))
+    floor = r.mean() / 16.0
+    return float((e / torch.maximum(r, floor)).max().sqrt())
+
+
 def _grad_report(model, ref_grads, names=None):
     """[(name, cosine, norm ratio)] of every trainable tensor's gradient against the fp32 oracle's."""
     rows = []
@@ -109,9 +124,16 @@ def test_bf16_p92_step_on_the_shipped_kernels_vs_network_oracle():
     for i, (s, t) in enumerate(zip(model.student_hidden_outputs, model.teacher_hidden_outputs)):
         errs[f"student hint {i}"] = _rel_l2(s, r["student_hints"][i])
         errs[f"teacher hint {i}"] = _rel_l2(t, r["teacher_hints"][i])
+    tiles = {"student logits": _worst_tile(out_st, r["student_logits"], px=512), "teacher logits": _worst_tile(out_tc, r["teacher_logits"], px=512)}
+    for i, (s, t) in enumerate(zip(model.student_hidden_outputs, model.teacher_hidden_outputs)):
+        tiles[f"student hint {i}"] = _worst_tile(s, r["student_hints"][i])
+        tiles[f"teacher hint {i}"] = _worst_tile(t, r["teacher_hints"][i])
     rows = _grad_report(model, r["grads"])
-    print("bf16 P92 2x512x2048 vs net_ref:", {k: f"{v:.2e}" for k, v in errs.items()},
+    print("bf16 P92 2x512x2048 vs net_ref:", {k: f"{v:.2e}" for k, v in errs.items()}, "worst tile", {k: f"{v:.2e}" for k, v in tiles.items()},
           "hint", hint.item(), r["hint_loss"].item(), [(n, f"{c:.5f}", f"{q:.4f}") for n, c, q in rows])
+    # ... and no single 256-pixel x 256-channel tile may stand out: a tile that lost one 64-channel k-step of K = 4608 is off by 12 %,
+    # a stale or unwritten one by 100 %; measured: the worst tile is within 1.2x of the global figure (logits 5e-3, hints 1.2e-2); bars 1.5x the global ones
+    assert tiles["student logits"] < 1.5e-2 and tiles["teacher logits"] < 1.5e-2 and max(tiles.values()) < 3e-2, tiles
     # measured (round 3): logits 4e-3, hints 7e-3 .. 1e-2 relative L2, hint loss 8e-4, gradient cosines >= 0.99997, norms within
     # 0.13 % -- the bars leave 2-3x of that
     assert errs["student logits"] < 1e-2 and errs["teacher logits"] < 1e-2 and max(errs.values()) < 2e-2, errs
@@ -132,9 +154,14 @@ def _check_step(model, r, hint, kd, out_st, out_tc, n_grads, what):
     for i, (s, t) in enumerate(zip(model.student_hidden_outputs, model.teacher_hidden_outputs)):
         errs[f"student hint {i}"] = _rel_l2(s, r["student_hints"][i])
         errs[f"teacher hint {i}"] = _rel_l2(t, r["teacher_hints"][i])
+    tiles = {"student logits": _worst_tile(out_st, r["student_logits"], px=512), "teacher logits": _worst_tile(out_tc, r["teacher_logits"], px=512)}
+    for i, (s, t) in enumerate(zip(model.student_hidden_outputs, model.teacher_hidden_outputs)):
+        tiles[f"student hint {i}"] = _worst_tile(s, r["student_hints"][i])
+        tiles[f"teacher hint {i}"] = _worst_tile(t, r["teacher_hints"][i])
     rows = _grad_report(model, r["grads"])
-    print(what, {k: f"{v:.2e}" for k, v in errs.items()}, "hint", hint.item(), r["hint_loss"].item(),
-          "worst gradients", sorted(rows, key=lambda t: t[1])[:3])
+    print(what, {k: f"{v:.2e}" for k, v in errs.items()}, "worst tile", {k: f"{v:.2e}" for k, v in tiles.items()}, "hint", hint.item(),
+          r["hint_loss"].item(), "worst gradients", sorted(rows, key=lambda t: t[1])[:3])
+    assert tiles["student logits"] < 1.5e-2 and tiles["teacher logits"] < 1.5e-2 and max(tiles.values()) < 3e-2, tiles   # (see the P92 test)
     # the bars of the P92 test: logits 1e-2, hints 2e-2 relative L2, hint loss 5e-3, gradient cosine 0.9995, norm within 1 %
     assert errs["student logits"] < 1e-2 and errs["teacher logits"] < 1e-2 and max(errs.values()) < 2e-2, errs
     assert abs(hint.item() - r["hint_loss"].item()) <= 5e-3 * abs(r["hint_loss"].item())

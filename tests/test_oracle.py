@@ -46,6 +46,37 @@ def test_ce_and_anchors(golden):
     close(orc.mse(g["anchor.x"], g["anchor.t"], 1000)[0], 2022.908, rtol=1e-5)
 
 
+def test_loss_constructor_variants(golden):
+    """MSELoss(reduction='sum'), CrossEntropyLoss2d(weight, size_average): the oracle against the reference's own values and gradients."""
+    g = golden("variants")
+    loss, grad = orc.mse_sum(g["mse_sum.s"], g["mse_sum.t"], 19)
+    close(loss, g["mse_sum.loss"], rtol=1e-5)
+    close(grad, g["mse_sum.grad"], rtol=1e-5, atol=1e-7)
+    for tag, w, avg in (("ce_w_mean", g["ce.w"], True), ("ce_w_sum", g["ce.w"], False), ("ce_sum", None, False)):
+        loss, grad = orc.ce2d_weighted(g["ce.x"], g["ce.target"], w, avg)
+        close(loss, g[f"{tag}.loss"], rtol=1e-5)
+        close(grad, g[f"{tag}.grad"], rtol=1e-4, atol=1e-7)
+    close(orc.ce2d_weighted(g["ce.x"], g["ce.target"], None, True, want_grad=False)[0], orc.ce2d(g["ce.x"], g["ce.target"]), rtol=1e-12)
+
+
+def dwsep_bias_ref(g):
+    """DepthwiseSeparableBlock(bias=True) restated from oracle ops: forward and all six gradients."""
+    C, Co, k, p, d, H, W = [int(v) for v in g["dwsep_bias.cfg"]]
+    x, wdw, bdw, wpw, bpw, gy = (g[f"dwsep_bias.{n}"] for n in ("x", "w_dw", "b_dw", "w_pw", "b_pw", "gy"))
+    mid = orc.conv2d_fwd(x, wdw, bias=bdw, pad=p, dil=d, groups=C)
+    y = orc.conv2d_fwd(mid, wpw, bias=bpw)
+    gmid = orc.conv2d_dgrad(gy, wpw, mid.shape)
+    return {"y": y, "gx": orc.conv2d_dgrad(gmid, wdw, x.shape, pad=p, dil=d, groups=C),
+            "gw_dw": orc.conv2d_wgrad(x, gmid, wdw.shape, pad=p, dil=d, groups=C), "gb_dw": gmid.sum(axis=(0, 2, 3)),
+            "gw_pw": orc.conv2d_wgrad(mid, gy, wpw.shape), "gb_pw": gy.sum(axis=(0, 2, 3))}
+
+
+def test_dwsep_block_with_bias(golden):
+    g = golden("variants")
+    for n, v in dwsep_bias_ref(g).items():
+        close(v, g[f"dwsep_bias.{n}"], rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("tag", ["k9d5", "k3d1"])
 def test_dwsep_block(golden, tag):
     g = golden("dwsep")

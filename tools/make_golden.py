@@ -157,6 +157,44 @@ def g_dwsep():
     save("dwsep", **out)
 
 
+def g_variants():
+    """Constructor variants the shipped KD configs do not use but the reference's classes accept: MSELoss(reduction='sum')
+    (losses/MSELoss.py:9-16), CrossEntropyLoss2d(weight, size_average) (losses/CrossEntropy.py:5-14), and
+    DepthwiseSeparableBlock(bias=True) (depthwise_separable_conv.py:7-9): values and every gradient."""
+    out = {}
+    h, g = seeded_input("var.h", (2, 24, 9, 13)), seeded_input("var.g", (2, 24, 9, 13))
+    s = h.clone().requires_grad_(True)
+    loss = ref_losses.MSELoss(reduction='sum', num_classes=19)(s, g)
+    loss.backward()
+    out.update({"mse_sum.s": h.numpy(), "mse_sum.t": g.numpy(), "mse_sum.loss": np.float64(loss.item()), "mse_sum.grad": s.grad.numpy()})
+    x = seeded_input("var.ce.x", (2, 19, 11, 17), 2.0)
+    tgt = torch.randint(0, 19, (2, 11, 17), generator=torch.Generator().manual_seed(11))
+    tgt[0, :2] = 255
+    w = torch.rand(19, generator=torch.Generator().manual_seed(12)) + 0.25
+    out.update({"ce.x": x.numpy(), "ce.target": tgt.numpy(), "ce.w": w.numpy()})
+    for tag, kw in (("ce_w_mean", dict(weight=w, size_average=True)), ("ce_w_sum", dict(weight=w, size_average=False)),
+                    ("ce_sum", dict(size_average=False))):
+        xs = x.clone().requires_grad_(True)
+        loss = ref_losses.CrossEntropyLoss2d(ignore_index=255, **kw)(xs, tgt)
+        loss.backward()
+        out[f"{tag}.loss"] = np.float64(loss.item())
+        out[f"{tag}.grad"] = xs.grad.numpy()
+    C, Co, k, p, d, H, W = 64, 64, 3, 2, 2, 12, 16
+    blk = DepthwiseSeparableBlock(C, Co, k, p, d, groups=C, bias=True)
+    seeded_fill_(blk, "var.dwsep_bias.")
+    xb = seeded_input("var.dwsep_bias.x", (2, C, H, W)).requires_grad_(True)
+    y = blk(xb)
+    gy = seeded_input("var.dwsep_bias.gy", tuple(y.shape))
+    y.backward(gy)
+    out["dwsep_bias.cfg"] = np.array([C, Co, k, p, d, H, W])
+    for n, t in (("x", xb.detach()), ("w_dw", blk.separable_conv.weight.detach()), ("b_dw", blk.separable_conv.bias.detach()),
+                 ("w_pw", blk.pointwise_conv.weight.detach()), ("b_pw", blk.pointwise_conv.bias.detach()), ("y", y.detach()), ("gy", gy),
+                 ("gx", xb.grad), ("gw_dw", blk.separable_conv.weight.grad), ("gb_dw", blk.separable_conv.bias.grad),
+                 ("gw_pw", blk.pointwise_conv.weight.grad), ("gb_pw", blk.pointwise_conv.bias.grad)):
+        out[f"dwsep_bias.{n}"] = t.numpy()
+    save("variants", **out)
+
+
 def g_resblock():
     """models/encoders/wider_resnet.py:119-182 IdentityResidualBlock in eval mode: fwd + input grad."""
     out = {}
@@ -693,7 +731,7 @@ def g_keys():
     print("wrote", path, len(inv), "entries", sum(int(np.prod(v)) for k, v in inv.items() if "num_batches" not in k and "running" not in k), "params")
 
 
-ALL = dict(keys=g_keys, gscnn=g_gscnn, confusion=g_confusion, taylor=g_taylor, taylor_steps=g_taylor_steps, tta=g_tta, gscnn_step_full=g_gscnn_step_full, student_step_full=g_student_step_full, trainer_epoch=g_trainer_epoch, classification_epoch=g_classification_epoch, losses=g_losses, dwsep=g_dwsep, resblock=g_resblock, aspp=g_aspp, ops=g_ops, radam=g_radam,
+ALL = dict(keys=g_keys, gscnn=g_gscnn, confusion=g_confusion, taylor=g_taylor, taylor_steps=g_taylor_steps, tta=g_tta, gscnn_step_full=g_gscnn_step_full, student_step_full=g_student_step_full, trainer_epoch=g_trainer_epoch, classification_epoch=g_classification_epoch, losses=g_losses, variants=g_variants, dwsep=g_dwsep, resblock=g_resblock, aspp=g_aspp, ops=g_ops, radam=g_radam,
            student_step=g_student_step)
 
 if __name__ == "__main__":
