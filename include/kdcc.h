@@ -110,6 +110,20 @@ size_t kd_bn_sums_finish_workspace(int32_t rows, int32_t C);
 int kd_bn_sums_finish(const float *part, int32_t rows, int32_t C, float *s1, float *s2, void *workspace, size_t workspace_bytes,
                       kd_stream_t stream);
 
+/* K-concatenated 1x1 convolution: y = epilogue([x | x2] . w_cat^T) with ONE accumulator chain over K = d->Cin + Cin2 -- the two
+ * 1x1 convs that land on the same tensor in the bottleneck blocks of WRN-38 (models/encoders/wider_resnet.py:143-182:
+ * `out = self.convs(bn1); out.add_(shortcut)` with `shortcut = self.proj_conv(bn1)`: conv3 and proj_conv in mod6 / mod7), and in
+ * their backward the input gradients of conv1 and proj_conv, which both land on bn1's output.  The shortcut tensor is never
+ * written and read back and one wide epilogue disappears.  d describes the FIRST source (N,H,W,Cin,ldx; 1x1, stride 1, pad 0,
+ * bf16); x2 is an (N,H,W,Cin2) view with pixel stride ldx2; w_cat is [Cout][Cin + Cin2] in `dtype` (the two packed weights
+ * concatenated along K).  Runs on the persistent 256 x 256 ping-pong kernel only: kd_conv1x1_dual_supported() says whether (d,
+ * Cin2, ep) selects it (M % 256 == 0, Cout % 256 == 0, >= 224 tiles, 16-B friendly epilogue); otherwise KD_ERR_UNSUPPORTED and
+ * the caller runs the two convs (the second with res_pre).  Same values as those two launches up to the bf16 rounding of the
+ * intermediate (the concatenated form rounds once). */
+int32_t kd_conv1x1_dual_supported(const kd_conv_desc *d, int32_t Cin2, int32_t ldx2, const kd_conv_epilogue *ep);
+int kd_conv1x1_dual_fwd(const kd_conv_desc *d, const void *x, const void *x2, int32_t Cin2, int32_t ldx2, const void *w_cat,
+                        const kd_conv_epilogue *ep, kd_stream_t stream);
+
 /* Weight packing (runs on device, on `stream`).  src: the reference's
  * nn.Conv2d.weight, fp32 (Cout, Cin, kh, kw) contiguous.
  *   KD_PACK_FWD   dst[co][ky][kx][ci]            = src[co][ci][ky][kx]

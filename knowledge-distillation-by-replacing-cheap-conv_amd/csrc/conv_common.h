@@ -13,6 +13,10 @@ struct ConvParams {
     int epi_batch;  // A/B hook: 0 = one pass at a time (KDCC_EPI_BATCH=0)
     int tune;       // A/B hook (KDCC_CONV_TUNE)
     int stagger_us; // A/B hook (KDCC_CONV_STAGGER, with tune & 16384)
+    // second A source of a K-concatenated 1x1 conv (kd_conv1x1_dual_fwd): K stages [0, nk1) read x, [nk1, nk) read x2 (its own
+    // pixel stride); w is [Cout][Cin + Cin2].  nk1 == nk when there is one source.
+    const void *x2;
+    int ldx2, nk1;
     kd_conv_epilogue ep;
 };
 }  // namespace kdconv

@@ -1091,18 +1091,24 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_persist_kerne
             }
             tm0 = tm * CF::BM;
             tn0 = tn * CF::BN;
-            ao = (tm0 + wv * GA * PR + srow) * p.ldx + chunk * EPC;
+            ao = tm0 + wv * GA * PR + srow;          // this lane's row of piece 0 (times the source's pixel stride in issue())
             bo = (tn0 + wv * 2 * GB * PR + srow) * p.Ktot + chunk * EPC;
         };
         // issue iterator: (tile, k stage) of the next stage this wave stages, and the global count of stages it has staged
         int it_tile = walk.t, it_k = 0, it_g = 0, it_ao = 0, it_bo = 0, it_m0, it_n0;
         offsets(it_tile, it_m0, it_n0, it_ao, it_bo);
+        const T *__restrict__ xg2 = (const T *)p.x2;
         auto issue = [&]() {
             if (it_tile >= walk.t_end) return;
             char *la = lds + (it_g & 1) * CF::STAGE + wv * (GA * 1024);
             const char *ga[GA], *gb[GB];
+            // K-concatenated 1x1 (two A sources, kd_conv1x1_dual_fwd): stages >= nk1 come from x2; the choice is wave-uniform
+            const bool second = it_k >= p.nk1;
+            const T *src = second ? xg2 : xg;
+            const int ldr = second ? p.ldx2 : p.ldx, ks = second ? it_k - p.nk1 : it_k;
+            const int a0 = it_ao * ldr + chunk * EPC + ks * BK;
 #pragma unroll
-            for (int j = 0; j < GA; ++j) ga[j] = (const char *)(xg + (it_ao + j * PR * p.ldx + it_k * BK)) - j * 1024;
+            for (int j = 0; j < GA; ++j) ga[j] = (const char *)(src + (a0 + j * PR * ldr)) - j * 1024;
             glds16_x4(ga[0], ga[1], ga[2], ga[3], la);
             if (wv < 4) {   // B, which both groups read, comes from group 0 alone (published by its wait a full stage early)
                 char *lb = lds + (it_g & 1) * CF::STAGE + CF::STAGE_A + wv * (2 * GB * 1024);
@@ -1507,8 +1513,10 @@ extern "C" int32_t kd_conv2d_bn_sums_rows(const kd_conv_desc *d, const kd_conv_e
     return (int32_t)((long long)d->N * d->Ho * d->Wo / 128);
 }
 
-extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w_packed, const kd_conv_epilogue *ep,
-                             kd_stream_t stream)
+// x2 != nullptr: K-concatenated 1x1 conv (kd_conv1x1_dual_fwd) -- d->Cin is the TOTAL reduction depth, channels [0, cin1) come from
+// x (pixel stride d->ldx), [cin1, d->Cin) from x2 (pixel stride ldx2); only the persistent ping-pong 1x1 kernel takes it.
+static int conv2d_fwd_impl(const kd_conv_desc *d, const void *x, const void *w_packed, const kd_conv_epilogue *ep,
+                           kd_stream_t stream, const void *x2, int cin1, int ldx2)
 {
     KD_REQUIRE(d && x && w_packed && ep, KD_ERR_INVALID, "kd_conv2d_fwd: null argument");
     KD_REQUIRE(d->dtype == KD_F32 || d->dtype == KD_BF16, KD_ERR_INVALID, "kd_conv2d_fwd: bad dtype %d", d->dtype);
@@ -1520,7 +1528,7 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
                "kd_conv2d_fwd: kernel %dx%d not supported (1x1, 3x3)", d->kh, d->kw);
     KD_REQUIRE(d->stride >= 1 && d->dil >= 1 && d->pad >= 0, KD_ERR_INVALID, "kd_conv2d_fwd: bad stride/dil/pad");
     KD_REQUIRE(d->Cin % bk == 0, KD_ERR_UNSUPPORTED, "kd_conv2d_fwd: Cin=%d must be a multiple of %d", d->Cin, bk);
-    KD_REQUIRE(d->ldx >= d->Cin && (d->ldx * es) % 16 == 0, KD_ERR_INVALID, "kd_conv2d_fwd: bad ldx=%d", d->ldx);
+    KD_REQUIRE(d->ldx >= (x2 ? cin1 : d->Cin) && (d->ldx * es) % 16 == 0, KD_ERR_INVALID, "kd_conv2d_fwd: bad ldx=%d", d->ldx);
     KD_REQUIRE(kd_aligned16(x) && kd_aligned16(w_packed), KD_ERR_INVALID, "kd_conv2d_fwd: x/w must be 16-B aligned");
     const int ho = (d->H + 2 * d->pad - d->dil * (d->kh - 1) - 1) / d->stride + 1;
     const int wo = (d->W + 2 * d->pad - d->dil * (d->kw - 1) - 1) / d->stride + 1;
@@ -1539,6 +1547,7 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
     p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.ldx = d->ldx;
     p.HoWo = d->Ho * d->Wo;
     p.Ktot = d->kh * d->kw * d->Cin;
+    p.x2 = x2; p.ldx2 = ldx2; p.nk1 = 0x7fffffff;
     p.ep = *ep;
     {
         static int eb = -1;
@@ -1604,6 +1613,9 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
                         d->W % 256 == 0 && p.M % 256 == 0 && d->H >= 2 * d->dil && d->Cout % 128 == 0 && d->Cin % 64 == 0 && sel.vec_ok && !ep->raw_f32 && nops <= 1 &&
                         !ep->bn_sums && !(p.tune & 512) && (long long)(p.M / 256) * (d->Cout / 128) >= 2 * ncu &&
                         (duo >= 2 || d->Cout == 128);
+    if (x2)   // two A sources: the persistent ping-pong 1x1 kernel only (kd_conv1x1_dual_supported)
+        KD_REQUIRE(!duo_ok && !sel.use_row_persist && sel.use_igemm_persist && pp_row() && cin1 % (CfgWide::RB / es) == 0, KD_ERR_UNSUPPORTED,
+                   "kd_conv1x1_dual_fwd: this shape does not select conv_igemm_persist_kernel<pp> (ask kd_conv1x1_dual_supported first)");
     if (duo_ok) {
         p.tiles_n = d->Cout / 128;
         p.tiles_m = p.M / 256;
@@ -1653,8 +1665,9 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
         // Opt-in for A/B: KDCC_CONV_LW_PW=1.
         static int lw_pw = -1;
         if (lw_pw < 0) { const char *v = getenv("KDCC_CONV_LW_PW"); lw_pw = (v && v[0] == '1') ? 1 : 0; }
-        const bool lw = lw_pw && lw_row() && pp_row() && d->Cin % 128 == 0 && !(p.tune & 512);
-        KD_NOTE_KERNEL(lw ? "conv_pw_lw_kernel" : pp_row() ? "conv_igemm_persist_kernel<pp>" : "conv_igemm_persist_kernel<lockstep>");
+        if (x2) p.nk1 = cin1 / (CfgWide::RB / es);
+        const bool lw = lw_pw && lw_row() && pp_row() && d->Cin % 128 == 0 && !(p.tune & 512) && !x2;
+        KD_NOTE_KERNEL(lw ? "conv_pw_lw_kernel" : x2 ? "conv_igemm_persist_kernel<pp,dual>" : pp_row() ? "conv_igemm_persist_kernel<pp>" : "conv_igemm_persist_kernel<lockstep>");
         if (lw) {
             KD_REQUIRE(kd_launch_conv_pw_lw(p, nops | (ep->bn_sums ? 4 : 0), grid.x, s), KD_ERR_UNSUPPORTED, "kd_conv2d_fwd: no conv_pw_lw_kernel instantiation for %d epilogue operands", nops);
         } else if (pp_row()) {
@@ -1726,6 +1739,49 @@ extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w
     }
     KD_CHECK_LAUNCH("kd_conv2d_fwd");
     return KD_OK;
+}
+
+extern "C" int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w_packed, const kd_conv_epilogue *ep,
+                             kd_stream_t stream)
+{
+    return conv2d_fwd_impl(d, x, w_packed, ep, stream, nullptr, 0, 0);
+}
+
+// ---- K-concatenated 1x1 conv: y = [x | x2] . [w | w2]^T in ONE accumulator chain ------------------------------------------------
+// The bottleneck blocks of WRN-38 (mod6 / mod7, wider_resnet.py:143-182) end in `out = conv3(...); out.add_(shortcut)` with
+// shortcut = proj_conv(bn1) -- two 1x1 convs onto the same output.  As one GEMM over the concatenated K (mod6: 1024 + 1024, mod7:
+// 2048 + 2048) the 2048- / 4096-channel shortcut tensor is never written and read back and one wide epilogue disappears; the same
+// for the input gradient of the block (conv1's and proj_conv's dgrads both land on bn1's output: K = Cmid + Cout).
+static bool dual_shape_ok(const kd_conv_desc *d, int Cin2, int ldx2, const kd_conv_epilogue *ep, kd_conv_desc *tot)
+{
+    if (!d || !ep || d->dtype != KD_BF16 || d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0 || d->H != d->Ho || d->W != d->Wo) return false;
+    if (Cin2 <= 0 || d->Cin % 64 != 0 || Cin2 % 64 != 0 || ldx2 < Cin2 || (ldx2 * 2) % 16 != 0) return false;
+    *tot = *d;
+    tot->Cin = d->Cin + Cin2;
+    static int tn = -1;
+    if (tn < 0) tn = KD_TUNING_ENV_INT("KDCC_CONV_TUNE");
+    const ConvSel c = conv_select(tot, ep, tn);
+    static int dual = -1;
+    if (dual < 0) { const char *v = getenv("KDCC_CONV_DUAL"); dual = !(v && v[0] == '0'); }   // A/B: 0 = two launches (engine falls back)
+    return dual && c.use_igemm_persist && !c.use_row_persist && pp_row();
+}
+
+extern "C" int32_t kd_conv1x1_dual_supported(const kd_conv_desc *d, int32_t Cin2, int32_t ldx2, const kd_conv_epilogue *ep)
+{
+    kd_conv_desc tot;
+    return dual_shape_ok(d, Cin2, ldx2, ep, &tot) ? 1 : 0;
+}
+
+extern "C" int kd_conv1x1_dual_fwd(const kd_conv_desc *d, const void *x, const void *x2, int32_t Cin2, int32_t ldx2, const void *w_cat,
+                                   const kd_conv_epilogue *ep, kd_stream_t stream)
+{
+    KD_REQUIRE(d && x && x2 && w_cat && ep, KD_ERR_INVALID, "kd_conv1x1_dual_fwd: null argument");
+    KD_REQUIRE(kd_aligned16(x2), KD_ERR_INVALID, "kd_conv1x1_dual_fwd: x2 must be 16-B aligned");
+    kd_conv_desc tot;
+    KD_REQUIRE(dual_shape_ok(d, Cin2, ldx2, ep, &tot), KD_ERR_UNSUPPORTED,
+               "kd_conv1x1_dual_fwd: needs a bf16 1x1 / stride-1 conv on the persistent 256 x 256 tiles (kd_conv1x1_dual_supported)");
+    KD_REQUIRE((long long)d->N * d->H * d->W * ldx2 < (1ll << 31), KD_ERR_UNSUPPORTED, "kd_conv1x1_dual_fwd: x2 exceeds 2^31 elements");
+    return conv2d_fwd_impl(&tot, x, w_cat, ep, stream, x2, d->Cin, ldx2);
 }
 
 extern "C" int kd_debug_conv_tlog(unsigned long long *dst, size_t bytes)

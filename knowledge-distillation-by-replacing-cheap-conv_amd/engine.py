@@ -46,6 +46,7 @@ _SMALL_CONV = os.environ.get("KDCC_SMALL_CONV", "1") != "0"  # A/B: 0 = GSCNN re
 _SPLIT_DEC_DGRAD = os.environ.get("KDCC_SPLIT_DEC_DGRAD", "1") != "0"   # A/B: 0 = the decoder's 304-channel input gradient in one launch
 _STEM_POOL = os.environ.get("KDCC_STEM_POOL", "1") != "0"   # A/B: 0 = stem conv and pool2 as two kernels
 _DW_SUM = os.environ.get("KDCC_DW_SUM", "1") != "0"   # A/B: 0 = one depthwise input-gradient launch per ASPP branch
+_CONV_DUAL = os.environ.get("KDCC_CONV_DUAL", "1") != "0"   # A/B: 0 = a bottleneck block's conv3 / proj_conv (and conv1 / proj_conv input gradients) as two launches
 _FUSE_BN_SUMS = os.environ.get("KDCC_FUSE_BN_SUMS", "1") != "0"   # A/B: 0 = eval-BN parameter sums by kd_channel_sums only
 
 
@@ -92,6 +93,7 @@ class _Site:
             raise EngineError(f"{name}: unsupported module {type(mod).__name__} in the student graph")
         conv = mod.pointwise_conv if self.cheap else mod
         self.cout = conv.out_channels
+        self.cin = (mod.separable_conv if self.cheap else conv).in_channels
         if self.cheap:
             self.k, self.pad, self.dil = mod.geometry
             self.stride = 1
@@ -219,6 +221,28 @@ class StudentEngine:
             return ops.pack_conv_weight(w, self.dtype, KD_PACK_DGRAD)
         return self._packed(conv.weight, ("dgrad", self.dtype, cout_pad, cin_rot, id(gate) if gate is not None else None), make,
                             extra=gate.weight._version if gate is not None else None)
+
+    def _w_cat(self, conv_a, conv_b, mode):
+        """Packed operand of the K-concatenated 1x1 conv [a | b] (ops.conv2d(..., x2=...)): mode "fwd" -- conv_a and conv_b map
+        different inputs onto the SAME output (a bottleneck block's conv3 and proj_conv): [Cout][Cin_a + Cin_b]; mode "dgrad" -- they
+        read the SAME input (conv1 and proj_conv): the input gradient's operand [Cin][Cout_a + Cout_b]."""
+        def make():
+            wa = (self._w_fwd if mode == "fwd" else self._w_dgrad)(conv_a)
+            wb = (self._w_fwd if mode == "fwd" else self._w_dgrad)(conv_b)
+            return torch.cat([wa, wb], dim=3).contiguous()
+        return self._packed(conv_a.weight, ("cat", mode, self.dtype, id(conv_b.weight)), make, extra=conv_b.weight._version)
+
+    def _dual_ok(self, a_shape, cin_a, cin_b, cout, operands, conv_a, conv_b, site=None):
+        """Can two 1x1 convs onto / from one tensor run as one K-concatenated launch (bf16, stride 1, plain weights)?"""
+        if self.dtype != torch.bfloat16 or not _CONV_DUAL:
+            return False
+        for c in (conv_a, conv_b):
+            if not isinstance(c, nn.Conv2d) or c.kernel_size != (1, 1) or c.stride != (1, 1) or c.padding != (0, 0) or c.bias is not None:
+                return False
+        if site is not None and (site.cheap or site.gate is not None or site.name in self._probes):
+            return False
+        N, H, W = a_shape[:3]
+        return ops.conv1x1_dual_ok_dims(N, H, W, cin_a, cin_b, cout, self.dtype, operands)
 
     def _w_dw(self, conv, flip):
         return self._packed(conv.weight, ("dw", flip), lambda: ops.pack_dw_weight(conv.weight, flip))
@@ -808,8 +832,16 @@ class StudentEngine:
         rec = {"name": name, "blk": blk, "sites": sites, "a_in": [], "mid": [], "rg_a": [], "hint_raw": [None] * len(sites),
                "x_raw": x_raw, "rg_in": rg_in, "proj": hasattr(blk, "proj_conv")}
         rg_a1 = rg_in or _is_trainable(blk.bn1)      # a1 = relu(bn1(x))
+        # bottleneck blocks (mod6 / mod7): conv3 and proj_conv are two 1x1 convs onto the block output -- one K-concatenated launch
+        # [conv2's activation | a1] . [W3 | Wp]^T, the shortcut tensor never exists (ops.conv2d(..., x2=))
+        dual = (rec["proj"] and len(sites) == 3 and sites[-1].k == 1 and sites[-1].stride == 1 and
+                self._dual_ok(a1.shape, sites[-1].cin, a1.shape[3], sites[-1].cout, 0, sites[-1].mod, blk.proj_conv, sites[-1]))
+        rec["dual"] = dual
         # shortcut
-        if rec["proj"]:
+        if dual:
+            shortcut = None
+            rg_short = rg_a1 or blk.proj_conv.weight.requires_grad
+        elif rec["proj"]:
             pc = blk.proj_conv
             ho = ops.conv_out_size(a1.shape[1], 1, pc.stride[0], 0, 1)
             wo = ops.conv_out_size(a1.shape[2], 1, pc.stride[0], 0, 1)
@@ -838,7 +870,8 @@ class StudentEngine:
             if last:
                 want_raw = need_raw or hinted or probed
                 raw = self._new(N, ho, wo, site.cout) if want_raw else None
-                kw["res_pre"] = shortcut
+                if not dual:
+                    kw["res_pre"] = shortcut
                 if next_bn is not None:
                     sc, sh = self._bn_fold(next_bn)
                     a_next = self._new(N, ho, wo, site.cout)
@@ -853,6 +886,9 @@ class StudentEngine:
             if site.cheap:
                 mid = ops.dwconv(a, self._w_dw(site.mod.separable_conv, False), site.k, site.pad, site.dil)
                 ops.conv2d(mid, self._w_fwd(site.mod.pointwise_conv), **kw)
+            elif last and dual:
+                mid = None
+                ops.conv2d(a, self._w_cat(site.mod, blk.proj_conv, "fwd"), x2=a1, **kw)
             else:
                 mid = None
                 ops.conv2d(a, self._w_fwd(site.mod, gate=site.gate), site.stride, site.pad, site.dil, **kw)
@@ -1188,7 +1224,10 @@ class StudentEngine:
                     if rec["proj"]:
                         psite = _Site(f"{rec['name']}.proj_conv", blk.proj_conv)
                         self._conv_wgrad(blk.proj_conv, a_in, g_out, grads)
-                        if need_in:
+                        # conv1 and proj_conv both read a_in: their input gradients as ONE K-concatenated 1x1 launch [g | g_out]
+                        dual_bwd = (need_in and site.k == 1 and site.stride == 1 and g_out.is_contiguous() and g.is_contiguous() and
+                                    self._dual_ok(g.shape, site.cout, g_out.shape[3], site.cin, 1, site.mod, blk.proj_conv, site))
+                        if need_in and not dual_bwd:
                             ep["res_pre"] = self._dense_dgrad(psite, g_out, in_hw=(a_in.shape[1], a_in.shape[2]))
                     elif rec["rg_in"]:
                         sub = g_out
@@ -1196,7 +1235,12 @@ class StudentEngine:
                 fused = []
                 if _FUSE_BN_SUMS and need_in and not site.cheap and self._wants_bn_sums(bn_seq, act_gate):
                     ep["bn_sums"] = fused       # the dense input gradient's epilogue takes the BN parameter sums where it can
-                g_in = self._site_bwd(site, a_in, rec["mid"][i], g, grads, need_in, **ep)
+                if i == 0 and g_out is not None and rec["proj"] and dual_bwd:
+                    self._conv_wgrad(site.mod, a_in, g, grads, gate=site.gate)
+                    g_in = self._new(g.shape[0], g.shape[1], g.shape[2], site.cin)
+                    ops.conv2d(g, self._w_cat(site.mod, blk.proj_conv, "dgrad"), out_raw=g_in, x2=g_out, **ep)
+                else:
+                    g_in = self._site_bwd(site, a_in, rec["mid"][i], g, grads, need_in, **ep)
                 if g_in is not None:
                     self._bn_param_grads(bn_seq, g_in, a_in, grads, sub=sub, gate=act_gate, sums=fused[0] if fused else None)
             elif i == 0 and g is None and g_out is not None:

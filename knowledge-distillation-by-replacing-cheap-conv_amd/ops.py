@@ -109,17 +109,30 @@ def pack_conv_weight(w, dtype, mode=KD_PACK_FWD, cin_pad=None):
     return out
 
 
+class DualUnsupported(_lib.KdccError):
+    """conv2d(..., x2=...) on a shape the K-concatenated 1x1 kernel does not take: run the two convs instead."""
+
+
 def conv2d(x, w_packed, stride=1, pad=0, dil=1, *, res_pre=None, mask=None, mask_scale=None, res_post=None,
-           out_raw=None, out_act=None, act_scale=None, act_shift=None, act_relu=False, algo_cin=None, algo_cout=None, bn_sums=None):
+           out_raw=None, out_act=None, act_scale=None, act_shift=None, act_relu=False, algo_cin=None, algo_cout=None, bn_sums=None,
+           x2=None):
     """Implicit-GEMM conv; w_packed is (Cout,kh,kw,Cin). Outputs are caller-provided NHWC views.
+    x2: a second (N,H,W,Cin2) source of a K-concatenated 1x1 conv -- w_packed is then (Cout,1,1,Cin + Cin2), the result
+    [x | x2] . w^T in one accumulator chain (kd_conv1x1_dual_fwd); raises DualUnsupported where the kernel does not apply.
     bn_sums: an empty list (backward, with `mask`): when the kernel this problem selects can take the eval-BN parameter sums in
     its epilogue, (s1, s2) = per-channel sums of the masked gradient and of it times `mask` are appended -- what
     channel_sums(out_raw, sub=res_post, a=mask) would return from another pass over the tensors; otherwise it stays empty."""
     _need_cuda(x, w_packed)
     N, H, W, Cin = x.shape
     Cout, kh, kw, Cin_w = w_packed.shape
-    if Cin_w != Cin:
-        raise ValueError(f"conv2d: input has {Cin} channels, packed weight expects {Cin_w}")
+    Cin2 = 0
+    if x2 is not None:
+        _need_cuda(x2)
+        if tuple(x2.shape[:3]) != (N, H, W) or x2.dtype != x.dtype or (kh, kw, stride, pad) != (1, 1, 1, 0):
+            raise ValueError("conv2d: x2 needs a 1x1 / stride-1 conv and a source of the same pixels and dtype")
+        Cin2 = x2.shape[3]
+    if Cin_w != Cin + Cin2:
+        raise ValueError(f"conv2d: input has {Cin + Cin2} channels, packed weight expects {Cin_w}")
     if w_packed.dtype != x.dtype or not w_packed.is_contiguous():
         raise ValueError("conv2d: packed weight must be contiguous and of the activation dtype")
     Ho, Wo = conv_out_size(H, kh, stride, pad, dil), conv_out_size(W, kw, stride, pad, dil)
@@ -161,13 +174,19 @@ def conv2d(x, w_packed, stride=1, pad=0, dil=1, *, res_pre=None, mask=None, mask
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(_lib.lib().kd_conv2d_fwd(C.byref(d), _ptr(x), _ptr(w_packed), C.byref(ep), stream_ptr()), "kd_conv2d_fwd")
+    if x2 is not None:
+        ld2 = nhwc_ld(x2)
+        if not _lib.lib().kd_conv1x1_dual_supported(C.byref(d), Cin2, ld2, C.byref(ep)):
+            raise DualUnsupported(f"conv2d: no K-concatenated kernel for {H}x{W} {Cin}+{Cin2}->{Cout}")
+        check(_lib.lib().kd_conv1x1_dual_fwd(C.byref(d), _ptr(x), _ptr(x2), Cin2, ld2, _ptr(w_packed), C.byref(ep), stream_ptr()), "kd_conv1x1_dual_fwd")
+    else:
+        check(_lib.lib().kd_conv2d_fwd(C.byref(d), _ptr(x), _ptr(w_packed), C.byref(ep), stream_ptr()), "kd_conv2d_fwd")
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         epi = "".join(c for c, t in (("p", res_pre), ("m", mask), ("q", res_post), ("r", out_raw), ("a", out_act)) if t is not None)
-        prof.append(("conv_igemm", 2.0 * N * Ho * Wo * (algo_cout or Cout) * kh * kw * (algo_cin or Cin), e0, e1,
-                     f"{kh}x{kw} s{stride} d{dil} {H}x{W} {Cin}->{Cout} [{epi}{'s' if sums_rows else ''}]", _lib.last_kernel()))
+        prof.append(("conv_igemm", 2.0 * N * Ho * Wo * (algo_cout or Cout) * kh * kw * (algo_cin or (Cin + Cin2)), e0, e1,
+                     f"{kh}x{kw} s{stride} d{dil} {H}x{W} {Cin}{'+%d' % Cin2 if Cin2 else ''}->{Cout} [{epi}{'s' if sums_rows else ''}]", _lib.last_kernel()))
     if sums_rows > 0:
         s12 = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
         need = _lib.lib().kd_bn_sums_finish_workspace(sums_rows, Cout)
@@ -176,6 +195,40 @@ def conv2d(x, w_packed, stride=1, pad=0, dil=1, *, res_pre=None, mask=None, mask
               "kd_bn_sums_finish")
         bn_sums.append((s12[0], s12[1]))
     return out_raw, out_act
+
+
+def conv1x1_dual_ok(x, x2, Cout, operands=0):
+    """Does the K-concatenated 1x1 kernel take [x | x2] -> Cout with `operands` epilogue operands (dense, freshly allocated outputs)?"""
+    if x2 is None or not x.is_cuda or x.dtype != torch.bfloat16 or x2.dtype != x.dtype or tuple(x2.shape[:3]) != tuple(x.shape[:3]):
+        return False
+    N, H, W, Cin = x.shape
+    d = ConvDesc(dt_of(x), N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, 1, nhwc_ld(x))
+    ep = ConvEpilogue()
+    some = C.c_void_p(x.data_ptr())          # (alignment and strides are all the selection reads of an operand)
+    if operands >= 1:
+        ep.mask, ep.ld_mask = some, Cout
+    if operands >= 2:
+        ep.res_post, ep.ld_res_post = some, Cout
+    if operands >= 3:
+        ep.res_pre, ep.ld_res_pre = some, Cout
+    ep.out_raw, ep.ld_raw = some, Cout
+    return bool(_lib.lib().kd_conv1x1_dual_supported(C.byref(d), x2.shape[3], nhwc_ld(x2), C.byref(ep)))
+
+
+def conv1x1_dual_ok_dims(N, H, W, Cin, Cin2, Cout, dtype, operands=0):
+    """conv1x1_dual_ok for dense tensors of these sizes (before they exist)."""
+    if dtype != torch.bfloat16:
+        return False
+    d = ConvDesc(KD_BF16, N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, 1, Cin)
+    ep = ConvEpilogue()
+    if operands >= 1:
+        ep.mask, ep.ld_mask = C.c_void_p(256), Cout       # (the selection reads only alignment and strides of an operand)
+    if operands >= 2:
+        ep.res_post, ep.ld_res_post = C.c_void_p(256), Cout
+    if operands >= 3:
+        ep.res_pre, ep.ld_res_pre = C.c_void_p(256), Cout
+    ep.out_raw, ep.ld_raw = C.c_void_p(256), Cout
+    return bool(_lib.lib().kd_conv1x1_dual_supported(C.byref(d), Cin2, Cin2, C.byref(ep)))
 
 
 def pw_wgrad(a, dy, dw, accumulate=False, workspace=None):

@@ -311,6 +311,64 @@ def test_conv_persistent_epilogues(K, case, opnds, outs):
         assert_close(host_nchw(out_act), act_ref, dt, f"act {case} {opnds}")
 
 
+@pytest.mark.parametrize("case,opnds,outs", [
+    # (N, H, W, Cin1, Cin2, Cout), epilogue operands, outputs -- the K-concatenated 1x1 conv of the bottleneck blocks
+    ((1, 160, 512, 64, 128, 256), (), ("raw", "act")),              # forward form: conv3 | proj_conv -> block output + next activation
+    ((1, 160, 512, 128, 64, 256), ("mask",), ("raw",)),             # backward form: conv1 | proj_conv input gradients through bn1's mask
+    ((2, 20, 512, 192, 64, 2048), ("mask", "post"), ("raw",)),      # N tiles walked four at a time, two operands
+    ((1, 80, 1024, 64, 64, 256), ("pre", "mask", "post"), ("raw", "act")),
+])
+def test_conv1x1_dual(K, case, opnds, outs):
+    """kd_conv1x1_dual_fwd: [x | x2] . [w | w2]^T in one accumulator chain (wider_resnet.py:143-182: conv3 + proj_conv onto the block
+    output; their transposes in the backward) against the oracle's two convs, and against the two-launch form it replaces."""
+    dt = "bf16"
+    N, H, W, C1, C2, Cout = case
+    x1, x2 = q(rnd(N, C1, H, W), dt), q(np.maximum(rnd(N, C2, H, W), 0), dt)
+    w1 = q(rnd(Cout, C1, 1, 1, scale=(1.0 / C1) ** 0.5), dt)
+    w2 = q(rnd(Cout, C2, 1, 1, scale=(1.0 / C2) ** 0.5), dt)
+    pre, post = q(rnd(N, Cout, H, W), dt), q(rnd(N, Cout, H, W), dt)
+    mask = q(np.maximum(rnd(N, Cout, H, W), 0), dt)
+    mscale, ascale, ashift = rnd(Cout) * 0.2 + 1.0, rnd(Cout) * 0.2 + 1.0, rnd(Cout) * 0.3
+    bc = lambda v: v[None, :, None, None]
+    ref = orc.conv2d_fwd(x1, w1) + orc.conv2d_fwd(x2, w2)
+    if "pre" in opnds:
+        ref = ref + pre
+    if "mask" in opnds:
+        ref = np.where(mask > 0, ref * bc(mscale), 0.0)
+    if "post" in opnds:
+        ref = ref + post
+    act_ref = np.maximum(ref * bc(ascale) + bc(ashift), 0)
+    cu = lambda v: torch.from_numpy(v).cuda()
+    wcat = torch.cat([K.pack_conv_weight(cu(w1), DT[dt]), K.pack_conv_weight(cu(w2), DT[dt])], dim=3).contiguous()
+    x1d, x2d = dev_nhwc(x1, dt), dev_nhwc(x2, dt, ld=C2 + 16)
+    assert K.conv1x1_dual_ok(x1d, x2d, Cout, len(opnds))
+    kw = dict(res_pre=dev_nhwc(pre, dt) if "pre" in opnds else None,
+              mask=dev_nhwc(mask, dt) if "mask" in opnds else None, mask_scale=cu(mscale) if "mask" in opnds else None,
+              res_post=dev_nhwc(post, dt) if "post" in opnds else None,
+              act_scale=cu(ascale) if "act" in outs else None, act_shift=cu(ashift) if "act" in outs else None, act_relu="act" in outs)
+    mk = lambda: (torch.zeros((N, H, W, Cout), dtype=DT[dt], device="cuda") if "raw" in outs else None,
+                  torch.zeros((N, H, W, Cout), dtype=DT[dt], device="cuda") if "act" in outs else None)
+    out_raw, out_act = mk()
+    K.conv2d(x1d, wcat, x2=x2d, out_raw=out_raw, out_act=out_act, **kw)
+    selected("conv_igemm_persist_kernel<pp,dual>", f"{case}")
+    if out_raw is not None:
+        assert_close(host_nchw(out_raw), ref, dt, f"dual raw {case} {opnds}")
+    if out_act is not None:
+        assert_close(host_nchw(out_act), act_ref, dt, f"dual act {case} {opnds}")
+    if "pre" not in opnds:     # the form it replaces: conv(x2) stored in bf16, then conv(x1) with it as res_pre
+        short = torch.empty((N, H, W, Cout), dtype=DT[dt], device="cuda")
+        K.conv2d(x2d, K.pack_conv_weight(cu(w2), DT[dt]), out_raw=short)
+        r2, a2 = mk()
+        K.conv2d(x1d, K.pack_conv_weight(cu(w1), DT[dt]), out_raw=r2, out_act=a2, **{**kw, "res_pre": short})
+        for a, b in ((out_raw, r2), (out_act, a2)):
+            if a is not None:
+                assert_close(host_nchw(a), host_nchw(b), dt, f"dual vs two launches {case}")
+    # a shape the persistent kernel does not take must be refused loudly, not computed some other way
+    small = dev_nhwc(q(rnd(1, C1, 8, 16), dt), dt)
+    with pytest.raises(K.DualUnsupported):
+        K.conv2d(small, wcat, x2=dev_nhwc(q(rnd(1, C2, 8, 16), dt), dt), out_raw=torch.zeros((1, 8, 16, Cout), dtype=DT[dt], device="cuda"))
+
+
 @pytest.mark.parametrize("case,kernel", [
     ((1, 24, 512, 4096, 1280, 3, 12, 12), "conv_row_lw_kernel"),       # ASPP rate 12 at the network's real K = 9 x 4096, H = 2 dil
     ((1, 8, 1536, 2048, 1280, 3, 4, 4), "conv_row_lw_kernel"),         # mod7 dil 4, K = 9 x 2048: three tiles per image row
