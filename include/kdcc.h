@@ -124,6 +124,12 @@ int32_t kd_conv1x1_dual_supported(const kd_conv_desc *d, int32_t Cin2, int32_t l
 int kd_conv1x1_dual_fwd(const kd_conv_desc *d, const void *x, const void *x2, int32_t Cin2, int32_t ldx2, const void *w_cat,
                         const kd_conv_epilogue *ep, kd_stream_t stream);
 
+/* Workgroups of the persistent conv kernels' grids from now on: 0 = one per CU (default), else n (rounded down to a multiple of 8,
+ * at most the CU count) -- leaves CUs to a kernel on another stream, i.e. the RCCL all-reduce of a gradient bucket that
+ * parallel.GradReducer launches from inside backward (the reference's single-process trainer has no counterpart,
+ * trainer/layerwise_trainer.py:235-239).  Overrides the KDCC_PERSIST_CUS environment default; results are bit-identical for any n. */
+int kd_conv_set_persist_cus(int32_t n);
+
 /* Weight packing (runs on device, on `stream`).  src: the reference's
  * nn.Conv2d.weight, fp32 (Cout, Cin, kh, kw) contiguous.
  *   KD_PACK_FWD   dst[co][ky][kx][ci]            = src[co][ci][ky][kx]

@@ -70,6 +70,7 @@ _SIGS = {
     "kd_conv2d_fwd": (c_int, [_P(ConvDesc), c_vp, c_vp, _P(ConvEpilogue), c_vp]),
     "kd_conv1x1_dual_supported": (c_int, [_P(ConvDesc), c_int, c_int, _P(ConvEpilogue)]),
     "kd_conv1x1_dual_fwd": (c_int, [_P(ConvDesc), c_vp, c_vp, c_int, c_int, c_vp, _P(ConvEpilogue), c_vp]),
+    "kd_conv_set_persist_cus": (c_int, [c_int]),
     "kd_conv2d_bn_sums_rows": (c_int, [_P(ConvDesc), _P(ConvEpilogue)]),
     "kd_bn_sums_finish_workspace": (c_sz, [c_int, c_int]),
     "kd_bn_sums_finish": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),

@@ -1513,6 +1513,29 @@ extern "C" int32_t kd_conv2d_bn_sums_rows(const kd_conv_desc *d, const kd_conv_e
     return (int32_t)((long long)d->N * d->Ho * d->Wo / 128);
 }
 
+// Workgroups of the persistent conv grids: one per CU, or fewer (a multiple of 8, one XCD round) when KDCC_PERSIST_CUS / kd_conv_set_persist_cus
+// says so -- that leaves CUs to a kernel on another stream (the RCCL all-reduce the reducer launches from inside backward, which
+// otherwise only gets a CU between two conv launches).  Results do not depend on it: a tile's arithmetic is the same whichever
+// workgroup computes it (tests/test_ddp_gpu.py).
+static int g_persist_cus = -1;   // -1: not read yet; 0: every CU
+static int persist_cus_value(int ncu)
+{
+    if (g_persist_cus < 0) {
+        const char *v = getenv("KDCC_PERSIST_CUS");
+        g_persist_cus = v ? atoi(v) : 0;
+        if (g_persist_cus < 0) g_persist_cus = 0;
+    }
+    int n = g_persist_cus;
+    if (n < 8 || n > ncu) n = ncu;
+    return n - n % 8;
+}
+extern "C" int kd_conv_set_persist_cus(int32_t n)
+{
+    KD_REQUIRE(n >= 0, KD_ERR_INVALID, "kd_conv_set_persist_cus: n must be >= 0 (0 = one workgroup per CU)");
+    g_persist_cus = n;
+    return KD_OK;
+}
+
 // x2 != nullptr: K-concatenated 1x1 conv (kd_conv1x1_dual_fwd) -- d->Cin is the TOTAL reduction depth, channels [0, cin1) come from
 // x (pixel stride d->ldx), [cin1, d->Cin) from x2 (pixel stride ldx2); only the persistent ping-pong 1x1 kernel takes it.
 static int conv2d_fwd_impl(const kd_conv_desc *d, const void *x, const void *w_packed, const kd_conv_epilogue *ep,
@@ -1572,16 +1595,7 @@ static int conv2d_fwd_impl(const kd_conv_desc *d, const void *x, const void *w_p
     // e.g. 248) leaves CUs free for a concurrent kernel -- the RCCL all-reduce the gradient reducer launches on its side stream
     // from inside backward -- which otherwise only gets a CU between two conv launches.  Results do not depend on it: a tile's
     // arithmetic is the same whichever workgroup computes it (tests/test_ddp_gpu.py).
-    auto persist_cus = [&]() {
-        static int n = -1;
-        if (n < 0) {
-            const char *v = getenv("KDCC_PERSIST_CUS");
-            n = v ? atoi(v) : 0;
-            if (n < 8 || n > ncu) n = ncu;
-            n -= n % 8;
-        }
-        return n;
-    };
+    auto persist_cus = [&]() { return persist_cus_value(ncu); };
     auto launch = [&](auto cf, auto tag) {
         using CF = decltype(cf);
         using T = decltype(tag);

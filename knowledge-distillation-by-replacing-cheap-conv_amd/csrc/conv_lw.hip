@@ -106,6 +106,10 @@ __global__ __launch_bounds__(256, 1) void conv_row_lw_kernel(const ConvParams p)
         t.lo = x0 == 0 ? (uint32_t)d : 0u;
         t.span = (x0 + 256 == p.W ? 256u + d : 320u) - t.lo;
         t.abase = (u64)p.x + (u64)(2ll * ((long long)((n * p.H + ho) * p.W + (x0 - d)) * p.ldx));
+#ifdef KDCC_TUNING
+        // timing ablation 2048 (tools/power_sweep.py): every tile stages image 0's rows 0 / d / 2d -- the input stays in the XCD's L2
+        if (p.tune & 2048) t.abase = (u64)p.x + (u64)(2ll * ((long long)(d * p.W + (x0 - d)) * p.ldx));
+#endif
         t.bbase = (u64)p.w + (u64)(2ll * (long long)t.n0 * p.Ktot);
     };
     // period q of a tile = (channel block q / nky, kernel row kylo + q % nky)
@@ -115,6 +119,13 @@ __global__ __launch_bounds__(256, 1) void conv_row_lw_kernel(const ConvParams p)
     Tile cur, nxt;
     int c_tile = walk.t;
     decode(c_tile, cur);
+#ifdef KDCC_TUNING
+    // 1024 (tools/power_sweep.py): shader-clock and 100-MHz stamps around the whole workgroup -> the clock this kernel ran at
+    if ((p.tune & 1024) && tid == 0 && blockIdx.x < 512) {
+        lw_tlog[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime();
+        lw_tlog[blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 
     // ---- prologue: row buffer of period 0 and the B slots of its k-steps 0 .. 3 (generic pieces: 64-bit lane addresses, lanes
     // outside the image read the zero page) ---------------------------------------------------------------------------------------
@@ -215,6 +226,12 @@ __global__ __launch_bounds__(256, 1) void conv_row_lw_kernel(const ConvParams p)
     }
 #undef LW_ACC_RW
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the staging ran ahead of the last tile: nothing may land after the wave ends
+#ifdef KDCC_TUNING
+    if ((p.tune & 1024) && tid == 0 && blockIdx.x < 512) {
+        lw_tlog[blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memtime();
+        lw_tlog[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 

@@ -33,6 +33,23 @@ class GradReducer:
         if cur:
             self._close(cur)
         self._stream = None
+        self._set_conv_grid_cap()
+
+    # Workgroups the persistent conv kernels launch while this reducer exchanges buckets from inside backward.  Measured on one
+    # MI355X (tools/sidestream_probe.py -> profiles/r05_sidestream.json: the headline mode-A step with a stand-in exchange kernel
+    # per bucket on the side stream): a side-stream kernel that becomes runnable when a bucket's last gradient kernel retires
+    # starts 13 us later whether the conv grids hold 256, 248, 240 or 224 workgroups -- it is dispatched at the kernel boundary,
+    # ahead of the next conv launch's workgroups -- and it runs for the same 0.2 ms under the next conv launch either way, while
+    # every 8 CUs withheld from the conv kernels cost 3.3 % of the step (178.97 -> 184.93 -> 186.43 -> 190.99 ms).  So the cap this
+    # reducer sets for world > 1 is NONE (one workgroup per CU); KDCC_PERSIST_CUS in the environment still overrides it for an
+    # A/B on the 8-GPU node, where the exchange is a multi-step RCCL ring instead of one copy.
+    CONV_GRID_CAP = 0
+
+    def _set_conv_grid_cap(self):
+        import os
+        if self.world > 1 and torch.cuda.is_available() and "KDCC_PERSIST_CUS" not in os.environ:
+            from . import _lib
+            _lib.check(_lib.lib().kd_conv_set_persist_cus(self.CONV_GRID_CAP), "kd_conv_set_persist_cus")
 
     def _close(self, plist):
         dev = plist[0].device
