@@ -73,7 +73,7 @@ struct DwMfmaParams {
     int N, H, W, C, dil, ldx, ldy;
     int nty, ntx, ncg;
     int nitems, nseg;    // work items per (image, channel group); segments they are split into
-    int dbg;             // timing-only ablation hook (KDCC_DW_DBG): 1 = no MFMA phase, 2 = no output phase, 4 = no LDS fill of the next tile, 8 = no load requests, 16 = no output stores
+    int dbg;             // timing-only ablation hook (KDCC_DW_DBG): 1 = no MFMA phase, 2 = no output phase, 4 = no LDS fill of the next tile, 8 = no load requests, 16 = no output stores, 32 = no Toeplitz rebuild per branch, 64 = no workgroup barriers in the item loop
     LpGeom lp;           // lattice-planar operands (LP kernels: the fan-out's outputs, the summing kernel's inputs)
 };
 
@@ -237,8 +237,14 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
     Item wi = decode_item(p, cur);
     while (cur < iend && (wi.RV <= 0 || wi.CV <= 0)) { ++cur; if (cur < iend) wi = decode_item(p, cur); }
     if (cur >= iend) return;   // block-uniform
+    // Branch order: item i walks its NB branches forwards when i is even, backwards when it is odd, so that the branch an item ends
+    // on is the branch the next item starts with and its Toeplitz operands are still in registers: two rebuilds per item instead
+    // of three (a rebuild is 144 two-byte LDS reads per wave: 12 % of the fan-out launch, tools/dw_ablate.sh bit 32).  Tied to the
+    // item's index, not to the loop count, so the order -- and in the summing kernel the fp32 accumulation order -- of an item does
+    // not depend on how the items are split into segments.
+    auto brof = [&](int step, int item) { return (NB > 1 && (item & 1)) ? NB - 1 - step : step; };
     Staged st;
-    fetch_item<XLP>(p, xb0, wi, tid, st);
+    fetch_item<XLP>(p, FAN ? xb0 : rsrc_of(brof(0, cur)), wi, tid, st);
 
     // taps -> bf16 tables (loads issued together, then converted)
     {
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
 
     const int fi = lane & 15, kg = lane >> 4;
     uint4 B[2][9];
-    build_toeplitz(smem, 0, wave, fi, kg, B);
+    build_toeplitz(smem, brof(0, cur), wave, fi, kg, B);
 
     int buf = 0, b = 0;
     f32x4_t acc[2][2][4];
@@ -295,7 +301,8 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
         }
         if (nb == NB) nb = 0;
         const bool fetch = more && (!FAN || b == 0);
-        const __amdgpu_buffer_rsrc_t xn = FAN ? xb0 : rsrc_of(nb);
+        const int br_now = brof(b, cur), br_next = brof(nb, nb == 0 ? nxt : cur);   // branches of this step and of the next one
+        const __amdgpu_buffer_rsrc_t xn = FAN ? xb0 : rsrc_of(br_next);
 
         // ---- 2. MFMA ---------------------------------------------------------------------------------------------------------
         char *X = smem + buf * XBYTES;
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
         if (NB == 1 || FAN || last) {
             // every wave is done reading X (plain / sum: the output staging overwrites it) or is done reading the staging
             // of the previous output (fan-out: the staging lives in the idle second buffer, X stays for the next output)
-            __syncthreads();
+            if (!(p.dbg & 64)) __syncthreads();   // (64: timing ablation without the workgroup barriers of the item loop: races, wrong results)
 
             // ---- 3. accumulators -> [pixel][16 ch] bf16 -> NHWC --------------------------------------------------------------
             // staging rows are OPX pixels wide so the last (overlapping) column tile can be written whole; the 4-B channel
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
                     }
                 }
             }
-            __syncthreads();
+            if (!(p.dbg & 64)) __syncthreads();
             if (!(p.dbg & 2)) {
                 // thread = (8-channel half, column, row mod 4): no divisions, 16-B loads/stores
                 const int h = tid & 1, col = (tid >> 1) & 63, rq = tid >> 7;
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
                         const char *osrc = S + col * OSTR + ((h ^ ((col >> 2) & 1)) << 4);
                         const bool s1 = col & 1, s2 = col & 2;
                         // (buffer stores: the plane's base in SGPRs, one 32-bit cell offset per lane)
-                        const __amdgpu_buffer_rsrc_t yr = lattice_rsrc(NB > 2 && b == 2 ? p.ys[1] : (b == 1 ? p.ys[0] : p.y), p.lp, n, cgi);
+                        const __amdgpu_buffer_rsrc_t yr = lattice_rsrc(NB > 2 && br_now == 2 ? p.ys[1] : (br_now == 1 ? p.ys[0] : p.y), p.lp, n, cgi);
                         const uint32_t ocol = (uint32_t)(((wi.ry * d + wi.rx) * p.lp.Ly + wi.ty * TLY) * p.lp.Lx + wi.tx * TLX + col) * 32u + (uint32_t)h * 16u;
                         const uint32_t rstep = (uint32_t)p.lp.Lx * 32u;
 #pragma unroll
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
                     const int xx = wi.rx + d * (wi.tx * TLX + col);
                     const char *osrc = S + col * OSTR + ((h ^ ((col >> 2) & 1)) << 4);
                     const bool s1 = col & 1, s2 = col & 2;
-                    bf16_t *yb = FAN && NB > 2 && b == 2 ? p.ys[1] : (FAN && b == 1 ? p.ys[0] : p.y);
+                    bf16_t *yb = FAN && NB > 2 && br_now == 2 ? p.ys[1] : (FAN && br_now == 1 ? p.ys[0] : p.y);
                     bf16_t *ycol = yb + ((size_t)n * p.H * p.W + xx) * p.ldy + c0 + h * 8;
 #pragma unroll
                     for (int k = 0; k < (TLY + 3) / 4; ++k) {
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
             }
         }
         if (FAN && !last) {   // same tile, next output: only the operands change
-            build_toeplitz(smem, nb, wave, fi, kg, B);
+            if (!(p.dbg & 32)) build_toeplitz(smem, br_next, wave, fi, kg, B);   // (32: timing ablation, stale operands)
             b = nb;
             continue;
         }
@@ -417,11 +424,11 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
         // ---- 4. prefetched registers -> the other X buffer ---------------------------------------------------------------------
         // (plain / sum: last read two steps ago, behind that step's closing barrier; fan-out: it held the output staging the
         // waves have just been reading)
-        if (FAN) __syncthreads();
+        if (FAN && !(p.dbg & 64)) __syncthreads();
         buf ^= 1;
         if (!(p.dbg & 4)) write_item(smem + buf * XBYTES, tid, st);
-        if (NB > 1) build_toeplitz(smem, nb, wave, fi, kg, B);
-        __syncthreads();
+        if (NB > 1 && br_next != br_now && !(p.dbg & 32)) build_toeplitz(smem, br_next, wave, fi, kg, B);   // (equal across an item boundary)
+        if (!(p.dbg & 64)) __syncthreads();
         cur = nxt;
         wi = wn;
         b = nb;
