@@ -435,302 +435,6 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
     }
 }
 
-// ---- the same arithmetic, TWO independent workgroups per CU ---------------------------------------------------------------------
-// profiles/r05_dw_anatomy.md: with every load and store removed the fan-out launch above still takes 4.3 of its 4.9 ms -- a work item is
-// a chain of serial phases in ONE lock-step workgroup per CU (matrix phases at their floor for 27 % of the time; Toeplitz rebuilds,
-// eight barriers, LDS fills and output staging with the matrix pipes idle for the rest).  Here a workgroup is 4 waves and needs half
-// the LDS, so two of them share a CU and one's barriers / rebuilds / staging run under the other's MFMAs:
-//   * half-height work items (13 lattice rows, 21 staged): ONE X buffer of 42.7 KiB (the next item waits in registers, as above) + an
-//     output staging of its own (22.75 KiB: the fan-out keeps X across its outputs) + the tap tables = 79 KiB;
-//   * a wave owns 4 of the 16 channels as two passes of two (the Toeplitz operands of two channels fill the registers); the passes and
-//     branches of an item are walked in a snake whose direction alternates from item to item, so the operands an item ends on are the
-//     ones the next item starts with: 3 NB - 1 rebuilds per item;
-//   * 16 output rows per MFMA for 13 valid ones: rows 13-15 read past the staged rows into the staging area (finite or not: an MFMA
-//     output row depends on its own A row only) and are never stored.
-// Same values as dw_mfma_fwd_kernel bit for bit (per output element the same nine accumulation steps in the same order; the summing
-// form adds its inputs in the order the snake gives the item, which like there depends on the item's index only).
-constexpr int NT2 = 256, TLY2 = 13, RY2 = TLY2 + 8;
-constexpr int X2BYTES = (RY2 * RSTR + 64 + 15) & ~15;
-constexpr int ST2BYTES = TLY2 * OPX * OSTR;
-constexpr int DUO_LDS = X2BYTES + ST2BYTES;          // + WTBYTES per branch
-constexpr int ITEMS2 = RY2 * 64;                     // stage-in units per work item
-constexpr int NIT2 = (ITEMS2 + NT2 - 1) / NT2;
-static_assert(NIT2 == 6, "fetch_item2 / the interleaved fetch are written for 6 units per thread");
-static_assert(2 * (DUO_LDS + MAXB * WTBYTES) <= 160 * 1024, "two workgroups per CU");
-
-struct Staged2 {
-    uint4 a[NIT2], b[NIT2];
-    uint32_t ok[NIT2];
-};
-
-__device__ __forceinline__ Item decode_item2(const DwMfmaParams &p, int e)
-{
-    Item it;
-    const int d = p.dil;
-    it.rx = e % d; e /= d;
-    it.ry = e % d; e /= d;
-    it.tx = e % p.ntx;
-    it.ty = e / p.ntx;
-    const int Ly = (p.H - it.ry + d - 1) / d, Lx = (p.W - it.rx + d - 1) / d;
-    it.RV = min(TLY2, Ly - it.ty * TLY2);
-    it.CV = min(TLX, Lx - it.tx * TLX);
-    return it;
-}
-
-__device__ __forceinline__ void fetch_unit2(int it, const DwMfmaParams &p, __amdgpu_buffer_rsrc_t xr, const Item &w, int tid, Staged2 &s)
-{
-    const int d = p.dil;
-    const int unit = tid + it * NT2;
-    const int h = unit & 1, lp = (unit >> 1) & 31, r = unit >> 6;
-    const int ly = w.ty * TLY2 + r - 4, lx = w.tx * TLX + 2 * lp - 4;
-    const int yy = w.ry + d * ly, xa = w.rx + d * lx, xb2 = xa + d;
-    const bool rok = ly >= 0 && yy < p.H && lp < 30 && unit < ITEMS2;
-    const bool aok = rok && lx >= 0 && xa < p.W, bok = rok && lx + 1 >= 0 && xb2 < p.W;
-    const uint32_t pb = (uint32_t)p.ldx * 2u;
-    const uint32_t oa = (uint32_t)(yy * p.W + xa) * pb + (uint32_t)h * 16u;
-    s.a[it] = bload16(xr, aok ? oa : BUF_OOB);
-    s.b[it] = bload16(xr, bok ? oa + (uint32_t)d * pb : BUF_OOB);
-    s.ok[it] = (aok ? 0x0000ffffu : 0u) | (bok ? 0xffff0000u : 0u);
-}
-
-__device__ __forceinline__ void write_item2(char *X, int tid, const Staged2 &s)
-{
-    for (int e = tid; e < RY2 * 8 + 16; e += NT2) {   // row pads + tail: K padding, must be finite
-        const int r = e >> 3;
-        if (r < RY2) *(uint32_t *)(X + r * RSTR + CG * CSTR + (e & 7) * 4) = 0u;
-        else *(uint32_t *)(X + RY2 * RSTR + (e - RY2 * 8) * 4) = 0u;
-    }
-#pragma unroll
-    for (int it = 0; it < NIT2; ++it) {
-        const int unit = tid + it * NT2;
-        if (unit < ITEMS2) {
-            const int h = unit & 1, lp = (unit >> 1) & 31, r = unit >> 6;
-            char *dst = X + r * RSTR + (h * 8) * CSTR + lp * 4;
-            const uint32_t a[4] = {s.a[it].x, s.a[it].y, s.a[it].z, s.a[it].w};
-            const uint32_t b[4] = {s.b[it].x, s.b[it].y, s.b[it].z, s.b[it].w};
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                *(uint32_t *)(dst + (2 * m) * CSTR) = ((a[m] & 0xffffu) | (b[m] << 16)) & s.ok[it];
-                *(uint32_t *)(dst + (2 * m + 1) * CSTR) = ((a[m] >> 16) | (b[m] & 0xffff0000u)) & s.ok[it];
-            }
-        }
-    }
-}
-
-// Toeplitz operands of channels (ch, ch + 1) of the group from the bf16 tap table of branch `b`
-__device__ __forceinline__ void build_toeplitz2(const char *taps, int b, int ch, int fi, int kg, uint4 (&B)[2][9])
-{
-    int widx[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int kx = kg * 8 + q - fi;
-        widx[q] = (kx >= 0 && kx < 9 ? kx : 15) * 2;
-    }
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-        for (int ky = 0; ky < 9; ++ky) {
-            const char *wr = taps + b * WTBYTES + ((ch + cc) * 9 + ky) * 32;
-            uint32_t v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = *(const bf16_t *)(wr + widx[q]);
-            B[cc][ky] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
-        }
-}
-
-template <int NB, bool FAN>
-__global__ __launch_bounds__(NT2, 2) void dw_mfma_fwd_duo_kernel(DwMfmaParams p)
-{
-    static_assert(NB >= 1 && NB <= MAXB && (NB > 1 || !FAN), "one to three inputs (sum) or outputs (fan-out)");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *const X = smem, *const S = smem + X2BYTES, *const taps = smem + DUO_LDS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int lin = xcd_remap(blockIdx.x, gridDim.x);
-    const int cgi = lin % p.ncg; lin /= p.ncg;
-    const int seg = lin % p.nseg;
-    const int n = lin / p.nseg;
-    const int c0 = cgi * CG;
-    const int ibeg = (int)((long long)p.nitems * seg / p.nseg), iend = (int)((long long)p.nitems * (seg + 1) / p.nseg);
-    const size_t img = (size_t)n * p.H * p.W * p.ldx + c0;
-    const __amdgpu_buffer_rsrc_t xb0 = image_rsrc(p.x + img, p.H, p.W, p.ldx);
-    const __amdgpu_buffer_rsrc_t xb1 = image_rsrc((NB > 1 && !FAN ? p.xs[0] : p.x) + img, p.H, p.W, p.ldx);
-    const __amdgpu_buffer_rsrc_t xb2 = image_rsrc((NB > 2 && !FAN ? p.xs[1] : p.x) + img, p.H, p.W, p.ldx);
-    auto rsrc_of = [&](int b) { return NB > 2 && b == 2 ? xb2 : (NB > 1 && b == 1 ? xb1 : xb0); };
-    const int d = p.dil;
-
-    int cur = ibeg;
-    Item wi = decode_item2(p, cur);
-    while (cur < iend && (wi.RV <= 0 || wi.CV <= 0)) { ++cur; if (cur < iend) wi = decode_item2(p, cur); }
-    if (cur >= iend) return;   // block-uniform
-    // the snake: an item has 2 NB steps (branch, pass); even items walk them forwards, odd items backwards
-    auto step_of = [&](int t, int item, int &br, int &ps) {
-        const int u = (item & 1) ? 2 * NB - 1 - t : t;
-        br = u >> 1;
-        ps = (u & 1) ^ (br & 1);           // (0,0) (0,1) (1,1) (1,0) (2,0) (2,1)
-    };
-    int br, ps;
-    step_of(0, cur, br, ps);
-    Staged2 st;
-#pragma unroll
-    for (int it = 0; it < NIT2; ++it) fetch_unit2(it, p, FAN ? xb0 : rsrc_of(br), wi, tid, st);
-
-    {   // taps -> bf16 tables [branch][channel][ky][16]
-        constexpr int NW = (CG * 81 + NT2 - 1) / NT2;
-        bf16_t *wt = (bf16_t *)taps;
-        for (int e = tid; e < NB * CG * 9 * 16; e += NT2) wt[e] = 0;
-        __syncthreads();
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const float *wsrc = b == 0 ? p.w : p.ws[b > 0 ? b - 1 : 0];
-#pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                const int e = tid + i * NT2;
-                if (e < CG * 81) {
-                    const int c = e & 15, tap = e >> 4, ky = tap / 9, kx = tap - ky * 9;
-                    wt[b * (WTBYTES / 2) + (c * 9 + ky) * 16 + kx] = f32_to_bf16(wsrc[(size_t)tap * p.C + c0 + c]);
-                }
-            }
-        }
-    }
-    write_item2(X, tid, st);
-    __syncthreads();
-
-    const int fi = lane & 15, kg = lane >> 4;
-    uint4 B[2][9];
-    build_toeplitz2(taps, br, 4 * wave + 2 * ps, fi, kg, B);
-    int have_br = br, have_ps = ps;
-
-    f32x4_t acc[FAN ? 1 : 2][2][4];      // fan-out: one pass at a time (staged right away); sum: both passes live across the inputs
-    int tb = 0;                          // position of the branch in the item's order
-    int nxt = cur;
-    Item wn = wi;
-    bool more = false;
-    while (true) {                       // one iteration = one branch of the item = two passes
-        // ---- what comes next: the next item (fan-out: looked up at the item's first branch; sum: at its last)
-        if (FAN ? tb == 0 : tb == NB - 1) {
-            nxt = cur + 1;
-            if (nxt < iend) wn = decode_item2(p, nxt);
-            while (nxt < iend && (wn.RV <= 0 || wn.CV <= 0)) { ++nxt; if (nxt < iend) wn = decode_item2(p, nxt); }
-            more = nxt < iend;
-        }
-        // prefetch during this branch: fan-out -- the next item, under the item's first branch; sum -- the tile of the next
-        // (item, branch); three of its six units per pass
-        const bool wraps = tb == NB - 1;                        // the next branch belongs to the next item
-        int nbr, nps;
-        step_of(wraps ? 0 : 2 * (tb + 1), wraps ? nxt : cur, nbr, nps);
-        const bool fetch = FAN ? (more && tb == 0) : (wraps ? more : true);
-        Item wf = wi;                                           // (by value: a reference picked at run time would put both in memory)
-        if (FAN || wraps) wf = wn;
-        const __amdgpu_buffer_rsrc_t xn = FAN ? xb0 : rsrc_of(nbr);
-        const int CV = wi.CV, RV = wi.RV;
-        const int njt = (CV + 15) >> 4;
-        const int jlast = max(((CV + 7) & ~7) - 16, 0);
-        const bool last_input = tb == NB - 1;
-
-        // accumulators of a pass -> staging [pixel][16 ch]
-        auto stage_pass = [&](const f32x4_t (&R)[2][4], int pass) __attribute__((always_inline)) {
-            char *ob = S + ((kg * 4) * OPX + fi) * OSTR;
-            const int slot = 2 * wave + pass;
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                if (jt < njt) {
-                    const int cb = min(jt * 16, jlast);
-                    char *o = ob + cb * OSTR + ((slot ^ ((cb + fi) & 7)) << 2);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (kg * 4 + r < TLY2) *(uint32_t *)(o + r * OPX * OSTR) = pack_bf16x2(R[0][jt][r], R[1][jt][r]);
-                }
-            }
-        };
-        // one pass (J = 0, 1: the unit numbers of the interleaved fetch are compile-time constants, so the staging registers are never
-        // indexed dynamically -- a run-time choice between two unit numbers sends the whole struct to scratch memory)
-        auto do_pass = [&](auto jtag) __attribute__((always_inline)) {
-            constexpr int J = decltype(jtag)::value;
-            step_of(2 * tb + J, cur, br, ps);
-            if (have_br != br || have_ps != ps) {
-                if (!(p.dbg & 32)) build_toeplitz2(taps, br, 4 * wave + 2 * ps, fi, kg, B);
-                have_br = br; have_ps = ps;
-            }
-            auto mfma_pass = [&](f32x4_t (&A)[2][4]) __attribute__((always_inline)) {
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    const char *xc = X + (4 * wave + 2 * ps + cc) * CSTR + kg * 16;
-#pragma unroll
-                    for (int jt = 0; jt < 4; ++jt) {
-                        if (NB == 1 || FAN || tb == 0) A[cc][jt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                        const int stp = cc * 4 + jt;
-                        if (fetch) {
-                            if (stp == 0) fetch_unit2(3 * J + 0, p, xn, wf, tid, st);
-                            if (stp == 3) fetch_unit2(3 * J + 1, p, xn, wf, tid, st);
-                            if (stp == 6) fetch_unit2(3 * J + 2, p, xn, wf, tid, st);
-                        }
-                        if (jt < njt && !(p.dbg & 1)) {
-                            const char *xa = xc + fi * RSTR + min(jt * 16, jlast) * 2;
-#pragma unroll
-                            for (int ky = 0; ky < 9; ++ky) {
-                                const uint4 a = *(const uint4 *)(xa + ky * RSTR);
-                                Mma<bf16_t>::run(a, B[cc][ky], A[cc][jt]);
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                }
-            };
-            // (the two accumulator sets of the summing form are picked by a branch, not by an index: they must stay in registers)
-            if (FAN || ps == 0) mfma_pass(acc[0]);
-            else mfma_pass(acc[FAN ? 0 : 1]);
-            if constexpr (FAN) {
-                // (the staging was last read by the previous output's store phase: behind that phase's closing barrier)
-                if (!(p.dbg & 2)) stage_pass(acc[0], ps);
-            }
-        };
-        do_pass(std::integral_constant<int, 0>{});
-        do_pass(std::integral_constant<int, 1>{});
-        if constexpr (!FAN) {
-            if (last_input && !(p.dbg & 2)) { stage_pass(acc[0], 0); stage_pass(acc[FAN ? 0 : 1], 1); }
-        }
-        if (!FAN && !last_input) {
-            // sum: every wave is done with this input's tile -> the next input's tile (in registers) replaces it
-            if (!(p.dbg & 64)) __syncthreads();
-            if (!(p.dbg & 4)) write_item2(X, tid, st);
-            if (!(p.dbg & 64)) __syncthreads();
-        }
-        if (FAN || last_input) {
-            if (!(p.dbg & 64)) __syncthreads();      // staging complete; (last output / sum: every wave is done with X as well)
-            const bool refill = more && last_input;
-            if (refill && !(p.dbg & 4)) write_item2(X, tid, st);     // the next item's tile, under the stores below
-            if (!(p.dbg & 2)) {
-                const int h = tid & 1, col = (tid >> 1) & 63, rq = tid >> 7;
-                if (col < CV) {
-                    const int xx = wi.rx + d * (wi.tx * TLX + col);
-                    const char *osrc = S + col * OSTR + ((h ^ ((col >> 2) & 1)) << 4);
-                    const bool s1 = col & 1, s2 = col & 2;
-                    bf16_t *yb = FAN && NB > 2 && br == 2 ? p.ys[1] : (FAN && br == 1 ? p.ys[0] : p.y);
-                    bf16_t *ycol = yb + ((size_t)n * p.H * p.W + xx) * p.ldy + c0 + h * 8;
-#pragma unroll
-                    for (int k = 0; k < (TLY2 + 1) / 2; ++k) {
-                        const int row = rq + 2 * k;
-                        if (row < RV) {
-                            const uint4 o = *(const uint4 *)(osrc + row * OPX * OSTR);
-                            const uint32_t a0 = s1 ? o.y : o.x, a1 = s1 ? o.x : o.y, a2 = s1 ? o.w : o.z, a3 = s1 ? o.z : o.w;
-                            const int yy = wi.ry + d * (wi.ty * TLY2 + row);
-                            if (!(p.dbg & 16)) *(uint4 *)(ycol + (size_t)yy * p.W * p.ldy) = make_uint4(s2 ? a2 : a0, s2 ? a3 : a1, s2 ? a0 : a2, s2 ? a1 : a3);
-                        }
-                    }
-                }
-            }
-            if (!(p.dbg & 64)) __syncthreads();      // staging free again / the refilled tile is published
-        }
-        // ---- advance ------------------------------------------------------------------------------------------------------------
-        if (++tb == NB) {
-            if (!more) break;
-            tb = 0;
-            cur = nxt;
-            wi = wn;
-        }
-    }
-}
-
 // ---- weight gradient -----------------------------------------------------------------------------------------------------
 // dW[ky][kx] = sum_{ly,lx} g[ly][lx] * x[ly + ky - 4][lx + kx - 4] on every residue lattice.  One MFMA per (staged x
 // row R, block of 32 lattice columns, channel):
@@ -1166,21 +870,6 @@ static void dw_mfma_split3(int N, int C, int H, int W, int dil, int *nty, int *n
     *nseg = (int)s;
 }
 
-static void dw_mfma_split2(int N, int C, int H, int W, int dil, int *nty, int *ntx, int *nitems, int *nseg)
-{
-    const int LH = (H + dil - 1) / dil, LW = (W + dil - 1) / dil;
-    *nty = (LH + TLY2 - 1) / TLY2;
-    *ntx = (LW + TLX - 1) / TLX;
-    const long long ni = (long long)*nty * *ntx * dil * dil;
-    *nitems = ni > (1 << 24) ? 0 : (int)ni;
-    // two workgroups per CU: aim at two rounds of 512, keep >= 4 items per workgroup
-    const long long groups = (long long)N * (C / CG);
-    long long s = (1024 + groups - 1) / groups;
-    if (s > ni / 4) s = ni / 4;
-    if (s < 1) s = 1;
-    *nseg = (int)s;
-}
-
 static void dw_mfma_split(int N, int C, int H, int W, int dil, int *nty, int *ntx, int *nitems, int *nseg)
 {
     const int LH = (H + dil - 1) / dil, LW = (W + dil - 1) / dil;
@@ -1276,39 +965,8 @@ int kd_internal_dw_mfma_fwd_n(const kd_dw_desc *d, int nb, int fan, const void *
     { static int dbg = -1; if (dbg < 0) dbg = KD_TUNING_ENV_INT("KDCC_DW_DBG"); p.dbg = dbg; }   // phase ablations: tuning build only
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.dil = d->dil; p.ldx = d->ldx; p.ldy = d->ldy;
     p.lp = lp_geom(d);
-    // two independent 4-wave workgroups per CU on half-height items (dw_mfma_fwd_duo_kernel): measured SLOWER (fan-out 5.23 vs 4.78 ms,
-    // sum 12.0 vs 4.32 with 47 spilled registers; profiles/r05_dw_anatomy.md) -- opt-in for A/B: KDCC_DW_DUO=1
-    static int duo = -1;
-    if (duo < 0) { const char *e = getenv("KDCC_DW_DUO"); duo = (e && e[0] == '1') ? 1 : 0; }
-    if (duo && !lp && nb >= 2) {   // (one branch: the 8-wave kernel below; its second accumulator set spills here)
-        dw_mfma_split2(d->N, d->C, d->H, d->W, d->dil, &p.nty, &p.ntx, &p.nitems, &p.nseg);
-        p.ncg = d->C / CG;
-        if (p.nitems <= 0) return 0;
-        const long long blocks2 = (long long)d->N * p.ncg * p.nseg;
-        if (blocks2 > 0x7fffffffLL || (long long)d->N * d->H * d->W > 0x7fffffffLL) return 0;
-        const int lds2 = DUO_LDS + nb * WTBYTES;
-        typedef void (*kern2_t)(DwMfmaParams);
-        const kern2_t fn2 = nb == 1 ? dw_mfma_fwd_duo_kernel<1, false>
-                          : nb == 2 ? (fan ? dw_mfma_fwd_duo_kernel<2, true> : dw_mfma_fwd_duo_kernel<2, false>)
-                                    : (fan ? dw_mfma_fwd_duo_kernel<3, true> : dw_mfma_fwd_duo_kernel<3, false>);
-        static bool attr2[2][MAXB + 1] = {};
-        if (!attr2[fan ? 1 : 0][nb]) {
-            if (hipFuncSetAttribute((const void *)fn2, hipFuncAttributeMaxDynamicSharedMemorySize, lds2) != hipSuccess) {
-                kd_set_error("kd_dwconv_fwd: cannot reserve %d B of LDS", lds2);
-                return KD_ERR_HIP;
-            }
-            attr2[fan ? 1 : 0][nb] = true;
-        }
-        KD_NOTE_KERNEL(nb == 1 ? "dw_mfma_fwd_duo_kernel<1,false>" : nb == 2 ? (fan ? "dw_mfma_fwd_duo_kernel<2,true>" : "dw_mfma_fwd_duo_kernel<2,false>")
-                               : (fan ? "dw_mfma_fwd_duo_kernel<3,true>" : "dw_mfma_fwd_duo_kernel<3,false>"));
-        hipLaunchKernelGGL(fn2, dim3((unsigned)blocks2), dim3(NT2), lds2, s, p);
-        hipError_t err2 = hipGetLastError();
-        if (err2 != hipSuccess) {
-            kd_set_error("kd_dwconv_fwd(mfma duo): launch failed: %s", hipGetErrorString(err2));
-            return KD_ERR_HIP;
-        }
-        return 1;
-    }
+    // (a second, independent workgroup per CU on half-height items was built and measured slower -- the Toeplitz rebuilds multiply:
+    // profiles/r05_dw_anatomy.md, commit dc356ad)
     dw_mfma_split(d->N, d->C, d->H, d->W, d->dil, &p.nty, &p.ntx, &p.nitems, &p.nseg);
     p.ncg = d->C / CG;
     if (p.nitems <= 0) return 0;
