@@ -21,6 +21,7 @@ from ..parallel import mean_scalar
 from ..utils import CityscapesMetricTracker, EarlyStopTracker, MetricTracker, inf_loop
 from ..utils import optim as optim_module
 from ..utils.optim.lr_scheduler import MyOneCycleLR, MyReduceLROnPlateau
+from ..utils.plan_schedule import PlanSchedule
 
 _LOSS_KEYS = ('loss', 'supervised_loss', 'kd_loss', 'hint_loss', 'teacher_loss')
 
@@ -66,75 +67,69 @@ class LayerwiseTrainer(BaseTrainer):
             self.resume(self.config['trainer']['resume_path'])
 
     # ------------------------------------------------------------------ epoch preparation (host side)
+    def _schedule(self, config=None):
+        """config['pruning'] as a table {epoch: Stage} (utils/plan_schedule.py), read once per config object."""
+        config = self.config if config is None else config
+        cached = self.__dict__.get('_plan_schedule')
+        if cached is None or cached[0] is not config:
+            cached = (config, PlanSchedule(config['pruning']))
+            self._plan_schedule = cached
+        return cached[1]
+
     def prepare_train_epoch(self, epoch, config=None):
-        """Apply the plan entries scheduled for `epoch`: replace layers, (re)register hints, unfreeze, fix the optimizer."""
-        if config is None:
-            config = self.config
+        """Start of an epoch (reference trainer/layerwise_trainer.py:72-145): trackers and schedulers start over, then the stage the plan
+        schedules for this epoch -- if any -- is applied to the student and the optimizer is made to match the new trainable set."""
+        schedule = self._schedule(config)
         self.reset_scheduler()
-        pruning = config['pruning']
-        if (epoch == 1) and (len(pruning['pruning_plan']) + len(pruning['hint']) + len(pruning['unfreeze'])) == 0:
-            self.logger.debug('Train a student with identical architecture with teacher')
+        stage = schedule.stage(epoch)
+        self.logger.info('EPOCH: ' + str(epoch))
+        if stage is None:
+            self.logger.info('the plan schedules nothing for this epoch')
+            return
+        for line in stage.describe():
+            self.logger.info(line)
+        if stage.train_everything:
             for param in self.model.student.parameters():
                 param.requires_grad = True
-            self.logger.info(self.model.dump_trainable_params())
-            self.create_new_optimizer()
-            return
-        epochs = [x['epoch'] for x in pruning['pruning_plan'] + pruning['hint'] + pruning['unfreeze']]
-        if epoch not in epochs:
-            self.logger.info('EPOCH: ' + str(epoch))
-            self.logger.info('There is no update ...')
-            return
-        replaced_layers = [x for x in pruning['pruning_plan'] if x['epoch'] == epoch]
-        hint_layers = [x['name'] for x in pruning['hint'] if x['epoch'] == epoch]
-        unfreeze_cfg = [x for x in pruning['unfreeze'] if x['epoch'] == epoch]
-        unfreeze_layers = [x['name'] for x in unfreeze_cfg]
-        self.logger.info('EPOCH: ' + str(epoch))
-        self.logger.info('Replaced layers: ' + str(replaced_layers))
-        self.logger.info('Hint layers: ' + str(hint_layers))
-        self.logger.info('Unfreeze layers: ' + str(unfreeze_layers))
-        if 'args' in pruning:
-            kwargs = pruning['args']
         else:
-            self.logger.warning('Using deprecate checkpoint...')
-            kwargs = pruning['pruner']
-        self.model.replace(replaced_layers, **kwargs)
-        self.model.register_hint_layers(hint_layers)
-        self.model.unfreeze(unfreeze_layers)
+            if schedule.deprecated_kwargs:
+                self.logger.warning("config['pruning'] has no 'args': taking the block arguments from 'pruner' (old checkpoint)")
+            self.model.replace(stage.replace, **schedule.block_kwargs)
+            self.model.register_hint_layers(stage.hints)
+            self.model.unfreeze(stage.unfreeze_names)
         if epoch == 1:
-            self.create_new_optimizer()   # fresh optimizer: no stale momentum (the one passed to __init__ is discarded)
+            self.create_new_optimizer()           # fresh optimizer and LR scheduler: the ones passed to __init__ never saw these parameters
         else:
-            self.update_optimizer(unfreeze_cfg)
-        self._reducer = None              # trainable set changed: rebuild the gradient buckets lazily
+            self.update_optimizer(stage.unfreeze)
+        self._reducer = None                      # trainable set changed: rebuild the gradient buckets lazily
         self.logger.info(self.model.dump_trainable_params())
-        self.logger.info(self.model.dump_student_teacher_blocks_info())
+        if not stage.train_everything:
+            self.logger.info(self.model.dump_student_teacher_blocks_info())
 
     def update_optimizer(self, unfreeze_config):
-        """Add the newly unfrozen layers as param groups ({'name':..., 'epoch':..., 'lr'(optional): ...})."""
-        if len(unfreeze_config) > 0:
-            self.logger.debug('Updating optimizer for new layer')
-        for cfg in unfreeze_config:
-            self.logger.debug('Add parameters of layer: {} to optimizer'.format(cfg['name']))
-            layer = self.model.get_block(cfg['name'], self.model.student)
-            optimizer_arg = self.config['optimizer']['args']
-            if "lr" in cfg:
-                optimizer_arg['lr'] = cfg['lr']
-            self.optimizer.add_param_group({'params': layer.parameters(), **optimizer_arg})
+        """One new param group per layer unfrozen after epoch 1 (entries {'name', 'epoch', ['lr']}): the optimizer's configured
+        arguments, with the entry's own learning rate when it names one (reference :152-173)."""
+        for entry in unfreeze_config:
+            group = dict(self.config['optimizer']['args'])
+            if 'lr' in entry:
+                group['lr'] = entry['lr']
+                self.config['optimizer']['args']['lr'] = entry['lr']   # (the reference overwrites its config dict: later groups inherit it)
+            group['params'] = list(self.model.get_block(entry['name'], self.model.student).parameters())
+            self.logger.debug('optimizer: + {} ({} tensors, lr {})'.format(entry['name'], len(group['params']), group.get('lr')))
+            self.optimizer.add_param_group(group)
 
     def create_new_optimizer(self):
-        self.logger.debug('Creating new optimizer ...')
-        self.optimizer = self.config.init_obj('optimizer', optim_module,
-                                              [p for p in self.model.student.parameters() if p.requires_grad])
+        """Optimizer and LR scheduler built from the config over what is trainable NOW (reference :175-188)."""
+        trainable = [p for p in self.model.student.parameters() if p.requires_grad]
+        self.optimizer = self.config.init_obj('optimizer', optim_module, trainable)
         self.lr_scheduler = self.config.init_obj('lr_scheduler', optim_module.lr_scheduler, self.optimizer)
+        self.logger.debug('optimizer rebuilt over {} tensors'.format(len(trainable)))
 
     def reset_scheduler(self):
-        """Reset schedulers, metrics and trackers when new layers are unfrozen."""
-        self.weight_scheduler.reset()
-        self.val_iou_tracker.reset()
-        self.train_metrics.reset()
-        self.valid_metrics.reset()
-        self.train_iou_metrics.reset()
-        self.valid_iou_metrics.reset()
-        self.train_teacher_iou_metrics.reset()
+        """Everything that tracks progress within a stage starts over (reference :190-201)."""
+        for tracker in (self.weight_scheduler, self.val_iou_tracker, self.train_metrics, self.valid_metrics, self.train_iou_metrics,
+                        self.valid_iou_metrics, self.train_teacher_iou_metrics):
+            tracker.reset()
         if isinstance(self.lr_scheduler, MyReduceLROnPlateau):
             self.lr_scheduler.reset()
 

@@ -21,6 +21,7 @@ from ..parallel import mean_scalar
 from ..utils import ImportanceFilterTracker
 from ..utils.optim.lr_scheduler import MyOneCycleLR, MyReduceLROnPlateau
 from .layerwise_trainer import LayerwiseTrainer
+from ..utils.plan_schedule import PlanSchedule
 
 
 class TaylorPruneTrainer(LayerwiseTrainer):
@@ -38,24 +39,26 @@ class TaylorPruneTrainer(LayerwiseTrainer):
         else:
             self.optimizer = None   # nothing trainable (a plan without gates): importance tracking only
 
+    def _schedule(self, config=None):
+        config = self.config if config is None else config
+        cached = self.__dict__.get('_plan_schedule')
+        if cached is None or cached[0] is not config:
+            cached = (config, PlanSchedule(config['pruning'], which=('pruning_plan',)))   # only the plan opens a stage here (reference :75-131)
+            self._plan_schedule = cached
+        return cached[1]
+
     def prepare_train_epoch(self, epoch, config=None):
-        """Gate the layers scheduled for `epoch` (reference :75-131: only `pruning_plan` decides whether anything happens)."""
-        if config is None:
-            config = self.config
-        pruning = config['pruning']
-        if epoch not in [x['epoch'] for x in pruning['pruning_plan']]:
-            self.logger.info('EPOCH: ' + str(epoch))
-            self.logger.info('There is no update ...')
-            return
-        gated_layers = [x for x in pruning['pruning_plan'] if x['epoch'] == epoch]
+        """Gate the layers the plan schedules for `epoch`; trackers start over afterwards."""
+        schedule = self._schedule(config)
+        stage = schedule.stage(epoch)
         self.logger.info('EPOCH: ' + str(epoch))
-        self.logger.info('Replaced layers: ' + str(gated_layers))
-        if 'args' in pruning:
-            kwargs = pruning['args']
-        else:
-            self.logger.warning('Using deprecate checkpoint...')
-            kwargs = pruning['pruner']
-        self.model.replace(gated_layers, **kwargs)
+        if stage is None or stage.train_everything:
+            self.logger.info('the plan schedules nothing for this epoch')
+            return
+        self.logger.info('gate ' + str(stage.replace))
+        if schedule.deprecated_kwargs:
+            self.logger.warning("config['pruning'] has no 'args': taking the gate arguments from 'pruner' (old checkpoint)")
+        self.model.replace(stage.replace, **schedule.block_kwargs)
         self.importance_tracker.update_importance_list(self.model.added_gates)
         if epoch == 1 or self.optimizer is None:
             self.create_new_optimizer()
@@ -67,11 +70,11 @@ class TaylorPruneTrainer(LayerwiseTrainer):
             known = {id(p) for g in self.optimizer.param_groups for p in g['params']}
             fresh = [p for p in self.model.student.parameters() if p.requires_grad and id(p) not in known]
             if fresh:
-                self.logger.debug('Add {} new gate tensors to the optimizer'.format(len(fresh)))
+                self.logger.debug('optimizer: + {} new gate tensors'.format(len(fresh)))
                 self.optimizer.add_param_group({'params': fresh, **self.config['optimizer']['args']})
-            self.update_optimizer([x for x in pruning.get('unfreeze', []) if x['epoch'] == epoch
-                                   and not any(id(q) in {id(f) for f in fresh}
-                                               for q in self.model.get_block(x['name'], self.model.student).parameters())])
+            fresh_ids = {id(f) for f in fresh}
+            self.update_optimizer([e for e in stage.unfreeze
+                                   if not any(id(q) in fresh_ids for q in self.model.get_block(e['name'], self.model.student).parameters())])
         self._reducer = None              # trainable set changed: rebuild the gradient buckets lazily
         self.logger.info(self.model.dump_trainable_params())
         self.logger.info(self.model.dump_student_teacher_blocks_info())

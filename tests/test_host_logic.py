@@ -214,3 +214,30 @@ def test_sliding_window_merge_matches_reference_reverse_mapping(golden):
     cursor[0] = 0
     px = model.inference_test(img.unsqueeze(0), {"scales": [1.0], "crop_size": crop, "window_count": "pixel"})
     assert not torch.allclose(px[0], ref, rtol=1e-3, atol=1e-3, equal_nan=True)
+
+
+def test_plan_schedule_table():
+    """utils/plan_schedule.py: config['pruning'] read once into {epoch: Stage} with the reference's semantics
+    (trainer/layerwise_trainer.py:72-145): an entry acts at the start of its epoch; an empty section = identical architecture."""
+    from kdcc_amd.utils.plan_schedule import PlanSchedule
+    pruning = {"args": {"kernel_size": 9, "padding": 20, "dilation": 5},
+               "pruning_plan": [{"name": "mod4.block2.convs.conv2", "epoch": 1}, {"name": "aspp.features.1.0", "epoch": 3}],
+               "hint": [{"name": "mod4.block2.convs.conv2", "epoch": 1}, {"name": "aspp.features.1.0", "epoch": 3}],
+               "unfreeze": [{"name": "mod4.block2.convs.conv2", "epoch": 1}, {"name": "aspp.features.1.0", "epoch": 3, "lr": 1e-3},
+                            {"name": "mod5.block1", "epoch": 5}]}
+    s = PlanSchedule(pruning)
+    assert s.epochs == [1, 3, 5] and not s.identical_architecture and not s.deprecated_kwargs
+    assert s.block_kwargs == {"kernel_size": 9, "padding": 20, "dilation": 5}
+    assert s.stage(2) is None and s.stage(4) is None
+    st = s.stage(3)
+    assert [e["name"] for e in st.replace] == ["aspp.features.1.0"] and st.hints == ["aspp.features.1.0"]
+    assert st.unfreeze_names == ["aspp.features.1.0"] and st.unfreeze[0]["lr"] == 1e-3
+    st5 = s.stage(5)
+    assert st5.replace == [] and st5.hints == [] and st5.unfreeze_names == ["mod5.block1"]     # an unfreeze-only stage
+    # the Taylor trainer: only plan entries open a stage, the other lists ride along
+    t = PlanSchedule(pruning, which=("pruning_plan",))
+    assert t.epochs == [1, 3] and t.stage(5) is None and t.stage(3).unfreeze_names == ["aspp.features.1.0"]
+    # identical architecture, and the deprecated key of old checkpoints
+    e = PlanSchedule({"pruning_plan": [], "hint": [], "unfreeze": [], "pruner": {"kernel_size": 3}})
+    assert e.identical_architecture and e.epochs == [1] and e.stage(1).train_everything and e.deprecated_kwargs
+    assert e.block_kwargs == {"kernel_size": 3}
