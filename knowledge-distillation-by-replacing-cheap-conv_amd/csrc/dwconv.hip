@@ -645,8 +645,8 @@ namespace {
 // rows of an NHWC tensor <-> rows in lattice order (dense [rows][C] with stride ld_rows): the 1x1 convs next to the depthwise
 // kernels run over rows in lattice order, their other operand / result (the branch's 256-channel output, hint gradient) lives
 // in image order.  A thread moves 16 B; gather zero-fills the rows of padded cells and of the plane's tail.
-template <bool GATHER>
-__global__ void lattice_rows_kernel(const uint4 *__restrict__ img, uint4 *__restrict__ rows, long long nrows, int N, int H, int W, int d,
+template <bool GATHER>   // GATHER: img -> rows; else rows -> img (the two never alias: checked by the caller's shapes, not assumed by the compiler)
+__global__ void lattice_rows_kernel(uint4 *img, uint4 *rows, long long nrows, int N, int H, int W, int d,
                                     int Ly, int Lx, int c16, int ld_img16, int ld_rows16)
 {
     const long long total = nrows * c16;
@@ -660,7 +660,7 @@ __global__ void lattice_rows_kernel(const uint4 *__restrict__ img, uint4 *__rest
         const int yy = cls / d + d * ly, xx = cls % d + d * lx;
         const bool in = r < N && yy < H && xx < W;
         if (GATHER) rows[row * ld_rows16 + c] = in ? img[((r * H + yy) * W + xx) * ld_img16 + c] : make_uint4(0u, 0u, 0u, 0u);
-        else if (in) const_cast<uint4 *>(img)[((r * H + yy) * W + xx) * ld_img16 + c] = rows[row * ld_rows16 + c];
+        else if (in) img[((r * H + yy) * W + xx) * ld_img16 + c] = rows[row * ld_rows16 + c];
     }
 }
 }  // namespace
@@ -689,10 +689,10 @@ extern "C" int kd_lattice_rows_move(int32_t dtype, int32_t N, int32_t H, int32_t
     const long long total = nrows * (C / v);
     const unsigned grid = (unsigned)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
     if (to_rows)
-        hipLaunchKernelGGL(lattice_rows_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4 *)img, (uint4 *)rows, nrows, N, H, W,
+        hipLaunchKernelGGL(lattice_rows_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (uint4 *)img, (uint4 *)rows, nrows, N, H, W,
                            dil, Ly, Lx, C / v, ld_img / v, ld_rows / v);
     else
-        hipLaunchKernelGGL(lattice_rows_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4 *)img, (uint4 *)rows, nrows, N, H, W,
+        hipLaunchKernelGGL(lattice_rows_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (uint4 *)img, (uint4 *)rows, nrows, N, H, W,
                            dil, Ly, Lx, C / v, ld_img / v, ld_rows / v);
     KD_CHECK_LAUNCH("kd_lattice_rows_move");
     return KD_OK;
