@@ -86,6 +86,8 @@ def kd_step(model, crit, opt, data, target, mode="A"):
     loss = hint                      # "Only use hint loss", layerwise_trainer.py:233-235
     if mode == "B":
         loss = kd + hint             # north-star mode: the KD term is back-propagated too (classification_trainer.py:37)
+    if getattr(model, "prefetch_next", False):
+        model.prefetch_teacher(data)     # --teacher-stream backward: the NEXT step's teacher forward (same synthetic batch) under this backward
     loss.backward()
     opt.step()
     opt.zero_grad()
@@ -265,6 +267,7 @@ def run_config(a, device, rank, world, plan_name=None, mode=None, arch=None, hin
     model.overlap_teacher = not a.no_overlap
     model.teacher_backend = a.teacher
     model.hip_teacher_side_stream = a.teacher_stream == "side"
+    model.prefetch_next = a.teacher_stream == "backward"
     model.share_frozen_prefix = bool(a.share_prefix)
     if world > 1:
         eng = model._student_engine()
@@ -356,7 +359,7 @@ def run_config(a, device, rank, world, plan_name=None, mode=None, arch=None, hin
 
     # what actually ran: the PyTorch teacher overlaps on a side stream unless --no-overlap; the engine teacher runs in stream
     # order unless --teacher-stream side
-    overlapped = bool(model.overlap_teacher) and (a.teacher == "torch" or a.teacher_stream == "side")
+    overlapped = (bool(model.overlap_teacher) and (a.teacher == "torch" or a.teacher_stream == "side")) or a.teacher_stream == "backward"
     res = None
     if rank == 0:
         # dominant kernel family: the implicit-GEMM conv (forward + input gradient); live HIP-event timing of every launch on
@@ -506,8 +509,10 @@ def main():
     ap.add_argument("--ref-logging", action="store_true",
                     help="also do the reference's per-step host syncs (five .item() calls, layerwise_trainer.py:244-250); the "
                          "default measures the step without them, as this trainer runs it (metrics stay on the device)")
-    ap.add_argument("--teacher-stream", default="main", choices=["main", "side"],
-                    help="with --teacher hip: run the engine teacher on a side HIP stream concurrently with the student forward")
+    ap.add_argument("--teacher-stream", default="main", choices=["main", "side", "backward"],
+                    help="with --teacher hip: side = the engine teacher on a side HIP stream concurrently with the student forward; "
+                         "backward = the teacher's forward for the next step launched on the side stream right before this step's "
+                         "loss.backward() (DepthwiseStudent.prefetch_teacher: the placement north_star names)")
     ap.add_argument("--share-prefix", action="store_true",
                     help="opt-in: compute the frozen layers the student shares bit for bit with the teacher once per step "
                          "(stem .. the block before the first cheap conv); same numbers, ~8 %% fewer FLOPs than the reference's "

@@ -199,9 +199,38 @@ class DepthwiseStudent(nn.Module):
         with torch.no_grad():
             return self.teacher(xt)
 
+    def prefetch_teacher(self, x):
+        """Start the frozen teacher's forward for the NEXT batch `x` now, on the side HIP stream: called between the criteria and
+        `loss.backward()` of the current step, the teacher's logits / hints for the next step are produced while the student's
+        backward runs on the main stream (the placement BASELINE's north_star describes; the reference runs the teacher inside
+        `forward`, models/students/depthwise_student.py:168-177).  The next `forward(x)` -- the same tensor object, unmodified --
+        takes these outputs instead of running the teacher; any other input discards them.  Same values bit for bit (the teacher is
+        frozen and deterministic).  Returns False where it does not apply (non-fused students, Gated-SCNN's shared Canny prior,
+        `share_frozen_prefix`)."""
+        self._prefetched = None
+        if not self.fused or not x.is_cuda or self.share_frozen_prefix or isinstance(self.teacher, GSCNN):
+            return False
+        if self._side_stream is None or self._side_stream.device != x.device:
+            self._side_stream = torch.cuda.Stream(device=x.device)
+        main = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(main)                       # x has been produced / transferred on the main stream
+        self._side_stream.wait_event(ready)      # ... and nothing else of the main stream is waited for: the backward runs beside it
+        keep = self.teacher_hidden_outputs       # (the current step's hints stay what the criteria saw)
+        with torch.cuda.stream(self._side_stream):
+            pred = self._teacher_forward(x)
+        hints = self.teacher_hidden_outputs
+        self.teacher_hidden_outputs = keep
+        self._prefix = None
+        done = torch.cuda.Event()
+        done.record(self._side_stream)
+        self._prefetched = ((x.data_ptr(), tuple(x.shape), x._version), pred, hints, done)
+        return True
+
     def forward(self, x):
         self.student_hidden_outputs = []
         self.teacher_hidden_outputs = []
+        pre, self._prefetched = getattr(self, "_prefetched", None), None
         if not self.fused:
             with torch.no_grad():
                 teacher_pred = self.teacher(x)
@@ -216,7 +245,21 @@ class DepthwiseStudent(nn.Module):
                 self._teacher_engine.edge_prior = engine.edge_prior
             self._shared_prior = engine.edge_prior
         hip_teacher = self.teacher_backend == "hip" and isinstance(self.teacher, (DeepWV3Plus, GSCNN))
-        if self.overlap_teacher and (not hip_teacher or self.hip_teacher_side_stream):
+        if pre is not None and pre[0] == (x.data_ptr(), tuple(x.shape), x._version):
+            # the teacher already ran for this batch, on the side stream under the previous step's backward (prefetch_teacher)
+            _, teacher_pred, thints, done = pre
+            main = torch.cuda.current_stream()
+            main.wait_event(done)
+            for t in [teacher_pred] + list(thints):
+                if isinstance(t, LazyLogits) and t.pending:
+                    t.low.record_stream(main)
+                else:
+                    t.record_stream(main)
+            self.teacher_hidden_outputs = thints
+            self.prefetch_hits = getattr(self, "prefetch_hits", 0) + 1
+            self._prefix = None
+            student_pred, hints = run_student(engine, x)
+        elif self.overlap_teacher and (not hip_teacher or self.hip_teacher_side_stream):
             # frozen teacher on a side stream: its logits/hints are consumed only by the losses, so it can overlap the
             # student's forward on the main stream (PyTorch-ROCm teacher: always; engine teacher: opt-in, since two
             # chip-filling MFMA kernel streams only trade tail effects -- measured in DESIGN.md section 5)

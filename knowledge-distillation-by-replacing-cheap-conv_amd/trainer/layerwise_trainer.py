@@ -199,8 +199,10 @@ class LayerwiseTrainer(BaseTrainer):
         self._clean_cache()
         self._attach_reducer()
 
-        for batch_idx, (data, target) in enumerate(self.train_data_loader):
-            data, target = data.to(self.device, non_blocking=True), target.to(self.device, non_blocking=True)
+        # trainer.teacher_overlap = "backward" (opt-in): the teacher's forward for batch i + 1 is launched on the side stream right
+        # before batch i's loss.backward() (DepthwiseStudent.prefetch_teacher), which needs batch i + 1 on the device one step early
+        lookahead = str(self.config['trainer'].get('teacher_overlap', 'none')) == 'backward' and hasattr(self.model, 'prefetch_teacher')
+        for batch_idx, (data, target, next_data) in enumerate(self._device_batches(self.train_data_loader, lookahead)):
             output_st, output_tc = self.model(data)
 
             supervised_loss = self.criterions[0](output_st, target) / self.accumulation_steps
@@ -211,6 +213,8 @@ class LayerwiseTrainer(BaseTrainer):
             loss = hint_loss                                        # only use hint loss (reference :233-235)
             if self.backprop == 'kd+hint':                          # SURVEY 8(d) mode B, opt-in: trainer.backprop
                 loss = kd_loss + hint_loss
+            if next_data is not None and batch_idx != self.len_epoch:
+                self.model.prefetch_teacher(next_data)
             loss.backward()
             self._reduce_unfused_grads()
             if batch_idx % self.accumulation_steps == 0:
@@ -262,6 +266,26 @@ class LayerwiseTrainer(BaseTrainer):
                 self.lr_scheduler.step()
         self.weight_scheduler.step()
         return log
+
+    def _device_batches(self, loader, lookahead):
+        """(data, target, next_data) with the tensors on the device; with `lookahead` the following batch's data is transferred one
+        step early and handed out as next_data (None for the last batch, and always None without lookahead)."""
+        to = lambda t: t.to(self.device, non_blocking=True)
+        if not lookahead:
+            for data, target in loader:
+                yield to(data), to(target), None
+            return
+        it = iter(loader)
+        try:
+            data, target = next(it)
+        except StopIteration:
+            return
+        cur = (to(data), to(target))
+        for data, target in it:
+            nxt = (to(data), to(target))
+            yield cur[0], cur[1], nxt[0]
+            cur = nxt
+        yield cur[0], cur[1], None
 
     def _valid_epoch(self, epoch):
         self._clean_cache()
