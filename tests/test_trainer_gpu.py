@@ -10,7 +10,10 @@ from _netutil import trainer_config  # noqa: E402
 from _seeded import sample_idx, seeded_fill_, seeded_input  # noqa: E402
 
 
-def test_layerwise_trainer_epoch_matches_reference(golden, tmp_path):
+@pytest.mark.parametrize("teacher_overlap", ["none", "backward"])
+def test_layerwise_trainer_epoch_matches_reference(golden, tmp_path, teacher_overlap):
+    """teacher_overlap = "backward": the same epoch with the teacher's forward for batch i + 1 launched on the side stream before
+    batch i's loss.backward() (trainer.teacher_overlap, DepthwiseStudent.prefetch_teacher) -- same reference golden."""
     import kdcc_amd
     from kdcc_amd import ConfigParser, losses, models
     from kdcc_amd.models.students import DepthwiseStudent
@@ -20,7 +23,9 @@ def test_layerwise_trainer_epoch_matches_reference(golden, tmp_path):
 
     g = golden("trainer_epoch_g4")
     plan = [str(s) for s in g["plan"]]
-    config = ConfigParser(trainer_config(plan, lr=float(g["lr"]), len_epoch=2, save_dir=str(tmp_path)), run_id="t")
+    cfg = trainer_config(plan, lr=float(g["lr"]), len_epoch=2, save_dir=str(tmp_path))
+    cfg["trainer"]["teacher_overlap"] = teacher_overlap
+    config = ConfigParser(cfg, run_id="t")
     teacher = config.init_obj("teacher", models)          # resolves DeepWV3Plus by name, like train.py:35
     seeded_fill_(teacher, "teacher.")
     teacher.eval()
@@ -40,6 +45,7 @@ def test_layerwise_trainer_epoch_matches_reference(golden, tmp_path):
                for i in range(3)]
     tr = LayerwiseTrainer(model, crit, [], opt, config, batches, None, sched, WeightScheduler(config["weight_scheduler"]))
     log = tr._train_epoch(1)
+    assert getattr(model, "prefetch_hits", 0) == (2 if teacher_overlap == "backward" else 0)     # batches 1 and 2 of the three
     for k in ("loss", "supervised_loss", "kd_loss", "hint_loss", "teacher_loss"):
         np.testing.assert_allclose(log[k], float(g["log:" + k]), rtol=1e-3, err_msg=k)
     for k in ("train_teacher_mIoU", "train_student_mIoU"):
