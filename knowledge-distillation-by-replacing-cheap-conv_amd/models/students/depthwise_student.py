@@ -216,6 +216,7 @@ class DepthwiseStudent(nn.Module):
         ready = torch.cuda.Event()
         ready.record(main)                       # x has been produced / transferred on the main stream
         self._side_stream.wait_event(ready)      # ... and nothing else of the main stream is waited for: the backward runs beside it
+        x.record_stream(self._side_stream)       # (the batch may be dropped by its owner before the side stream has read it)
         keep = self.teacher_hidden_outputs       # (the current step's hints stay what the criteria saw)
         with torch.cuda.stream(self._side_stream):
             pred = self._teacher_forward(x)
