@@ -168,3 +168,34 @@ print("RESULT " + json.dumps(out))
     assert res["256"]["row"][1] == ["conv_row_lw_kernel"] and res["256"]["pw"][1] == ["conv_igemm_persist_kernel<pp>"] and \
         res["256"]["pp128"][1] == ["conv_row_tall_kernel"], res["256"]
     assert res["248"] == res["256"]
+
+
+def test_persist_cus_set_at_run_time_is_bit_identical_and_reducer_sets_no_cap():
+    """kd_conv_set_persist_cus (the run-time form of KDCC_PERSIST_CUS, what parallel.GradReducer calls for world > 1): the K-concatenated
+    1x1 kernel and the 3x3 lone-wave kernel give the same bits on 256, 248 and 64 workgroups, in one process; GradReducer's measured
+    default is no cap (profiles/r05_sidestream.json)."""
+    import kdcc_amd
+    from kdcc_amd import _lib, ops, parallel
+    g = torch.Generator(device="cuda").manual_seed(21)
+    x1 = torch.randn(1, 160, 512, 64, device="cuda", generator=g).bfloat16()
+    x2 = torch.randn(1, 160, 512, 128, device="cuda", generator=g).relu().bfloat16()
+    wc = (torch.randn(256, 1, 1, 192, device="cuda", generator=g) * 0.07).bfloat16()
+    x3 = torch.randn(2, 96, 512, 128, device="cuda", generator=g).bfloat16()
+    w3 = (torch.randn(512, 3, 3, 128, device="cuda", generator=g) * 0.05).bfloat16()
+    outs = {}
+    try:
+        for cus in (0, 248, 64):
+            _lib.check(_lib.lib().kd_conv_set_persist_cus(cus), "kd_conv_set_persist_cus")
+            ya = torch.zeros(1, 160, 512, 256, device="cuda", dtype=torch.bfloat16)
+            yb = torch.zeros(2, 96, 512, 512, device="cuda", dtype=torch.bfloat16)
+            with _lib.kernel_log() as log:
+                ops.conv2d(x1, wc, x2=x2, out_raw=ya)
+                ops.conv2d(x3, w3, 1, 2, 2, out_raw=yb)
+            assert sorted(k for k, v in log.counts.items() if v) == ["conv_igemm_persist_kernel<pp,dual>", "conv_row_lw_kernel"], log.counts
+            outs[cus] = (ya.clone(), yb.clone())
+    finally:
+        _lib.lib().kd_conv_set_persist_cus(0)
+    for cus in (248, 64):
+        assert torch.equal(outs[cus][0], outs[0][0]) and torch.equal(outs[cus][1], outs[0][1]), cus
+    assert _lib.lib().kd_conv_set_persist_cus(-1) != 0           # refused, not clamped
+    assert parallel.GradReducer.CONV_GRID_CAP == 0

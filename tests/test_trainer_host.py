@@ -165,3 +165,18 @@ def test_save_resume_update_optimizer(tmp_path):
     for (n1, p1), (n2, p2) in zip(model.student.named_parameters(), model2.student.named_parameters()):
         assert n1 == n2 and torch.equal(p1, p2) and p1.requires_grad == p2.requires_grad, n1
     assert json.load(open(tr2.config.save_dir / "config.json"))["trainer"]["resume_path"] == str(path)
+
+
+def test_device_batches_lookahead():
+    """LayerwiseTrainer._device_batches: with look-ahead (trainer.teacher_overlap = 'backward') every batch is handed out together with
+    the NEXT batch's data -- the very tensor object that comes back as `data` one step later, which is how
+    DepthwiseStudent.prefetch_teacher recognises it -- and the last one with None; without it, always None."""
+    import types
+    from kdcc_amd.trainer import LayerwiseTrainer
+    self = types.SimpleNamespace(device=torch.device("cpu"))
+    loader = [(torch.full((1, 2), float(i)), torch.tensor([i])) for i in range(4)]
+    got = list(LayerwiseTrainer._device_batches(self, loader, True))
+    assert [int(t.item()) for _, t, _ in got] == [0, 1, 2, 3]
+    assert all(got[i][2] is got[i + 1][0] for i in range(3)) and got[3][2] is None
+    assert [n for _, _, n in LayerwiseTrainer._device_batches(self, loader, False)] == [None] * 4
+    assert list(LayerwiseTrainer._device_batches(self, [], True)) == []
