@@ -73,7 +73,7 @@ def _filter_weight(i, channels, device):
     return _FW[key]
 
 
-def kd_step(model, crit, opt, data, target, mode="A"):
+def kd_step(model, crit, opt, data, target, mode="A", prefetch=True):
     from kdcc_amd.losses import WeightedHintMSELoss
     out_st, out_tc = model(data)
     sup = crit[0](out_st, target)
@@ -86,7 +86,7 @@ def kd_step(model, crit, opt, data, target, mode="A"):
     loss = hint                      # "Only use hint loss", layerwise_trainer.py:233-235
     if mode == "B":
         loss = kd + hint             # north-star mode: the KD term is back-propagated too (classification_trainer.py:37)
-    if getattr(model, "prefetch_next", False):
+    if prefetch and getattr(model, "prefetch_next", False):
         model.prefetch_teacher(data)     # --teacher-stream backward: the NEXT step's teacher forward (same synthetic batch) under this backward
     loss.backward()
     opt.step()
@@ -291,6 +291,9 @@ def run_config(a, device, rank, world, plan_name=None, mode=None, arch=None, hin
     ops.PROFILER = None if a.no_profiler else prof      # two HIP events per kernel launch inside the timed region (--no-profiler: none)
     t0 = time.perf_counter()
     for _ in range(steps):
+        # (--teacher-stream backward: every step prefetches the next one's teacher, the last one included; the window is closed by
+        # torch.cuda.synchronize(), a DEVICE-wide wait, so that last forward is finished inside it: the first step's teacher ran
+        # during warm-up, the last step's extra one replaces it -- exactly `steps` teacher forwards are timed)
         loss, sup, kd, tl = kd_step(model, crit, opt, data, target, mode)
         if a.ref_logging:
             _ = (loss.item(), sup.item(), kd.item(), loss.item(), tl.item())
@@ -323,7 +326,15 @@ def run_config(a, device, rank, world, plan_name=None, mode=None, arch=None, hin
             for (k, kern), (cnt, ms, work, fam) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 f.write(f"{k}\t{kern}\t{cnt / steps:g}\t{ms / cnt:.4f}\t{work * cnt / ms / (1e6 if fam in ('depthwise', 'channel_sums') else 1e9):.0f}\t{ms / steps:.3f}\n")
     replicas_identical = None
+    # what the process group actually was (not an echo of --gpus): ranks, backend, the device each rank ran on
+    ranks_seen, backend = 1, None
+    devices = [{"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(),
+                "pci_bus_id": getattr(torch.cuda.get_device_properties(device), "pci_bus_id", None)}]
     if world > 1:
+        ranks_seen, backend = torch.distributed.get_world_size(), torch.distributed.get_backend()
+        box = [None] * ranks_seen
+        torch.distributed.all_gather_object(box, devices[0])
+        devices = box
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -389,6 +400,7 @@ def run_config(a, device, rank, world, plan_name=None, mode=None, arch=None, hin
                                    f"{a.height}x{a.width}, {a.batch} image/GPU, random-init weights",
                        "plan": plan_name, "mode": mode, "arch": arch, "hint_loss": hint_loss, "per_gpu_batch": a.batch,
                        "global_batch": world * a.batch, "parallelism": f"dp{world}",
+                       "ranks_seen": ranks_seen, "backend": backend, "rank_devices": devices,
                        "replicas_identical_after_run": replicas_identical, "teacher_overlap": overlapped,
                        "teacher_backend": a.teacher, "per_step_host_syncs": bool(a.ref_logging),
                        "share_frozen_prefix": bool(a.share_prefix), "per_gpu_batch_sweep": sweep},
@@ -432,7 +444,9 @@ def compact_record(res, full_path=None):
                                   f"{res.get('_hw', '1024x2048')}, {cfg['per_gpu_batch']} img/GPU, random init, teacher through the "
                                   f"{'HIP engine' if cfg['teacher_backend'] == 'hip' else 'PyTorch-ROCm side stream'}"),
                      **{k: cfg[k] for k in ("plan", "mode", "arch", "hint_loss", "per_gpu_batch", "global_batch", "parallelism",
-                                            "teacher_backend", "share_frozen_prefix", "replicas_identical_after_run")}}
+                                            "teacher_backend", "share_frozen_prefix", "replicas_identical_after_run",
+                                            "ranks_seen", "backend")},
+                     "rank_devices": [d["device"] for d in cfg["rank_devices"]]}
     out["roofline"] = {"bound": rf["bound"], "kernel": "kd_conv2d_fwd (dense conv fwd + dgrad: conv_row_lw / conv_igemm_persist / "
                                                        "conv_row_tall / one-tile kernels)",
                        **{k: _r(rf.get(k)) for k in ("achieved", "peak", "unit", "frac", "traffic", "traffic_src", "launches_per_step",
@@ -471,6 +485,34 @@ SUB_RECORDS = (
      "BASELINE.md section 4 'fp32 parity mode separately': the same P92 step with fp32 storage and fp32 MFMA (the path the 1e-3 parity tests run), "
      "2 images, 1 warm-up + 2 timed steps; frac against the 157.3 TFLOP/s fp32 matrix peak"),
 )
+
+
+def _launch_ranks(n):
+    """Run this same command line as `n` ranks of one node (one process per GPU over RCCL; reference: `n_gpu` in the config is all
+    a user sets, base/base_trainer.py:16-19).  The ranks are children of a `python -m torch.distributed.run` child; their stdout is
+    read line by line: rank 0's JSON record goes to this process's stdout, anything else to stderr.  Returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL fails with hipIpcGetMemHandle otherwise
+    env.setdefault("OMP_NUM_THREADS", str(max(1, cpu_share() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    print(f"[bench] --gpus {n} without WORLD_SIZE: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    for line in proc.stdout:
+        is_record = False
+        if line.startswith("{"):
+            try:
+                is_record = "metric" in json.loads(line)
+            except ValueError:
+                pass
+        (sys.stdout if is_record else sys.stderr).write(line)
+        (sys.stdout if is_record else sys.stderr).flush()
+    return proc.wait()
 
 
 def main():
@@ -521,6 +563,11 @@ def main():
                     help="hip: frozen teacher graph through the engine's HIP kernels (default); torch: teacher as a PyTorch-ROCm "
                          "module (MIOpen) on a side stream, the split north_star describes")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` typed without a launcher: start the N ranks as FRESH child processes.  This process has not
+        # touched the GPU (no torch.cuda call, no kdcc_amd import) and never does; nothing is re-exec'd.
+        raise SystemExit(_launch_ranks(a.gpus))
 
     import kdcc_amd
     from kdcc_amd import parallel

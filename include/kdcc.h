@@ -124,8 +124,8 @@ int32_t kd_conv1x1_dual_supported(const kd_conv_desc *d, int32_t Cin2, int32_t l
 int kd_conv1x1_dual_fwd(const kd_conv_desc *d, const void *x, const void *x2, int32_t Cin2, int32_t ldx2, const void *w_cat,
                         const kd_conv_epilogue *ep, kd_stream_t stream);
 
-/* Workgroups of the persistent conv kernels' grids from now on: 0 = one per CU (default), else n (rounded down to a multiple of 8,
- * at most the CU count) -- leaves CUs to a kernel on another stream, i.e. the RCCL all-reduce of a gradient bucket that
+/* Workgroups of the persistent conv kernels' grids from now on: 0 = one per CU (default), else n rounded down to a multiple of 8
+ * and clamped to [8, CU count] (0 < n < 8 gives 8, n above the CU count gives the full chip; the value is process-wide and atomic) -- leaves CUs to a kernel on another stream, i.e. the RCCL all-reduce of a gradient bucket that
  * parallel.GradReducer launches from inside backward (the reference's single-process trainer has no counterpart,
  * trainer/layerwise_trainer.py:235-239).  Overrides the KDCC_PERSIST_CUS environment default; results are bit-identical for any n. */
 int kd_conv_set_persist_cus(int32_t n);
@@ -224,9 +224,11 @@ int kd_dwconv_wgrad_multi(const kd_dw_desc *d, int32_t n, const void *x, const v
  *     [C/16 planes][rows][16 channels],   row(n, ry, rx, ly, lx) = ((n*d*d + ry*d + rx)*Ly + ly)*Lx + lx,
  *     Ly = ceil(H/d), Lx = ceil(W/d),  pixel (y, x) = (ry + d*ly, rx + d*lx),  rows = kd_lattice_rows() (a multiple of 256)
  * the pixels of one residue class of one image are consecutive rows, so the same tile is one contiguous run per lattice row.
- * Cells whose pixel is outside the image and the tail rows of a plane hold zeros (writers keep them zero).  1x1 convs take
- * such a tensor as a GEMM operand over `rows` rows (kd_conv1x1_rows, kd_pw_wgrad_rows); their 256-channel side is a dense
- * [rows][C] matrix in the same row order, moved from / to image order by kd_lattice_rows_move. */
+ * Cells whose pixel is outside the image and the tail rows of a plane hold zeros (writers keep them zero).
+ * EXPERIMENTAL / benchmark-only: no GEMM entry point of this library consumes the [C/16][rows][16] layout (the 1x1 convs next
+ * to the depthwise kernels read NHWC), so nothing in the engine uses these entry points; they exist to measure what contiguous
+ * depthwise intermediates are worth (1-5 %, profiles/r05_aspp_dw_lattice_ab.json) and are tested bit for bit against the NHWC
+ * ones.  kd_lattice_rows_move converts between a dense [rows][C] matrix in lattice row order and image order. */
 int64_t kd_lattice_rows(int32_t N, int32_t H, int32_t W, int32_t dil);
 /* 1 when the fan-out / sum / multi-gradient launches of n (2 or 3) branches of geometry d can run on lattice-planar
  * intermediates (bf16, 9x9, C % 16 == 0, 32-bit plane offsets); otherwise the caller keeps NHWC intermediates. */

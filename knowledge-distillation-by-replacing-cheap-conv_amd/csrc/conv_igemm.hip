@@ -12,6 +12,7 @@
 // Epilogue: accumulators -> per-wave LDS patch -> 8-channel (16/32 B) vector rows:
 // residual add, BN(eval)+ReLU of the next layer, ReLU-mask backward, dual outputs.
 #include <stdlib.h>
+#include <atomic>
 #include <string.h>
 
 #include "conv_common.h"
@@ -1517,22 +1518,25 @@ extern "C" int32_t kd_conv2d_bn_sums_rows(const kd_conv_desc *d, const kd_conv_e
 // says so -- that leaves CUs to a kernel on another stream (the RCCL all-reduce the reducer launches from inside backward, which
 // otherwise only gets a CU between two conv launches).  Results do not depend on it: a tile's arithmetic is the same whichever
 // workgroup computes it (tests/test_ddp_gpu.py).
-static int g_persist_cus = -1;   // -1: not read yet; 0: every CU
+static std::atomic<int> g_persist_cus{-1};   // -1: not read yet; 0: every CU (process-wide; launches on any thread / device read it)
 static int persist_cus_value(int ncu)
 {
-    if (g_persist_cus < 0) {
+    int n = g_persist_cus.load(std::memory_order_relaxed);
+    if (n < 0) {
         const char *v = getenv("KDCC_PERSIST_CUS");
-        g_persist_cus = v ? atoi(v) : 0;
-        if (g_persist_cus < 0) g_persist_cus = 0;
+        n = v ? atoi(v) : 0;
+        if (n < 0) n = 0;
+        int expect = -1;
+        if (!g_persist_cus.compare_exchange_strong(expect, n)) n = expect;   // (a concurrent kd_conv_set_persist_cus wins)
     }
-    int n = g_persist_cus;
-    if (n < 8 || n > ncu) n = ncu;
+    if (n == 0 || n > ncu) n = ncu;        // 0 = every CU; a cap above the CU count is the full chip
+    if (n < 8) n = 8;                      // a cap below one XCD round is one XCD round (never "the full chip")
     return n - n % 8;
 }
 extern "C" int kd_conv_set_persist_cus(int32_t n)
 {
     KD_REQUIRE(n >= 0, KD_ERR_INVALID, "kd_conv_set_persist_cus: n must be >= 0 (0 = one workgroup per CU)");
-    g_persist_cus = n;
+    g_persist_cus.store(n);
     return KD_OK;
 }
 

@@ -888,7 +888,15 @@ class StudentEngine:
                 ops.conv2d(mid, self._w_fwd(site.mod.pointwise_conv), **kw)
             elif last and dual:
                 mid = None
-                ops.conv2d(a, self._w_cat(site.mod, blk.proj_conv, "fwd"), x2=a1, **kw)
+                try:
+                    ops.conv2d(a, self._w_cat(site.mod, blk.proj_conv, "fwd"), x2=a1, **kw)
+                except ops.DualUnsupported:
+                    # _dual_ok asked for dense operands of these sizes; the real epilogue / views can still be refused (raised
+                    # before anything is launched).  kdcc.h's contract: fall back to the two launches.
+                    rec["dual"] = False
+                    shortcut = self._new(N, ho, wo, site.cout)
+                    ops.conv2d(a1, self._w_fwd(blk.proj_conv), 1, 0, 1, out_raw=shortcut)
+                    ops.conv2d(a, self._w_fwd(site.mod, gate=site.gate), site.stride, site.pad, site.dil, res_pre=shortcut, **kw)
             else:
                 mid = None
                 ops.conv2d(a, self._w_fwd(site.mod, gate=site.gate), site.stride, site.pad, site.dil, **kw)
@@ -1238,7 +1246,13 @@ class StudentEngine:
                 if i == 0 and g_out is not None and rec["proj"] and dual_bwd:
                     self._conv_wgrad(site.mod, a_in, g, grads, gate=site.gate)
                     g_in = self._new(g.shape[0], g.shape[1], g.shape[2], site.cin)
-                    ops.conv2d(g, self._w_cat(site.mod, blk.proj_conv, "dgrad"), out_raw=g_in, x2=g_out, **ep)
+                    try:
+                        ops.conv2d(g, self._w_cat(site.mod, blk.proj_conv, "dgrad"), out_raw=g_in, x2=g_out, **ep)
+                    except ops.DualUnsupported:      # refused on the real epilogue (nothing was launched): the two-launch form
+                        if ep.get("bn_sums") is not None:
+                            del ep["bn_sums"][:]
+                        ep["res_pre"] = self._dense_dgrad(psite, g_out, in_hw=(a_in.shape[1], a_in.shape[2]))
+                        g_in = self._dense_dgrad(site, g, in_hw=(a_in.shape[1], a_in.shape[2]), **ep)
                 else:
                     g_in = self._site_bwd(site, a_in, rec["mid"][i], g, grads, need_in, **ep)
                 if g_in is not None:

@@ -218,6 +218,10 @@ class DepthwiseStudent(nn.Module):
         self._side_stream.wait_event(ready)      # ... and nothing else of the main stream is waited for: the backward runs beside it
         x.record_stream(self._side_stream)       # (the batch may be dropped by its owner before the side stream has read it)
         keep = self.teacher_hidden_outputs       # (the current step's hints stay what the criteria saw)
+        # a list of its own for the prefetched forward: the engine teacher rebinds the attribute, but a hooked PyTorch teacher
+        # (teacher_backend "torch") APPENDS to whatever list is there -- into `keep`, it would pair the next step's student hints
+        # with this step's teacher hints
+        self.teacher_hidden_outputs = []
         with torch.cuda.stream(self._side_stream):
             pred = self._teacher_forward(x)
         hints = self.teacher_hidden_outputs

@@ -32,7 +32,8 @@ def _full_record():
             "dtype": "bf16", "data": "synthetic", "_hw": "1024x2048",
             "profiler": {"events_in_timed_region": True, "ms_per_step_without_events": 190.123456, "ab_steps": 8},
             "config": {"workload": "w" * 400, "plan": "P92", "mode": "A", "arch": "deeplab", "hint_loss": "mse", "per_gpu_batch": 8,
-                       "global_batch": 8, "parallelism": "dp1", "replicas_identical_after_run": None, "teacher_overlap": False,
+                       "global_batch": 8, "parallelism": "dp1", "ranks_seen": 1, "backend": None,
+                       "rank_devices": [{"rank": 0, "device": 0, "name": "AMD Instinct MI355X", "pci_bus_id": 5}], "replicas_identical_after_run": None, "teacher_overlap": False,
                        "teacher_backend": "hip", "per_step_host_syncs": False, "share_frozen_prefix": False,
                        "per_gpu_batch_sweep": {str(n): {"images_per_sec": 40.123456, "ms_per_step": 24.9, "steps": 8} for n in (1, 2, 4)}},
             "roofline": _roofline(), "dense_wgrad": None,

@@ -440,3 +440,29 @@ def test_bench_two_ranks_child_process(tmp_path):
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 2 and rec["scaling"] == "weak"
     assert rec["config"]["replicas_identical_after_run"] is True
     assert rec["value"] > 0 and rec["steps"] == 3
+
+
+def test_bench_gpus_2_without_a_launcher(tmp_path):
+    """`python bench.py --gpus 2 ...` exactly as the driver types it -- no torch.distributed.run on the command line, no WORLD_SIZE:
+    bench.py starts its own two ranks as fresh child processes (bench._launch_ranks), relays rank 0's ONE JSON line and the exit
+    code.  Both ranks share this box's GPU and gloo carries the buckets, as in the test above."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KDCC_DIST_SHARE_GPU="1", KDCC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--no-sub-records", "--no-batch-sweep", "--batch", "1", "--height", "512", "--width", "1024",
+           "--full-record", str(tmp_path / "full.json")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]     # the parent's stdout is rank 0's record, nothing else
+    assert len(lines[0]) < 4096
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["ranks_seen"] == 2 and rec["config"]["backend"] == "gloo"
+    assert rec["config"]["replicas_identical_after_run"] is True
+    assert rec["config"]["rank_devices"] == [0, 0] and rec["config"]["global_batch"] == 2
+    assert rec["value"] > 0 and rec["steps"] == 2

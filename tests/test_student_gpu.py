@@ -261,7 +261,8 @@ def test_shared_frozen_prefix_is_bit_identical(golden):
     assert names[m1._student_engine().shareable_prefix(m1._teacher_engine)] == "mod3.block2"
 
 
-def test_teacher_prefetched_under_the_previous_backward_is_bit_identical():
+@pytest.mark.parametrize("backend", ["hip", "torch"])
+def test_teacher_prefetched_under_the_previous_backward_is_bit_identical(backend):
     """DepthwiseStudent.prefetch_teacher: the frozen teacher's forward for the next batch launched on the side stream before
     loss.backward() (north_star's placement; reference models/students/depthwise_student.py:168-177 runs it inside forward).  Three
     steps with and without it: losses, hints, every gradient and every updated parameter bit-identical, and every step after the first
@@ -275,6 +276,7 @@ def test_teacher_prefetched_under_the_previous_backward_is_bit_identical():
 
     def run(prefetch):
         model, crit, opt, _ = bench.build(plan, torch.bfloat16, torch.device("cuda", 0))
+        model.teacher_backend = backend      # "torch": hooked PyTorch-ROCm teacher, whose hooks APPEND to teacher_hidden_outputs
         model.prefetch_hits = 0
         out = []
         for i, x in enumerate(xs):
@@ -298,6 +300,14 @@ def test_teacher_prefetched_under_the_previous_backward_is_bit_identical():
     got, hits1 = run(True)
     assert hits0 == 0 and hits1 == len(xs) - 1
     for a, b in zip(ref, got):
+        assert len(a[2]) == len(b[2]) == len(plan)        # one teacher hint per hint site: this batch's, not two batches' worth
+        if backend == "torch":
+            # MIOpen picks its solvers per process state, so two builds of the PyTorch teacher are compared to bf16 tolerance; a
+            # hint list paired with the PREVIOUS batch's teacher hints (the aliasing this guards against) is off by O(1)
+            assert torch.allclose(a[0], b[0], rtol=2e-2) and torch.allclose(a[1], b[1], rtol=2e-2, atol=1e-3)
+            for u, v in zip(a[2], b[2]):
+                assert (u.float() - v.float()).norm() <= 2e-2 * u.float().norm()
+            continue
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
         for u, v in zip(a[2] + a[3] + a[4], b[2] + b[3] + b[4]):
             assert torch.equal(u, v)

@@ -180,3 +180,20 @@ def test_device_batches_lookahead():
     assert all(got[i][2] is got[i + 1][0] for i in range(3)) and got[3][2] is None
     assert [n for _, _, n in LayerwiseTrainer._device_batches(self, loader, False)] == [None] * 4
     assert list(LayerwiseTrainer._device_batches(self, [], True)) == []
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE (the form the driver types) must start two ranks itself and relay
+    their exit code.  Without a GPU each rank gets as far as the process group (gloo) and then refuses loudly -- the point here is
+    that the parent neither dies with 'launch with torch.distributed.run' nor touches a device."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-sub-records"], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert "starting 2 ranks" in r.stderr, r.stderr[-2000:]
+    assert "launch with torch.distributed.run" not in r.stderr
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "needs an MI355X" in r.stderr, r.stderr[-2000:]
+        assert r.stdout.strip() == ""
