@@ -27,6 +27,7 @@
 #include "igemm_core.h"
 
 long long kd_internal_lattice_rows(int N, int H, int W, int dil);
+int kd_internal_dw_lw_fanout(const kd_dw_desc *d, int nb, const void *x, const float *const *ws, void *const *ys, hipStream_t s);
 
 namespace {
 
@@ -949,6 +950,10 @@ int kd_internal_dw_mfma_fwd_n(const kd_dw_desc *d, int nb, int fan, const void *
     // (16-channel) pieces here, which the memory system serves at about a third of the rate of the register kernel's
     // 128-B-per-pixel rows (measured: 1.22 vs 0.99 ms at 4096 channels, mask + residual, 2 images).
     if (bias || (ep && (ep->res_pre || ep->mask || ep->res_post))) return 0;
+    if (fan && nb >= 2 && !lp) {     // round 6: the fan-out on the lone-wave kernel (dwconv_lw.hip) where it applies
+        const int took = kd_internal_dw_lw_fanout(d, nb, xs[0], ws, ys, s);
+        if (took != 0) return took;
+    }
     DwMfmaParams p;
     static int enabled = -1;
     if (enabled < 0) {

@@ -1,0 +1,396 @@
+#!/usr/bin/env python3
+"""Generator of csrc/dw_lw_body.inc: the hand-scheduled item loop of dw_lw_fan3_kernel (csrc/dwconv_lw.hip), the fan-out
+y_b = dwconv(x, w_b) of the three replaced ASPP branches (reference models/deeplabv3/deeplabv3.py:64-75) on the matrix cores,
+one wave per SIMD.
+
+Work item = (residue class, 13 x 52 lattice tile) of one (image, 16-channel group); a workgroup (4 waves, wave w = channels
+4w .. 4w+3) walks a list of items.  Item = 4 tile phases (column tiles of 16); per phase and wave 84 MFMAs: for each of its 4
+channels, 7 X fragments (K slots, dwconv_lw.hip) x 3 branches.  The Toeplitz operands of all 12 (branch, channel) pairs are
+resident: fragment f = (b*4 + c)*7 + m in a[4f : 4f+3] for f < 64, in v[176 + 4(f-64) : +3] above.  Between the MFMAs of
+phase t (slot k = 0 .. 83, one MFMA each) the generator deals:
+  * the fragment reads of the next channel (ds_read_b128, one per three MFMAs), and during channel 3 those of the NEXT tile's
+    channel 0 (k = 63 ..): the X buffer of the next item is published by the barrier of phase 3;
+  * k = 0 .. 13: tile t-1's second channel pair, accumulators -> bf16 pairs (v_cvt_pk_bf16_f32 in place) -> staging;
+  * k = 20: s_waitcnt lgkmcnt(0) + s_barrier -- the ONLY barrier of a phase, in the MFMA shadow: tile t-1's staging is complete,
+    the other staging buffer is free, and (t = 3) the next item's X buffer is complete;
+  * k = 22 ..: tile t-1's store-out: 6 x (ds_read_b128 staging -> buffer_store_dwordx4 NHWC), rows / columns past the item's
+    valid extent get an out-of-range offset (dropped);
+  * k = 44 ..: this tile's first channel pair -> staging (the other buffer);
+  * the next item's tile: phase 0 / 1 issue its 5 units of loads (2 x buffer_load_dwordx4 per unit, out-of-range offsets for
+    the stencil's zero padding), phase 2 / 3 transpose them into the idle X buffer (v_perm_b32 + ds_write2_b32).
+All LDS / vector-memory waits are COUNTED: the generator tracks the issue order of DS and VMEM operations (both queues retire
+in order) and emits s_waitcnt lgkmcnt(n) / vmcnt(n) with n = operations issued after the one needed; both queues are drained
+once per item (top of phase 0), which is where the loop is entered.  Scalar loads (item descriptors) are only issued right in
+front of a lgkmcnt(0).
+
+usage: python tools/gen_dw_lw.py   (rewrites csrc/dw_lw_body.inc; `--check` exits 1 when the file is stale: tests/test_abi.py)"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "knowledge-distillation-by-replacing-cheap-conv_amd", "csrc", "dw_lw_body.inc")
+
+NB = 3
+CSTR = 128
+RSTR = 16 * CSTR + 32
+XB = (21 * RSTR + 15) & ~15
+SPX = 48
+STILE = 16 * 16 * SPX
+SBUF = 3 * STILE
+S_OFF = 2 * XB
+NM = 7
+
+# ---- vector registers ----------------------------------------------------------------------------------------------------------
+def AFR(s, m):          # X fragment set s (channel parity), MFMA m
+    return 28 * s + 4 * m
+def ACC(s, cc, b):      # accumulators: set s (channel pair parity), channel cc of the pair, branch b
+    return 56 + 24 * s + 12 * cc + 4 * b
+def FD(j, half):        # fill data of unit j: half 0 = cell a, 1 = cell b
+    return 104 + 8 * j + 4 * half
+SOD = (144, 148)        # store-out data quads
+VA = [152 + m for m in range(NM)]   # fragment read addresses (tile base + slot offset of this lane), stepped in place
+V_SWR, V_SRD, V_SOPK, V_YTOFF, V_FPK, V_GTH, V_DST0 = 159, 160, 161, 162, 163, 164, 165
+V_DST = V_GB = 166      # fetch base (phases 0, 1) / transposing-write base (phases 2, 3) of the next item: never live together
+V_IN = 167              # NOT clobbered: the one VGPR input operand (address of the thread's constant block) lives here
+V_CA, V_OOB = 168, 169
+V_SO0, V_SO1 = 170, 171
+VT = (172, 173, 174)
+V_SRD1 = 175            # V_SRD + 8 staging rows
+def BFRAG(b, c, m):
+    f = (b * 4 + c) * NM + m
+    return f"a[{4 * f}:{4 * f + 3}]" if f < 64 else f"v[{176 + 4 * (f - 64)}:{176 + 4 * (f - 64) + 3}]"
+
+# ---- scalar registers (all clobbered; s32 / s100 / s101 are reserved by the compiler, inputs live below s36) ----------------------------
+RX = "s[36:39]"
+RY = ["s[40:43]", "s[44:47]", "s[48:51]"]
+# current item: valid rows, column byte offsets of its 4 tiles (one byte each), valid columns of its 4 tiles (one byte each), output base
+C_RV, C_CBP, C_LIMP, C_YB = 52, 53, 54, 55
+H_RV, H_CBP, H_LIMP, H_YB = 56, 57, 58, 59       # the same of the next item, held from phase 2 on
+NXT = 60                # s[60:75]: descriptor of the next item
+D_XB, D_RLO, D_RSP, D_CLO, D_CSP, D_YB, D_RV, D_CBP, D_LIMP = 0, 1, 2, 3, 4, 5, 6, 7, 8
+SO_OFF, SO_LIM, SO_RV = 76, 77, 78
+S_CNT, S_TP = 79, "s[80:81]"          # items left, pointer to the descriptor AFTER the next item's
+S_XN, S_XD = 82, 83                   # LDS offset of the idle X buffer, signed step to it from the current one
+S_ROWM = "s[84:85]"
+S_SC12 = (None, 86, 87, 88, 89)       # 12 j lattice columns of x in bytes
+S_DELTA, S_T0 = 90, 91                # step of the fragment read addresses to the next tile; temporary
+S_M0, S_M1 = "s[92:93]", "s[94:95]"   # store-out lane masks
+S_PH, S_PL, S_T1 = 96, 97, 98         # v_perm selectors (high halves / low halves of two dwords); temporary
+CLOBBER_S = list(range(36, 99))
+
+
+def byte_of(dst, src, t):
+    return f"s_bfe_u32 s{dst}, s{src}, {(8 << 16) | (8 * t)}"
+
+
+class Gen:
+    def __init__(self):
+        self.L = []
+        self.ds = []    # tags of DS operations in issue order since the last lgkmcnt(0)
+        self.vm = []
+        self.tagn = 0
+
+    def emit(self, s):
+        self.L.append(s)
+
+    def ds_op(self, s, tag=None):
+        self.tagn += 1
+        tag = tag or f"ds{self.tagn}"
+        self.ds.append(tag)
+        self.emit(s)
+        return tag
+
+    def vm_op(self, s, tag=None):
+        self.tagn += 1
+        tag = tag or f"vm{self.tagn}"
+        self.vm.append(tag)
+        self.emit(s)
+        return tag
+
+    def wait(self, ds_tags=(), vm_tags=()):
+        """wait until every named operation has retired (operations it does not find were drained already)"""
+        nl = nv = None
+        for t in ds_tags:
+            if t in self.ds:
+                n = self.ds[::-1].index(t)          # operations issued after the MOST RECENT one of that name
+                nl = n if nl is None else min(nl, n)
+        for t in vm_tags:
+            if t in self.vm:
+                n = self.vm[::-1].index(t)
+                nv = n if nv is None else min(nv, n)
+        if nl is None and nv is None:
+            return
+        parts = []
+        if nv is not None:
+            nv = min(nv, 63)                         # (the counter's width: waiting for more than asked is safe)
+            parts.append(f"vmcnt({nv})")
+            self.vm = self.vm[len(self.vm) - nv:] if nv else []
+        if nl is not None:
+            nl = min(nl, 15)
+            parts.append(f"lgkmcnt({nl})")
+            self.ds = self.ds[len(self.ds) - nl:] if nl else []
+        self.emit("s_waitcnt " + " ".join(parts))
+
+    def drain(self, vm=True):
+        self.emit("s_waitcnt vmcnt(0) lgkmcnt(0)" if vm else "s_waitcnt lgkmcnt(0)")
+        self.ds = []
+        if vm:
+            self.vm = []
+
+
+def mfma(g, acc, afr, b, c, m, zero):
+    g.emit(f"v_mfma_f32_16x16x32_bf16 v[{acc}:{acc + 3}], v[{afr}:{afr + 3}], {BFRAG(b, c, m)}, " + ("0" if zero else f"v[{acc}:{acc + 3}]"))
+
+
+def pair_out(cp, sb):
+    """accumulators of channel pair cp (set cp) -> staging buffer sb: 12 x (cvt in place, 4-B store)"""
+    cv, wr = [], []
+    for b in range(NB):
+        for r in range(4):
+            lo, hi = ACC(cp, 0, b) + r, ACC(cp, 1, b) + r
+            cv.append(f"v_cvt_pk_bf16_f32 v{lo}, v{lo}, v{hi}")
+            wr.append(f"ds_write_b32 v{V_SWR}, v{lo} offset:{sb * SBUF + b * STILE + r * 16 * SPX + cp * 4}")     # (V_SWR, V_SRD include S_OFF)
+    return cv, wr
+
+
+def fetch_prep():
+    """item-level part of the next item's fetch: row mask, column position, base offset of this thread's first unit"""
+    return [f"v_bfe_u32 v{VT[0]}, v{V_FPK}, 0, 8", f"v_subrev_u32 v{VT[0]}, s{NXT + D_RLO}, v{VT[0]}",
+            f"v_cmp_gt_u32_e64 {S_ROWM}, s{NXT + D_RSP}, v{VT[0]}",
+            f"v_bfe_u32 v{V_CA}, v{V_FPK}, 8, 8", f"v_subrev_u32 v{V_CA}, s{NXT + D_CLO}, v{V_CA}",
+            f"v_add_u32 v{V_GB}, s{NXT + D_XB}, v{V_GTH}"]
+
+
+def fetch_unit(g, j):
+    """returns (instruction list with VMEM markers) for unit j: cells a (column c) and b (column c + 1)"""
+    t0, t1, t2 = VT[0], VT[1], VT[2]
+    L = []
+    if j:
+        L += [f"v_add_u32 v{t0}, {12 * j}, v{V_CA}", f"v_add_u32 v{t1}, s{S_SC12[j]}, v{V_GB}"]
+        ca, gb = t0, t1
+    else:
+        ca, gb = V_CA, V_GB
+    L += [f"v_cmp_gt_u32_e32 vcc, s{NXT + D_CSP}, v{ca}", f"s_and_b64 vcc, vcc, {S_ROWM}", f"v_cndmask_b32_e32 v{t2}, v{V_OOB}, v{gb}, vcc",
+          ("VM", f"buffer_load_dwordx4 v[{FD(j, 0)}:{FD(j, 0) + 3}], v{t2}, {RX}, 0 offen", f"fa{j}"),
+          f"v_add_u32 v{t0}, 1, v{ca}", f"v_add_u32 v{t1}, %[ssc], v{gb}",
+          f"v_cmp_gt_u32_e32 vcc, s{NXT + D_CSP}, v{t0}", f"s_and_b64 vcc, vcc, {S_ROWM}", f"v_cndmask_b32_e32 v{t2}, v{V_OOB}, v{t1}, vcc",
+          ("VM", f"buffer_load_dwordx4 v[{FD(j, 1)}:{FD(j, 1) + 3}], v{t2}, {RX}, 0 offen", f"fb{j}")]
+    return L
+
+
+def write_unit(j):
+    """registers -> idle X buffer, transposed: per channel pair m one v_perm pair + ds_write2_b32 (dword offsets (2m)*32 + 6j, +32)"""
+    L = [("WAITVM", (f"fa{j}", f"fb{j}"))]
+    for m in range(4):
+        a, b = FD(j, 0) + m, FD(j, 1) + m
+        t = VT[m & 1]
+        L += [f"v_perm_b32 v{t}, v{b}, v{a}, s{S_PH}",      # (a >> 16) | (b & 0xffff0000)
+              f"v_perm_b32 v{a}, v{b}, v{a}, s{S_PL}",      # (a & 0xffff) | (b << 16)
+              ("DS", f"ds_write2_b32 v{V_DST}, v{a}, v{t} offset0:{(2 * m) * 32 + 6 * j} offset1:{(2 * m + 1) * 32 + 6 * j}")]
+    return L
+
+
+def store_out_prep():
+    """masks and offsets of the tile whose staging the barrier has just published (SO_* scalars)"""
+    t0 = VT[0]
+    return [f"v_bfe_u32 v{t0}, v{V_SOPK}, 8, 8", f"v_cmp_gt_i32_e32 vcc, s{SO_LIM}, v{t0}",          # column of the tile < valid columns
+            f"v_bfe_u32 v{t0}, v{V_SOPK}, 0, 8", f"v_cmp_gt_i32_e64 {S_M0}, s{SO_RV}, v{t0}",        # row rq < RV
+            f"s_and_b64 {S_M0}, {S_M0}, vcc",
+            f"v_add_u32 v{t0}, 8, v{t0}", f"v_cmp_gt_i32_e64 {S_M1}, s{SO_RV}, v{t0}",               # row rq + 8 < RV
+            f"s_and_b64 vcc, {S_M1}, vcc",
+            f"v_add_u32 v{VT[1]}, s{SO_OFF}, v{V_YTOFF}", f"v_add_u32 v{VT[2]}, %[syr8], v{VT[1]}",
+            f"v_cndmask_b32_e32 v{V_SO1}, v{V_OOB}, v{VT[2]}, vcc",
+            f"v_cndmask_b32_e64 v{V_SO0}, v{V_OOB}, v{VT[1]}, {S_M0}"]
+
+
+def phase(g, t, last_only=False):
+    sb = t & 1
+    slots = [[] for _ in range(85)]     # slot k: issued behind MFMA k (slot 84: after the last one)
+
+    # ---- fragment reads: channel c + 1 during channel c; the next tile's channel 0 during channel 3
+    for c in range(3):
+        for m in range(NM):
+            slots[21 * c + 1 + 3 * m].append(("DS", f"ds_read_b128 v[{AFR((c + 1) & 1, m)}:{AFR((c + 1) & 1, m) + 3}], v{VA[m]} offset:{(c + 1) * CSTR}", f"A{(c + 1) & 1}{m}"))
+            if c == 2:   # channel 3's read of slot m is out: the address moves on to the next tile (this item's, or the next item's first)
+                slots[21 * c + 2 + 3 * m].append(f"v_add_u32 v{VA[m]}, s{S_DELTA}, v{VA[m]}")
+    for m in range(NM):
+        slots[63 + m].append(("DS", f"ds_read_b128 v[{AFR(0, m)}:{AFR(0, m) + 3}], v{VA[m]}", f"A0{m}"))
+    # step to the next tile's fragments: phase t -> t + 1 inside the item, phase 3 -> the next item's buffer and first tile
+    if t < 3:
+        slots[40] += [byte_of(S_T0, C_CBP, t + 1), byte_of(S_T1, C_CBP, t), f"s_sub_u32 s{S_DELTA}, s{S_T0}, s{S_T1}"]
+    else:
+        slots[40] += [byte_of(S_T0, H_CBP, 0), byte_of(S_T1, C_CBP, 3), f"s_sub_u32 s{S_DELTA}, s{S_T0}, s{S_T1}", f"s_add_u32 s{S_DELTA}, s{S_DELTA}, s{S_XD}"]
+
+    # ---- tile t-1's second pair -> staging (the buffer of tile t-1)
+    cv, wr = pair_out(1, sb ^ 1)
+    for i in range(12):
+        slots[i].append(cv[i])
+        slots[i + 2].append(("DS", wr[i]))
+    # ---- barrier in the MFMA shadow
+    if t == 2:      # hold what the next item's tiles and store-out need; its descriptor registers are reloaded in phase 3
+        slots[18] += [f"s_mov_b32 s{H_RV}, s{NXT + D_RV}", f"s_mov_b32 s{H_YB}, s{NXT + D_YB}",
+                      f"s_mov_b32 s{H_CBP}, s{NXT + D_CBP}", f"s_mov_b32 s{H_LIMP}, s{NXT + D_LIMP}"]
+    if t == 3:      # descriptor of the item after the next (the pointer stops at the last one: an item is then fetched twice, never used)
+        slots[20] += [f"s_load_dwordx16 s[{NXT}:{NXT + 15}], {S_TP}, 0x0",
+                      f"s_cmp_gt_u32 s{S_CNT}, 3", f"s_cselect_b32 s{S_T0}, 64, 0",
+                      f"s_add_u32 s80, s80, s{S_T0}", "s_addc_u32 s81, s81, 0"]
+    slots[20].append(("BARRIER",))
+    if t == 3:      # no item behind the next one: it stages nothing (zero valid rows: every load out of range)
+        slots[20] += [f"s_cmp_gt_u32 s{S_CNT}, 2", f"s_cselect_b32 s{NXT + D_RSP}, s{NXT + D_RSP}, 0"]
+    # ---- tile t-1's store-out
+    prep = store_out_prep()
+    for i, ins in enumerate(prep):
+        slots[21 + i // 2].append(ins)
+    k0 = 28
+    for rr in range(2):
+        for b in range(NB):
+            i = rr * NB + b
+            q = SOD[i & 1]
+            slots[k0 + 4 * i].append(("DS", f"ds_read_b128 v[{q}:{q + 3}], v{V_SRD1 if rr else V_SRD} offset:{(sb ^ 1) * SBUF + b * STILE}", f"so{i}"))
+            slots[k0 + 4 * i + 6].append(("WAITDS", (f"so{i}",)))
+            slots[k0 + 4 * i + 6].append(("VM", f"buffer_store_dwordx4 v[{q}:{q + 3}], v{V_SO1 if rr else V_SO0}, {RY[b]}, 0 offen", f"st{i}"))
+    # ---- this tile's first pair -> staging
+    cv, wr = pair_out(0, sb)
+    for i in range(12):
+        slots[44 + 2 * i].append(cv[i])
+        slots[46 + 2 * i].append(("DS", wr[i]))
+    # ---- SO_* of this tile for the next phase's store-out; item-level scalars
+    slots[82] += [byte_of(S_T0, C_CBP, t), f"s_lshr_b32 s{S_T0}, s{S_T0}, 1", f"s_mul_i32 s{S_T0}, s{S_T0}, %[syc]", f"s_add_u32 s{SO_OFF}, s{S_T0}, s{C_YB}",
+                  byte_of(SO_LIM, C_LIMP, t), f"s_mov_b32 s{SO_RV}, s{C_RV}"]
+    # ---- the next item's tile
+    # (instruction groups that use vcc / the VT temporaries must not straddle the store-out preparation in slots 21 .. 26)
+    if t == 0:
+        for i, ins in enumerate(fetch_prep()):
+            slots[14 + i].append(ins)
+        fill = fetch_unit(g, 0) + fetch_unit(g, 1) + fetch_unit(g, 2)
+        where = [50 + i for i in range(34)]
+    elif t == 1:
+        fill = fetch_unit(g, 3) + fetch_unit(g, 4)
+        where = [52 + i for i in range(32)]
+    elif t == 2:
+        slots[14].append(f"v_add_u32 v{V_DST}, s{S_XN}, v{V_DST0}")
+        fill = write_unit(0) + write_unit(1) + write_unit(2)
+        where = [42 + i for i in range(42)]
+    else:
+        # units 3, 4 go in front of THIS phase's barrier (k = 20): it publishes the next item's X buffer
+        fill = write_unit(3) + write_unit(4)
+        where = [i for i in range(20)]
+    per = -(-len(fill) // len(where))
+    for i, ins in enumerate(fill):
+        slots[where[min(i // per, len(where) - 1)]].append(ins)
+
+    # ---- emit
+    for k in range(84):
+        c, i = divmod(k, 21)
+        m, b = divmod(i, 3)
+        cp, cc = divmod(c, 2)
+        if b == 0:
+            g.wait(ds_tags=(f"A{c & 1}{m}",))
+        mfma(g, ACC(cp, cc, b), AFR(c & 1, m), b, c, m, zero=(m == 0))
+        for ins in slots[k]:
+            put(g, ins)
+    for ins in slots[84]:
+        put(g, ins)
+
+
+def put(g, ins):
+    if isinstance(ins, str):
+        g.emit(ins)
+    elif ins[0] == "DS":
+        g.ds_op(ins[1], ins[2] if len(ins) > 2 else None)
+    elif ins[0] == "VM":
+        g.vm_op(ins[1], ins[2] if len(ins) > 2 else None)
+    elif ins[0] == "WAITDS":
+        g.wait(ds_tags=ins[1])
+    elif ins[0] == "WAITVM":
+        g.wait(vm_tags=ins[1])
+    elif ins[0] == "BARRIER":
+        g.drain(vm=False)
+        g.emit("s_barrier")
+    else:
+        raise ValueError(ins)
+
+
+def build():
+    g = Gen()
+    e = g.emit
+    # ---- prologue: per-thread constants (v152 .. v166) and the 20 VGPR-resident operand fragments from LDS
+    for i in range(3):
+        g.ds_op(f"ds_read_b128 v[{152 + 4 * i}:{152 + 4 * i + 3}], %[vlc] offset:{16 * i}")
+    g.ds_op(f"ds_read_b96 v[164:166], %[vlc] offset:48")
+    g.drain(vm=False)
+    for j in range(20):
+        g.ds_op(f"ds_read_b128 v[{176 + 4 * j}:{176 + 4 * j + 3}], v166 offset:{1024 * j}")
+        if j % 8 == 7:
+            g.drain(vm=False)
+    e(f"v_add_u32 v{V_SRD1}, {8 * 16 * SPX}, v{V_SRD}")
+    e(f"s_mov_b64 s[36:37], %[sx]"); e("s_mov_b32 s38, %[snrx]"); e("s_mov_b32 s39, 0x00020000")
+    for b in range(NB):
+        e(f"s_mov_b64 s[{40 + 4 * b}:{41 + 4 * b}], %[sy{b}]"); e(f"s_mov_b32 s{42 + 4 * b}, %[snry]"); e(f"s_mov_b32 s{43 + 4 * b}, 0x00020000")
+    for j in range(1, 5):
+        e(f"s_mul_i32 s{S_SC12[j]}, %[ssc], {12 * j}")
+    e(f"s_mov_b32 s{S_CNT}, %[scnt]"); e(f"s_mov_b64 {S_TP}, %[stab]")
+    e(f"s_mov_b32 s{S_PH}, 0x07060302"); e(f"s_mov_b32 s{S_PL}, 0x05040100")
+    e(f"v_mov_b32 v{V_OOB}, 0x80000000")
+    e(f"s_mov_b32 s{S_XN}, {XB}"); e(f"s_mov_b32 s{S_XD}, {XB}")
+    # current item = first descriptor, next = second (or the first again with nothing to stage when there is only one)
+    e(f"s_load_dwordx16 s[{NXT}:{NXT + 15}], {S_TP}, 0x0")
+    g.drain(vm=False)
+    e(f"s_mov_b32 s{C_RV}, s{NXT + D_RV}"); e(f"s_mov_b32 s{C_YB}, s{NXT + D_YB}")
+    e(f"s_mov_b32 s{C_CBP}, s{NXT + D_CBP}"); e(f"s_mov_b32 s{C_LIMP}, s{NXT + D_LIMP}")
+    e(f"s_cmp_gt_u32 s{S_CNT}, 1"); e(f"s_cselect_b32 s{S_T0}, 64, 0"); e(f"s_add_u32 s80, s80, s{S_T0}"); e("s_addc_u32 s81, s81, 0")
+    e(f"s_load_dwordx16 s[{NXT}:{NXT + 15}], {S_TP}, 0x0")
+    g.drain(vm=False)
+    e(f"s_cmp_gt_u32 s{S_CNT}, 1"); e(f"s_cselect_b32 s{NXT + D_RSP}, s{NXT + D_RSP}, 0")
+    e(f"s_cmp_gt_u32 s{S_CNT}, 2"); e(f"s_cselect_b32 s{S_T0}, 64, 0"); e(f"s_add_u32 s80, s80, s{S_T0}"); e("s_addc_u32 s81, s81, 0")
+    # nothing to store out in front of the first tile
+    e(f"s_mov_b32 s{SO_OFF}, 0"); e(f"s_mov_b32 s{SO_LIM}, 0"); e(f"s_mov_b32 s{SO_RV}, 0")
+    e("s_barrier")          # every wave has read its constants / operands: the staging area and X buffer 1 may be written
+    for m in range(NM):
+        g.ds_op(f"ds_read_b128 v[{AFR(0, m)}:{AFR(0, m) + 3}], v{VA[m]}", f"A0{m}")
+    e("DWLW_ITEM_%=:")
+    g.drain()               # both queues are empty at the top of an item: the loop is entered and re-entered in the same state
+    for t in range(4):
+        phase(g, t)
+    # ---- next item
+    e(f"s_mov_b32 s{C_RV}, s{H_RV}"); e(f"s_mov_b32 s{C_YB}, s{H_YB}"); e(f"s_mov_b32 s{C_CBP}, s{H_CBP}"); e(f"s_mov_b32 s{C_LIMP}, s{H_LIMP}")
+    e(f"s_sub_u32 s{S_XN}, {XB}, s{S_XN}"); e(f"s_sub_u32 s{S_XD}, 0, s{S_XD}")
+    e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1"); e(f"s_cmp_eq_u32 s{S_CNT}, 0"); e("s_cbranch_scc0 DWLW_ITEM_%=")
+    # ---- drain: the last tile's second pair, barrier, its store-out
+    g.drain()
+    cv, wr = pair_out(1, 1)
+    for i in range(12):
+        e(cv[i])
+    for i in range(12):
+        g.ds_op(wr[i])
+    g.drain(vm=False)
+    e("s_barrier")
+    for ins in store_out_prep():
+        e(ins)
+    for rr in range(2):
+        for b in range(NB):
+            q = SOD[b & 1]
+            t = g.ds_op(f"ds_read_b128 v[{q}:{q + 3}], v{V_SRD1 if rr else V_SRD} offset:{SBUF + b * STILE}")
+            g.wait(ds_tags=(t,))
+            g.vm_op(f"buffer_store_dwordx4 v[{q}:{q + 3}], v{V_SO1 if rr else V_SO0}, {RY[b]}, 0 offen")
+    g.drain()
+    return g.L
+
+
+def render():
+    L = build()
+    out = ["// GENERATED by tools/gen_dw_lw.py -- do not edit (tests/test_abi.py checks it is current)",
+           "#define DW_LW3_ASM \\"]
+    out += [f'    "{ins}\\n\\t" \\' for ins in L]
+    out.append('    ""')
+    out.append("#define DW_LW3_CLOBBER " + ", ".join(f'"s{i}"' for i in CLOBBER_S) + ', "vcc", "memory", ' + ", ".join(f'"v{i}"' for i in range(0, 256) if i != V_IN))
+    return "\n".join(out) + "\n"
+
+
+if __name__ == "__main__":
+    txt = render()
+    if "--check" in sys.argv:
+        sys.exit(0 if os.path.exists(OUT) and open(OUT).read() == txt else 1)
+    with open(OUT, "w") as f:
+        f.write(txt)
+    print(f"wrote {OUT}: {txt.count(chr(10))} lines")
