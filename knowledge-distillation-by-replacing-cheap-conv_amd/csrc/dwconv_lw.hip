@@ -330,6 +330,12 @@ const ItemTable *item_table(const kd_dw_desc *d)
             v[8] |= (t < njt ? CV - cb : 0) << (8 * t);
         }
         v[15] = ry | (rx << 8) | (ty << 16) | (tx << 24);
+        {   // timing-only ablations (tuning build): 1 = no output stores (no valid columns), 2 = no load requests (no valid rows)
+            static int dbg = -1;
+            if (dbg < 0) dbg = KD_TUNING_ENV_INT("KDCC_DW_LW_DBG");
+            if (dbg & 1) v[8] = 0;
+            if (dbg & 2) v[2] = 0;
+        }
         host.insert(host.end(), v, v + 16);
     }
     ItemTable t;
@@ -361,7 +367,14 @@ int kd_internal_dw_lw_fanout(const kd_dw_desc *d, int nb, const void *x, const f
     if (!enabled) return 0;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return 0;   // (the table upload is a synchronous copy)
-    const ItemTable *tab = item_table(d);
+    kd_dw_desc dd = *d;
+    {
+        static int dbg = -1;
+        if (dbg < 0) dbg = KD_TUNING_ENV_INT("KDCC_DW_LW_DBG");
+        if (dbg & 4) dd.ldy = 16;
+        if (dbg & 8) dd.ldx = 16;
+    }
+    const ItemTable *tab = item_table(&dd);
     if (!tab) return 0;
     DwLwParams p;
     for (int b = 0; b < MAXB; ++b) {
@@ -371,6 +384,13 @@ int kd_internal_dw_lw_fanout(const kd_dw_desc *d, int nb, const void *x, const f
     }
     p.items = tab->dptr;
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.dil = d->dil; p.ldx = d->ldx; p.ldy = d->ldy;
+    {   // timing-only (tuning build): 4 = outputs / 8 = input addressed as DENSE 16-channel images (32-B pixels side by side): the same
+        // requests on cache- and TLB-friendly addresses.  (Tables are keyed on ldx / ldy, so the descriptors follow.)
+        static int dbg = -1;
+        if (dbg < 0) dbg = KD_TUNING_ENV_INT("KDCC_DW_LW_DBG");
+        if (dbg & 4) p.ldy = 16;
+        if (dbg & 8) p.ldx = 16;
+    }
     p.nitems = tab->nvalid;
     dw_lw_split(d->N, d->C, tab->nvalid, &p.nseg);
     p.ncg = d->C / CG;

@@ -349,7 +349,11 @@ def build():
     for m in range(NM):
         g.ds_op(f"ds_read_b128 v[{AFR(0, m)}:{AFR(0, m) + 3}], v{VA[m]}", f"A0{m}")
     e("DWLW_ITEM_%=:")
-    g.drain()               # both queues are empty at the top of an item: the loop is entered and re-entered in the same state
+    # The LDS queue is drained at the top of an item, so the loop is entered and re-entered in the same state.  The vector-memory
+    # queue is NOT: the last tile's output stores stay in flight across the item boundary (draining them stalled every item for a
+    # store round trip).  That is sound because every vmcnt wait below counts the operations issued AFTER the load it needs, all of
+    # them inside the item body; older stores only make the wait longer, never shorter.
+    g.drain(vm=False)
     for t in range(4):
         phase(g, t)
     # ---- next item
