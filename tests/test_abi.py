@@ -146,3 +146,32 @@ def test_hand_scheduled_loops_pass_the_schedule_interpreter():
         assert any("holds data from" in f for f in tall())
     finally:
         G.ISSUED, G.TALL_WAIT, G.tall_shift = issued, waits, shift
+
+
+def test_depthwise_lone_wave_loop_is_generated_interpreted_and_audited():
+    """csrc/dw_lw_body.inc is the output of tools/gen_dw_lw.py (the item loop of dw_lw_fan3_kernel, dwconv_lw.hip).  tools/check_dw_lw.py
+    interprets the generated stream with the hardware's two in-order queues (LDS, vector memory) and its counted waits -- every MFMA
+    fragment, staged output and transposed tile register must have landed before it is read, every barrier must find the LDS queue
+    empty -- and audits the compiled kernel (no compiler instruction in the accumulation file once the operands sit there, all 336
+    MFMAs in the one statement, no scratch, v167 the only vector input).  The interpreter is held to account: waits made one
+    operation too lax, in either queue, must be reported."""
+    import shutil
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_dw_lw.py"), "--check"])
+    assert r.returncode == 0, "csrc/dw_lw_body.inc is stale: run python tools/gen_dw_lw.py"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_dw_lw as C
+    import gen_dw_lw as G
+    assert C.interpret(G.build()) == []
+    try:
+        G.SLACK_DS = 1
+        assert any("in flight" in f for f in C.interpret(G.build()))
+        G.SLACK_DS, G.SLACK_VM = 0, 1
+        assert any("buffer_load" in f and "in flight" in f for f in C.interpret(G.build()))
+    finally:
+        G.SLACK_DS = G.SLACK_VM = 0
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dw_lw.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]

@@ -656,7 +656,7 @@ def test_dwconv_fanout_lattice(K, case):
         o.t[:, used:].zero_()
     K.dwconv_fanout_lattice(xd, taps, k, p, d, outs=outs)
     selected(f"dw_mfma_fwd_kernel<{n},true,lattice>", f"dw fan-out lattice {case}")
-    plain = K.dwconv_fanout(xd, taps, k, p, d)
+    plain = [K.dwconv(xd, t, k, p, d) for t in taps]     # (the 8-wave kernel's arithmetic; the NHWC fan-out of three runs on dw_lw_fan3_kernel)
     for i, (o, w) in enumerate(zip(outs, ws)):
         assert torch.equal(o.to_nhwc(), plain[i]), f"lattice fan-out output {i} differs from the NHWC launch"
         want = K.image_to_lattice(plain[i], d)

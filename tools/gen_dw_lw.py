@@ -31,6 +31,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "knowledge-distillation-by-replacing-cheap-conv_amd", "csrc", "dw_lw_body.inc")
 
 NB = 3
+NT_ST = " nt" if os.environ.get("KDCC_GEN_NT", "0") in ("1", "3") else ""     # experiment: non-temporal output stores / tile loads
+NT_LD = " nt" if os.environ.get("KDCC_GEN_NT", "0") in ("2", "3") else ""
 CSTR = 128
 RSTR = 16 * CSTR + 32
 XB = (21 * RSTR + 15) & ~15
@@ -39,6 +41,7 @@ STILE = 16 * 16 * SPX
 SBUF = 3 * STILE
 S_OFF = 2 * XB
 NM = 7
+SLACK_DS = SLACK_VM = 0     # (tests/test_abi.py mutates these: every counted wait that many operations too lax must be caught by tools/check_dw_lw.py)
 
 # ---- vector registers ----------------------------------------------------------------------------------------------------------
 def AFR(s, m):          # X fragment set s (channel parity), MFMA m
@@ -122,11 +125,11 @@ class Gen:
             return
         parts = []
         if nv is not None:
-            nv = min(nv, 63)                         # (the counter's width: waiting for more than asked is safe)
+            nv = min(nv + SLACK_VM, 63)              # (the counter's width: waiting for more than asked is safe)
             parts.append(f"vmcnt({nv})")
             self.vm = self.vm[len(self.vm) - nv:] if nv else []
         if nl is not None:
-            nl = min(nl, 15)
+            nl = min(nl + SLACK_DS, 15)
             parts.append(f"lgkmcnt({nl})")
             self.ds = self.ds[len(self.ds) - nl:] if nl else []
         self.emit("s_waitcnt " + " ".join(parts))
@@ -171,10 +174,10 @@ def fetch_unit(g, j):
     else:
         ca, gb = V_CA, V_GB
     L += [f"v_cmp_gt_u32_e32 vcc, s{NXT + D_CSP}, v{ca}", f"s_and_b64 vcc, vcc, {S_ROWM}", f"v_cndmask_b32_e32 v{t2}, v{V_OOB}, v{gb}, vcc",
-          ("VM", f"buffer_load_dwordx4 v[{FD(j, 0)}:{FD(j, 0) + 3}], v{t2}, {RX}, 0 offen", f"fa{j}"),
+          ("VM", f"buffer_load_dwordx4 v[{FD(j, 0)}:{FD(j, 0) + 3}], v{t2}, {RX}, 0 offen{NT_LD}", f"fa{j}"),
           f"v_add_u32 v{t0}, 1, v{ca}", f"v_add_u32 v{t1}, %[ssc], v{gb}",
           f"v_cmp_gt_u32_e32 vcc, s{NXT + D_CSP}, v{t0}", f"s_and_b64 vcc, vcc, {S_ROWM}", f"v_cndmask_b32_e32 v{t2}, v{V_OOB}, v{t1}, vcc",
-          ("VM", f"buffer_load_dwordx4 v[{FD(j, 1)}:{FD(j, 1) + 3}], v{t2}, {RX}, 0 offen", f"fb{j}")]
+          ("VM", f"buffer_load_dwordx4 v[{FD(j, 1)}:{FD(j, 1) + 3}], v{t2}, {RX}, 0 offen{NT_LD}", f"fb{j}")]
     return L
 
 
@@ -248,7 +251,7 @@ def phase(g, t, last_only=False):
             q = SOD[i & 1]
             slots[k0 + 4 * i].append(("DS", f"ds_read_b128 v[{q}:{q + 3}], v{V_SRD1 if rr else V_SRD} offset:{(sb ^ 1) * SBUF + b * STILE}", f"so{i}"))
             slots[k0 + 4 * i + 6].append(("WAITDS", (f"so{i}",)))
-            slots[k0 + 4 * i + 6].append(("VM", f"buffer_store_dwordx4 v[{q}:{q + 3}], v{V_SO1 if rr else V_SO0}, {RY[b]}, 0 offen", f"st{i}"))
+            slots[k0 + 4 * i + 6].append(("VM", f"buffer_store_dwordx4 v[{q}:{q + 3}], v{V_SO1 if rr else V_SO0}, {RY[b]}, 0 offen{NT_ST}", f"st{i}"))
     # ---- this tile's first pair -> staging
     cv, wr = pair_out(0, sb)
     for i in range(12):
