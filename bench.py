@@ -254,13 +254,16 @@ def class_rooflines(prof, steps, peak_tflops):
 
 
 def run_config(a, device, rank, world, plan_name=None, mode=None, arch=None, hint_loss="mse", steps=None, warmup=None,
-               batch_sweep=True, dtype_name=None, batch=None):
+               batch_sweep=True, dtype_name=None, batch=None, share_prefix=None, ref_logging=None):
     """Build one configuration, run `warmup` untimed + `steps` timed KD train steps, return (record, model, cpu_sd, plan)."""
     from kdcc_amd import ops, parallel
     plan_name, mode, arch = plan_name or a.plan, mode or a.mode, arch or a.arch
     steps, warmup = steps or a.steps, a.warmup if warmup is None else warmup
     if dtype_name is not None or batch is not None:       # a sub-record in another storage type / batch (the fp32 parity path)
         a = argparse.Namespace(**{**vars(a), "dtype": dtype_name or a.dtype, "batch": batch or a.batch})
+    if share_prefix is not None or ref_logging is not None:      # sub-records: the opt-in shared frozen prefix / the reference's per-step host syncs
+        a = argparse.Namespace(**{**vars(a), "share_prefix": a.share_prefix if share_prefix is None else share_prefix,
+                                  "ref_logging": a.ref_logging if ref_logging is None else ref_logging})
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     plan = PLANS[plan_name]
     model, crit, opt, cpu_sd = build(plan, dtype, device, mode=mode, arch=arch, hint_loss=hint_loss)
@@ -481,6 +484,12 @@ SUB_RECORDS = (
     ("modeB", dict(mode="B"), "north-star mode B: loss = KLDiv + hints, all 92.1 M student parameters trainable (37.74 TFLOP/img)"),
     ("gscnn_P86", dict(arch="gscnn", plan_name="P86"), "BASELINE config 5: Gated-SCNN student, cfg/cityscapes/51M_gscnn_all.json plan"),
     ("weighted_hint", dict(hint_loss="weighted"), "BASELINE config 4: WeightedHintMSELoss feature-hint KD, filter_weight = rand(C) (rand:7)"),
+    ("share_prefix", dict(share_prefix=True),
+     "opt-in DepthwiseStudent.share_frozen_prefix: the frozen layers the student shares bit for bit with the teacher (stem .. the block before the "
+     "first cheap conv) computed once per step -- same numbers, ~8 % fewer FLOPs than the reference's two full forwards; NOT the headline"),
+    ("ref_logging", dict(ref_logging=True),
+     "SURVEY 8(d) 'with the reference's per-step logging syncs': the headline step plus the five .item() host syncs of "
+     "trainer/layerwise_trainer.py:244-250 after every step"),
     ("f32_parity", dict(dtype_name="f32", batch=2, steps=2, warmup=1),
      "BASELINE.md section 4 'fp32 parity mode separately': the same P92 step with fp32 storage and fp32 MFMA (the path the 1e-3 parity tests run), "
      "2 images, 1 warm-up + 2 timed steps; frac against the 157.3 TFLOP/s fp32 matrix peak"),
@@ -595,7 +604,7 @@ def main():
             del m
             keep = {k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "dense_wgrad", "losses")}
             keep["what"] = what
-            keep["config"] = {k: r["config"][k] for k in ("plan", "mode", "arch", "hint_loss", "per_gpu_batch")}
+            keep["config"] = {k: r["config"][k] for k in ("plan", "mode", "arch", "hint_loss", "per_gpu_batch", "share_frozen_prefix", "per_step_host_syncs")}
             keep["roofline"]["peak_tflops"] = r["roofline"]["peak"]
             subs[name] = keep
         res["sub_records"] = subs

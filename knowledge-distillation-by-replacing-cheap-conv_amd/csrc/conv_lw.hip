@@ -169,17 +169,25 @@ __global__ __launch_bounds__(256, 1) void conv_row_lw_kernel(const ConvParams p)
         const uint32_t nper = (uint32_t)(p.nkc * cur.nky);
         const u64 sAn = a_of(cur, 0, 1), sBn = b_of(cur, 0, 1), sAnT = a_of(nxt, 0, 0), sBnT = b_of(nxt, 0, 0);
         const int dAs = (int)dWl2, dAw = (int)(128 - (cur.nky - 1) * dWl2), dBs = 6 * p.Cin, dBw = 128 - (cur.nky - 1) * 6 * p.Cin;
-        asm volatile(LW_TILE_ASM
-                     : [sBp] "+s"(sBp), LW_ACC_RW
-                     : [va0] "v"(va[0]), [va1] "v"(va[1]), [va2] "v"(va[2]), [va3] "v"(va[3]), [va4] "v"(va[4]), [va5] "v"(va[5]), [vb] "v"(vb),
-                       [voa0] "v"(voa[0]), [voa1] "v"(voa[1]), [voa2] "v"(voa[2]), [voa3] "v"(voa[3]), [voa4] "v"(voa[4]), [voa5] "v"(voa[5]),
-                       [voa6] "v"(voa[6]), [voa7] "v"(voa[7]), [voa8] "v"(voa[8]), [voa9] "v"(voa[9]), [vob0] "v"(vob[0]), [vob1] "v"(vob[1]),
-                       [vob2] "v"(vob[2]), [vob3] "v"(vob[3]), [vz0] "v"(vz0), [vz1] "v"(vz1), [vzero] "v"(vzero), [vr0] "v"(vr0),
-                       [sAn] "s"(sAn), [sBn] "s"(sBn), [sAnT] "s"(sAnT), [sBnT] "s"(sBnT), [slo] "s"(cur.lo), [ssp] "s"(cur.span),
-                       [sloT] "s"(nxt.lo), [sspT] "s"(nxt.span), [sdAs] "s"(dAs), [sdAw] "s"(dAw), [sdBs] "s"(dBs), [sdBw] "s"(dBw),
-                       [snky] "s"((uint32_t)cur.nky), [snper] "s"(nper), [s2c] "s"(s2c), [sflag] "s"(flag), [spar] "s"(par),
+#define LW_TILE_OPERANDS \
+: [sBp] "+s"(sBp), LW_ACC_RW \
+                     : [va0] "v"(va[0]), [va1] "v"(va[1]), [va2] "v"(va[2]), [va3] "v"(va[3]), [va4] "v"(va[4]), [va5] "v"(va[5]), [vb] "v"(vb), \
+                       [voa0] "v"(voa[0]), [voa1] "v"(voa[1]), [voa2] "v"(voa[2]), [voa3] "v"(voa[3]), [voa4] "v"(voa[4]), [voa5] "v"(voa[5]), \
+                       [voa6] "v"(voa[6]), [voa7] "v"(voa[7]), [voa8] "v"(voa[8]), [voa9] "v"(voa[9]), [vob0] "v"(vob[0]), [vob1] "v"(vob[1]), \
+                       [vob2] "v"(vob[2]), [vob3] "v"(vob[3]), [vz0] "v"(vz0), [vz1] "v"(vz1), [vzero] "v"(vzero), [vr0] "v"(vr0), \
+                       [sAn] "s"(sAn), [sBn] "s"(sBn), [sAnT] "s"(sAnT), [sBnT] "s"(sBnT), [slo] "s"(cur.lo), [ssp] "s"(cur.span), \
+                       [sloT] "s"(nxt.lo), [sspT] "s"(nxt.span), [sdAs] "s"(dAs), [sdAw] "s"(dAw), [sdBs] "s"(dBs), [sdBw] "s"(dBw), \
+                       [snky] "s"((uint32_t)cur.nky), [snper] "s"(nper), [s2c] "s"(s2c), [sflag] "s"(flag), [spar] "s"(par), \
                        [sldsA] "s"(sldsA), [sldsB] "s"(sldsB)
-                     : "memory", "scc", "vcc", LW_CLOBBER_S, LW_CLOBBER_FRAG);
+#ifdef KDCC_TUNING
+        // KDCC_CONV_TUNE & 32768: the deliberately broken schedule (one barrier removed, wave 0 delayed: tools/gen_conv_lw.py BROKEN) --
+        // the defect tests/test_lw_bitwise_gpu.py's A/B has to find; results are wrong by construction
+        if (p.tune & 32768)
+            asm volatile(LW_TILE_BROKEN_ASM LW_TILE_OPERANDS, [swv] "s"(wv) : "memory", "scc", "vcc", LW_CLOBBER_S, LW_CLOBBER_FRAG);
+        else
+#endif
+        asm volatile(LW_TILE_ASM LW_TILE_OPERANDS : "memory", "scc", "vcc", LW_CLOBBER_S, LW_CLOBBER_FRAG);
+#undef LW_TILE_OPERANDS
         par = (par + nper) & 1u;
         // ---- the tile is complete: accumulators -> memory (conv_common.h ig_epilogue_rows16, 128 x 64 at a time) ----------------
         asm volatile("s_nop 15\n\ts_nop 15" : LW_ACC_RW : : "memory");   // the last MFMAs' results have reached the accumulator file

@@ -40,7 +40,7 @@ def _full_record():
             "losses": {"hint": 123.456789012, "supervised": 3.0123456, "kd": 1e-6, "teacher": 3.0123456},
             "cpu_baseline": {"unit": "images/sec", "cores": 16, "host_cpu_count": 256, "kind": "port", "value": 0.01761234,
                              "step_1024x2048_s": 56.7812, "step_512x1024_s": 13.651234, "sample": "s" * 300},
-            "sub_records": {n: sub for n in ("P79", "modeB", "gscnn_P86", "weighted_hint")}}
+            "sub_records": {n: sub for n in ("P79", "modeB", "gscnn_P86", "weighted_hint", "share_prefix", "ref_logging", "f32_parity")}}
 
 
 def test_compact_line_is_short_and_complete():
@@ -59,7 +59,7 @@ def test_compact_line_is_short_and_complete():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in rec["cpu_baseline"], k
     assert abs(rec["value"] - full["value"]) < 1e-2 and abs(rec["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-3
-    assert set(rec["sub_records"]) == {"P79", "modeB", "gscnn_P86", "weighted_hint"}
+    assert set(rec["sub_records"]) == {"P79", "modeB", "gscnn_P86", "weighted_hint", "share_prefix", "ref_logging", "f32_parity"}
     assert rec["sub_records"]["modeB"]["wgrad_frac"] == 0.412
     assert rec["batch_sweep"] == {"1": 40.12, "2": 40.12, "4": 40.12}
     assert len(rec["roofline"]["classes"]) == 13 and rec["roofline"]["classes"]["losses"][1] == 0.544

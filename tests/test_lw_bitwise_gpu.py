@@ -23,10 +23,11 @@ import lw_check  # noqa: E402  (the case table only: importing it touches neithe
 BATCH = 8
 
 
-def _arm(lw):
+def _arm(lw, only="", **extra):
     env = dict(os.environ, KDCC_CONV_LW=lw, KDCC_CONV_LW_PW="1", KDCC_CONV_DUO="0")
     env.pop("KDCC_LIB", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lw_check.py"), "--child", "--batch", str(BATCH), "--iters", "1"],
+    env.update(extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lw_check.py"), "--child", "--batch", str(BATCH), "--iters", "1", "--only", only],
                        env=env, capture_output=True, text=True, timeout=900)
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
     assert r.returncode == 0 and line, f"child KDCC_CONV_LW={lw} failed rc={r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
@@ -61,3 +62,20 @@ def test_lone_wave_kernels_bit_identical_to_ping_pong(arms, case):
     assert lw["finite"] and pp["finite"], name
     assert len(lw["digest"]) == len(outs)
     assert lw["digest"] == pp["digest"], f"{name} {opnds} -> {outs}: {want_lw} and {want_pp} differ (sha256 of the outputs at {BATCH} images)"
+
+
+def test_the_ab_finds_a_deliberately_missing_barrier(arms):
+    """The self-test of the check above: the diagnostics build carries the same generated loop with ONE barrier removed and wave 0
+    delayed in front of it (tools/gen_conv_lw.py BROKEN, KDCC_CONV_TUNE=32768 with KDCC_LIB=tuning; the shipped library compiles it
+    out) -- the defect class that produced round 4's "rare wrong tiles".  Every conv_row_lw_kernel case of the table must then differ
+    from the ping-pong arm: a bitwise A/B that stayed green on this schedule would be worth nothing."""
+    sys.path.insert(0, ROOT)
+    subprocess.check_call(["make", "-s", "-j", "8", "-C", os.path.join(ROOT, "knowledge-distillation-by-replacing-cheap-conv_amd", "csrc"), "TUNING=1"])
+    names = [c[0] for c in lw_check.CASES if _expected(c[0], c[1], c[2], c[4], c[5])[0] == "conv_row_lw_kernel"][:6]
+    assert len(names) >= 3
+    broken = _arm("1", only=",".join(names), KDCC_LIB="tuning", KDCC_CONV_TUNE="32768")
+    for name in names:
+        assert broken[name]["kernel"] == ["conv_row_lw_kernel"], name
+        assert broken[name]["digest"] != arms["pp"][name]["digest"], f"{name}: the A/B did not notice the missing barrier"
+    sane = _arm("1", only=names[0], KDCC_LIB="tuning")        # the diagnostics build without the fault: identical again
+    assert sane[names[0]]["digest"] == arms["pp"][names[0]]["digest"]

@@ -405,6 +405,42 @@ def test_conv_at_real_reduction_depth_per_tile(K, case, kernel):
         assert worst < 1e-2, f"{what} {case}: worst tile relative L2 {worst:.2e} (bf16 output rounding is 2e-3)"
 
 
+@pytest.mark.parametrize("case,kernel", [
+    ((8, 128, 256, 128, 768, 3, 2, 2), "conv_row_lw_kernel"),              # 1024 M tiles x 3 N tiles = 3072 tiles, 8 images, dil 2
+    ((8, 128, 256, 256, 768, 1, 0, 1), "conv_igemm_persist_kernel<pp>"),   # the same grid on the gathered 1x1 kernel
+])
+def test_conv_at_bench_batch_per_tile(K, case, kernel):
+    """The persistent kernels at the BENCH's batch: 8 images and more than 2048 tiles in one launch, so the image stride of the
+    input / output addressing and the tile walk past 2048 tiles are checked by the oracle, not only by the determinism / property
+    tests of tests/test_fullsize_gpu.py.  Every pixel of all 8 images for 32 output channels spread over the three N tiles (the
+    oracle runs on the sliced weight), judged per 256-pixel x N-tile tile (wider_resnet.py:124-167)."""
+    dt = "bf16"
+    N, H, W, Cin, Cout, k, p, d = case
+    x = q(np.maximum(rnd(N, Cin, H, W), 0), dt)
+    w = q(rnd(Cout, Cin, k, k, scale=(2.0 / (Cin * k * k)) ** 0.5), dt)
+    ascale, ashift = rnd(Cout) * 0.2 + 1.0, rnd(Cout) * 0.3
+    out_raw = torch.zeros((N, H, W, Cout), dtype=DT[dt], device="cuda")
+    out_act = torch.zeros((N, H, W, Cout), dtype=DT[dt], device="cuda")
+    K.conv2d(dev_nhwc(x, dt), K.pack_conv_weight(torch.from_numpy(w).cuda(), DT[dt]), 1, p, d, out_raw=out_raw, out_act=out_act,
+             act_scale=torch.from_numpy(ascale).cuda(), act_shift=torch.from_numpy(ashift).cuda(), act_relu=True)
+    selected(kernel, f"{case}")
+    assert (N * H * W // 256) * (Cout // 256) > 2048
+    cs = np.arange(0, Cout, 24)
+    ci = torch.from_numpy(cs).cuda()
+    ref = orc.conv2d_fwd(x, w[cs], pad=p, dil=d)
+    act_ref = np.maximum(ref * ascale[cs][None, :, None, None] + ashift[cs][None, :, None, None], 0)
+    sl = lambda t: t.index_select(3, ci).float().cpu().numpy().transpose(0, 3, 1, 2)     # (slice on the device: the full tensors are 0.8 GB in fp32)
+    for what, got, want in (("raw", sl(out_raw), ref), ("act", sl(out_act), act_ref)):
+        assert_close(got, want, dt, f"{what} {case}")
+        tn = cs // 256
+        worst = 0.0
+        for t in np.unique(tn):
+            e = ((got[:, tn == t] - want[:, tn == t]) ** 2).reshape(N, -1, H, W // 256, 256).sum(axis=(1, 4))
+            r = (want[:, tn == t] ** 2).reshape(N, -1, H, W // 256, 256).sum(axis=(1, 4))
+            worst = max(worst, float(np.sqrt((e / np.maximum(r, r.mean() / 16)).max())))
+        assert worst < 1e-2, f"{what} {case}: worst tile relative L2 {worst:.2e} (bf16 output rounding is 2e-3)"
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_conv_wide_tile_dgrad_epilogue(K, dt):
     """Backward use of the wide tiles: dgrad (KD_PACK_DGRAD weights) of a 3x3 dil-2 conv on row-buffer tiles and of a 1x1 on

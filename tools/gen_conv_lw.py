@@ -52,8 +52,14 @@ def frag_regs(s):
     return [base + 4 * i for i in range(8)], [base + 32 + 4 * j for j in range(8)]
 
 
+BROKEN = False      # main() sets it while it renders LW_TILE_BROKEN_ASM (tuning build only, tests/test_lw_bitwise_gpu.py's self-test)
+
+
 def kstep(par, p, zero=False):
-    """zero: the tile's first k-step -- the MFMAs take 0 as their C operand (the accumulators still hold the previous tile)"""
+    """zero: the tile's first k-step -- the MFMAs take 0 as their C operand (the accumulators still hold the previous tile).
+    BROKEN: the even body's k-step 3 loses its barrier and wave 0 sleeps ~60 k cycles at its start, so the other waves run one
+    k-step ahead of it -- they read fragments of pieces wave 0 has not staged yet, and stage into the slot it has yet to read: the
+    defect class (a missing barrier) the bitwise A/B test has to catch, made deterministic."""
     cur = p & 1
     areg, breg = frag_regs(cur)
     nareg, nbreg = frag_regs(1 - cur)
@@ -91,6 +97,9 @@ def kstep(par, p, zero=False):
                          f"global_load_lds_dwordx4 %[voa{j}], {SAN}", "s_not_b64 exec, exec",
                          f"ds_write_b128 %[vz{nb}], %[vzero] offset:{j * 1024}", "s_mov_b64 exec, -1"]
     L = []
+    broken_here = BROKEN and par == 0 and p == 3 and not zero
+    if broken_here:
+        L += ["s_cmp_lg_u32 %[swv], 0", f"s_cbranch_scc1 LWBRK{par}{p}_%="] + ["s_sleep 127"] * 8 + [f"LWBRK{par}{p}_%=:"]
     k = 0
     for i in range(8):
         for j in range(8):
@@ -109,7 +118,8 @@ def kstep(par, p, zero=False):
             L.append(f"s_mov_b32 {SFLAG}, 0")
     else:
         L.append(f"s_waitcnt vmcnt({n}) lgkmcnt(0)")
-    L.append("s_barrier")
+    if not broken_here:
+        L.append("s_barrier")
     return L
 
 
@@ -460,6 +470,10 @@ def main():
     o = ["// GENERATED by tools/gen_conv_lw.py -- do not edit (python tools/gen_conv_lw.py rewrites it).",
          "// The hand-scheduled main loop of conv_row_lw_kernel; see the generator for the schedule.", ""]
     o += ["#define LW_TILE_ASM \\", cstr(tile()), ""]
+    global BROKEN
+    BROKEN = True
+    o += ["#ifdef KDCC_TUNING", "#define LW_TILE_BROKEN_ASM \\", cstr(tile()), "#endif", ""]
+    BROKEN = False
     o += ["#define LW_REFILL_ASM \\", cstr(refill()), ""]
     o += ["#define DUO_TILE_ASM \\", cstr(tile_duo()), ""]
     o += ["#define DUO_REFILL_ASM \\", cstr(refill_duo()), ""]
