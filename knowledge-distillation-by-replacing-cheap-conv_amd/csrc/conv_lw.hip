@@ -182,11 +182,12 @@ __global__ __launch_bounds__(256, 1) void conv_row_lw_kernel(const ConvParams p)
 #ifdef KDCC_TUNING
         // KDCC_CONV_TUNE & 32768: the deliberately broken schedule (one barrier removed, wave 0 delayed: tools/gen_conv_lw.py BROKEN) --
         // the defect tests/test_lw_bitwise_gpu.py's A/B has to find; results are wrong by construction
-        if (p.tune & 32768)
-            asm volatile(LW_TILE_BROKEN_ASM LW_TILE_OPERANDS, [swv] "s"(wv) : "memory", "scc", "vcc", LW_CLOBBER_S, LW_CLOBBER_FRAG);
-        else
-#endif
+        // (the diagnostics build always runs the variant; brk = 0 takes the regular path through it)
+        const uint32_t brk = (p.tune & 32768) ? 1u : 0u;
+        asm volatile(LW_TILE_BROKEN_ASM LW_TILE_OPERANDS, [swv] "s"((uint32_t)wv), [sbrk] "s"(brk) : "memory", "scc", "vcc", LW_CLOBBER_S, LW_CLOBBER_FRAG);
+#else
         asm volatile(LW_TILE_ASM LW_TILE_OPERANDS : "memory", "scc", "vcc", LW_CLOBBER_S, LW_CLOBBER_FRAG);
+#endif
 #undef LW_TILE_OPERANDS
         par = (par + nper) & 1u;
         // ---- the tile is complete: accumulators -> memory (conv_common.h ig_epilogue_rows16, 128 x 64 at a time) ----------------

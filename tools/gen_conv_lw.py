@@ -98,8 +98,9 @@ def kstep(par, p, zero=False):
                          f"ds_write_b128 %[vz{nb}], %[vzero] offset:{j * 1024}", "s_mov_b64 exec, -1"]
     L = []
     broken_here = BROKEN and par == 0 and p == 3 and not zero
-    if broken_here:
-        L += ["s_cmp_lg_u32 %[swv], 0", f"s_cbranch_scc1 LWBRK{par}{p}_%="] + ["s_sleep 127"] * 8 + [f"LWBRK{par}{p}_%=:"]
+    if broken_here:      # (%[sbrk] = 0: the regular schedule)
+        L += ["s_cmp_eq_u32 %[sbrk], 0", f"s_cbranch_scc1 LWBRK{par}{p}_%=", "s_cmp_lg_u32 %[swv], 0", f"s_cbranch_scc1 LWBRK{par}{p}_%="] + \
+             ["s_sleep 127"] * 8 + [f"LWBRK{par}{p}_%=:"]
     k = 0
     for i in range(8):
         for j in range(8):
@@ -118,7 +119,9 @@ def kstep(par, p, zero=False):
             L.append(f"s_mov_b32 {SFLAG}, 0")
     else:
         L.append(f"s_waitcnt vmcnt({n}) lgkmcnt(0)")
-    if not broken_here:
+    if broken_here:
+        L += ["s_cmp_lg_u32 %[sbrk], 0", f"s_cbranch_scc1 LWNOBAR{par}{p}_%=", "s_barrier", f"LWNOBAR{par}{p}_%=:"]
+    else:
         L.append("s_barrier")
     return L
 
