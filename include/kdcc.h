@@ -93,7 +93,11 @@ typedef struct kd_conv_epilogue {
     float *bn_sums;       /* optional, with `mask`: [M/128][2][Cout] fp32 partial sums over blocks of 128 output pixels of
                              g = (mask > 0 ? v * mask_scale : 0) and of g * mask -- the eval-mode BN parameter gradients'
                              reductions, taken where the input gradient is produced instead of by kd_channel_sums reading it
-                             back.  Only the kernels kd_conv2d_bn_sums_rows() reports write it; finish with kd_bn_sums_finish */
+                             back.  Only the kernels kd_conv2d_bn_sums_rows() reports write it; finish with kd_bn_sums_finish.
+                             WITHOUT `mask` (forward, round 6): part[r][0][c] = sum over the 128 pixels of row block r of the
+                             values stored to out_raw, part[r][1][c] = 0 -- the global average pool of the ASPP image-pooling branch
+                             (models/deeplabv3/deeplabv3.py:59-62) taken where its input is produced; kd_aspp_image_pool_sums
+                             consumes the rows.  Only the ping-pong 1x1 kernel with no epilogue operand and out_raw alone. */
 } kd_conv_epilogue;
 
 int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w_packed,
@@ -291,6 +295,12 @@ size_t kd_aspp_image_pool_workspace(int32_t N, int32_t Cin, int32_t Cout);
 int kd_aspp_image_pool(int32_t dtype, const void *x, int32_t ldx, const float *w, const float *scale,
                        const float *shift, void *y, int32_t ldy, int32_t N, int32_t H, int32_t W,
                        int32_t Cin, int32_t Cout, void *workspace, size_t workspace_bytes, kd_stream_t stream);
+/* The same branch from per-128-pixel channel sums that the producing conv's epilogue already took (kd_conv_epilogue.bn_sums without
+ * a mask: `part` = [N*H*W/128][2][Cin], rows of an image consecutive; H*W % 128 == 0): no pass over x.  Rows are added in order
+ * (bit-reproducible).  Same workspace size as kd_aspp_image_pool. */
+int kd_aspp_image_pool_sums(int32_t dtype, const float *part, const float *w, const float *scale, const float *shift, void *y,
+                            int32_t ldy, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void *workspace,
+                            size_t workspace_bytes, kd_stream_t stream);
 
 /* ------------------------------------------------- backward of the trunk plumbing
  * (autograd of the calls above; needed once gradients flow through the whole student: loss = kd + hint with every

@@ -128,6 +128,7 @@ _SIGS = {
     "kd_aspp_image_pool_workspace": (c_sz, [c_int, c_int, c_int]),
     "kd_aspp_image_pool": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_vp, c_sz, c_vp]),
+    "kd_aspp_image_pool_sums": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
     "kd_bn_fold": (c_int, [c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_int, c_vp]),
     "kd_copy_cast": (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_i64, c_vp]),
     "kd_loss_workspace": (c_sz, [c_int, c_int, c_i64]),

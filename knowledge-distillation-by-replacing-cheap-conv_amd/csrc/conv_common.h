@@ -110,8 +110,12 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
     typedef bf16_t T;
     constexpr int NOPS = NOPS_ & 3;
     constexpr bool SUMS = (NOPS_ & 4) != 0;
-    static_assert((MI == 8 || (MI == 4 && !(NOPS_ & 4))) && NOPS_ >= 0 && NOPS_ <= 7 && NOPS_ != 4,
-                  "128-row wave sub-tiles (64 rows at a time: conv_row_duo_kernel, no sums); sums need the mask operand");
+    // NOPS_ == 8 (round 6): no operands, and the per-channel sums of the OUTPUT over the wave's 128 rows go to the same partial rows
+    // (S1 = sum of the stored values, S2 = 0) -- the global average pool of models/deeplabv3/deeplabv3.py:59-62 taken where the
+    // tensor it pools is produced, instead of another pass over 2 GB
+    constexpr bool OSUMS = NOPS_ == 8;
+    static_assert((MI == 8 || (MI == 4 && !(NOPS_ & 12))) && NOPS_ >= 0 && (NOPS_ <= 7 || NOPS_ == 8) && NOPS_ != 4,
+                  "128-row wave sub-tiles (64 rows at a time: conv_row_duo_kernel, no sums); eval-BN sums need the mask operand, output sums no operand");
     const kd_conv_epilogue &e = p.ep;
     // every per-lane address below derives from this copy: the compiler cannot hoist them out of the tile loop into
     // registers that would stay live through the main loop (which runs at the 256-VGPR limit)
@@ -244,6 +248,10 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
 #pragma unroll
                     for (int q = 0; q < 8; ++q) v[q] += t[q];
                 }
+                if constexpr (OSUMS) {     // (no operands: v holds the bf16 values that are stored)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) bs1[q] += v[q];
+                }
                 if constexpr (OUTS != 0) {
                     const int srow = (hb * 8 + ps) * 16;       // bytes per ld: row (hb * 8 + ps) * 8 of the wave's 128
                     if constexpr ((OUTS & 1) != 0) {
@@ -288,7 +296,7 @@ __device__ __forceinline__ void ig_epilogue_rows16(const ConvParams &p, char *pa
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
-    if constexpr (SUMS) {
+    if constexpr (SUMS || OSUMS) {
         // lanes l, l + 8, .., l + 56 hold the same 8 channels (rows lrow + 8 k): butterfly over lane bits 3-5 in a fixed order,
         // then lane l < 8 writes partial row mw / 128 of [M / 128][2][Cout] (summed in row order by kd_bn_sums_finish)
 #pragma unroll

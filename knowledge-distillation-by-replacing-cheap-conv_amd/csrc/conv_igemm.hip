@@ -1074,7 +1074,7 @@ __global__ __launch_bounds__(64 * CF::NW, CF::WPE) void conv_igemm_persist_kerne
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    const int nst_epi = 2 * MI * ((p.ep.out_raw ? 1 : 0) + (p.ep.out_act ? 1 : 0)) + ((NOPS & 4) ? 4 : 0);
+    const int nst_epi = 2 * MI * ((p.ep.out_raw ? 1 : 0) + (p.ep.out_act ? 1 : 0)) + ((NOPS & 12) ? 4 : 0);
     if constexpr (PP) {
         // Ping-pong with seamless tile transitions: the staging runs ahead of the compute ACROSS tiles -- group 0 always issues
         // the stage two ahead of the one it computes, group 1 its rows of the stage one ahead, whichever tile that stage
@@ -1505,10 +1505,18 @@ static ConvSel conv_select(const kd_conv_desc *d, const kd_conv_epilogue *ep, in
  * that kernel does not produce them (the caller then runs kd_channel_sums on the result). */
 extern "C" int32_t kd_conv2d_bn_sums_rows(const kd_conv_desc *d, const kd_conv_epilogue *ep)
 {
-    if (!d || !ep || !ep->mask || d->dtype != KD_BF16 || d->N <= 0 || d->Ho <= 0 || d->Wo <= 0) return 0;
+    if (!d || !ep || d->dtype != KD_BF16 || d->N <= 0 || d->Ho <= 0 || d->Wo <= 0) return 0;
     static int tn = -1;
     if (tn < 0) tn = KD_TUNING_ENV_INT("KDCC_CONV_TUNE");
     const ConvSel c = conv_select(d, ep, tn);
+    if (!ep->mask) {
+        // no mask: the sums of the OUTPUT (S1 = sum of the stored values, S2 = 0), which only the ping-pong 1x1 kernel without
+        // epilogue operands and with the raw output alone takes (the tensor the ASPP image pooling averages)
+        static int lw_pw = -1;
+        if (lw_pw < 0) { const char *v = getenv("KDCC_CONV_LW_PW"); lw_pw = (v && v[0] == '1') ? 1 : 0; }
+        if (!c.use_igemm_persist || c.nops != 0 || !ep->out_raw || ep->out_act || ep->raw_f32 || (tn & 512) || !pp_row() || lw_pw) return 0;
+        return (int32_t)((long long)d->N * d->Ho * d->Wo / 128);
+    }
     // (the ping-pong instantiations with one or two epilogue operands; with three the sums' registers spill 150 values)
     if (!(c.use_row_persist || c.use_igemm_persist || c.use_pp128) || (tn & 512) || !pp_row() || (c.use_row_persist && d->dil > 32) || c.nops > 2) return 0;
     return (int32_t)((long long)d->N * d->Ho * d->Wo / 128);
@@ -1689,7 +1697,8 @@ static int conv2d_fwd_impl(const kd_conv_desc *d, const void *x, const void *w_p
         if (lw) {
             KD_REQUIRE(kd_launch_conv_pw_lw(p, nops | (ep->bn_sums ? 4 : 0), grid.x, s), KD_ERR_UNSUPPORTED, "kd_conv2d_fwd: no conv_pw_lw_kernel instantiation for %d epilogue operands", nops);
         } else if (pp_row()) {
-            if (nops == 0) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 0, true>), grid, dim3(512), 0, s, p);
+            if (nops == 0 && ep->bn_sums) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 8, true>), grid, dim3(512), 0, s, p);
+            else if (nops == 0) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 0, true>), grid, dim3(512), 0, s, p);
             else if (ep->bn_sums && nops == 1) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 5, true>), grid, dim3(512), 0, s, p);
             else if (ep->bn_sums && nops == 2) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 6, true>), grid, dim3(512), 0, s, p);
             else if (nops == 1) hipLaunchKernelGGL((conv_igemm_persist_kernel<CfgWide, 1, true>), grid, dim3(512), 0, s, p);

@@ -180,25 +180,54 @@ __device__ __forceinline__ void write_item(char *X, int tid, const Staged &s)
     }
 }
 
-// Toeplitz operands of this wave's two channels from the bf16 tap table of input `b`
-__device__ __forceinline__ void build_toeplitz(const char *smem, int b, int wave, int fi, int kg, uint4 (&B)[2][9])
+// K slots (round 6, shared with dwconv_lw.hip): an output tile of 16 lattice columns reads 24 input columns per tap row, so one
+// MFMA (K = 32) per tap row wastes a quarter of its contraction.  The contraction index is only a label: the 9 x 3 (tap row, 8-column
+// group) pairs are dealt into 28 K groups = NM = 7 MFMAs per tile instead of 9.  Slot q = 4 m + kg of MFMA m: lane (i, kg) reads
+// row i + ky, columns cg * 8 .. + 7 of the tile, and its B fragment holds taps kx = cg * 8 + e - j of tap row ky.  ky < 0: the 28th
+// slot (zero operand).  Slots pair up as the lanes one ds_read_b128 group serves (kg 0 / 1, kg 2 / 3): a pair whose column groups
+// differ in parity is conflict-free at RSTR == 32 (mod 256) -- nine (ky, 0) | (ky, 1) pairs and (8, 2) | none; the four pairs of
+// the remaining (ky, 2) groups cost one extra LDS cycle per lane group.
+constexpr int NM = 7;
+__device__ __forceinline__ void slot_of(int q, int &ky, int &cg)
 {
-    int widx[8];   // byte offset of tap kx = kg*8 + q - fi in a table row (slot 15 holds zero)
+    const int pr = q >> 1, e = q & 1;
+    if (pr < 9) { ky = pr; cg = e; }
+    else if (pr == 9) { ky = e ? -1 : 8; cg = e ? 1 : 2; }
+    else { ky = 2 * (pr - 10) + e; cg = 2; }
+}
+// this lane's byte offset of MFMA m's slot inside a tile (tap row * RSTR + column group * 16), relative to the tile's (row i, column 0)
+__device__ __forceinline__ void slot_offsets(int kg, int (&sl)[NM])
+{
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int kx = kg * 8 + q - fi;
-        widx[q] = (kx >= 0 && kx < 9 ? kx : 15) * 2;
+    for (int m = 0; m < NM; ++m) {
+        int ky, cg;
+        slot_of(4 * m + kg, ky, cg);
+        sl[m] = ky < 0 ? 0 : ky * RSTR + cg * 16;
     }
+}
+
+// Toeplitz operands of this wave's two channels from the bf16 tap table of input `b`
+__device__ __forceinline__ void build_toeplitz(const char *smem, int b, int wave, int fi, int kg, uint4 (&B)[2][NM])
+{
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc)
+    for (int m = 0; m < NM; ++m) {
+        int ky, cg;
+        slot_of(4 * m + kg, ky, cg);
+        int widx[8];   // byte offset of tap kx = cg*8 + q - fi in a table row (slot 15 holds zero)
 #pragma unroll
-        for (int ky = 0; ky < 9; ++ky) {
-            const char *wr = smem + WT_OFF + b * WTBYTES + ((wave * 2 + cc) * 9 + ky) * 32;
+        for (int q = 0; q < 8; ++q) {
+            const int kx = cg * 8 + q - fi;
+            widx[q] = (ky >= 0 && kx >= 0 && kx < 9 ? kx : 15) * 2;
+        }
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const char *wr = smem + WT_OFF + b * WTBYTES + ((wave * 2 + cc) * 9 + max(ky, 0)) * 32;
             uint32_t v[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = *(const bf16_t *)(wr + widx[q]);
-            B[cc][ky] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+            B[cc][m] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
         }
+    }
 }
 
 // NB = 1: y = dwconv(x, w).
@@ -278,8 +307,10 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
     __syncthreads();
 
     const int fi = lane & 15, kg = lane >> 4;
-    uint4 B[2][9];
+    uint4 B[2][NM];
     build_toeplitz(smem, brof(0, cur), wave, fi, kg, B);
+    int sl[NM];
+    slot_offsets(kg, sl);
 
     int buf = 0, b = 0;
     f32x4_t acc[2][2][4];
@@ -313,7 +344,7 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
         const int jlast = max(((CV + 7) & ~7) - 16, 0);          // last column tile start (multiple of 8: 16-B reads)
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
-            const char *xc = X + (wave * 2 + cc) * CSTR + kg * 16;
+            const char *xc = X + (wave * 2 + cc) * CSTR;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -332,11 +363,11 @@ __global__ __launch_bounds__(NT, 1) void dw_mfma_fwd_kernel(DwMfmaParams p)
                     if (mt < nmt && jt < njt && !(p.dbg & 1)) {
                         const char *xa = xc + ((mt ? m1 : 0) + fi) * RSTR + min(jt * 16, jlast) * 2;
 #pragma unroll
-                        for (int ky = 0; ky < 9; ++ky) {
-                            const uint4 a = *(const uint4 *)(xa + ky * RSTR);
-                            Mma<bf16_t>::run(a, B[cc][ky], acc[cc][mt][jt]);
+                        for (int m = 0; m < NM; ++m) {
+                            const uint4 a = *(const uint4 *)(xa + sl[m]);
+                            Mma<bf16_t>::run(a, B[cc][m], acc[cc][mt][jt]);
                         }
-                        __builtin_amdgcn_sched_barrier(0);   // one tile's 9 fragments in flight at a time (register budget)
+                        __builtin_amdgcn_sched_barrier(0);   // one tile's 7 fragments in flight at a time (register budget)
                     }
                 }
             }

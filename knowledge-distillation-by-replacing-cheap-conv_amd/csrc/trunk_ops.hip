@@ -558,6 +558,19 @@ __global__ __launch_bounds__(256) void gap_finish_kernel(const float *__restrict
     for (int k = 0; k < GAP_CHUNKS; ++k) s += partial[(size_t)k * N * C + i];
     mean[i] = s / (float)HW;
 }
+// mean[n][c] from the partial rows a conv epilogue wrote while it produced the pooled tensor (kd_conv_epilogue.bn_sums without a
+// mask: part[row][0][c] = sum over 128 pixels): rows n * rpi .. + rpi - 1 belong to image n, added in row order (fixed: bit-reproducible)
+__global__ __launch_bounds__(256) void gap_rows_finish_kernel(const float *__restrict__ part, float *__restrict__ mean, int N, int rpi,
+                                                              int HW, int C)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    const float *src = part + (size_t)n * rpi * 2 * C + c;
+    float s = 0.f;
+    for (int r = 0; r < rpi; ++r) s += src[(size_t)r * 2 * C];
+    mean[i] = s / (float)HW;
+}
 __global__ __launch_bounds__(256) void img_conv_kernel(const float *__restrict__ mean, const float *__restrict__ w,
                                                        const float *__restrict__ scale, const float *__restrict__ shift,
                                                        float *__restrict__ out, int Cin, int Cout)
@@ -770,6 +783,32 @@ extern "C" int kd_aspp_image_pool(int32_t dtype, const void *x, int32_t ldx, con
     if (dtype == KD_BF16) hipLaunchKernelGGL(broadcast_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, vec, (bf16_t *)y, ldy, N, HW, Cout);
     else hipLaunchKernelGGL(broadcast_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, vec, (float *)y, ldy, N, HW, Cout);
     KD_CHECK_LAUNCH("kd_aspp_image_pool");
+    return KD_OK;
+}
+
+/* kd_aspp_image_pool with the pooled sums already taken: part = the [N*H*W/128][2][Cin] partial rows kd_conv2d_fwd /
+ * kd_conv1x1_dual_fwd wrote into ep->bn_sums (no mask) while producing the tensor.  H*W % 128 == 0 (an image is whole rows).
+ * workspace: kd_aspp_image_pool_workspace(N, Cin, Cout). */
+extern "C" int kd_aspp_image_pool_sums(int32_t dtype, const float *part, const float *w, const float *scale, const float *shift, void *y,
+                                       int32_t ldy, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void *workspace,
+                                       size_t workspace_bytes, kd_stream_t stream)
+{
+    KD_REQUIRE(part && w && scale && shift && y && workspace, KD_ERR_INVALID, "kd_aspp_image_pool_sums: null argument");
+    KD_REQUIRE(dtype == KD_F32 || dtype == KD_BF16, KD_ERR_INVALID, "kd_aspp_image_pool_sums: bad dtype");
+    const int es = kd_elem_size(dtype);
+    KD_REQUIRE(Cout % 8 == 0 && kd_aligned16(y) && (ldy * es) % 16 == 0, KD_ERR_INVALID, "kd_aspp_image_pool_sums: Cout %% 8 and 16-B alignment required");
+    KD_REQUIRE(N > 0 && H > 0 && W > 0 && (H * W) % 128 == 0, KD_ERR_INVALID, "kd_aspp_image_pool_sums: an image must be a whole number of 128-pixel rows");
+    KD_REQUIRE(workspace_bytes >= kd_aspp_image_pool_workspace(N, Cin, Cout), KD_ERR_WORKSPACE, "kd_aspp_image_pool_sums: workspace too small");
+    float *mean = (float *)workspace + (size_t)GAP_CHUNKS * N * Cin;
+    float *vec = mean + (size_t)N * Cin;
+    const int HW = H * W;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gap_rows_finish_kernel, dim3((N * Cin + 255) / 256), dim3(256), 0, s, part, mean, N, HW / 128, HW, Cin);
+    hipLaunchKernelGGL(img_conv_kernel, dim3((Cout + 3) / 4, N), dim3(256), 0, s, mean, w, scale, shift, vec, Cin, Cout);
+    const long long total = (long long)N * HW * (Cout / 8);
+    if (dtype == KD_BF16) hipLaunchKernelGGL(broadcast_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, vec, (bf16_t *)y, ldy, N, HW, Cout);
+    else hipLaunchKernelGGL(broadcast_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, vec, (float *)y, ldy, N, HW, Cout);
+    KD_CHECK_LAUNCH("kd_aspp_image_pool_sums");
     return KD_OK;
 }
 

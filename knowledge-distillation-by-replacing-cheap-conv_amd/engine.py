@@ -48,6 +48,7 @@ _STEM_POOL = os.environ.get("KDCC_STEM_POOL", "1") != "0"   # A/B: 0 = stem conv
 _DW_SUM = os.environ.get("KDCC_DW_SUM", "1") != "0"   # A/B: 0 = one depthwise input-gradient launch per ASPP branch
 _CONV_DUAL = os.environ.get("KDCC_CONV_DUAL", "1") != "0"   # A/B: 0 = a bottleneck block's conv3 / proj_conv (and conv1 / proj_conv input gradients) as two launches
 _FUSE_BN_SUMS = os.environ.get("KDCC_FUSE_BN_SUMS", "1") != "0"   # A/B: 0 = eval-BN parameter sums by kd_channel_sums only
+_FUSE_GAP = os.environ.get("KDCC_FUSE_GAP", "1") != "0"   # A/B: 0 = the ASPP image pooling reads the trunk output again instead of taking the producing conv's channel sums
 
 
 class EngineError(RuntimeError):
@@ -406,8 +407,13 @@ class StudentEngine:
             mod_end = is_last or flat[bi + 1][0].split(".")[0] != name.split(".")[0]
             if self.is_gscnn and mod_end and name.split(".")[0] in ("mod3", "mod4"):
                 need_raw = True   # dsn3 / dsn4 read the raw module outputs
+            # the trunk's last block produces the tensor the ASPP image-pooling branch averages: its conv epilogue takes the per-channel
+            # sums where the kernel can (ops.conv2d(out_sums=)), and the pooling never reads the 4096-channel map
+            gap = [] if (is_last and _FUSE_GAP and self.dtype == torch.bfloat16) else None
             x_raw, a, rg, rec = self._block_fwd(name, blk, x_raw, a, rg, nxt.bn1 if nxt is not None else None, need_raw,
-                                                want, note_hint, bi)
+                                                want, note_hint, bi, out_sums=gap)
+            if gap:
+                tape["x7_sums"] = gap[0]
             tape["blocks"].append(rec)
             if self.is_gscnn and mod_end:
                 tape.setdefault("mods", {})[name.split(".")[0]] = x_raw
@@ -442,7 +448,7 @@ class StudentEngine:
         lead = self._aspp_lead(aspp)
         cat = self._new(N, h8, w8, red * (nb + lead))
         sc, sh = self._bn_fold(aspp.img_conv[1])
-        ops.aspp_image_pool(x7, aspp.img_conv[0].weight.detach(), sc, sh, cat[..., 0:red])
+        ops.aspp_image_pool(x7, aspp.img_conv[0].weight.detach(), sc, sh, cat[..., 0:red], sums=tape.get("x7_sums"))
         if lead == 2:   # edge branch: resampled edge attention -> 1x1 (1 -> red) -> BN -> ReLU
             sc, sh = self._bn_fold(aspp.edge_conv[1])
             ops.edge_aspp(tape["acts"], aspp.edge_conv[0].weight.detach().float().reshape(-1).contiguous(), sc, sh, cat[..., red:2 * red])
@@ -819,7 +825,7 @@ class StudentEngine:
                            small=(h8, w8))
         return logits
 
-    def _block_fwd(self, name, blk, x_raw, a1, rg_in, next_bn, need_raw, want, note_hint, bi):
+    def _block_fwd(self, name, blk, x_raw, a1, rg_in, next_bn, need_raw, want, note_hint, bi, out_sums=None):
         """One pre-activation residual block.  a1 = relu(bn1(x)) already produced by the previous kernel.
         rg_in: a trainable parameter lies upstream of the block input."""
         convs = [(n, m) for n, m in blk.convs.named_children() if n.startswith("conv")]
@@ -878,6 +884,8 @@ class StudentEngine:
                     kw.update(out_act=a_next, act_scale=sc, act_shift=sh, act_relu=True)
                 kw["out_raw"] = raw
                 x_out = raw
+                if out_sums is not None and not site.cheap and site.gate is None:
+                    kw["out_sums"] = out_sums
             else:
                 sc, sh = self._act_fold(bns[f"bn{i + 2}"], _act_gate(bns[f"bn{i + 2}"]))
                 act = self._new(N, ho, wo, site.cout)

@@ -115,13 +115,16 @@ class DualUnsupported(_lib.KdccError):
 
 def conv2d(x, w_packed, stride=1, pad=0, dil=1, *, res_pre=None, mask=None, mask_scale=None, res_post=None,
            out_raw=None, out_act=None, act_scale=None, act_shift=None, act_relu=False, algo_cin=None, algo_cout=None, bn_sums=None,
-           x2=None):
+           x2=None, out_sums=None):
     """Implicit-GEMM conv; w_packed is (Cout,kh,kw,Cin). Outputs are caller-provided NHWC views.
     x2: a second (N,H,W,Cin2) source of a K-concatenated 1x1 conv -- w_packed is then (Cout,1,1,Cin + Cin2), the result
     [x | x2] . w^T in one accumulator chain (kd_conv1x1_dual_fwd); raises DualUnsupported where the kernel does not apply.
     bn_sums: an empty list (backward, with `mask`): when the kernel this problem selects can take the eval-BN parameter sums in
     its epilogue, (s1, s2) = per-channel sums of the masked gradient and of it times `mask` are appended -- what
-    channel_sums(out_raw, sub=res_post, a=mask) would return from another pass over the tensors; otherwise it stays empty."""
+    channel_sums(out_raw, sub=res_post, a=mask) would return from another pass over the tensors; otherwise it stays empty.
+    out_sums: an empty list (forward, no epilogue operand, out_raw alone): when the selected kernel can sum its output per channel
+    over blocks of 128 pixels in its epilogue, the [M/128][2][Cout] partial rows are appended (aspp_image_pool(..., sums=) takes
+    them: the global average pool of the tensor without another pass over it); otherwise it stays empty."""
     _need_cuda(x, w_packed)
     N, H, W, Cin = x.shape
     Cout, kh, kw, Cin_w = w_packed.shape
@@ -170,6 +173,13 @@ def conv2d(x, w_packed, stride=1, pad=0, dil=1, *, res_pre=None, mask=None, mask
         if sums_rows > 0:
             part = torch.empty((sums_rows, 2, Cout), dtype=torch.float32, device=x.device)
             ep.bn_sums = _ptr(part)
+    out_rows = 0
+    if out_sums is not None and mask is None and res_pre is None and res_post is None and out_act is None and out_raw is not None:
+        out_rows = int(_lib.lib().kd_conv2d_bn_sums_rows(C.byref(d), C.byref(ep)))
+        if out_rows > 0:
+            opart = torch.empty((out_rows, 2, Cout), dtype=torch.float32, device=x.device)
+            ep.bn_sums = _ptr(opart)
+            out_sums.append(opart)
     prof = PROFILER
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
@@ -186,7 +196,7 @@ def conv2d(x, w_packed, stride=1, pad=0, dil=1, *, res_pre=None, mask=None, mask
         e1.record()
         epi = "".join(c for c, t in (("p", res_pre), ("m", mask), ("q", res_post), ("r", out_raw), ("a", out_act)) if t is not None)
         prof.append(("conv_igemm", 2.0 * N * Ho * Wo * (algo_cout or Cout) * kh * kw * (algo_cin or (Cin + Cin2)), e0, e1,
-                     f"{kh}x{kw} s{stride} d{dil} {H}x{W} {Cin}{'+%d' % Cin2 if Cin2 else ''}->{Cout} [{epi}{'s' if sums_rows else ''}]", _lib.last_kernel()))
+                     f"{kh}x{kw} s{stride} d{dil} {H}x{W} {Cin}{'+%d' % Cin2 if Cin2 else ''}->{Cout} [{epi}{'s' if sums_rows or out_rows else ''}]", _lib.last_kernel()))
     if sums_rows > 0:
         s12 = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
         need = _lib.lib().kd_bn_sums_finish_workspace(sums_rows, Cout)
@@ -646,8 +656,9 @@ def upsample_bilinear_ac(x, size, out=None, out_dtype=None, align_corners=True):
     return out
 
 
-def aspp_image_pool(x, w, scale, shift, out):
-    """x (N,H,W,Cin); w (Cout,Cin[,1,1]) fp32; writes the broadcast branch into `out` (N,H,W,Cout) view."""
+def aspp_image_pool(x, w, scale, shift, out, sums=None):
+    """x (N,H,W,Cin); w (Cout,Cin[,1,1]) fp32; writes the broadcast branch into `out` (N,H,W,Cout) view.
+    sums: the [N*H*W/128][2][Cin] partial rows the conv that produced x took in its epilogue (conv2d(out_sums=)): x is not read."""
     _need_cuda(x, w, scale, shift, out)
     N, H, W, Cin = x.shape
     Cout = out.shape[3]
@@ -656,6 +667,13 @@ def aspp_image_pool(x, w, scale, shift, out):
         raise ValueError("aspp_image_pool: bad operands")
     need = _lib.lib().kd_aspp_image_pool_workspace(N, Cin, Cout)
     ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    if sums is not None:
+        _need_cuda(sums)
+        if tuple(sums.shape) != (N * H * W // 128, 2, Cin) or (H * W) % 128 or sums.dtype != torch.float32 or not sums.is_contiguous():
+            raise ValueError("aspp_image_pool: sums must be the contiguous fp32 [N*H*W/128][2][Cin] partial rows of x")
+        check(_lib.lib().kd_aspp_image_pool_sums(dt_of(x), _ptr(sums), _ptr(w), _ptr(scale), _ptr(shift), _ptr(out), nhwc_ld(out),
+                                                 N, H, W, Cin, Cout, _ptr(ws), need, stream_ptr()), "kd_aspp_image_pool_sums")
+        return out
     check(_lib.lib().kd_aspp_image_pool(dt_of(x), _ptr(x), nhwc_ld(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(out),
                                         nhwc_ld(out), N, H, W, Cin, Cout, _ptr(ws), need, stream_ptr()), "kd_aspp_image_pool")
     return out

@@ -94,7 +94,7 @@ def _step(model, backprop="hint"):
 
 
 SHIPPED_MODE_A = ["conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>", "conv_row_tall_kernel",
-                  "dw_mfma_fwd_kernel<1,false>", "dw_mfma_fwd_kernel<3,true>", "dw_mfma_fwd_kernel<3,false>",
+                  "dw_mfma_fwd_kernel<1,false>", "dw_lw_fan3_kernel", "dw_mfma_fwd_kernel<3,false>",
                   "dw_mfma_wgrad_kernel", "dw_mfma_wgrad_multi_kernel<3>", "stem_pool_kernel", "conv_wgrad_wide_kernel"]   # (the pointwise weight gradients take the 256x256 wgrad tile)
 
 
@@ -189,7 +189,7 @@ def test_bf16_weighted_hint_step_vs_network_oracle():
         kd = losses.KLDivergenceLoss(1)(out_st, out_tc)
         hint.backward()
         torch.cuda.synchronize()
-    for k in ("conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>", "dw_mfma_fwd_kernel<3,true>", "dw_mfma_wgrad_multi_kernel<3>"):
+    for k in ("conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>", "dw_lw_fan3_kernel", "dw_mfma_wgrad_multi_kernel<3>"):
         assert log.counts.get(k, 0) > 0, (k, log.counts)
     tsd = seeded_teacher_sd()
     ssd = net_ref.make_student_sd(tsd, P92, seeded_cheap_weights(tsd, P92))
@@ -386,7 +386,7 @@ def test_fullsize_bench_step_determinism_batch_independence_and_prefix_sharing()
     ("modeB", dict(mode="B"), ("conv_wgrad_row_kernel", "conv_wgrad_wide_kernel", "conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>",
                               "conv_row_tall_kernel", "dw_mfma_wgrad_multi_kernel<3>", "bn_sums_epilogue", "stem_wgrad_mfma_kernel")),
     ("gscnn_P86", dict(arch="gscnn", plan="P86"), ("conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>", "conv_row_tall_kernel",
-                                                   "conv3x3_small_kernel<64>", "gated_conv_mfma_kernel", "dw_mfma_fwd_kernel<3,true>")),
+                                                   "conv3x3_small_kernel<64>", "gated_conv_mfma_kernel", "dw_lw_fan3_kernel")),
 ])
 def test_fullsize_bench_subrecords_are_deterministic(name, kw, must):
     """The other two steps bench.py times as sub-records -- mode B (loss = KLDiv + hints, every student parameter trainable) and

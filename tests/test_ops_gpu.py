@@ -1312,3 +1312,44 @@ def test_cheap_conv_block_module_small_channels(K, golden):
         assert_close(x.grad.cpu().numpy(), g[f"{tag}.gx"], "f32", f"{tag} gx")
         assert_close(blk.separable_conv.weight.grad.cpu().numpy(), g[f"{tag}.gw_dw"], "f32", f"{tag} gw_dw")
         assert_close(blk.pointwise_conv.weight.grad.cpu().numpy(), g[f"{tag}.gw_pw"], "f32", f"{tag} gw_pw")
+
+
+@pytest.mark.parametrize("dual", [False, True])
+def test_conv_output_sums_feed_the_image_pooling(K, dual):
+    """conv2d(out_sums=): the ping-pong 1x1 kernel sums its output per channel over blocks of 128 pixels in its epilogue (the tensor
+    the ASPP image-pooling branch averages, models/deeplabv3/deeplabv3.py:59-62, produced by mod7's last block) and
+    aspp_image_pool(sums=) finishes the branch without reading the map.  Against the sums of the stored tensor (exact per block up to
+    the fp32 order), against the separate-pass pooling, and per image: every image has its own rows."""
+    dt = "bf16"
+    N, H, W, C1, C2, Cout, red = 3, 64, 256, 128, 64, 512, 64
+    x1, x2 = q(rnd(N, C1, H, W), dt), q(rnd(N, C2, H, W), dt)
+    x1[1] *= 3.0          # images differ in scale: rows of different images must not mix
+    w = q(rnd(Cout, C1 + C2 if dual else C1, 1, 1, scale=0.08), dt)
+    wp = K.pack_conv_weight(torch.from_numpy(w).cuda(), DT[dt])
+    out = torch.zeros((N, H, W, Cout), dtype=DT[dt], device="cuda")
+    sums = []
+    if dual:
+        K.conv2d(dev_nhwc(x1, dt), wp, x2=dev_nhwc(x2, dt), out_raw=out, out_sums=sums)
+        selected("conv_igemm_persist_kernel<pp,dual>", "output sums, dual")
+    else:
+        K.conv2d(dev_nhwc(x1, dt), wp, out_raw=out, out_sums=sums)
+        selected("conv_igemm_persist_kernel<pp>", "output sums")
+    assert len(sums) == 1 and tuple(sums[0].shape) == (N * H * W // 128, 2, Cout)
+    part = sums[0].cpu().numpy()
+    ref_out = orc.conv2d_fwd(np.concatenate([x1, x2], 1) if dual else x1, w)
+    assert_close(host_nchw(out), ref_out, dt, "conv with output sums")
+    blocks = out.float().reshape(N * H * W // 128, 128, Cout).sum(1).cpu().numpy()      # sums of the STORED (rounded) values
+    np.testing.assert_allclose(part[:, 0], blocks, rtol=2e-5, atol=2e-4)
+    assert not part[:, 1].any()
+    wi = rnd(red, Cout, scale=0.05)
+    sc, sh = torch.from_numpy(rnd(red) * 0.2 + 1.0).cuda(), torch.from_numpy(rnd(red) * 0.1).cuda()
+    a = torch.zeros((N, H, W, red), dtype=DT[dt], device="cuda")
+    b = torch.zeros_like(a)
+    K.aspp_image_pool(out, torch.from_numpy(wi).cuda(), sc, sh, a)
+    K.aspp_image_pool(out, torch.from_numpy(wi).cuda(), sc, sh, b, sums=sums[0])
+    assert float((a.float() - b.float()).abs().max()) <= 2.0 ** -7 * float(a.float().abs().max())
+    mean = host_nchw(out).mean(axis=(2, 3))                                               # (N, Cout) of the stored tensor
+    want = np.maximum((mean @ wi.T) * sc.cpu().numpy() + sh.cpu().numpy(), 0)
+    got = b.float().cpu().numpy()[:, 0, 0, :]
+    np.testing.assert_allclose(got, want, rtol=2e-2, atol=2e-3)
+    assert float((b.float() - b[:, :1, :1, :].float()).abs().max()) == 0.0                  # broadcast over the pixels
