@@ -1601,7 +1601,7 @@ static int conv2d_fwd_impl(const kd_conv_desc *d, const void *x, const void *w_p
     const bool half = sel.half, row_wide = sel.row_wide, row_x = sel.row_x, row_narrow = sel.row_narrow;
     KD_REQUIRE(!ep->bn_sums || kd_conv2d_bn_sums_rows(d, ep) > 0, KD_ERR_UNSUPPORTED,
                "kd_conv2d_fwd: bn_sums is not produced by the kernel this problem selects (ask kd_conv2d_bn_sums_rows first)");
-    if (ep->bn_sums) KD_NOTE_KERNEL("bn_sums_epilogue");   // (kernel-selection log: counted next to the kernel that carries it)
+    if (ep->bn_sums) KD_NOTE_KERNEL(ep->mask ? "bn_sums_epilogue" : "out_sums_epilogue");   // (kernel-selection log: counted next to the kernel that carries it)
     hipStream_t s = (hipStream_t)stream;
     // Workgroups of the persistent kernels (one per CU, each walks tiles for 1-6 ms).  KDCC_PERSIST_CUS=n (a multiple of 8,
     // e.g. 248) leaves CUs free for a concurrent kernel -- the RCCL all-reduce the gradient reducer launches on its side stream
