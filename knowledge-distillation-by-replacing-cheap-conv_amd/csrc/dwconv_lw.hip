@@ -64,6 +64,7 @@ struct DwLwParams {
     const float *w[MAXB];      // taps [81][C] per branch
     bf16_t *y[MAXB];           // fan-out: one output per branch; sum: y[0]
     int N, H, W, C, dil, ldx, ldy;
+    long long xplane, yplane;  // 0: NHWC (pixel stride ldx / ldy).  > 0: channel-planar [C/64][N*H*W][64] -- elements between two 64-channel planes, pixel stride 64
     const int *items;          // descriptors of the non-empty work items of one (image, channel group), 16 dwords each
     int nty, ntx, ncg, nitems, nseg;
 };
@@ -165,8 +166,9 @@ __global__ __launch_bounds__(LNT, 1) void dw_lw_fan3_kernel(DwLwParams p)
     const int ibeg = (int)((long long)p.nitems * seg / p.nseg), iend = (int)((long long)p.nitems * (seg + 1) / p.nseg);
     if (ibeg >= iend) return;   // workgroup-uniform
     const int d = p.dil;
-    const bf16_t *ximg = p.x[0] + (size_t)n * p.H * p.W * p.ldx + c0;
-    const size_t img_y = (size_t)n * p.H * p.W * p.ldy + c0;
+    // (planar tensors: channel group cgi = 16 channels at offset (cgi & 3) * 16 of plane cgi >> 2)
+    const bf16_t *ximg = p.x[0] + (p.xplane ? (size_t)(cgi >> 2) * p.xplane + (size_t)n * p.H * p.W * 64 + (cgi & 3) * 16 : (size_t)n * p.H * p.W * p.ldx + c0);
+    const size_t img_y = p.yplane ? (size_t)(cgi >> 2) * p.yplane + (size_t)n * p.H * p.W * 64 + (cgi & 3) * 16 : (size_t)n * p.H * p.W * p.ldy + c0;
     const int nrx = (int)((((size_t)p.H * p.W - 1) * p.ldx + CG) * 2), nry = (int)((((size_t)p.H * p.W - 1) * p.ldy + CG) * 2);
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)ximg, 0, nrx, 0x00020000);
 
@@ -373,6 +375,8 @@ int kd_internal_dw_lw_fanout(const kd_dw_desc *d, int nb, const void *x, const f
         if (dbg < 0) dbg = KD_TUNING_ENV_INT("KDCC_DW_LW_DBG");
         if (dbg & 4) dd.ldy = 16;
         if (dbg & 8) dd.ldx = 16;
+        if (dbg & 16) dd.ldy = 64;
+        if (dbg & 32) dd.ldx = 64;
     }
     const ItemTable *tab = item_table(&dd);
     if (!tab) return 0;
@@ -390,6 +394,10 @@ int kd_internal_dw_lw_fanout(const kd_dw_desc *d, int nb, const void *x, const f
         if (dbg < 0) dbg = KD_TUNING_ENV_INT("KDCC_DW_LW_DBG");
         if (dbg & 4) p.ldy = 16;
         if (dbg & 8) p.ldx = 16;
+        // 16 = outputs / 32 = input addressed as channel-planar [C/64][N*H*W][64] tensors (timing: the values land in other places)
+        p.xplane = p.yplane = 0;
+        if (dbg & 16) { p.ldy = 64; p.yplane = (long long)d->N * d->H * d->W * 64; }
+        if (dbg & 32) { p.ldx = 64; p.xplane = (long long)d->N * d->H * d->W * 64; }
     }
     p.nitems = tab->nvalid;
     dw_lw_split(d->N, d->C, tab->nvalid, &p.nseg);
