@@ -563,13 +563,24 @@ __global__ __launch_bounds__(256) void gap_finish_kernel(const float *__restrict
 __global__ __launch_bounds__(256) void gap_rows_finish_kernel(const float *__restrict__ part, float *__restrict__ mean, int N, int rpi,
                                                               int HW, int C)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N * C) return;
-    const int n = i / C, c = i - n * C;
-    const float *src = part + (size_t)n * rpi * 2 * C + c;
+    // block = 32 channels x 8 row slices of one image; a slice's rows are added in order, then the 8 slices in order
+    __shared__ float red[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl, n = blockIdx.y;
+    const int per = (rpi + 7) / 8, r0 = sl * per, r1 = min(rpi, r0 + per);
     float s = 0.f;
-    for (int r = 0; r < rpi; ++r) s += src[(size_t)r * 2 * C];
-    mean[i] = s / (float)HW;
+    if (c < C) {
+        const float *src = part + (size_t)n * rpi * 2 * C + c;
+        for (int r = r0; r < r1; ++r) s += src[(size_t)r * 2 * C];
+    }
+    red[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][cl];
+        mean[(size_t)n * C + c] = t / (float)HW;
+    }
 }
 __global__ __launch_bounds__(256) void img_conv_kernel(const float *__restrict__ mean, const float *__restrict__ w,
                                                        const float *__restrict__ scale, const float *__restrict__ shift,
@@ -803,7 +814,7 @@ extern "C" int kd_aspp_image_pool_sums(int32_t dtype, const float *part, const f
     float *vec = mean + (size_t)N * Cin;
     const int HW = H * W;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(gap_rows_finish_kernel, dim3((N * Cin + 255) / 256), dim3(256), 0, s, part, mean, N, HW / 128, HW, Cin);
+    hipLaunchKernelGGL(gap_rows_finish_kernel, dim3((Cin + 31) / 32, N), dim3(256), 0, s, part, mean, N, HW / 128, HW, Cin);
     hipLaunchKernelGGL(img_conv_kernel, dim3((Cout + 3) / 4, N), dim3(256), 0, s, mean, w, scale, shift, vec, Cin, Cout);
     const long long total = (long long)N * HW * (Cout / 8);
     if (dtype == KD_BF16) hipLaunchKernelGGL(broadcast_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, vec, (bf16_t *)y, ldy, N, HW, Cout);
