@@ -207,6 +207,12 @@ CONV_CLASSES = (("conv_row_lw_kernel", "conv3x3_row_lone_wave_256x256"), ("conv_
                 ("conv_row_tall_kernel", "conv3x3_row_lone_wave_512x128"), ("conv_row_pp128_kernel", "conv3x3_row_512x128"))
 
 
+# depthwise classes with a floor record: (tensors one launch moves, MFMAs per (output element, branch)): a 13 x 52 item-channel-branch is 4 column tiles x 7
+# MFMAs in the forward / input-gradient kernels (K slots), 21 rows x 2 column blocks of Hankel MFMAs in the weight gradient
+DW_FLOORS = {"depthwise_fwd_fanout": (4, 28 / (13 * 52)), "depthwise_dgrad_sum": (4, 28 / (13 * 52)), "depthwise_wgrad": (4, 42 / (13 * 52))}
+DW_CLOCK_HZ = 2.1e9
+
+
 def _classify(rec):
     fam, kern, label = rec[0], (rec[5] if len(rec) > 5 else ""), rec[4]
     if fam == "conv_igemm":
@@ -250,6 +256,14 @@ def class_rooflines(prof, steps, peak_tflops):
                      "achieved": rate, "unit": "GB/s" if hbm else "TFLOP/s", "peak": PEAK_HBM_GBS if hbm else peak_tflops,
                      "frac": rate / (PEAK_HBM_GBS if hbm else peak_tflops),
                      ("algorithmic_gb_per_step" if hbm else "algorithmic_tflop_per_step"): work / steps / (1e9 if hbm else 1e12)}
+        if name in DW_FLOORS:
+            # the class's true floors: matrix work at 16 cycles per MFMA on 1024 SIMDs, bytes at the 6.3 TB/s a
+            # contiguous stream gets, and bytes at the 2.5 TB/s the memory system delivers on these kernels' 32-B channel slices
+            # (profiles/r06_dw_anatomy.md) -- the HBM fraction above is against 8 TB/s
+            tensors, mfma_per_elem = DW_FLOORS[name]
+            elems = work / steps / 2.0 / tensors * (tensors - 1)          # (output element, branch) pairs per step
+            out[name]["floor_ms"] = {"matrix": elems * mfma_per_elem * 16 / (1024 * DW_CLOCK_HZ) * 1e3, "bytes_at_6.3TBps": work / steps / 6.3e12 * 1e3,
+                                     "bytes_at_2.5TBps_pattern": work / steps / 2.5e12 * 1e3}
     return out
 
 
@@ -455,6 +469,9 @@ def compact_record(res, full_path=None):
                        **{k: _r(rf.get(k)) for k in ("achieved", "peak", "unit", "frac", "traffic", "traffic_src", "launches_per_step",
                                                  "ms_per_step_in_kernel", "algorithmic_tflop_per_step")},
                        "classes": {n: [_r(c["ms_per_step"], 3), _r(c["frac"], 3)] for n, c in rf["classes"].items()},
+                       "dw_floor_ms": {n: [_r(c["floor_ms"]["matrix"], 3), _r(c["floor_ms"]["bytes_at_6.3TBps"], 3), _r(c["floor_ms"]["bytes_at_2.5TBps_pattern"], 3)]
+                                       for n, c in rf["classes"].items() if "floor_ms" in c},
+                       "dw_floor_fmt": "[matrix, bytes / 6.3 TB/s, bytes / 2.5 TB/s (measured cap of 32-B channel slices)] ms per step",
                        "classes_fmt": "[ms_per_step, frac of its roof (mfma 2500 TFLOP/s | hbm 8000 GB/s)]"}
     if res.get("profiler"):
         out["profiler"] = {k: _r(v) for k, v in res["profiler"].items()}
