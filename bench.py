@@ -5,6 +5,8 @@ Cityscapes-shaped tensors (BASELINE.json).  One process per GPU:
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (no launcher: bench.py starts that torch.distributed.run itself as a fresh
+                                                          child process before anything touches a GPU, and relays rank 0's line)
 
 A step = what trainer/layerwise_trainer.py:220-239 of the reference does per batch: teacher forward (frozen, PyTorch-
 ROCm), student forward (HIP engine), the four criteria (CE x2, KD, hint), loss = hint loss, backward, (N>1: bucketed
