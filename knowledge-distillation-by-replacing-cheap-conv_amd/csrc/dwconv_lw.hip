@@ -297,17 +297,20 @@ struct ItemTable {
 std::mutex g_tab_mu;
 std::vector<ItemTable> g_tabs;
 
-const ItemTable *item_table(const kd_dw_desc *d)
+// (returns a copy: the vector may grow under another thread's call once the lock is released; dptr == nullptr: no table)
+ItemTable item_table(const kd_dw_desc *d)
 {
+    ItemTable none;
+    memset(&none, 0, sizeof(none));
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess) return none;
     std::lock_guard<std::mutex> lk(g_tab_mu);
     for (const ItemTable &t : g_tabs)
-        if (t.H == d->H && t.W == d->W && t.dil == d->dil && t.ldx == d->ldx && t.ldy == d->ldy && t.dev == dev) return &t;
+        if (t.H == d->H && t.W == d->W && t.dil == d->dil && t.ldx == d->ldx && t.ldy == d->ldy && t.dev == dev) return t;
     const int dl = d->dil, H = d->H, W = d->W;
     const int LH = (H + dl - 1) / dl, LW = (W + dl - 1) / dl;
     const int nty = (LH + TLY - 1) / TLY, ntx = (LW + TLX - 1) / TLX;
-    if (nty > 255 || ntx > 255 || dl > 255) return nullptr;
+    if (nty > 255 || ntx > 255 || dl > 255) return none;
     std::vector<int> host;
     for (int e = 0; e < nty * ntx * dl * dl; ++e) {
         int q = e;
@@ -344,11 +347,11 @@ const ItemTable *item_table(const kd_dw_desc *d)
     t.H = H; t.W = W; t.dil = dl; t.ldx = d->ldx; t.ldy = d->ldy; t.dev = dev;
     t.nvalid = (int)(host.size() / 16);
     t.dptr = nullptr;
-    if (t.nvalid == 0) return nullptr;
-    if (hipMalloc((void **)&t.dptr, host.size() * sizeof(int)) != hipSuccess) return nullptr;
-    if (hipMemcpy(t.dptr, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { hipFree(t.dptr); return nullptr; }
+    if (t.nvalid == 0) return none;
+    if (hipMalloc((void **)&t.dptr, host.size() * sizeof(int)) != hipSuccess) return none;
+    if (hipMemcpy(t.dptr, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { hipFree(t.dptr); return none; }
     g_tabs.push_back(t);
-    return &g_tabs.back();
+    return t;
 }
 }  // namespace
 
@@ -378,8 +381,9 @@ int kd_internal_dw_lw_fanout(const kd_dw_desc *d, int nb, const void *x, const f
         if (dbg & 16) dd.ldy = 64;
         if (dbg & 32) dd.ldx = 64;
     }
-    const ItemTable *tab = item_table(&dd);
-    if (!tab) return 0;
+    const ItemTable tabv = item_table(&dd);
+    if (!tabv.dptr) return 0;
+    const ItemTable *tab = &tabv;
     DwLwParams p;
     for (int b = 0; b < MAXB; ++b) {
         p.x[b] = (const bf16_t *)x;

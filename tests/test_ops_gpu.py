@@ -617,12 +617,16 @@ def test_dwconv_fanout(K, dt, case):
     (3, 7, 9, 16),           # a residue class of 2 x 2 pixels: one short item per class, single column tile
     (1, 5, 5, 48),           # one pixel per class, three channel groups
     (1, 266, 40, 16),        # five row tiles, 8 columns
+    (2, 10, 30, 16, 1),      # dilation 1, ONE work item per workgroup (the item loop's exit on its first pass)
+    (1, 20, 30, 32, 1),      # dilation 1, two items per workgroup (nothing to stage behind the second)
+    (1, 40, 120, 16, 2),     # dilation 2: four classes of 20 x 60, two row tiles and two column tiles each
 ])
 def test_dwconv_fanout_lone_wave_shapes(K, case):
     """dw_lw_fan3_kernel against the oracle on the geometries its work-item descriptors distinguish: tiles in both directions,
     ragged last tiles, classes shorter than a tile, items with fewer than four column tiles, one-item workgroups."""
-    N, H, W, Cc = case
-    k, p, d, dt = 9, 20, 5, "bf16"
+    N, H, W, Cc = case[:4]
+    d = case[4] if len(case) > 4 else 5
+    k, p, dt = 9, 4 * d, "bf16"
     x = q(rnd(N, Cc, H, W), dt)
     ws = [rnd(Cc, 1, k, k, scale=1.0 / k) for _ in range(3)]
     taps = [K.pack_dw_weight(torch.from_numpy(w).cuda()) for w in ws]
