@@ -312,11 +312,21 @@ ItemTable item_table(const kd_dw_desc *d)
     const int nty = (LH + TLY - 1) / TLY, ntx = (LW + TLX - 1) / TLX;
     if (nty > 255 || ntx > 255 || dl > 255) return none;
     std::vector<int> host;
+    // order: the row tiles of one (class, column tile) back to back -- a tile shares its 8 halo rows with its vertical neighbour, and
+    // fetched 9 us apart instead of 25 items apart the second fetch still finds most of them in the XCD's L2
+    static int tile_major = -1;      // A/B: KDCC_DW_LW_ORDER=0 = classes innermost (round 6's first order: the halo rows are fetched from HBM twice)
+    if (tile_major < 0) { const char *v = getenv("KDCC_DW_LW_ORDER"); tile_major = (v && v[0] == '0') ? 1 : 0; }
     for (int e = 0; e < nty * ntx * dl * dl; ++e) {
-        int q = e;
-        const int rx = q % dl; q /= dl;
-        const int ry = q % dl; q /= dl;
-        const int tx = q % ntx, ty = q / ntx;
+        int q = e, rx, ry, tx, ty;
+        if (tile_major) {
+            rx = q % dl; q /= dl;
+            ry = q % dl; q /= dl;
+            tx = q % ntx; ty = q / ntx;
+        } else {
+            ty = q % nty; q /= nty;
+            tx = q % ntx; q /= ntx;
+            rx = q % dl; ry = q / dl;
+        }
         const int Ly = (H - ry + dl - 1) / dl, Lx = (W - rx + dl - 1) / dl;
         const int RV = std::min(TLY, Ly - ty * TLY), CV = std::min(TLX, Lx - tx * TLX);
         if (RV <= 0 || CV <= 0) continue;

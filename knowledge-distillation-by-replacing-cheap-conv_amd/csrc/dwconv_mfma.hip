@@ -700,13 +700,15 @@ struct DwWgMultiParams {
     LpGeom lp;           // GLP: the gradients g[] are lattice-planar (x stays NHWC)
 };
 
-__device__ __forceinline__ Item decode_item3(int H, int W, int d, int ntx, int e)
+// (round 6: the row tiles of one (class, column tile) are consecutive items -- a half-height item shares 8 staged x rows with its vertical
+// neighbour, and fetched back to back the second fetch finds most of them in the XCD's L2 instead of going to HBM again)
+__device__ __forceinline__ Item decode_item3(int H, int W, int d, int ntx, int nty, int e)
 {
     Item it;
-    it.rx = e % d; e /= d;
-    it.ry = e % d; e /= d;
-    it.tx = e % ntx;
-    it.ty = e / ntx;
+    it.ty = e % nty; e /= nty;
+    it.tx = e % ntx; e /= ntx;
+    it.rx = e % d;
+    it.ry = e / d;
     const int Ly = (H - it.ry + d - 1) / d, Lx = (W - it.rx + d - 1) / d;
     it.RV = min(TLY3, Ly - it.ty * TLY3);
     it.CV = min(TLX, Lx - it.tx * TLX);
@@ -793,8 +795,8 @@ __global__ __launch_bounds__(NTW, 1) void dw_mfma_wgrad_multi_kernel(DwWgMultiPa
     for (int b = 0; b < NG; ++b) acc[b][0] = acc[b][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     int cur = ibeg;
-    Item wi = decode_item3(p.H, p.W, p.dil, p.ntx, cur < iend ? cur : 0);
-    while (cur < iend && (wi.RV <= 0 || wi.CV <= 0)) { ++cur; if (cur < iend) wi = decode_item3(p.H, p.W, p.dil, p.ntx, cur); }
+    Item wi = decode_item3(p.H, p.W, p.dil, p.ntx, p.nty, cur < iend ? cur : 0);
+    while (cur < iend && (wi.RV <= 0 || wi.CV <= 0)) { ++cur; if (cur < iend) wi = decode_item3(p.H, p.W, p.dil, p.ntx, p.nty, cur); }
     if (cur < iend) {
         Staged3<NIX3> sx;
         Staged3<NIG3> sg0, sg1, sg2;
@@ -820,8 +822,8 @@ __global__ __launch_bounds__(NTW, 1) void dw_mfma_wgrad_multi_kernel(DwWgMultiPa
         while (true) {
             int nxt = cur + 1;
             Item wn = wi;
-            if (nxt < iend) wn = decode_item3(p.H, p.W, p.dil, p.ntx, nxt);
-            while (nxt < iend && (wn.RV <= 0 || wn.CV <= 0)) { ++nxt; if (nxt < iend) wn = decode_item3(p.H, p.W, p.dil, p.ntx, nxt); }
+            if (nxt < iend) wn = decode_item3(p.H, p.W, p.dil, p.ntx, p.nty, nxt);
+            while (nxt < iend && (wn.RV <= 0 || wn.CV <= 0)) { ++nxt; if (nxt < iend) wn = decode_item3(p.H, p.W, p.dil, p.ntx, p.nty, nxt); }
             const bool more = nxt < iend;
 
             const int RV = wi.RV;
