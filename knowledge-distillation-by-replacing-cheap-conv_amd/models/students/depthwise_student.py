@@ -222,8 +222,17 @@ class DepthwiseStudent(nn.Module):
         # (teacher_backend "torch") APPENDS to whatever list is there -- into `keep`, it would pair the next step's student hints
         # with this step's teacher hints
         self.teacher_hidden_outputs = []
+        # experiment: KDCC_TEACHER_CUS=n caps the persistent conv grids of the prefetched teacher's launches,
+        # KDCC_STUDENT_CUS=m those of everything launched afterwards -- the two networks then share the chip by CUs instead of by time
+        import os
+        tcus, scus = os.environ.get("KDCC_TEACHER_CUS"), os.environ.get("KDCC_STUDENT_CUS")
+        if tcus is not None:
+            from ... import _lib
+            _lib.check(_lib.lib().kd_conv_set_persist_cus(int(tcus)), "kd_conv_set_persist_cus")
         with torch.cuda.stream(self._side_stream):
             pred = self._teacher_forward(x)
+        if tcus is not None:
+            _lib.check(_lib.lib().kd_conv_set_persist_cus(int(scus or 0)), "kd_conv_set_persist_cus")
         hints = self.teacher_hidden_outputs
         self.teacher_hidden_outputs = keep
         self._prefix = None
