@@ -1,7 +1,7 @@
-// Depthwise 9x9 dilated convolution on the matrix cores, ONE WAVE PER SIMD (round 6): the fan-out  y_b = dwconv(x, w_b)
-// of the two or three depthwise convs that read one tensor (the replaced ASPP branches' forward, reference
-// models/deeplabv3/deeplabv3.py:64-75 over models/students/transform_blocks/depthwise_separable_conv.py:7-13), and the
-// sum  y = sum_b dwconv(x_b, w_b)  (the input gradient of that tensor).
+// Depthwise 9x9 dilated convolution on the matrix cores, ONE WAVE PER SIMD (round 6): the fan-out  y_b = dwconv(x, w_b)  of the
+// three depthwise convs that read one tensor (the replaced ASPP branches' forward, reference models/deeplabv3/deeplabv3.py:64-75
+// over models/students/transform_blocks/depthwise_separable_conv.py:7-13).  (Two branches, the summed input gradient and the
+// weight gradients stay on the 8- / 16-wave kernels of dwconv_mfma.hip: profiles/r06_dw_anatomy.md has the arithmetic.)
 //
 // What profiles/r05_dw_anatomy.md found in dw_mfma_fwd_kernel (dwconv_mfma.hip: 8 lock-step waves, 2 channels each): a
 // third of every launch is neither arithmetic nor memory -- the Toeplitz operands of a branch are rebuilt from the tap table
@@ -60,9 +60,9 @@ constexpr uint32_t BUF_OOB = 0x80000000u;
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 struct DwLwParams {
-    const bf16_t *x[MAXB];     // fan-out: x[0]; sum: one input per branch
+    const bf16_t *x[MAXB];     // the input (x[0]; the other slots repeat it)
     const float *w[MAXB];      // taps [81][C] per branch
-    bf16_t *y[MAXB];           // fan-out: one output per branch; sum: y[0]
+    bf16_t *y[MAXB];           // one output per branch
     int N, H, W, C, dil, ldx, ldy;
     long long xplane, yplane;  // 0: NHWC (pixel stride ldx / ldy).  > 0: channel-planar [C/64][N*H*W][64] -- elements between two 64-channel planes, pixel stride 64
     const int *items;          // descriptors of the non-empty work items of one (image, channel group), 16 dwords each
@@ -70,13 +70,9 @@ struct DwLwParams {
 };
 
 struct Item {
-    int ry, rx, ty, tx, RV, CV;
+    int ry, rx, ty, tx;
 };
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t image_rsrc(const bf16_t *base, int H, int W, int ld)
-{
-    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)((((size_t)H * W - 1) * ld + CG) * 2), 0x00020000);
-}
 __device__ __forceinline__ uint4 bload16(__amdgpu_buffer_rsrc_t r, uint32_t off)
 {
     const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
@@ -93,13 +89,6 @@ __device__ __forceinline__ void slot_of(int q, int &ky, int &cg)
     if (pr < 9) { ky = pr; cg = e; }
     else if (pr == 9) { ky = e ? -1 : 8; cg = e ? 1 : 2; }
     else { ky = 2 * (pr - 10) + e; cg = 2; }
-}
-
-__device__ __forceinline__ uint32_t pack2(float lo, float hi)     // one v_cvt_pk_bf16_f32 (RNE)
-{
-    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t));
 }
 
 struct Unit {
