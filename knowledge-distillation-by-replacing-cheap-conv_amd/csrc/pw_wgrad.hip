@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include "igemm_core.h"
+#include "wgrad_lw_body.inc"
 
 namespace {
 
@@ -725,6 +726,106 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row_kernel(const WgradParam
     }
 }
 
+// ---- the same tile on ONE wave per SIMD (round 6; stage loop generated by tools/gen_wgrad_lw.py -> wgrad_lw_body.inc) ----------------
+// conv_wgrad_row_kernel's stage takes 3300 cycles for 1536 cycles of MFMAs: its phases (LDS-DMA issue 1670, transposing fragment reads
+// 1340, MFMAs 1800 when run alone, tools/wgrad_timeline.py) barely overlap in 8 lock-step waves.  Here 4 waves (wave (wm, wn) = 64 Cout x
+// [3 kx x 64 Cin]: 48 accumulator tiles in a[0:191], fragments in v[128:255]) run a hand-dealt stream: per 32-pixel k-step 48 MFMAs with
+// the 32 ds_read_b64_tr_b16 of the next k-step, 4-5 LDS-DMA pieces and the fragment addresses' ring-slot step between them, one barrier
+// per stage.  Same decomposition (grid, splits, kernel row per workgroup), the same LDS images and the same K order: bit-identical partial
+// slabs.  Cin % 128 == 0, Cout % 128 == 0, dil <= 8 (row buffer of 80 rows: every wave stages 4 dy + 5 row-buffer pieces per stage).
+__global__ __launch_bounds__(256, 1) void conv_wgrad_lw_kernel(const WgradParams p)
+{
+    __shared__ __attribute__((aligned(1024))) char lds[WR_NST * WR_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int ky = lin % 3; lin /= 3;
+    const int tile = lin % p.tiles, split = lin / p.tiles;
+    const int t_ci = tile % p.tiles_ci, t_co = tile / p.tiles_ci;
+    const int co0 = t_co * 128, ci0 = t_ci * 128;
+    const int m_begin = split * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+    const int nst = max(0, (m_end - m_begin) / 64);   // (an empty split writes its zero slab: the generated loop skips itself)
+    const int d = p.dil;
+    const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
+    const int q = lane >> 4, li = lane & 15;
+
+    // fragment addresses (ring slot 0): A = dy^T tile wm * 4 + i, B = row-buffer tile (kx, wn * 4 + c) read at row offset kx * dil; the
+    // swizzle is keyed on the LDS row (tr_f), which for the shifted row-buffer reads depends on kx * dil and on the half
+    uint32_t va[4], vb[12][2];
+    {
+        const int mA = 8 * q + (li >> 2), fA = tr_f(mA);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) va[i] = lbase + mA * 256 + (((wm * 4 + i) ^ fA) << 5) + (li & 3) * 8;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const int kx = j >> 2, ct = wn * 4 + (j & 3);
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int m = kx * d + 8 * q + (li >> 2) + 4 * hf;
+                vb[j][hf] = lbase + 16384 + m * 256 + ((ct ^ tr_f(m)) << 5) + (li & 3) * 8;
+            }
+        }
+    }
+    // LDS-DMA sources: byte offsets from the stage's first dy pixel / first row-buffer pixel; wave w stages pieces w, w + 4, ...
+    const int prow = lane >> 4, slot = lane & 15;
+    uint32_t voy[4], vox[5];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = (wv + 4 * k) * 4 + prow;
+        voy[k] = (uint32_t)(r * p.ldy + co0 + (slot ^ (tr_f(r) << 1)) * 8) * 2u;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int r = (wv + 4 * k) * 4 + prow;
+        vox[k] = (uint32_t)(r * p.lda + ci0 + (slot ^ (tr_f(r) << 1)) * 8) * 2u;
+    }
+    const uint32_t vr0 = (uint32_t)(wv * 4 + prow);                    // this lane's buffer row in piece 0 (piece k: + 16 k)
+    const uint32_t vzl = lbase + wv * 1024 + lane * 16;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4w_t;
+    const u32x4w_t vzero = {0u, 0u, 0u, 0u};
+
+    // stage 0 of the split
+    const uint32_t n = fastdiv((uint32_t)m_begin, p.mg_howo, p.sh_howo);
+    const uint32_t rem = (uint32_t)m_begin - n * (uint32_t)(p.H * p.W);
+    const uint32_t ho = fastdiv(rem, p.mg_wo, p.sh_wo);
+    const uint32_t x0 = rem - ho * (uint32_t)p.W;
+    const bf16_t *syb = (const bf16_t *)p.dy + (size_t)m_begin * p.ldy;
+    const bf16_t *sxb = (const bf16_t *)p.a + ((long long)m_begin + (long long)(ky - 1) * d * p.W - d) * p.lda;   // (only dereferenced for lanes inside the image)
+    const uint32_t sdy = 64u * p.ldy * 2u, sdx = 64u * p.lda * 2u;
+    const int skyd = (ky - 1) * d;
+    const uint32_t send1 = 64u + d, send2 = 64u + 2u * d, sldsw = lbase + wv * 1024;
+
+    typedef __attribute__((ext_vector_type(32))) float f32x32_t;
+    f32x32_t A0, A1, A2, A3, A4, A5, A6, A7;
+    asm volatile(WGRAD_LW_ZERO_ASM : "=a"(A0), "=a"(A1), "=a"(A2), "=a"(A3), "=a"(A4), "=a"(A5), "=a"(A6), "=a"(A7));
+#define WGLW_ACC_RW "+a"(A0), "+a"(A1), "+a"(A2), "+a"(A3), "+a"(A4), "+a"(A5), "+a"(A6), "+a"(A7)
+    asm volatile(WGRAD_LW_LOOP_ASM
+                 : [va0] "+v"(va[0]), [va1] "+v"(va[1]), [va2] "+v"(va[2]), [va3] "+v"(va[3]),
+                   [vb0a] "+v"(vb[0][0]), [vb0b] "+v"(vb[0][1]), [vb1a] "+v"(vb[1][0]), [vb1b] "+v"(vb[1][1]), [vb2a] "+v"(vb[2][0]), [vb2b] "+v"(vb[2][1]),
+                   [vb3a] "+v"(vb[3][0]), [vb3b] "+v"(vb[3][1]), [vb4a] "+v"(vb[4][0]), [vb4b] "+v"(vb[4][1]), [vb5a] "+v"(vb[5][0]), [vb5b] "+v"(vb[5][1]),
+                   [vb6a] "+v"(vb[6][0]), [vb6b] "+v"(vb[6][1]), [vb7a] "+v"(vb[7][0]), [vb7b] "+v"(vb[7][1]), [vb8a] "+v"(vb[8][0]), [vb8b] "+v"(vb[8][1]),
+                   [vb9a] "+v"(vb[9][0]), [vb9b] "+v"(vb[9][1]), [vb10a] "+v"(vb[10][0]), [vb10b] "+v"(vb[10][1]), [vb11a] "+v"(vb[11][0]), [vb11b] "+v"(vb[11][1]),
+                   WGLW_ACC_RW
+                 : [voy0] "v"(voy[0]), [voy1] "v"(voy[1]), [voy2] "v"(voy[2]), [voy3] "v"(voy[3]),
+                   [vox0] "v"(vox[0]), [vox1] "v"(vox[1]), [vox2] "v"(vox[2]), [vox3] "v"(vox[3]), [vox4] "v"(vox[4]),
+                   [vr0] "v"(vr0), [vzl] "v"(vzl), [vzero] "v"(vzero),
+                   [syb] "s"(syb), [sxb] "s"(sxb), [sx0] "s"(x0), [sho] "s"(ho), [snst] "s"((uint32_t)nst), [sdy] "s"(sdy), [sdx] "s"(sdx),
+                   [sW] "s"((uint32_t)p.W), [sH] "s"((uint32_t)p.H), [sd] "s"((uint32_t)d), [send1] "s"(send1), [send2] "s"(send2), [skyd] "s"(skyd),
+                   [sldsw] "s"(sldsw)
+                 : "memory", "scc", "vcc", WGRAD_LW_CLOBBER_S, WGRAD_LW_CLOBBER_V);
+    // accumulators -> the split's fp32 slab: D[co = 16 i + 4 q + r][ci = li] of tile (i, j = kx * 4 + c)
+    float *out0 = p.part + ((size_t)split * 9 + ky * 3) * p.Cout * p.Cin + (size_t)co0 * p.Cin + ci0;
+    const float *out1 = out0 + (size_t)p.Cout * p.Cin, *out2 = out1 + (size_t)p.Cout * p.Cin;
+    const uint32_t vob = (uint32_t)((wm * 64 + q * 4) * p.Cin + wn * 64 + li) * 4u, cin4 = (uint32_t)p.Cin * 4u;
+    asm volatile(WGRAD_LW_STORE_ASM
+                 : WGLW_ACC_RW
+                 : [vob] "v"(vob), [vcin4] "s"(cin4), [sout0] "s"(out0), [sout1] "s"(out1), [sout2] "s"(out2)
+                 : "memory", "v127");
+#undef WGLW_ACC_RW
+}
+
 // plan of the row-buffer kernel: ~2.5 one-per-CU workgroups per CU, >= 8 stages per split
 int fill_splits(int per, int max_splits);   // below, next to wide_plan
 void row_plan(long long M, int Cin, int Cout, int &tiles, int &tiles_ci, int &splits, int &rps)
@@ -997,6 +1098,12 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
         fastdiv_magic((uint32_t)(d->H * d->W), p.mg_howo, p.sh_howo);
         fastdiv_magic((uint32_t)d->W, p.mg_wo, p.sh_wo);
         p.tiles = tiles;
+        static int lwmode = -1;
+        if (lwmode < 0) { const char *e = getenv("KDCC_WGRAD_LW"); lwmode = (e && e[0] == '0') ? 0 : 1; }   // A/B: 0 = conv_wgrad_row_kernel (8 waves); bit-identical
+        if (lwmode && !p.dbg && d->Cin % 128 == 0 && d->Cout % 128 == 0 && d->dil <= 8) {
+            KD_NOTE_KERNEL("conv_wgrad_lw_kernel");
+            hipLaunchKernelGGL(conv_wgrad_lw_kernel, dim3((unsigned)(tiles * splits * 3)), dim3(256), 0, s, p);
+        } else {
         KD_NOTE_KERNEL("conv_wgrad_row_kernel");
 #ifdef KDCC_TUNING
         static int il = -1;
@@ -1010,6 +1117,7 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
         else
 #endif
         hipLaunchKernelGGL((conv_wgrad_row_kernel<false, 1>), dim3((unsigned)(tiles * splits * 3)), dim3(512), 0, s, p);
+        }
     } else if (wide) {
         KD_NOTE_KERNEL("conv_wgrad_wide_kernel");
         if (!p.geom && !wide_general) hipLaunchKernelGGL(conv_wgrad_wide_kernel<true>, grid, dim3(512), 0, s, p);

@@ -148,6 +148,36 @@ def test_hand_scheduled_loops_pass_the_schedule_interpreter():
         G.ISSUED, G.TALL_WAIT, G.tall_shift = issued, waits, shift
 
 
+def test_weight_gradient_lone_wave_loop_is_generated_interpreted_and_audited():
+    """csrc/wgrad_lw_body.inc is the output of tools/gen_wgrad_lw.py (the stage loop of conv_wgrad_lw_kernel, pw_wgrad.hip).
+    tools/check_wgrad_lw.py walks the generated stream with the two in-order queues and their counted waits: fragments landed before
+    their MFMA, every LDS-DMA piece of a stage landed before the barrier behind which the stage is read, ring slots overwritten only
+    behind the barrier that retires them; and audits the compiled kernel (the accumulation file untouched by the compiler, 96 MFMAs in
+    one statement, no scratch).  Mutations it has to reject: the vector-memory waits one piece too lax; the LDS waits two reads too lax
+    (ONE is absorbed by design: the zero-fill ds_write of a row-buffer piece is not counted by the generator, under an all-zero EXEC
+    it might never enter the queue)."""
+    import shutil
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_wgrad_lw.py"), "--check"])
+    assert r.returncode == 0, "csrc/wgrad_lw_body.inc is stale: run python tools/gen_wgrad_lw.py"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_wgrad_lw as C
+    import gen_wgrad_lw as G
+    assert C.interpret(G.build()) == []
+    try:
+        G.SLACK_VM = 1
+        assert any("in flight at the barrier" in f for f in C.interpret(G.build()))
+        G.SLACK_VM, G.SLACK_DS = 0, 2
+        assert any("ds_read_b64_tr_b16" in f and "in flight" in f for f in C.interpret(G.build()))
+    finally:
+        G.SLACK_DS = G.SLACK_VM = 0
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_wgrad_lw.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+
+
 def test_depthwise_lone_wave_loop_is_generated_interpreted_and_audited():
     """csrc/dw_lw_body.inc is the output of tools/gen_dw_lw.py (the item loop of dw_lw_fan3_kernel, dwconv_lw.hip).  tools/check_dw_lw.py
     interprets the generated stream with the hardware's two in-order queues (LDS, vector memory) and its counted waits -- every MFMA

@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Checks of the lone-wave dense weight-gradient kernel (conv_wgrad_lw_kernel, csrc/pw_wgrad.hip + the generated csrc/wgrad_lw_body.inc).
+
+1. Schedule interpreter (no hipcc needed).  The generated stream is walked prologue -> stage body x 3 -> drain as the hardware retires
+   it: LDS operations and vector-memory operations are two IN-ORDER queues, `s_waitcnt lgkmcnt(n) / vmcnt(n)` retires all but the n
+   youngest of a queue.  Checked:
+   * every MFMA's fragment registers have landed (no transposing read into them is still in the LDS queue), and no read overwrites a
+     fragment register an older read is still in flight for;
+   * the LDS-DMA pieces are numbered by the stage they belong to (prologue: stages 0 and 1 whole and the first five pieces of stage 2;
+     stage body `it`: the last four pieces of stage it + 2 in k-step 0, the first five of stage it + 3 in k-step 1).  At the barrier
+     of stage body `it` no piece of a stage <= it + 1 may be in flight (k-step 1 reads stage it + 1 right behind it), at the
+     prologue's barrier none of stage 0; no LDS operation may be in flight at a barrier;
+   * the reads of k-step 0's fragments (ring offset 0 / 1024: stage it + 1) come behind the barrier, those of k-step 1's (offset 8192 /
+     9216: stage it) in front of it; the pieces that overwrite stage it - 1's slot come behind it;
+   * one barrier and 96 MFMAs per stage body, nothing in flight at the end.
+2. ISA audit (needs hipcc): in the compiled kernel no compiler-generated instruction touches an accumulation register, the 96 MFMAs
+   sit in ONE inline-asm statement, no scratch.
+
+usage: check_wgrad_lw.py [--no-isa]; exit 1 on a finding.  tests/test_abi.py runs it and holds it to account with mutated schedules."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "knowledge-distillation-by-replacing-cheap-conv_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+VREG = re.compile(r"\bv\[(\d+):(\d+)\]")
+
+
+def vregs(text):
+    out = []
+    for m in VREG.finditer(text):
+        out += list(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
+
+
+def interpret(lines, bodies=3):
+    findings = []
+    top = lines.index("WGL_LOOP_%=:")
+    back = max(i for i, l in enumerate(lines) if l.startswith("s_cbranch_scc1 WGL_LOOP"))
+    seq = [(l, -1) for l in lines[:top]]
+    for it in range(bodies):
+        seq += [(l, it) for l in lines[top + 1:back + 1]]
+    seq += [(l, bodies) for l in lines[back + 1:]]
+    ds, vm = [], []                 # ds: (dest regs, text); vm: stage of the piece
+    n_piece = 0
+    stats = {}
+
+    def stage_of(n):
+        if n < 23:
+            return 0 if n < 9 else 1 if n < 18 else 2
+        k = n - 23
+        it, r = divmod(k, 9)
+        return it + 2 if r < 4 else it + 3
+
+    barrier_seen = {}
+    for ins, it in seq:
+        op = ins.split(" ")[0]
+        st = stats.setdefault(it, {"mfma": 0, "barrier": 0})
+        if op == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", ins)
+            if m:
+                k = int(m.group(1))
+                ds = ds[len(ds) - k:] if k else []
+            m = re.search(r"vmcnt\((\d+)\)", ins)
+            if m:
+                k = int(m.group(1))
+                vm = vm[len(vm) - k:] if k else []
+            continue
+        if op == "s_barrier":
+            st["barrier"] += 1
+            barrier_seen[it] = True
+            if ds:
+                findings.append(f"body {it}: s_barrier with LDS operations in flight: {ds[-1][1]}")
+            limit = 0 if it < 0 else it + 1
+            late = [s for s in vm if s <= limit]
+            if late:
+                findings.append(f"body {it}: {len(late)} LDS-DMA piece(s) of stage {min(late)} in flight at the barrier behind which stage {limit} is read")
+            continue
+        if op.startswith("v_mfma"):
+            st["mfma"] += 1
+            pend = {r: t for d, t in ds for r in d}
+            for r in vregs(ins):
+                if r in pend:
+                    findings.append(f"body {it}: `{ins}` reads v{r} while `{pend[r]}` is in flight")
+            continue
+        if op.startswith("ds_read"):
+            dst = vregs(ins.split(",")[0])
+            pend = {r: t for d, t in ds for r in d}
+            for r in dst:
+                if r in pend:
+                    findings.append(f"body {it}: `{ins}` overwrites v{r} while `{pend[r]}` is in flight")
+            ds.append((dst, ins))
+            if it >= 0 and it < bodies:
+                off = int(re.search(r"offset:(\d+)", ins).group(1))
+                ks = 1 if off >= 8192 else 0
+                if ks == 0 and not barrier_seen.get(it):
+                    findings.append(f"body {it}: a read of stage {it + 1} in front of the barrier that publishes it: {ins}")
+                if ks == 1 and barrier_seen.get(it):
+                    findings.append(f"body {it}: a read of stage {it} behind the barrier that retires it: {ins}")
+            continue
+        if op.startswith("ds_write"):
+            ds.append(([], ins))
+            continue
+        if op.startswith("global_load_lds"):
+            s = stage_of(n_piece)
+            n_piece += 1
+            vm.append(s)
+            if 0 <= it < bodies and s == it + 3 and not barrier_seen.get(it):
+                findings.append(f"body {it}: a piece of stage {s} overwrites stage {it - 1}'s slot in front of the barrier: {ins}")
+            continue
+    for it, st in stats.items():
+        if 0 <= it < bodies and (st["mfma"] != 96 or st["barrier"] != 1):
+            findings.append(f"body {it}: {st['mfma']} MFMAs / {st['barrier']} barriers (96 / 1 expected)")
+    if ds or vm:
+        findings.append(f"operations still in flight at the end: {len(ds)} LDS, {len(vm)} vector memory")
+    return findings
+
+
+def audit_isa(text):
+    findings = []
+    m = re.search(r"^(_ZN\S*conv_wgrad_lw_kernel\S*):\s*;[^\n]*\n(.*?)\.Lfunc_end", text, flags=re.M | re.S)
+    if not m:
+        return ["conv_wgrad_lw_kernel not found in the assembly"]
+    name, code = m.group(1), m.group(2)
+    in_asm, per_stmt, cur = False, [], 0
+    for l in code.split("\n"):
+        if "#ASMSTART" in l:
+            in_asm, cur = True, 0
+            continue
+        if "#ASMEND" in l:
+            in_asm = False
+            per_stmt.append(cur)
+            continue
+        s = l.split(";")[0].strip()
+        if not s or s.startswith("."):
+            continue
+        if in_asm:
+            cur += s.count("v_mfma")
+        else:
+            if "v_mfma" in s:
+                findings.append(f"{name}: compiler-generated MFMA")
+            if re.search(r"\ba\d+\b|\ba\[\d+:\d+\]", s) or "accvgpr" in s:
+                findings.append(f"{name}: compiler instruction touches an accumulation register: {s}")
+            if "scratch_" in s:
+                findings.append(f"{name}: scratch access: {s}")
+    if sorted(per_stmt) != [0, 0, 96]:
+        findings.append(f"{name}: expected three inline-asm statements (zero, loop with 96 MFMAs, store), found MFMA counts {per_stmt}")
+    return findings
+
+
+def main():
+    import gen_wgrad_lw as G
+    findings = interpret(G.build())
+    n_isa = 0
+    if "--no-isa" not in sys.argv and os.path.exists(HIPCC):
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "pw_wgrad.s")
+            subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-result", "-Wno-unused-value", "-S",
+                                   "--cuda-device-only", os.path.join(CSRC, "pw_wgrad.hip"), "-o", out], stderr=subprocess.DEVNULL)
+            findings += audit_isa(open(out).read())
+            n_isa = 1
+    for f in findings[:40]:
+        print(f)
+    print(f"check_wgrad_lw: schedule interpreted, ISA audited: {bool(n_isa)}, {len(findings)} findings")
+    sys.exit(1 if findings else 0)
+
+
+if __name__ == "__main__":
+    main()

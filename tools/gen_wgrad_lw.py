@@ -1,0 +1,313 @@
+#!/usr/bin/env python3
+"""Generator of csrc/wgrad_lw_body.inc: the hand-scheduled stage loop of conv_wgrad_lw_kernel (csrc/pw_wgrad.hip), the dense
+3x3 / stride-1 / 'same' weight gradient (reference: loss.backward() through models/encoders/wider_resnet.py:124-137 in mode B,
+trainer/classification_trainer.py:37-39) with ONE wave per SIMD.
+
+Same decomposition, LDS images and K order as conv_wgrad_row_kernel (pw_wgrad.hip) -- results are bit-identical -- : a workgroup owns
+(kernel row ky, tile of 128 Cout x 128 Cin, pixel split); a K stage is 64 consecutive pixels of one image row: dy image 64 rows x 256 B
+and the activations as a ROW BUFFER of up to 80 rows x 256 B (halo included, zeros outside the image) which the three kx taps read
+at row offsets kx * dil; four 40-KiB stages in a ring.  What changes is who does the work: 4 waves (wave (wm, wn) = 64 Cout x [3 kx x 64
+Cin] = 48 accumulator tiles in a[0:191]) instead of 8, and every ds_read_b64_tr_b16 fragment read, every LDS-DMA piece and every
+address update dealt between the 48 MFMAs of a k-step (32 pixels) by this generator.
+
+Per stage st (two k-steps):
+  k-step 0: 48 MFMAs on fragment set 0; the 32 transposing reads of (st, k-step 1) into set 1; the second half of stage st + 2's
+            pieces (4 row-buffer pieces per wave); s_waitcnt vmcnt(9) lgkmcnt(0) -- stage st + 1 has landed -- and ONE barrier.
+  k-step 1: 48 MFMAs on set 1; the 28 fragment addresses move on to the next ring slot; the 32 reads of (st + 1, k-step 0) into set 0;
+            the first half of stage st + 3's pieces (4 dy pieces + 1 row-buffer piece per wave) into the slot of stage st - 1.
+Row-buffer pieces are issued under EXEC = the lanes whose pixel lies inside the image row (and inside the 64 + 2 dil rows that are read);
+the other lanes' 16 bytes are zero-filled by a ds_write under the complementary mask (conv_lw.hip's scheme).  Every wave issues the
+same 9 vector-memory operations per stage, so the counted waits are the same immediates for all waves.
+
+usage: python tools/gen_wgrad_lw.py   (rewrites csrc/wgrad_lw_body.inc; `--check` exits 1 when the file is stale: tests/test_abi.py)"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "knowledge-distillation-by-replacing-cheap-conv_amd", "csrc", "wgrad_lw_body.inc")
+
+STAGE = 40960
+XOFF = 16384
+NI, NJ = 4, 12          # A fragments (16-row Cout tiles), B fragments ((kx, 16-column Cin tile) pairs: j = kx * 4 + c) per wave
+
+
+def acc(i, j):
+    return 4 * (i * NJ + j)
+
+
+def frag(s, what, k):
+    base = 128 + 64 * s
+    return base + 4 * k if what == "A" else base + 16 + 4 * k
+
+
+# scalar registers (clobbered)
+S_YB, S_XB = "s[40:41]", "s[42:43]"       # source bases of the stage being staged: dy, activations (row buffer row 0)
+S_LO, S_SPAN = 44, 45                     # its valid row-buffer rows [lo, lo + span)
+S_X0, S_HO = 46, 47                       # its first pixel's column / image row
+S_LEFT = 48                               # stages left to stage for real (beyond the split's end the last one is staged again, all rows masked)
+S_SLOT_A, S_SLOT_B = 49, 50               # LDS byte offset of the ring slot the first / second half-stage is staged into
+S_CNT = 51                                # stages left to compute
+S_RSLOT = 52                              # ring slot (0..3) of the stage whose fragments are read next
+S_STEP = 53                               # byte step of the fragment addresses to that slot
+S_M0 = 54
+S_T0, S_T1 = 55, 56
+S_XB2 = "s[58:59]"                        # row-buffer source base of the SECOND half-stage (the first half's stage moved on in between)
+S_LO2, S_SPAN2 = 60, 61
+CLOBBER_S = list(range(40, 62))
+VT = 127                                  # lane temporary
+SLACK_DS = SLACK_VM = 0                   # mutation hooks of tools/check_wgrad_lw.py's self-test: every counted wait that many operations too lax
+
+
+class Gen:
+    def __init__(self):
+        self.L, self.ds, self.vm = [], [], []
+
+    def emit(self, s):
+        self.L.append(s)
+
+    def ds_op(self, s, tag):
+        self.ds.append(tag)
+        self.emit(s)
+
+    def vm_op(self, s, tag):
+        self.vm.append(tag)
+        self.emit(s)
+
+    def wait_ds(self, tags):
+        n = None
+        for t in tags:
+            if t in self.ds:
+                k = self.ds[::-1].index(t)
+                n = k if n is None else min(n, k)
+        if n is None:
+            return
+        n = min(n + SLACK_DS, 15)
+        self.emit(f"s_waitcnt lgkmcnt({n})")
+        self.ds = self.ds[len(self.ds) - n:] if n else []
+
+
+def reads(g, s, ks, slots, first, last):
+    """the 32 transposing reads of a k-step's fragments into set s, one or two per slot over [first, last]"""
+    ins = []
+    for i in range(NI):
+        f = frag(s, "A", i)
+        ins.append((f"ds_read_b64_tr_b16 v[{f}:{f + 1}], %[va{i}] offset:{ks * 8192}", f"A{s}{i}a"))
+        ins.append((f"ds_read_b64_tr_b16 v[{f + 2}:{f + 3}], %[va{i}] offset:{ks * 8192 + 1024}", f"A{s}{i}b"))
+    for j in range(NJ):
+        f = frag(s, "B", j)
+        ins.append((f"ds_read_b64_tr_b16 v[{f}:{f + 1}], %[vb{j}a] offset:{ks * 8192}", f"B{s}{j}a"))
+        ins.append((f"ds_read_b64_tr_b16 v[{f + 2}:{f + 3}], %[vb{j}b] offset:{ks * 8192}", f"B{s}{j}b"))
+    # order: the fragments the next k-step's first MFMAs need come first (A0, then B0.., A1 ..)
+    order = [0, 1] + list(range(8, 8 + 2 * NJ)) + [2, 3, 4, 5, 6, 7]
+    n = last - first + 1
+    for k, idx in enumerate(order):
+        slots[first + (k * n) // len(order)].append(("DS",) + ins[idx])
+
+
+def dy_piece(k, slot_reg):
+    return [f"s_add_u32 m0, s{slot_reg}, %[sldsw]", f"s_add_u32 m0, m0, {k * 4096}", "s_nop 0",
+            ("VM", f"global_load_lds_dwordx4 %[voy{k}], {S_YB}", f"y{k}")]
+
+
+def x_piece(k, slot_reg, xb, lo, span):
+    return [f"s_add_u32 m0, s{slot_reg}, %[sldsw]", f"s_add_u32 m0, m0, {XOFF + k * 4096}",
+            f"v_add_u32 v{VT}, {16 * k}, %[vr0]", f"v_subrev_u32 v{VT}, s{lo}, v{VT}", f"v_cmpx_gt_u32 vcc, s{span}, v{VT}",
+            ("VM", f"global_load_lds_dwordx4 %[vox{k}], {xb}", f"x{k}"), "s_not_b64 exec, exec",
+            f"v_add_u32 v{VT}, s{slot_reg}, %[vzl]",
+            # (NOT tracked in the LDS queue: under an all-zero EXEC the write may never enter it, and a counted wait that assumed it did
+            #  would be too lax; leaving it out makes every count a lower bound of the operations really issued behind a read)
+            f"ds_write_b128 v{VT}, %[vzero] offset:{XOFF + k * 4096}",
+            "s_mov_b64 exec, -1"]
+
+
+def advance_iterator():
+    """the stage being staged moves on by 64 pixels (while stages are left; afterwards the last one is staged again with every row masked)"""
+    return [f"s_sub_u32 s{S_LEFT}, s{S_LEFT}, 1", f"s_cmp_gt_i32 s{S_LEFT}, 0", "s_cbranch_scc0 WGL_END_%=",
+            f"s_add_u32 s40, s40, %[sdy]", "s_addc_u32 s41, s41, 0", f"s_add_u32 s42, s42, %[sdx]", "s_addc_u32 s43, s43, 0",
+            f"s_add_u32 s{S_X0}, s{S_X0}, 64", f"s_cmp_ge_u32 s{S_X0}, %[sW]", "s_cbranch_scc0 WGL_SAME_%=",
+            f"s_mov_b32 s{S_X0}, 0", f"s_add_u32 s{S_HO}, s{S_HO}, 1", f"s_cmp_ge_u32 s{S_HO}, %[sH]", f"s_cselect_b32 s{S_HO}, 0, s{S_HO}",
+            "WGL_SAME_%=:", "s_branch WGL_MASK_%=", "WGL_END_%=:", f"s_mov_b32 s{S_LEFT}, 0", "WGL_MASK_%=:"] + masks()
+
+
+def masks():
+    """lo / span of the stage at (x0, ho): rows of the buffer inside the image row, none when the kernel row leaves the image or nothing is left"""
+    return [f"s_cmp_eq_u32 s{S_X0}, 0", f"s_cselect_b32 s{S_LO}, %[sd], 0",                                     # first tile of a row: pixels x0 - d + r < 0
+            f"s_add_u32 s{S_T0}, s{S_X0}, 64", f"s_cmp_eq_u32 s{S_T0}, %[sW]", f"s_cselect_b32 s{S_T0}, %[send1], %[send2]",   # last tile: 64 + d rows, else 64 + 2 d
+            f"s_sub_u32 s{S_SPAN}, s{S_T0}, s{S_LO}",
+            f"s_add_i32 s{S_T1}, s{S_HO}, %[skyd]", f"s_cmp_lt_u32 s{S_T1}, %[sH]", f"s_cselect_b32 s{S_SPAN}, s{S_SPAN}, 0",   # (unsigned: hi < 0 wraps)
+            f"s_cmp_gt_i32 s{S_LEFT}, 0", f"s_cselect_b32 s{S_SPAN}, s{S_SPAN}, 0"]
+
+
+def emit_slots(g, slots, body):
+    for k, m in enumerate(body):
+        g.emit(m)
+        for ins in slots[k]:
+            put(g, ins)
+    for ins in slots[len(body)]:
+        put(g, ins)
+
+
+def put(g, ins):
+    if isinstance(ins, str):
+        g.emit(ins)
+    elif ins[0] == "DS":
+        g.ds_op(ins[1], ins[2])
+    elif ins[0] == "VM":
+        g.vm_op(ins[1], ins[2])
+    else:
+        raise ValueError(ins)
+
+
+def kstep(g, s, first_stage_flag=None):
+    """48 MFMAs on fragment set s with counted waits for their operands; returns the MFMA list as emit-time closures"""
+    out = []
+    for i in range(NI):
+        for j in range(NJ):
+            a, b = frag(s, "A", i), frag(s, "B", j)
+            out.append((i, j, f"v_mfma_f32_16x16x32_bf16 a[{acc(i, j)}:{acc(i, j) + 3}], v[{a}:{a + 3}], v[{b}:{b + 3}], a[{acc(i, j)}:{acc(i, j) + 3}]"))
+    return out
+
+
+def run_kstep(g, s, slots):
+    for k, (i, j, m) in enumerate(kstep(g, s)):
+        need = [f"B{s}{j}a", f"B{s}{j}b"] + ([f"A{s}{i}a", f"A{s}{i}b"] if j == 0 else [])
+        g.wait_ds(need)
+        g.emit(m)
+        for ins in slots[k]:
+            put(g, ins)
+    for ins in slots[48]:
+        put(g, ins)
+
+
+def build():
+    g = Gen()
+    e = g.emit
+    # ---- set-up: the staging iterator starts at stage 0 of the split (an empty split only writes its zero slab)
+    e("s_cmp_eq_u32 %[snst], 0"); e("s_cbranch_scc1 WGL_SKIP_%=")
+    e("s_mov_b32 s54, m0")
+    e(f"s_mov_b64 {S_YB}, %[syb]"); e(f"s_mov_b64 {S_XB}, %[sxb]")
+    e(f"s_mov_b32 s{S_X0}, %[sx0]"); e(f"s_mov_b32 s{S_HO}, %[sho]"); e(f"s_mov_b32 s{S_LEFT}, %[snst]"); e(f"s_mov_b32 s{S_CNT}, %[snst]")
+    for ins in masks():
+        e(ins)
+    # ---- prologue: stages 0 and 1 whole, the first half of stage 2
+    for st in range(3):
+        e(f"s_mov_b32 s{S_SLOT_A}, {st * STAGE}")
+        for k in range(4):
+            for ins in dy_piece(k, S_SLOT_A):
+                put(g, ins)
+        for ins in x_piece(0, S_SLOT_A, S_XB, S_LO, S_SPAN):
+            put(g, ins)
+        if st < 2:
+            for k in range(1, 5):
+                for ins in x_piece(k, S_SLOT_A, S_XB, S_LO, S_SPAN):
+                    put(g, ins)
+            for ins in advance_iterator_tagged(f"P{st}"):
+                e(ins)
+        else:
+            # the second half of stage 2 is issued in the loop's first k-step: keep its source and masks, then move the iterator on
+            e(f"s_mov_b64 {S_XB2}, {S_XB}"); e(f"s_mov_b32 s{S_LO2}, s{S_LO}"); e(f"s_mov_b32 s{S_SPAN2}, s{S_SPAN}")
+            for ins in advance_iterator_tagged("P2"):
+                e(ins)
+    e(f"s_waitcnt vmcnt({14 + SLACK_VM}) lgkmcnt(0)")       # stage 0 has landed (stage 1's 9 and stage 2's 5 operations may be outstanding)
+    g.ds, g.vm = [], []
+    e("s_barrier")
+    slots = [[] for _ in range(49)]
+    reads(g, 0, 0, slots, 0, 0)
+    for ins in slots[0]:
+        put(g, ins)
+    # the loop is entered with its first fragments landed; its counted waits are those of the STEADY state (the reads of set 0 dealt into
+    # the previous stage's second k-step), which the loop body below is generated against (fixpoint of the queue at the loop top)
+    e("s_waitcnt lgkmcnt(0)")
+    e(f"s_mov_b32 s{S_RSLOT}, 0"); e(f"s_mov_b32 s{S_SLOT_B}, {2 * STAGE}"); e(f"s_mov_b32 s{S_SLOT_A}, {3 * STAGE}")
+    e("WGL_LOOP_%=:")
+    body, top = loop_body([])
+    body2, top2 = loop_body(top)
+    assert top2 == top, "the LDS queue at the loop top is not a fixpoint"
+    g.L += body2
+    e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1"); e(f"s_cmp_lg_u32 s{S_CNT}, 0"); e("s_cbranch_scc1 WGL_LOOP_%=")
+    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    e("s_mov_b32 m0, s54")
+    e("s_nop 15"); e("s_nop 15")
+    e("WGL_SKIP_%=:")
+    return g.L
+
+
+def loop_body(ds_at_top):
+    """one stage; returns (instructions, LDS queue at its end)"""
+    g = Gen()
+    g.ds = list(ds_at_top)
+    e = g.emit
+    # ---- k-step 0: set 0; reads of (st, 1) into set 1; second half of stage st + 2
+    slots = [[] for _ in range(49)]
+    reads(g, 1, 1, slots, 1, 40)
+    for n, k in enumerate(range(1, 5)):
+        slots[4 + 10 * n] += x_piece(k, S_SLOT_B, S_XB2, S_LO2, S_SPAN2)
+    run_kstep(g, 0, slots)
+    e(f"s_waitcnt vmcnt({9 + SLACK_VM}) lgkmcnt(0)")        # stage st + 1 has landed: only stage st + 2's nine operations are younger
+    g.ds, g.vm = [], []
+    e("s_barrier")
+    # ---- k-step 1: set 1; fragment addresses to the next slot; reads of (st + 1, 0) into set 0; first half of stage st + 3
+    slots = [[] for _ in range(49)]
+    slots[0] += [f"s_add_u32 s{S_RSLOT}, s{S_RSLOT}, 1", f"s_and_b32 s{S_RSLOT}, s{S_RSLOT}, 3", f"s_mov_b32 s{S_STEP}, {STAGE}",
+                 f"s_cmp_eq_u32 s{S_RSLOT}, 0", f"s_cselect_b32 s{S_STEP}, {-3 * STAGE}, s{S_STEP}"]
+    adr = [f"%[va{i}]" for i in range(NI)] + [f"%[vb{j}{h}]" for j in range(NJ) for h in "ab"]
+    for n, a in enumerate(adr):
+        slots[1 + n // 3].append(f"v_add_u32 {a}, s{S_STEP}, {a}")
+    reads(g, 0, 0, slots, 11, 46)
+    half = []
+    for k in range(4):
+        half.append(dy_piece(k, S_SLOT_A))
+    half.append(x_piece(0, S_SLOT_A, S_XB, S_LO, S_SPAN))
+    for n, p in enumerate(half):
+        slots[3 + 9 * n] += p
+    # the staging iterator: this stage's second half keeps (source, masks), the ring slots rotate, the iterator moves on to stage st + 4
+    slots[47] += [f"s_mov_b64 {S_XB2}, {S_XB}", f"s_mov_b32 s{S_LO2}, s{S_LO}", f"s_mov_b32 s{S_SPAN2}, s{S_SPAN}",
+                  f"s_mov_b32 s{S_SLOT_B}, s{S_SLOT_A}", f"s_add_u32 s{S_SLOT_A}, s{S_SLOT_A}, {STAGE}", f"s_cmp_eq_u32 s{S_SLOT_A}, {4 * STAGE}",
+                  f"s_cselect_b32 s{S_SLOT_A}, 0, s{S_SLOT_A}"] + advance_iterator_tagged("L")
+    run_kstep(g, 1, slots)
+    return g.L, list(g.ds)
+
+
+_TAGN = [0]
+
+
+def advance_iterator_tagged(tag):
+    return [l.replace("WGL_END_%=", f"WGL_END{tag}_%=").replace("WGL_SAME_%=", f"WGL_SAME{tag}_%=").replace("WGL_MASK_%=", f"WGL_MASK{tag}_%=")
+            for l in advance_iterator()]
+
+
+def store_block():
+    """accumulators -> the fp32 partial slab: tile (i, j = kx * 4 + c), row r: out[kx] + lane offset + (16 i + r) rows + 64 c bytes"""
+    L = []
+    for i in range(NI):
+        for r in range(4):
+            L.append(f"v_mov_b32 v{VT}, {16 * i + r}")
+            L.append(f"v_mad_u32_u24 v{VT}, v{VT}, %[vcin4], %[vob]")
+            for j in range(NJ):
+                kx, c = divmod(j, 4)
+                L.append(f"global_store_dword v{VT}, a{acc(i, j) + r}, %[sout{kx}] offset:{64 * c}")
+    L.append("s_waitcnt vmcnt(0)")
+    return L
+
+
+def cstr(lines):
+    return " \\\n".join('    "' + l + '\\n\\t"' for l in lines)
+
+
+def render():
+    o = ["// GENERATED by tools/gen_wgrad_lw.py -- do not edit (tests/test_abi.py checks it is current)", "",
+         "#define WGRAD_LW_LOOP_ASM \\", cstr(build()), "",
+         "#define WGRAD_LW_STORE_ASM \\", cstr(store_block()), "",
+         "#define WGRAD_LW_ZERO_ASM \\", cstr([f"v_accvgpr_write_b32 a{n}, 0" for n in range(256)]), "",
+         "#define WGRAD_LW_CLOBBER_S " + ", ".join(f'"s{i}"' for i in CLOBBER_S),
+         "#define WGRAD_LW_CLOBBER_V " + ", ".join(f'"v{i}"' for i in range(127, 256)), ""]
+    return "\n".join(o)
+
+
+if __name__ == "__main__":
+    txt = render()
+    if "--check" in sys.argv:
+        sys.exit(0 if os.path.exists(OUT) and open(OUT).read() == txt else 1)
+    with open(OUT, "w") as f:
+        f.write(txt)
+    print(f"wrote {OUT}: {txt.count(chr(10))} lines")
