@@ -730,8 +730,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row_kernel(const WgradParam
 // conv_wgrad_row_kernel's stage takes 3300 cycles for 1536 cycles of MFMAs: its phases (LDS-DMA issue 1670, transposing fragment reads
 // 1340, MFMAs 1800 when run alone, tools/wgrad_timeline.py) barely overlap in 8 lock-step waves.  Here 4 waves (wave (wm, wn) = 64 Cout x
 // [3 kx x 64 Cin]: 48 accumulator tiles in a[0:191], fragments in v[128:255]) run a hand-dealt stream: per 32-pixel k-step 48 MFMAs with
-// the 32 ds_read_b64_tr_b16 of the next k-step, 4-5 LDS-DMA pieces and the fragment addresses' ring-slot step between them, one barrier
-// per stage.  Same decomposition (grid, splits, kernel row per workgroup), the same LDS images and the same K order: bit-identical partial
+// the 32 ds_read_b64_tr_b16 of the next k-step and 4-5 LDS-DMA pieces between them, one barrier per stage; the loop is unrolled over the
+// four ring slots, so a stage's slot is an immediate of its reads and pieces.  Same decomposition (grid, splits, kernel row per workgroup), the same LDS images and the same K order: bit-identical partial
 // slabs.  Cin % 128 == 0, Cout % 128 == 0, dil <= 8 (row buffer of 80 rows: every wave stages 4 dy + 5 row-buffer pieces per stage).
 __global__ __launch_bounds__(256, 1) void conv_wgrad_lw_kernel(const WgradParams p)
 {
@@ -782,9 +782,15 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_lw_kernel(const WgradParams
         vox[k] = (uint32_t)(r * p.lda + ci0 + (slot ^ (tr_f(r) << 1)) * 8) * 2u;
     }
     const uint32_t vr0 = (uint32_t)(wv * 4 + prow);                    // this lane's buffer row in piece 0 (piece k: + 16 k)
-    const uint32_t vzl = lbase + wv * 1024 + lane * 16;
+    const uint32_t vzl = lbase + 16384 + wv * 1024 + lane * 16, vzh = vzl + 2 * WR_STAGE;   // its 16 bytes of that piece in ring slot 0 / 2
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4w_t;
     const u32x4w_t vzero = {0u, 0u, 0u, 0u};
+    // the fragment addresses a second time, for ring slots 2 and 3 (a ds offset field holds 16 bits: slot 3 does not fit behind slot 0)
+    uint32_t wa[4], wb[12][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wa[i] = va[i] + 2 * WR_STAGE;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) { wb[j][0] = vb[j][0] + 2 * WR_STAGE; wb[j][1] = vb[j][1] + 2 * WR_STAGE; }
 
     // stage 0 of the split
     const uint32_t n = fastdiv((uint32_t)m_begin, p.mg_howo, p.sh_howo);
@@ -801,20 +807,23 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_lw_kernel(const WgradParams
     f32x32_t A0, A1, A2, A3, A4, A5, A6, A7;
     asm volatile(WGRAD_LW_ZERO_ASM : "=a"(A0), "=a"(A1), "=a"(A2), "=a"(A3), "=a"(A4), "=a"(A5), "=a"(A6), "=a"(A7));
 #define WGLW_ACC_RW "+a"(A0), "+a"(A1), "+a"(A2), "+a"(A3), "+a"(A4), "+a"(A5), "+a"(A6), "+a"(A7)
+#define WGLW_ADDR(P, A, B)                                                                                                                       \
+    [P##a0] "v"(A[0]), [P##a1] "v"(A[1]), [P##a2] "v"(A[2]), [P##a3] "v"(A[3]), [P##b0a] "v"(B[0][0]), [P##b0b] "v"(B[0][1]),                    \
+    [P##b1a] "v"(B[1][0]), [P##b1b] "v"(B[1][1]), [P##b2a] "v"(B[2][0]), [P##b2b] "v"(B[2][1]), [P##b3a] "v"(B[3][0]), [P##b3b] "v"(B[3][1]),    \
+    [P##b4a] "v"(B[4][0]), [P##b4b] "v"(B[4][1]), [P##b5a] "v"(B[5][0]), [P##b5b] "v"(B[5][1]), [P##b6a] "v"(B[6][0]), [P##b6b] "v"(B[6][1]),    \
+    [P##b7a] "v"(B[7][0]), [P##b7b] "v"(B[7][1]), [P##b8a] "v"(B[8][0]), [P##b8b] "v"(B[8][1]), [P##b9a] "v"(B[9][0]), [P##b9b] "v"(B[9][1]),    \
+    [P##b10a] "v"(B[10][0]), [P##b10b] "v"(B[10][1]), [P##b11a] "v"(B[11][0]), [P##b11b] "v"(B[11][1])
     asm volatile(WGRAD_LW_LOOP_ASM
-                 : [va0] "+v"(va[0]), [va1] "+v"(va[1]), [va2] "+v"(va[2]), [va3] "+v"(va[3]),
-                   [vb0a] "+v"(vb[0][0]), [vb0b] "+v"(vb[0][1]), [vb1a] "+v"(vb[1][0]), [vb1b] "+v"(vb[1][1]), [vb2a] "+v"(vb[2][0]), [vb2b] "+v"(vb[2][1]),
-                   [vb3a] "+v"(vb[3][0]), [vb3b] "+v"(vb[3][1]), [vb4a] "+v"(vb[4][0]), [vb4b] "+v"(vb[4][1]), [vb5a] "+v"(vb[5][0]), [vb5b] "+v"(vb[5][1]),
-                   [vb6a] "+v"(vb[6][0]), [vb6b] "+v"(vb[6][1]), [vb7a] "+v"(vb[7][0]), [vb7b] "+v"(vb[7][1]), [vb8a] "+v"(vb[8][0]), [vb8b] "+v"(vb[8][1]),
-                   [vb9a] "+v"(vb[9][0]), [vb9b] "+v"(vb[9][1]), [vb10a] "+v"(vb[10][0]), [vb10b] "+v"(vb[10][1]), [vb11a] "+v"(vb[11][0]), [vb11b] "+v"(vb[11][1]),
-                   WGLW_ACC_RW
-                 : [voy0] "v"(voy[0]), [voy1] "v"(voy[1]), [voy2] "v"(voy[2]), [voy3] "v"(voy[3]),
+                 : WGLW_ACC_RW
+                 : WGLW_ADDR(v, va, vb), WGLW_ADDR(w, wa, wb),
+                   [voy0] "v"(voy[0]), [voy1] "v"(voy[1]), [voy2] "v"(voy[2]), [voy3] "v"(voy[3]),
                    [vox0] "v"(vox[0]), [vox1] "v"(vox[1]), [vox2] "v"(vox[2]), [vox3] "v"(vox[3]), [vox4] "v"(vox[4]),
-                   [vr0] "v"(vr0), [vzl] "v"(vzl), [vzero] "v"(vzero),
+                   [vr0] "v"(vr0), [vzl] "v"(vzl), [vzh] "v"(vzh), [vzero] "v"(vzero),
                    [syb] "s"(syb), [sxb] "s"(sxb), [sx0] "s"(x0), [sho] "s"(ho), [snst] "s"((uint32_t)nst), [sdy] "s"(sdy), [sdx] "s"(sdx),
                    [sW] "s"((uint32_t)p.W), [sH] "s"((uint32_t)p.H), [sd] "s"((uint32_t)d), [send1] "s"(send1), [send2] "s"(send2), [skyd] "s"(skyd),
                    [sldsw] "s"(sldsw)
                  : "memory", "scc", "vcc", WGRAD_LW_CLOBBER_S, WGRAD_LW_CLOBBER_V);
+#undef WGLW_ADDR
     // accumulators -> the split's fp32 slab: D[co = 16 i + 4 q + r][ci = li] of tile (i, j = kx * 4 + c)
     float *out0 = p.part + ((size_t)split * 9 + ky * 3) * p.Cout * p.Cin + (size_t)co0 * p.Cin + ci0;
     const float *out1 = out0 + (size_t)p.Cout * p.Cin, *out2 = out1 + (size_t)p.Cout * p.Cin;

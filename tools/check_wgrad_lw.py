@@ -1,19 +1,20 @@
 #!/usr/bin/env python3
 """Checks of the lone-wave dense weight-gradient kernel (conv_wgrad_lw_kernel, csrc/pw_wgrad.hip + the generated csrc/wgrad_lw_body.inc).
 
-1. Schedule interpreter (no hipcc needed).  The generated stream is walked prologue -> stage body x 3 -> drain as the hardware retires
-   it: LDS operations and vector-memory operations are two IN-ORDER queues, `s_waitcnt lgkmcnt(n) / vmcnt(n)` retires all but the n
+1. Schedule interpreter (no hipcc needed).  The generated stream is walked prologue -> the four unrolled stage bodies, twice -> drain as the hardware retires
+   it, once along the boundary path of every row-buffer piece (EXEC masks + zero fill) and once along the interior path: LDS operations and vector-memory operations are two IN-ORDER queues, `s_waitcnt lgkmcnt(n) / vmcnt(n)` retires all but the n
    youngest of a queue.  Checked:
    * every MFMA's fragment registers have landed (no transposing read into them is still in the LDS queue), and no read overwrites a
      fragment register an older read is still in flight for;
-   * the LDS-DMA pieces are numbered by the stage they belong to (prologue: stages 0 and 1 whole and the first five pieces of stage 2;
-     stage body `it`: the last four pieces of stage it + 2 in k-step 0, the first five of stage it + 3 in k-step 1).  At the barrier
+   * the LDS-DMA pieces are numbered by the stage they belong to (prologue: stages 0, 1, 2 whole and the first five pieces of stage 3;
+     stage body `it`: the last four pieces of stage it + 3 in k-step 0, the first five of stage it + 4 in k-step 1).  At the barrier
      of stage body `it` no piece of a stage <= it + 1 may be in flight (k-step 1 reads stage it + 1 right behind it), at the
      prologue's barrier none of stage 0; no LDS operation may be in flight at a barrier;
    * the reads of k-step 0's fragments (ring offset 0 / 1024: stage it + 1) come behind the barrier, those of k-step 1's (offset 8192 /
-     9216: stage it) in front of it; the pieces that overwrite stage it - 1's slot come behind it;
+     9216: stage it) in front of it; the pieces that overwrite stage it's slot (stage it + 4) come behind it;
+   * every fragment read and every piece addresses the ring slot (stage mod 4) of the stage it belongs to;
    * one barrier and 96 MFMAs per stage body, nothing in flight at the end.
-2. ISA audit (needs hipcc): in the compiled kernel no compiler-generated instruction touches an accumulation register, the 96 MFMAs
+2. ISA audit (needs hipcc): in the compiled kernel no compiler-generated instruction touches an accumulation register, the 4 x 96 MFMAs
    sit in ONE inline-asm statement, no scratch.
 
 usage: check_wgrad_lw.py [--no-isa]; exit 1 on a finding.  tests/test_abi.py runs it and holds it to account with mutated schedules."""
@@ -38,24 +39,60 @@ def vregs(text):
     return out
 
 
-def interpret(lines, bodies=3):
+STAGE = 40960
+
+
+def linearize(lines, fast):
+    """one of the two paths of every row-buffer piece: the boundary path (masks + zero fill; fast = False) or the interior one"""
+    out, skip_to = [], None
+    for l in lines:
+        if skip_to:
+            if l == skip_to:
+                skip_to = None
+            continue
+        m = re.match(r"s_cbranch_scc1 (WGL_XF\d+_%=)", l)
+        if m:
+            if fast:
+                skip_to = m.group(1) + ":"
+            continue
+        m = re.match(r"s_branch (WGL_XD\d+_%=)", l)
+        if m:
+            skip_to = m.group(1) + ":"
+            continue
+        if re.match(r"WGL_X[FD]\d+_%=:", l):
+            continue
+        out.append(l)
+    return out
+
+
+def interpret(lines, passes=2):
+    return interpret_path(linearize(lines, False), passes) + [f"(interior path) {f}" for f in interpret_path(linearize(lines, True), passes)]
+
+
+def interpret_path(lines, passes):
     findings = []
     top = lines.index("WGL_LOOP_%=:")
     back = max(i for i, l in enumerate(lines) if l.startswith("s_cbranch_scc1 WGL_LOOP"))
     seq = [(l, -1) for l in lines[:top]]
-    for it in range(bodies):
-        seq += [(l, it) for l in lines[top + 1:back + 1]]
+    it = 0
+    for p in range(passes):
+        for l in lines[top + 1:back + 1]:
+            seq.append((l, it))
+            if l.startswith("s_cbranch_scc0 WGL_DONE") or l.startswith("s_cbranch_scc1 WGL_LOOP"):
+                it += 1
+    bodies = it
     seq += [(l, bodies) for l in lines[back + 1:]]
     ds, vm = [], []                 # ds: (dest regs, text); vm: stage of the piece
     n_piece = 0
     stats = {}
+    m0 = None
 
     def stage_of(n):
-        if n < 23:
-            return 0 if n < 9 else 1 if n < 18 else 2
-        k = n - 23
+        if n < 32:
+            return n // 9
+        k = n - 32
         it, r = divmod(k, 9)
-        return it + 2 if r < 4 else it + 3
+        return it + 3 if r < 4 else it + 4
 
     barrier_seen = {}
     for ins, it in seq:
@@ -70,6 +107,9 @@ def interpret(lines, bodies=3):
             if m:
                 k = int(m.group(1))
                 vm = vm[len(vm) - k:] if k else []
+            continue
+        if op == "s_add_u32" and ins.startswith("s_add_u32 m0, %[sldsw], "):
+            m0 = int(ins.rsplit(" ", 1)[1])
             continue
         if op == "s_barrier":
             st["barrier"] += 1
@@ -95,9 +135,13 @@ def interpret(lines, bodies=3):
                 if r in pend:
                     findings.append(f"body {it}: `{ins}` overwrites v{r} while `{pend[r]}` is in flight")
             ds.append((dst, ins))
-            if it >= 0 and it < bodies:
-                off = int(re.search(r"offset:(\d+)", ins).group(1))
-                ks = 1 if off >= 8192 else 0
+            off = int(re.search(r"offset:(\d+)", ins).group(1))
+            ring = off // STAGE + (2 if re.search(r"%\[w[ab]", ins) else 0)
+            ks = 1 if off % STAGE >= 8192 else 0
+            if 0 <= it < bodies:
+                want = it if ks else it + 1
+                if ring != want % 4:
+                    findings.append(f"body {it}: a read of stage {want} addresses ring slot {ring}: {ins}")
                 if ks == 0 and not barrier_seen.get(it):
                     findings.append(f"body {it}: a read of stage {it + 1} in front of the barrier that publishes it: {ins}")
                 if ks == 1 and barrier_seen.get(it):
@@ -110,8 +154,11 @@ def interpret(lines, bodies=3):
             s = stage_of(n_piece)
             n_piece += 1
             vm.append(s)
-            if 0 <= it < bodies and s == it + 3 and not barrier_seen.get(it):
-                findings.append(f"body {it}: a piece of stage {s} overwrites stage {it - 1}'s slot in front of the barrier: {ins}")
+            if m0 is None or m0 // STAGE != s % 4:
+                findings.append(f"body {it}: a piece of stage {s} goes to M0 = {m0} (ring slot {None if m0 is None else m0 // STAGE}): {ins}")
+            m0 = None
+            if 0 <= it < bodies and s == it + 4 and not barrier_seen.get(it):
+                findings.append(f"body {it}: a piece of stage {s} overwrites stage {it}'s slot in front of the barrier that retires it: {ins}")
             continue
     for it, st in stats.items():
         if 0 <= it < bodies and (st["mfma"] != 96 or st["barrier"] != 1):
@@ -148,8 +195,8 @@ def audit_isa(text):
                 findings.append(f"{name}: compiler instruction touches an accumulation register: {s}")
             if "scratch_" in s:
                 findings.append(f"{name}: scratch access: {s}")
-    if sorted(per_stmt) != [0, 0, 96]:
-        findings.append(f"{name}: expected three inline-asm statements (zero, loop with 96 MFMAs, store), found MFMA counts {per_stmt}")
+    if sorted(per_stmt) != [0, 0, 384]:
+        findings.append(f"{name}: expected three inline-asm statements (zero, the four unrolled stage bodies with 384 MFMAs, store), found MFMA counts {per_stmt}")
     return findings
 
 

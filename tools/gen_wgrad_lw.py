@@ -11,13 +11,21 @@ Cin] = 48 accumulator tiles in a[0:191]) instead of 8, and every ds_read_b64_tr_
 address update dealt between the 48 MFMAs of a k-step (32 pixels) by this generator.
 
 Per stage st (two k-steps):
-  k-step 0: 48 MFMAs on fragment set 0; the 32 transposing reads of (st, k-step 1) into set 1; the second half of stage st + 2's
-            pieces (4 row-buffer pieces per wave); s_waitcnt vmcnt(9) lgkmcnt(0) -- stage st + 1 has landed -- and ONE barrier.
-  k-step 1: 48 MFMAs on set 1; the 28 fragment addresses move on to the next ring slot; the 32 reads of (st + 1, k-step 0) into set 0;
-            the first half of stage st + 3's pieces (4 dy pieces + 1 row-buffer piece per wave) into the slot of stage st - 1.
-Row-buffer pieces are issued under EXEC = the lanes whose pixel lies inside the image row (and inside the 64 + 2 dil rows that are read);
-the other lanes' 16 bytes are zero-filled by a ds_write under the complementary mask (conv_lw.hip's scheme).  Every wave issues the
-same 9 vector-memory operations per stage, so the counted waits are the same immediates for all waves.
+  k-step 0: 48 MFMAs on fragment set 0; the 32 transposing reads of (st, k-step 1) into set 1; the second half of stage st + 3's
+            pieces (4 row-buffer pieces per wave); s_waitcnt vmcnt(18) lgkmcnt(0) -- stage st + 1 has landed, st + 2 and st + 3 may be in
+            flight -- and ONE barrier: it publishes stage st + 1 and retires stage st (all of whose reads precede it).
+  k-step 1: 48 MFMAs on set 1; the 32 reads of (st + 1, k-step 0) into set 0; the first half of stage st + 4's pieces (4 dy pieces +
+            1 row-buffer piece per wave) into the slot of stage st.
+The loop is unrolled over the FOUR ring slots, so that a stage's slot is an immediate: the 28 fragment addresses exist twice (slots 0 / 1
+and slots 2 / 3: a ds offset field holds 16 bits) and never move (28 VALU per stage saved: -3.5 % measured), and M0 of a piece is one
+s_add of a literal.
+(The first version staged one stage later -- st + 3 into the slot of st - 1 -- and had the second half of a stage in flight for ONE stage
+ time, ~1 us: less than the memory latency under load; the ablations of tools/wgrad_lw_ablate.sh showed the wait.)
+Row-buffer pieces of a BOUNDARY stage (first / last 64 pixels of an image row, a kernel row outside the image, beyond the split's
+end) are issued under EXEC = the lanes whose pixel lies inside the image row (and inside the 64 + 2 dil rows that are read); the other
+lanes' 16 bytes are zero-filled by a ds_write under the complementary mask (conv_lw.hip's scheme).  An interior stage takes a short
+path: pieces 0-3 whole, piece 4 under EXEC = its 2 dil rows that are read, no zero fill (-4 % measured).  Every wave issues the same 9
+vector-memory operations per stage on either path, so the counted waits are the same immediates for all waves.
 
 usage: python tools/gen_wgrad_lw.py   (rewrites csrc/wgrad_lw_body.inc; `--check` exits 1 when the file is stale: tests/test_abi.py)"""
 import os
@@ -45,16 +53,16 @@ S_YB, S_XB = "s[40:41]", "s[42:43]"       # source bases of the stage being stag
 S_LO, S_SPAN = 44, 45                     # its valid row-buffer rows [lo, lo + span)
 S_X0, S_HO = 46, 47                       # its first pixel's column / image row
 S_LEFT = 48                               # stages left to stage for real (beyond the split's end the last one is staged again, all rows masked)
-S_SLOT_A, S_SLOT_B = 49, 50               # LDS byte offset of the ring slot the first / second half-stage is staged into
+S_BND, S_BND2 = 49, 50                    # 1: the stage being staged (first / second half) is a boundary stage (masks + zero fill)
 S_CNT = 51                                # stages left to compute
-S_RSLOT = 52                              # ring slot (0..3) of the stage whose fragments are read next
-S_STEP = 53                               # byte step of the fragment addresses to that slot
+S_2D = 52                                 # 2 * dil
 S_M0 = 54
 S_T0, S_T1 = 55, 56
 S_XB2 = "s[58:59]"                        # row-buffer source base of the SECOND half-stage (the first half's stage moved on in between)
 S_LO2, S_SPAN2 = 60, 61
 CLOBBER_S = list(range(40, 62))
 VT = 127                                  # lane temporary
+ABL = int(os.environ.get("KDCC_GEN_WGRAD_ABL", "0"))   # TIMING ablations (tools/wgrad_lw_ablate.sh; results wrong): 1 no LDS-DMA, 2 no fragment reads, 4 no MFMAs, 8 no zero fill, 16 no address steps
 SLACK_DS = SLACK_VM = 0                   # mutation hooks of tools/check_wgrad_lw.py's self-test: every counted wait that many operations too lax
 
 
@@ -86,17 +94,18 @@ class Gen:
         self.ds = self.ds[len(self.ds) - n:] if n else []
 
 
-def reads(g, s, ks, slots, first, last):
-    """the 32 transposing reads of a k-step's fragments into set s, one or two per slot over [first, last]"""
+def reads(g, s, ks, slots, first, last, ring):
+    """the 32 transposing reads of a k-step's fragments of the stage in ring slot `ring` into set s, one or two per slot over [first, last]"""
     ins = []
+    a, off = ("v", (ring & 1) * STAGE + ks * 8192) if ring < 2 else ("w", (ring & 1) * STAGE + ks * 8192)
     for i in range(NI):
         f = frag(s, "A", i)
-        ins.append((f"ds_read_b64_tr_b16 v[{f}:{f + 1}], %[va{i}] offset:{ks * 8192}", f"A{s}{i}a"))
-        ins.append((f"ds_read_b64_tr_b16 v[{f + 2}:{f + 3}], %[va{i}] offset:{ks * 8192 + 1024}", f"A{s}{i}b"))
+        ins.append((f"ds_read_b64_tr_b16 v[{f}:{f + 1}], %[{a}a{i}] offset:{off}", f"A{s}{i}a"))
+        ins.append((f"ds_read_b64_tr_b16 v[{f + 2}:{f + 3}], %[{a}a{i}] offset:{off + 1024}", f"A{s}{i}b"))
     for j in range(NJ):
         f = frag(s, "B", j)
-        ins.append((f"ds_read_b64_tr_b16 v[{f}:{f + 1}], %[vb{j}a] offset:{ks * 8192}", f"B{s}{j}a"))
-        ins.append((f"ds_read_b64_tr_b16 v[{f + 2}:{f + 3}], %[vb{j}b] offset:{ks * 8192}", f"B{s}{j}b"))
+        ins.append((f"ds_read_b64_tr_b16 v[{f}:{f + 1}], %[{a}b{j}a] offset:{off}", f"B{s}{j}a"))
+        ins.append((f"ds_read_b64_tr_b16 v[{f + 2}:{f + 3}], %[{a}b{j}b] offset:{off}", f"B{s}{j}b"))
     # order: the fragments the next k-step's first MFMAs need come first (A0, then B0.., A1 ..)
     order = [0, 1] + list(range(8, 8 + 2 * NJ)) + [2, 3, 4, 5, 6, 7]
     n = last - first + 1
@@ -104,20 +113,27 @@ def reads(g, s, ks, slots, first, last):
         slots[first + (k * n) // len(order)].append(("DS",) + ins[idx])
 
 
-def dy_piece(k, slot_reg):
-    return [f"s_add_u32 m0, s{slot_reg}, %[sldsw]", f"s_add_u32 m0, m0, {k * 4096}", "s_nop 0",
+_PIECE = [0]
+
+
+def dy_piece(k, ring):
+    return [f"s_add_u32 m0, %[sldsw], {ring * STAGE + k * 4096}", "s_nop 0",
             ("VM", f"global_load_lds_dwordx4 %[voy{k}], {S_YB}", f"y{k}")]
 
 
-def x_piece(k, slot_reg, xb, lo, span):
-    return [f"s_add_u32 m0, s{slot_reg}, %[sldsw]", f"s_add_u32 m0, m0, {XOFF + k * 4096}",
+def x_piece(k, ring, xb, lo, span, bnd):
+    _PIECE[0] += 1
+    n = _PIECE[0]
+    fast = ([("VM", f"global_load_lds_dwordx4 %[vox{k}], {xb}", f"x{k}")] if k < 4 else
+            [f"v_cmpx_gt_u32 vcc, s{S_2D}, %[vr0]", ("VM", f"global_load_lds_dwordx4 %[vox{k}], {xb}", f"x{k}"), "s_mov_b64 exec, -1"])
+    vz = "%[vzl]" if ring < 2 else "%[vzh]"          # this lane's 16 bytes of piece 0 of the row buffer in ring slot 0 / 2
+    return [f"s_add_u32 m0, %[sldsw], {ring * STAGE + XOFF + k * 4096}", f"s_cmp_eq_u32 s{bnd}, 0", f"s_cbranch_scc1 WGL_XF{n}_%=",
             f"v_add_u32 v{VT}, {16 * k}, %[vr0]", f"v_subrev_u32 v{VT}, s{lo}, v{VT}", f"v_cmpx_gt_u32 vcc, s{span}, v{VT}",
             ("VM", f"global_load_lds_dwordx4 %[vox{k}], {xb}", f"x{k}"), "s_not_b64 exec, exec",
-            f"v_add_u32 v{VT}, s{slot_reg}, %[vzl]",
             # (NOT tracked in the LDS queue: under an all-zero EXEC the write may never enter it, and a counted wait that assumed it did
             #  would be too lax; leaving it out makes every count a lower bound of the operations really issued behind a read)
-            f"ds_write_b128 v{VT}, %[vzero] offset:{XOFF + k * 4096}",
-            "s_mov_b64 exec, -1"]
+            f"ds_write_b128 {vz}, %[vzero] offset:{(ring & 1) * STAGE + k * 4096}",
+            "s_mov_b64 exec, -1", f"s_branch WGL_XD{n}_%=", f"WGL_XF{n}_%=:"] + fast + [f"WGL_XD{n}_%=:"]
 
 
 def advance_iterator():
@@ -130,12 +146,15 @@ def advance_iterator():
 
 
 def masks():
-    """lo / span of the stage at (x0, ho): rows of the buffer inside the image row, none when the kernel row leaves the image or nothing is left"""
-    return [f"s_cmp_eq_u32 s{S_X0}, 0", f"s_cselect_b32 s{S_LO}, %[sd], 0",                                     # first tile of a row: pixels x0 - d + r < 0
+    """lo / span of the stage at (x0, ho): rows of the buffer inside the image row, none when the kernel row leaves the image or nothing
+    is left; bnd = 1 unless all of the 64 + 2 dil rows that are read lie inside the image"""
+    return [f"s_cmp_eq_u32 s{S_X0}, 0", f"s_cselect_b32 s{S_LO}, %[sd], 0", f"s_cselect_b32 s{S_BND}, 1, 0",       # first tile of a row: pixels x0 - d + r < 0
             f"s_add_u32 s{S_T0}, s{S_X0}, 64", f"s_cmp_eq_u32 s{S_T0}, %[sW]", f"s_cselect_b32 s{S_T0}, %[send1], %[send2]",   # last tile: 64 + d rows, else 64 + 2 d
+            f"s_cselect_b32 s{S_BND}, 1, s{S_BND}",
             f"s_sub_u32 s{S_SPAN}, s{S_T0}, s{S_LO}",
             f"s_add_i32 s{S_T1}, s{S_HO}, %[skyd]", f"s_cmp_lt_u32 s{S_T1}, %[sH]", f"s_cselect_b32 s{S_SPAN}, s{S_SPAN}, 0",   # (unsigned: hi < 0 wraps)
-            f"s_cmp_gt_i32 s{S_LEFT}, 0", f"s_cselect_b32 s{S_SPAN}, s{S_SPAN}, 0"]
+            f"s_cselect_b32 s{S_BND}, s{S_BND}, 1",
+            f"s_cmp_gt_i32 s{S_LEFT}, 0", f"s_cselect_b32 s{S_SPAN}, s{S_SPAN}, 0", f"s_cselect_b32 s{S_BND}, s{S_BND}, 1"]
 
 
 def emit_slots(g, slots, body):
@@ -149,17 +168,33 @@ def emit_slots(g, slots, body):
 
 def put(g, ins):
     if isinstance(ins, str):
+        if (ABL & 8 and ins.startswith("ds_write")) or (ABL & 16 and ins.startswith("v_add_u32 %[v")):
+            return
         g.emit(ins)
     elif ins[0] == "DS":
-        g.ds_op(ins[1], ins[2])
+        if ABL & 384 and ins[2].endswith("b"):      # 128: half the reads (half the bytes); 256: pairs as ONE ds_read_b128 (same bytes, half the instructions)
+            return
+        if ABL & 256:
+            import re
+            m = re.match(r"ds_read_b64_tr_b16 v\[(\d+):\d+\], (\S+) offset:(\d+)", ins[1])
+            g.ds_op(f"ds_read_b128 v[{m.group(1)}:{int(m.group(1)) + 3}], {m.group(2)} offset:{m.group(3)}", ins[2])
+            return
+        if not ABL & 2:
+            g.ds_op(ins[1], ins[2])
     elif ins[0] == "VM":
-        g.vm_op(ins[1], ins[2])
+        if ABL & 32:      # the same memory request into registers instead of LDS (+ 64: and an ordinary ds_write_b128 of as many bytes)
+            _, voff, base = ins[1].replace(",", " ").split(None, 2)
+            g.vm_op(f"global_load_dwordx4 v[100:103], {voff}, {base}", ins[2])
+            if ABL & 64:
+                g.emit("ds_write_b128 %[vzl], v[104:107]")
+        elif not ABL & 1:
+            g.vm_op(ins[1], ins[2])
     else:
         raise ValueError(ins)
 
 
 def kstep(g, s, first_stage_flag=None):
-    """48 MFMAs on fragment set s with counted waits for their operands; returns the MFMA list as emit-time closures"""
+    """the 48 MFMAs on fragment set s"""
     out = []
     for i in range(NI):
         for j in range(NJ):
@@ -172,7 +207,8 @@ def run_kstep(g, s, slots):
     for k, (i, j, m) in enumerate(kstep(g, s)):
         need = [f"B{s}{j}a", f"B{s}{j}b"] + ([f"A{s}{i}a", f"A{s}{i}b"] if j == 0 else [])
         g.wait_ds(need)
-        g.emit(m)
+        if not ABL & 4:
+            g.emit(m)
         for ins in slots[k]:
             put(g, ins)
     for ins in slots[48]:
@@ -182,49 +218,53 @@ def run_kstep(g, s, slots):
 def build():
     g = Gen()
     e = g.emit
+    _PIECE[0] = 0
     # ---- set-up: the staging iterator starts at stage 0 of the split (an empty split only writes its zero slab)
     e("s_cmp_eq_u32 %[snst], 0"); e("s_cbranch_scc1 WGL_SKIP_%=")
     e("s_mov_b32 s54, m0")
     e(f"s_mov_b64 {S_YB}, %[syb]"); e(f"s_mov_b64 {S_XB}, %[sxb]")
     e(f"s_mov_b32 s{S_X0}, %[sx0]"); e(f"s_mov_b32 s{S_HO}, %[sho]"); e(f"s_mov_b32 s{S_LEFT}, %[snst]"); e(f"s_mov_b32 s{S_CNT}, %[snst]")
+    e(f"s_lshl_b32 s{S_2D}, %[sd], 1")
     for ins in masks():
         e(ins)
-    # ---- prologue: stages 0 and 1 whole, the first half of stage 2
-    for st in range(3):
-        e(f"s_mov_b32 s{S_SLOT_A}, {st * STAGE}")
+    # ---- prologue: stages 0, 1 and 2 whole, the first half of stage 3
+    for st in range(4):
         for k in range(4):
-            for ins in dy_piece(k, S_SLOT_A):
+            for ins in dy_piece(k, st):
                 put(g, ins)
-        for ins in x_piece(0, S_SLOT_A, S_XB, S_LO, S_SPAN):
+        for ins in x_piece(0, st, S_XB, S_LO, S_SPAN, S_BND):
             put(g, ins)
-        if st < 2:
+        if st < 3:
             for k in range(1, 5):
-                for ins in x_piece(k, S_SLOT_A, S_XB, S_LO, S_SPAN):
+                for ins in x_piece(k, st, S_XB, S_LO, S_SPAN, S_BND):
                     put(g, ins)
             for ins in advance_iterator_tagged(f"P{st}"):
                 e(ins)
         else:
-            # the second half of stage 2 is issued in the loop's first k-step: keep its source and masks, then move the iterator on
-            e(f"s_mov_b64 {S_XB2}, {S_XB}"); e(f"s_mov_b32 s{S_LO2}, s{S_LO}"); e(f"s_mov_b32 s{S_SPAN2}, s{S_SPAN}")
-            for ins in advance_iterator_tagged("P2"):
+            # the second half of stage 3 is issued in the loop's first k-step: keep its source and masks, then move the iterator on
+            for ins in keep_second_half():
                 e(ins)
-    e(f"s_waitcnt vmcnt({14 + SLACK_VM}) lgkmcnt(0)")       # stage 0 has landed (stage 1's 9 and stage 2's 5 operations may be outstanding)
+            for ins in advance_iterator_tagged("P3"):
+                e(ins)
+    e(f"s_waitcnt vmcnt({23 + SLACK_VM}) lgkmcnt(0)")       # stage 0 has landed (9 + 9 + 5 operations of stages 1, 2, 3 may be outstanding)
     g.ds, g.vm = [], []
     e("s_barrier")
     slots = [[] for _ in range(49)]
-    reads(g, 0, 0, slots, 0, 0)
+    reads(g, 0, 0, slots, 0, 0, 0)
     for ins in slots[0]:
         put(g, ins)
     # the loop is entered with its first fragments landed; its counted waits are those of the STEADY state (the reads of set 0 dealt into
-    # the previous stage's second k-step), which the loop body below is generated against (fixpoint of the queue at the loop top)
+    # the previous stage's second k-step), which the loop bodies below are generated against (fixpoint of the queue at the loop top)
     e("s_waitcnt lgkmcnt(0)")
-    e(f"s_mov_b32 s{S_RSLOT}, 0"); e(f"s_mov_b32 s{S_SLOT_B}, {2 * STAGE}"); e(f"s_mov_b32 s{S_SLOT_A}, {3 * STAGE}")
     e("WGL_LOOP_%=:")
-    body, top = loop_body([])
-    body2, top2 = loop_body(top)
-    assert top2 == top, "the LDS queue at the loop top is not a fixpoint"
-    g.L += body2
-    e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1"); e(f"s_cmp_lg_u32 s{S_CNT}, 0"); e("s_cbranch_scc1 WGL_LOOP_%=")
+    _, top = loop_body([], 0)
+    for r in range(4):
+        body, top2 = loop_body(top, r)
+        assert top2 == top, "the LDS queue at the loop top is not a fixpoint"
+        g.L += body
+        e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1"); e(f"s_cmp_lg_u32 s{S_CNT}, 0")
+        e("s_cbranch_scc1 WGL_LOOP_%=" if r == 3 else "s_cbranch_scc0 WGL_DONE_%=")
+    e("WGL_DONE_%=:")
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     e("s_mov_b32 m0, s54")
     e("s_nop 15"); e("s_nop 15")
@@ -232,38 +272,36 @@ def build():
     return g.L
 
 
-def loop_body(ds_at_top):
-    """one stage; returns (instructions, LDS queue at its end)"""
+def keep_second_half():
+    return [f"s_mov_b64 {S_XB2}, {S_XB}", f"s_mov_b32 s{S_LO2}, s{S_LO}", f"s_mov_b32 s{S_SPAN2}, s{S_SPAN}", f"s_mov_b32 s{S_BND2}, s{S_BND}"]
+
+
+def loop_body(ds_at_top, r):
+    """one stage whose ring slot is r; returns (instructions, LDS queue at its end)"""
     g = Gen()
     g.ds = list(ds_at_top)
     e = g.emit
-    # ---- k-step 0: set 0; reads of (st, 1) into set 1; second half of stage st + 2
+    n0 = _PIECE[0]
+    # ---- k-step 0: set 0; reads of (st, 1) into set 1; second half of stage st + 3
     slots = [[] for _ in range(49)]
-    reads(g, 1, 1, slots, 1, 40)
+    reads(g, 1, 1, slots, 1, 40, r)
     for n, k in enumerate(range(1, 5)):
-        slots[4 + 10 * n] += x_piece(k, S_SLOT_B, S_XB2, S_LO2, S_SPAN2)
+        slots[4 + 10 * n] += x_piece(k, (r + 3) & 3, S_XB2, S_LO2, S_SPAN2, S_BND2)
     run_kstep(g, 0, slots)
-    e(f"s_waitcnt vmcnt({9 + SLACK_VM}) lgkmcnt(0)")        # stage st + 1 has landed: only stage st + 2's nine operations are younger
+    e(f"s_waitcnt vmcnt({18 + SLACK_VM}) lgkmcnt(0)")        # stage st + 1 has landed: only the 18 operations of stages st + 2 and st + 3 are younger
     g.ds, g.vm = [], []
     e("s_barrier")
-    # ---- k-step 1: set 1; fragment addresses to the next slot; reads of (st + 1, 0) into set 0; first half of stage st + 3
+    # ---- k-step 1: set 1; reads of (st + 1, 0) into set 0; first half of stage st + 4 into the slot of stage st
     slots = [[] for _ in range(49)]
-    slots[0] += [f"s_add_u32 s{S_RSLOT}, s{S_RSLOT}, 1", f"s_and_b32 s{S_RSLOT}, s{S_RSLOT}, 3", f"s_mov_b32 s{S_STEP}, {STAGE}",
-                 f"s_cmp_eq_u32 s{S_RSLOT}, 0", f"s_cselect_b32 s{S_STEP}, {-3 * STAGE}, s{S_STEP}"]
-    adr = [f"%[va{i}]" for i in range(NI)] + [f"%[vb{j}{h}]" for j in range(NJ) for h in "ab"]
-    for n, a in enumerate(adr):
-        slots[1 + n // 3].append(f"v_add_u32 {a}, s{S_STEP}, {a}")
-    reads(g, 0, 0, slots, 11, 46)
+    reads(g, 0, 0, slots, 8, 46, (r + 1) & 3)
     half = []
     for k in range(4):
-        half.append(dy_piece(k, S_SLOT_A))
-    half.append(x_piece(0, S_SLOT_A, S_XB, S_LO, S_SPAN))
+        half.append(dy_piece(k, r))
+    half.append(x_piece(0, r, S_XB, S_LO, S_SPAN, S_BND))
     for n, p in enumerate(half):
         slots[3 + 9 * n] += p
-    # the staging iterator: this stage's second half keeps (source, masks), the ring slots rotate, the iterator moves on to stage st + 4
-    slots[47] += [f"s_mov_b64 {S_XB2}, {S_XB}", f"s_mov_b32 s{S_LO2}, s{S_LO}", f"s_mov_b32 s{S_SPAN2}, s{S_SPAN}",
-                  f"s_mov_b32 s{S_SLOT_B}, s{S_SLOT_A}", f"s_add_u32 s{S_SLOT_A}, s{S_SLOT_A}, {STAGE}", f"s_cmp_eq_u32 s{S_SLOT_A}, {4 * STAGE}",
-                  f"s_cselect_b32 s{S_SLOT_A}, 0, s{S_SLOT_A}"] + advance_iterator_tagged("L")
+    # the staging iterator: this stage's second half keeps (source, masks), the iterator moves on to stage st + 5
+    slots[47] += keep_second_half() + advance_iterator_tagged(f"L{r}")
     run_kstep(g, 1, slots)
     return g.L, list(g.ds)
 
@@ -300,7 +338,7 @@ def render():
          "#define WGRAD_LW_STORE_ASM \\", cstr(store_block()), "",
          "#define WGRAD_LW_ZERO_ASM \\", cstr([f"v_accvgpr_write_b32 a{n}, 0" for n in range(256)]), "",
          "#define WGRAD_LW_CLOBBER_S " + ", ".join(f'"s{i}"' for i in CLOBBER_S),
-         "#define WGRAD_LW_CLOBBER_V " + ", ".join(f'"v{i}"' for i in range(127, 256)), ""]
+         "#define WGRAD_LW_CLOBBER_V " + ", ".join(f'"v{i}"' for i in range(100 if ABL & 32 else 127, 256)), ""]
     return "\n".join(o)
 
 
