@@ -153,10 +153,9 @@ def test_weight_gradient_lone_wave_loop_is_generated_interpreted_and_audited():
     tools/check_wgrad_lw.py walks the generated stream with the two in-order queues and their counted waits: fragments landed before
     their MFMA, every LDS-DMA piece of a stage landed before the barrier behind which the stage is read, ring slots overwritten only
     behind the barrier that retires them; and audits the compiled kernel (the accumulation file untouched by the compiler, 96 MFMAs in
-    one statement, no scratch).  The stream is walked along both paths of the row-buffer pieces (boundary stages: EXEC masks + zero
-    fill; interior stages: whole pieces).  Mutations it has to reject: the vector-memory waits one piece too lax; the LDS waits one read
-    too lax (caught on the interior path; on the boundary path ONE is absorbed by design: the zero-fill ds_write of a piece is not
-    counted by the generator, under an all-zero EXEC it might never enter the queue)."""
+    one statement, no scratch).  The stream is walked with the zero fill of the row-buffer pieces issued (boundary stages) and skipped
+    (interior stages).  Mutations it has to reject: the vector-memory waits one piece too lax; the LDS waits one read too lax (caught
+    with the zero fill skipped; with it issued ONE is absorbed by design: the generator does not count a write that may be skipped)."""
     import shutil
     import subprocess
     import sys

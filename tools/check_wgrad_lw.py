@@ -2,7 +2,7 @@
 """Checks of the lone-wave dense weight-gradient kernel (conv_wgrad_lw_kernel, csrc/pw_wgrad.hip + the generated csrc/wgrad_lw_body.inc).
 
 1. Schedule interpreter (no hipcc needed).  The generated stream is walked prologue -> the four unrolled stage bodies, twice -> drain as the hardware retires
-   it, once along the boundary path of every row-buffer piece (EXEC masks + zero fill) and once along the interior path: LDS operations and vector-memory operations are two IN-ORDER queues, `s_waitcnt lgkmcnt(n) / vmcnt(n)` retires all but the n
+   it, once with the zero fill of every row-buffer piece issued and once with all of them skipped: LDS operations and vector-memory operations are two IN-ORDER queues, `s_waitcnt lgkmcnt(n) / vmcnt(n)` retires all but the n
    youngest of a queue.  Checked:
    * every MFMA's fragment registers have landed (no transposing read into them is still in the LDS queue), and no read overwrites a
      fragment register an older read is still in flight for;
@@ -42,31 +42,10 @@ def vregs(text):
 STAGE = 40960
 
 
-def linearize(lines, fast):
-    """one of the two paths of every row-buffer piece: the boundary path (masks + zero fill; fast = False) or the interior one"""
-    out, skip_to = [], None
-    for l in lines:
-        if skip_to:
-            if l == skip_to:
-                skip_to = None
-            continue
-        m = re.match(r"s_cbranch_scc1 (WGL_XF\d+_%=)", l)
-        if m:
-            if fast:
-                skip_to = m.group(1) + ":"
-            continue
-        m = re.match(r"s_branch (WGL_XD\d+_%=)", l)
-        if m:
-            skip_to = m.group(1) + ":"
-            continue
-        if re.match(r"WGL_X[FD]\d+_%=:", l):
-            continue
-        out.append(l)
-    return out
-
-
 def interpret(lines, passes=2):
-    return interpret_path(linearize(lines, False), passes) + [f"(interior path) {f}" for f in interpret_path(linearize(lines, True), passes)]
+    """both outcomes of the pieces' zero fill: issued (boundary stages), skipped (s_cbranch_execz taken: interior stages)"""
+    skipped = [l for l in lines if not l.startswith("ds_write_b128")]
+    return interpret_path(lines, passes) + [f"(zero fill skipped) {f}" for f in interpret_path(skipped, passes)]
 
 
 def interpret_path(lines, passes):

@@ -21,11 +21,13 @@ and slots 2 / 3: a ds offset field holds 16 bits) and never move (28 VALU per st
 s_add of a literal.
 (The first version staged one stage later -- st + 3 into the slot of st - 1 -- and had the second half of a stage in flight for ONE stage
  time, ~1 us: less than the memory latency under load; the ablations of tools/wgrad_lw_ablate.sh showed the wait.)
-Row-buffer pieces of a BOUNDARY stage (first / last 64 pixels of an image row, a kernel row outside the image, beyond the split's
-end) are issued under EXEC = the lanes whose pixel lies inside the image row (and inside the 64 + 2 dil rows that are read); the other
-lanes' 16 bytes are zero-filled by a ds_write under the complementary mask (conv_lw.hip's scheme).  An interior stage takes a short
-path: pieces 0-3 whole, piece 4 under EXEC = its 2 dil rows that are read, no zero fill (-4 % measured).  Every wave issues the same 9
-vector-memory operations per stage on either path, so the counted waits are the same immediates for all waves.
+Row-buffer pieces are issued under EXEC = the lanes whose pixel lies inside the image row (and inside the 64 + 2 dil rows that are read);
+the other lanes' 16 bytes are zero-filled by a ds_write under the complementary mask (conv_lw.hip's scheme), skipped when that mask is
+empty.  Every wave issues the same 9 vector-memory operations per stage, so the counted waits are the same immediates for all waves.
+Everything that is not an MFMA -- the reads, the pieces (cut into groups of 2-4 instructions), the staging iterator (branch-free, in
+groups that keep an SCC producer with its consumers) -- is dealt EVENLY over the 48 gaps of a k-step: a lone wave issues one instruction
+per ~4 cycles and an MFMA occupies the pipe for 16, so a gap holds three instructions for free and every further one delays the matrix
+pipe (the first version put a piece's ten instructions, or the iterator's 35, into one gap: ~350 of its 2230 cycles per stage).
 
 usage: python tools/gen_wgrad_lw.py   (rewrites csrc/wgrad_lw_body.inc; `--check` exits 1 when the file is stale: tests/test_abi.py)"""
 import os
@@ -53,15 +55,17 @@ S_YB, S_XB = "s[40:41]", "s[42:43]"       # source bases of the stage being stag
 S_LO, S_SPAN = 44, 45                     # its valid row-buffer rows [lo, lo + span)
 S_X0, S_HO = 46, 47                       # its first pixel's column / image row
 S_LEFT = 48                               # stages left to stage for real (beyond the split's end the last one is staged again, all rows masked)
-S_BND, S_BND2 = 49, 50                    # 1: the stage being staged (first / second half) is a boundary stage (masks + zero fill)
+S_T2 = 49
 S_CNT = 51                                # stages left to compute
-S_2D = 52                                 # 2 * dil
 S_M0 = 54
 S_T0, S_T1 = 55, 56
 S_XB2 = "s[58:59]"                        # row-buffer source base of the SECOND half-stage (the first half's stage moved on in between)
 S_LO2, S_SPAN2 = 60, 61
-CLOBBER_S = list(range(40, 62))
-VT = 127                                  # lane temporary
+S_MASK = [62, 64, 66, 68, 70]             # lane masks of the five row-buffer pieces (pairs)
+CLOBBER_S = list(range(40, 72))
+VTS = [122, 123, 124, 125, 126]           # lane temporaries, one per row-buffer piece
+VT = 127
+V_CLOBBER0 = 122
 ABL = int(os.environ.get("KDCC_GEN_WGRAD_ABL", "0"))   # TIMING ablations (tools/wgrad_lw_ablate.sh; results wrong): 1 no LDS-DMA, 2 no fragment reads, 4 no MFMAs, 8 no zero fill, 16 no address steps
 SLACK_DS = SLACK_VM = 0                   # mutation hooks of tools/check_wgrad_lw.py's self-test: every counted wait that many operations too lax
 
@@ -117,53 +121,52 @@ _PIECE = [0]
 
 
 def dy_piece(k, ring):
-    return [f"s_add_u32 m0, %[sldsw], {ring * STAGE + k * 4096}", "s_nop 0",
-            ("VM", f"global_load_lds_dwordx4 %[voy{k}], {S_YB}", f"y{k}")]
+    """-> groups of instructions; a group stays together between two MFMAs"""
+    return [[f"s_add_u32 m0, %[sldsw], {ring * STAGE + k * 4096}", "s_nop 0", ("VM", f"global_load_lds_dwordx4 %[voy{k}], {S_YB}", f"y{k}")]]
 
 
-def x_piece(k, ring, xb, lo, span, bnd):
+def x_piece(k, ring, xb, lo, span):
+    """Row-buffer piece k (rows 16 k + 4 wave + lane / 16 of the buffer): the lanes whose pixel lies inside the image row and inside the
+    64 + 2 dil rows that are read are loaded, the others zero-filled under the complementary mask (conv_lw.hip's scheme).  Branch-free
+    (but for the skip of an empty zero fill) and cut into four groups of 2-4 instructions: the first version had the ten of them between
+    ONE pair of MFMAs and the matrix pipe waited ~30 cycles per piece."""
     _PIECE[0] += 1
     n = _PIECE[0]
-    fast = ([("VM", f"global_load_lds_dwordx4 %[vox{k}], {xb}", f"x{k}")] if k < 4 else
-            [f"v_cmpx_gt_u32 vcc, s{S_2D}, %[vr0]", ("VM", f"global_load_lds_dwordx4 %[vox{k}], {xb}", f"x{k}"), "s_mov_b64 exec, -1"])
+    vt, m = VTS[k], f"s[{S_MASK[k]}:{S_MASK[k] + 1}]"
     vz = "%[vzl]" if ring < 2 else "%[vzh]"          # this lane's 16 bytes of piece 0 of the row buffer in ring slot 0 / 2
-    return [f"s_add_u32 m0, %[sldsw], {ring * STAGE + XOFF + k * 4096}", f"s_cmp_eq_u32 s{bnd}, 0", f"s_cbranch_scc1 WGL_XF{n}_%=",
-            f"v_add_u32 v{VT}, {16 * k}, %[vr0]", f"v_subrev_u32 v{VT}, s{lo}, v{VT}", f"v_cmpx_gt_u32 vcc, s{span}, v{VT}",
-            ("VM", f"global_load_lds_dwordx4 %[vox{k}], {xb}", f"x{k}"), "s_not_b64 exec, exec",
-            # (NOT tracked in the LDS queue: under an all-zero EXEC the write may never enter it, and a counted wait that assumed it did
-            #  would be too lax; leaving it out makes every count a lower bound of the operations really issued behind a read)
-            f"ds_write_b128 {vz}, %[vzero] offset:{(ring & 1) * STAGE + k * 4096}",
-            "s_mov_b64 exec, -1", f"s_branch WGL_XD{n}_%=", f"WGL_XF{n}_%=:"] + fast + [f"WGL_XD{n}_%=:"]
+    return [[f"v_add_u32 v{vt}, {16 * k}, %[vr0]", f"v_subrev_u32 v{vt}, s{lo}, v{vt}"],
+            [f"v_cmp_gt_u32 {m}, s{span}, v{vt}", f"s_add_u32 m0, %[sldsw], {ring * STAGE + XOFF + k * 4096}"],
+            [f"s_mov_b64 exec, {m}", ("VM", f"global_load_lds_dwordx4 %[vox{k}], {xb}", f"x{k}"), "s_mov_b64 exec, -1"],
+            # (the zero fill is NOT tracked in the LDS queue: it is skipped when no lane needs it, and a counted wait that assumed it
+            #  was issued would be too lax; leaving it out makes every count a lower bound of the operations issued behind a read)
+            [f"s_not_b64 exec, {m}", f"s_cbranch_execz WGL_NZ{n}_%=", f"ds_write_b128 {vz}, %[vzero] offset:{(ring & 1) * STAGE + k * 4096}",
+             f"WGL_NZ{n}_%=:", "s_mov_b64 exec, -1"]]
 
 
 def advance_iterator():
-    """the stage being staged moves on by 64 pixels (while stages are left; afterwards the last one is staged again with every row masked)"""
-    return [f"s_sub_u32 s{S_LEFT}, s{S_LEFT}, 1", f"s_cmp_gt_i32 s{S_LEFT}, 0", "s_cbranch_scc0 WGL_END_%=",
-            f"s_add_u32 s40, s40, %[sdy]", "s_addc_u32 s41, s41, 0", f"s_add_u32 s42, s42, %[sdx]", "s_addc_u32 s43, s43, 0",
-            f"s_add_u32 s{S_X0}, s{S_X0}, 64", f"s_cmp_ge_u32 s{S_X0}, %[sW]", "s_cbranch_scc0 WGL_SAME_%=",
-            f"s_mov_b32 s{S_X0}, 0", f"s_add_u32 s{S_HO}, s{S_HO}, 1", f"s_cmp_ge_u32 s{S_HO}, %[sH]", f"s_cselect_b32 s{S_HO}, 0, s{S_HO}",
-            "WGL_SAME_%=:", "s_branch WGL_MASK_%=", "WGL_END_%=:", f"s_mov_b32 s{S_LEFT}, 0", "WGL_MASK_%=:"] + masks()
+    """the stage being staged moves on by 64 pixels while stages are left; afterwards the last one is staged again with every row masked.
+    Branch-free, in groups that keep an SCC producer with its consumers (MFMA, LDS and vector-memory instructions leave SCC alone)."""
+    return [[f"s_sub_u32 s{S_LEFT}, s{S_LEFT}, 1", f"s_cmp_gt_i32 s{S_LEFT}, 0", f"s_cselect_b32 s{S_T0}, %[sdy], 0", f"s_cselect_b32 s{S_T1}, %[sdx], 0",
+             f"s_cselect_b32 s{S_T2}, 64, 0"],
+            [f"s_max_i32 s{S_LEFT}, s{S_LEFT}, 0", f"s_add_u32 s40, s40, s{S_T0}", "s_addc_u32 s41, s41, 0"],
+            [f"s_add_u32 s42, s42, s{S_T1}", "s_addc_u32 s43, s43, 0", f"s_add_u32 s{S_X0}, s{S_X0}, s{S_T2}"],
+            [f"s_cmp_ge_u32 s{S_X0}, %[sW]", f"s_cselect_b32 s{S_X0}, 0, s{S_X0}", f"s_cselect_b32 s{S_T0}, 1, 0", f"s_add_u32 s{S_HO}, s{S_HO}, s{S_T0}"],
+            [f"s_cmp_ge_u32 s{S_HO}, %[sH]", f"s_cselect_b32 s{S_HO}, 0, s{S_HO}"]] + masks()
 
 
 def masks():
-    """lo / span of the stage at (x0, ho): rows of the buffer inside the image row, none when the kernel row leaves the image or nothing
-    is left; bnd = 1 unless all of the 64 + 2 dil rows that are read lie inside the image"""
-    return [f"s_cmp_eq_u32 s{S_X0}, 0", f"s_cselect_b32 s{S_LO}, %[sd], 0", f"s_cselect_b32 s{S_BND}, 1, 0",       # first tile of a row: pixels x0 - d + r < 0
-            f"s_add_u32 s{S_T0}, s{S_X0}, 64", f"s_cmp_eq_u32 s{S_T0}, %[sW]", f"s_cselect_b32 s{S_T0}, %[send1], %[send2]",   # last tile: 64 + d rows, else 64 + 2 d
-            f"s_cselect_b32 s{S_BND}, 1, s{S_BND}",
-            f"s_sub_u32 s{S_SPAN}, s{S_T0}, s{S_LO}",
-            f"s_add_i32 s{S_T1}, s{S_HO}, %[skyd]", f"s_cmp_lt_u32 s{S_T1}, %[sH]", f"s_cselect_b32 s{S_SPAN}, s{S_SPAN}, 0",   # (unsigned: hi < 0 wraps)
-            f"s_cselect_b32 s{S_BND}, s{S_BND}, 1",
-            f"s_cmp_gt_i32 s{S_LEFT}, 0", f"s_cselect_b32 s{S_SPAN}, s{S_SPAN}, 0", f"s_cselect_b32 s{S_BND}, s{S_BND}, 1"]
+    """lo / span of the stage at (x0, ho): rows of the buffer inside the image row, none when the kernel row leaves the image or nothing is left"""
+    return [[f"s_cmp_eq_u32 s{S_X0}, 0", f"s_cselect_b32 s{S_LO}, %[sd], 0", f"s_add_u32 s{S_T0}, s{S_X0}, 64"],                        # first tile of a row: pixels x0 - d + r < 0
+            [f"s_cmp_eq_u32 s{S_T0}, %[sW]", f"s_cselect_b32 s{S_T0}, %[send1], %[send2]", f"s_sub_u32 s{S_SPAN}, s{S_T0}, s{S_LO}"],  # last tile: 64 + d rows, else 64 + 2 d
+            [f"s_add_i32 s{S_T1}, s{S_HO}, %[skyd]", f"s_cmp_lt_u32 s{S_T1}, %[sH]", f"s_cselect_b32 s{S_SPAN}, s{S_SPAN}, 0"],          # (unsigned: hi < 0 wraps)
+            [f"s_cmp_gt_i32 s{S_LEFT}, 0", f"s_cselect_b32 s{S_SPAN}, s{S_SPAN}, 0"]]
 
 
-def emit_slots(g, slots, body):
-    for k, m in enumerate(body):
-        g.emit(m)
-        for ins in slots[k]:
-            put(g, ins)
-    for ins in slots[len(body)]:
-        put(g, ins)
+def deal(slots, groups, first, last):
+    """the groups, in order, at evenly spaced gaps of [first, last]"""
+    n = len(groups)
+    for k, grp in enumerate(groups):
+        slots[first + (k * (last - first + 1)) // n] += grp
 
 
 def put(g, ins):
@@ -219,33 +222,28 @@ def build():
     g = Gen()
     e = g.emit
     _PIECE[0] = 0
+
+    def flat(groups):
+        for grp in groups:
+            for ins in grp:
+                put(g, ins)
     # ---- set-up: the staging iterator starts at stage 0 of the split (an empty split only writes its zero slab)
     e("s_cmp_eq_u32 %[snst], 0"); e("s_cbranch_scc1 WGL_SKIP_%=")
     e("s_mov_b32 s54, m0")
     e(f"s_mov_b64 {S_YB}, %[syb]"); e(f"s_mov_b64 {S_XB}, %[sxb]")
     e(f"s_mov_b32 s{S_X0}, %[sx0]"); e(f"s_mov_b32 s{S_HO}, %[sho]"); e(f"s_mov_b32 s{S_LEFT}, %[snst]"); e(f"s_mov_b32 s{S_CNT}, %[snst]")
-    e(f"s_lshl_b32 s{S_2D}, %[sd], 1")
-    for ins in masks():
-        e(ins)
+    flat(masks())
     # ---- prologue: stages 0, 1 and 2 whole, the first half of stage 3
     for st in range(4):
         for k in range(4):
-            for ins in dy_piece(k, st):
-                put(g, ins)
-        for ins in x_piece(0, st, S_XB, S_LO, S_SPAN, S_BND):
-            put(g, ins)
+            flat(dy_piece(k, st))
+        flat(x_piece(0, st, S_XB, S_LO, S_SPAN))
         if st < 3:
             for k in range(1, 5):
-                for ins in x_piece(k, st, S_XB, S_LO, S_SPAN, S_BND):
-                    put(g, ins)
-            for ins in advance_iterator_tagged(f"P{st}"):
-                e(ins)
+                flat(x_piece(k, st, S_XB, S_LO, S_SPAN))
         else:
-            # the second half of stage 3 is issued in the loop's first k-step: keep its source and masks, then move the iterator on
-            for ins in keep_second_half():
-                e(ins)
-            for ins in advance_iterator_tagged("P3"):
-                e(ins)
+            flat([keep_second_half()])      # the second half of stage 3 is issued in the loop's first k-step: keep its source and masks
+        flat(advance_iterator())
     e(f"s_waitcnt vmcnt({23 + SLACK_VM}) lgkmcnt(0)")       # stage 0 has landed (9 + 9 + 5 operations of stages 1, 2, 3 may be outstanding)
     g.ds, g.vm = [], []
     e("s_barrier")
@@ -273,7 +271,7 @@ def build():
 
 
 def keep_second_half():
-    return [f"s_mov_b64 {S_XB2}, {S_XB}", f"s_mov_b32 s{S_LO2}, s{S_LO}", f"s_mov_b32 s{S_SPAN2}, s{S_SPAN}", f"s_mov_b32 s{S_BND2}, s{S_BND}"]
+    return [f"s_mov_b64 {S_XB2}, {S_XB}", f"s_mov_b32 s{S_LO2}, s{S_LO}", f"s_mov_b32 s{S_SPAN2}, s{S_SPAN}"]
 
 
 def loop_body(ds_at_top, r):
@@ -281,37 +279,28 @@ def loop_body(ds_at_top, r):
     g = Gen()
     g.ds = list(ds_at_top)
     e = g.emit
-    n0 = _PIECE[0]
     # ---- k-step 0: set 0; reads of (st, 1) into set 1; second half of stage st + 3
     slots = [[] for _ in range(49)]
-    reads(g, 1, 1, slots, 1, 40, r)
-    for n, k in enumerate(range(1, 5)):
-        slots[4 + 10 * n] += x_piece(k, (r + 3) & 3, S_XB2, S_LO2, S_SPAN2, S_BND2)
+    reads(g, 1, 1, slots, 0, 38, r)
+    grp = []
+    for k in range(1, 5):
+        grp += x_piece(k, (r + 3) & 3, S_XB2, S_LO2, S_SPAN2)
+    deal(slots, grp, 1, 46)
     run_kstep(g, 0, slots)
     e(f"s_waitcnt vmcnt({18 + SLACK_VM}) lgkmcnt(0)")        # stage st + 1 has landed: only the 18 operations of stages st + 2 and st + 3 are younger
     g.ds, g.vm = [], []
     e("s_barrier")
-    # ---- k-step 1: set 1; reads of (st + 1, 0) into set 0; first half of stage st + 4 into the slot of stage st
+    # ---- k-step 1: set 1; reads of (st + 1, 0) into set 0; first half of stage st + 4 into the slot of stage st; the staging iterator:
+    # this stage's second half keeps (source, masks), then the iterator moves on to stage st + 5
     slots = [[] for _ in range(49)]
-    reads(g, 0, 0, slots, 8, 46, (r + 1) & 3)
-    half = []
+    reads(g, 0, 0, slots, 6, 46, (r + 1) & 3)
+    grp = []
     for k in range(4):
-        half.append(dy_piece(k, r))
-    half.append(x_piece(0, r, S_XB, S_LO, S_SPAN, S_BND))
-    for n, p in enumerate(half):
-        slots[3 + 9 * n] += p
-    # the staging iterator: this stage's second half keeps (source, masks), the iterator moves on to stage st + 5
-    slots[47] += keep_second_half() + advance_iterator_tagged(f"L{r}")
+        grp += dy_piece(k, r)
+    grp += x_piece(0, r, S_XB, S_LO, S_SPAN) + [keep_second_half()] + advance_iterator()
+    deal(slots, grp, 0, 47)
     run_kstep(g, 1, slots)
     return g.L, list(g.ds)
-
-
-_TAGN = [0]
-
-
-def advance_iterator_tagged(tag):
-    return [l.replace("WGL_END_%=", f"WGL_END{tag}_%=").replace("WGL_SAME_%=", f"WGL_SAME{tag}_%=").replace("WGL_MASK_%=", f"WGL_MASK{tag}_%=")
-            for l in advance_iterator()]
 
 
 def store_block():
@@ -338,7 +327,7 @@ def render():
          "#define WGRAD_LW_STORE_ASM \\", cstr(store_block()), "",
          "#define WGRAD_LW_ZERO_ASM \\", cstr([f"v_accvgpr_write_b32 a{n}, 0" for n in range(256)]), "",
          "#define WGRAD_LW_CLOBBER_S " + ", ".join(f'"s{i}"' for i in CLOBBER_S),
-         "#define WGRAD_LW_CLOBBER_V " + ", ".join(f'"v{i}"' for i in range(100 if ABL & 32 else 127, 256)), ""]
+         "#define WGRAD_LW_CLOBBER_V " + ", ".join(f'"v{i}"' for i in range(100 if ABL & 32 else V_CLOBBER0, 256)), ""]
     return "\n".join(o)
 
 
