@@ -732,7 +732,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row_kernel(const WgradParam
 // [3 kx x 64 Cin]: 48 accumulator tiles in a[0:191], fragments in v[128:255]) run a hand-dealt stream: per 32-pixel k-step 48 MFMAs with
 // the 32 ds_read_b64_tr_b16 of the next k-step and 4-5 LDS-DMA pieces between them, one barrier per stage; the loop is unrolled over the
 // four ring slots, so a stage's slot is an immediate of its reads and pieces.  Same decomposition (grid, splits, kernel row per workgroup), the same LDS images and the same K order: bit-identical partial
-// slabs.  Cin % 128 == 0, Cout % 128 == 0, dil <= 8 (row buffer of 80 rows: every wave stages 4 dy + 5 row-buffer pieces per stage).
+// slabs.  Cout % 128 == 0, Cin % 8 == 0 (the lanes of a ragged last Cin tile neither load nor store), dil <= 8 (row buffer of 80 rows:
+// every wave stages 4 dy + 5 row-buffer pieces per stage).
 __global__ __launch_bounds__(256, 1) void conv_wgrad_lw_kernel(const WgradParams p)
 {
     __shared__ __attribute__((aligned(1024))) char lds[WR_NST * WR_STAGE];
@@ -785,11 +786,15 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_lw_kernel(const WgradParams
         const int r = (wv + 4 * k) * 4 + prow;
         voy[k] = (uint32_t)(r * p.ldy + co0 + (slot ^ (tr_f(r) << 1)) * 8) * 2u;
     }
+    unsigned long long chm[5], stm[4];   // lanes of a row-buffer piece / of a column tile of the store whose input channel exists (ragged last Cin tile)
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        const int r = (wv + 4 * k) * 4 + prow;
-        vox[k] = (uint32_t)(r * p.lda + ci0 + (slot ^ (tr_f(r) << 1)) * 8) * 2u;
+        const int r = (wv + 4 * k) * 4 + prow, c = (slot ^ (tr_f(r) << 1)) * 8;
+        vox[k] = (uint32_t)(r * p.lda + ci0 + c) * 2u;
+        chm[k] = __ballot(ci0 + c < p.Cin);
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) stm[c] = __ballot(ci0 + wn * 64 + c * 16 + (lane & 15) < p.Cin);
     const uint32_t vr0 = (uint32_t)(wv * 4 + prow);                    // this lane's buffer row in piece 0 (piece k: + 16 k)
     const uint32_t vzl = lbase + 16384 + wv * 1024 + lane * 16, vzh = vzl + 2 * WR_STAGE;   // its 16 bytes of that piece in ring slot 0 / 2
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4w_t;
@@ -830,7 +835,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_lw_kernel(const WgradParams
                    [vr0] "v"(vr0), [vzl] "v"(vzl), [vzh] "v"(vzh), [vzero] "v"(vzero),
                    [syb] "s"(syb), [sxb] "s"(sxb), [sx0] "s"(x0), [sho] "s"(ho), [snst] "s"((uint32_t)nst), [sdy] "s"(sdy), [sdx] "s"(sdx),
                    [sW] "s"((uint32_t)p.W), [sH] "s"((uint32_t)p.H), [sd] "s"((uint32_t)d), [send1] "s"(send1), [send2] "s"(send2), [skyd] "s"(skyd),
-                   [sldsw] "s"(sldsw)
+                   [sldsw] "s"(sldsw), [schm0] "s"(chm[0]), [schm1] "s"(chm[1]), [schm2] "s"(chm[2]), [schm3] "s"(chm[3]), [schm4] "s"(chm[4])
                  : "memory", "scc", "vcc", WGRAD_LW_CLOBBER_S, WGRAD_LW_CLOBBER_V);
 #undef WGLW_ADDR
     // accumulators -> the split's fp32 slab: D[co = 16 i + 4 q + r][ci = li] of tile (i, j = kx * 4 + c)
@@ -839,7 +844,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_lw_kernel(const WgradParams
     const uint32_t vob = (uint32_t)((wm * 64 + q * 4) * p.Cin + wn * 64 + li) * 4u, cin4 = (uint32_t)p.Cin * 4u;
     asm volatile(WGRAD_LW_STORE_ASM
                  : WGLW_ACC_RW
-                 : [vob] "v"(vob), [vcin4] "s"(cin4), [sout0] "s"(out0), [sout1] "s"(out1), [sout2] "s"(out2)
+                 : [vob] "v"(vob), [vcin4] "s"(cin4), [sout0] "s"(out0), [sout1] "s"(out1), [sout2] "s"(out2),
+                   [sstm0] "s"(stm[0]), [sstm1] "s"(stm[1]), [sstm2] "s"(stm[2]), [sstm3] "s"(stm[3])
                  : "memory", "v127");
 #undef WGLW_ACC_RW
 }
@@ -1118,7 +1124,7 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
         p.tiles = tiles;
         static int lwmode = -1;
         if (lwmode < 0) { const char *e = getenv("KDCC_WGRAD_LW"); lwmode = (e && e[0] == '0') ? 0 : 1; }   // A/B: 0 = conv_wgrad_row_kernel (8 waves); bit-identical
-        if (lwmode && !p.dbg && d->Cin % 128 == 0 && d->Cout % 128 == 0 && d->dil <= 8) {
+        if (lwmode && !p.dbg && d->Cout % 128 == 0 && d->dil <= 8) {   // (Cin % 8 == 0: row_eligible; a ragged last Cin tile is masked)
             KD_NOTE_KERNEL("conv_wgrad_lw_kernel");
             hipLaunchKernelGGL(conv_wgrad_lw_kernel, dim3((unsigned)(tiles * splits * 3)), dim3(256), 0, s, p);
         } else {

@@ -1127,7 +1127,8 @@ WGRAD_CASES = [
     (1, 16, 128, 256, 512, 3, 1, 2, 2),   # four Cout tiles, two Cin tiles, 32 stages: ring fill / steady state / drain
     (2, 8, 64, 128, 320, 3, 1, 4, 4),     # ragged third Cout tile, dilation 4
     (1, 3, 64, 64, 256, 3, 1, 1, 1),      # three stages per split: shorter than the ring
-    # Cin, Cout % 128 == 0, dil <= 8: conv_wgrad_lw_kernel (one wave per SIMD, generated stage loop)
+    # Cout % 128 == 0, dil <= 8: conv_wgrad_lw_kernel (one wave per SIMD, generated stage loop; a ragged last Cin tile is masked)
+    (1, 6, 64, 200, 128, 3, 1, 2, 2),     # 200 input channels: 72 of the second Cin tile
     (1, 2, 64, 128, 128, 3, 1, 8, 8),     # two stages, the largest dilation: kernel rows 0 and 2 never meet the image
     (3, 5, 192, 256, 128, 3, 1, 5, 5),    # three stages per image row, odd dilation, splits that end inside an image
     (2, 7, 64, 128, 384, 3, 1, 1, 1),     # one stage per image row (first and last tile at once), three Cout tiles
@@ -1147,8 +1148,8 @@ def test_conv_wgrad(K, dt, case):
     dw = torch.full((Cout, Cin, k, k), 3.0, device="cuda")
     K.conv2d_wgrad(dev_nhwc(x, dt, ld=Cin + 16), gyd, dw, s, p, d)
     if dt == "bf16" and k == 3 and s == 1 and p == d and W % 64 == 0 and d <= 16:
-        # the row-buffer cases: one wave per SIMD where both channel counts are multiples of 128 (dil <= 8), else the 8-wave kernel
-        selected("conv_wgrad_lw_kernel" if Cin % 128 == 0 and Cout % 128 == 0 and d <= 8 else "conv_wgrad_row_kernel", f"wgrad {case}")
+        # the row-buffer cases: one wave per SIMD where Cout is a multiple of 128 (dil <= 8), else the 8-wave kernel
+        selected("conv_wgrad_lw_kernel" if Cout % 128 == 0 and d <= 8 else "conv_wgrad_row_kernel", f"wgrad {case}")
     elif dt == "bf16" and Cin >= 256 and Cout >= 256:
         selected("conv_wgrad_wide_kernel", f"wgrad {case}")     # the 256 x 256 tile cases
     assert_close(dw.cpu().numpy(), ref, dt, f"wgrad {case}")

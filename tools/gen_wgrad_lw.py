@@ -7,7 +7,7 @@ Same decomposition, LDS images and K order as conv_wgrad_row_kernel (pw_wgrad.hi
 (kernel row ky, tile of 128 Cout x 128 Cin, pixel split); a K stage is 64 consecutive pixels of one image row: dy image 64 rows x 256 B
 and the activations as a ROW BUFFER of up to 80 rows x 256 B (halo included, zeros outside the image) which the three kx taps read
 at row offsets kx * dil; four 40-KiB stages in a ring.  What changes is who does the work: 4 waves (wave (wm, wn) = 64 Cout x [3 kx x 64
-Cin] = 48 accumulator tiles in a[0:191]) instead of 8, and every ds_read_b64_tr_b16 fragment read, every LDS-DMA piece and every
+Cin] = 48 accumulator tiles in a[0:191]) instead of 8 (Cout % 128 == 0; Cin % 8 == 0: a ragged last Cin tile is masked), and every ds_read_b64_tr_b16 fragment read, every LDS-DMA piece and every
 address update dealt between the 48 MFMAs of a k-step (32 pixels) by this generator.
 
 Per stage st (two k-steps):
@@ -135,7 +135,8 @@ def x_piece(k, ring, xb, lo, span):
     vt, m = VTS[k], f"s[{S_MASK[k]}:{S_MASK[k] + 1}]"
     vz = "%[vzl]" if ring < 2 else "%[vzh]"          # this lane's 16 bytes of piece 0 of the row buffer in ring slot 0 / 2
     return [[f"v_add_u32 v{vt}, {16 * k}, %[vr0]", f"v_subrev_u32 v{vt}, s{lo}, v{vt}"],
-            [f"v_cmp_gt_u32 {m}, s{span}, v{vt}", f"s_add_u32 m0, %[sldsw], {ring * STAGE + XOFF + k * 4096}"],
+            [f"v_cmp_gt_u32 {m}, s{span}, v{vt}", f"s_add_u32 m0, %[sldsw], {ring * STAGE + XOFF + k * 4096}",
+             f"s_and_b64 {m}, {m}, %[schm{k}]"],        # (and inside the Cin channels of the tensor: the last Cin tile may be ragged)
             [f"s_mov_b64 exec, {m}", ("VM", f"global_load_lds_dwordx4 %[vox{k}], {xb}", f"x{k}"), "s_mov_b64 exec, -1"],
             # (the zero fill is NOT tracked in the LDS queue: it is skipped when no lane needs it, and a counted wait that assumed it
             #  was issued would be too lax; leaving it out makes every count a lower bound of the operations issued behind a read)
@@ -304,15 +305,18 @@ def loop_body(ds_at_top, r):
 
 
 def store_block():
-    """accumulators -> the fp32 partial slab: tile (i, j = kx * 4 + c), row r: out[kx] + lane offset + (16 i + r) rows + 64 c bytes"""
+    """accumulators -> the fp32 partial slab: tile (i, j = kx * 4 + c), row r: out[kx] + lane offset + (16 i + r) rows + 64 c bytes; the
+    lanes of column tile c whose input channel lies beyond Cin (ragged last Cin tile) do not store"""
     L = []
-    for i in range(NI):
-        for r in range(4):
-            L.append(f"v_mov_b32 v{VT}, {16 * i + r}")
-            L.append(f"v_mad_u32_u24 v{VT}, v{VT}, %[vcin4], %[vob]")
-            for j in range(NJ):
-                kx, c = divmod(j, 4)
-                L.append(f"global_store_dword v{VT}, a{acc(i, j) + r}, %[sout{kx}] offset:{64 * c}")
+    for c in range(4):
+        L.append(f"s_mov_b64 exec, %[sstm{c}]")
+        for i in range(NI):
+            for r in range(4):
+                L.append(f"v_mov_b32 v{VT}, {16 * i + r}")
+                L.append(f"v_mad_u32_u24 v{VT}, v{VT}, %[vcin4], %[vob]")
+                for kx in range(3):
+                    L.append(f"global_store_dword v{VT}, a{acc(i, kx * 4 + c) + r}, %[sout{kx}] offset:{64 * c}")
+    L.append("s_mov_b64 exec, -1")
     L.append("s_waitcnt vmcnt(0)")
     return L
 

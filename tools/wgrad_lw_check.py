@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """conv_wgrad_lw_kernel (one wave per SIMD, generated stage loop: tools/gen_wgrad_lw.py) against conv_wgrad_row_kernel (8 waves), the
-kernel it replaces on the 3x3 layers whose channel counts are multiples of 128: the same launches in two FRESH child processes
+kernel it replaces on the 3x3 layers with Cout % 128 == 0: the same launches in two FRESH child processes
 (KDCC_WGRAD_LW=1 / 0: the switch is read once per process), the fp32 weight gradients compared BIT FOR BIT (same decomposition, same
 LDS images, same k order into the same fp32 chains: any difference is a defect), and the time of each.
 usage: python tools/wgrad_lw_check.py [--batch N] [--iters K] [--only substr,substr]"""
@@ -27,6 +27,8 @@ CASES = [
     ("mod6 d4 512->1024", None, 128, 256, 512, 1024, 4),
     ("mod7 d4 1024->2048", None, 128, 256, 1024, 2048, 4),
     ("final 256->256", None, 512, 1024, 256, 256, 1),
+    ("final 304->256", None, 512, 1024, 304, 256, 1),      # the decoder's first 3x3: a ragged third Cin tile (48 of 128 channels)
+    ("mod2 64->128", None, 512, 1024, 64, 128, 1),         # half a Cin tile
     # small / edge shapes: fewer stages than the ring holds, one stage per image row (W = 64: first and last tile at once), the
     # largest dilation of the kernel, kernel rows that leave the image for most of the rows, splits that end inside an image
     ("edge 3 rows W64", 1, 3, 64, 128, 128, 1),
@@ -36,6 +38,10 @@ CASES = [
     ("edge d2 20 rows", 1, 20, 128, 128, 128, 2),
     ("edge 2 imgs W64", 2, 9, 64, 128, 128, 1),
     ("edge d3 13 imgs", 13, 5, 64, 128, 384, 3),
+    ("edge ragged 304", 1, 12, 64, 304, 256, 1),
+    ("edge ragged 72 d4", 2, 8, 64, 72, 128, 4),
+    ("edge ragged 200 d2", 1, 5, 128, 200, 128, 2),
+    ("edge ragged 8 d8", 1, 4, 64, 8, 128, 8),
 ]
 
 
