@@ -66,6 +66,7 @@ CLOBBER_S = list(range(40, 72))
 VTS = [122, 123, 124, 125, 126]           # lane temporaries, one per row-buffer piece
 VT = 127
 V_CLOBBER0 = 122
+PHASES = os.environ.get("KDCC_GEN_WGRAD_PHASES", "")    # experiment: "r0,r1,g0,g1;r0,r1,g0,g1" = gap ranges of the reads / the other groups in k-step 0 ; 1
 ABL = int(os.environ.get("KDCC_GEN_WGRAD_ABL", "0"))   # TIMING ablations (tools/wgrad_lw_ablate.sh; results wrong): 1 no LDS-DMA, 2 no fragment reads, 4 no MFMAs, 8 no zero fill, 16 no address steps
 SLACK_DS = SLACK_VM = 0                   # mutation hooks of tools/check_wgrad_lw.py's self-test: every counted wait that many operations too lax
 
@@ -282,11 +283,12 @@ def loop_body(ds_at_top, r):
     e = g.emit
     # ---- k-step 0: set 0; reads of (st, 1) into set 1; second half of stage st + 3
     slots = [[] for _ in range(49)]
-    reads(g, 1, 1, slots, 0, 38, r)
+    ph = [[int(x) for x in q.split(",")] for q in PHASES.split(";")] if PHASES else [[0, 38, 1, 46], [6, 46, 0, 47]]
+    reads(g, 1, 1, slots, ph[0][0], ph[0][1], r)
     grp = []
     for k in range(1, 5):
         grp += x_piece(k, (r + 3) & 3, S_XB2, S_LO2, S_SPAN2)
-    deal(slots, grp, 1, 46)
+    deal(slots, grp, ph[0][2], ph[0][3])
     run_kstep(g, 0, slots)
     e(f"s_waitcnt vmcnt({18 + SLACK_VM}) lgkmcnt(0)")        # stage st + 1 has landed: only the 18 operations of stages st + 2 and st + 3 are younger
     g.ds, g.vm = [], []
@@ -294,12 +296,12 @@ def loop_body(ds_at_top, r):
     # ---- k-step 1: set 1; reads of (st + 1, 0) into set 0; first half of stage st + 4 into the slot of stage st; the staging iterator:
     # this stage's second half keeps (source, masks), then the iterator moves on to stage st + 5
     slots = [[] for _ in range(49)]
-    reads(g, 0, 0, slots, 6, 46, (r + 1) & 3)
+    reads(g, 0, 0, slots, ph[1][0], ph[1][1], (r + 1) & 3)
     grp = []
     for k in range(4):
         grp += dy_piece(k, r)
     grp += x_piece(0, r, S_XB, S_LO, S_SPAN) + [keep_second_half()] + advance_iterator()
-    deal(slots, grp, 0, 47)
+    deal(slots, grp, ph[1][2], ph[1][3])
     run_kstep(g, 1, slots)
     return g.L, list(g.ds)
 
