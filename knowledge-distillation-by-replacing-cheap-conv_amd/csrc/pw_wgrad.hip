@@ -10,6 +10,7 @@
 
 #include "igemm_core.h"
 #include "wgrad_lw_body.inc"
+#include "wgrad_pw_lw_body.inc"
 
 namespace {
 
@@ -453,6 +454,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide_kernel(const WgradPara
             }
 }
 
+// ---- the wide tile of the 1x1 / stride-1 layers on ONE wave per SIMD (round 6; stage loop generated by tools/gen_wgrad_pw_lw.py) ----
+// conv_wgrad_wide_kernel<true> keeps one 64-KiB stage in flight and runs its fragment reads and MFMAs as bulk phases of 8 waves
+// (MFMA busy 0.50).  Here 4 waves of 128 Cout x 128 Cin (64 accumulator tiles = a[0:255], two fragment sets in v[128:255]) walk the
+// same pixels 32 at a time: four 32-KiB stages in a ring (three in flight), per stage 64 MFMAs with the wave's 8 LDS-DMA pieces of
+// stage st + 3 dealt into the first 32 gaps, one barrier, and the 32 transposing reads of stage st + 1 dealt into the last 32.
+// Same tiles, splits and K order: bit-identical slabs.  Cin % 256 == 0, Cout % 256 == 0, M % 64 == 0.
+__global__ __launch_bounds__(256, 1) void conv_wgrad_pw_lw_kernel(const WgradParams p);
+
 // ---- row-buffer tile for 3x3 / stride 1 / 'same' convs: 128 (Cout) x [3 taps kx] x 128 (Cin) per workgroup -------------------------
 // Per tap the kernels above stage dy and the (shifted) activations again: nine passes over both tensors.  Here a K stage is 64
 // consecutive pixels of ONE image row (W % 64 == 0): dy is staged once and serves the three kx taps of a kernel row, and the
@@ -850,6 +859,72 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_lw_kernel(const WgradParams
 #undef WGLW_ACC_RW
 }
 
+__global__ __launch_bounds__(256, 1) void conv_wgrad_pw_lw_kernel(const WgradParams p)
+{
+    __shared__ __attribute__((aligned(1024))) char lds[4 * 32768];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const int tile = blockIdx.x, split = blockIdx.y;
+    const int t_ci = tile % p.tiles_ci, t_co = tile / p.tiles_ci;
+    const int co0 = t_co * 256, ci0 = t_ci * 256;
+    const int m_begin = split * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+    const int nst = max(0, (m_end - m_begin) / 32);
+    const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
+    const int q = lane >> 4, li = lane & 15;
+
+    // fragment addresses in ring slot 0 (and, second copy, slot 2): image wm holds this wave's 128 output channels, image 2 + wn its input channels
+    uint32_t va[8], vb[8], wa[8], wb[8];
+    {
+        const int m0 = 8 * q + (li >> 2), f = tr_f(m0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const uint32_t o = (uint32_t)(m0 * 256 + ((t ^ f) << 5) + (li & 3) * 8);
+            va[t] = lbase + wm * 8192 + o; vb[t] = lbase + (2 + wn) * 8192 + o;
+            wa[t] = va[t] + 65536; wb[t] = vb[t] + 65536;
+        }
+    }
+    // LDS-DMA sources: wave w stages pieces 2 w + j (rows (2 w + j) * 4 ..) of every image; byte offsets from the stage's first pixel
+    const int prow = lane >> 4, slot = lane & 15;
+    uint32_t voy[4], vox[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (wv * 2 + j) * 4 + prow, c = (slot ^ (tr_f(r) << 1)) * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            voy[j * 2 + h] = (uint32_t)(r * p.ldy + co0 + h * 128 + c) * 2u;
+            vox[j * 2 + h] = (uint32_t)(r * p.lda + ci0 + h * 128 + c) * 2u;
+        }
+    }
+    const bf16_t *syb = (const bf16_t *)p.dy + (size_t)m_begin * p.ldy, *sxb = (const bf16_t *)p.a + (size_t)m_begin * p.lda;
+    const uint32_t sdy = 32u * p.ldy * 2u, sdx = 32u * p.lda * 2u, sldsw = lbase + wv * 2048;
+
+    typedef __attribute__((ext_vector_type(32))) float f32x32_t;
+    f32x32_t A0, A1, A2, A3, A4, A5, A6, A7;
+    asm volatile(WGRAD_LW_ZERO_ASM : "=a"(A0), "=a"(A1), "=a"(A2), "=a"(A3), "=a"(A4), "=a"(A5), "=a"(A6), "=a"(A7));
+#define WGPW_ACC_RW "+a"(A0), "+a"(A1), "+a"(A2), "+a"(A3), "+a"(A4), "+a"(A5), "+a"(A6), "+a"(A7)
+#define WGPW_ADDR(P, A, B)                                                                                                            \
+    [P##a0] "v"(A[0]), [P##a1] "v"(A[1]), [P##a2] "v"(A[2]), [P##a3] "v"(A[3]), [P##a4] "v"(A[4]), [P##a5] "v"(A[5]), [P##a6] "v"(A[6]), \
+    [P##a7] "v"(A[7]), [P##b0] "v"(B[0]), [P##b1] "v"(B[1]), [P##b2] "v"(B[2]), [P##b3] "v"(B[3]), [P##b4] "v"(B[4]), [P##b5] "v"(B[5]), \
+    [P##b6] "v"(B[6]), [P##b7] "v"(B[7])
+    asm volatile(WGRAD_PW_LW_LOOP_ASM
+                 : WGPW_ACC_RW
+                 : WGPW_ADDR(v, va, vb), WGPW_ADDR(w, wa, wb),
+                   [voy0] "v"(voy[0]), [voy1] "v"(voy[1]), [voy2] "v"(voy[2]), [voy3] "v"(voy[3]),
+                   [vox0] "v"(vox[0]), [vox1] "v"(vox[1]), [vox2] "v"(vox[2]), [vox3] "v"(vox[3]),
+                   [syb] "s"(syb), [sxb] "s"(sxb), [snst] "s"((uint32_t)nst), [sdy] "s"(sdy), [sdx] "s"(sdx), [sldsw] "s"(sldsw)
+                 : "memory", "scc", WGRAD_PW_LW_CLOBBER_S, WGRAD_PW_LW_CLOBBER_V);
+#undef WGPW_ADDR
+    float *out = p.part + (size_t)split * p.Cout * p.Cin + (size_t)co0 * p.Cin + ci0;
+    const uint32_t vob = (uint32_t)((wm * 128 + q * 4) * p.Cin + wn * 128 + li) * 4u, cin4 = (uint32_t)p.Cin * 4u;
+    asm volatile(WGRAD_PW_LW_STORE_ASM
+                 : WGPW_ACC_RW
+                 : [vob] "v"(vob), [vcin4] "s"(cin4), [sout] "s"(out)
+                 : "memory", "v127");
+#undef WGPW_ACC_RW
+}
+
 // plan of the row-buffer kernel: ~2.5 one-per-CU workgroups per CU, >= 8 stages per split
 int fill_splits(int per, int max_splits);   // below, next to wide_plan
 void row_plan(long long M, int Cin, int Cout, int &tiles, int &tiles_ci, int &splits, int &rps)
@@ -965,6 +1040,15 @@ int fill_splits(int per, int max_splits)
     return splits;
 }
 
+// conv_wgrad_pw_lw_kernel instead of conv_wgrad_wide_kernel<true>: whole 256 x 256 tiles, whole 32-pixel stages, and splits long enough
+// for its longer fill (accumulator file zeroed, three stages ahead) and drain (256 dword stores per lane) to pay: measured at 8 images
+// (tools/wgrad_lw_check.py) 2048->4096 (4096 stages per split) x 1.27, 1024->2048 / 2048->1024 (1024) x 1.22 / x 1.40, but 4096->256 (512:
+// one Cout tile, bound by the activations' HBM stream) x 0.92, 512->1024 (256) x 0.90, 1280->256 (160) x 1.06, 512->512 (128) x 1.01.
+bool pw_lw_pays(long long M, int Cin, int Cout, int rps, int mode)   // mode: KDCC_WGRAD_PW_LW (0 never, 1 where it pays, 2 wherever it can run)
+{
+    return mode && Cin % 256 == 0 && Cout % 256 == 0 && M % 64 == 0 && rps % 32 == 0 && (mode == 2 || rps / 32 >= 768);
+}
+
 void wide_plan(long long M, int Cin, int Cout, int taps, int &tiles, int &tiles_ci, int &splits, int &rps)
 {
     tiles_ci = (Cin + 255) / 256;
@@ -1021,7 +1105,13 @@ extern "C" int kd_pw_wgrad(int32_t dtype, int32_t M, int32_t Cin, int32_t Cout, 
     p.mg_howo = p.sh_howo = p.mg_wo = p.sh_wo = 0;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)tiles, (unsigned)splits);
-    if (wide) { KD_NOTE_KERNEL("conv_wgrad_wide_kernel"); hipLaunchKernelGGL(conv_wgrad_wide_kernel<true>, grid, dim3(512), 0, s, p); }
+    static int pwlw = -1;
+    if (pwlw < 0) { const char *e = getenv("KDCC_WGRAD_PW_LW"); pwlw = e ? atoi(e) : 1; }   // A/B: 0 = conv_wgrad_wide_kernel (8 waves) everywhere, 2 = the lone-wave kernel wherever it can run; bit-identical
+    if (wide && !p.dbg && pw_lw_pays(M, Cin, Cout, rps, pwlw)) {
+        KD_NOTE_KERNEL("conv_wgrad_pw_lw_kernel");
+        hipLaunchKernelGGL(conv_wgrad_pw_lw_kernel, grid, dim3(256), 0, s, p);
+    }
+    else if (wide) { KD_NOTE_KERNEL("conv_wgrad_wide_kernel"); hipLaunchKernelGGL(conv_wgrad_wide_kernel<true>, grid, dim3(512), 0, s, p); }
     else if (dtype == KD_BF16 && Cin % 8 == 0 && Cout % 8 == 0) launch_tr(grid, s, p);
     else if (dtype == KD_BF16) { KD_NOTE_KERNEL("pw_wgrad_kernel<bf16>"); hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, p); }
     else { KD_NOTE_KERNEL("pw_wgrad_kernel<f32>"); hipLaunchKernelGGL(pw_wgrad_kernel<float>, grid, dim3(256), 0, s, p); }
@@ -1143,9 +1233,16 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
         hipLaunchKernelGGL((conv_wgrad_row_kernel<false, 1>), dim3((unsigned)(tiles * splits * 3)), dim3(512), 0, s, p);
         }
     } else if (wide) {
+        static int pwlw = -1;
+        if (pwlw < 0) { const char *e = getenv("KDCC_WGRAD_PW_LW"); pwlw = e ? atoi(e) : 1; }   // A/B: 0 = conv_wgrad_wide_kernel (8 waves) everywhere, 2 = the lone-wave kernel wherever it can run; bit-identical
+        if (!p.dbg && !p.geom && !wide_general && taps == 1 && pw_lw_pays(M, d->Cin, d->Cout, rps, pwlw)) {
+            KD_NOTE_KERNEL("conv_wgrad_pw_lw_kernel");
+            hipLaunchKernelGGL(conv_wgrad_pw_lw_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, s, p);
+        } else {
         KD_NOTE_KERNEL("conv_wgrad_wide_kernel");
         if (!p.geom && !wide_general) hipLaunchKernelGGL(conv_wgrad_wide_kernel<true>, grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL(conv_wgrad_wide_kernel<false>, grid, dim3(512), 0, s, p);
+        }
     }
     else if (d->dtype == KD_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0) launch_tr(grid, s, p);
     else if (d->dtype == KD_BF16) { KD_NOTE_KERNEL("pw_wgrad_kernel<bf16>"); hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, p); }

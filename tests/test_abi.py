@@ -172,6 +172,18 @@ def test_weight_gradient_lone_wave_loop_is_generated_interpreted_and_audited():
         assert any("ds_read_b64_tr_b16" in f and "in flight" in f for f in C.interpret(G.build()))
     finally:
         G.SLACK_DS = G.SLACK_VM = 0
+    # the 1x1 form (conv_wgrad_pw_lw_kernel, tools/gen_wgrad_pw_lw.py): same checks, same mutations
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_wgrad_pw_lw.py"), "--check"])
+    assert r.returncode == 0, "csrc/wgrad_pw_lw_body.inc is stale: run python tools/gen_wgrad_pw_lw.py"
+    import gen_wgrad_pw_lw as GP
+    assert C.interpret_pw(GP.build()) == []
+    try:
+        GP.SLACK_VM = 1
+        assert any("in flight at the barrier" in f for f in C.interpret_pw(GP.build()))
+        GP.SLACK_VM, GP.SLACK_DS = 0, 1
+        assert any("ds_read_b64_tr_b16" in f and "in flight" in f for f in C.interpret_pw(GP.build()))
+    finally:
+        GP.SLACK_DS = GP.SLACK_VM = 0
     if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
         pytest.skip("no hipcc")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_wgrad_lw.py")], capture_output=True, text=True)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Checks of the lone-wave dense weight-gradient kernel (conv_wgrad_lw_kernel, csrc/pw_wgrad.hip + the generated csrc/wgrad_lw_body.inc).
+"""Checks of the lone-wave dense weight-gradient kernels (conv_wgrad_lw_kernel, csrc/pw_wgrad.hip + the generated csrc/wgrad_lw_body.inc; and, with
+interpret_pw below, conv_wgrad_pw_lw_kernel + csrc/wgrad_pw_lw_body.inc).
 
 1. Schedule interpreter (no hipcc needed).  The generated stream is walked prologue -> the four unrolled stage bodies, twice -> drain as the hardware retires
    it, once with the zero fill of every row-buffer piece issued and once with all of them skipped: LDS operations and vector-memory operations are two IN-ORDER queues, `s_waitcnt lgkmcnt(n) / vmcnt(n)` retires all but the n
@@ -147,11 +148,85 @@ def interpret_path(lines, passes):
     return findings
 
 
-def audit_isa(text):
+def interpret_pw(lines, passes=2):
+    """the same walk for conv_wgrad_pw_lw_kernel's loop (tools/gen_wgrad_pw_lw.py): 32-pixel stages of 32 KiB, the prologue stages 0-2, body `it`
+    the 8 pieces of stage it + 3 in its first half, ONE barrier in its middle (no piece of a stage <= it + 1 and no LDS operation in
+    flight), behind it the 32 reads of stage it + 1 -- every one of them in ring slot (it + 1) mod 4 --, 64 MFMAs per body"""
     findings = []
-    m = re.search(r"^(_ZN\S*conv_wgrad_lw_kernel\S*):\s*;[^\n]*\n(.*?)\.Lfunc_end", text, flags=re.M | re.S)
+    top = lines.index("WGP_LOOP_%=:")
+    back = max(i for i, l in enumerate(lines) if l.startswith("s_cbranch_scc1 WGP_LOOP"))
+    seq = [(l, -1) for l in lines[:top]]
+    it = 0
+    for p in range(passes):
+        for l in lines[top + 1:back + 1]:
+            seq.append((l, it))
+            if l.startswith("s_cbranch_scc0 WGP_DONE") or l.startswith("s_cbranch_scc1 WGP_LOOP"):
+                it += 1
+    bodies = it
+    seq += [(l, bodies) for l in lines[back + 1:]]
+    ds, vm, n_piece, m0, stats, barrier_seen = [], [], 0, None, {}, {}
+    for ins, it in seq:
+        op = ins.split(" ")[0]
+        st = stats.setdefault(it, {"mfma": 0, "barrier": 0})
+        if op == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", ins)
+            if m:
+                k = int(m.group(1))
+                ds = ds[len(ds) - k:] if k else []
+            m = re.search(r"vmcnt\((\d+)\)", ins)
+            if m:
+                k = int(m.group(1))
+                vm = vm[len(vm) - k:] if k else []
+        elif op == "s_add_u32" and ins.startswith("s_add_u32 m0, %[sldsw], "):
+            m0 = int(ins.rsplit(" ", 1)[1])
+        elif op == "s_barrier":
+            st["barrier"] += 1
+            barrier_seen[it] = True
+            if ds:
+                findings.append(f"body {it}: s_barrier with LDS operations in flight: {ds[-1][1]}")
+            limit = 0 if it < 0 else it + 1
+            late = [x for x in vm if x <= limit]
+            if late:
+                findings.append(f"body {it}: {len(late)} LDS-DMA piece(s) of stage {min(late)} in flight at the barrier behind which stage {limit} is read")
+        elif op.startswith("v_mfma"):
+            st["mfma"] += 1
+            pend = {r: t for d, t in ds for r in d}
+            for r in vregs(ins):
+                if r in pend:
+                    findings.append(f"body {it}: `{ins}` reads v{r} while `{pend[r]}` is in flight")
+        elif op.startswith("ds_read"):
+            dst = vregs(ins.split(",")[0])
+            pend = {r: t for d, t in ds for r in d}
+            for r in dst:
+                if r in pend:
+                    findings.append(f"body {it}: `{ins}` overwrites v{r} while `{pend[r]}` is in flight")
+            ds.append((dst, ins))
+            off = int(re.search(r"offset:(\d+)", ins).group(1))
+            ring = off // 32768 + (2 if re.search(r"%\[w[ab]", ins) else 0)
+            if it < bodies and ring != (it + 1) % 4:
+                findings.append(f"body {it}: a read of stage {it + 1} addresses ring slot {ring}: {ins}")
+            if it < bodies and not barrier_seen.get(it):
+                findings.append(f"body {it}: a read of stage {it + 1} in front of the barrier that publishes it: {ins}")
+        elif op.startswith("global_load_lds"):
+            s_ = n_piece // 8 if n_piece < 24 else (n_piece - 24) // 8 + 3
+            n_piece += 1
+            vm.append(s_)
+            if m0 is None or m0 // 32768 != s_ % 4:
+                findings.append(f"body {it}: a piece of stage {s_} goes to M0 = {m0}: {ins}")
+            m0 = None
+    for it, st in stats.items():
+        if 0 <= it < bodies and (st["mfma"] != 64 or st["barrier"] != 1):
+            findings.append(f"body {it}: {st['mfma']} MFMAs / {st['barrier']} barriers (64 / 1 expected)")
+    if ds or vm:
+        findings.append(f"operations still in flight at the end: {len(ds)} LDS, {len(vm)} vector memory")
+    return findings
+
+
+def audit_isa(text, kernel="conv_wgrad_lw_kernel", n_mfma=384):
+    findings = []
+    m = re.search(r"^(_ZN\S*" + kernel + r"\S*):\s*;[^\n]*\n(.*?)\.Lfunc_end", text, flags=re.M | re.S)
     if not m:
-        return ["conv_wgrad_lw_kernel not found in the assembly"]
+        return [kernel + " not found in the assembly"]
     name, code = m.group(1), m.group(2)
     in_asm, per_stmt, cur = False, [], 0
     for l in code.split("\n"):
@@ -174,21 +249,22 @@ def audit_isa(text):
                 findings.append(f"{name}: compiler instruction touches an accumulation register: {s}")
             if "scratch_" in s:
                 findings.append(f"{name}: scratch access: {s}")
-    if sorted(per_stmt) != [0, 0, 384]:
-        findings.append(f"{name}: expected three inline-asm statements (zero, the four unrolled stage bodies with 384 MFMAs, store), found MFMA counts {per_stmt}")
+    if sorted(per_stmt) != [0, 0, n_mfma]:
+        findings.append(f"{name}: expected three inline-asm statements (zero, the four unrolled stage bodies with {n_mfma} MFMAs, store), found MFMA counts {per_stmt}")
     return findings
 
 
 def main():
     import gen_wgrad_lw as G
-    findings = interpret(G.build())
+    import gen_wgrad_pw_lw as GP
+    findings = interpret(G.build()) + [f"(1x1 loop) {f}" for f in interpret_pw(GP.build())]
     n_isa = 0
     if "--no-isa" not in sys.argv and os.path.exists(HIPCC):
         with tempfile.TemporaryDirectory() as td:
             out = os.path.join(td, "pw_wgrad.s")
             subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-result", "-Wno-unused-value", "-S",
                                    "--cuda-device-only", os.path.join(CSRC, "pw_wgrad.hip"), "-o", out], stderr=subprocess.DEVNULL)
-            findings += audit_isa(open(out).read())
+            findings += audit_isa(open(out).read()) + audit_isa(open(out).read(), "conv_wgrad_pw_lw_kernel", 256)
             n_isa = 1
     for f in findings[:40]:
         print(f)

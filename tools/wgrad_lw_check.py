@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """conv_wgrad_lw_kernel (one wave per SIMD, generated stage loop: tools/gen_wgrad_lw.py) against conv_wgrad_row_kernel (8 waves), the
 kernel it replaces on the 3x3 layers with Cout % 128 == 0: the same launches in two FRESH child processes
-(KDCC_WGRAD_LW=1 / 0: the switch is read once per process), the fp32 weight gradients compared BIT FOR BIT (same decomposition, same
+(KDCC_WGRAD_LW = KDCC_WGRAD_PW_LW = 1 / 0: the switches are read once per process; the 1x1 cases compare conv_wgrad_pw_lw_kernel with
+conv_wgrad_wide_kernel<true>), the fp32 weight gradients compared BIT FOR BIT (same decomposition, same
 LDS images, same k order into the same fp32 chains: any difference is a defect), and the time of each.
 usage: python tools/wgrad_lw_check.py [--batch N] [--iters K] [--only substr,substr]"""
 import argparse
@@ -42,6 +43,18 @@ CASES = [
     ("edge ragged 72 d4", 2, 8, 64, 72, 128, 4),
     ("edge ragged 200 d2", 1, 5, 128, 200, 128, 2),
     ("edge ragged 8 d8", 1, 4, 64, 8, 128, 8),
+    # 1x1 / stride 1 (dil 0 marks them): conv_wgrad_pw_lw_kernel against conv_wgrad_wide_kernel<true> (KDCC_WGRAD_PW_LW)
+    ("pw 2048->4096", None, 128, 256, 2048, 4096, 0),
+    ("pw 1024->2048", None, 128, 256, 1024, 2048, 0),
+    ("pw 2048->1024", None, 128, 256, 2048, 1024, 0),
+    ("pw 4096->256", None, 128, 256, 4096, 256, 0),
+    ("pw 512->1024", None, 128, 256, 512, 1024, 0),
+    ("pw 1280->256", None, 128, 256, 1280, 256, 0),
+    ("pw 512->512", None, 128, 256, 512, 512, 0),
+    ("pw edge 2 stages", 1, 1, 64, 256, 256, 0),          # fewer stages than the prologue stages
+    ("pw edge 8 stages", 1, 4, 64, 512, 256, 0),
+    ("pw edge 30 stages", 3, 5, 64, 256, 512, 0),
+    ("pw edge 1 img 128x128", 1, 128, 128, 256, 256, 0),
 ]
 
 
@@ -57,8 +70,10 @@ def child(a):
         g = torch.Generator(device="cuda").manual_seed(zlib.crc32(name.encode()) & 0xffff)
         x = torch.randn((N, H, W, Cin + 16), device="cuda", generator=g).relu().bfloat16()[..., :Cin]      # (a pixel stride that is not the channel count)
         dy = (torch.randn((N, H, W, Cout), device="cuda", generator=g) * 0.1).bfloat16()
-        dw = torch.full((Cout, Cin, 3, 3), 7.0, device="cuda")
-        ops.conv2d_wgrad(x, dy, dw, 1, d, d)
+        k = 3 if d else 1
+        dw = torch.full((Cout, Cin, k, k), 7.0, device="cuda")
+        run = (lambda: ops.conv2d_wgrad(x, dy, dw, 1, d, max(d, 1))) if name.find("pwapi") < 0 else (lambda: ops.pw_wgrad(x, dy, dw))
+        run()
         kern = _lib.last_kernel()
         kern = kern if isinstance(kern, str) else ",".join(kern)
         torch.cuda.synchronize()
@@ -66,19 +81,19 @@ def child(a):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(a.iters):
-            ops.conv2d_wgrad(x, dy, dw, 1, d, d)
+            run()
         e1.record()
         torch.cuda.synchronize()
         again = hashlib.sha256(dw.cpu().numpy().tobytes()).hexdigest()
         res[name] = {"kernel": kern, "digest": first, "stable": first == again, "finite": bool(torch.isfinite(dw).all()),
                      "absmax": float(dw.abs().max()), "ms": e0.elapsed_time(e1) / a.iters,
-                     "tflops": 2.0 * N * H * W * Cin * Cout * 9 / (e0.elapsed_time(e1) / a.iters) / 1e9}
+                     "tflops": 2.0 * N * H * W * Cin * Cout * k * k / (e0.elapsed_time(e1) / a.iters) / 1e9}
         print(f"{name}: {kern} {res[name]['ms']:.3f} ms {res[name]['tflops']:.0f} TFLOP/s", file=sys.stderr, flush=True)
     print("RESULT " + json.dumps(res), flush=True)
 
 
 def arm(lw, a, **extra):
-    env = dict(os.environ, KDCC_WGRAD_LW=lw)
+    env = dict(os.environ, KDCC_WGRAD_LW=lw, KDCC_WGRAD_PW_LW="2" if lw == "1" else "0")      # (2: the 1x1 kernel wherever it can run, also where the library would not choose it)
     env.update(extra)
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--batch", str(a.batch), "--iters", str(a.iters), "--only", a.only],
                        env=env, capture_output=True, text=True, timeout=900)
