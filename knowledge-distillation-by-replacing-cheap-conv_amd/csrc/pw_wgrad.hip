@@ -865,7 +865,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_pw_lw_kernel(const WgradPar
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1;
-    const int tile = blockIdx.x, split = blockIdx.y;
+    // 1-D grid, XCD-aware: the tiles of one split are neighbours on ONE XCD (they stream the same dy rows / the same activation rows at
+    // the same time); dealt round-robin, the 16 Cin tiles of the 4096 -> 256 layer fetched their split's dy into eight L2s
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = lin % p.tiles, split = lin / p.tiles;
     const int t_ci = tile % p.tiles_ci, t_co = tile / p.tiles_ci;
     const int co0 = t_co * 256, ci0 = t_ci * 256;
     const int m_begin = split * p.rows_per_split;
@@ -1040,13 +1043,14 @@ int fill_splits(int per, int max_splits)
     return splits;
 }
 
-// conv_wgrad_pw_lw_kernel instead of conv_wgrad_wide_kernel<true>: whole 256 x 256 tiles, whole 32-pixel stages, and splits long enough
-// for its longer fill (accumulator file zeroed, three stages ahead) and drain (256 dword stores per lane) to pay: measured at 8 images
-// (tools/wgrad_lw_check.py) 2048->4096 (4096 stages per split) x 1.27, 1024->2048 / 2048->1024 (1024) x 1.22 / x 1.40, but 4096->256 (512:
-// one Cout tile, bound by the activations' HBM stream) x 0.92, 512->1024 (256) x 0.90, 1280->256 (160) x 1.06, 512->512 (128) x 1.01.
-bool pw_lw_pays(long long M, int Cin, int Cout, int rps, int mode)   // mode: KDCC_WGRAD_PW_LW (0 never, 1 where it pays, 2 wherever it can run)
+// conv_wgrad_pw_lw_kernel instead of conv_wgrad_wide_kernel<true>: whole 256 x 256 tiles and whole 32-pixel stages.  Measured at 8 images
+// (tools/wgrad_lw_check.py, ms incl. the reduce): 2048->4096 4.49 -> 3.28, 1024->2048 1.19 -> 0.80, 2048->1024 1.17 -> 0.78, 4096->256 0.85 -> 0.66,
+// 512->1024 0.34 -> 0.22, 1280->256 0.24 -> 0.18, 512->512 0.20 -> 0.15.  (With the workgroups dealt round-robin over the XCDs, as the 8-wave
+// kernel's 2-D grid is, the short splits were SLOWER than the 8-wave kernel, x 0.90-0.92: the tiles of a split fetched their shared rows into
+// eight L2s.)  mode: KDCC_WGRAD_PW_LW, 0 = never.
+bool pw_lw_pays(long long M, int Cin, int Cout, int rps, int mode)
 {
-    return mode && Cin % 256 == 0 && Cout % 256 == 0 && M % 64 == 0 && rps % 32 == 0 && (mode == 2 || rps / 32 >= 768);
+    return mode && Cin % 256 == 0 && Cout % 256 == 0 && M % 64 == 0 && rps % 32 == 0;
 }
 
 void wide_plan(long long M, int Cin, int Cout, int taps, int &tiles, int &tiles_ci, int &splits, int &rps)
@@ -1106,10 +1110,10 @@ extern "C" int kd_pw_wgrad(int32_t dtype, int32_t M, int32_t Cin, int32_t Cout, 
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)tiles, (unsigned)splits);
     static int pwlw = -1;
-    if (pwlw < 0) { const char *e = getenv("KDCC_WGRAD_PW_LW"); pwlw = e ? atoi(e) : 1; }   // A/B: 0 = conv_wgrad_wide_kernel (8 waves) everywhere, 2 = the lone-wave kernel wherever it can run; bit-identical
+    if (pwlw < 0) { const char *e = getenv("KDCC_WGRAD_PW_LW"); pwlw = e ? atoi(e) : 1; }   // A/B: 0 = conv_wgrad_wide_kernel (8 waves); bit-identical
     if (wide && !p.dbg && pw_lw_pays(M, Cin, Cout, rps, pwlw)) {
         KD_NOTE_KERNEL("conv_wgrad_pw_lw_kernel");
-        hipLaunchKernelGGL(conv_wgrad_pw_lw_kernel, grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL(conv_wgrad_pw_lw_kernel, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, p);
     }
     else if (wide) { KD_NOTE_KERNEL("conv_wgrad_wide_kernel"); hipLaunchKernelGGL(conv_wgrad_wide_kernel<true>, grid, dim3(512), 0, s, p); }
     else if (dtype == KD_BF16 && Cin % 8 == 0 && Cout % 8 == 0) launch_tr(grid, s, p);
@@ -1234,10 +1238,10 @@ extern "C" int kd_conv2d_wgrad(const kd_conv_desc *d, const void *x, const void 
         }
     } else if (wide) {
         static int pwlw = -1;
-        if (pwlw < 0) { const char *e = getenv("KDCC_WGRAD_PW_LW"); pwlw = e ? atoi(e) : 1; }   // A/B: 0 = conv_wgrad_wide_kernel (8 waves) everywhere, 2 = the lone-wave kernel wherever it can run; bit-identical
+        if (pwlw < 0) { const char *e = getenv("KDCC_WGRAD_PW_LW"); pwlw = e ? atoi(e) : 1; }   // A/B: 0 = conv_wgrad_wide_kernel (8 waves); bit-identical
         if (!p.dbg && !p.geom && !wide_general && taps == 1 && pw_lw_pays(M, d->Cin, d->Cout, rps, pwlw)) {
             KD_NOTE_KERNEL("conv_wgrad_pw_lw_kernel");
-            hipLaunchKernelGGL(conv_wgrad_pw_lw_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, s, p);
+            hipLaunchKernelGGL(conv_wgrad_pw_lw_kernel, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, p);
         } else {
         KD_NOTE_KERNEL("conv_wgrad_wide_kernel");
         if (!p.geom && !wide_general) hipLaunchKernelGGL(conv_wgrad_wide_kernel<true>, grid, dim3(512), 0, s, p);

@@ -95,7 +95,7 @@ def _step(model, backprop="hint"):
 
 SHIPPED_MODE_A = ["conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>", "conv_row_tall_kernel",
                   "dw_mfma_fwd_kernel<1,false>", "dw_lw_fan3_kernel", "dw_mfma_fwd_kernel<3,false>", "out_sums_epilogue",
-                  "dw_mfma_wgrad_kernel", "dw_mfma_wgrad_multi_kernel<3>", "stem_pool_kernel", "conv_wgrad_wide_kernel"]   # (the pointwise weight gradients take the 256x256 wgrad tile)
+                  "dw_mfma_wgrad_kernel", "dw_mfma_wgrad_multi_kernel<3>", "stem_pool_kernel", "conv_wgrad_pw_lw_kernel"]   # (the pointwise weight gradients take the 256x256 wgrad tile, one wave per SIMD)
 
 
 def test_bf16_p92_step_on_the_shipped_kernels_vs_network_oracle():
@@ -231,7 +231,7 @@ def test_bf16_mode_b_step_on_the_shipped_kernels_vs_network_oracle():
     model._x = x.cuda()
     with _lib.kernel_log() as log:
         out_st, out_tc, hint, kd, loss = _step(model, "kd+hint")
-    for k in ("conv_wgrad_lw_kernel", "conv_wgrad_wide_kernel", "conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>",
+    for k in ("conv_wgrad_lw_kernel", "conv_wgrad_pw_lw_kernel", "conv_wgrad_wide_kernel", "conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>",
               "dw_mfma_wgrad_kernel", "dw_mfma_fwd_kernel<3,false>", "bn_sums_epilogue"):
         assert log.counts.get(k, 0) > 0, (k, log.counts)
     # the eval-BN parameter sums ride in the input-gradient epilogues: only the sites those kernels do not cover still read the
@@ -383,7 +383,7 @@ def test_fullsize_bench_step_determinism_batch_independence_and_prefix_sharing()
 
 
 @pytest.mark.parametrize("name,kw,must", [
-    ("modeB", dict(mode="B"), ("conv_wgrad_lw_kernel", "conv_wgrad_wide_kernel", "conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>",
+    ("modeB", dict(mode="B"), ("conv_wgrad_lw_kernel", "conv_wgrad_pw_lw_kernel", "conv_wgrad_wide_kernel", "conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>",
                               "conv_row_tall_kernel", "dw_mfma_wgrad_multi_kernel<3>", "bn_sums_epilogue", "stem_wgrad_mfma_kernel")),
     ("gscnn_P86", dict(arch="gscnn", plan="P86"), ("conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>", "conv_row_tall_kernel",
                                                    "conv3x3_small_kernel<64>", "gated_conv_mfma_kernel", "dw_lw_fan3_kernel")),

@@ -482,13 +482,16 @@ def test_conv_dgrad_with_bn_relu_mask(K, dt, k, p, d):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("shape", [(2, 8, 16, 64, 128), (1, 13, 9, 128, 64), (1, 40, 64, 256, 64)])
+@pytest.mark.parametrize("shape", [(2, 8, 16, 64, 128), (1, 13, 9, 128, 64), (1, 40, 64, 256, 64),
+                                   (1, 12, 64, 512, 256), (1, 3, 64, 256, 256)])    # (whole 256 x 256 tiles: conv_wgrad_pw_lw_kernel in bf16)
 def test_pw_wgrad(K, dt, shape):
     N, H, W, Cin, Cout = shape
     a, gy = q(rnd(N, Cin, H, W), dt), q(rnd(N, Cout, H, W), dt)
     ref = orc.conv2d_wgrad(a, gy, (Cout, Cin, 1, 1))
     dw = torch.full((Cout, Cin, 1, 1), 7.0, device="cuda")
     K.pw_wgrad(dev_nhwc(a, dt), dev_nhwc(gy, dt), dw)
+    if dt == "bf16" and Cin % 256 == 0 and Cout % 256 == 0:
+        selected("conv_wgrad_pw_lw_kernel", f"pw_wgrad {shape}")
     assert_close(dw.cpu().numpy(), ref, dt, "pw_wgrad")
     K.pw_wgrad(dev_nhwc(a, dt), dev_nhwc(gy, dt), dw, accumulate=True)
     assert_close(dw.cpu().numpy(), 2 * ref, dt, "pw_wgrad accumulate")
@@ -1117,6 +1120,10 @@ WGRAD_CASES = [
     (1, 33, 40, 256, 256, 3, 1, 2, 2),
     (2, 21, 31, 512, 256, 1, 1, 0, 1),
     (1, 24, 40, 256, 512, 3, 2, 1, 1),
+    # 1x1 / stride 1, whole 256 x 256 tiles, pixels % 64 == 0: conv_wgrad_pw_lw_kernel (one wave per SIMD, 32-pixel stages)
+    (1, 8, 64, 256, 512, 1, 1, 0, 1),     # 16 stages in one split... or several: ring fill, steady state, drain
+    (2, 16, 32, 512, 256, 1, 1, 0, 1),    # two Cin tiles
+    (1, 2, 32, 256, 256, 1, 1, 0, 1),     # two stages: fewer than the prologue stages
     # W % 64 == 0, 3x3 / stride 1 / 'same': the row-buffer kernel (bf16; one dy stage per kernel row, taps at row offsets)
     (2, 9, 64, 64, 128, 3, 1, 1, 1),      # 18 stages: ring fill, steady state and drain; border rows
     (1, 20, 128, 128, 128, 3, 1, 2, 2),   # dilation 2, two stages per image row
@@ -1151,7 +1158,9 @@ def test_conv_wgrad(K, dt, case):
         # the row-buffer cases: one wave per SIMD where Cout is a multiple of 128 (dil <= 8), else the 8-wave kernel
         selected("conv_wgrad_lw_kernel" if Cout % 128 == 0 and d <= 8 else "conv_wgrad_row_kernel", f"wgrad {case}")
     elif dt == "bf16" and Cin >= 256 and Cout >= 256:
-        selected("conv_wgrad_wide_kernel", f"wgrad {case}")     # the 256 x 256 tile cases
+        # the 256 x 256 tile cases: one wave per SIMD for 1x1 / stride 1 with whole tiles and stages, else the 8-wave kernel
+        pw_lw = k == 1 and s == 1 and p == 0 and Cin % 256 == 0 and Cout % 256 == 0 and (N * H * W) % 64 == 0
+        selected("conv_wgrad_pw_lw_kernel" if pw_lw else "conv_wgrad_wide_kernel", f"wgrad {case}")
     assert_close(dw.cpu().numpy(), ref, dt, f"wgrad {case}")
     K.conv2d_wgrad(dev_nhwc(x, dt), gyd, dw, s, p, d, accumulate=True)
     assert_close(dw.cpu().numpy(), 2 * ref, dt, f"wgrad accumulate {case}")

@@ -93,7 +93,7 @@ def child(a):
 
 
 def arm(lw, a, **extra):
-    env = dict(os.environ, KDCC_WGRAD_LW=lw, KDCC_WGRAD_PW_LW="2" if lw == "1" else "0")      # (2: the 1x1 kernel wherever it can run, also where the library would not choose it)
+    env = dict(os.environ, KDCC_WGRAD_LW=lw, KDCC_WGRAD_PW_LW=lw)
     env.update(extra)
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--batch", str(a.batch), "--iters", str(a.iters), "--only", a.only],
                        env=env, capture_output=True, text=True, timeout=900)
