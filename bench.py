@@ -434,7 +434,7 @@ def run_config(a, device, rank, world, plan_name=None, mode=None, arch=None, hin
                          "launches_per_step": len(conv) / max(steps, 1), "ms_per_step_in_kernel": ms / max(steps, 1),
                          "algorithmic_tflop_per_step": flops / max(steps, 1) / 1e12,
                          "classes": class_rooflines(prof, max(steps, 1), peak)},
-            "dense_wgrad": ({"kernel": "conv_wgrad_lw_kernel / conv_wgrad_row_kernel / conv_wgrad_wide_kernel / pw_wgrad_tr_kernel via kd_conv2d_wgrad",
+            "dense_wgrad": ({"kernel": "conv_wgrad_lw_kernel (3x3) / conv_wgrad_pw_lw_kernel (1x1) / conv_wgrad_wide_kernel / pw_wgrad_tr_kernel via kd_conv2d_wgrad",
                              "achieved": wg_flops / (wg_ms * 1e-3) / 1e12, "unit": "TFLOP/s", "peak": peak,
                              "frac": wg_flops / (wg_ms * 1e-3) / 1e12 / peak, "launches_per_step": len(wg) / max(steps, 1),
                              "ms_per_step_in_kernel": wg_ms / max(steps, 1),

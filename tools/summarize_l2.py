@@ -8,7 +8,7 @@ import sys
 
 FAMILIES = [("conv_row_lw", ("conv_row_lw_kernel",)), ("conv_row_tall (512 x 128)", ("conv_row_tall_kernel",)), ("conv_row_pp128", ("conv_row_pp128_kernel",)),
             ("conv_igemm_persist (1x1)", ("conv_igemm_persist_kernel",)), ("conv_igemm_row (rate 36)", ("conv_igemm_row_kernel",)),
-            ("conv_igemm (one tile)", ("conv_igemm_kernel",)), ("conv_wgrad_wide", ("conv_wgrad_wide_kernel",)),
+            ("conv_igemm (one tile)", ("conv_igemm_kernel",)), ("conv_wgrad_wide", ("conv_wgrad_wide_kernel",)), ("conv_wgrad_pw_lw (1x1, lone wave)", ("conv_wgrad_pw_lw_kernel",)), ("conv_wgrad_lw (3x3, lone wave)", ("conv_wgrad_lw_kernel",)),
             ("dw_lw_fan3", ("dw_lw_fan3_kernel",)), ("dw_mfma_fwd", ("dw_mfma_fwd_kernel",)), ("dw_mfma_wgrad_multi", ("dw_mfma_wgrad_multi_kernel",)), ("dw_mfma_wgrad", ("dw_mfma_wgrad_kernel",)),
             ("dwconv_fwd", ("dwconv_fwd_kernel",))]
 acc = collections.defaultdict(lambda: collections.defaultdict(float))

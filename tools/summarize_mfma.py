@@ -20,7 +20,7 @@ FAMILIES = [("conv_row_lw<256x256, one wave per SIMD>", ("conv_row_lw_kernel",))
             ("conv_igemm_row<CfgRowN 256x128>", ("conv_igemm_row_kernel", "CfgRowT<4, 4, 2, 64")),
             ("conv_igemm<CfgWide 256x256 gathered>", ("conv_igemm_kernel", "Cfg<8, 2, 4, 2, 128")),
             ("conv_igemm<CfgNarrow2 256x128 gathered>", ("conv_igemm_kernel", "Cfg<4, 4, 2, 3, 64")),
-            ("conv_wgrad_wide", ("conv_wgrad_wide_kernel",)), ("conv_wgrad_lw<one wave per SIMD>", ("conv_wgrad_lw_kernel",)), ("conv_wgrad_row", ("conv_wgrad_row_kernel",)), ("pw_wgrad_tr", ("pw_wgrad_tr_kernel",)),
+            ("conv_wgrad_wide", ("conv_wgrad_wide_kernel",)), ("conv_wgrad_lw<3x3, one wave per SIMD>", ("conv_wgrad_lw_kernel",)), ("conv_wgrad_pw_lw<1x1, one wave per SIMD>", ("conv_wgrad_pw_lw_kernel",)), ("conv_wgrad_row", ("conv_wgrad_row_kernel",)), ("pw_wgrad_tr", ("pw_wgrad_tr_kernel",)),
             ("dw_lw_fan3 (lone-wave fan-out)", ("dw_lw_fan3_kernel",)), ("dw_mfma_fwd", ("dw_mfma_fwd_kernel",)), ("dw_mfma_wgrad", ("dw_mfma_wgrad_kernel",)),
             ("dw_mfma_wgrad_multi", ("dw_mfma_wgrad_multi_kernel",))]
 acc = collections.defaultdict(lambda: collections.defaultdict(float))

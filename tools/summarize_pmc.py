@@ -7,7 +7,7 @@ import csv, json, sys
 
 FAMILIES = {"conv_igemm": ("conv_igemm", "conv_row_persist", "conv_row_pp128", "conv_row_lw", "conv_row_tall"), "dw_mfma_fwd": "dw_mfma_fwd",
             "dw_lw_fan3": "dw_lw_fan3_kernel", "dw_mfma_wgrad_multi": "dw_mfma_wgrad_multi", "dw_mfma_wgrad": "dw_mfma_wgrad_kernel",
-            "dwconv_fwd": "dwconv_fwd_kernel", "pw_wgrad": "pw_wgrad", "conv_wgrad_lw": "conv_wgrad_lw_kernel", "conv_wgrad_row": "conv_wgrad_row_kernel",
+            "dwconv_fwd": "dwconv_fwd_kernel", "pw_wgrad": "pw_wgrad", "conv_wgrad_lw": "conv_wgrad_lw_kernel", "conv_wgrad_pw_lw": "conv_wgrad_pw_lw_kernel", "conv_wgrad_row": "conv_wgrad_row_kernel",
             "conv_wgrad_wide": "conv_wgrad_wide_kernel"}
 
 
