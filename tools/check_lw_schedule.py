@@ -156,8 +156,8 @@ def run(lines, w, on_read, max_steps=400000):
             w.dma(w.m0, w.val(a[1]))
         elif op == "ds_write_b128":
             pass      # zero fill under the complementary mask of the piece just issued: same region, same interval
-        elif op in ("v_add_u32", "v_subrev_u32", "v_cmpx_gt_u32", "s_nop", "s_setprio", "s_not_b64"):
-            pass
+        elif op in ("v_add_u32", "v_subrev_u32", "v_cmpx_gt_u32", "v_cmp_gt_u32", "s_nop", "s_setprio", "s_not_b64", "s_cbranch_execz"):
+            pass      # (lane masks are not modelled: a piece counts as issued whatever its EXEC, its zero fill as never skipped)
         elif op == "s_mov_b32" or op == "s_mov_b64":
             w.put(a[0], w.val(a[1]))
         elif op == "s_add_u32":

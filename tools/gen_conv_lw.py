@@ -43,7 +43,9 @@ SAN, SBN = "s[76:77]", "s[78:79]"     # the period being staged: row-buffer sour
 SLO, SSPAN = "s80", "s81"             # ... its valid buffer rows [lo, lo + span)
 SKY, SIN, SCNT, SFLAG = "s82", "s83", "s84", "s85"   # kernel-row position of the staged period, in-tile periods left to stage, periods left to compute, stores-outstanding flag
 ST0, ST1, ST2 = "s86", "s87", "s91"
-CLOBBER_S = ["s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91"]
+SMASK = "s[92:93]"        # lane mask of the row-buffer piece being staged
+CLOBBER_S = ["s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93"]
+SPREAD = os.environ.get("KDCC_GEN_LW_SPREAD", "1") != "0"     # experiment switch: 0 = a row-buffer piece's eight instructions between ONE pair of MFMAs (rounds 4-5)
 VT = "v127"               # lane temporary (clobbered)
 
 
@@ -91,6 +93,17 @@ def kstep(par, p, zero=False):
     at = (12, 28, 44, 60)
     for n, j in enumerate(A_PIECES[p]):
         nb = par ^ 1
+        if SPREAD:
+            # the piece's instructions in four gaps instead of one (round 6: a lone wave hides ~2 instructions per MFMA gap, eight in one gap
+            # stall the matrix pipe): lane mask into an SGPR pair, load under it, zero fill under its complement (skipped when empty)
+            tag = f"{par}{p}{'z' if zero else ''}{j}"
+            slots[at[n]] += [f"v_add_u32 {VT}, {8 * j}, %[vr0]", f"v_subrev_u32 {VT}, {SLO}, {VT}"]      # buffer row of the lane - lo
+            slots[at[n] + 1] += [f"v_cmp_gt_u32 {SMASK}, {SSPAN}, {VT}",                                  # lo <= row < lo + span
+                                 f"s_add_u32 m0, %[sldsA], {nb * ABUF + j * 1024}"]
+            slots[at[n] + 2] += [f"s_mov_b64 exec, {SMASK}", f"global_load_lds_dwordx4 %[voa{j}], {SAN}", "s_mov_b64 exec, -1"]
+            slots[at[n] + 3] += [f"s_not_b64 exec, {SMASK}", f"s_cbranch_execz LWNZ{tag}_%=", f"ds_write_b128 %[vz{nb}], %[vzero] offset:{j * 1024}",
+                                 f"LWNZ{tag}_%=:", "s_mov_b64 exec, -1"]
+            continue
         slots[at[n]] += [f"s_add_u32 m0, %[sldsA], {nb * ABUF + j * 1024}",
                          f"v_add_u32 {VT}, {8 * j}, %[vr0]", f"v_subrev_u32 {VT}, {SLO}, {VT}",     # buffer row of the lane - lo
                          f"v_cmpx_gt_u32 vcc, {SSPAN}, {VT}",                                       # EXEC: lo <= row < lo + span
@@ -253,7 +266,7 @@ def refill_1x1():
 DUO_ABUF, DUO_BSLOT, DUO_B0 = 320 * 64, 128 * 64, 2 * 320 * 64
 D_SAN1, D_SBN1, D_LO1, D_SP1 = "s[76:77]", "s[78:79]", "s80", "s81"       # period P + 1
 D_SAN2, D_SBN2, D_LO2, D_SP2 = "s[92:93]", "s[94:95]", "s96", "s97"       # period P + 2
-DUO_CLOBBER_S = CLOBBER_S + ["s92", "s93", "s94", "s95", "s96", "s97"]
+DUO_CLOBBER_S = CLOBBER_S + ["s94", "s95", "s96", "s97"]
 D_VT = "v31"
 
 
@@ -371,10 +384,20 @@ TALL_WAIT = (13, 4, 13)
 TALL_FLAGWIN = int(os.environ.get("KDCC_GEN_TALL_FLAGWIN", "2"))   # experiment (timing only, wrong results above 2): k-steps after an epilogue whose waits ignore vmcnt
 
 
-def tall_a_piece(j, buf):
-    return [f"s_add_u32 m0, %[sldsA], {buf * TALL_ABUF + j * 1024}", f"v_add_u32 {VT}, {16 * j}, %[vr0]", f"v_subrev_u32 {VT}, {D_LO2}, {VT}",
-            f"v_cmpx_gt_u32 vcc, {D_SP2}, {VT}", f"global_load_lds_dwordx4 %[voa{j}], {D_SAN2}", "s_not_b64 exec, exec",
-            f"ds_write_b128 %[vz{buf}], %[vzero] offset:{j * 1024}", "s_mov_b64 exec, -1"]
+T_MASK = "s[80:81]"       # lane mask of the row-buffer piece being staged (the 512 x 128 loop has no period P + 1 masks in s80 / s81)
+
+
+def tall_a_piece(j, buf, tag=""):
+    """-> the piece's instructions as groups for consecutive MFMA gaps (one group when KDCC_GEN_LW_SPREAD=0)"""
+    if SPREAD:
+        return [[f"v_add_u32 {VT}, {16 * j}, %[vr0]", f"v_subrev_u32 {VT}, {D_LO2}, {VT}"],
+                [f"v_cmp_gt_u32 {T_MASK}, {D_SP2}, {VT}", f"s_add_u32 m0, %[sldsA], {buf * TALL_ABUF + j * 1024}"],
+                [f"s_mov_b64 exec, {T_MASK}", f"global_load_lds_dwordx4 %[voa{j}], {D_SAN2}", "s_mov_b64 exec, -1"],
+                [f"s_not_b64 exec, {T_MASK}", f"s_cbranch_execz LTNZ{tag}{j}_%=", f"ds_write_b128 %[vz{buf}], %[vzero] offset:{j * 1024}",
+                 f"LTNZ{tag}{j}_%=:", "s_mov_b64 exec, -1"]]
+    return [[f"s_add_u32 m0, %[sldsA], {buf * TALL_ABUF + j * 1024}", f"v_add_u32 {VT}, {16 * j}, %[vr0]", f"v_subrev_u32 {VT}, {D_LO2}, {VT}",
+             f"v_cmpx_gt_u32 vcc, {D_SP2}, {VT}", f"global_load_lds_dwordx4 %[voa{j}], {D_SAN2}", "s_not_b64 exec, exec",
+             f"ds_write_b128 %[vz{buf}], %[vzero] offset:{j * 1024}", "s_mov_b64 exec, -1"]]
 
 
 def tall_shift(tag):
@@ -416,7 +439,8 @@ def tall_kstep(b, zero=False):
         slots[k] += [f"s_add_u32 m0, %[sldsB], {(b & 3) * TALL_BSLOT + j * 1024}", "s_nop 0", f"global_load_lds_dwordx4 %[vob{j}], {SB}"]
     if kx == 2:
         for n, j in enumerate(range(9)):
-            slots[(8, 14, 23, 29, 35, 41, 48, 54, 60)[n]] += tall_a_piece(j, per)
+            for g, grp in enumerate(tall_a_piece(j, per, f"{b}z" if zero else f"{b}")):
+                slots[(8, 14, 23, 29, 35, 41, 48, 54, 60)[n] + g] += grp
     L = []
     k = 0
     for i in range(8):
