@@ -82,8 +82,12 @@ def kstep(par, p, zero=False):
     if p == 2:
         slots[2].append(f"s_mov_b64 {SB}, {SBN}")          # positions 0 .. 3 of the period being staged
     for j, k in enumerate((4, 20, 36, 52)):
-        slots[k] += [f"s_add_u32 m0, %[sldsB], {slot_cur * BSLOT + j * 1024}", "s_nop 0",
-                     f"global_load_lds_dwordx4 %[vob{j}], {SB}"]
+        if SPREAD:     # (M0 one gap ahead of the piece: the MFMA between them is the wait state an s_nop provided)
+            slots[k - 1].append(f"s_add_u32 m0, %[sldsB], {slot_cur * BSLOT + j * 1024}")
+            slots[k].append(f"global_load_lds_dwordx4 %[vob{j}], {SB}")
+        else:
+            slots[k] += [f"s_add_u32 m0, %[sldsB], {slot_cur * BSLOT + j * 1024}", "s_nop 0",
+                         f"global_load_lds_dwordx4 %[vob{j}], {SB}"]
     # advance the B pointer: +64 B to the second k-half, then on to the next tap
     if p & 1:
         slots[54] += ["s_add_u32 s88, s88, %[s2c]", "s_addc_u32 s89, s89, 0"]
@@ -436,7 +440,11 @@ def tall_kstep(b, zero=False):
     else:
         slots[2].append(f"s_mov_b64 {SB}, {D_SBN2}")                                  # (P + 2, tap 0)
     for j, k in enumerate((5, 20)):
-        slots[k] += [f"s_add_u32 m0, %[sldsB], {(b & 3) * TALL_BSLOT + j * 1024}", "s_nop 0", f"global_load_lds_dwordx4 %[vob{j}], {SB}"]
+        if SPREAD:
+            slots[k - 1].append(f"s_add_u32 m0, %[sldsB], {(b & 3) * TALL_BSLOT + j * 1024}")
+            slots[k].append(f"global_load_lds_dwordx4 %[vob{j}], {SB}")
+        else:
+            slots[k] += [f"s_add_u32 m0, %[sldsB], {(b & 3) * TALL_BSLOT + j * 1024}", "s_nop 0", f"global_load_lds_dwordx4 %[vob{j}], {SB}"]
     if kx == 2:
         for n, j in enumerate(range(9)):
             for g, grp in enumerate(tall_a_piece(j, per, f"{b}z" if zero else f"{b}")):

@@ -123,7 +123,9 @@ _PIECE = [0]
 
 def dy_piece(k, ring):
     """-> groups of instructions; a group stays together between two MFMAs"""
-    return [[f"s_add_u32 m0, %[sldsw], {ring * STAGE + k * 4096}", "s_nop 0", ("VM", f"global_load_lds_dwordx4 %[voy{k}], {S_YB}", f"y{k}")]]
+    # (M0 one gap ahead of the piece: the MFMA between them is the wait state the hardware asks for; in the prologue, where the groups follow
+    #  each other directly, the next piece's M0 write is not that piece's own, so an s_nop stands in)
+    return [[f"s_add_u32 m0, %[sldsw], {ring * STAGE + k * 4096}"], [("NOP",), ("VM", f"global_load_lds_dwordx4 %[voy{k}], {S_YB}", f"y{k}")]]
 
 
 def x_piece(k, ring, xb, lo, span):
@@ -171,7 +173,14 @@ def deal(slots, groups, first, last):
         slots[first + (k * (last - first + 1)) // n] += grp
 
 
+IN_LOOP = [False]
+
+
 def put(g, ins):
+    if isinstance(ins, tuple) and ins[0] == "NOP":
+        if not IN_LOOP[0]:
+            g.emit("s_nop 0")
+        return
     if isinstance(ins, str):
         if (ABL & 8 and ins.startswith("ds_write")) or (ABL & 16 and ins.startswith("v_add_u32 %[v")):
             return
@@ -278,6 +287,14 @@ def keep_second_half():
 
 def loop_body(ds_at_top, r):
     """one stage whose ring slot is r; returns (instructions, LDS queue at its end)"""
+    IN_LOOP[0] = True
+    try:
+        return _loop_body(ds_at_top, r)
+    finally:
+        IN_LOOP[0] = False
+
+
+def _loop_body(ds_at_top, r):
     g = Gen()
     g.ds = list(ds_at_top)
     e = g.emit

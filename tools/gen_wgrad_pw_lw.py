@@ -66,7 +66,8 @@ def pieces(ring):
     for q in range(4):
         for j in range(2):
             src, base = (f"%[voy{j * 2 + q}]", S_YB) if q < 2 else (f"%[vox{j * 2 + q - 2}]", S_XB)
-            out.append([f"s_add_u32 m0, %[sldsw], {ring * STAGE + q * IMG + j * 1024}", "s_nop 0", ("VM", f"global_load_lds_dwordx4 {src}, {base}", f"p{q}{j}")])
+            out.append([f"s_add_u32 m0, %[sldsw], {ring * STAGE + q * IMG + j * 1024}"])       # (M0 one MFMA gap ahead of its piece; prologue: an s_nop)
+            out.append([("NOP",), ("VM", f"global_load_lds_dwordx4 {src}, {base}", f"p{q}{j}")])
     return out
 
 
@@ -77,8 +78,14 @@ def advance_iterator():
             ["s_add_u32 s42, s42, s%d" % S_T1, "s_addc_u32 s43, s43, 0"]]
 
 
+IN_LOOP = [False]
+
+
 def put(g, ins):
-    if isinstance(ins, str):
+    if isinstance(ins, tuple) and ins[0] == "NOP":
+        if not IN_LOOP[0]:
+            g.emit("s_nop 0")
+    elif isinstance(ins, str):
         g.emit(ins)
     elif ins[0] == "DS":
         g.ds_op(ins[1], ins[2])
@@ -95,6 +102,7 @@ def deal(slots, groups, first, last):
 def body(ds_at_top, r):
     """stage st in ring slot r, fragment set r & 1; returns (instructions, LDS queue at its end)"""
     G0.SLACK_DS = SLACK_DS
+    IN_LOOP[0] = True
     g = G0.Gen()
     g.ds = list(ds_at_top)
     s = r & 1
@@ -115,6 +123,7 @@ def body(ds_at_top, r):
                 put(g, ins)
             k += 1
     G0.SLACK_DS = 0
+    IN_LOOP[0] = False
     return g.L, list(g.ds)
 
 
