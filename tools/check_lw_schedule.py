@@ -178,7 +178,7 @@ def run(lines, w, on_read, max_steps=400000):
             x = w.val(a[1]) & 0xffffffff
             x = x - (1 << 32) if x >> 31 else x
             w.put(a[0], (x >> w.val(a[2])) & 0xffffffff)
-        elif op == "s_cselect_b32":
+        elif op in ("s_cselect_b32", "s_cselect_b64"):
             w.put(a[0], w.val(a[1]) if w.scc else w.val(a[2]))
         elif op in ("s_cmp_eq_u32", "s_cmp_lg_u32", "s_cmp_gt_i32"):
             x, y = w.val(a[0]) & 0xffffffff, w.val(a[1]) & 0xffffffff

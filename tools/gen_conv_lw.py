@@ -113,6 +113,11 @@ def kstep(par, p, zero=False):
                          f"v_cmpx_gt_u32 vcc, {SSPAN}, {VT}",                                       # EXEC: lo <= row < lo + span
                          f"global_load_lds_dwordx4 %[voa{j}], {SAN}", "s_not_b64 exec, exec",
                          f"ds_write_b128 %[vz{nb}], %[vzero] offset:{j * 1024}", "s_mov_b64 exec, -1"]
+    if SPREAD and p == 5:
+        # the staging iterator, branch-free, in the last gaps of the period's last k-step (rounds 4-5: ~18 scalar instructions behind the barrier,
+        # with the matrix pipe idle)
+        for k, grp in zip((48, 50, 53, 56, 58, 60), step_iterator_groups()):
+            slots[k] += grp
     L = []
     broken_here = BROKEN and par == 0 and p == 3 and not zero
     if broken_here:      # (%[sbrk] = 0: the regular schedule)
@@ -143,8 +148,20 @@ def kstep(par, p, zero=False):
     return L
 
 
+def step_iterator_groups():
+    """step_iterator() without branches, in groups that keep an SCC producer with its consumers: both alternatives are computed, s_cselect picks"""
+    return [[f"s_sub_u32 {SIN}, {SIN}, 1", f"s_add_u32 {SKY}, {SKY}, 1"],
+            [f"s_cmp_eq_u32 {SKY}, %[snky]", f"s_cselect_b32 {ST0}, %[sdAw], %[sdAs]", f"s_cselect_b32 {ST1}, %[sdBw], %[sdBs]", f"s_cselect_b32 {SKY}, 0, {SKY}"],
+            [f"s_ashr_i32 {ST2}, {ST0}, 31", f"s_add_u32 s76, s76, {ST0}", f"s_addc_u32 s77, s77, {ST2}"],
+            [f"s_ashr_i32 {ST2}, {ST1}, 31", f"s_add_u32 s78, s78, {ST1}", f"s_addc_u32 s79, s79, {ST2}"],
+            [f"s_cmp_gt_i32 {SIN}, 0", f"s_cselect_b64 {SAN}, {SAN}, %[sAnT]", f"s_cselect_b64 {SBN}, {SBN}, %[sBnT]"],
+            [f"s_cmp_gt_i32 {SIN}, 0", f"s_cselect_b32 {SLO}, {SLO}, %[sloT]", f"s_cselect_b32 {SSPAN}, {SSPAN}, %[sspT]"]]
+
+
 def step_iterator(par):
     """the staging iterator moves on by one period: next kernel row / channel block of this tile, or the next tile's first period"""
+    if SPREAD:
+        return []          # (dealt into k-step 5's gaps: step_iterator_groups)
     return [f"s_sub_u32 {SIN}, {SIN}, 1", f"s_cmp_gt_i32 {SIN}, 0", f"s_cbranch_scc0 LWT{par}_%=",
             f"s_add_u32 {SKY}, {SKY}, 1", f"s_cmp_eq_u32 {SKY}, %[snky]",
             f"s_cselect_b32 {ST0}, %[sdAw], %[sdAs]", f"s_cselect_b32 {ST1}, %[sdBw], %[sdBs]", f"s_cselect_b32 {SKY}, 0, {SKY}",
