@@ -45,6 +45,7 @@ SKY, SIN, SCNT, SFLAG = "s82", "s83", "s84", "s85"   # kernel-row position of th
 ST0, ST1, ST2 = "s86", "s87", "s91"
 SMASK = "s[92:93]"        # lane mask of the row-buffer piece being staged
 CLOBBER_S = ["s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93"]
+NOBAR = os.environ.get("KDCC_GEN_LW_NOBAR", "0") == "1"
 SPREAD = os.environ.get("KDCC_GEN_LW_SPREAD", "1") != "0"     # experiment switch: 0 = a row-buffer piece's eight instructions between ONE pair of MFMAs (rounds 4-5)
 VT = "v127"               # lane temporary (clobbered)
 
@@ -143,6 +144,8 @@ def kstep(par, p, zero=False):
         L.append(f"s_waitcnt vmcnt({n}) lgkmcnt(0)")
     if broken_here:
         L += ["s_cmp_lg_u32 %[sbrk], 0", f"s_cbranch_scc1 LWNOBAR{par}{p}_%=", "s_barrier", f"LWNOBAR{par}{p}_%=:"]
+    elif NOBAR and (p & 1) == 0:
+        pass               # TIMING experiment (KDCC_GEN_LW_NOBAR=1, results wrong): what a barrier per TWO k-steps could buy at most
     else:
         L.append("s_barrier")
     return L
