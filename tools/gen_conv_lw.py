@@ -36,7 +36,7 @@ OUT = os.path.join(ROOT, "knowledge-distillation-by-replacing-cheap-conv_amd", "
 ABUF = 320 * 128          # one row buffer (320 rows x 128 B)
 BSLOT = 256 * 64          # one B slot (256 output channels x 32 channels of K)
 A_PIECES = ((0, 1, 2, 3), (4, 5, 6), (7, 8, 9), (), (), ())     # row-buffer pieces issued at k-step p
-ISSUED = [4 + len(a) for a in A_PIECES]                         # VMEM operations per k-step and wave
+ISSUED = [(8 if os.environ.get("KDCC_GEN_LW_BREG", "0") == "1" else 4) + len(a) for a in A_PIECES]                         # VMEM operations per k-step and wave
 # scalar registers owned by the statement (clobbered)
 SB = "s[88:89]"           # running B source pointer (k-step h + 4)
 SAN, SBN = "s[76:77]", "s[78:79]"     # the period being staged: row-buffer source base, weight base
@@ -46,6 +46,7 @@ ST0, ST1, ST2 = "s86", "s87", "s91"
 SMASK = "s[92:93]"        # lane mask of the row-buffer piece being staged
 CLOBBER_S = ["s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93"]
 NOBAR = os.environ.get("KDCC_GEN_LW_NOBAR", "0") == "1"
+BREG = os.environ.get("KDCC_GEN_LW_BREG", "0") == "1"     # TIMING experiment (results wrong): the weight operand straight into registers -- per k-step and wave eight global_load_dwordx4 instead of four LDS-DMA pieces + eight ds_read_b128
 SPREAD = os.environ.get("KDCC_GEN_LW_SPREAD", "1") != "0"     # experiment switch: 0 = a row-buffer piece's eight instructions between ONE pair of MFMAs (rounds 4-5)
 VT = "v127"               # lane temporary (clobbered)
 
@@ -75,7 +76,8 @@ def kstep(par, p, zero=False):
         kx, ks, buf = 0, 0, par ^ 1
     slot_next = (2 * par + p + 1) & 3
     reads = [f"ds_read_b128 v[{nareg[i]}:{nareg[i] + 3}], %[va{kx * 2 + ks}] offset:{i * 2048 + buf * ABUF}" for i in range(8)]
-    reads += [f"ds_read_b128 v[{nbreg[j]}:{nbreg[j] + 3}], %[vb] offset:{slot_next * BSLOT + j * 1024}" for j in range(8)]
+    if not BREG:
+        reads += [f"ds_read_b128 v[{nbreg[j]}:{nbreg[j] + 3}], %[vb] offset:{slot_next * BSLOT + j * 1024}" for j in range(8)]
     for r, ins in enumerate(reads):
         slots[1 + 3 * r].append(ins)
     # ---- B pieces of k-step h + 4 into slot h & 3
@@ -83,7 +85,10 @@ def kstep(par, p, zero=False):
     if p == 2:
         slots[2].append(f"s_mov_b64 {SB}, {SBN}")          # positions 0 .. 3 of the period being staged
     for j, k in enumerate((4, 20, 36, 52)):
-        if SPREAD:     # (M0 one gap ahead of the piece: the MFMA between them is the wait state an s_nop provided)
+        if BREG:
+            slots[k - 8 if k >= 8 else k].append(f"global_load_dwordx4 v[{96 + 8 * j}:{99 + 8 * j}], %[vob{j}], {SB}")
+            slots[k].append(f"global_load_dwordx4 v[{100 + 8 * j}:{103 + 8 * j}], %[vob{j}], {SB} offset:512")
+        elif SPREAD:     # (M0 one gap ahead of the piece: the MFMA between them is the wait state an s_nop provided)
             slots[k - 1].append(f"s_add_u32 m0, %[sldsB], {slot_cur * BSLOT + j * 1024}")
             slots[k].append(f"global_load_lds_dwordx4 %[vob{j}], {SB}")
         else:
@@ -546,7 +551,7 @@ def main():
             o += [f"#define LW_READ_ACC_{i}_{jg}_ASM \\", cstr(read_acc(i, jg)), ""]
     o += ["#define LW_ZERO_ACC_ASM \\", cstr([f"v_accvgpr_write_b32 a{n}, 0" for n in range(256)]), ""]
     o += ["#define LW_CLOBBER_ACC " + ", ".join(f'"a{n}"' for n in range(256)),
-          "#define LW_CLOBBER_FRAG " + ", ".join(f'"v{n}"' for n in range(127, 256)),
+          "#define LW_CLOBBER_FRAG " + ", ".join(f'"v{n}"' for n in range(96 if BREG else 127, 256)),
           "#define LW_CLOBBER_S " + ", ".join(f'"{s}"' for s in CLOBBER_S), ""]
     text = "\n".join(o)
     if len(sys.argv) > 1 and sys.argv[1] == "--check":
