@@ -46,6 +46,7 @@ ST0, ST1, ST2 = "s86", "s87", "s91"
 SMASK = "s[92:93]"        # lane mask of the row-buffer piece being staged
 CLOBBER_S = ["s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93"]
 NOBAR = os.environ.get("KDCC_GEN_LW_NOBAR", "0") == "1"
+NOVM = os.environ.get("KDCC_GEN_LW_NOVM", "0") == "1"     # TIMING experiment (results wrong): the k-step waits ignore vmcnt = the loop never waits for a piece to land
 BREG = os.environ.get("KDCC_GEN_LW_BREG", "0") == "1"     # TIMING experiment (results wrong): the weight operand straight into registers -- per k-step and wave eight global_load_dwordx4 instead of four LDS-DMA pieces + eight ds_read_b128
 SPREAD = os.environ.get("KDCC_GEN_LW_SPREAD", "1") != "0"     # experiment switch: 0 = a row-buffer piece's eight instructions between ONE pair of MFMAs (rounds 4-5)
 VT = "v127"               # lane temporary (clobbered)
@@ -142,11 +143,11 @@ def kstep(par, p, zero=False):
         # right after an epilogue its stores are younger than the pieces this wait is for and older than this period's: leave
         # them outstanding (the counter saturates at 63)
         L += [f"s_cmp_eq_u32 {SFLAG}, 0", f"s_cbranch_scc1 LWN{tag}_%=", "s_waitcnt vmcnt(63) lgkmcnt(0)", f"s_branch LWD{tag}_%=",
-              f"LWN{tag}_%=:", f"s_waitcnt vmcnt({n}) lgkmcnt(0)", f"LWD{tag}_%=:"]
+              f"LWN{tag}_%=:", f"s_waitcnt vmcnt({63 if NOVM else n}) lgkmcnt(0)", f"LWD{tag}_%=:"]
         if p == 1:
             L.append(f"s_mov_b32 {SFLAG}, 0")
     else:
-        L.append(f"s_waitcnt vmcnt({n}) lgkmcnt(0)")
+        L.append(f"s_waitcnt vmcnt({63 if NOVM else n}) lgkmcnt(0)")
     if broken_here:
         L += ["s_cmp_lg_u32 %[sbrk], 0", f"s_cbranch_scc1 LWNOBAR{par}{p}_%=", "s_barrier", f"LWNOBAR{par}{p}_%=:"]
     elif NOBAR and (p & 1) == 0:
