@@ -410,7 +410,8 @@ def refill_duo():
 # Tiles have an even number of periods (Cin % 64 == 0), so a tile starts at b = 0 or b = 6 (operand spar): fragment set 0, row buffer 0,
 # B slot 0 or 2.
 TALL_ABUF, TALL_BSLOT = 576 * 64, 128 * 64
-TALL_WAIT = (13, 4, 13)
+TALL_BAL = os.environ.get("KDCC_GEN_TALL_BAL", "0") == "1"     # (what a third row buffer could buy at most: tools/tall_bal_probe.sh)
+TALL_WAIT = (10, 10, 10) if TALL_BAL else (13, 4, 13)
 TALL_FLAGWIN = int(os.environ.get("KDCC_GEN_TALL_FLAGWIN", "2"))   # experiment (timing only, wrong results above 2): k-steps after an epilogue whose waits ignore vmcnt
 
 
@@ -471,7 +472,11 @@ def tall_kstep(b, zero=False):
             slots[k].append(f"global_load_lds_dwordx4 %[vob{j}], {SB}")
         else:
             slots[k] += [f"s_add_u32 m0, %[sldsB], {(b & 3) * TALL_BSLOT + j * 1024}", "s_nop 0", f"global_load_lds_dwordx4 %[vob{j}], {SB}"]
-    if kx == 2:
+    if TALL_BAL:       # TIMING experiment (results wrong: the pieces overwrite a buffer that is being read): three row-buffer pieces in every k-step
+        for n, j in enumerate(range(3 * kx, 3 * kx + 3)):
+            for g, grp in enumerate(tall_a_piece(j, per, f"{b}z" if zero else f"{b}")):
+                slots[(8, 29, 48)[n] + g] += grp
+    elif kx == 2:
         for n, j in enumerate(range(9)):
             for g, grp in enumerate(tall_a_piece(j, per, f"{b}z" if zero else f"{b}")):
                 slots[(8, 14, 23, 29, 35, 41, 48, 54, 60)[n] + g] += grp
