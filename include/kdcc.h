@@ -98,7 +98,16 @@ typedef struct kd_conv_epilogue {
                              values stored to out_raw, part[r][1][c] = 0 -- the global average pool of the ASPP image-pooling branch
                              (models/deeplabv3/deeplabv3.py:59-62) taken where its input is produced; kd_aspp_image_pool_sums
                              consumes the rows.  Only the ping-pong 1x1 kernel with no epilogue operand and out_raw alone. */
+    /* Optional, round 6: a 1x1 classifier applied to the activation INSTEAD of storing it (out_raw and out_act NULL):
+     *   cls_out[m][c] = sum_k bf16(act(scale[k] * v[m][k] + shift[k])) * cls_w[c][k],  c < ncls <= 32, fp32, pixel stride ld_cls floats;
+     * cls_w is a [32][Cout] matrix in the conv's dtype, rows >= ncls zero (kd_pack_conv_weight of the 1x1 weight padded to 32 outputs).
+     * The reference's `final` head (models/deeplabv3/deeplabv3.py:127-139: conv3x3 -> BN -> ReLU -> conv1x1 onto the classes) where nothing
+     * else reads the 256-channel activation: it is neither written nor read back.  Same bf16 activation and bf16 weights as the
+     * two-launch form, fp32 summation in another order.  Only conv_row_lw_kernel (bf16 3x3 / stride 1 / 'same', Cout == 256, no epilogue
+     * operand, no bn_sums); kd_conv2d_cls_supported() says whether (d, ep) selects it, kd_conv2d_fwd refuses otherwise. */
+    const void *cls_w;    float *cls_out;      int32_t ld_cls;      int32_t ncls;
 } kd_conv_epilogue;
+int32_t kd_conv2d_cls_supported(const kd_conv_desc *d, const kd_conv_epilogue *ep);
 
 int kd_conv2d_fwd(const kd_conv_desc *d, const void *x, const void *w_packed,
                   const kd_conv_epilogue *ep, kd_stream_t stream);

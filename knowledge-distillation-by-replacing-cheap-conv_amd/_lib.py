@@ -38,7 +38,8 @@ class ConvEpilogue(C.Structure):
                 ("res_post", c_vp), ("ld_res_post", c_int),
                 ("out_raw", c_vp), ("ld_raw", c_int), ("raw_f32", c_int),
                 ("out_act", c_vp), ("ld_act", c_int), ("act_scale", c_vp), ("act_shift", c_vp), ("act_relu", c_int),
-                ("bn_sums", c_vp)]
+                ("bn_sums", c_vp),
+                ("cls_w", c_vp), ("cls_out", c_vp), ("ld_cls", c_int), ("ncls", c_int)]
 
 
 class DwDesc(C.Structure):
@@ -72,6 +73,7 @@ _SIGS = {
     "kd_conv1x1_dual_fwd": (c_int, [_P(ConvDesc), c_vp, c_vp, c_int, c_int, c_vp, _P(ConvEpilogue), c_vp]),
     "kd_conv_set_persist_cus": (c_int, [c_int]),
     "kd_conv2d_bn_sums_rows": (c_int, [_P(ConvDesc), _P(ConvEpilogue)]),
+    "kd_conv2d_cls_supported": (c_int, [_P(ConvDesc), _P(ConvEpilogue)]),
     "kd_bn_sums_finish_workspace": (c_sz, [c_int, c_int]),
     "kd_bn_sums_finish": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "kd_pack_conv_weight": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),

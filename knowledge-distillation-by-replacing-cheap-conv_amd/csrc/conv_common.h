@@ -494,6 +494,154 @@ __device__ __forceinline__ void lw_epilogue_rows16(const ConvParams &p, char *pa
     }
 }
 
+// ---- the decoder's classifier in the epilogue of its last 3x3 (round 6; conv_row_lw_kernel<16>) ------------------------------------
+// final[3] -> BN -> ReLU -> final[6] (a 1x1 onto the classes; models/deeplabv3/deeplabv3.py:127-139 of the reference): the 256-channel
+// activation between them is written and read back for nothing else when no gradient flows through it (the frozen teacher; the student
+// when the loss is the hints alone).  Cout == 256 is ONE N tile, so a workgroup holds every channel of its 256 pixels: the classifier
+// runs on the accumulators instead.  Per 16-pixel tile and 64-channel half the packed raw accumulators pass through the wave's LDS patch
+// exactly as in lw_epilogue_rows16 (same bf16 rounding of the raw value, same act_pair arithmetic: the activation that feeds the MFMAs is
+// bit for bit the tensor the two-launch form stores), are read back as MFMA B fragments (lane = pixel row, 8 consecutive channels), and
+// multiply the classifier rows (A fragments, loaded once per tile from the [32][Cout] bf16 matrix, rows >= ncls zero): D[class][pixel]
+// in fp32.  The two waves that own the channel halves of a pixel row exchange their partial logits through their patches (two pixel
+// tiles = 4 KiB per round, fixed order: low half + high half) and the low-half wave stores.  Differences to the two-launch form: the
+// fp32 summation order over the 256 channels only.
+struct LwClsState {
+    uint4 w[2][2][2];        // [64-channel half][32-channel k-step][class tile]
+    float sc[2][2][8], sh[2][2][8];   // BN scale / shift of the channels this lane feeds to the MFMAs: [half][k-step][8 channels]
+    f32x4_t acc[8][2];       // [pixel tile][class tile]
+};
+__device__ __forceinline__ void lw_cls_begin(const ConvParams &p, int nw, int lane, LwClsState &s)
+{
+    asm volatile("" : "+v"(lane));
+    const int li = lane & 15, kq = lane >> 4;
+    const bf16_t *w = (const bf16_t *)p.ep.cls_w;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+                s.w[h][kc][ct] = *(const uint4 *)(w + (size_t)(ct * 16 + li) * p.Cout + nw + h * 64 + kc * 32 + kq * 8);
+    // (loaded here, ahead of the accumulator read-out: a lone wave has nobody to hide their latency behind)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { s.sc[h][kc][q] = 1.f; s.sh[h][kc][q] = 0.f; }
+            if (p.ep.act_scale) ld8(p.ep.act_scale + nw + h * 64 + kc * 32 + kq * 8, s.sc[h][kc]);
+            if (p.ep.act_shift) ld8(p.ep.act_shift + nw + h * 64 + kc * 32 + kq * 8, s.sh[h][kc]);
+        }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) s.acc[i][ct] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+}
+// one 64-channel half (channels nwh .. nwh + 63 of the tile) of the wave's 128 pixels
+__device__ __forceinline__ void lw_epilogue_cls16(const ConvParams &p, char *patch, uint2 (&acc)[8][4], int lane, const uint4 (&w)[2][2],
+                                                  const float (&sc)[2][8], const float (&sh)[2][8], f32x4_t (&cacc)[8][2])
+{
+    typedef bf16_t T;
+    const kd_conv_epilogue &e = p.ep;
+    asm volatile("" : "+v"(lane));
+    const int frow = lane & 15, fq = lane >> 4;
+    const short relu_w = e.act_relu ? (short)0 : (short)-32768;
+    const i16x2_v relu_i16 = {relu_w, relu_w};
+    auto write_tile = [&](int i) __attribute__((always_inline)) {        // 16 rows x 64 channels, 8-B chunk c of row r at c ^ r (lw_epilogue_rows16's image)
+        char *pt = patch + (i & 1) * 2048;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(uint2 *)(pt + frow * 128 + (((j * 4 + fq) ^ frow) << 3)) = acc[i][j];
+    };
+    auto lds_order = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    write_tile(0);
+    write_tile(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        lds_order();
+        const char *pt = patch + (i & 1) * 2048;
+        uint4 raw[2];
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {      // row frow, channels kc * 32 + fq * 8 .. + 7 = 8-B chunks c, c + 1
+            const int c = kc * 8 + fq * 2;
+            const uint2 lo = *(const uint2 *)(pt + frow * 128 + ((c ^ frow) << 3));
+            const uint2 hi = *(const uint2 *)(pt + frow * 128 + (((c + 1) ^ frow) << 3));
+            raw[kc] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+        lds_order();
+        if (i + 2 < 8) write_tile(i + 2);      // into the patch half tile i was read from (queued behind that read)
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4c_t;
+        u32x4c_t fb[2];
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            float v[8];
+            ld8((const T *)&raw[kc], v);
+            const f32x2_v s0 = {sc[kc][0], sc[kc][1]}, s1 = {sc[kc][2], sc[kc][3]}, s2 = {sc[kc][4], sc[kc][5]}, s3 = {sc[kc][6], sc[kc][7]};
+            const f32x2_v h0 = {sh[kc][0], sh[kc][1]}, h1 = {sh[kc][2], sh[kc][3]}, h2 = {sh[kc][4], sh[kc][5]}, h3 = {sh[kc][6], sh[kc][7]};
+            fb[kc] = (u32x4c_t){act_pair(v[0], v[1], s0, h0, relu_i16), act_pair(v[2], v[3], s1, h1, relu_i16),
+                                act_pair(v[4], v[5], s2, h2, relu_i16), act_pair(v[6], v[7], s3, h3, relu_i16)};
+        }
+        // The tile's four MFMAs as ONE asm statement on vector registers: an intrinsic's accumulator would be placed in the accumulation file,
+        // which the tile statement owns; and, being asm, the statement has to bring its own wait states -- hipcc does not know that what it
+        // reads next (copies of the sums, the LDS stores of lw_cls_finish) comes out of the matrix pipe (the first version, one MFMA per
+        // statement and no s_nop, returned garbage in 0.3 % of the logits)
+        const u32x4c_t w00 = {w[0][0].x, w[0][0].y, w[0][0].z, w[0][0].w}, w01 = {w[0][1].x, w[0][1].y, w[0][1].z, w[0][1].w},
+                       w10 = {w[1][0].x, w[1][0].y, w[1][0].z, w[1][0].w}, w11 = {w[1][1].x, w[1][1].y, w[1][1].z, w[1][1].w};
+        asm volatile("s_nop 3\n\t"
+                     "v_mfma_f32_16x16x32_bf16 %0, %2, %6, %0\n\t"
+                     "v_mfma_f32_16x16x32_bf16 %1, %3, %6, %1\n\t"
+                     "v_mfma_f32_16x16x32_bf16 %0, %4, %7, %0\n\t"
+                     "v_mfma_f32_16x16x32_bf16 %1, %5, %7, %1\n\t"
+                     "s_nop 15\n\ts_nop 3"
+                     : "+v"(cacc[i][0]), "+v"(cacc[i][1])
+                     : "v"(w00), "v"(w01), "v"(w10), "v"(w11), "v"(fb[0]), "v"(fb[1]));
+    }
+    lds_order();
+}
+// the waves (wm, 0) and (wm, 1) hold the two channel halves of pixels mw .. mw + 127: low + high through the patches, (wm, 0) stores
+__device__ __forceinline__ void lw_cls_finish(const ConvParams &p, char *patches, int wv, int mw, int lane, f32x4_t (&cacc)[8][2])
+{
+    const kd_conv_epilogue &e = p.ep;
+    asm volatile("" : "+v"(lane));
+    const int li = lane & 15, q = lane >> 4, wn = wv & 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (wn == 1) {
+            char *own = patches + wv * 4096;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) *(f32x4_t *)(own + ((t * 2 + ct) * 64 + lane) * 16) = cacc[2 * r + t][ct];
+        }
+        __syncthreads();
+        if (wn == 0) {
+            const char *other = patches + (wv + 1) * 4096;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float *dst = e.cls_out + (size_t)(mw + (2 * r + t) * 16 + li) * e.ld_cls;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const f32x4_t hi = *(const f32x4_t *)(other + ((t * 2 + ct) * 64 + lane) * 16);
+                    const f32x4_t v = cacc[2 * r + t][ct] + hi;
+                    const int c0 = ct * 16 + 4 * q;
+                    typedef float f32x4u_t __attribute__((ext_vector_type(4), aligned(4)));
+                    if (c0 + 4 <= e.ncls) {
+                        *(f32x4u_t *)(dst + c0) = v;      // one 16-B store (dword-aligned: 19 classes = 76 B per pixel); four dword stores made the epilogue store-issue-bound
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (c0 + k < e.ncls) dst[c0 + k] = v[k];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // the tiles of this workgroup: XCD x owns a contiguous range of tile ids (as xcd_remap deals them), its workgroups take
 // them round-robin, so the tiles in flight on one XCD at any time are neighbours (shared image rows / weight slabs in L2)
 // A/B experiment (tuning build, KDCC_CONV_TUNE & 16384): every second workgroup of an XCD starts p.stagger_us microseconds late, so

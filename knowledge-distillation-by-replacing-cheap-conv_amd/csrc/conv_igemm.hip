@@ -1522,6 +1522,20 @@ extern "C" int32_t kd_conv2d_bn_sums_rows(const kd_conv_desc *d, const kd_conv_e
     return (int32_t)((long long)d->N * d->Ho * d->Wo / 128);
 }
 
+/* The classifier epilogue (kd_conv_epilogue.cls_w): conv_row_lw_kernel only, one N tile (Cout == 256), nothing else in the epilogue. */
+extern "C" int32_t kd_conv2d_cls_supported(const kd_conv_desc *d, const kd_conv_epilogue *ep)
+{
+    if (!d || !ep || !ep->cls_w || !ep->cls_out || d->dtype != KD_BF16 || d->N <= 0 || d->Ho <= 0 || d->Wo <= 0) return 0;
+    if (d->Cout != 256 || ep->ncls < 1 || ep->ncls > 32 || ep->ld_cls < ep->ncls || !kd_aligned16(ep->cls_w)) return 0;
+    if (ep->out_raw || ep->out_act || ep->bn_sums || ep->raw_f32) return 0;
+    static int tn = -1;
+    if (tn < 0) tn = KD_TUNING_ENV_INT("KDCC_CONV_TUNE");
+    static int duo = -1;
+    if (duo < 0) { const char *v = getenv("KDCC_CONV_DUO"); duo = v ? atoi(v) : 0; }
+    const ConvSel c = conv_select(d, ep, tn);
+    return c.use_row_persist && c.nops == 0 && duo < 2 && lw_row() && pp_row() && d->dil <= 32 && d->H >= 2 * d->dil && !(tn & 512);
+}
+
 // Workgroups of the persistent conv grids: one per CU, or fewer (a multiple of 8, one XCD round) when KDCC_PERSIST_CUS / kd_conv_set_persist_cus
 // says so -- that leaves CUs to a kernel on another stream (the RCCL all-reduce the reducer launches from inside backward, which
 // otherwise only gets a CU between two conv launches).  Results do not depend on it: a tile's arithmetic is the same whichever
@@ -1573,7 +1587,10 @@ static int conv2d_fwd_impl(const kd_conv_desc *d, const void *x, const void *w_p
     const long long w_elems = (long long)d->Cout * d->kh * d->kw * d->Cin;
     KD_REQUIRE(in_elems < (1ll << 31) && w_elems < (1ll << 31), KD_ERR_UNSUPPORTED,
                "kd_conv2d_fwd: tensor exceeds 2^31 elements");
-    KD_REQUIRE(ep->out_raw || ep->out_act, KD_ERR_INVALID, "kd_conv2d_fwd: no output requested");
+    const bool cls = ep->cls_w != nullptr || ep->cls_out != nullptr;
+    KD_REQUIRE(!cls || (!x2 && kd_conv2d_cls_supported(d, ep)), KD_ERR_UNSUPPORTED,
+               "kd_conv2d_fwd: the classifier epilogue needs conv_row_lw_kernel with one N tile and nothing else in the epilogue (ask kd_conv2d_cls_supported first)");
+    KD_REQUIRE(cls || ep->out_raw || ep->out_act, KD_ERR_INVALID, "kd_conv2d_fwd: no output requested");
 
     ConvParams p;
     p.x = x; p.w = w_packed;
@@ -1602,6 +1619,7 @@ static int conv2d_fwd_impl(const kd_conv_desc *d, const void *x, const void *w_p
     KD_REQUIRE(!ep->bn_sums || kd_conv2d_bn_sums_rows(d, ep) > 0, KD_ERR_UNSUPPORTED,
                "kd_conv2d_fwd: bn_sums is not produced by the kernel this problem selects (ask kd_conv2d_bn_sums_rows first)");
     if (ep->bn_sums) KD_NOTE_KERNEL(ep->mask ? "bn_sums_epilogue" : "out_sums_epilogue");   // (kernel-selection log: counted next to the kernel that carries it)
+    if (cls) KD_NOTE_KERNEL("cls_epilogue");
     hipStream_t s = (hipStream_t)stream;
     // Workgroups of the persistent kernels (one per CU, each walks tiles for 1-6 ms).  KDCC_PERSIST_CUS=n (a multiple of 8,
     // e.g. 248) leaves CUs free for a concurrent kernel -- the RCCL all-reduce the gradient reducer launches on its side stream
@@ -1666,7 +1684,7 @@ static int conv2d_fwd_impl(const kd_conv_desc *d, const void *x, const void *w_p
         const bool lw = lw_row() && pp_row() && d->dil <= 32 && d->H >= 2 * d->dil && !(p.tune & 512);
         KD_NOTE_KERNEL((p.tune & 512) ? "conv_row_persist_kernel<dbg>" : lw ? "conv_row_lw_kernel" : (pp_row() && d->dil <= 32) ? "conv_row_persist_kernel<pp>" : "conv_row_persist_kernel<lockstep>");
         if (lw) {
-            KD_REQUIRE(kd_launch_conv_row_lw(p, nops | (ep->bn_sums ? 4 : 0), grid.x, s), KD_ERR_UNSUPPORTED, "kd_conv2d_fwd: no conv_row_lw_kernel instantiation for %d epilogue operands", nops);
+            KD_REQUIRE(kd_launch_conv_row_lw(p, cls ? 16 : (nops | (ep->bn_sums ? 4 : 0)), grid.x, s), KD_ERR_UNSUPPORTED, "kd_conv2d_fwd: no conv_row_lw_kernel instantiation for %d epilogue operands", nops);
         } else if (p.tune & 512) {   // phase clocks (tools/conv_timeline.py)
             if (nops == 0) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 0, true, true>), grid, dim3(512), 0, s, p);
             else if (nops == 1) hipLaunchKernelGGL((conv_row_persist_kernel<CfgRow, 1, true, true>), grid, dim3(512), 0, s, p);

@@ -206,6 +206,22 @@ __global__ __launch_bounds__(256, 1) void conv_row_lw_kernel(const ConvParams p)
         acc[I][2] = make_uint2(pack_bf16x2_v(t8, t9), pack_bf16x2_v(t10, t11));                                                           \
         acc[I][3] = make_uint2(pack_bf16x2_v(t12, t13), pack_bf16x2_v(t14, t15));                                                         \
     }
+        if constexpr (NOPS_ == 16) {     // the classifier on the accumulators instead of an activation store (conv_common.h lw_epilogue_cls16)
+            LwClsState cs;
+            lw_cls_begin(p, nw, lane, cs);
+            {
+                uint2 acc[8][4];
+                LW_RD(0, 0) LW_RD(1, 0) LW_RD(2, 0) LW_RD(3, 0) LW_RD(4, 0) LW_RD(5, 0) LW_RD(6, 0) LW_RD(7, 0)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (as below: nothing older than the stores may be pending)
+                lw_epilogue_cls16(p, patch, acc, lane, cs.w[0], cs.sc[0], cs.sh[0], cs.acc);
+            }
+            {
+                uint2 acc[8][4];
+                LW_RD(0, 1) LW_RD(1, 1) LW_RD(2, 1) LW_RD(3, 1) LW_RD(4, 1) LW_RD(5, 1) LW_RD(6, 1) LW_RD(7, 1)
+                lw_epilogue_cls16(p, patch, acc, lane, cs.w[1], cs.sc[1], cs.sh[1], cs.acc);
+            }
+            lw_cls_finish(p, lds + LW_NEED, wv, mw, lane, cs.acc);
+        } else {
         LwEpiConsts k0, k1;
         lw_epilogue_consts<NOPS_>(p, nw, lane, k0);      // (their latency passes under the accumulator read-out)
         {
@@ -225,6 +241,7 @@ __global__ __launch_bounds__(256, 1) void conv_row_lw_kernel(const ConvParams p)
             if (p.ep.out_raw && p.ep.out_act) lw_epilogue_rows16<NOPS_, 3>(p, patch, acc, mw, nw + 64, lane, k1);
             else if (p.ep.out_act) lw_epilogue_rows16<NOPS_, 2>(p, patch, acc, mw, nw + 64, lane, k1);
             else lw_epilogue_rows16<NOPS_, 1>(p, patch, acc, mw, nw + 64, lane, k1);
+        }
         }
 #undef LW_RD
         }
@@ -751,6 +768,7 @@ bool kd_launch_conv_row_lw(const ConvParams &p, int nops_sums, unsigned grid, hi
     case 3: hipLaunchKernelGGL((conv_row_lw_kernel<3>), g, b, 0, s, p); return true;
     case 5: hipLaunchKernelGGL((conv_row_lw_kernel<5>), g, b, 0, s, p); return true;
     case 6: hipLaunchKernelGGL((conv_row_lw_kernel<6>), g, b, 0, s, p); return true;
+    case 16: hipLaunchKernelGGL((conv_row_lw_kernel<16>), g, b, 0, s, p); return true;     // classifier epilogue (no operand)
     default: return false;
     }
 }

@@ -810,11 +810,22 @@ class StudentEngine:
         ops.conv2d(dec0, self._w_fwd(f[0], cin_pad=cpad, cin_rot=nf), 1, 1, 1, out_act=d1, act_scale=sc, act_shift=sh, act_relu=True,
                    algo_cin=cdec)
         sc, sh = self._bn_fold(f[4])
-        d2 = self._new(N, h2, w2, f[3].out_channels)
-        ops.conv2d(d1, self._w_fwd(f[3]), 1, 1, 1, out_act=d2, act_scale=sc, act_shift=sh, act_relu=True)
         ncls = f[6].out_channels
         d3 = self._new(N, h2, w2, ncls, dtype=torch.float32)
-        ops.conv2d(d2, self._w_fwd(f[6]), out_raw=d3)
+        # Where nothing differentiates through the head's last activation (the frozen teacher; the student when the loss is the hints alone),
+        # the classifier runs in the epilogue of final[3] and the 256-channel tensor is neither written nor read back (kd_conv_epilogue.cls_w)
+        fuse_cls = (not self.logits_need_grad and not any(q.requires_grad for q in list(f[3].parameters()) + list(f[6].parameters())) and
+                    f[6].bias is None and ncls <= 32 and f[6].kernel_size == (1, 1) and ops.conv_cls_ok(d1, f[3].out_channels, 3, 1))
+        d2 = None
+        if fuse_cls:
+            try:
+                ops.conv2d(d1, self._w_fwd(f[3]), 1, 1, 1, act_scale=sc, act_shift=sh, act_relu=True, cls_w=self._w_fwd(f[6], cout_pad=32), cls_out=d3)
+            except ops.ClsUnsupported:
+                fuse_cls = False
+        if not fuse_cls:
+            d2 = self._new(N, h2, w2, f[3].out_channels)
+            ops.conv2d(d1, self._w_fwd(f[3]), 1, 1, 1, out_act=d2, act_scale=sc, act_shift=sh, act_relu=True)
+            ops.conv2d(d2, self._w_fwd(f[6]), out_raw=d3)
         if self.lazy_logits and self._lazy_call and not self.logits_need_grad:
             # nothing differentiates through the logits: hand out the half-resolution tensor behind the full-resolution
             # signature (lazy.LazyLogits); the logged criteria interpolate in registers, anything else materialises it

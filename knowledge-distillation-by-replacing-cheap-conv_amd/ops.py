@@ -6,6 +6,7 @@ a wider NHWC buffer).  Every function validates shapes on the host before a
 kernel is launched and enqueues on torch's current HIP stream.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -113,10 +114,17 @@ class DualUnsupported(_lib.KdccError):
     """conv2d(..., x2=...) on a shape the K-concatenated 1x1 kernel does not take: run the two convs instead."""
 
 
+class ClsUnsupported(_lib.KdccError):
+    """conv2d(..., cls_w=, cls_out=) on a problem whose kernel does not carry the classifier epilogue: store the activation and run the 1x1."""
+
+
 def conv2d(x, w_packed, stride=1, pad=0, dil=1, *, res_pre=None, mask=None, mask_scale=None, res_post=None,
            out_raw=None, out_act=None, act_scale=None, act_shift=None, act_relu=False, algo_cin=None, algo_cout=None, bn_sums=None,
-           x2=None, out_sums=None):
+           x2=None, out_sums=None, cls_w=None, cls_out=None):
     """Implicit-GEMM conv; w_packed is (Cout,kh,kw,Cin). Outputs are caller-provided NHWC views.
+    cls_w / cls_out: a (32,1,1,Cout) packed 1x1 classifier (rows >= ncls zero: pack_conv_weight of the weight padded to 32 outputs) and a
+    (N,Ho,Wo,ncls) fp32 tensor: the classifier is applied to the activation act(scale * v + shift) in the conv's epilogue INSTEAD of storing
+    it (no out_raw / out_act); raises ClsUnsupported where conv_cls_ok() is false.
     x2: a second (N,H,W,Cin2) source of a K-concatenated 1x1 conv -- w_packed is then (Cout,1,1,Cin + Cin2), the result
     [x | x2] . w^T in one accumulator chain (kd_conv1x1_dual_fwd); raises DualUnsupported where the kernel does not apply.
     bn_sums: an empty list (backward, with `mask`): when the kernel this problem selects can take the eval-BN parameter sums in
@@ -167,6 +175,17 @@ def conv2d(x, w_packed, stride=1, pad=0, dil=1, *, res_pre=None, mask=None, mask
     chk_vec(act_scale, "act_scale"); chk_vec(act_shift, "act_shift")
     ep.act_scale, ep.act_shift, ep.act_relu = _ptr(act_scale), _ptr(act_shift), int(act_relu)
     ep.bn_sums = None
+    if (cls_w is None) != (cls_out is None):
+        raise ValueError("conv2d: cls_w and cls_out come together")
+    if cls_w is not None:
+        _need_cuda(cls_w, cls_out)
+        if tuple(cls_w.shape) != (32, 1, 1, Cout) or cls_w.dtype != x.dtype or not cls_w.is_contiguous():
+            raise ValueError(f"conv2d: cls_w must be a contiguous (32,1,1,{Cout}) packed weight of the activation dtype")
+        if cls_out.dtype != torch.float32 or tuple(cls_out.shape[:3]) != (N, Ho, Wo) or cls_out.shape[3] > 32 or cls_out.stride(3) != 1:
+            raise ValueError("conv2d: cls_out must be (N,Ho,Wo,ncls <= 32) fp32")
+        ep.cls_w, ep.cls_out, ep.ld_cls, ep.ncls = _ptr(cls_w), _ptr(cls_out), nhwc_ld(cls_out), cls_out.shape[3]
+        if x2 is not None or not _lib.lib().kd_conv2d_cls_supported(C.byref(d), C.byref(ep)):
+            raise ClsUnsupported(f"conv2d: no classifier epilogue for {kh}x{kw} {H}x{W} {Cin}->{Cout}")
     sums_rows = 0
     if bn_sums is not None and mask is not None:
         sums_rows = int(_lib.lib().kd_conv2d_bn_sums_rows(C.byref(d), C.byref(ep)))
@@ -194,7 +213,7 @@ def conv2d(x, w_packed, stride=1, pad=0, dil=1, *, res_pre=None, mask=None, mask
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        epi = "".join(c for c, t in (("p", res_pre), ("m", mask), ("q", res_post), ("r", out_raw), ("a", out_act)) if t is not None)
+        epi = "".join(c for c, t in (("p", res_pre), ("m", mask), ("q", res_post), ("r", out_raw), ("a", out_act), ("c", cls_out)) if t is not None)
         prof.append(("conv_igemm", 2.0 * N * Ho * Wo * (algo_cout or Cout) * kh * kw * (algo_cin or (Cin + Cin2)), e0, e1,
                      f"{kh}x{kw} s{stride} d{dil} {H}x{W} {Cin}{'+%d' % Cin2 if Cin2 else ''}->{Cout} [{epi}{'s' if sums_rows or out_rows else ''}]", _lib.last_kernel()))
     if sums_rows > 0:
@@ -205,6 +224,17 @@ def conv2d(x, w_packed, stride=1, pad=0, dil=1, *, res_pre=None, mask=None, mask
               "kd_bn_sums_finish")
         bn_sums.append((s12[0], s12[1]))
     return out_raw, out_act
+
+
+def conv_cls_ok(x, Cout, k=3, dil=1):
+    """Does the kernel kd_conv2d_fwd selects for this 'same' conv of x carry the classifier epilogue (conv2d(..., cls_w=, cls_out=))?"""
+    if not x.is_cuda or x.dtype != torch.bfloat16 or os.environ.get("KDCC_FUSE_CLS", "1") == "0":
+        return False
+    N, H, W, Cin = x.shape
+    d = ConvDesc(dt_of(x), N, H, W, Cin, H, W, Cout, k, k, 1, dil * (k // 2), dil, nhwc_ld(x))
+    ep = ConvEpilogue()
+    ep.cls_w, ep.cls_out, ep.ld_cls, ep.ncls = C.c_void_p(256), C.c_void_p(256), 32, 19     # (the selection reads alignment and sizes only)
+    return bool(_lib.lib().kd_conv2d_cls_supported(C.byref(d), C.byref(ep)))
 
 
 def conv1x1_dual_ok(x, x2, Cout, operands=0):

@@ -95,7 +95,7 @@ def _step(model, backprop="hint"):
 
 SHIPPED_MODE_A = ["conv_row_lw_kernel", "conv_igemm_persist_kernel<pp>", "conv_row_tall_kernel",
                   "dw_mfma_fwd_kernel<1,false>", "dw_lw_fan3_kernel", "dw_mfma_fwd_kernel<3,false>", "out_sums_epilogue",
-                  "dw_mfma_wgrad_kernel", "dw_mfma_wgrad_multi_kernel<3>", "stem_pool_kernel", "conv_wgrad_pw_lw_kernel"]   # (the pointwise weight gradients take the 256x256 wgrad tile, one wave per SIMD)
+                  "dw_mfma_wgrad_kernel", "dw_mfma_wgrad_multi_kernel<3>", "stem_pool_kernel", "conv_wgrad_pw_lw_kernel", "cls_epilogue"]   # (the pointwise weight gradients take the 256x256 wgrad tile, one wave per SIMD)
 
 
 def test_bf16_p92_step_on_the_shipped_kernels_vs_network_oracle():

@@ -1372,3 +1372,42 @@ def test_conv_output_sums_feed_the_image_pooling(K, dual):
     got = b.float().cpu().numpy()[:, 0, 0, :]
     np.testing.assert_allclose(got, want, rtol=2e-2, atol=2e-3)
     assert float((b.float() - b[:, :1, :1, :].float()).abs().max()) == 0.0                  # broadcast over the pixels
+
+
+@pytest.mark.parametrize("case", [(1, 224, 256, 64, 19, 1), (2, 128, 256, 128, 19, 2), (1, 240, 512, 64, 32, 1), (1, 224, 256, 64, 5, 1)])
+def test_conv_classifier_epilogue(K, case):
+    """conv2d(cls_w=, cls_out=): the 1x1 classifier of the reference's `final` head (models/deeplabv3/deeplabv3.py:127-139: conv3x3 -> BN ->
+    ReLU -> conv1x1 onto the classes) applied in the epilogue of conv_row_lw_kernel<16> to the activation it would have stored.  Against
+    the two-launch form on the same kernels (the activation is bit for bit the stored tensor, the weights the same bf16 values: only the
+    fp32 order of the 256-term sums differs) and against the oracle; pixel tiles in both directions, two images, 19 / 32 / 5 classes,
+    a stale output buffer."""
+    dt = "bf16"
+    N, H, W, Cin, ncls, d = case
+    Cout = 256
+    x = q(rnd(N, Cin, H, W), dt)
+    w = q(rnd(Cout, Cin, 3, 3, scale=(2.0 / (9 * Cin)) ** 0.5), dt)
+    wc = q(rnd(ncls, Cout, 1, 1, scale=0.08), dt)
+    sc, sh = (rnd(Cout) * 0.2 + 1.0).astype(np.float32), (rnd(Cout) * 0.3).astype(np.float32)
+    scd, shd = torch.from_numpy(sc).cuda(), torch.from_numpy(sh).cuda()
+    wp = K.pack_conv_weight(torch.from_numpy(w).cuda(), DT[dt])
+    wcd = torch.zeros((32, Cout, 1, 1), device="cuda")
+    wcd[:ncls] = torch.from_numpy(wc).cuda()
+    wcp32 = K.pack_conv_weight(wcd, DT[dt])
+    xd = dev_nhwc(x, dt)
+    assert K.conv_cls_ok(xd, Cout, 3, d)
+    fused = torch.full((N, H, W, ncls), 7.0, device="cuda")
+    K.conv2d(xd, wp, 1, d, d, act_scale=scd, act_shift=shd, act_relu=True, cls_w=wcp32, cls_out=fused)
+    selected("conv_row_lw_kernel", f"classifier epilogue {case}")
+    act = torch.zeros((N, H, W, Cout), dtype=DT[dt], device="cuda")
+    K.conv2d(xd, wp, 1, d, d, out_act=act, act_scale=scd, act_shift=shd, act_relu=True)
+    two = torch.einsum("nhwc,kc->nhwk", act.float().double(), torch.from_numpy(wc[:, :, 0, 0]).cuda().double()).float()      # (the stored activation x the same bf16 weights)
+    a, b = fused.cpu().numpy(), two.cpu().numpy()
+    scale = np.abs(b).max()
+    assert np.isfinite(a).all() and np.abs(a - b).max() <= 2e-5 * scale + 1e-6, (case, np.abs(a - b).max(), scale)
+    ref_act = np.maximum(orc.conv2d_fwd(x, w, pad=d, dil=d) * sc[None, :, None, None] + sh[None, :, None, None], 0)
+    ref = np.einsum("nchw,kc->nhwk", q(ref_act.astype(np.float32), dt), wc[:, :, 0, 0])
+    l2 = float(np.sqrt(((a - ref) ** 2).sum() / max((ref ** 2).sum(), 1e-30)))
+    assert l2 <= 4e-3, (case, l2)
+    # refusals: anything else in the epilogue, another tile shape
+    with pytest.raises(K.ClsUnsupported):
+        K.conv2d(xd, wp, 1, d, d, out_act=act, act_scale=scd, act_shift=shd, act_relu=True, cls_w=wcp32, cls_out=fused)

@@ -56,6 +56,13 @@ def audit(text):
                 findings.append(f"{name}: compiler instruction touches an accumulator register: {it[1].strip()}")
         # 2. all MFMAs in one statement
         mf = [it[2].count("v_mfma") for it in items if it[0] == "asm" and "v_mfma" in it[2]]
+        if "conv_row_lw_kernelILi16E" in name:
+            # the classifier epilogue (conv_common.h lw_epilogue_cls16): 2 halves x 8 pixel tiles statements of four MFMAs (2 k-steps x 2 class
+            # tiles) whose operands are all VGPRs -- none of them may name an accumulation register -- each closed by its own wait states
+            extra = [it[2] for it in items if it[0] == "asm" and it[2].count("v_mfma") == 4]
+            if len(extra) != 16 or any(re.search(r"\ba\[?\d", b) or "s_nop 15" not in b for b in extra):
+                findings.append(f"{name}: expected 16 four-MFMA statements on vector registers (with their wait states) in the classifier epilogue, found {len(extra)}")
+            mf = [n for n in mf if n != 4]
         want = [320] if "conv_pw_lw" in name else [224] if "conv_row_duo" in name else [896]      # 1x1: one pass over the four slots; 3x3: two period bodies; + the zero-C first k-step(s)
         if mf != want:
             findings.append(f"{name}: expected one inline-asm statement with {want[0]} MFMAs, found {mf}")
